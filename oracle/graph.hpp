@@ -1,0 +1,748 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see lie.hpp header).  PARITY UNPINNED at the GTSAM
+// boundary: no live reference test pins ISAM2::update, BetweenFactor, BearingRangeFactor,
+// numericalDerivative or the custom factors.
+//
+// CPU restatement of the reference factor-graph backend:
+//   SemanticFactorGraph            backend/sloam/src/factorgraph/graph.cpp:14-371
+//   CubeMeasurement / CubeFactor   include/factorgraph/cubeFactor.h:25-172, src/factorgraph/cubeFactor.cpp:17-53
+//   CylinderMeasurement / Factor   include/factorgraph/cylinderFactor.h:22-128, src/factorgraph/cylinderFactor.cpp:20-51
+// plus the GTSAM 4.0.3 pieces those call: PriorFactor / BetweenFactor<Pose3>,
+// BearingRangeFactor<Pose3,Point3>, noiseModel::Diagonal whitening, numericalDerivative21/22
+// and the ISAM2::update + calculateEstimate step, each marked [GTSAM].
+//
+// iSAM2-equivalent update rule [GTSAM, Kaess et al. 2012; params graph.cpp:15-17]:
+//   every solve(): (1) new factors/variables join (delta = 0); (2) every variable whose
+//   |delta|_inf >= relinearizeThreshold (0.1) gets theta <- theta (+) delta; (3) because
+//   cached linearisations are only reused for factors none of whose variables moved, the
+//   linear system is J(theta) d = -r(theta) over ALL factors; it is solved exactly (the
+//   reference's multifrontal Cholesky is exact too; its 1e-3 wildfire cut-off on the
+//   back-substitution is NOT restated — documented deviation); (4) estimate = theta (+) delta.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <unordered_map>
+#include <vector>
+
+#include "lie.hpp"
+
+namespace orc {
+
+enum VarType { V_POSE = 0, V_POINT = 1, V_CUBE = 2, V_CYL = 3 };
+static inline int var_dim(int t) { return t == V_POSE ? 6 : t == V_POINT ? 3 : t == V_CUBE ? 9 : 7; }
+
+// value layouts: POSE R(9) t(3); POINT xyz; CUBE R(9) t(3) scale(3); CYL root(3) ray(3) radius
+struct Var {
+  int type;
+  double val[15];
+  double delta[9];
+};
+
+enum FType { F_PRIOR = 0, F_BETWEEN = 1, F_BR = 2, F_CUBE = 3, F_CYL = 4 };
+static inline int fac_dim(int t) { return t == F_BR ? 3 : t == F_CUBE ? 9 : t == F_CYL ? 7 : 6; }
+
+// measurement layouts: PRIOR/BETWEEN pose R(9) t(3); BR bearing(3) range(1);
+// CUBE R(9) t(3) scale(3) in the sensor frame; CYL root(3) ray(3) radius in the sensor frame
+struct Factor {
+  int type;
+  int v0, v1;
+  double z[15];
+  double sigma[9];
+};
+
+struct GraphParams {
+  int pose_chart = CHART_CAYLEY;     // GTSAM 4.0.3 default build; CHART_EXPMAP = GTSAM_POSE3_EXPMAP builds
+  double relin_threshold = 0.1;      // graph.cpp:17
+  double noise_floor = 0.01;         // graph.h:125
+  double prior_sigma[6] = {1e-6, 1e-6, 1e-6, 1e-6, 1e-6, 1e-6};  // graphWrapper.cpp:31
+  double odom_sigma[6] = {0.1, 0.1, 0.1, 0.1, 0.1, 0.1};         // :32
+  double cube_sigma[9] = {0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1};  // :33
+  double relmeas_sigma[6] = {0.1, 0.1, 0.1, 0.1, 0.1, 0.1};      // :34
+  double cyl_sigma = 400.0;          // graphWrapper.cpp:60  (100 * ones * 4)
+  double bearing_sigma = 1.0;        // graphWrapper.cpp:63-64
+  double numdiff_delta = 1e-6;       // cubeFactor.cpp:43,48 ; cylinderFactor.cpp:41,46
+  int num_threads = 1;
+};
+
+inline Pose var_pose(const Var& v) {
+  Pose T;
+  std::memcpy(T.R, v.val, 9 * sizeof(double));
+  std::memcpy(T.t, v.val + 9, 3 * sizeof(double));
+  return T;
+}
+inline void set_var_pose(Var& v, const Pose& T) {
+  std::memcpy(v.val, T.R, 9 * sizeof(double));
+  std::memcpy(v.val + 9, T.t, 3 * sizeof(double));
+}
+
+// value (+) tangent per variable type.
+//   Pose3: x * ChartAtOrigin::Retract(v) [GTSAM];  Point3: p + v;
+//   CubeMeasurement::retract cubeFactor.h:95-114 (pose.retract(v[0:6]) default chart, scale + v[6:9]);
+//   CylinderMeasurement::retract cylinderFactor.h:59-64 — tangent order [ray(3), root(3), radius].
+inline void var_retract(const Var& in, const double* d, int chart, Var& out) {
+  out.type = in.type;
+  switch (in.type) {
+    case V_POSE: {
+      set_var_pose(out, pose_retract(var_pose(in), d, chart));
+      break;
+    }
+    case V_POINT:
+      for (int i = 0; i < 3; ++i) out.val[i] = in.val[i] + d[i];
+      break;
+    case V_CUBE: {
+      set_var_pose(out, pose_retract(var_pose(in), d, chart));
+      for (int i = 0; i < 3; ++i) out.val[12 + i] = in.val[12 + i] + d[6 + i];
+      break;
+    }
+    case V_CYL:
+      for (int i = 0; i < 3; ++i) out.val[3 + i] = in.val[3 + i] + d[i];   // ray
+      for (int i = 0; i < 3; ++i) out.val[i] = in.val[i] + d[3 + i];       // root
+      out.val[6] = in.val[6] + d[6];
+      break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Unwhitened factor errors.
+// ---------------------------------------------------------------------------------------
+
+// [GTSAM] PriorFactor<Pose3>::evaluateError: -Local(x, prior);  H = I.
+inline void err_prior(const Factor& f, const Var& x, int chart, double* e) {
+  Pose Z;
+  std::memcpy(Z.R, f.z, 72); std::memcpy(Z.t, f.z + 9, 24);
+  double l[6];
+  pose_local(var_pose(x), Z, l, chart);
+  for (int i = 0; i < 6; ++i) e[i] = -l[i];
+}
+
+// [GTSAM] BetweenFactor<Pose3>::evaluateError: Local(measured, x1^-1 x2);
+// H1 = -Ad((x1^-1 x2)^-1), H2 = I (chart Jacobian dropped; no SLOW_BUT_CORRECT_BETWEENFACTOR).
+inline void err_between(const Factor& f, const Var& x1, const Var& x2, int chart, double* e) {
+  Pose Z;
+  std::memcpy(Z.R, f.z, 72); std::memcpy(Z.t, f.z + 9, 24);
+  Pose h = pose_between(var_pose(x1), var_pose(x2));
+  pose_local(Z, h, e, chart);
+}
+
+// [GTSAM] BearingRangeFactor<Pose3,Point3>: Local(measured, (bearing, range)) =
+// [Unit3 local at the MEASURED bearing (2); range - measured (1)].
+inline void err_br(const Factor& f, const Var& x, const Var& p, double* e) {
+  double q[3];
+  pose_transform_to(var_pose(x), p.val, q);
+  const double rho = norm3(q);
+  double b[3] = {q[0] / rho, q[1] / rho, q[2] / rho};
+  unit3_local(f.z, b, e);
+  e[2] = rho - f.z[3];
+}
+
+// CubeFactor::evaluateError cubeFactor.cpp:35: m_.project(p).localCoordinates(cube_lmrk)
+//   = [ Pose3::Logmap(q.pose^-1 * (p * m.pose)) ; m.scale - q.scale ]   (cubeFactor.h:46-87,121-127)
+inline void err_cube(const Factor& f, const Var& x, const Var& c, double* e) {
+  Pose M;
+  std::memcpy(M.R, f.z, 72); std::memcpy(M.t, f.z + 9, 24);
+  Pose proj = pose_compose(var_pose(x), M);
+  Pose err = pose_compose(pose_inverse(var_pose(c)), proj);
+  pose_logmap(err, e);
+  for (int i = 0; i < 3; ++i) e[6 + i] = f.z[12 + i] - c.val[12 + i];
+}
+
+// CylinderFactor::evaluateError cylinderFactor.cpp:35: m_.project(p).localCoordinates(q)
+//   project: root' = p * root, ray' = R * ray (cylinderFactor.h:71-77)
+//   localCoordinates(q) = [ q.ray - ray' ; q.root - root' ; radius' - q.radius ] (cylinderFactor.h:45-51;
+//   Point3::localCoordinates(q) = q - p [GTSAM])
+inline void err_cyl(const Factor& f, const Var& x, const Var& q, double* e) {
+  Pose T = var_pose(x);
+  double root[3], ray[3];
+  pose_transform_from(T, f.z, root);
+  mat3_vec(T.R, f.z + 3, ray);
+  for (int i = 0; i < 3; ++i) e[i] = q.val[3 + i] - ray[i];
+  for (int i = 0; i < 3; ++i) e[3 + i] = q.val[i] - root[i];
+  e[6] = f.z[6] - q.val[6];
+}
+
+// [GTSAM] numericalDerivative11 with Y = Vector: H.col(j) = ((h(x (+) d e_j) - hx) - (h(x (-) d e_j) - hx)) / (2 d)
+template <class ErrFn>
+inline void numdiff(ErrFn fn, const Var& x, int m, int chart, double delta, double* H /* m x dim row-major */) {
+  const int n = var_dim(x.type);
+  double hx[9], e1[9], e2[9], dx[9];
+  fn(x, hx);
+  const double factor = 1.0 / (2.0 * delta);
+  for (int j = 0; j < n; ++j) dx[j] = 0.0;
+  for (int j = 0; j < n; ++j) {
+    Var xp, xm;
+    dx[j] = delta;
+    var_retract(x, dx, chart, xp);
+    fn(xp, e1);
+    dx[j] = -delta;
+    var_retract(x, dx, chart, xm);
+    fn(xm, e2);
+    dx[j] = 0.0;
+    for (int i = 0; i < m; ++i) H[i * n + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * factor;
+  }
+}
+
+struct LinFactor {
+  int m, d0, d1;     // rows, dims of var0/var1 (d1 = 0 for prior)
+  double r[9];       // whitened residual
+  double J0[81];     // m x d0 row-major, whitened
+  double J1[81];     // m x d1
+};
+
+inline void linearize_factor(const Factor& f, const std::vector<Var>& vars, const GraphParams& P, LinFactor& L) {
+  const int chart = P.pose_chart;
+  L.m = fac_dim(f.type);
+  const Var& x0 = vars[f.v0];
+  L.d0 = var_dim(x0.type);
+  L.d1 = 0;
+  switch (f.type) {
+    case F_PRIOR: {
+      err_prior(f, x0, chart, L.r);
+      for (int i = 0; i < 36; ++i) L.J0[i] = 0.0;
+      for (int i = 0; i < 6; ++i) L.J0[7 * i] = 1.0;
+      break;
+    }
+    case F_BETWEEN: {
+      const Var& x1 = vars[f.v1];
+      L.d1 = 6;
+      err_between(f, x0, x1, chart, L.r);
+      Pose hinv = pose_between(var_pose(x1), var_pose(x0));
+      double Ad[36];
+      pose_adjoint(hinv, Ad);
+      for (int i = 0; i < 36; ++i) { L.J0[i] = -Ad[i]; L.J1[i] = 0.0; }
+      for (int i = 0; i < 6; ++i) L.J1[7 * i] = 1.0;
+      break;
+    }
+    case F_BR: {
+      const Var& p = vars[f.v1];
+      L.d1 = 3;
+      err_br(f, x0, p, L.r);
+      // [GTSAM] Pose3::bearing / Pose3::range analytic Jacobians:
+      //   q = R^T (p - t);  D_q_pose = [skew(q), -I];  D_q_point = R^T
+      //   D_b_q = B(b)^T (I - b b^T)/|q|  (basis at the PREDICTED bearing);  D_rho_q = b^T
+      Pose T = var_pose(x0);
+      double q[3];
+      pose_transform_to(T, p.val, q);
+      const double rho = norm3(q);
+      double b[3] = {q[0] / rho, q[1] / rho, q[2] / rho};
+      double B[6];
+      unit3_basis(b, B);
+      double Dn[9];
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Dn[3 * i + j] = ((i == j ? 1.0 : 0.0) - b[i] * b[j]) / rho;
+      double Dm[9];  // 3x3: rows 0-1 = B^T Dn, row 2 = b^T
+      for (int r = 0; r < 2; ++r)
+        for (int j = 0; j < 3; ++j) Dm[3 * r + j] = B[r] * Dn[j] + B[2 + r] * Dn[3 + j] + B[4 + r] * Dn[6 + j];
+      for (int j = 0; j < 3; ++j) Dm[6 + j] = b[j];
+      double Sq[9];
+      skew(q, Sq);
+      double Rt[9];
+      mat3_T(T.R, Rt);
+      for (int r = 0; r < 3; ++r) {
+        for (int j = 0; j < 3; ++j) {
+          double s = 0, u = 0;
+          for (int k = 0; k < 3; ++k) { s += Dm[3 * r + k] * Sq[3 * k + j]; u += Dm[3 * r + k] * Rt[3 * k + j]; }
+          L.J0[6 * r + j] = s;
+          L.J0[6 * r + 3 + j] = -Dm[3 * r + j];
+          L.J1[3 * r + j] = u;
+        }
+      }
+      break;
+    }
+    case F_CUBE: {
+      const Var& c = vars[f.v1];
+      L.d1 = 9;
+      err_cube(f, x0, c, L.r);
+      numdiff([&](const Var& xx, double* e) { err_cube(f, xx, c, e); }, x0, 9, chart, P.numdiff_delta, L.J0);
+      numdiff([&](const Var& cc, double* e) { err_cube(f, x0, cc, e); }, c, 9, chart, P.numdiff_delta, L.J1);
+      break;
+    }
+    case F_CYL: {
+      const Var& c = vars[f.v1];
+      L.d1 = 7;
+      err_cyl(f, x0, c, L.r);
+      numdiff([&](const Var& xx, double* e) { err_cyl(f, xx, c, e); }, x0, 7, chart, P.numdiff_delta, L.J0);
+      numdiff([&](const Var& cc, double* e) { err_cyl(f, x0, cc, e); }, c, 7, chart, P.numdiff_delta, L.J1);
+      break;
+    }
+  }
+  // [GTSAM] noiseModel::Diagonal::WhitenSystem: rows divided by sigma.
+  for (int i = 0; i < L.m; ++i) {
+    const double inv = 1.0 / f.sigma[i];
+    L.r[i] *= inv;
+    for (int j = 0; j < L.d0; ++j) L.J0[i * L.d0 + j] *= inv;
+    for (int j = 0; j < L.d1; ++j) L.J1[i * L.d1 + j] *= inv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Dense blocked Cholesky (lower, row-major, in place).  Returns 0 or 1+index of the failing pivot.
+// ---------------------------------------------------------------------------------------
+inline int chol_lower(double* A, int n, int lda, int nthreads) {
+  const int NB = 64;
+  (void)nthreads;
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int nb = std::min(NB, n - k0);
+    // diagonal block
+    for (int j = k0; j < k0 + nb; ++j) {
+      double* Aj = A + (size_t)j * lda;
+      double s = Aj[j];
+      for (int k = k0; k < j; ++k) s -= Aj[k] * Aj[k];
+      if (!(s > 0.0)) return j + 1;
+      const double d = std::sqrt(s);
+      Aj[j] = d;
+      for (int i = j + 1; i < k0 + nb; ++i) {
+        double* Ai = A + (size_t)i * lda;
+        double t = Ai[j];
+        for (int k = k0; k < j; ++k) t -= Ai[k] * Aj[k];
+        Ai[j] = t / d;
+      }
+    }
+    const int r0 = k0 + nb;
+    if (r0 >= n) break;
+    // panel: A[i, k0:k0+nb] <- A[i, k0:k0+nb] * L_kk^-T
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int i = r0; i < n; ++i) {
+      double* Ai = A + (size_t)i * lda;
+      for (int j = k0; j < k0 + nb; ++j) {
+        const double* Aj = A + (size_t)j * lda;
+        double t = Ai[j];
+        for (int k = k0; k < j; ++k) t -= Ai[k] * Aj[k];
+        Ai[j] = t / Aj[j];
+      }
+    }
+    // trailing update: A[i, j] -= sum_k A[i,k] A[j,k],  r0 <= j <= i < n
+    const int nt = (n - r0 + NB - 1) / NB;
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+    for (int tile = 0; tile < nt * nt; ++tile) {
+      const int ti = tile / nt, tj = tile % nt;
+      if (tj > ti) continue;
+      const int i0 = r0 + ti * NB, i1 = std::min(n, i0 + NB);
+      const int j0 = r0 + tj * NB, j1 = std::min(n, j0 + NB);
+      for (int i = i0; i < i1; ++i) {
+        double* Ai = A + (size_t)i * lda;
+        const double* Pi = Ai + k0;
+        const int jend = (ti == tj) ? std::min(j1, i + 1) : j1;
+        int j = j0;
+        for (; j + 4 <= jend; j += 4) {
+          const double* P0 = A + (size_t)j * lda + k0;
+          const double* P1 = P0 + lda;
+          const double* P2 = P1 + lda;
+          const double* P3 = P2 + lda;
+          double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma omp simd reduction(+ : s0, s1, s2, s3)
+          for (int k = 0; k < nb; ++k) {
+            const double a = Pi[k];
+            s0 += a * P0[k]; s1 += a * P1[k]; s2 += a * P2[k]; s3 += a * P3[k];
+          }
+          Ai[j] -= s0; Ai[j + 1] -= s1; Ai[j + 2] -= s2; Ai[j + 3] -= s3;
+        }
+        for (; j < jend; ++j) {
+          const double* P0 = A + (size_t)j * lda + k0;
+          double s0 = 0;
+#pragma omp simd reduction(+ : s0)
+          for (int k = 0; k < nb; ++k) s0 += Pi[k] * P0[k];
+          Ai[j] -= s0;
+        }
+      }
+    }
+  }
+  return 0;
+}
+inline void chol_solve_lower(const double* L, int n, int lda, double* b) {
+  for (int i = 0; i < n; ++i) {
+    const double* Li = L + (size_t)i * lda;
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= Li[k] * b[k];
+    b[i] = s / Li[i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = b[i] / L[(size_t)i * lda + i];
+    b[i] = s;
+    for (int k = 0; k < i; ++k) b[k] -= L[(size_t)i * lda + k] * s;
+  }
+}
+// small SPD inverse (d <= 9) via Cholesky; returns false if not SPD
+inline bool spd_inverse(const double* H, int d, double* Hinv) {
+  double L[81];
+  std::memcpy(L, H, sizeof(double) * d * d);
+  if (chol_lower(L, d, d, 1) != 0) return false;
+  for (int c = 0; c < d; ++c) {
+    double e[9];
+    for (int i = 0; i < d; ++i) e[i] = (i == c) ? 1.0 : 0.0;
+    chol_solve_lower(L, d, d, e);
+    for (int i = 0; i < d; ++i) Hinv[i * d + c] = e[i];
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// The graph: SemanticFactorGraph API (graph.h:70-121) over the iSAM2-equivalent solver.
+// ---------------------------------------------------------------------------------------
+struct SolveStats {
+  int n_pose = 0, n_lm = 0, n_factors = 0, n_relin = 0;
+  double t_linearize = 0, t_schur = 0, t_chol = 0, t_total = 0;
+  int chol_fail = 0;
+};
+
+class Graph {
+ public:
+  GraphParams P;
+  std::vector<Var> vars;          // theta (linearisation points) + delta, merged ("in isam")
+  std::vector<Var> estimate;      // currEstimate (graph.cpp:267)
+  std::vector<Factor> factors;    // merged
+  std::vector<Var> pend_vars;     // fvalues (graph.h:151)
+  std::vector<uint64_t> pend_keys;
+  std::vector<Factor> pend_factors;  // fgraph, v0/v1 hold KEYS until merge
+  std::vector<uint64_t> pend_fk0, pend_fk1;
+  std::unordered_map<uint64_t, int> key2var;   // merged keys
+  std::vector<uint64_t> var_keys;
+  SolveStats stats;
+
+  // key = (char << 56) | idx, mirroring gtsam::Symbol; robot chars graph.cpp:325-371
+  static uint64_t pose_key(int robot, uint64_t idx) {
+    static const char cs[13] = {'x', 'y', 'z', 'm', 'n', 'o', 'p', 'q', 'r', 's', 't', 'v', 'w'};
+    const char c = (robot >= 0 && robot < 13) ? cs[robot] : 0;
+    return ((uint64_t)(unsigned char)c << 56) | idx;
+  }
+  static uint64_t lm_key(char c, uint64_t idx) { return ((uint64_t)(unsigned char)c << 56) | idx; }
+
+  bool value_exists(uint64_t k) const { return key2var.count(k) != 0; }
+
+  void insert_value(uint64_t key, const Var& v) {
+    pend_keys.push_back(key);
+    pend_vars.push_back(v);
+  }
+  void add_factor(const Factor& f, uint64_t k0, uint64_t k1) {
+    pend_factors.push_back(f);
+    pend_fk0.push_back(k0);
+    pend_fk1.push_back(k1);
+  }
+
+  // graph.cpp:24-42
+  void setPriors(const Pose& prior, int robot) {
+    Factor f{};
+    f.type = F_PRIOR;
+    std::memcpy(f.z, prior.R, 72); std::memcpy(f.z + 9, prior.t, 24);
+    for (int i = 0; i < 6; ++i) f.sigma[i] = P.prior_sigma[i];
+    add_factor(f, pose_key(robot, 0), 0);
+    Var v{}; v.type = V_POSE; set_var_pose(v, prior);
+    insert_value(pose_key(robot, 0), v);
+  }
+  void add_between_raw(uint64_t k0, uint64_t k1, const Pose& rel, const double* sigma6) {
+    Factor f{};
+    f.type = F_BETWEEN;
+    std::memcpy(f.z, rel.R, 72); std::memcpy(f.z + 9, rel.t, 24);
+    for (int i = 0; i < 6; ++i) f.sigma[i] = sigma6[i];
+    add_factor(f, k0, k1);
+  }
+  // graph.cpp:44-151 (non-loop-closure branch; the loopClosureFound branch adds a second
+  // between factor with noise_model_closure and a different initial value, see addLoopClosureFactor)
+  void addKeyPoseAndBetween(uint64_t prevIdx, uint64_t curIdx, const Pose& rel, const Pose& est, int robot) {
+    const double dist = std::max(norm3(rel.t), P.noise_floor);
+    double s[6];
+    for (int i = 0; i < 6; ++i) s[i] = P.odom_sigma[i] * dist;
+    add_between_raw(pose_key(robot, prevIdx), pose_key(robot, curIdx), rel, s);
+    Var v{}; v.type = V_POSE; set_var_pose(v, est);
+    insert_value(pose_key(robot, curIdx), v);
+  }
+  // graph.cpp:153-156
+  void addPointLandmarkKey(uint64_t idx, const double* xyz) {
+    Var v{}; v.type = V_POINT;
+    v.val[0] = xyz[0]; v.val[1] = xyz[1]; v.val[2] = xyz[2];
+    insert_value(lm_key('u', idx), v);
+  }
+  // graph.cpp:158-180; Pose3().bearing(p) = Unit3(p) = p/|p| [GTSAM]
+  void addRangeBearingFactor(uint64_t poseIdx, uint64_t lmIdx, const double* bearing, double range, int robot) {
+    Factor f{};
+    f.type = F_BR;
+    const double n = norm3(bearing);
+    for (int i = 0; i < 3; ++i) f.z[i] = bearing[i] / n;
+    f.z[3] = range;
+    for (int i = 0; i < 3; ++i) f.sigma[i] = P.bearing_sigma;
+    add_factor(f, pose_key(robot, poseIdx), lm_key('u', lmIdx));
+  }
+  // graph.cpp:182-196 ; cylinder given in the world frame: root, ray, radius
+  void addCylinderFactor(uint64_t poseIdx, uint64_t cylIdx, const Pose& pose, const double* root, const double* ray,
+                         double radius, bool exists, int robot) {
+    Pose inv = pose_inverse(pose);
+    Factor f{};
+    f.type = F_CYL;
+    pose_transform_from(inv, root, f.z);
+    mat3_vec(inv.R, ray, f.z + 3);
+    f.z[6] = radius;
+    for (int i = 0; i < 7; ++i) f.sigma[i] = P.cyl_sigma;
+    add_factor(f, pose_key(robot, poseIdx), lm_key('l', cylIdx));
+    if (!exists) {
+      Var v{}; v.type = V_CYL;
+      for (int i = 0; i < 3; ++i) { v.val[i] = root[i]; v.val[3 + i] = ray[i]; }
+      v.val[6] = radius;
+      insert_value(lm_key('l', cylIdx), v);
+    }
+  }
+  // graph.cpp:198-231 ; cube given in the world frame
+  void addCubeFactor(uint64_t poseIdx, uint64_t cubeIdx, const Pose& pose, const Pose& cube_world, const double* scale,
+                     bool exists, int robot) {
+    Pose local = pose_compose(pose_inverse(pose), cube_world);
+    const double dist = std::max(norm3(local.t), 0.1);
+    Factor f{};
+    f.type = F_CUBE;
+    std::memcpy(f.z, local.R, 72); std::memcpy(f.z + 9, local.t, 24);
+    for (int i = 0; i < 3; ++i) f.z[12 + i] = scale[i];
+    for (int i = 0; i < 9; ++i) f.sigma[i] = P.cube_sigma[i] * dist;
+    add_factor(f, pose_key(robot, poseIdx), lm_key('c', cubeIdx));
+    if (!exists) {
+      Var v{}; v.type = V_CUBE;
+      set_var_pose(v, cube_world);
+      for (int i = 0; i < 3; ++i) v.val[12 + i] = scale[i];
+      insert_value(lm_key('c', cubeIdx), v);
+    }
+  }
+  // graph.cpp:233-245 ; noise_model_closure = 0.01 * odom (graphWrapper.cpp:55)
+  void addLoopClosureFactor(const Pose& rel, uint64_t prevIdx, int robot1, uint64_t curIdx, int robot2) {
+    double s[6];
+    for (int i = 0; i < 6; ++i) s[i] = P.odom_sigma[i] * 0.01;
+    add_between_raw(pose_key(robot1, prevIdx), pose_key(robot2, curIdx), rel, s);
+  }
+  // graph.cpp:247-258
+  void addRelativeMeasFactor(const Pose& rel, uint64_t prevIdx, int robot1, uint64_t curIdx, int robot2) {
+    const double dist = std::max(norm3(rel.t), P.noise_floor);
+    double s[6];
+    for (int i = 0; i < 6; ++i) s[i] = P.relmeas_sigma[i] * dist;
+    add_between_raw(pose_key(robot1, prevIdx), pose_key(robot2, curIdx), rel, s);
+  }
+
+  // graph.cpp:290-312: false + identity when the key is absent
+  bool getPose(uint64_t idx, int robot, Pose& out) const {
+    auto it = key2var.find(pose_key(robot, idx));
+    if (it == key2var.end() || (size_t)it->second >= estimate.size()) { pose_identity(out); return false; }
+    out = var_pose(estimate[it->second]);
+    return true;
+  }
+  const Var* getLandmark(char c, uint64_t idx) const {
+    auto it = key2var.find(lm_key(c, idx));
+    if (it == key2var.end() || (size_t)it->second >= estimate.size()) return nullptr;
+    return &estimate[it->second];
+  }
+
+  // graph.cpp:260-272
+  int solve();
+};
+
+inline double now_sec();
+
+inline int Graph::solve() {
+  const double t0 = now_sec();
+  // (1) merge fvalues / fgraph  [GTSAM ISAM2::update: new variables get delta = 0]
+  for (size_t i = 0; i < pend_vars.size(); ++i) {
+    if (key2var.count(pend_keys[i])) continue;  // GTSAM would throw ValuesKeyAlreadyExists
+    Var v = pend_vars[i];
+    for (int k = 0; k < 9; ++k) v.delta[k] = 0.0;
+    key2var[pend_keys[i]] = (int)vars.size();
+    var_keys.push_back(pend_keys[i]);
+    vars.push_back(v);
+  }
+  for (size_t i = 0; i < pend_factors.size(); ++i) {
+    Factor f = pend_factors[i];
+    auto a = key2var.find(pend_fk0[i]);
+    if (a == key2var.end()) continue;
+    f.v0 = a->second;
+    f.v1 = -1;
+    if (f.type != F_PRIOR) {
+      auto b = key2var.find(pend_fk1[i]);
+      if (b == key2var.end()) continue;
+      f.v1 = b->second;
+    }
+    factors.push_back(f);
+  }
+  pend_vars.clear(); pend_keys.clear(); pend_factors.clear(); pend_fk0.clear(); pend_fk1.clear();
+
+  // (2) relinearisation  [GTSAM CheckRelinearizationFull: maxDelta >= threshold]
+  stats = SolveStats();
+  for (auto& v : vars) {
+    const int d = var_dim(v.type);
+    double mx = 0.0;
+    for (int k = 0; k < d; ++k) mx = std::max(mx, std::fabs(v.delta[k]));
+    if (mx >= P.relin_threshold) {
+      Var nv;
+      var_retract(v, v.delta, P.pose_chart, nv);
+      std::memcpy(v.val, nv.val, sizeof(v.val));
+      ++stats.n_relin;
+    }
+  }
+
+  // (3) linearise everything at theta; landmark-eliminating Schur complement; dense Cholesky.
+  std::vector<int> pidx(vars.size(), -1), lidx(vars.size(), -1);
+  std::vector<int> pose_vars, lm_vars;
+  for (size_t i = 0; i < vars.size(); ++i) {
+    if (vars[i].type == V_POSE) { pidx[i] = (int)pose_vars.size(); pose_vars.push_back((int)i); }
+    else { lidx[i] = (int)lm_vars.size(); lm_vars.push_back((int)i); }
+  }
+  const int np = (int)pose_vars.size(), nl = (int)lm_vars.size();
+  const int n = 6 * np;
+  stats.n_pose = np; stats.n_lm = nl; stats.n_factors = (int)factors.size();
+  std::vector<LinFactor> lin(factors.size());
+  const int nthreads = P.num_threads;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+  for (size_t i = 0; i < factors.size(); ++i) linearize_factor(factors[i], vars, P, lin[i]);
+  const double t1 = now_sec();
+
+  std::vector<double> S((size_t)n * n, 0.0), g(n, 0.0);
+  struct LmAcc { double H[81]; double g[9]; std::vector<int> fac; };
+  std::vector<LmAcc> acc(nl);
+  for (auto& a : acc) { std::memset(a.H, 0, sizeof(a.H)); std::memset(a.g, 0, sizeof(a.g)); }
+  auto add_block = [&](int pi, int pj, const double* Ja, int da, const double* Jb, int db, int m) {
+    // S[6pi.., 6pj..] += Ja^T Jb   (only if pi >= pj blockwise; full block on the diagonal)
+    (void)da; (void)db;
+    for (int a = 0; a < 6; ++a)
+      for (int b = 0; b < 6; ++b) {
+        double s = 0.0;
+        for (int r = 0; r < m; ++r) s += Ja[r * 6 + a] * Jb[r * 6 + b];
+        S[(size_t)(6 * pi + a) * n + 6 * pj + b] += s;
+      }
+  };
+  for (size_t i = 0; i < factors.size(); ++i) {
+    const Factor& f = factors[i];
+    const LinFactor& L = lin[i];
+    const int p0 = pidx[f.v0];
+    add_block(p0, p0, L.J0, 6, L.J0, 6, L.m);
+    for (int a = 0; a < 6; ++a) {
+      double s = 0.0;
+      for (int r = 0; r < L.m; ++r) s += L.J0[r * 6 + a] * L.r[r];
+      g[6 * p0 + a] += s;
+    }
+    if (f.type == F_BETWEEN) {
+      const int p1 = pidx[f.v1];
+      add_block(p1, p1, L.J1, 6, L.J1, 6, L.m);
+      if (p1 >= p0) add_block(p1, p0, L.J1, 6, L.J0, 6, L.m);
+      else add_block(p0, p1, L.J0, 6, L.J1, 6, L.m);
+      for (int a = 0; a < 6; ++a) {
+        double s = 0.0;
+        for (int r = 0; r < L.m; ++r) s += L.J1[r * 6 + a] * L.r[r];
+        g[6 * p1 + a] += s;
+      }
+    } else if (f.type != F_PRIOR) {
+      LmAcc& A = acc[lidx[f.v1]];
+      const int d = L.d1;
+      for (int a = 0; a < d; ++a) {
+        for (int b = 0; b < d; ++b) {
+          double s = 0.0;
+          for (int r = 0; r < L.m; ++r) s += L.J1[r * d + a] * L.J1[r * d + b];
+          A.H[a * d + b] += s;
+        }
+        double s = 0.0;
+        for (int r = 0; r < L.m; ++r) s += L.J1[r * d + a] * L.r[r];
+        A.g[a] += s;
+      }
+      A.fac.push_back((int)i);
+    }
+  }
+  // Schur complement of every landmark block
+  std::vector<double> Hinv_all((size_t)nl * 81, 0.0);
+  std::vector<std::vector<double>> Eall(nl);
+  for (int l = 0; l < nl; ++l) {
+    LmAcc& A = acc[l];
+    const int d = var_dim(vars[lm_vars[l]].type);
+    double* Hinv = &Hinv_all[(size_t)l * 81];
+    if (A.fac.empty()) continue;
+    if (!spd_inverse(A.H, d, Hinv)) {
+      stats.chol_fail = 1;
+      if (getenv("ORC_DEBUG")) {
+        fprintf(stderr, "[oracle] landmark %d type %d dim %d nfac %zu H not SPD:\n", l, vars[lm_vars[l]].type, d, A.fac.size());
+        for (int a = 0; a < d; ++a) { for (int b = 0; b < d; ++b) fprintf(stderr, " %.6e", A.H[a * d + b]); fprintf(stderr, "\n"); }
+      }
+      return -2;
+    }
+    const int nf = (int)A.fac.size();
+    std::vector<double>& E = Eall[l];
+    E.assign((size_t)nf * 6 * d, 0.0);  // E_a = J0^T J1 (6 x d)
+    std::vector<double> Fm((size_t)nf * 6 * d);
+    for (int a = 0; a < nf; ++a) {
+      const LinFactor& L = lin[A.fac[a]];
+      double* Ea = &E[(size_t)a * 6 * d];
+      for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < d; ++c) {
+          double s = 0.0;
+          for (int k = 0; k < L.m; ++k) s += L.J0[k * 6 + r] * L.J1[k * d + c];
+          Ea[r * d + c] = s;
+        }
+      double* Fa = &Fm[(size_t)a * 6 * d];
+      for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < d; ++c) {
+          double s = 0.0;
+          for (int k = 0; k < d; ++k) s += Ea[r * d + k] * Hinv[k * d + c];
+          Fa[r * d + c] = s;
+        }
+    }
+    for (int a = 0; a < nf; ++a) {
+      const int pa = pidx[factors[A.fac[a]].v0];
+      const double* Fa = &Fm[(size_t)a * 6 * d];
+      for (int r = 0; r < 6; ++r) {
+        double s = 0.0;
+        for (int k = 0; k < d; ++k) s += Fa[r * d + k] * A.g[k];
+        g[6 * pa + r] -= s;
+      }
+      for (int b = 0; b < nf; ++b) {
+        const int pb = pidx[factors[A.fac[b]].v0];
+        if (pb > pa) continue;
+        const double* Eb = &E[(size_t)b * 6 * d];
+        for (int r = 0; r < 6; ++r)
+          for (int c = 0; c < 6; ++c) {
+            double s = 0.0;
+            for (int k = 0; k < d; ++k) s += Fa[r * d + k] * Eb[c * d + k];
+            S[(size_t)(6 * pa + r) * n + 6 * pb + c] -= s;
+          }
+      }
+    }
+  }
+  const double t2 = now_sec();
+  const int cf = chol_lower(S.data(), n, n, nthreads);
+  if (cf != 0) { stats.chol_fail = cf; return -1; }
+  std::vector<double> dp(n);
+  for (int i = 0; i < n; ++i) dp[i] = -g[i];
+  chol_solve_lower(S.data(), n, n, dp.data());
+  const double t3 = now_sec();
+  for (int p = 0; p < np; ++p)
+    for (int k = 0; k < 6; ++k) vars[pose_vars[p]].delta[k] = dp[6 * p + k];
+  for (int l = 0; l < nl; ++l) {
+    LmAcc& A = acc[l];
+    Var& v = vars[lm_vars[l]];
+    const int d = var_dim(v.type);
+    if (A.fac.empty()) { for (int k = 0; k < d; ++k) v.delta[k] = 0.0; continue; }
+    double rhs[9];
+    for (int k = 0; k < d; ++k) rhs[k] = A.g[k];
+    for (size_t a = 0; a < A.fac.size(); ++a) {
+      const int pa = pidx[factors[A.fac[a]].v0];
+      const double* Ea = &Eall[l][a * 6 * d];
+      for (int k = 0; k < d; ++k) {
+        double s = 0.0;
+        for (int r = 0; r < 6; ++r) s += Ea[r * d + k] * dp[6 * pa + r];
+        rhs[k] += s;
+      }
+    }
+    const double* Hinv = &Hinv_all[(size_t)l * 81];
+    for (int k = 0; k < d; ++k) {
+      double s = 0.0;
+      for (int c = 0; c < d; ++c) s += Hinv[k * d + c] * rhs[c];
+      v.delta[k] = -s;
+    }
+  }
+  // (4) calculateEstimate: theta (+) delta
+  estimate.resize(vars.size());
+  for (size_t i = 0; i < vars.size(); ++i) {
+    var_retract(vars[i], vars[i].delta, P.pose_chart, estimate[i]);
+    std::memcpy(estimate[i].delta, vars[i].delta, sizeof(vars[i].delta));
+  }
+  const double t4 = now_sec();
+  stats.t_linearize = t1 - t0; stats.t_schur = t2 - t1; stats.t_chol = t3 - t2; stats.t_total = t4 - t0;
+  return 0;
+}
+
+}  // namespace orc
+
+#include <chrono>
+namespace orc {
+inline double now_sec() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace orc

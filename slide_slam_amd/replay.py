@@ -1,0 +1,85 @@
+"""ROS-free replay harness: feeds a synthetic frame log through a backend object in the order
+``SLOAMNode::runSLOAMNode`` (reference sloamNode.cpp:762-1036) and its caller
+``InputManager::RunInputNode`` (inputNode.cpp:158-181) would.
+
+``backend`` is any object exposing ``process_frame(robot, rel7, prev7, det, mode)``,
+``ingest_solve()``, ``end_frame(robot)`` and ``graph`` (the product's ``SlideBackend`` or, in
+tests and the CPU-baseline leg only, the oracle wrapper).
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from .synth import frame_detections, pose7_to_Rt, pose7
+
+IDENT7 = np.array([0, 0, 0, 0, 0, 0, 1.0])
+
+
+def _compose7(a, b):
+    Ra, ta = pose7_to_Rt(a)
+    Rb, tb = pose7_to_Rt(b)
+    return pose7(Ra @ Rb, Ra @ tb + ta)
+
+
+def replay_single(backend, log, robot=0, n_frames=None, collect=True):
+    """Single-robot replay: every frame = associate + add factors + solve (one pose-graph update)."""
+    P = len(log["rel7"]) if n_frames is None else n_frames
+    prev = IDENT7.copy()
+    out = dict(pose7=[], cyl_id=[], cube_id=[], ell_id=[], t_frame=[])
+    for k in range(P):
+        det = frame_detections(log, k)
+        t0 = time.perf_counter()
+        r = backend.process_frame(robot, log["rel7"][k], prev, det, 0)
+        t1 = time.perf_counter()
+        if r["status"] != 0:
+            raise RuntimeError(f"solve failed at frame {k}: status {r['status']}")
+        prev = r["pose7"].copy()
+        if collect:
+            out["pose7"].append(prev.copy())
+            out["cyl_id"].append(r["cyl_id"].copy()); out["cube_id"].append(r["cube_id"].copy())
+            out["ell_id"].append(r["ell_id"].copy())
+        out["t_frame"].append(t1 - t0)
+    return out
+
+
+def replay_multi(backend, data, host=0, n_frames=None):
+    """Multi-robot replay on ONE host graph (the reference's per-host replica): per time step the host
+    robot's own frame (add + solve), then every other robot's packet of that step is ingested
+    (sloamNode.cpp:912-1002: associate against the host's maps, add, one solve per robot), then the
+    map refresh + current-pose fetch (:1010-1014).  Inter-robot TFs are known a priori (identity:
+    all odometry is expressed in the common world frame, databaseManager.cpp:22-45 priorTFKnown)."""
+    cfg = data["cfg"]
+    logs = data["logs"]
+    R = cfg.robots
+    P = cfg.poses_per_robot if n_frames is None else n_frames
+    prev = [IDENT7.copy() for _ in range(R)]
+    rel_by_step = {}
+    for (k, a, b, rel) in data["relmeas"]:
+        rel_by_step.setdefault(k, []).append((a, b, rel))
+    out = dict(host_pose7=[], ids=[])
+    for k in range(P):
+        det = frame_detections(logs[host], k)
+        r = backend.process_frame(host, logs[host]["rel7"][k], prev[host], det, 1)
+        if r["status"] != 0:
+            raise RuntimeError(f"host solve failed at step {k}")
+        ids = [(r["cyl_id"].copy(), r["cube_id"].copy(), r["ell_id"].copy())]
+        for o in range(R):
+            if o == host:
+                continue
+            # foreign key pose = that robot's own dead-reckoned chain (it never sees the host's optimisation)
+            est = _compose7(prev[o], logs[o]["rel7"][k])
+            ro = backend.process_frame(o, logs[o]["rel7"][k], est, frame_detections(logs[o], k), 2)
+            prev[o] = est
+            ids.append((ro["cyl_id"].copy(), ro["cube_id"].copy(), ro["ell_id"].copy()))
+            st = backend.ingest_solve()
+            if st != 0:
+                raise RuntimeError(f"ingest solve failed at step {k} robot {o}")
+        for (a, b, rel) in rel_by_step.get(k, []):
+            backend.graph.add_relative_meas(rel, k, a, k, b)   # queued; consumed by the next solve()
+        st, pose = backend.end_frame(host)
+        prev[host] = pose.copy()
+        out["host_pose7"].append(pose.copy())
+        out["ids"].append(ids)
+    return out
