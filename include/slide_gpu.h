@@ -1,0 +1,239 @@
+/*
+ * slide_gpu.h — C-ABI boundary of the MI355X-native SlideSLAM backend hot path.
+ *
+ * The reference (lunarlab-gatech/SLIDE_SLAM, backend/sloam) has no plugin / FFI interface for this
+ * path: the seam is a set of in-process C++ class methods called from SLOAMNode
+ * (backend/sloam/src/core/sloamNode.cpp).  Every entry point below names the reference method it
+ * replaces (paths relative to backend/sloam/).  All types are POD, all matrices row-major, poses are
+ *     pose7 = tx, ty, tz, qx, qy, qz, qw      (geometry_msgs/Pose order; the trajectory file order
+ *                                              of sloamNode.cpp:318-337)
+ * and always mean T_world<-sensor ("tf_sensor_to_map", include/factorgraph/graph.h:44).
+ * Functions return an int status, never throw across the ABI, and every handle serialises its own
+ * calls with an internal mutex (the reference leaves add_* vs solve() unsynchronised).
+ *
+ * There is NO CPU fallback behind this header: every compute entry point runs hand-written HIP
+ * kernels on a gfx950 device and fails with SLIDE_ERR_HIP when none is usable.
+ */
+#ifndef SLIDE_GPU_H_
+#define SLIDE_GPU_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLIDE_OK 0
+#define SLIDE_MISSING 1          /* key absent: getPose() == false semantics (graph.cpp:297-311) */
+#define SLIDE_ERR_INVALID (-1)   /* bad argument / robot id outside [0, SLIDE_MAX_ROBOTS) */
+#define SLIDE_ERR_NOT_SPD (-2)   /* a landmark block or the reduced pose system is not positive definite */
+#define SLIDE_ERR_CAPACITY (-3)  /* a fixed on-chip capacity was exceeded (e.g. > 16384 landmarks of one class in the K-NN gate) */
+#define SLIDE_ERR_HIP (-4)       /* HIP runtime error or no gfx950 device */
+#define SLIDE_ERR_RUNTIME (-5)   /* the reference would throw std::runtime_error here (sloam.cpp:349,355) */
+
+#define SLIDE_MAX_ROBOTS 13      /* include/factorgraph/graph.h:11 */
+
+#define SLIDE_CHART_CAYLEY 0     /* GTSAM 4.0.3 default Pose3 chart (cubeFactor.h:96-97) */
+#define SLIDE_CHART_EXPMAP 1     /* GTSAM_POSE3_EXPMAP builds */
+
+#define SLIDE_CLS_CYLINDER 0
+#define SLIDE_CLS_CUBE 1
+#define SLIDE_CLS_ELLIPSOID 2    /* ellipsoids become Point3 landmarks in the graph (graphWrapper.cpp:157-202) */
+
+/* Parameter names/defaults mirror the rosparam reads of the reference:
+ * graphWrapper.cpp:31-34,55,60,63-64 ; graph.cpp:15-17 ; graph.h:125 ; sloamNode.cpp:151-153 ;
+ * {cylinder,cube,ellipsoid}MapManager.cpp K = 50 / 30 / 1000. */
+typedef struct slide_params_t {
+  int pose_chart;                 /* SLIDE_CHART_* */
+  double relinearize_threshold;   /* 0.1 */
+  double noise_floor;             /* 0.01 */
+  double noise_model_prior_first_pose_vec[6]; /* 1e-6 */
+  double noise_model_odom_vec[6];             /* 0.1  */
+  double noise_model_cube_vec[9];             /* 0.1  */
+  double noise_model_rel_meas_vec[6];         /* 0.1  */
+  double cylinder_sigma;          /* 400 */
+  double bearing_range_sigma;     /* 1   */
+  double numdiff_delta;           /* 1e-6 (cubeFactor.cpp:43,48) */
+  double cylinder_match_thresh;   /* 2.0 */
+  double cuboid_match_thresh;     /* 2.0 */
+  double ellipsoid_match_thresh;  /* 0.75 */
+  int knn_cylinder, knn_cube, knn_ellipsoid;  /* 50, 30, 1000 */
+  int number_of_robots;           /* <= SLIDE_MAX_ROBOTS */
+  int device;                     /* HIP device ordinal, -1 = current */
+} slide_params_t;
+
+void slide_default_params(slide_params_t* p);
+/* 0 when a gfx950 device is present and usable, SLIDE_ERR_HIP otherwise (message via slide_last_error). */
+int slide_device_check(int device);
+const char* slide_last_error(void);
+const char* slide_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * S1 — SemanticFactorGraph (include/factorgraph/graph.h:70-121, src/factorgraph/graph.cpp)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct slide_graph slide_graph_t;
+
+slide_graph_t* slide_graph_create(const slide_params_t* p);          /* SemanticFactorGraph() graph.cpp:14-22 */
+void slide_graph_destroy(slide_graph_t* g);
+
+int slide_graph_set_prior(slide_graph_t* g, int robot, const double pose7[7]);              /* setPriors graph.cpp:24-42 */
+int slide_graph_add_keypose_between(slide_graph_t* g, int robot, uint64_t from_idx, uint64_t to_idx,
+                                    const double rel7[7], const double est7[7]);            /* addKeyPoseAndBetween graph.cpp:44-151 */
+int slide_graph_add_loop_closure(slide_graph_t* g, const double rel7[7], uint64_t from_idx, int from_robot,
+                                 uint64_t to_idx, int to_robot);                            /* addLoopClosureFactor graph.cpp:233-245 */
+int slide_graph_add_relative_meas(slide_graph_t* g, const double rel7[7], uint64_t from_idx, int from_robot,
+                                  uint64_t to_idx, int to_robot);                           /* addRelativeMeasFactor graph.cpp:247-258 */
+int slide_graph_add_point_landmark(slide_graph_t* g, uint64_t lm_idx, const double xyz[3]); /* addPointLandmarkKey graph.cpp:153-156 */
+int slide_graph_add_range_bearing(slide_graph_t* g, int robot, uint64_t pose_idx, uint64_t lm_idx,
+                                  const double bearing[3], double range);                   /* addRangeBearingFactor graph.cpp:158-180 */
+int slide_graph_add_cube(slide_graph_t* g, int robot, uint64_t pose_idx, uint64_t cube_idx, const double pose_world7[7],
+                         const double cube_world7[7], const double scale[3], int already_exists); /* addCubeFactor graph.cpp:198-231 */
+int slide_graph_add_cylinder(slide_graph_t* g, int robot, uint64_t pose_idx, uint64_t cyl_idx,
+                             const double pose_world7[7], const double root[3], const double ray[3], double radius,
+                             int already_exists);                                           /* addCylinderFactor graph.cpp:182-196 */
+/* One iSAM2-equivalent update: isam->update(fgraph, fvalues); currEstimate = calculateEstimate()  (graph.cpp:260-272). */
+int slide_graph_solve(slide_graph_t* g);
+/* n batch Gauss-Newton iterations over the whole graph (relinearise every variable each time): the
+ * "ms per Gauss-Newton iteration" unit of BASELINE.json.  Equivalent to solve() with threshold 0. */
+int slide_graph_gauss_newton(slide_graph_t* g, int iterations);
+
+int slide_graph_get_pose(slide_graph_t* g, int robot, uint64_t idx, double out7[7]);        /* getPose graph.cpp:290-312: SLIDE_MISSING + identity */
+int slide_graph_get_pose12(slide_graph_t* g, int robot, uint64_t idx, double out12[12]);    /* same, R row-major (9) + t (3) */
+int slide_graph_get_all_poses(slide_graph_t* g, int robot, double* out7N, uint64_t cap, uint64_t* n_out); /* getAllPoses graphWrapper.cpp:313-338 */
+/* cls = SLIDE_CLS_*: cylinder -> 7 (root, ray, radius), cube -> 15 (R, t, scale), ellipsoid/point -> 3.
+ * getCylinder / getCube / getCentroidLandmark graph.cpp:274-288 (absent key: zeros + SLIDE_MISSING). */
+int slide_graph_get_landmark(slide_graph_t* g, int cls, uint64_t idx, double* out);
+/* counts: [poses, landmarks, factors, relinearised vars in the last solve, chol dim] */
+int slide_graph_stats(slide_graph_t* g, int64_t out5[5]);
+/* Per-kernel device timings (HIP events on the launch stream) of the solves since the last reset.
+ * names: caller buffer of n_max * 32 chars; ms_total / launches: n_max entries.  Returns #entries. */
+int slide_graph_set_profiling(slide_graph_t* g, int on);
+int slide_graph_get_profile(slide_graph_t* g, char* names, double* ms_total, int64_t* launches, int n_max);
+
+/* The dense kernel behind solve(): x = A^-1 b for a symmetric positive definite A (n x n, row- or
+ * column-major: only the lower triangle in column-major sense, A[i + j*n] with i >= j, is read) by
+ * the blocked FP64-MFMA Cholesky the reduced pose system uses (the reference delegates this to
+ * GTSAM's CHOLESKY factorisation, graph.cpp:15).  ms_out (may be NULL): device time of `repeats`
+ * factor+solve passes measured with HIP events on the launch stream. */
+int slide_dense_spd_solve(const double* A, int n, const double* b, double* x, int repeats, double* ms_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * S3 — association (include/core/sloam.h:88-108, src/core/sloam.cpp:73-306; *MapManager::getSubmap)
+ * Stand-alone entry points on caller-provided host buffers (copied to HBM, kernels run, results copied back).
+ * ---------------------------------------------------------------------------------------------- */
+/* *MapManager::getSubmap candidate gate (cubeMapManager.cpp:36-75 etc.): exact float32 K-NN of the
+ * first-seen cloud to the query position; out_idx = map indices nearest first, *out_k = min(K, n). */
+int slide_submap_knn(const float* cloud_xyz, uint64_t n, const double query_xyz[3], int K, int32_t* out_idx, int* out_k);
+/* sloam::matchModels sloam.cpp:73-111 (cylinders; objects in the world frame). out = submap index or -1. */
+int slide_assoc_match_cylinders(int n_cur, const double* root, const double* ray, const int32_t* label, int n_map,
+                                const double* map_root, const double* map_ray, const int32_t* map_label, double thresh,
+                                int32_t* out_idx);
+/* sloam::matchCubeModels :113-156 (cls = SLIDE_CLS_CUBE, labels ignored) and
+ * sloam::matchEllipsoidModels :158-203 (cls = SLIDE_CLS_ELLIPSOID, label-gated). */
+int slide_assoc_match_boxes(int cls, int n_cur, const double* xyz, const int32_t* label, int n_map, const double* map_xyz,
+                            const int32_t* map_label, double thresh, int32_t* out_idx);
+/* Batched association sweep (roofline leg): n_query independent frames, each n_obs ellipsoid detections
+ * (xyz + label) against ONE resident map of n_map landmarks: K-NN gate to each query's robot position,
+ * then label-gated nearest neighbour.  Inputs are DEVICE pointers (already resident in HBM); runs on
+ * `stream` (a hipStream_t cast to void*, NULL = default stream).  out_map_idx: n_query * n_obs. */
+int slide_assoc_sweep_batch_device(const float* d_cloud_xyz, const double* d_model_xyz, const int32_t* d_label, int n_map,
+                                   const double* d_query_pos, const double* d_obs_xyz, const int32_t* d_obs_label,
+                                   int n_query, int n_obs, int K, double thresh, int32_t* d_out_map_idx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * S2 + runSLOAMNode — the per-key-frame update (src/core/sloamNode.cpp:762-1036 without ROS):
+ * submap gate -> projectModels -> match -> updateMap -> addSLOAMObservation -> solve ->
+ * updateFactorGraphMap -> getCurrPose.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct slide_backend slide_backend_t;
+
+/* Body-frame detections of one key frame: field order/precision of sloam_msgs/SemanticMeasSyncOdom
+ * (ROSCylinder/ROSCube/ROSEllipsoid; float32 fields already widened to double by the caller). */
+typedef struct slide_detections_t {
+  int n_cyl;
+  const double* cyl_root;    /* 3 * n_cyl */
+  const double* cyl_ray;     /* 3 * n_cyl */
+  const double* cyl_radius;  /* n_cyl */
+  const int32_t* cyl_label;
+  int n_cube;
+  const double* cube_pose7;  /* 7 * n_cube */
+  const double* cube_scale;  /* 3 * n_cube */
+  const int32_t* cube_label;
+  int n_ell;
+  const double* ell_pose7;
+  const double* ell_scale;
+  const int32_t* ell_label;
+} slide_detections_t;
+
+typedef struct slide_frame_result_t {
+  double out_pose7[7];   /* outPose (sloamNode.cpp:1028) */
+  int32_t* cyl_match;    /* caller buffers (may be NULL): submap index or -1, sloam.cpp:224-226 */
+  int32_t* cube_match;
+  int32_t* ell_match;
+  int32_t* cyl_id;       /* global landmark ids used in the graph (L / C / U index) */
+  int32_t* cube_id;
+  int32_t* ell_id;
+  int optimized;         /* addSLOAMObservation's return value */
+  double ms_association; /* the two timers the reference keeps (sloamNode.cpp:845-849, 888-897), host wall clock */
+  double ms_graph;
+} slide_frame_result_t;
+
+#define SLIDE_FRAME_HOST 0           /* host robot's own key frame: pose = prev * rel; add + solve + map refresh */
+#define SLIDE_FRAME_HOST_DEFERRED 1  /* same, map refresh deferred to slide_backend_end_frame (foreign packets pending) */
+#define SLIDE_FRAME_FOREIGN 2        /* another robot's packet (sloamNode.cpp:938-999): prev7 is the key pose ALREADY in the host frame; no solve */
+
+slide_backend_t* slide_backend_create(const slide_params_t* p);
+void slide_backend_destroy(slide_backend_t* b);
+int slide_backend_process_frame(slide_backend_t* b, int mode, int robot, const double rel7[7], const double prev7[7],
+                                const slide_detections_t* det, slide_frame_result_t* res);
+int slide_backend_ingest_solve(slide_backend_t* b);                        /* sloamNode.cpp:1000 */
+int slide_backend_end_frame(slide_backend_t* b, int robot, double out7[7]); /* sloamNode.cpp:1010-1014 */
+slide_graph_t* slide_backend_graph(slide_backend_t* b);                    /* borrowed; owned by the backend */
+/* [cyl_counter_, cube_counter_, point_landmark_counter_, #factors] + pose_counter_robot_ (graphWrapper.h:128-134) */
+int slide_backend_counts(slide_backend_t* b, uint64_t out4[4], uint64_t* pose_counters, int n_robots);
+/* map model read-back (getRawMap): cylinder -> 7 doubles; cube / ellipsoid -> xyz + scale (6 doubles) */
+int slide_backend_map_model(slide_backend_t* b, int cls, int idx, double* out, int* hits, int* label);
+
+/* ------------------------------------------------------------------------------------------------
+ * S4 — inter-robot map-to-map association
+ * ---------------------------------------------------------------------------------------------- */
+/* SlideMatch parameters: PlaceRecognition::ParamInit (src/core/place_recognition.cpp:24-78). */
+typedef struct slide_place_params_t {
+  double dilation_factor;            /* 1.2 */
+  double search_xy_step_size;        /* 0.5 */
+  double match_yaw_half_range;       /* rad (180 deg) */
+  double search_yaw_step_size;       /* rad (2 deg) */
+  double match_threshold_position;   /* 0.5 */
+  double match_threshold_dimension;  /* 1.0 */
+  int disable_yaw_search;
+  int ignore_dimension;
+  int min_num_inliers;               /* 5 */
+  int use_nonlinear_least_squares;   /* use_lsq, true */
+  int min_num_map_objects_to_start;  /* 1 */
+  int max_rings;                     /* -1 = all; replaces the wall-clock compute_budget_sec */
+} slide_place_params_t;
+void slide_place_default_params(slide_place_params_t* p);
+/* PlaceRecognition::MatchMaps place_recognition.cpp:98-387 on already-centred maps.
+ * ref7 / qry7: rows [label, x, y, z, d1, d2, d3].  best_xyyaw: winning (x, y, yaw); pair_*: matched pairs
+ * (caller buffers of nq entries).  Returns the best inlier count (>= 0) or a negative SLIDE_ERR_*. */
+int slide_match_maps(const double* ref7, int nr, const double* qry7, int nq, const slide_place_params_t* p,
+                     double best_xyyaw[3], int32_t* pair_ref_idx, int32_t* pair_qry_idx, int64_t* n_candidates);
+/* PlaceRecognition::findInterLoopClosure :498-538 (centring, sweep, inlier gate, Kabsch refinement).
+ * Returns 1 found / 0 not found / negative error.  tf16: 4x4 row-major query->reference. */
+int slide_find_inter_loop_closure(const double* ref7, int nr, const double* qry7, int nq, const slide_place_params_t* p,
+                                  double tf16[16], int* inliers, double xyzyaw[4]);
+
+/* CLIPPER pairwise-consistency affinity (clipper_semantic_object/src/clipper.cpp:21-65 with the
+ * EuclideanDistance invariant src/invariants/euclidean_distance.cpp:13-31).  D1: n1 points of `dim`
+ * doubles (point-major), A: m x 2 association list.  M_out: m x m row-major, upper triangle filled. */
+int slide_clipper_affinity(const double* D1, int n1, const double* D2, int n2, int dim, const int32_t* A, int m,
+                           double sigma, double epsilon, double mindist, double affinityeps, double* M_out);
+
+/* sloam::FindRelativeMeasurementMatch / GetIndexClosestPoseMstPair (src/core/sloam.cpp:321-440).
+ * Stamps are (sec, nsec) pairs.  Host-side logic (tiny, sequential): no kernel. */
+int slide_closest_stamp(const int64_t* sec, const int64_t* nsec, int n, int64_t qsec, int64_t qnsec, int* idx, double* diff);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLIDE_GPU_H_ */

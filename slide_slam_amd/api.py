@@ -1,0 +1,374 @@
+"""ctypes binding of include/slide_gpu.h (the C-ABI drop-in boundary of the sloam backend hot path).
+
+The shared library carries gfx950 HIP kernels only.  There is no CPU fallback: importing works
+anywhere (so that symbol/ABI tests run without a GPU), but every compute call fails loudly with
+``SlideError`` when the library or a gfx950 device is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libslide_gpu.so")
+_LIB = None
+
+SLIDE_OK, SLIDE_MISSING = 0, 1
+ERR = {-1: "SLIDE_ERR_INVALID", -2: "SLIDE_ERR_NOT_SPD", -3: "SLIDE_ERR_CAPACITY", -4: "SLIDE_ERR_HIP", -5: "SLIDE_ERR_RUNTIME"}
+CHART_CAYLEY, CHART_EXPMAP = 0, 1
+CLS_CYLINDER, CLS_CUBE, CLS_ELLIPSOID = 0, 1, 2
+FRAME_HOST, FRAME_HOST_DEFERRED, FRAME_FOREIGN = 0, 1, 2
+
+# every symbol include/slide_gpu.h declares (checked by tests/test_abi.py against the header text)
+EXPORTS = [
+    "slide_default_params", "slide_device_check", "slide_last_error", "slide_version",
+    "slide_graph_create", "slide_graph_destroy", "slide_graph_set_prior", "slide_graph_add_keypose_between",
+    "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
+    "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
+    "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
+    "slide_graph_get_landmark", "slide_graph_stats", "slide_graph_set_profiling", "slide_graph_get_profile",
+    "slide_dense_spd_solve", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device",
+    "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
+    "slide_backend_end_frame", "slide_backend_graph", "slide_backend_counts", "slide_backend_map_model",
+    "slide_place_default_params", "slide_match_maps", "slide_find_inter_loop_closure", "slide_clipper_affinity",
+    "slide_closest_stamp",
+]
+
+
+class SlideError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("pose_chart", C.c_int), ("relinearize_threshold", C.c_double), ("noise_floor", C.c_double),
+                ("noise_model_prior_first_pose_vec", C.c_double * 6), ("noise_model_odom_vec", C.c_double * 6),
+                ("noise_model_cube_vec", C.c_double * 9), ("noise_model_rel_meas_vec", C.c_double * 6),
+                ("cylinder_sigma", C.c_double), ("bearing_range_sigma", C.c_double), ("numdiff_delta", C.c_double),
+                ("cylinder_match_thresh", C.c_double), ("cuboid_match_thresh", C.c_double),
+                ("ellipsoid_match_thresh", C.c_double), ("knn_cylinder", C.c_int), ("knn_cube", C.c_int),
+                ("knn_ellipsoid", C.c_int), ("number_of_robots", C.c_int), ("device", C.c_int)]
+
+
+class Detections(C.Structure):
+    _fields_ = [("n_cyl", C.c_int), ("cyl_root", C.c_void_p), ("cyl_ray", C.c_void_p), ("cyl_radius", C.c_void_p),
+                ("cyl_label", C.c_void_p), ("n_cube", C.c_int), ("cube_pose7", C.c_void_p), ("cube_scale", C.c_void_p),
+                ("cube_label", C.c_void_p), ("n_ell", C.c_int), ("ell_pose7", C.c_void_p), ("ell_scale", C.c_void_p),
+                ("ell_label", C.c_void_p)]
+
+
+class FrameResult(C.Structure):
+    _fields_ = [("out_pose7", C.c_double * 7), ("cyl_match", C.c_void_p), ("cube_match", C.c_void_p),
+                ("ell_match", C.c_void_p), ("cyl_id", C.c_void_p), ("cube_id", C.c_void_p), ("ell_id", C.c_void_p),
+                ("optimized", C.c_int), ("ms_association", C.c_double), ("ms_graph", C.c_double)]
+
+
+class PlaceParams(C.Structure):
+    _fields_ = [("dilation_factor", C.c_double), ("search_xy_step_size", C.c_double), ("match_yaw_half_range", C.c_double),
+                ("search_yaw_step_size", C.c_double), ("match_threshold_position", C.c_double),
+                ("match_threshold_dimension", C.c_double), ("disable_yaw_search", C.c_int), ("ignore_dimension", C.c_int),
+                ("min_num_inliers", C.c_int), ("use_nonlinear_least_squares", C.c_int),
+                ("min_num_map_objects_to_start", C.c_int), ("max_rings", C.c_int)]
+
+
+def lib():
+    """Load libslide_gpu.so (built by slide_slam_amd.build / __graft_entry__.build)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise SlideError(f"{LIB_PATH} is missing: run `python -m slide_slam_amd.build` (hipcc, gfx950). "
+                             "There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.slide_last_error.restype = C.c_char_p
+        L.slide_version.restype = C.c_char_p
+        L.slide_graph_create.restype = C.c_void_p
+        L.slide_backend_create.restype = C.c_void_p
+        L.slide_backend_graph.restype = C.c_void_p
+        _LIB = L
+    return _LIB
+
+
+def last_error() -> str:
+    return lib().slide_last_error().decode()
+
+
+def _check(rc, allow_missing=False):
+    if rc == SLIDE_OK or (allow_missing and rc == SLIDE_MISSING):
+        return rc
+    raise SlideError(f"{ERR.get(rc, rc)}: {last_error()}")
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    lib().slide_default_params(C.byref(p))
+    for k, v in kw.items():
+        if isinstance(v, (list, tuple, np.ndarray)):
+            arr = getattr(p, k)
+            for i, x in enumerate(v):
+                arr[i] = float(x)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def device_check(device: int = -1) -> None:
+    _check(lib().slide_device_check(C.c_int(device)))
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class SlideGraph:
+    """SemanticFactorGraph seam (reference include/factorgraph/graph.h:70-121) on the MI355X."""
+
+    def __init__(self, params: Params | None = None, handle=None):
+        self.L = lib()
+        self.own = handle is None
+        if handle is None:
+            h = self.L.slide_graph_create(C.byref(params) if params is not None else None)
+            if not h:
+                raise SlideError(f"slide_graph_create failed: {last_error()}")
+            handle = C.c_void_p(h)
+        self.h = handle
+
+    def __del__(self):
+        if getattr(self, "own", False) and getattr(self, "h", None):
+            self.L.slide_graph_destroy(self.h)
+            self.h = None
+
+    def set_prior(self, robot, pose7):
+        _check(self.L.slide_graph_set_prior(self.h, C.c_int(robot), _p(_d(pose7))))
+
+    def add_keypose_between(self, robot, frm, to, rel7, est7):
+        _check(self.L.slide_graph_add_keypose_between(self.h, C.c_int(robot), C.c_uint64(frm), C.c_uint64(to), _p(_d(rel7)),
+                                                      _p(_d(est7))))
+
+    def add_loop_closure(self, rel7, i1, r1, i2, r2):
+        _check(self.L.slide_graph_add_loop_closure(self.h, _p(_d(rel7)), C.c_uint64(i1), C.c_int(r1), C.c_uint64(i2),
+                                                   C.c_int(r2)))
+
+    def add_relative_meas(self, rel7, i1, r1, i2, r2):
+        _check(self.L.slide_graph_add_relative_meas(self.h, _p(_d(rel7)), C.c_uint64(i1), C.c_int(r1), C.c_uint64(i2),
+                                                    C.c_int(r2)))
+
+    def add_point_landmark(self, idx, xyz):
+        _check(self.L.slide_graph_add_point_landmark(self.h, C.c_uint64(idx), _p(_d(xyz))))
+
+    def add_range_bearing(self, robot, pose_idx, lm_idx, bearing, rng):
+        _check(self.L.slide_graph_add_range_bearing(self.h, C.c_int(robot), C.c_uint64(pose_idx), C.c_uint64(lm_idx),
+                                                    _p(_d(bearing)), C.c_double(rng)))
+
+    def add_cube(self, robot, pose_idx, cube_idx, pose7, cube7, scale, exists):
+        _check(self.L.slide_graph_add_cube(self.h, C.c_int(robot), C.c_uint64(pose_idx), C.c_uint64(cube_idx), _p(_d(pose7)),
+                                           _p(_d(cube7)), _p(_d(scale)), C.c_int(int(exists))))
+
+    def add_cylinder(self, robot, pose_idx, cyl_idx, pose7, root, ray, radius, exists):
+        _check(self.L.slide_graph_add_cylinder(self.h, C.c_int(robot), C.c_uint64(pose_idx), C.c_uint64(cyl_idx),
+                                               _p(_d(pose7)), _p(_d(root)), _p(_d(ray)), C.c_double(radius),
+                                               C.c_int(int(exists))))
+
+    def solve(self):
+        return _check(self.L.slide_graph_solve(self.h))
+
+    def gauss_newton(self, iterations=1):
+        return _check(self.L.slide_graph_gauss_newton(self.h, C.c_int(iterations)))
+
+    def get_pose(self, robot, idx):
+        out = np.zeros(7)
+        st = _check(self.L.slide_graph_get_pose(self.h, C.c_int(robot), C.c_uint64(idx), _p(out)), True)
+        return st, out
+
+    def get_pose12(self, robot, idx):
+        out = np.zeros(12)
+        st = _check(self.L.slide_graph_get_pose12(self.h, C.c_int(robot), C.c_uint64(idx), _p(out)), True)
+        return st, out
+
+    def get_all_poses(self, robot, cap):
+        out = np.zeros((cap, 7))
+        n = C.c_uint64(0)
+        _check(self.L.slide_graph_get_all_poses(self.h, C.c_int(robot), _p(out), C.c_uint64(cap), C.byref(n)))
+        return out[: n.value]
+
+    def get_landmark(self, cls, idx):
+        out = np.zeros(15)
+        st = _check(self.L.slide_graph_get_landmark(self.h, C.c_int(cls), C.c_uint64(idx), _p(out)), True)
+        return st, out[: (7, 15, 3)[cls]]
+
+    def stats(self):
+        out = np.zeros(5, np.int64)
+        _check(self.L.slide_graph_stats(self.h, _p(out)))
+        return dict(n_pose=int(out[0]), n_lm=int(out[1]), n_factors=int(out[2]), n_relin=int(out[3]), chol_dim=int(out[4]))
+
+    def set_profiling(self, on=True):
+        _check(self.L.slide_graph_set_profiling(self.h, C.c_int(int(on))))
+
+    def get_profile(self):
+        names = C.create_string_buffer(32 * 32)
+        ms = np.zeros(32)
+        cnt = np.zeros(32, np.int64)
+        n = self.L.slide_graph_get_profile(self.h, names, _p(ms), _p(cnt), C.c_int(32))
+        out = {}
+        for i in range(n):
+            nm = names.raw[32 * i: 32 * i + 32].split(b"\0")[0].decode()
+            out[nm] = dict(ms=float(ms[i]), launches=int(cnt[i]))
+        return out
+
+
+class SlideBackend:
+    """runSLOAMNode seam (reference src/core/sloamNode.cpp:762-1036) on the MI355X."""
+
+    def __init__(self, params: Params | None = None, num_robots: int = 1):
+        self.L = lib()
+        self.n_robots = num_robots
+        h = self.L.slide_backend_create(C.byref(params) if params is not None else None)
+        if not h:
+            raise SlideError(f"slide_backend_create failed: {last_error()}")
+        self.h = C.c_void_p(h)
+        self.graph = SlideGraph(handle=C.c_void_p(self.L.slide_backend_graph(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.slide_backend_destroy(self.h)
+            self.h = None
+
+    def process_frame(self, robot, rel7, prev7, det, mode=FRAME_HOST):
+        nc, nb, ne = len(det["cyl_label"]), len(det["cube_label"]), len(det["ell_label"])
+        a = [_d(det["cyl_root"]), _d(det["cyl_ray"]), _d(det["cyl_radius"]), _i(det["cyl_label"]),
+             _d(det["cube_pose7"]), _d(det["cube_scale"]), _i(det["cube_label"]),
+             _d(det["ell_pose7"]), _d(det["ell_scale"]), _i(det["ell_label"])]
+        D = Detections(nc, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), nb, _p(a[4]), _p(a[5]), _p(a[6]), ne, _p(a[7]),
+                       _p(a[8]), _p(a[9]))
+        cm, bm, em = np.full(nc, -1, np.int32), np.full(nb, -1, np.int32), np.full(ne, -1, np.int32)
+        cid, bid, eid = np.full(nc, -1, np.int32), np.full(nb, -1, np.int32), np.full(ne, -1, np.int32)
+        R = FrameResult()
+        R.cyl_match, R.cube_match, R.ell_match = _p(cm), _p(bm), _p(em)
+        R.cyl_id, R.cube_id, R.ell_id = _p(cid), _p(bid), _p(eid)
+        rc = self.L.slide_backend_process_frame(self.h, C.c_int(mode), C.c_int(robot), _p(_d(rel7)), _p(_d(prev7)),
+                                                C.byref(D), C.byref(R))
+        if rc not in (SLIDE_OK, -2):
+            _check(rc)
+        return dict(status=int(rc), pose7=np.array(R.out_pose7[:]), cyl_match=cm, cube_match=bm, ell_match=em,
+                    cyl_id=cid, cube_id=bid, ell_id=eid, t_assoc=R.ms_association * 1e-3, t_graph=R.ms_graph * 1e-3)
+
+    def ingest_solve(self):
+        return self.L.slide_backend_ingest_solve(self.h)
+
+    def end_frame(self, robot):
+        out = np.zeros(7)
+        st = self.L.slide_backend_end_frame(self.h, C.c_int(robot), _p(out))
+        return int(st), out
+
+    def counts(self):
+        out = np.zeros(4, np.uint64)
+        pc = np.zeros(13, np.uint64)
+        _check(self.L.slide_backend_counts(self.h, _p(out), _p(pc), C.c_int(13)))
+        return dict(cyl=int(out[0]), cube=int(out[1]), point=int(out[2]), factors=int(out[3]),
+                    poses=pc[: self.n_robots].astype(np.int64))
+
+    def map_model(self, cls, idx):
+        out = np.zeros(7)
+        hits, label = C.c_int(0), C.c_int(0)
+        st = _check(self.L.slide_backend_map_model(self.h, C.c_int(cls), C.c_int(idx), _p(out), C.byref(hits), C.byref(label)),
+                    True)
+        return int(st), out[: 7 if cls == 0 else 6], hits.value, label.value
+
+
+def dense_spd_solve(A, b, repeats=1):
+    """x = A^-1 b on the GPU (blocked FP64-MFMA Cholesky); returns (x, device ms over `repeats` passes)."""
+    A = np.asfortranarray(np.asarray(A, dtype=np.float64))
+    n = A.shape[0]
+    x = np.zeros(n)
+    ms = C.c_double(0)
+    _check(lib().slide_dense_spd_solve(A.ctypes.data_as(C.c_void_p), C.c_int(n), _p(_d(b)), _p(x), C.c_int(repeats),
+                                       C.byref(ms)))
+    return x, ms.value
+
+
+# ---- stand-alone association / place recognition ---------------------------------------------------------
+def submap_knn(cloud_xyz_f32, query_xyz, K):
+    cloud = np.ascontiguousarray(cloud_xyz_f32, dtype=np.float32)
+    n = cloud.shape[0]
+    out = np.zeros(max(min(K, n), 1), np.int32)
+    k = C.c_int(0)
+    _check(lib().slide_submap_knn(_p(cloud), C.c_uint64(n), _p(_d(query_xyz)), C.c_int(K), _p(out), C.byref(k)))
+    return out[: k.value]
+
+
+def match_cylinders(root, ray, label, map_root, map_ray, map_label, thresh):
+    n, m = len(label), len(map_label)
+    out = np.full(max(n, 1), -1, np.int32)
+    _check(lib().slide_assoc_match_cylinders(C.c_int(n), _p(_d(root)), _p(_d(ray)), _p(_i(label)), C.c_int(m), _p(_d(map_root)),
+                                             _p(_d(map_ray)), _p(_i(map_label)), C.c_double(thresh), _p(out)))
+    return out[:n]
+
+
+def match_boxes(cls, xyz, label, map_xyz, map_label, thresh):
+    n, m = len(label), len(map_label)
+    out = np.full(max(n, 1), -1, np.int32)
+    _check(lib().slide_assoc_match_boxes(C.c_int(cls), C.c_int(n), _p(_d(xyz)), _p(_i(label)), C.c_int(m), _p(_d(map_xyz)),
+                                         _p(_i(map_label)), C.c_double(thresh), _p(out)))
+    return out[:n]
+
+
+def place_default_params(**kw) -> PlaceParams:
+    p = PlaceParams()
+    lib().slide_place_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def match_maps(ref7, qry7, params: PlaceParams):
+    ref7, qry7 = _d(ref7), _d(qry7)
+    nr, nq = ref7.shape[0], qry7.shape[0]
+    best = np.zeros(3)
+    pr, pq = np.full(max(nq, 1), -1, np.int32), np.full(max(nq, 1), -1, np.int32)
+    nc = C.c_int64(0)
+    inl = lib().slide_match_maps(_p(ref7), C.c_int(nr), _p(qry7), C.c_int(nq), C.byref(params), _p(best), _p(pr), _p(pq),
+                                 C.byref(nc))
+    if inl < 0 and inl != -10000:
+        _check(inl)
+    k = max(inl, 0)
+    return dict(inliers=int(inl), xyyaw=best, ref_idx=pr[:k], qry_idx=pq[:k], candidates=int(nc.value))
+
+
+def find_inter_loop_closure(ref7, qry7, params: PlaceParams):
+    ref7, qry7 = _d(ref7), _d(qry7)
+    tf = np.zeros(16)
+    inl = C.c_int(0)
+    xyzyaw = np.zeros(4)
+    rc = lib().slide_find_inter_loop_closure(_p(ref7), C.c_int(ref7.shape[0]), _p(qry7), C.c_int(qry7.shape[0]),
+                                             C.byref(params), _p(tf), C.byref(inl), _p(xyzyaw))
+    if rc < 0:
+        _check(rc)
+    return dict(found=bool(rc), tf=tf.reshape(4, 4), inliers=inl.value, xyzyaw=xyzyaw)
+
+
+def clipper_affinity(D1, D2, A, sigma=0.01, epsilon=0.06, mindist=0.0, affinityeps=1e-4):
+    D1, D2 = _d(D1), _d(D2)
+    A = _i(A)
+    m = A.shape[0]
+    M = np.zeros((m, m))
+    _check(lib().slide_clipper_affinity(_p(D1), C.c_int(D1.shape[0]), _p(D2), C.c_int(D2.shape[0]), C.c_int(D1.shape[1]), _p(A),
+                                        C.c_int(m), C.c_double(sigma), C.c_double(epsilon), C.c_double(mindist),
+                                        C.c_double(affinityeps), _p(M)))
+    return M
+
+
+def closest_stamp(sec, nsec, qsec, qnsec):
+    sec = np.ascontiguousarray(sec, dtype=np.int64)
+    nsec = np.ascontiguousarray(nsec, dtype=np.int64)
+    idx, diff = C.c_int(0), C.c_double(0)
+    lib().slide_closest_stamp(_p(sec), _p(nsec), C.c_int(len(sec)), C.c_int64(qsec), C.c_int64(qnsec), C.byref(idx),
+                              C.byref(diff))
+    return idx.value, diff.value

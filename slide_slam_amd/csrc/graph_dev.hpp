@@ -1,0 +1,74 @@
+// Device-resident factor-graph state (HBM, SoA per record kind) shared by the host graph object and
+// the HIP kernels.  One Gauss-Newton / iSAM2-equivalent update of the reference
+// (SemanticFactorGraph::solve, backend/sloam/src/factorgraph/graph.cpp:260-272) runs as:
+//   relin -> linearise -> landmark reduce (H_ll, H_ll^-1, E, F, u) -> pose reduce (H_pp, g_p)
+//   -> Schur assemble (dense reduced pose system, column-major lower) -> blocked FP64-MFMA Cholesky
+//   (forward substitution rides along as an extra row) -> backward substitution -> landmark
+//   back-substitution -> estimate = theta (+) delta.
+#pragma once
+#include <stdint.h>
+
+namespace sl {
+
+enum { VT_POSE = 0, VT_POINT = 1, VT_CUBE = 2, VT_CYL = 3 };
+enum { FT_BR = 2, FT_CUBE = 3, FT_CYL = 4 };
+
+constexpr int NB = 64;  // Cholesky tile edge
+
+__host__ __device__ inline int lm_dim(int t) { return t == VT_POINT ? 3 : (t == VT_CUBE ? 9 : 7); }
+__host__ __device__ inline int lf_rows(int t) { return t == FT_BR ? 3 : (t == FT_CUBE ? 9 : 7); }
+// packed sizes (doubles) of one landmark factor's linearisation record [r | Jp (m x 6) | Jl (m x d)]
+__host__ __device__ inline int lf_jsize(int t) { return t == FT_BR ? 30 : (t == FT_CUBE ? 144 : 98); }
+// and of its Schur record [E (6 x d) | F (6 x d) | u (6)]
+__host__ __device__ inline int lf_esize(int t) { return t == FT_BR ? 42 : (t == FT_CUBE ? 114 : 90); }
+
+struct GraphDev {
+  // ---- variables -------------------------------------------------------------------------
+  int P, L;
+  double* pose_val;    // 12 P   theta: R row-major (9) + t (3)
+  double* pose_delta;  // 6 P
+  double* pose_est;    // 12 P   theta (+) delta
+  int* lm_type;        // L      VT_*
+  double* lm_val;      // 15 L   POINT xyz | CUBE R t scale | CYL root ray radius
+  double* lm_delta;    // 9 L
+  double* lm_est;      // 15 L
+  // ---- factors ---------------------------------------------------------------------------
+  int n_prior;
+  int* pr_pose; double* pr_z; double* pr_sigma;   // z: 12, sigma: 6
+  double* pr_r;                                   // 6 whitened residual (J = diag(1/sigma))
+  int n_between;
+  int* bt_i; int* bt_j; double* bt_z; double* bt_sigma;   // z: 12, sigma: 6
+  double* bt_r; double* bt_J0;                    // 6 ; 36 (J1 = diag(1/sigma))
+  int n_lf;                                       // landmark factors, unified id space
+  int* lf_type; int* lf_pose; int* lf_lm; int* lf_slot;   // slot = index into the per-type z arrays
+  int64_t* lf_joff; int64_t* lf_eoff;             // offsets (doubles) into jbuf / ebuf
+  double* br_z;                                   // 4 per BR factor: bearing(3), range
+  double* cu_z; double* cu_sigma;                 // 15 ; 9
+  double* cy_z;                                   // 7
+  double* jbuf;                                   // per factor [r | Jp | Jl], whitened
+  double* ebuf;                                   // per factor [E | F | u]
+  // ---- topology --------------------------------------------------------------------------
+  int* lm_ptr; int* lm_fids;        // landmark -> factor ids (insertion order)
+  int* pose_ptr; int* pose_fids;    // pose -> factor ids sorted by (landmark id, factor id)
+  int* pose_bt_ptr; int* pose_bt;   // pose -> (between index << 1 | role), role 1 = second key
+  // ---- landmark blocks -------------------------------------------------------------------
+  double* lm_Hinv;   // 81 L  (d x d used)
+  double* lm_g;      // 9 L
+  // ---- pose blocks -----------------------------------------------------------------------
+  double* pose_H;    // 36 P
+  double* pose_g;    // 6 P   (already reduced: g_p - sum F g_l)
+  // ---- dense reduced system ----------------------------------------------------------------
+  double* S;         // column-major, ld rows x (T*NB) columns, lower triangle + RHS row at T*NB
+  int ld;            // (T + 1) * NB
+  int T;             // ceil(6 P / NB)
+  double* W;         // T * NB*NB : inverse of every diagonal Cholesky block (column-major)
+  double* yv;        // T*NB  forward-substituted RHS
+  double* dp;        // T*NB  reduced solution (delta_p = -dp)
+  int* status;       // [0] not-SPD flag (landmark), [1] not-SPD flag (chol), [2] #relinearised
+  // ---- parameters ------------------------------------------------------------------------
+  int chart;
+  double relin_thr;
+  double bearing_sigma, cyl_sigma, numdiff_delta;
+};
+
+}  // namespace sl

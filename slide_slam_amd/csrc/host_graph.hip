@@ -1,0 +1,468 @@
+// Host side of the device-resident factor graph (see host_graph.hpp).
+#include "host_graph.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+
+namespace sl {
+
+thread_local std::string g_last_error;
+
+bool hip_ok(hipError_t e, const char* what) {
+  if (e == hipSuccess) return true;
+  g_last_error = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what;
+  return false;
+}
+
+// ---- profiler ----------------------------------------------------------------------------------
+int Profiler::id_of(const char* name) {
+  for (size_t i = 0; i < names.size(); ++i)
+    if (names[i] == name) return (int)i;
+  names.push_back(name);
+  ms.push_back(0.0);
+  count.push_back(0);
+  return (int)names.size() - 1;
+}
+void Profiler::begin(int id, hipStream_t s) {
+  if (!on) return;
+  Rec r;
+  r.id = id;
+  for (hipEvent_t* e : {&r.a, &r.b}) {
+    if (!pool.empty()) { *e = pool.back(); pool.pop_back(); }
+    else (void)hipEventCreate(e);
+  }
+  (void)hipEventRecord(r.a, s);
+  recs.push_back(r);
+}
+void Profiler::end(hipStream_t s) {
+  if (!on || recs.empty()) return;
+  (void)hipEventRecord(recs.back().b, s);
+}
+void Profiler::collect() {
+  for (auto& r : recs) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.id] += t; count[r.id] += 1; }
+    pool.push_back(r.a);
+    pool.push_back(r.b);
+  }
+  recs.clear();
+}
+void Profiler::reset() {
+  for (auto& m : ms) m = 0.0;
+  for (auto& c : count) c = 0;
+}
+Profiler::~Profiler() {
+  for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto e : pool) (void)hipEventDestroy(e);
+}
+
+// ---- keys ----------------------------------------------------------------------------------------
+uint64_t HostGraph::pose_key(int robot, uint64_t idx) {
+  // gtsam::Symbol chars of SemanticFactorGraph::getSymbol (graph.cpp:325-371)
+  static const char cs[SLIDE_MAX_ROBOTS] = {'x', 'y', 'z', 'm', 'n', 'o', 'p', 'q', 'r', 's', 't', 'v', 'w'};
+  return ((uint64_t)(unsigned char)cs[robot] << 56) | idx;
+}
+uint64_t HostGraph::lm_key(int cls, uint64_t idx) {
+  const char c = cls == SLIDE_CLS_CYLINDER ? 'l' : (cls == SLIDE_CLS_CUBE ? 'c' : 'u');   // graph.h:41-58
+  return ((uint64_t)(unsigned char)c << 56) | idx;
+}
+
+HostGraph::HostGraph(const slide_params_t& p) : P(p) {}
+HostGraph::~HostGraph() {
+  if (stream) (void)hipStreamDestroy(stream);
+}
+int HostGraph::init() {
+  if (P.device >= 0) SL_HIP(hipSetDevice(P.device));
+  SL_HIP(hipStreamCreate(&stream));
+  if (d_status.ensure(8, 0, stream, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+  return SLIDE_OK;
+}
+
+static bool robot_ok(int r) { return r >= 0 && r < SLIDE_MAX_ROBOTS; }
+static void put12(const SE3& T, double* z) { to12(T, z); }
+
+int HostGraph::set_prior(int robot, const double* pose7) {
+  if (!robot_ok(robot)) return SLIDE_ERR_INVALID;
+  const SE3 T = from7(pose7);
+  PendFac f{};
+  f.type = 0;
+  f.k0 = pose_key(robot, 0);
+  put12(T, f.z);
+  for (int i = 0; i < 6; ++i) f.sigma[i] = P.noise_model_prior_first_pose_vec[i];
+  pend_facs.push_back(f);
+  PendVar v{};
+  v.key = f.k0;
+  v.type = VT_POSE;
+  put12(T, v.val);
+  pend_vars.push_back(v);
+  return SLIDE_OK;
+}
+int HostGraph::add_between_sigma(uint64_t k0, uint64_t k1, const SE3& rel, const double* sigma6) {
+  PendFac f{};
+  f.type = 1;
+  f.k0 = k0;
+  f.k1 = k1;
+  put12(rel, f.z);
+  for (int i = 0; i < 6; ++i) f.sigma[i] = sigma6[i];
+  pend_facs.push_back(f);
+  return SLIDE_OK;
+}
+int HostGraph::add_keypose_between(int robot, uint64_t from, uint64_t to, const double* rel7, const double* est7) {
+  if (!robot_ok(robot)) return SLIDE_ERR_INVALID;
+  const SE3 rel = from7(rel7);
+  // odom sigma scaled by max(|t_rel|, noise_floor) (graph.cpp:54-60)
+  const double dist = std::max(norm(rel.t), P.noise_floor);
+  double s[6];
+  for (int i = 0; i < 6; ++i) s[i] = P.noise_model_odom_vec[i] * dist;
+  add_between_sigma(pose_key(robot, from), pose_key(robot, to), rel, s);
+  PendVar v{};
+  v.key = pose_key(robot, to);
+  v.type = VT_POSE;
+  put12(from7(est7), v.val);
+  pend_vars.push_back(v);
+  return SLIDE_OK;
+}
+int HostGraph::add_loop_closure(const double* rel7, uint64_t i1, int r1, uint64_t i2, int r2) {
+  if (!robot_ok(r1) || !robot_ok(r2)) return SLIDE_ERR_INVALID;
+  double s[6];
+  for (int i = 0; i < 6; ++i) s[i] = P.noise_model_odom_vec[i] * 0.01;   // noise_model_closure graphWrapper.cpp:55
+  return add_between_sigma(pose_key(r1, i1), pose_key(r2, i2), from7(rel7), s);
+}
+int HostGraph::add_relative_meas(const double* rel7, uint64_t i1, int r1, uint64_t i2, int r2) {
+  if (!robot_ok(r1) || !robot_ok(r2)) return SLIDE_ERR_INVALID;
+  const SE3 rel = from7(rel7);
+  const double dist = std::max(norm(rel.t), P.noise_floor);   // graph.cpp:251-252
+  double s[6];
+  for (int i = 0; i < 6; ++i) s[i] = P.noise_model_rel_meas_vec[i] * dist;
+  return add_between_sigma(pose_key(r1, i1), pose_key(r2, i2), rel, s);
+}
+int HostGraph::add_point_landmark(uint64_t idx, const double* xyz) {
+  PendVar v{};
+  v.key = lm_key(SLIDE_CLS_ELLIPSOID, idx);
+  v.type = VT_POINT;
+  v.val[0] = xyz[0]; v.val[1] = xyz[1]; v.val[2] = xyz[2];
+  pend_vars.push_back(v);
+  return SLIDE_OK;
+}
+int HostGraph::add_range_bearing(int robot, uint64_t pose_idx, uint64_t lm_idx, const double* bearing, double range) {
+  if (!robot_ok(robot)) return SLIDE_ERR_INVALID;
+  PendFac f{};
+  f.type = FT_BR;
+  f.k0 = pose_key(robot, pose_idx);
+  f.k1 = lm_key(SLIDE_CLS_ELLIPSOID, lm_idx);
+  const double n = std::sqrt(bearing[0] * bearing[0] + bearing[1] * bearing[1] + bearing[2] * bearing[2]);
+  for (int i = 0; i < 3; ++i) f.z[i] = bearing[i] / n;   // Pose3().bearing(p) = Unit3(p)  (graph.cpp:163)
+  f.z[3] = range;
+  pend_facs.push_back(f);
+  return SLIDE_OK;
+}
+int HostGraph::add_cube(int robot, uint64_t pose_idx, uint64_t cube_idx, const SE3& pose, const SE3& cube_world,
+                        const double* scale, bool exists) {
+  if (!robot_ok(robot)) return SLIDE_ERR_INVALID;
+  const SE3 loc = compose(inverse(pose), cube_world);             // cube_global_meas.project(pose.inverse()) graph.cpp:211
+  const double dist = std::max(norm(loc.t), 0.1);                 // graph.cpp:214
+  PendFac f{};
+  f.type = FT_CUBE;
+  f.k0 = pose_key(robot, pose_idx);
+  f.k1 = lm_key(SLIDE_CLS_CUBE, cube_idx);
+  put12(loc, f.z);
+  for (int i = 0; i < 3; ++i) f.z[12 + i] = scale[i];
+  for (int i = 0; i < 9; ++i) f.sigma[i] = P.noise_model_cube_vec[i] * dist;
+  pend_facs.push_back(f);
+  if (!exists) {
+    PendVar v{};
+    v.key = f.k1;
+    v.type = VT_CUBE;
+    put12(cube_world, v.val);
+    for (int i = 0; i < 3; ++i) v.val[12 + i] = scale[i];
+    pend_vars.push_back(v);
+  }
+  return SLIDE_OK;
+}
+int HostGraph::add_cylinder(int robot, uint64_t pose_idx, uint64_t cyl_idx, const SE3& pose, const double* root,
+                            const double* ray, double radius, bool exists) {
+  if (!robot_ok(robot)) return SLIDE_ERR_INVALID;
+  const SE3 inv = inverse(pose);                                  // cylinder.project(pose.inverse()) graph.cpp:190
+  const V3 lr = transform_from(inv, V3{root[0], root[1], root[2]});
+  const V3 la = mul(inv.R, V3{ray[0], ray[1], ray[2]});
+  PendFac f{};
+  f.type = FT_CYL;
+  f.k0 = pose_key(robot, pose_idx);
+  f.k1 = lm_key(SLIDE_CLS_CYLINDER, cyl_idx);
+  f.z[0] = lr.x; f.z[1] = lr.y; f.z[2] = lr.z; f.z[3] = la.x; f.z[4] = la.y; f.z[5] = la.z; f.z[6] = radius;
+  pend_facs.push_back(f);
+  if (!exists) {
+    PendVar v{};
+    v.key = f.k1;
+    v.type = VT_CYL;
+    for (int i = 0; i < 3; ++i) { v.val[i] = root[i]; v.val[3 + i] = ray[i]; }
+    v.val[6] = radius;
+    pend_vars.push_back(v);
+  }
+  return SLIDE_OK;
+}
+
+// ---- merge fgraph / fvalues into the resident arrays (what isam->update(fgraph, fvalues) ingests) ------
+int HostGraph::merge_pending() {
+  for (const PendVar& v : pend_vars) {
+    if (v.type == VT_POSE) {
+      if (key2pose.count(v.key)) continue;   // GTSAM would throw ValuesKeyAlreadyExists
+      key2pose[v.key] = (int)(h_pose_val.size() / 12);
+      h_pose_val.insert(h_pose_val.end(), v.val, v.val + 12);
+      pose_fids.emplace_back();
+      pose_bt.emplace_back();
+    } else {
+      if (key2lm.count(v.key)) continue;
+      key2lm[v.key] = (int)h_lm_type.size();
+      h_lm_type.push_back(v.type);
+      h_lm_val.insert(h_lm_val.end(), v.val, v.val + 15);
+      lm_fids.emplace_back();
+    }
+  }
+  pend_vars.clear();
+  for (const PendFac& f : pend_facs) {
+    auto a = key2pose.find(f.k0);
+    if (a == key2pose.end()) continue;
+    if (f.type == 0) {
+      h_pr_pose.push_back(a->second);
+      h_pr_z.insert(h_pr_z.end(), f.z, f.z + 12);
+      h_pr_sigma.insert(h_pr_sigma.end(), f.sigma, f.sigma + 6);
+    } else if (f.type == 1) {
+      auto b = key2pose.find(f.k1);
+      if (b == key2pose.end()) continue;
+      const int bi = (int)h_bt_i.size();
+      h_bt_i.push_back(a->second);
+      h_bt_j.push_back(b->second);
+      h_bt_z.insert(h_bt_z.end(), f.z, f.z + 12);
+      h_bt_sigma.insert(h_bt_sigma.end(), f.sigma, f.sigma + 6);
+      pose_bt[a->second].push_back(bi << 1);
+      pose_bt[b->second].push_back((bi << 1) | 1);
+    } else {
+      auto b = key2lm.find(f.k1);
+      if (b == key2lm.end()) continue;
+      const int fid = (int)h_lf_type.size();
+      h_lf_type.push_back(f.type);
+      h_lf_pose.push_back(a->second);
+      h_lf_lm.push_back(b->second);
+      if (f.type == FT_BR) {
+        h_lf_slot.push_back((int)(h_br_z.size() / 4));
+        h_br_z.insert(h_br_z.end(), f.z, f.z + 4);
+      } else if (f.type == FT_CUBE) {
+        h_lf_slot.push_back((int)(h_cu_z.size() / 15));
+        h_cu_z.insert(h_cu_z.end(), f.z, f.z + 15);
+        h_cu_sigma.insert(h_cu_sigma.end(), f.sigma, f.sigma + 9);
+      } else {
+        h_lf_slot.push_back((int)(h_cy_z.size() / 7));
+        h_cy_z.insert(h_cy_z.end(), f.z, f.z + 7);
+      }
+      h_lf_joff.push_back(jbuf_used);
+      h_lf_eoff.push_back(ebuf_used);
+      jbuf_used += lf_jsize(f.type);
+      ebuf_used += lf_esize(f.type);
+      lm_fids[b->second].push_back(fid);
+      // keep the pose's list sorted by (landmark id, factor id): the Schur kernel merges two such lists
+      std::vector<int>& pl = pose_fids[a->second];
+      auto pos = std::upper_bound(pl.begin(), pl.end(), fid, [&](int x, int y) {
+        return h_lf_lm[x] != h_lf_lm[y] ? h_lf_lm[x] < h_lf_lm[y] : x < y;
+      });
+      pl.insert(pos, fid);
+    }
+  }
+  pend_facs.clear();
+  return SLIDE_OK;
+}
+
+template <class T>
+static int up_tail(DevArr<T>& d, const std::vector<T>& h, size_t old_n, size_t per, hipStream_t s) {
+  const size_t n = h.size();
+  if (d.ensure(std::max<size_t>(n, 1), old_n * per, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  return d.upload(h.data() + old_n * per, old_n * per, n - old_n * per, s);
+}
+static int up_csr(DevArr<int>& dptr, DevArr<int>& dval, const std::vector<std::vector<int>>& lists, std::vector<int>& ptr,
+                  std::vector<int>& val, hipStream_t s) {
+  ptr.resize(lists.size() + 1);
+  val.clear();
+  ptr[0] = 0;
+  for (size_t i = 0; i < lists.size(); ++i) {
+    val.insert(val.end(), lists[i].begin(), lists[i].end());
+    ptr[i + 1] = (int)val.size();
+  }
+  if (dptr.ensure(ptr.size(), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (dval.ensure(std::max<size_t>(val.size(), 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (dptr.upload(ptr.data(), 0, ptr.size(), s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  return dval.upload(val.data(), 0, val.size(), s);
+}
+
+int HostGraph::upload_new() {
+  hipStream_t s = stream;
+  const size_t Pn = h_pose_val.size() / 12, Ln = h_lm_type.size();
+  const size_t npr = h_pr_pose.size(), nbt = h_bt_i.size(), nlf = h_lf_type.size();
+#define UP(dev, host, oldn, per) \
+  if (up_tail(dev, host, oldn, per, s) != SLIDE_OK) return SLIDE_ERR_HIP
+  UP(d_pose_val, h_pose_val, up_P, 12);
+  if (d_pose_delta.ensure(std::max<size_t>(6 * Pn, 1), 6 * up_P, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (Pn > up_P) SL_HIP(hipMemsetAsync(d_pose_delta.d + 6 * up_P, 0, 6 * (Pn - up_P) * sizeof(double), s));
+  if (d_pose_est.ensure(std::max<size_t>(12 * Pn, 1), 12 * up_P, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  UP(d_lm_val, h_lm_val, up_L, 15);
+  UP(d_lm_type, h_lm_type, up_L, 1);
+  if (d_lm_delta.ensure(std::max<size_t>(9 * Ln, 1), 9 * up_L, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (Ln > up_L) SL_HIP(hipMemsetAsync(d_lm_delta.d + 9 * up_L, 0, 9 * (Ln - up_L) * sizeof(double), s));
+  if (d_lm_est.ensure(std::max<size_t>(15 * Ln, 1), 15 * up_L, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  UP(d_pr_pose, h_pr_pose, up_pr, 1);
+  UP(d_pr_z, h_pr_z, up_pr, 12);
+  UP(d_pr_sigma, h_pr_sigma, up_pr, 6);
+  if (d_pr_r.ensure(std::max<size_t>(6 * npr, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  UP(d_bt_i, h_bt_i, up_bt, 1);
+  UP(d_bt_j, h_bt_j, up_bt, 1);
+  UP(d_bt_z, h_bt_z, up_bt, 12);
+  UP(d_bt_sigma, h_bt_sigma, up_bt, 6);
+  if (d_bt_r.ensure(std::max<size_t>(6 * nbt, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_bt_J0.ensure(std::max<size_t>(36 * nbt, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  UP(d_lf_type, h_lf_type, up_lf, 1);
+  UP(d_lf_pose, h_lf_pose, up_lf, 1);
+  UP(d_lf_lm, h_lf_lm, up_lf, 1);
+  UP(d_lf_slot, h_lf_slot, up_lf, 1);
+  UP(d_lf_joff, h_lf_joff, up_lf, 1);
+  UP(d_lf_eoff, h_lf_eoff, up_lf, 1);
+  UP(d_br_z, h_br_z, up_br, 4);
+  UP(d_cu_z, h_cu_z, up_cu, 15);
+  UP(d_cu_sigma, h_cu_sigma, up_cu, 9);
+  UP(d_cy_z, h_cy_z, up_cy, 7);
+#undef UP
+  if (d_jbuf.ensure(std::max<int64_t>(jbuf_used, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_ebuf.ensure(std::max<int64_t>(ebuf_used, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_lm_Hinv.ensure(std::max<size_t>(81 * Ln, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_lm_g.ensure(std::max<size_t>(9 * Ln, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_pose_H.ensure(std::max<size_t>(36 * Pn, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_pose_g.ensure(std::max<size_t>(6 * Pn, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  std::vector<int> ptr, val;
+  if (up_csr(d_lm_ptr, d_lm_fids, lm_fids, ptr, val, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (up_csr(d_pose_ptr, d_pose_fids, pose_fids, ptr, val, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (up_csr(d_pose_bt_ptr, d_pose_bt, pose_bt, ptr, val, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  SL_HIP(hipStreamSynchronize(s));   // ptr / val are host temporaries
+  // dense reduced system
+  const int T = (int)((6 * Pn + NB - 1) / NB);
+  if (T > Tcap) {
+    int nc = Tcap ? Tcap : 4;
+    while (nc < T) nc = nc + nc / 2 + 1;
+    Tcap = nc;
+    const size_t ld = (size_t)(Tcap + 1) * NB;
+    // S is rewritten by every Schur pass, so nothing is carried over; zero once so the never-written
+    // strict upper tiles and the idle rows of the RHS tile hold finite values.
+    d_S.cap = 0;
+    if (d_S.d) { SL_HIP(hipFree(d_S.d)); d_S.d = nullptr; }
+    if (d_S.ensure(ld * (size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_W.ensure((size_t)Tcap * NB * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_yv.ensure((size_t)Tcap * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_dp.ensure((size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+  }
+  up_P = Pn; up_L = Ln; up_pr = npr; up_bt = nbt; up_lf = nlf;
+  up_br = h_br_z.size() / 4; up_cu = h_cu_z.size() / 15; up_cy = h_cy_z.size() / 7;
+
+  G.P = (int)Pn; G.L = (int)Ln;
+  G.pose_val = d_pose_val.d; G.pose_delta = d_pose_delta.d; G.pose_est = d_pose_est.d;
+  G.lm_type = d_lm_type.d; G.lm_val = d_lm_val.d; G.lm_delta = d_lm_delta.d; G.lm_est = d_lm_est.d;
+  G.n_prior = (int)npr; G.pr_pose = d_pr_pose.d; G.pr_z = d_pr_z.d; G.pr_sigma = d_pr_sigma.d; G.pr_r = d_pr_r.d;
+  G.n_between = (int)nbt; G.bt_i = d_bt_i.d; G.bt_j = d_bt_j.d; G.bt_z = d_bt_z.d; G.bt_sigma = d_bt_sigma.d;
+  G.bt_r = d_bt_r.d; G.bt_J0 = d_bt_J0.d;
+  G.n_lf = (int)nlf; G.lf_type = d_lf_type.d; G.lf_pose = d_lf_pose.d; G.lf_lm = d_lf_lm.d; G.lf_slot = d_lf_slot.d;
+  G.lf_joff = d_lf_joff.d; G.lf_eoff = d_lf_eoff.d;
+  G.br_z = d_br_z.d; G.cu_z = d_cu_z.d; G.cu_sigma = d_cu_sigma.d; G.cy_z = d_cy_z.d;
+  G.jbuf = d_jbuf.d; G.ebuf = d_ebuf.d;
+  G.lm_ptr = d_lm_ptr.d; G.lm_fids = d_lm_fids.d; G.pose_ptr = d_pose_ptr.d; G.pose_fids = d_pose_fids.d;
+  G.pose_bt_ptr = d_pose_bt_ptr.d; G.pose_bt = d_pose_bt.d;
+  G.lm_Hinv = d_lm_Hinv.d; G.lm_g = d_lm_g.d; G.pose_H = d_pose_H.d; G.pose_g = d_pose_g.d;
+  G.S = d_S.d; G.ld = (Tcap + 1) * NB; G.T = T; G.W = d_W.d; G.yv = d_yv.d; G.dp = d_dp.d;
+  G.status = d_status.d;
+  G.chart = P.pose_chart;
+  G.bearing_sigma = P.bearing_range_sigma; G.cyl_sigma = P.cylinder_sigma; G.numdiff_delta = P.numdiff_delta;
+  return SLIDE_OK;
+}
+
+int HostGraph::run_update(double relin_thr, int iterations) {
+  hipStream_t s = stream;
+  if (G.P == 0) return SLIDE_OK;
+  G.relin_thr = relin_thr;
+  SL_HIP(hipMemsetAsync(d_status.d, 0, 8 * sizeof(int), s));
+  static const char* kNames[] = {"relin", "linearize", "landmark_reduce", "pose_reduce", "schur_assemble", "chol_diag",
+                                 "chol_panel", "chol_update", "chol_extract_y", "chol_bwd", "backsub", "estimate"};
+  int id[12];
+  for (int i = 0; i < 12; ++i) id[i] = prof.id_of(kNames[i]);
+#define STAGE(i, call) do { prof.begin(id[i], s); call; prof.end(s); } while (0)
+  for (int it = 0; it < iterations; ++it) {
+    STAGE(0, launch_relin(G, s));
+    STAGE(1, launch_linearize(G, s));
+    STAGE(2, launch_landmark(G, s));
+    STAGE(3, launch_pose(G, s));
+    STAGE(4, launch_schur(G, s));
+    for (int k = 0; k < G.T; ++k) {
+      double* Wk = G.W + (size_t)k * NB * NB;
+      STAGE(5, launch_chol_diag(G.S, G.ld, k, Wk, G.status, s));
+      STAGE(6, launch_chol_panel(G.S, G.ld, k, G.T, Wk, s));
+      STAGE(7, launch_chol_update(G.S, G.ld, k, G.T, s));
+    }
+    STAGE(8, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, s));
+    for (int k = G.T - 1; k >= 0; --k) STAGE(9, launch_chol_bwd(G.S, G.ld, k, G.W + (size_t)k * NB * NB, G.yv, G.dp, s));
+    STAGE(10, launch_backsub(G, s));
+    STAGE(11, launch_estimate(G, s));
+  }
+#undef STAGE
+  int st[8];
+  SL_HIP(hipMemcpyAsync(st, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+  SL_HIP(hipStreamSynchronize(s));
+  SL_HIP(hipGetLastError());
+  if (prof.on) prof.collect();
+  last_relin = st[2];
+  if (st[0] || st[1]) {
+    g_last_error = st[0] ? "landmark block not positive definite" : "reduced pose system not positive definite";
+    return SLIDE_ERR_NOT_SPD;
+  }
+  return SLIDE_OK;
+}
+
+int HostGraph::solve() {
+  int rc = merge_pending();
+  if (rc != SLIDE_OK) return rc;
+  rc = upload_new();
+  if (rc != SLIDE_OK) return rc;
+  return run_update(P.relinearize_threshold, 1);
+}
+int HostGraph::gauss_newton(int iterations) {
+  int rc = merge_pending();
+  if (rc != SLIDE_OK) return rc;
+  rc = upload_new();
+  if (rc != SLIDE_OK) return rc;
+  return run_update(0.0, iterations);
+}
+
+int HostGraph::get_pose12(int robot, uint64_t idx, double* out12) {
+  SE3 I{eye3(), V3{0, 0, 0}};
+  to12(I, out12);
+  if (!robot_ok(robot)) return SLIDE_ERR_INVALID;
+  auto it = key2pose.find(pose_key(robot, idx));
+  if (it == key2pose.end() || (size_t)it->second >= up_P) return SLIDE_MISSING;
+  SL_HIP(hipMemcpyAsync(out12, d_pose_est.d + 12 * (size_t)it->second, 12 * sizeof(double), hipMemcpyDeviceToHost, stream));
+  SL_HIP(hipStreamSynchronize(stream));
+  return SLIDE_OK;
+}
+int HostGraph::lm_lid(int cls, uint64_t idx) const {
+  auto it = key2lm.find(lm_key(cls, idx));
+  if (it == key2lm.end() || (size_t)it->second >= up_L) return -1;
+  return it->second;
+}
+int HostGraph::get_landmark(int cls, uint64_t idx, double* out) {
+  const int n = cls == SLIDE_CLS_CYLINDER ? 7 : (cls == SLIDE_CLS_CUBE ? 15 : 3);
+  for (int i = 0; i < n; ++i) out[i] = 0.0;
+  const int lid = lm_lid(cls, idx);
+  if (lid < 0) return SLIDE_MISSING;
+  SL_HIP(hipMemcpyAsync(out, d_lm_est.d + 15 * (size_t)lid, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+  SL_HIP(hipStreamSynchronize(stream));
+  return SLIDE_OK;
+}
+void HostGraph::stats(int64_t* o) const {
+  o[0] = (int64_t)up_P; o[1] = (int64_t)up_L; o[2] = (int64_t)(up_pr + up_bt + up_lf); o[3] = last_relin;
+  o[4] = (int64_t)G.T * NB;
+}
+
+}  // namespace sl

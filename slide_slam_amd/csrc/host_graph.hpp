@@ -1,0 +1,155 @@
+// Host side of the device-resident factor graph: the SemanticFactorGraph seam of the reference
+// (backend/sloam/include/factorgraph/graph.h:70-121, src/factorgraph/graph.cpp) re-designed for one
+// MI355X: factors and variables are appended to SoA arrays in HBM, the host keeps only keys,
+// topology (CSR lists) and the pending fgraph / fvalues queues (graph.h:150-151).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/slide_gpu.h"
+#include "graph_dev.hpp"
+#include "kernels.hpp"
+#include "sl_math.hpp"
+
+namespace sl {
+
+extern thread_local std::string g_last_error;
+bool hip_ok(hipError_t e, const char* what);
+#define SL_HIP(x)                                     \
+  do {                                                \
+    if (!::sl::hip_ok((x), #x)) return SLIDE_ERR_HIP; \
+  } while (0)
+
+// growable device array; contents below `used` survive a growth
+template <class T>
+struct DevArr {
+  T* d = nullptr;
+  size_t cap = 0;
+  ~DevArr() { if (d) (void)hipFree(d); }
+  int ensure(size_t n, size_t used, hipStream_t s, bool zero_new = false) {
+    if (n <= cap) return SLIDE_OK;
+    size_t nc = cap ? cap : 1024;
+    while (nc < n) nc *= 2;
+    T* nd = nullptr;
+    SL_HIP(hipMalloc(&nd, nc * sizeof(T)));
+    if (zero_new) SL_HIP(hipMemsetAsync(nd, 0, nc * sizeof(T), s));
+    if (d && used) SL_HIP(hipMemcpyAsync(nd, d, used * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (d) {
+      SL_HIP(hipStreamSynchronize(s));
+      SL_HIP(hipFree(d));
+    }
+    d = nd;
+    cap = nc;
+    return SLIDE_OK;
+  }
+  int upload(const T* h, size_t off, size_t count, hipStream_t s) {
+    if (count == 0) return SLIDE_OK;
+    SL_HIP(hipMemcpyAsync(d + off, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+    return SLIDE_OK;
+  }
+};
+
+struct Profiler {
+  bool on = false;
+  struct Rec { int id; hipEvent_t a, b; };
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  std::vector<std::string> names;
+  std::vector<double> ms;
+  std::vector<int64_t> count;
+  int id_of(const char* name);
+  void begin(int id, hipStream_t s);
+  void end(hipStream_t s);
+  void collect();     // after a stream sync
+  void reset();
+  ~Profiler();
+};
+
+struct PendVar {
+  uint64_t key;
+  int type;
+  double val[15];
+};
+struct PendFac {
+  int type;          // 0 prior, 1 between, FT_BR, FT_CUBE, FT_CYL
+  uint64_t k0, k1;
+  double z[15];
+  double sigma[9];
+};
+
+class HostGraph {
+ public:
+  explicit HostGraph(const slide_params_t& p);
+  ~HostGraph();
+  int init();
+
+  // SemanticFactorGraph API (graph.cpp)
+  int set_prior(int robot, const double* pose7);
+  int add_keypose_between(int robot, uint64_t from, uint64_t to, const double* rel7, const double* est7);
+  int add_between_sigma(uint64_t k0, uint64_t k1, const SE3& rel, const double* sigma6);
+  int add_loop_closure(const double* rel7, uint64_t i1, int r1, uint64_t i2, int r2);
+  int add_relative_meas(const double* rel7, uint64_t i1, int r1, uint64_t i2, int r2);
+  int add_point_landmark(uint64_t idx, const double* xyz);
+  int add_range_bearing(int robot, uint64_t pose_idx, uint64_t lm_idx, const double* bearing, double range);
+  int add_cube(int robot, uint64_t pose_idx, uint64_t cube_idx, const SE3& pose, const SE3& cube_world, const double* scale,
+               bool exists);
+  int add_cylinder(int robot, uint64_t pose_idx, uint64_t cyl_idx, const SE3& pose, const double* root, const double* ray,
+                   double radius, bool exists);
+  int solve();                       // one iSAM2-equivalent update
+  int gauss_newton(int iterations);  // batch GN iterations (threshold 0)
+  int get_pose12(int robot, uint64_t idx, double* out12);   // SLIDE_MISSING + identity when absent
+  int get_landmark(int cls, uint64_t idx, double* out);
+  int lm_lid(int cls, uint64_t idx) const;                   // -1 when not merged yet
+  void stats(int64_t* out5) const;
+
+  static uint64_t pose_key(int robot, uint64_t idx);
+  static uint64_t lm_key(int cls, uint64_t idx);
+
+  slide_params_t P;
+  hipStream_t stream = nullptr;
+  std::mutex mtx;
+  Profiler prof;
+  GraphDev G{};
+
+ private:
+  int merge_pending();
+  int upload_new();
+  int run_update(double relin_thr, int iterations);
+
+  std::vector<PendVar> pend_vars;
+  std::vector<PendFac> pend_facs;
+  std::unordered_map<uint64_t, int> key2pose, key2lm;
+  // merged host mirrors (initial values; theta itself lives in HBM)
+  std::vector<double> h_pose_val, h_lm_val;
+  std::vector<int> h_lm_type;
+  std::vector<int> h_pr_pose; std::vector<double> h_pr_z, h_pr_sigma;
+  std::vector<int> h_bt_i, h_bt_j; std::vector<double> h_bt_z, h_bt_sigma;
+  std::vector<int> h_lf_type, h_lf_pose, h_lf_lm, h_lf_slot;
+  std::vector<int64_t> h_lf_joff, h_lf_eoff;
+  std::vector<double> h_br_z, h_cu_z, h_cu_sigma, h_cy_z;
+  int64_t jbuf_used = 0, ebuf_used = 0;
+  std::vector<std::vector<int>> lm_fids, pose_fids, pose_bt;
+  size_t up_P = 0, up_L = 0, up_pr = 0, up_bt = 0, up_lf = 0, up_br = 0, up_cu = 0, up_cy = 0;
+  int last_relin = 0;
+
+  DevArr<double> d_pose_val, d_pose_delta, d_pose_est, d_lm_val, d_lm_delta, d_lm_est;
+  DevArr<int> d_lm_type;
+  DevArr<int> d_pr_pose; DevArr<double> d_pr_z, d_pr_sigma, d_pr_r;
+  DevArr<int> d_bt_i, d_bt_j; DevArr<double> d_bt_z, d_bt_sigma, d_bt_r, d_bt_J0;
+  DevArr<int> d_lf_type, d_lf_pose, d_lf_lm, d_lf_slot;
+  DevArr<int64_t> d_lf_joff, d_lf_eoff;
+  DevArr<double> d_br_z, d_cu_z, d_cu_sigma, d_cy_z, d_jbuf, d_ebuf;
+  DevArr<int> d_lm_ptr, d_lm_fids, d_pose_ptr, d_pose_fids, d_pose_bt_ptr, d_pose_bt;
+  DevArr<double> d_lm_Hinv, d_lm_g, d_pose_H, d_pose_g;
+  DevArr<double> d_S, d_W, d_yv, d_dp;
+  DevArr<int> d_status;
+  int Tcap = 0;
+};
+
+}  // namespace sl

@@ -1,0 +1,75 @@
+// Launch wrappers of the HIP kernels (definitions in *_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "graph_dev.hpp"
+
+namespace sl {
+
+// solver_kernels.hip
+void launch_relin(const GraphDev& G, hipStream_t s);
+void launch_linearize(const GraphDev& G, hipStream_t s);
+void launch_landmark(const GraphDev& G, hipStream_t s);
+void launch_pose(const GraphDev& G, hipStream_t s);
+void launch_schur(const GraphDev& G, hipStream_t s);
+void launch_backsub(const GraphDev& G, hipStream_t s);
+void launch_estimate(const GraphDev& G, hipStream_t s);
+
+// chol_kernels.hip — blocked right-looking FP64 Cholesky of the (T*NB)^2 lower matrix S (column-major,
+// leading dimension ld = (T+1)*NB; the extra row tile carries the right-hand side), tile edge NB = 64.
+void launch_chol_diag(double* S, int ld, int k, double* W, int* status, hipStream_t s);
+void launch_chol_panel(double* S, int ld, int k, int T, const double* W, hipStream_t s);
+void launch_chol_update(double* S, int ld, int k, int T, hipStream_t s);
+void launch_chol_extract_y(const double* S, int ld, int T, double* yv, hipStream_t s);
+void launch_chol_bwd(const double* S, int ld, int k, const double* W, double* yv, double* dp, hipStream_t s);
+// stand-alone dense SPD solve on device buffers (used by the unit tests and the roofline bench leg)
+int chol_factor_solve(double* S, int ld, int T, double* W, double* yv, double* dp, int* status, hipStream_t s);
+
+// assoc_kernels.hip
+struct AssocFrameDev {
+  // map of one class, resident in HBM
+  const float* cloud;        // 3 n   first-seen float32 positions (K-NN gate)
+  const double* model;       // cyl: 7 n (root ray radius) ; box: 3 n (xyz)
+  const int32_t* label;      // n
+  int n;
+  int K;
+  double thresh;
+  double best_init;          // sloam.cpp:90 / :128,136 / :176,180
+  int label_gate;            // 0 none (cubes), 1 skip unless equal (ellipsoids), 2 distance = 1000 (cylinders)
+  int is_cyl;
+  // detections of this frame (body frame) and the pose estimate
+  const double* det;         // cyl: 7 per (root ray radius) ; box: pose12 (R t) per detection
+  const int32_t* det_label;
+  int n_det;
+  // outputs
+  double* det_world;         // same layout as det
+  int32_t* match_sub;        // submap index or -1
+  int32_t* match_map;        // map index or -1
+  int32_t* submap;           // K entries: map indices nearest first (matchesMap_)
+  int32_t* n_sub;            // 1
+};
+void launch_assoc_frame(const AssocFrameDev* classes3, const double* pose12, int* status, hipStream_t s);
+void launch_assoc_sweep(const float* cloud, const double* model_xyz, const int32_t* label, int n_map,
+                        const double* query_pos, const double* obs_xyz, const int32_t* obs_label, int n_query,
+                        int n_obs, int K, double thresh, int32_t* out_map_idx, hipStream_t s);
+void launch_map_refresh(double* cyl_model, int n_cyl, const int* cyl_lid, double* cube_xyz, int n_cube, const int* cube_lid,
+                        double* ell_xyz, int n_ell, const int* ell_lid, const double* lm_est, hipStream_t s);
+constexpr int ASSOC_MAX_N = 16384;
+
+// place_kernels.hip
+struct PlaceDev {
+  const double* ref7; int nr;
+  const double* qry7; int nq;
+  const double* xs; const double* ys; const double* yaws;   // candidate lattice values
+  const int32_t* cell_x; const int32_t* cell_y;             // per cell indices into xs / ys
+  long long n_cells; int n_yaw;
+  double thr_pos, thr_dim; int ignore_dim;
+  int32_t* inliers;                                         // n_cells * n_yaw
+};
+void launch_place_sweep(const PlaceDev& P, hipStream_t s);
+void launch_place_argmax(const int32_t* inliers, long long n, long long* best_idx, int32_t* best_val, hipStream_t s);
+void launch_clipper_affinity(const double* D1, const double* D2, int dim, const int32_t* A, int m, double sigma, double eps,
+                             double mindist, double affinityeps, double* M, hipStream_t s);
+
+}  // namespace sl

@@ -1,0 +1,139 @@
+// Inter-robot map-to-map association kernels.
+//   SlideMatch sweep: PlaceRecognition::MatchMaps (backend/sloam/src/core/place_recognition.cpp:98-387) —
+//   the exhaustive (x, y, yaw) lattice of label-gated inlier counting.  One wavefront per candidate
+//   transform; lanes own query objects and scan the reference map (staged in LDS, every lane reads the
+//   same entry -> LDS broadcast) in order with the reference's first-hit break; the lattice is
+//   produced on the host by the reference's own repeated-addition loops so every candidate value is
+//   bit-identical.  FP64 vector ALU / LDS bound: the maps are a few KB, HBM traffic is negligible.
+//   CLIPPER affinity: CLIPPER::scorePairwiseConsistency (clipper_semantic_object/src/clipper.cpp:21-65).
+// Compiled with -ffp-contract=off (threshold comparisons must round like the reference's x86-64 build).
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace sl {
+
+// LDS image: ref objects as 6 doubles [label, x, y, d1, d2, d3]
+__global__ __launch_bounds__(256) void k_place_sweep(PlaceDev P, const double* __restrict__ cosv, const double* __restrict__ sinv) {
+  extern __shared__ double ref[];
+  for (int e = threadIdx.x; e < P.nr * 6; e += blockDim.x) {
+    const int k = e / 6, f = e % 6;
+    const int src = f == 0 ? 0 : (f <= 2 ? f : f + 1);   // label, x, y, (skip z), d1, d2, d3
+    ref[e] = P.ref7[7 * (size_t)k + src];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long ncand = P.n_cells * P.n_yaw;
+  for (long long cand = wave; cand < ncand; cand += nwaves) {
+    const long long cell = cand / P.n_yaw;
+    const int iy = (int)(cand % P.n_yaw);
+    const double x = P.xs[P.cell_x[cell]], y = P.ys[P.cell_y[cell]];
+    const double c = cosv[iy], s = sinv[iy];
+    int inl = 0;
+    for (int j = lane; j < P.nq; j += 64) {
+      const double* q = P.qry7 + 7 * (size_t)j;
+      const double ql = q[0];
+      double tx = c * q[1] + (-s) * q[2] + x * 1.0;
+      double ty = s * q[1] + c * q[2] + y * 1.0;
+      const double tw = 0.0 * q[1] + 0.0 * q[2] + 1.0 * 1.0;
+      tx = tx / tw; ty = ty / tw;
+      for (int k = 0; k < P.nr; ++k) {
+        const double* m = ref + 6 * k;
+        if (m[0] != ql) continue;
+        const double xd = m[1] - tx, yd = m[2] - ty;
+        double avg = 0;
+        if (m[4] == 0 && m[5] == 0) {
+          avg = fabs(m[3] - q[4]);
+        } else {
+          avg += fabs(m[3] - q[4]);
+          avg += fabs(m[4] - q[5]);
+          avg += fabs(m[5] - q[6]);
+          avg /= 3;
+        }
+        const bool dist_ok = sqrt(xd * xd + yd * yd) < P.thr_pos;
+        const bool dim_ok = P.ignore_dim ? true : (avg < P.thr_dim);
+        if (dist_ok && dim_ok) { ++inl; break; }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) inl += __shfl_xor(inl, off);
+    if (lane == 0) P.inliers[cand] = inl;
+  }
+}
+
+// first index of the maximum (the reference keeps a candidate only when it has STRICTLY more inliers)
+__global__ __launch_bounds__(256) void k_place_argmax(const int32_t* __restrict__ v, long long n, long long* best_idx,
+                                                      int32_t* best_val) {
+  __shared__ long long sidx[256];
+  __shared__ int sval[256];
+  int bv = INT32_MIN;
+  long long bi = -1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int x = v[i];
+    if (x > bv) { bv = x; bi = i; }
+  }
+  sval[threadIdx.x] = bv;
+  sidx[threadIdx.x] = bi;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) {
+      const int ov = sval[threadIdx.x + st];
+      const long long oi = sidx[threadIdx.x + st];
+      if (oi >= 0 && (ov > sval[threadIdx.x] || (ov == sval[threadIdx.x] && (sidx[threadIdx.x] < 0 || oi < sidx[threadIdx.x])))) {
+        sval[threadIdx.x] = ov;
+        sidx[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { best_idx[blockIdx.x] = sidx[0]; best_val[blockIdx.x] = sval[0]; }
+}
+
+__global__ void k_clipper_affinity(const double* __restrict__ D1, const double* __restrict__ D2, int dim, const int32_t* __restrict__ A,
+                                   int m, double sigma, double eps, double mindist, double affinityeps, double* __restrict__ M) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= m || i >= m) return;
+  double out = 0.0;
+  if (j > i && A[2 * i] != A[2 * j] && A[2 * i + 1] != A[2 * j + 1]) {
+    const double* ai = D1 + (size_t)A[2 * i] * dim;
+    const double* aj = D1 + (size_t)A[2 * j] * dim;
+    const double* bi = D2 + (size_t)A[2 * i + 1] * dim;
+    const double* bj = D2 + (size_t)A[2 * j + 1] * dim;
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < dim; ++k) {
+      s1 += (ai[k] - aj[k]) * (ai[k] - aj[k]);
+      s2 += (bi[k] - bj[k]) * (bi[k] - bj[k]);
+    }
+    const double l1 = sqrt(s1), l2 = sqrt(s2);
+    if (!(mindist > 0 && (l1 < mindist || l2 < mindist))) {
+      const double c = fabs(l1 - l2);
+      const double scr = (c < eps) ? exp(-0.5 * c * c / (sigma * sigma)) : 0.0;
+      if (scr > affinityeps) out = scr;
+    }
+  }
+  M[(size_t)i * m + j] = out;
+}
+
+void launch_place_sweep(const PlaceDev& P, hipStream_t s) {
+  // cos/sin tables ride behind the yaw table: yaws[n_yaw .. 3 n_yaw)
+  const double* cosv = P.yaws + P.n_yaw;
+  const double* sinv = P.yaws + 2 * (size_t)P.n_yaw;
+  const long long ncand = P.n_cells * P.n_yaw;
+  long long blocks = (ncand + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_place_sweep, dim3((unsigned)blocks), dim3(256), (size_t)P.nr * 6 * sizeof(double), s, P, cosv, sinv);
+}
+void launch_place_argmax(const int32_t* inliers, long long n, long long* best_idx, int32_t* best_val, hipStream_t s) {
+  hipLaunchKernelGGL(k_place_argmax, dim3(256), dim3(256), 0, s, inliers, n, best_idx, best_val);
+}
+void launch_clipper_affinity(const double* D1, const double* D2, int dim, const int32_t* A, int m, double sigma, double eps,
+                             double mindist, double affinityeps, double* M, hipStream_t s) {
+  hipLaunchKernelGGL(k_clipper_affinity, dim3((m + 127) / 128, m), dim3(128), 0, s, D1, D2, dim, A, m, sigma, eps, mindist,
+                     affinityeps, M);
+}
+
+}  // namespace sl

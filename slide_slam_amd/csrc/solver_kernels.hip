@@ -1,0 +1,545 @@
+// Hand-written gfx950 kernels for the factor-graph update of the SlideSLAM backend
+// (reference: SemanticFactorGraph::solve backend/sloam/src/factorgraph/graph.cpp:260-272 ->
+// gtsam::ISAM2::update; factor definitions graph.cpp:24-258, cubeFactor.cpp:17-53,
+// cylinderFactor.cpp:20-51).  These kernels are HBM/L2-bound gather + small-block arithmetic in
+// FP64; the matrix-core work lives in chol_kernels.hip.  All reductions are gathers in a fixed
+// order (no floating-point atomics) so results are bit-stable run to run.
+#include <hip/hip_runtime.h>
+
+#include "graph_dev.hpp"
+#include "kernels.hpp"
+#include "sl_math.hpp"
+
+namespace sl {
+
+// ------------------------------------------------------------------------------------------------
+// variable (+) tangent, per variable type
+// ------------------------------------------------------------------------------------------------
+__device__ inline void pose_retract12(const double* in12, const double* d6, int chart, double* out12) {
+  to12(retract(from12(in12), d6, chart), out12);
+}
+__device__ inline void lm_retract(int type, const double* in, const double* d, int chart, double* out) {
+  if (type == VT_POINT) {
+    out[0] = in[0] + d[0]; out[1] = in[1] + d[1]; out[2] = in[2] + d[2];
+  } else if (type == VT_CUBE) {  // CubeMeasurement::retract cubeFactor.h:95-114
+    pose_retract12(in, d, chart, out);
+    out[12] = in[12] + d[6]; out[13] = in[13] + d[7]; out[14] = in[14] + d[8];
+  } else {  // CylinderMeasurement::retract cylinderFactor.h:59-64: tangent [ray, root, radius]
+    out[3] = in[3] + d[0]; out[4] = in[4] + d[1]; out[5] = in[5] + d[2];
+    out[0] = in[0] + d[3]; out[1] = in[1] + d[4]; out[2] = in[2] + d[5];
+    out[6] = in[6] + d[6];
+  }
+}
+
+// [GTSAM ISAM2 relinearisation] theta <- theta (+) delta where |delta|_inf >= threshold
+__global__ void k_relin(GraphDev G) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < G.P) {
+    double mx = 0.0;
+    for (int k = 0; k < 6; ++k) mx = fmax(mx, fabs(G.pose_delta[6 * t + k]));
+    if (mx >= G.relin_thr) {
+      double o[12];
+      pose_retract12(G.pose_val + 12 * (size_t)t, G.pose_delta + 6 * (size_t)t, G.chart, o);
+      for (int k = 0; k < 12; ++k) G.pose_val[12 * (size_t)t + k] = o[k];
+      atomicAdd(&G.status[2], 1);
+    }
+  } else if (t < G.P + G.L) {
+    const int l = t - G.P;
+    const int type = G.lm_type[l];
+    const int d = lm_dim(type);
+    double mx = 0.0;
+    for (int k = 0; k < d; ++k) mx = fmax(mx, fabs(G.lm_delta[9 * (size_t)l + k]));
+    if (mx >= G.relin_thr) {
+      double o[15];
+      lm_retract(type, G.lm_val + 15 * (size_t)l, G.lm_delta + 9 * (size_t)l, G.chart, o);
+      const int nv = type == VT_POINT ? 3 : (type == VT_CUBE ? 15 : 7);
+      for (int k = 0; k < nv; ++k) G.lm_val[15 * (size_t)l + k] = o[k];
+      atomicAdd(&G.status[2], 1);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// prior / between factors   [GTSAM PriorFactor / BetweenFactor<Pose3>]
+// ------------------------------------------------------------------------------------------------
+__global__ void k_lin_pose_factors(GraphDev G) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < G.n_prior) {
+    // r = -Local(x, prior), J = I
+    const SE3 X = from12(G.pose_val + 12 * (size_t)G.pr_pose[t]);
+    const SE3 Z = from12(G.pr_z + 12 * (size_t)t);
+    double l[6];
+    local(X, Z, l, G.chart);
+    for (int k = 0; k < 6; ++k) G.pr_r[6 * t + k] = -l[k] / G.pr_sigma[6 * t + k];
+  } else if (t < G.n_prior + G.n_between) {
+    const int b = t - G.n_prior;
+    const SE3 X1 = from12(G.pose_val + 12 * (size_t)G.bt_i[b]);
+    const SE3 X2 = from12(G.pose_val + 12 * (size_t)G.bt_j[b]);
+    const SE3 Z = from12(G.bt_z + 12 * (size_t)b);
+    const SE3 h = between(X1, X2);
+    double e[6];
+    local(Z, h, e, G.chart);          // r = Local(measured, x1^-1 x2)
+    double Ad[36];
+    adjoint(between(X2, X1), Ad);     // H1 = -Ad(h^-1), H2 = I
+    for (int r = 0; r < 6; ++r) {
+      const double w = 1.0 / G.bt_sigma[6 * b + r];
+      G.bt_r[6 * b + r] = e[r] * w;
+      for (int c = 0; c < 6; ++c) G.bt_J0[36 * (size_t)b + 6 * r + c] = -Ad[6 * r + c] * w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// landmark factors
+// ------------------------------------------------------------------------------------------------
+// CubeFactor::evaluateError cubeFactor.cpp:35:  [Logmap(C^-1 (X M)); s_meas - s_C]
+__device__ inline void cube_err(const SE3& X, const SE3& C, const double* cs, const double* z, double* e) {
+  const SE3 M = from12(z);
+  const SE3 err = compose(inverse(C), compose(X, M));
+  se3_log(err, e);
+  e[6] = z[12] - cs[0]; e[7] = z[13] - cs[1]; e[8] = z[14] - cs[2];
+}
+// CylinderFactor::evaluateError cylinderFactor.cpp:35: [q.ray - R ray ; q.root - X root ; radius_meas - q.radius]
+__device__ inline void cyl_err(const SE3& X, const double* q, const double* z, double* e) {
+  const V3 root = transform_from(X, V3{z[0], z[1], z[2]});
+  const V3 ray = mul(X.R, V3{z[3], z[4], z[5]});
+  e[0] = q[3] - ray.x; e[1] = q[4] - ray.y; e[2] = q[5] - ray.z;
+  e[3] = q[0] - root.x; e[4] = q[1] - root.y; e[5] = q[2] - root.z;
+  e[6] = z[6] - q[6];
+}
+
+__global__ void k_lin_lf(GraphDev G) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= G.n_lf) return;
+  const int type = G.lf_type[f];
+  const int p = G.lf_pose[f], l = G.lf_lm[f], slot = G.lf_slot[f];
+  double* out = G.jbuf + G.lf_joff[f];
+  const SE3 X = from12(G.pose_val + 12 * (size_t)p);
+  const double* lv = G.lm_val + 15 * (size_t)l;
+  if (type == FT_BR) {
+    // [GTSAM BearingRangeFactor<Pose3,Point3>] r = [sphere-local(z_b, b) ; rho - z_rho] / sigma
+    const double* z = G.br_z + 4 * (size_t)slot;
+    const double w = 1.0 / G.bearing_sigma;
+    const V3 q = transform_to(X, V3{lv[0], lv[1], lv[2]});
+    const double rho = norm(q);
+    const V3 b = (1.0 / rho) * q;
+    double e2[2];
+    sphere_local(V3{z[0], z[1], z[2]}, b, e2);
+    out[0] = e2[0] * w; out[1] = e2[1] * w; out[2] = (rho - z[3]) * w;
+    // D_q_pose = [hat(q), -I], D_q_point = R^T ; D_b_q = B(b)^T (I - b b^T)/rho ; D_rho_q = b^T
+    V3 b1, b2;
+    sphere_basis(b, b1, b2);
+    double Dm[9];
+    const double bb[3] = {b.x, b.y, b.z}, c1[3] = {b1.x, b1.y, b1.z}, c2[3] = {b2.x, b2.y, b2.z};
+    for (int j = 0; j < 3; ++j) {
+      double s1 = 0, s2 = 0;
+      for (int i = 0; i < 3; ++i) {
+        const double dn = ((i == j ? 1.0 : 0.0) - bb[i] * bb[j]) / rho;
+        s1 += c1[i] * dn; s2 += c2[i] * dn;
+      }
+      Dm[j] = s1; Dm[3 + j] = s2; Dm[6 + j] = bb[j];
+    }
+    const M3 Q = hat(q);
+    double* Jp = out + 3;
+    double* Jl = out + 21;
+    for (int r = 0; r < 3; ++r)
+      for (int j = 0; j < 3; ++j) {
+        double s = 0, u = 0;
+        for (int k = 0; k < 3; ++k) { s += Dm[3 * r + k] * Q.a[3 * k + j]; u += Dm[3 * r + k] * X.R.a[3 * j + k]; }
+        Jp[6 * r + j] = s * w;
+        Jp[6 * r + 3 + j] = -Dm[3 * r + j] * w;
+        Jl[3 * r + j] = u * w;
+      }
+  } else if (type == FT_CUBE) {
+    // numericalDerivative21/22 with delta = 1e-6 through the variables' own retract (cubeFactor.cpp:41-50)
+    const double* z = G.cu_z + 15 * (size_t)slot;
+    const double* sg = G.cu_sigma + 9 * (size_t)slot;
+    const SE3 C = from12(lv);
+    const double cs[3] = {lv[12], lv[13], lv[14]};
+    double hx[9], e1[9], e2[9];
+    cube_err(X, C, cs, z, hx);
+    for (int i = 0; i < 9; ++i) out[i] = hx[i] / sg[i];
+    double* Jp = out + 9;
+    double* Jl = out + 63;
+    const double dl = G.numdiff_delta, fac = 1.0 / (2.0 * dl);
+    for (int j = 0; j < 6; ++j) {
+      double dx[6] = {0, 0, 0, 0, 0, 0};
+      dx[j] = dl;
+      cube_err(retract(X, dx, G.chart), C, cs, z, e1);
+      dx[j] = -dl;
+      cube_err(retract(X, dx, G.chart), C, cs, z, e2);
+      for (int i = 0; i < 9; ++i) Jp[6 * i + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * fac / sg[i];
+    }
+    for (int j = 0; j < 9; ++j) {
+      if (j < 6) {
+        double dx[6] = {0, 0, 0, 0, 0, 0};
+        dx[j] = dl;
+        cube_err(X, retract(C, dx, G.chart), cs, z, e1);
+        dx[j] = -dl;
+        cube_err(X, retract(C, dx, G.chart), cs, z, e2);
+      } else {
+        double sp[3] = {cs[0], cs[1], cs[2]}, sm[3] = {cs[0], cs[1], cs[2]};
+        sp[j - 6] = cs[j - 6] + dl;
+        sm[j - 6] = cs[j - 6] + (-dl);
+        cube_err(X, C, sp, z, e1);
+        cube_err(X, C, sm, z, e2);
+      }
+      for (int i = 0; i < 9; ++i) Jl[9 * i + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * fac / sg[i];
+    }
+  } else {  // FT_CYL
+    const double* z = G.cy_z + 7 * (size_t)slot;
+    const double w = 1.0 / G.cyl_sigma;
+    double q[7];
+    for (int i = 0; i < 7; ++i) q[i] = lv[i];
+    double hx[7], e1[7], e2[7];
+    cyl_err(X, q, z, hx);
+    for (int i = 0; i < 7; ++i) out[i] = hx[i] * w;
+    double* Jp = out + 7;
+    double* Jl = out + 49;
+    const double dl = G.numdiff_delta, fac = 1.0 / (2.0 * dl);
+    for (int j = 0; j < 6; ++j) {
+      double dx[6] = {0, 0, 0, 0, 0, 0};
+      dx[j] = dl;
+      cyl_err(retract(X, dx, G.chart), q, z, e1);
+      dx[j] = -dl;
+      cyl_err(retract(X, dx, G.chart), q, z, e2);
+      for (int i = 0; i < 7; ++i) Jp[6 * i + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * fac * w;
+    }
+    for (int j = 0; j < 7; ++j) {
+      double d7[7] = {0, 0, 0, 0, 0, 0, 0}, qp[7], qm[7];
+      d7[j] = dl;
+      lm_retract(VT_CYL, q, d7, G.chart, qp);
+      d7[j] = -dl;
+      lm_retract(VT_CYL, q, d7, G.chart, qm);
+      cyl_err(X, qp, z, e1);
+      cyl_err(X, qm, z, e2);
+      for (int i = 0; i < 7; ++i) Jl[7 * i + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * fac * w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// landmark reduce: H_ll = sum Jl^T Jl, g_l = sum Jl^T r, H_ll^-1, and per factor
+// E = Jp^T Jl, F = E H_ll^-1, u = F g_l.   One thread per landmark, factors gathered in order.
+// ------------------------------------------------------------------------------------------------
+template <int D, int M>
+__device__ inline void landmark_body(const GraphDev& G, int l) {
+  double H[D * D], g[D];
+  for (int i = 0; i < D * D; ++i) H[i] = 0.0;
+  for (int i = 0; i < D; ++i) g[i] = 0.0;
+  const int f0 = G.lm_ptr[l], f1 = G.lm_ptr[l + 1];
+  for (int q = f0; q < f1; ++q) {
+    const int f = G.lm_fids[q];
+    const double* rec = G.jbuf + G.lf_joff[f];
+    const double* r = rec;
+    const double* Jl = rec + M + 6 * M;
+    for (int k = 0; k < M; ++k) {
+      double row[D];
+      for (int a = 0; a < D; ++a) row[a] = Jl[D * k + a];
+      const double rk = r[k];
+      for (int a = 0; a < D; ++a) {
+        g[a] += row[a] * rk;
+        for (int b = 0; b <= a; ++b) H[a * D + b] += row[a] * row[b];
+      }
+    }
+  }
+  double* Hinv = G.lm_Hinv + 81 * (size_t)l;
+  double* gout = G.lm_g + 9 * (size_t)l;
+  for (int a = 0; a < D; ++a) gout[a] = g[a];
+  if (f1 == f0) {
+    for (int i = 0; i < D * D; ++i) Hinv[i] = 0.0;
+    return;
+  }
+  // in-register Cholesky H = C C^T (lower), then Hinv = C^-T C^-1
+  bool ok = true;
+  for (int j = 0; j < D; ++j) {
+    double s = H[j * D + j];
+    for (int k = 0; k < j; ++k) s -= H[j * D + k] * H[j * D + k];
+    if (!(s > 0.0)) { ok = false; s = 1.0; }
+    const double dj = sqrt(s);
+    H[j * D + j] = dj;
+    for (int i = j + 1; i < D; ++i) {
+      double t = H[i * D + j];
+      for (int k = 0; k < j; ++k) t -= H[i * D + k] * H[j * D + k];
+      H[i * D + j] = t / dj;
+    }
+  }
+  if (!ok) atomicOr(&G.status[0], 1);
+  // Ci = C^-1 (lower) in place of the strict upper part's mirror: compute into Ci[]
+  double Ci[D * D];
+  for (int i = 0; i < D * D; ++i) Ci[i] = 0.0;
+  for (int c = 0; c < D; ++c) {
+    Ci[c * D + c] = 1.0 / H[c * D + c];
+    for (int i = c + 1; i < D; ++i) {
+      double s = 0.0;
+      for (int k = c; k < i; ++k) s -= H[i * D + k] * Ci[k * D + c];
+      Ci[i * D + c] = s / H[i * D + i];
+    }
+  }
+  double Hi[D * D];
+  for (int a = 0; a < D; ++a)
+    for (int b = 0; b <= a; ++b) {
+      double s = 0.0;
+      for (int k = a; k < D; ++k) s += Ci[k * D + a] * Ci[k * D + b];
+      Hi[a * D + b] = s;
+      Hi[b * D + a] = s;
+    }
+  for (int i = 0; i < D * D; ++i) Hinv[i] = Hi[i];
+  for (int q = f0; q < f1; ++q) {
+    const int f = G.lm_fids[q];
+    const double* rec = G.jbuf + G.lf_joff[f];
+    const double* Jp = rec + M;
+    const double* Jl = rec + M + 6 * M;
+    double* E = G.ebuf + G.lf_eoff[f];
+    double* F = E + 6 * D;
+    double* u = F + 6 * D;
+    for (int a = 0; a < 6; ++a) {
+      double Ea[D];
+      for (int c = 0; c < D; ++c) {
+        double s = 0.0;
+        for (int k = 0; k < M; ++k) s += Jp[6 * k + a] * Jl[D * k + c];
+        Ea[c] = s;
+        E[a * D + c] = s;
+      }
+      double ua = 0.0;
+      for (int c = 0; c < D; ++c) {
+        double s = 0.0;
+        for (int k = 0; k < D; ++k) s += Ea[k] * Hi[k * D + c];
+        F[a * D + c] = s;
+        ua += s * g[c];
+      }
+      u[a] = ua;
+    }
+  }
+}
+
+__global__ void k_landmark(GraphDev G) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= G.L) return;
+  const int type = G.lm_type[l];
+  if (type == VT_POINT) landmark_body<3, 3>(G, l);
+  else if (type == VT_CUBE) landmark_body<9, 9>(G, l);
+  else landmark_body<7, 7>(G, l);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pose reduce: H_pp (6x6) and the already-reduced gradient g_p - sum_f F_f g_l
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pose(GraphDev G) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= G.P) return;
+  double H[36], g[6];
+  for (int i = 0; i < 36; ++i) H[i] = 0.0;
+  for (int i = 0; i < 6; ++i) g[i] = 0.0;
+  for (int q = 0; q < G.n_prior; ++q) {
+    if (G.pr_pose[q] != p) continue;
+    for (int k = 0; k < 6; ++k) {
+      const double w = 1.0 / G.pr_sigma[6 * q + k];
+      H[7 * k] += w * w;
+      g[k] += w * G.pr_r[6 * q + k];
+    }
+  }
+  for (int q = G.pose_bt_ptr[p]; q < G.pose_bt_ptr[p + 1]; ++q) {
+    const int ent = G.pose_bt[q];
+    const int b = ent >> 1, role = ent & 1;
+    const double* r = G.bt_r + 6 * (size_t)b;
+    if (role == 1) {
+      for (int k = 0; k < 6; ++k) {
+        const double w = 1.0 / G.bt_sigma[6 * b + k];
+        H[7 * k] += w * w;
+        g[k] += w * r[k];
+      }
+    } else {
+      const double* J = G.bt_J0 + 36 * (size_t)b;
+      for (int k = 0; k < 6; ++k) {
+        for (int a = 0; a < 6; ++a) {
+          g[a] += J[6 * k + a] * r[k];
+          for (int c = 0; c < 6; ++c) H[6 * a + c] += J[6 * k + a] * J[6 * k + c];
+        }
+      }
+    }
+  }
+  for (int q = G.pose_ptr[p]; q < G.pose_ptr[p + 1]; ++q) {
+    const int f = G.pose_fids[q];
+    const int type = G.lf_type[f];
+    const int M = lf_rows(type), D = M;  // square landmark blocks: m == d for all three factor kinds
+    const double* rec = G.jbuf + G.lf_joff[f];
+    const double* Jp = rec + M;
+    for (int k = 0; k < M; ++k) {
+      const double rk = rec[k];
+      for (int a = 0; a < 6; ++a) {
+        const double ja = Jp[6 * k + a];
+        g[a] += ja * rk;
+        for (int c = 0; c < 6; ++c) H[6 * a + c] += ja * Jp[6 * k + c];
+      }
+    }
+    const double* u = G.ebuf + G.lf_eoff[f] + 12 * D;
+    for (int a = 0; a < 6; ++a) g[a] -= u[a];
+  }
+  for (int i = 0; i < 36; ++i) G.pose_H[36 * (size_t)p + i] = H[i];
+  for (int i = 0; i < 6; ++i) G.pose_g[6 * (size_t)p + i] = g[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Schur assemble: one thread per lower block (i >= j) of the reduced pose system
+//   S_ij = [i == j] H_pp,i + sum_between J_i^T J_j - sum_{l seen by i and j} F_fa E_fb^T
+// Co-observed landmarks are found by merging the two poses' landmark-sorted factor lists, so no
+// pair list is ever materialised and every block is written exactly once (S needs no memset).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_schur(GraphDev G) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long nb = (long long)G.P * (G.P + 1) / 2;
+  if (t >= nb) return;
+  long long i = (long long)floor((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (i * (i + 1) / 2 > t) --i;
+  while ((i + 1) * (i + 2) / 2 <= t) ++i;
+  const int pi = (int)i, pj = (int)(t - i * (i + 1) / 2);
+  double acc[36];
+  if (pi == pj) {
+    for (int k = 0; k < 36; ++k) acc[k] = G.pose_H[36 * (size_t)pi + k];
+  } else {
+    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+    for (int q = G.pose_bt_ptr[pi]; q < G.pose_bt_ptr[pi + 1]; ++q) {
+      const int ent = G.pose_bt[q];
+      const int b = ent >> 1, role = ent & 1;
+      const int other = role ? G.bt_i[b] : G.bt_j[b];
+      if (other != pj) continue;
+      const double* J = G.bt_J0 + 36 * (size_t)b;
+      if (role == 1) {   // pose i is the second key: J_i = diag(w), J_j = J0
+        for (int a = 0; a < 6; ++a) {
+          const double w = 1.0 / G.bt_sigma[6 * b + a];
+          for (int c = 0; c < 6; ++c) acc[6 * a + c] += w * J[6 * a + c];
+        }
+      } else {           // pose i is the first key: J_i = J0, J_j = diag(w)
+        for (int c = 0; c < 6; ++c) {
+          const double w = 1.0 / G.bt_sigma[6 * b + c];
+          for (int a = 0; a < 6; ++a) acc[6 * a + c] += J[6 * c + a] * w;
+        }
+      }
+    }
+  }
+  int a0 = G.pose_ptr[pi];
+  const int a1 = G.pose_ptr[pi + 1];
+  int b0 = G.pose_ptr[pj];
+  const int b1 = G.pose_ptr[pj + 1];
+  while (a0 < a1 && b0 < b1) {
+    const int la = G.lf_lm[G.pose_fids[a0]], lb = G.lf_lm[G.pose_fids[b0]];
+    if (la < lb) { ++a0; continue; }
+    if (lb < la) { ++b0; continue; }
+    int ae = a0, be = b0;
+    while (ae < a1 && G.lf_lm[G.pose_fids[ae]] == la) ++ae;
+    while (be < b1 && G.lf_lm[G.pose_fids[be]] == la) ++be;
+    const int D = lm_dim(G.lm_type[la]);
+    for (int x = a0; x < ae; ++x) {
+      const double* F = G.ebuf + G.lf_eoff[G.pose_fids[x]] + 6 * D;
+      for (int y = b0; y < be; ++y) {
+        const double* E = G.ebuf + G.lf_eoff[G.pose_fids[y]];
+        for (int a = 0; a < 6; ++a)
+          for (int c = 0; c < 6; ++c) {
+            double s = 0.0;
+            for (int k = 0; k < D; ++k) s += F[a * D + k] * E[c * D + k];
+            acc[6 * a + c] -= s;
+          }
+      }
+    }
+    a0 = ae; b0 = be;
+  }
+  double* S = G.S;
+  for (int c = 0; c < 6; ++c)
+    for (int a = 0; a < 6; ++a) S[(size_t)(6 * pj + c) * G.ld + 6 * pi + a] = acc[6 * a + c];
+}
+
+// padding (identity) between 6P and T*NB, and the RHS row (-g) at row T*NB
+__global__ void k_pad_rhs(GraphDev G) {
+  const int n = 6 * G.P, NT = G.T * NB;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < NT) {
+    const int c = (int)t;
+    G.S[(size_t)c * G.ld + NT] = (c < n) ? -G.pose_g[c] : 0.0;
+    return;
+  }
+  const long long u = t - NT;
+  const int npad = NT - n;
+  if (u >= (long long)npad * NT) return;
+  const int r = n + (int)(u / NT), c = (int)(u % NT);
+  if (c > r) return;
+  G.S[(size_t)c * G.ld + r] = (c == r) ? 1.0 : 0.0;
+}
+
+// landmark back-substitution  delta_l = -H_ll^-1 (g_l + sum_f E_f^T delta_p), and delta_p = dp
+__global__ void k_backsub(GraphDev G) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < G.P) {
+    for (int k = 0; k < 6; ++k) G.pose_delta[6 * (size_t)t + k] = G.dp[6 * (size_t)t + k];
+    return;
+  }
+  const int l = t - G.P;
+  if (l >= G.L) return;
+  const int D = lm_dim(G.lm_type[l]);
+  double rhs[9];
+  for (int k = 0; k < D; ++k) rhs[k] = G.lm_g[9 * (size_t)l + k];
+  for (int q = G.lm_ptr[l]; q < G.lm_ptr[l + 1]; ++q) {
+    const int f = G.lm_fids[q];
+    const double* E = G.ebuf + G.lf_eoff[f];
+    const double* d = G.dp + 6 * (size_t)G.lf_pose[f];
+    for (int k = 0; k < D; ++k) {
+      double s = 0.0;
+      for (int a = 0; a < 6; ++a) s += E[a * D + k] * d[a];
+      rhs[k] += s;
+    }
+  }
+  const double* Hi = G.lm_Hinv + 81 * (size_t)l;
+  for (int k = 0; k < D; ++k) {
+    double s = 0.0;
+    for (int c = 0; c < D; ++c) s += Hi[k * D + c] * rhs[c];
+    G.lm_delta[9 * (size_t)l + k] = -s;
+  }
+}
+
+// calculateEstimate(): theta (+) delta
+__global__ void k_estimate(GraphDev G) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < G.P) {
+    pose_retract12(G.pose_val + 12 * (size_t)t, G.pose_delta + 6 * (size_t)t, G.chart, G.pose_est + 12 * (size_t)t);
+  } else if (t < G.P + G.L) {
+    const int l = t - G.P;
+    lm_retract(G.lm_type[l], G.lm_val + 15 * (size_t)l, G.lm_delta + 9 * (size_t)l, G.chart, G.lm_est + 15 * (size_t)l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+void launch_relin(const GraphDev& G, hipStream_t s) {
+  if (G.P + G.L == 0) return;
+  hipLaunchKernelGGL(k_relin, dim3(blocks_for(G.P + G.L, 256)), dim3(256), 0, s, G);
+}
+void launch_linearize(const GraphDev& G, hipStream_t s) {
+  if (G.n_prior + G.n_between > 0)
+    hipLaunchKernelGGL(k_lin_pose_factors, dim3(blocks_for(G.n_prior + G.n_between, 128)), dim3(128), 0, s, G);
+  if (G.n_lf > 0) hipLaunchKernelGGL(k_lin_lf, dim3(blocks_for(G.n_lf, 128)), dim3(128), 0, s, G);
+}
+void launch_landmark(const GraphDev& G, hipStream_t s) {
+  if (G.L > 0) hipLaunchKernelGGL(k_landmark, dim3(blocks_for(G.L, 64)), dim3(64), 0, s, G);
+}
+void launch_pose(const GraphDev& G, hipStream_t s) {
+  if (G.P > 0) hipLaunchKernelGGL(k_pose, dim3(blocks_for(G.P, 64)), dim3(64), 0, s, G);
+}
+void launch_schur(const GraphDev& G, hipStream_t s) {
+  const long long nb = (long long)G.P * (G.P + 1) / 2;
+  if (nb == 0) return;
+  hipLaunchKernelGGL(k_schur, dim3(blocks_for(nb, 128)), dim3(128), 0, s, G);
+  const long long NT = (long long)G.T * NB;
+  const long long tot = NT + (NT - 6LL * G.P) * NT;
+  hipLaunchKernelGGL(k_pad_rhs, dim3(blocks_for(tot, 256)), dim3(256), 0, s, G);
+}
+void launch_backsub(const GraphDev& G, hipStream_t s) {
+  if (G.P + G.L == 0) return;
+  hipLaunchKernelGGL(k_backsub, dim3(blocks_for(G.P + G.L, 128)), dim3(128), 0, s, G);
+}
+void launch_estimate(const GraphDev& G, hipStream_t s) {
+  if (G.P + G.L == 0) return;
+  hipLaunchKernelGGL(k_estimate, dim3(blocks_for(G.P + G.L, 256)), dim3(256), 0, s, G);
+}
+
+}  // namespace sl

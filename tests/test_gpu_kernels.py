@@ -1,0 +1,104 @@
+"""GPU parity tests of the individual kernels, through the C-ABI, against the oracle / numpy."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _spd(n, rng, cond=1e4):
+    Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    d = np.exp(rng.uniform(0, np.log(cond), n))
+    return (Q * d) @ Q.T
+
+
+@pytest.mark.parametrize("n", [6, 64, 65, 200, 1000])
+def test_dense_spd_solve(gpu, n):
+    """FP64-MFMA blocked Cholesky + substitutions vs numpy (fp64): relative 1e-9 on a cond-1e4 system."""
+    rng = np.random.default_rng(n)
+    A = _spd(n, rng)
+    b = rng.normal(size=n)
+    x, _ = gpu.dense_spd_solve(A, b)
+    ref = np.linalg.solve(A, b)
+    assert np.linalg.norm(x - ref) <= 1e-9 * np.linalg.norm(ref)
+
+
+def test_dense_spd_solve_rejects_indefinite(gpu):
+    A = np.eye(70)
+    A[40, 40] = -1.0
+    with pytest.raises(gpu.SlideError):
+        gpu.dense_spd_solve(A, np.ones(70))
+
+
+@pytest.mark.parametrize("n,K", [(1, 30), (29, 30), (700, 1000), (5000, 1000), (16384, 50)])
+def test_submap_knn_matches_oracle(gpu, n, K):
+    """Exact float32 K-NN gate: identical index lists (nearest first, ties by index)."""
+    rng = np.random.default_rng(n + K)
+    cloud = rng.uniform(-60, 60, (n, 3)).astype(np.float32)
+    if n > 10:
+        cloud[5] = cloud[3]          # exact distance tie
+    q = rng.uniform(-60, 60, 3)
+    got = gpu.submap_knn(cloud, q, K)
+    out = np.zeros(max(min(K, n), 1), np.int32)
+    k = po.lib().orc_knn_f32(cloud.ctypes.data_as(C.c_void_p), C.c_int(n), q.ctypes.data_as(C.c_void_p), C.c_int(K),
+                             out.ctypes.data_as(C.c_void_p))
+    assert k == len(got)
+    assert np.array_equal(got, out[:k])
+
+
+def test_knn_capacity_error(gpu):
+    cloud = np.zeros((16385, 3), np.float32)
+    with pytest.raises(gpu.SlideError):
+        gpu.submap_knn(cloud, np.zeros(3), 10)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("cls", [1, 2])
+@pytest.mark.parametrize("n_cur,n_map", [(0, 5), (7, 0), (20, 1000), (64, 333)])
+def test_match_boxes(gpu, cls, n_cur, n_map):
+    rng = np.random.default_rng(cls * 1000 + n_cur + n_map)
+    mxyz = rng.uniform(-20, 20, (n_map, 3))
+    mlab = rng.integers(1, 4, n_map).astype(np.int32)
+    xyz = rng.uniform(-20, 20, (n_cur, 3))
+    lab = rng.integers(1, 4, n_cur).astype(np.int32)
+    if n_cur and n_map:
+        k = min(n_cur, n_map) // 2
+        xyz[:k] = mxyz[:k] + rng.normal(0, 0.2, (k, 3))      # true matches
+        lab[:k] = mlab[:k]
+        if n_map > 10:
+            mxyz[9] = mxyz[2]                                 # exact duplicate -> first index must win
+            mlab[9] = mlab[2]
+    thr = 2.0 if cls == 1 else 0.75
+    got = gpu.match_boxes(cls, xyz, lab, mxyz, mlab, thr)
+    exp = np.full(max(n_cur, 1), -1, np.int32)
+    po.lib().orc_match_boxes(C.c_int(cls), C.c_int(n_cur), _p(np.ascontiguousarray(xyz)), _p(lab), C.c_int(n_map),
+                             _p(np.ascontiguousarray(mxyz)), _p(mlab), C.c_double(thr), _p(exp))
+    assert np.array_equal(got, exp[:n_cur])
+
+
+@pytest.mark.parametrize("n_cur,n_map", [(0, 3), (5, 0), (12, 50), (40, 300)])
+def test_match_cylinders(gpu, n_cur, n_map):
+    rng = np.random.default_rng(n_cur * 7 + n_map)
+    mroot = np.column_stack([rng.uniform(-30, 30, (n_map, 2)), rng.normal(0, 0.3, n_map)])
+    mray = np.column_stack([rng.normal(0, 0.02, (n_map, 2)), np.ones(n_map)])
+    mlab = rng.integers(1, 3, n_map).astype(np.int32)
+    root = np.column_stack([rng.uniform(-30, 30, (n_cur, 2)), rng.normal(0, 0.3, n_cur)])
+    ray = np.column_stack([rng.normal(0, 0.02, (n_cur, 2)), np.ones(n_cur)])
+    lab = rng.integers(1, 3, n_cur).astype(np.int32)
+    if n_cur and n_map:
+        k = min(n_cur, n_map) // 2
+        root[:k] = mroot[:k] + rng.normal(0, 0.3, (k, 3))
+        lab[:k] = mlab[:k]
+    got = gpu.match_cylinders(root, ray, lab, mroot, mray, mlab, 2.0)
+    exp = np.full(max(n_cur, 1), -1, np.int32)
+    rad = np.zeros(max(n_cur, 1)); mrad = np.zeros(max(n_map, 1))
+    po.lib().orc_match_cylinders(C.c_int(n_cur), _p(np.ascontiguousarray(root)), _p(np.ascontiguousarray(ray)), _p(rad), _p(lab),
+                                 C.c_int(n_map), _p(np.ascontiguousarray(mroot)), _p(np.ascontiguousarray(mray)), _p(mrad),
+                                 _p(mlab), C.c_double(2.0), _p(exp))
+    assert np.array_equal(got, exp[:n_cur])
