@@ -283,6 +283,11 @@ int HostBackend::map_model(int cls, int idx, double* out, int* hits, int* label)
   SL_HIP(hipMemcpyAsync(out, M.d_model.d + (size_t)M.stride * idx, M.stride * sizeof(double), hipMemcpyDeviceToHost, g.stream));
   SL_HIP(hipStreamSynchronize(g.stream));
   if (cls != 0) for (int k = 0; k < 3; ++k) out[3 + k] = M.scale[3 * (size_t)idx + k];
+  if (cls == SLIDE_CLS_CUBE && (size_t)idx < M.up_lid) {
+    // updateCube (graphWrapper.cpp:245-249) also copies the optimised scale into the map model
+    double c15[15];
+    if (g.get_landmark(SLIDE_CLS_CUBE, (uint64_t)idx, c15) == SLIDE_OK) for (int k = 0; k < 3; ++k) out[3 + k] = c15[12 + k];
+  }
   *hits = M.hits[idx];
   *label = M.h_label[idx];
   return SLIDE_OK;

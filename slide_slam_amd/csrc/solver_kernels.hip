@@ -31,30 +31,58 @@ __device__ inline void lm_retract(int type, const double* in, const double* d, i
   }
 }
 
-// [GTSAM ISAM2 relinearisation] theta <- theta (+) delta where |delta|_inf >= threshold
+// [GTSAM ISAM2 relinearisation] theta <- theta (+) delta where |delta|_inf >= threshold.
+// Every private array below is indexed by fully unrolled loops only, so the kernel needs no scratch.
 __global__ void k_relin(GraphDev G) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < G.P) {
+    double d[6];
     double mx = 0.0;
-    for (int k = 0; k < 6; ++k) mx = fmax(mx, fabs(G.pose_delta[6 * t + k]));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { d[k] = G.pose_delta[6 * (size_t)t + k]; mx = fmax(mx, fabs(d[k])); }
     if (mx >= G.relin_thr) {
+      double* v = G.pose_val + 12 * (size_t)t;
       double o[12];
-      pose_retract12(G.pose_val + 12 * (size_t)t, G.pose_delta + 6 * (size_t)t, G.chart, o);
-      for (int k = 0; k < 12; ++k) G.pose_val[12 * (size_t)t + k] = o[k];
+      to12(retract(from12(v), d, G.chart), o);
+#pragma unroll
+      for (int k = 0; k < 12; ++k) v[k] = o[k];
       atomicAdd(&G.status[2], 1);
     }
   } else if (t < G.P + G.L) {
     const int l = t - G.P;
     const int type = G.lm_type[l];
-    const int d = lm_dim(type);
-    double mx = 0.0;
-    for (int k = 0; k < d; ++k) mx = fmax(mx, fabs(G.lm_delta[9 * (size_t)l + k]));
-    if (mx >= G.relin_thr) {
-      double o[15];
-      lm_retract(type, G.lm_val + 15 * (size_t)l, G.lm_delta + 9 * (size_t)l, G.chart, o);
-      const int nv = type == VT_POINT ? 3 : (type == VT_CUBE ? 15 : 7);
-      for (int k = 0; k < nv; ++k) G.lm_val[15 * (size_t)l + k] = o[k];
-      atomicAdd(&G.status[2], 1);
+    double* v = G.lm_val + 15 * (size_t)l;
+    const double* dl = G.lm_delta + 9 * (size_t)l;
+    if (type == VT_POINT) {
+      const double d0 = dl[0], d1 = dl[1], d2 = dl[2];
+      if (fmax(fmax(fabs(d0), fabs(d1)), fabs(d2)) >= G.relin_thr) {
+        v[0] += d0; v[1] += d1; v[2] += d2;
+        atomicAdd(&G.status[2], 1);
+      }
+    } else if (type == VT_CUBE) {
+      double d[9];
+      double mx = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { d[k] = dl[k]; mx = fmax(mx, fabs(d[k])); }
+      if (mx >= G.relin_thr) {
+        double o[12];
+        to12(retract(from12(v), d, G.chart), o);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) v[k] = o[k];
+        v[12] += d[6]; v[13] += d[7]; v[14] += d[8];
+        atomicAdd(&G.status[2], 1);
+      }
+    } else {
+      double d[7];
+      double mx = 0.0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) { d[k] = dl[k]; mx = fmax(mx, fabs(d[k])); }
+      if (mx >= G.relin_thr) {   // tangent order [ray, root, radius]
+        v[3] += d[0]; v[4] += d[1]; v[5] += d[2];
+        v[0] += d[3]; v[1] += d[4]; v[2] += d[5];
+        v[6] += d[6];
+        atomicAdd(&G.status[2], 1);
+      }
     }
   }
 }
@@ -62,7 +90,7 @@ __global__ void k_relin(GraphDev G) {
 // ------------------------------------------------------------------------------------------------
 // prior / between factors   [GTSAM PriorFactor / BetweenFactor<Pose3>]
 // ------------------------------------------------------------------------------------------------
-__global__ void k_lin_pose_factors(GraphDev G) {
+__global__ __launch_bounds__(128) void k_lin_pose_factors(GraphDev G) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < G.n_prior) {
     // r = -Local(x, prior), J = I
@@ -70,6 +98,7 @@ __global__ void k_lin_pose_factors(GraphDev G) {
     const SE3 Z = from12(G.pr_z + 12 * (size_t)t);
     double l[6];
     local(X, Z, l, G.chart);
+#pragma unroll
     for (int k = 0; k < 6; ++k) G.pr_r[6 * t + k] = -l[k] / G.pr_sigma[6 * t + k];
   } else if (t < G.n_prior + G.n_between) {
     const int b = t - G.n_prior;
@@ -81,9 +110,11 @@ __global__ void k_lin_pose_factors(GraphDev G) {
     local(Z, h, e, G.chart);          // r = Local(measured, x1^-1 x2)
     double Ad[36];
     adjoint(between(X2, X1), Ad);     // H1 = -Ad(h^-1), H2 = I
+#pragma unroll
     for (int r = 0; r < 6; ++r) {
       const double w = 1.0 / G.bt_sigma[6 * b + r];
       G.bt_r[6 * b + r] = e[r] * w;
+#pragma unroll
       for (int c = 0; c < 6; ++c) G.bt_J0[36 * (size_t)b + 6 * r + c] = -Ad[6 * r + c] * w;
     }
   }
@@ -108,7 +139,7 @@ __device__ inline void cyl_err(const SE3& X, const double* q, const double* z, d
   e[6] = z[6] - q[6];
 }
 
-__global__ void k_lin_lf(GraphDev G) {
+__global__ __launch_bounds__(128) void k_lin_lf(GraphDev G) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= G.n_lf) return;
   const int type = G.lf_type[f];
@@ -131,8 +162,10 @@ __global__ void k_lin_lf(GraphDev G) {
     sphere_basis(b, b1, b2);
     double Dm[9];
     const double bb[3] = {b.x, b.y, b.z}, c1[3] = {b1.x, b1.y, b1.z}, c2[3] = {b2.x, b2.y, b2.z};
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       double s1 = 0, s2 = 0;
+#pragma unroll
       for (int i = 0; i < 3; ++i) {
         const double dn = ((i == j ? 1.0 : 0.0) - bb[i] * bb[j]) / rho;
         s1 += c1[i] * dn; s2 += c2[i] * dn;
@@ -142,9 +175,12 @@ __global__ void k_lin_lf(GraphDev G) {
     const M3 Q = hat(q);
     double* Jp = out + 3;
     double* Jl = out + 21;
+#pragma unroll
     for (int r = 0; r < 3; ++r)
+#pragma unroll
       for (int j = 0; j < 3; ++j) {
         double s = 0, u = 0;
+#pragma unroll
         for (int k = 0; k < 3; ++k) { s += Dm[3 * r + k] * Q.a[3 * k + j]; u += Dm[3 * r + k] * X.R.a[3 * j + k]; }
         Jp[6 * r + j] = s * w;
         Jp[6 * r + 3 + j] = -Dm[3 * r + j] * w;
@@ -156,63 +192,66 @@ __global__ void k_lin_lf(GraphDev G) {
     const double* sg = G.cu_sigma + 9 * (size_t)slot;
     const SE3 C = from12(lv);
     const double cs[3] = {lv[12], lv[13], lv[14]};
-    double hx[9], e1[9], e2[9];
+    double hx[9], e1[9], e2[9], w[9];
     cube_err(X, C, cs, z, hx);
-    for (int i = 0; i < 9; ++i) out[i] = hx[i] / sg[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { w[i] = 1.0 / sg[i]; out[i] = hx[i] * w[i]; }
     double* Jp = out + 9;
     double* Jl = out + 63;
     const double dl = G.numdiff_delta, fac = 1.0 / (2.0 * dl);
     for (int j = 0; j < 6; ++j) {
-      double dx[6] = {0, 0, 0, 0, 0, 0};
-      dx[j] = dl;
-      cube_err(retract(X, dx, G.chart), C, cs, z, e1);
-      dx[j] = -dl;
-      cube_err(retract(X, dx, G.chart), C, cs, z, e2);
-      for (int i = 0; i < 9; ++i) Jp[6 * i + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * fac / sg[i];
+      double dp[6], dm[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { dp[k] = (k == j) ? dl : 0.0; dm[k] = (k == j) ? -dl : 0.0; }
+      cube_err(retract(X, dp, G.chart), C, cs, z, e1);
+      cube_err(retract(X, dm, G.chart), C, cs, z, e2);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Jp[6 * i + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * fac * w[i];
+      cube_err(X, retract(C, dp, G.chart), cs, z, e1);
+      cube_err(X, retract(C, dm, G.chart), cs, z, e2);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Jl[9 * i + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * fac * w[i];
     }
-    for (int j = 0; j < 9; ++j) {
-      if (j < 6) {
-        double dx[6] = {0, 0, 0, 0, 0, 0};
-        dx[j] = dl;
-        cube_err(X, retract(C, dx, G.chart), cs, z, e1);
-        dx[j] = -dl;
-        cube_err(X, retract(C, dx, G.chart), cs, z, e2);
-      } else {
-        double sp[3] = {cs[0], cs[1], cs[2]}, sm[3] = {cs[0], cs[1], cs[2]};
-        sp[j - 6] = cs[j - 6] + dl;
-        sm[j - 6] = cs[j - 6] + (-dl);
-        cube_err(X, C, sp, z, e1);
-        cube_err(X, C, sm, z, e2);
-      }
-      for (int i = 0; i < 9; ++i) Jl[9 * i + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * fac / sg[i];
+    for (int j = 0; j < 3; ++j) {
+      double sp[3], sm[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { sp[k] = cs[k] + ((k == j) ? dl : 0.0); sm[k] = cs[k] + ((k == j) ? -dl : 0.0); }
+      cube_err(X, C, sp, z, e1);
+      cube_err(X, C, sm, z, e2);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Jl[9 * i + 6 + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * fac * w[i];
     }
   } else {  // FT_CYL
     const double* z = G.cy_z + 7 * (size_t)slot;
     const double w = 1.0 / G.cyl_sigma;
     double q[7];
+#pragma unroll
     for (int i = 0; i < 7; ++i) q[i] = lv[i];
     double hx[7], e1[7], e2[7];
     cyl_err(X, q, z, hx);
+#pragma unroll
     for (int i = 0; i < 7; ++i) out[i] = hx[i] * w;
     double* Jp = out + 7;
     double* Jl = out + 49;
     const double dl = G.numdiff_delta, fac = 1.0 / (2.0 * dl);
     for (int j = 0; j < 6; ++j) {
-      double dx[6] = {0, 0, 0, 0, 0, 0};
-      dx[j] = dl;
-      cyl_err(retract(X, dx, G.chart), q, z, e1);
-      dx[j] = -dl;
-      cyl_err(retract(X, dx, G.chart), q, z, e2);
+      double dp[6], dm[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { dp[k] = (k == j) ? dl : 0.0; dm[k] = (k == j) ? -dl : 0.0; }
+      cyl_err(retract(X, dp, G.chart), q, z, e1);
+      cyl_err(retract(X, dm, G.chart), q, z, e2);
+#pragma unroll
       for (int i = 0; i < 7; ++i) Jp[6 * i + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * fac * w;
     }
     for (int j = 0; j < 7; ++j) {
-      double d7[7] = {0, 0, 0, 0, 0, 0, 0}, qp[7], qm[7];
-      d7[j] = dl;
-      lm_retract(VT_CYL, q, d7, G.chart, qp);
-      d7[j] = -dl;
-      lm_retract(VT_CYL, q, d7, G.chart, qm);
+      // CylinderMeasurement::retract: tangent [ray(3), root(3), radius] onto value [root, ray, radius]
+      const int vi = j < 3 ? j + 3 : (j < 6 ? j - 3 : 6);
+      double qp[7], qm[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) { qp[k] = q[k] + ((k == vi) ? dl : 0.0); qm[k] = q[k] + ((k == vi) ? -dl : 0.0); }
       cyl_err(X, qp, z, e1);
       cyl_err(X, qm, z, e2);
+#pragma unroll
       for (int i = 0; i < 7; ++i) Jl[7 * i + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * fac * w;
     }
   }
@@ -225,7 +264,9 @@ __global__ void k_lin_lf(GraphDev G) {
 template <int D, int M>
 __device__ inline void landmark_body(const GraphDev& G, int l) {
   double H[D * D], g[D];
+#pragma unroll
   for (int i = 0; i < D * D; ++i) H[i] = 0.0;
+#pragma unroll
   for (int i = 0; i < D; ++i) g[i] = 0.0;
   const int f0 = G.lm_ptr[l], f1 = G.lm_ptr[l + 1];
   for (int q = f0; q < f1; ++q) {
@@ -233,33 +274,43 @@ __device__ inline void landmark_body(const GraphDev& G, int l) {
     const double* rec = G.jbuf + G.lf_joff[f];
     const double* r = rec;
     const double* Jl = rec + M + 6 * M;
+#pragma unroll
     for (int k = 0; k < M; ++k) {
       double row[D];
+#pragma unroll
       for (int a = 0; a < D; ++a) row[a] = Jl[D * k + a];
       const double rk = r[k];
+#pragma unroll
       for (int a = 0; a < D; ++a) {
         g[a] += row[a] * rk;
+#pragma unroll
         for (int b = 0; b <= a; ++b) H[a * D + b] += row[a] * row[b];
       }
     }
   }
   double* Hinv = G.lm_Hinv + 81 * (size_t)l;
   double* gout = G.lm_g + 9 * (size_t)l;
+#pragma unroll
   for (int a = 0; a < D; ++a) gout[a] = g[a];
   if (f1 == f0) {
+#pragma unroll
     for (int i = 0; i < D * D; ++i) Hinv[i] = 0.0;
     return;
   }
   // in-register Cholesky H = C C^T (lower), then Hinv = C^-T C^-1
   bool ok = true;
+#pragma unroll
   for (int j = 0; j < D; ++j) {
     double s = H[j * D + j];
+#pragma unroll
     for (int k = 0; k < j; ++k) s -= H[j * D + k] * H[j * D + k];
     if (!(s > 0.0)) { ok = false; s = 1.0; }
     const double dj = sqrt(s);
     H[j * D + j] = dj;
+#pragma unroll
     for (int i = j + 1; i < D; ++i) {
       double t = H[i * D + j];
+#pragma unroll
       for (int k = 0; k < j; ++k) t -= H[i * D + k] * H[j * D + k];
       H[i * D + j] = t / dj;
     }
@@ -267,23 +318,31 @@ __device__ inline void landmark_body(const GraphDev& G, int l) {
   if (!ok) atomicOr(&G.status[0], 1);
   // Ci = C^-1 (lower) in place of the strict upper part's mirror: compute into Ci[]
   double Ci[D * D];
+#pragma unroll
   for (int i = 0; i < D * D; ++i) Ci[i] = 0.0;
+#pragma unroll
   for (int c = 0; c < D; ++c) {
     Ci[c * D + c] = 1.0 / H[c * D + c];
+#pragma unroll
     for (int i = c + 1; i < D; ++i) {
       double s = 0.0;
+#pragma unroll
       for (int k = c; k < i; ++k) s -= H[i * D + k] * Ci[k * D + c];
       Ci[i * D + c] = s / H[i * D + i];
     }
   }
   double Hi[D * D];
+#pragma unroll
   for (int a = 0; a < D; ++a)
+#pragma unroll
     for (int b = 0; b <= a; ++b) {
       double s = 0.0;
+#pragma unroll
       for (int k = a; k < D; ++k) s += Ci[k * D + a] * Ci[k * D + b];
       Hi[a * D + b] = s;
       Hi[b * D + a] = s;
     }
+#pragma unroll
   for (int i = 0; i < D * D; ++i) Hinv[i] = Hi[i];
   for (int q = f0; q < f1; ++q) {
     const int f = G.lm_fids[q];
@@ -293,17 +352,22 @@ __device__ inline void landmark_body(const GraphDev& G, int l) {
     double* E = G.ebuf + G.lf_eoff[f];
     double* F = E + 6 * D;
     double* u = F + 6 * D;
+#pragma unroll
     for (int a = 0; a < 6; ++a) {
       double Ea[D];
+#pragma unroll
       for (int c = 0; c < D; ++c) {
         double s = 0.0;
+#pragma unroll
         for (int k = 0; k < M; ++k) s += Jp[6 * k + a] * Jl[D * k + c];
         Ea[c] = s;
         E[a * D + c] = s;
       }
       double ua = 0.0;
+#pragma unroll
       for (int c = 0; c < D; ++c) {
         double s = 0.0;
+#pragma unroll
         for (int k = 0; k < D; ++k) s += Ea[k] * Hi[k * D + c];
         F[a * D + c] = s;
         ua += s * g[c];
@@ -313,7 +377,7 @@ __device__ inline void landmark_body(const GraphDev& G, int l) {
   }
 }
 
-__global__ void k_landmark(GraphDev G) {
+__global__ __launch_bounds__(64) void k_landmark(GraphDev G) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= G.L) return;
   const int type = G.lm_type[l];
@@ -325,14 +389,17 @@ __global__ void k_landmark(GraphDev G) {
 // ------------------------------------------------------------------------------------------------
 // pose reduce: H_pp (6x6) and the already-reduced gradient g_p - sum_f F_f g_l
 // ------------------------------------------------------------------------------------------------
-__global__ void k_pose(GraphDev G) {
+__global__ __launch_bounds__(64) void k_pose(GraphDev G) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= G.P) return;
   double H[36], g[6];
+#pragma unroll
   for (int i = 0; i < 36; ++i) H[i] = 0.0;
+#pragma unroll
   for (int i = 0; i < 6; ++i) g[i] = 0.0;
   for (int q = 0; q < G.n_prior; ++q) {
     if (G.pr_pose[q] != p) continue;
+#pragma unroll
     for (int k = 0; k < 6; ++k) {
       const double w = 1.0 / G.pr_sigma[6 * q + k];
       H[7 * k] += w * w;
@@ -344,6 +411,7 @@ __global__ void k_pose(GraphDev G) {
     const int b = ent >> 1, role = ent & 1;
     const double* r = G.bt_r + 6 * (size_t)b;
     if (role == 1) {
+#pragma unroll
       for (int k = 0; k < 6; ++k) {
         const double w = 1.0 / G.bt_sigma[6 * b + k];
         H[7 * k] += w * w;
@@ -351,9 +419,12 @@ __global__ void k_pose(GraphDev G) {
       }
     } else {
       const double* J = G.bt_J0 + 36 * (size_t)b;
+#pragma unroll
       for (int k = 0; k < 6; ++k) {
+#pragma unroll
         for (int a = 0; a < 6; ++a) {
           g[a] += J[6 * k + a] * r[k];
+#pragma unroll
           for (int c = 0; c < 6; ++c) H[6 * a + c] += J[6 * k + a] * J[6 * k + c];
         }
       }
@@ -367,16 +438,21 @@ __global__ void k_pose(GraphDev G) {
     const double* Jp = rec + M;
     for (int k = 0; k < M; ++k) {
       const double rk = rec[k];
+#pragma unroll
       for (int a = 0; a < 6; ++a) {
         const double ja = Jp[6 * k + a];
         g[a] += ja * rk;
+#pragma unroll
         for (int c = 0; c < 6; ++c) H[6 * a + c] += ja * Jp[6 * k + c];
       }
     }
     const double* u = G.ebuf + G.lf_eoff[f] + 12 * D;
+#pragma unroll
     for (int a = 0; a < 6; ++a) g[a] -= u[a];
   }
+#pragma unroll
   for (int i = 0; i < 36; ++i) G.pose_H[36 * (size_t)p + i] = H[i];
+#pragma unroll
   for (int i = 0; i < 6; ++i) G.pose_g[6 * (size_t)p + i] = g[i];
 }
 
@@ -386,7 +462,7 @@ __global__ void k_pose(GraphDev G) {
 // Co-observed landmarks are found by merging the two poses' landmark-sorted factor lists, so no
 // pair list is ever materialised and every block is written exactly once (S needs no memset).
 // ------------------------------------------------------------------------------------------------
-__global__ void k_schur(GraphDev G) {
+__global__ __launch_bounds__(128) void k_schur(GraphDev G) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long nb = (long long)G.P * (G.P + 1) / 2;
   if (t >= nb) return;
@@ -396,8 +472,10 @@ __global__ void k_schur(GraphDev G) {
   const int pi = (int)i, pj = (int)(t - i * (i + 1) / 2);
   double acc[36];
   if (pi == pj) {
+#pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = G.pose_H[36 * (size_t)pi + k];
   } else {
+#pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = 0.0;
     for (int q = G.pose_bt_ptr[pi]; q < G.pose_bt_ptr[pi + 1]; ++q) {
       const int ent = G.pose_bt[q];
@@ -406,13 +484,17 @@ __global__ void k_schur(GraphDev G) {
       if (other != pj) continue;
       const double* J = G.bt_J0 + 36 * (size_t)b;
       if (role == 1) {   // pose i is the second key: J_i = diag(w), J_j = J0
+#pragma unroll
         for (int a = 0; a < 6; ++a) {
           const double w = 1.0 / G.bt_sigma[6 * b + a];
+#pragma unroll
           for (int c = 0; c < 6; ++c) acc[6 * a + c] += w * J[6 * a + c];
         }
       } else {           // pose i is the first key: J_i = J0, J_j = diag(w)
+#pragma unroll
         for (int c = 0; c < 6; ++c) {
           const double w = 1.0 / G.bt_sigma[6 * b + c];
+#pragma unroll
           for (int a = 0; a < 6; ++a) acc[6 * a + c] += J[6 * c + a] * w;
         }
       }
@@ -434,7 +516,9 @@ __global__ void k_schur(GraphDev G) {
       const double* F = G.ebuf + G.lf_eoff[G.pose_fids[x]] + 6 * D;
       for (int y = b0; y < be; ++y) {
         const double* E = G.ebuf + G.lf_eoff[G.pose_fids[y]];
+#pragma unroll
         for (int a = 0; a < 6; ++a)
+#pragma unroll
           for (int c = 0; c < 6; ++c) {
             double s = 0.0;
             for (int k = 0; k < D; ++k) s += F[a * D + k] * E[c * D + k];
@@ -445,7 +529,9 @@ __global__ void k_schur(GraphDev G) {
     a0 = ae; b0 = be;
   }
   double* S = G.S;
+#pragma unroll
   for (int c = 0; c < 6; ++c)
+#pragma unroll
     for (int a = 0; a < 6; ++a) S[(size_t)(6 * pj + c) * G.ld + 6 * pi + a] = acc[6 * a + c];
 }
 
