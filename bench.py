@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py — pose-graph updates/s + ms per Gauss-Newton iteration of the SlideSLAM backend hot path on MI355X.
+
+A *step* is one pass of the hot path over the resident graph: relinearise every factor, assemble the
+landmark-eliminated (Schur) pose system, factor + solve it (FP64-MFMA Cholesky), back-substitute the
+landmarks and retract — i.e. one Gauss-Newton iteration = one pose-graph update
+(reference: SemanticFactorGraph::solve, backend/sloam/src/factorgraph/graph.cpp:260-272).
+
+Workload (BASELINE.json): the 8-robot / 10 k-landmark / 5 k-pose synthetic graph sharded one robot per GPU
+(configs[3]); at N GPUs the job is N robots of that graph (625 poses, ~1250 landmarks, ~12.5 k landmark
+factors each), so N = 8 is exactly configs[3] and N = 1 is one robot's shard.  Inputs are resident in
+HBM before the timed region.  Synthetic, seeded data (slide_slam_amd/synth.py).
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--preset C4shard] [--no-cpu] [--frames F]
+Multi-GPU: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak, public spec (MI355X_MICROARCH.md lists no f64 row)
+HBM_PEAK_GBS = 8000.0
+
+
+def build_graph(s, data, robot_log_idx, frames=None):
+    """Stream one robot's frame log through the per-frame path (association + add + iSAM2-equivalent update)."""
+    from slide_slam_amd.replay import replay_single
+    gb = s.SlideBackend(s.default_params(), 1)
+    out = replay_single(gb, data["logs"][robot_log_idx], n_frames=frames, collect=False)
+    return gb, out
+
+
+def cpu_baseline(data, robot_log_idx, frames, threads):
+    """The oracle (CPU restatement, C++ -O3 -march=native, `threads` OpenMP threads) timed on the same graph:
+    all frames are ingested without solving (association against the un-refined map), then ONE full
+    linearise + Schur + Cholesky + back-substitution pass is timed twice (second one = threshold 0)."""
+    from oracle import pyoracle as po
+    from slide_slam_amd.synth import frame_detections
+    L = po.lib(native=True)
+    ob = po.OracleBackend(po.OrcParams.default(num_threads=threads), 1, L=L)
+    log = data["logs"][robot_log_idx]
+    P = len(log["rel7"]) if frames is None else frames
+    gt = log["gt7"]
+    for k in range(P):
+        ob.process_frame(0, log["rel7"][k], gt[k], frame_detections(log, k), 2)
+    t0 = time.perf_counter()
+    st = ob.ingest_solve()
+    t1 = time.perf_counter()
+    ob.graph.set_relin_threshold(0.0)
+    st2 = ob.ingest_solve()
+    t2 = time.perf_counter()
+    stats = ob.graph.stats()
+    if st != 0 or st2 != 0:
+        raise RuntimeError("oracle solve failed")
+    per_iter = min(t1 - t0, t2 - t1)
+    return dict(value=1.0 / per_iter, unit="pose-graph updates/s", cores=threads, kind="port",
+                sample=f"2 full Gauss-Newton iterations of the same {stats['n_pose']}-pose / {stats['n_lm']}-landmark / "
+                       f"{stats['n_factors']}-factor graph (oracle = CPU restatement of the reference, not GTSAM), best of 2",
+                ms_per_iter=per_iter * 1e3, t_linearize_s=stats["t_linearize"], t_schur_s=stats["t_schur"],
+                t_chol_s=stats["t_chol"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preset", default="C4")
+    ap.add_argument("--frames", type=int, default=None, help="truncate each robot's log (debug)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+
+    import slide_slam_amd as s
+    from slide_slam_amd.synth import SynthConfig, make_robot_log, make_world
+    s.device_check()
+
+    cfg = SynthConfig.preset(args.preset)
+    # one robot per GPU: rank r replays robot r of the shared world (weak scaling; N = cfg.robots is the full config)
+    robot = rank % cfg.robots
+    world_map = make_world(cfg)
+    data = dict(cfg=cfg, world=world_map, logs={robot: make_robot_log(cfg, world_map, robot)})
+    t_b0 = time.perf_counter()
+    gb, rep = build_graph(s, data, robot, args.frames)
+    t_build = time.perf_counter() - t_b0
+    g = gb.graph
+    st = g.stats()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        g.gauss_newton(1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g.gauss_newton(1)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel device time (HIP events on the launch stream) over a separate profiled pass
+    g.set_profiling(True)
+    nprof = max(3, min(args.steps, 5))
+    for _ in range(nprof):
+        g.gauss_newton(1)
+    prof = g.get_profile()
+    g.set_profiling(False)
+
+    if rank == 0:
+        T = st["chol_dim"] // 64
+        n = st["chol_dim"]
+        # algorithmic FLOPs of the trailing updates of one factorisation (RHS row included): sum_k n_k^2 * 64
+        upd_flops = sum((((T - k - 1) * 64 + 1) ** 2) * 64.0 for k in range(T))
+        upd = prof.get("chol_update", dict(ms=0.0, launches=1))
+        upd_ms = upd["ms"] / max(upd["launches"], 1)
+        upd_launches_per_iter = upd["launches"] / nprof
+        flops_per_launch = upd_flops / max(upd_launches_per_iter, 1)
+        ach = flops_per_launch / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+        kernel_ms = {k: v["ms"] / nprof for k, v in prof.items()}
+        dominant = max(kernel_ms, key=kernel_ms.get)
+        res = {
+            "metric": "pose-graph updates/sec + ms/Gauss-Newton iter, 8-robot 10k-landmark graph",
+            "value": world * args.steps / dt,
+            "unit": "pose-graph updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_gn_iter": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (seeded, slide_slam_amd/synth.py)",
+            "config": {"workload": f"{cfg.name}: one robot sub-graph per GPU ({st['n_pose']} poses, {st['n_lm']} landmarks, "
+                                   f"{st['n_factors']} factors on rank 0); N=8 is BASELINE configs[3]",
+                       "robots": world, "reduced_system_dim": n, "chol_tile": 64},
+            "roofline": {"bound": "mfma", "kernel": "k_chol_update (v_mfma_f64_16x16x4_f64)", "achieved": ach,
+                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "flops_per_launch": flops_per_launch, "avg_launch_ms": upd_ms,
+                         "launches_per_iter": upd_launches_per_iter, "dominant_by_time": dominant},
+            "kernel_ms_per_iter": kernel_ms,
+            "stream_replay": {"frames": len(rep["t_frame"]), "updates_per_s": len(rep["t_frame"]) / max(sum(rep["t_frame"]), 1e-9),
+                              "ms_last_frame": rep["t_frame"][-1] * 1e3, "build_s": t_build},
+        }
+        if not args.no_cpu:
+            thr = args.cpu_threads or min(os.cpu_count() or 1, 16)
+            try:
+                res["cpu_baseline"] = cpu_baseline(data, robot, args.frames, thr)
+            except Exception as e:  # the GPU number stands on its own
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

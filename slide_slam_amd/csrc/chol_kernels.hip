@@ -23,57 +23,87 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 __device__ inline v4d mfma_f64(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ S, int ld, int k, double* __restrict__ W,
-                                                   int* status) {
-  __shared__ double A[NB][NB + 1];
-  __shared__ double Wm[NB][NB + 1];
-  __shared__ double lcol[NB];
-  __shared__ double wrow[NB];
-  const int tid = threadIdx.x;
-  double* base = S + (size_t)(k * NB) * ld + (size_t)k * NB;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int i = e % NB, j = e / NB;
-    A[i][j] = (i >= j) ? base[(size_t)j * ld + i] : 0.0;
-    Wm[i][j] = (i == j) ? 1.0 : 0.0;
-  }
-  __syncthreads();
-  for (int j = 0; j < NB; ++j) {
-    double d = A[j][j];
+// POTRF of one 64x64 diagonal block plus its explicit inverse W = L^-1, entirely in registers:
+// 256 threads as a 16x16 grid, thread (ti, tj) owns A[ti + 16p][tj + 16q] and W[..][..], p, q in 0..3.
+// Per column step the owners of column j (of A) and of row j (of W) publish them through a
+// double-buffered LDS vector; one barrier per step, no integer division, no scratch.
+template <int JQ>
+__device__ inline void diag_steps(double (&a)[4][4], double (&w)[4][4], double (*colraw)[NB], double (*wraw)[NB], int ti, int tj,
+                                  int* status) {
+#pragma unroll 1
+  for (int jt = 0; jt < 16; ++jt) {
+    const int j = 16 * JQ + jt;
+    const int buf = j & 1;
+    if (tj == jt) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) colraw[buf][ti + 16 * p] = a[p][JQ];
+    }
+    if (ti == jt) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wraw[buf][tj + 16 * q] = w[JQ][q];
+    }
+    __syncthreads();
+    double d = colraw[buf][j];
     if (!(d > 0.0)) {
-      if (tid == 0) atomicOr(&status[1], 1);
+      if (ti == 0 && tj == 0) atomicOr(&status[1], 1);
       d = 1.0;
     }
     const double inv = 1.0 / sqrt(d);
-    if (tid < NB) {
-      if (tid >= j) lcol[tid] = A[tid][j] * inv;
-    } else if (tid < 2 * NB) {
-      const int c = tid - NB;
-      if (c <= j) wrow[c] = Wm[j][c] * inv;
+    double li[4], lk[4], wr[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) li[p] = colraw[buf][ti + 16 * p] * inv;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { lk[q] = colraw[buf][tj + 16 * q] * inv; wr[q] = wraw[buf][tj + 16 * q] * inv; }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int i = ti + 16 * p;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = tj + 16 * q;
+        if (i > j && c > j && c <= i) a[p][q] -= li[p] * lk[q];   // trailing update
+        if (i > j && c <= j) w[p][q] -= li[p] * wr[q];            // forward substitution on the identity
+      }
     }
-    __syncthreads();
-    const int m = NB - 1 - j;
-    for (int e = tid; e < m * m; e += 256) {
-      const int i = j + 1 + e / m, kk = j + 1 + e % m;
-      if (kk <= i) A[i][kk] -= lcol[i] * lcol[kk];
+    if (tj == jt) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (ti + 16 * p >= j) a[p][JQ] = li[p];                   // column j of L is final
     }
-    const int w = j + 1;
-    for (int e = tid; e < m * w; e += 256) {
-      const int i = j + 1 + e / w, c = e % w;
-      Wm[i][c] -= lcol[i] * wrow[c];
+    if (ti == jt) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (tj + 16 * q <= j) w[JQ][q] = wr[q];                   // row j of W is final
     }
-    if (tid < NB) {
-      if (tid >= j) A[tid][j] = lcol[tid];
-    } else if (tid < 2 * NB) {
-      const int c = tid - NB;
-      if (c <= j) Wm[j][c] = wrow[c];
-    }
-    __syncthreads();
   }
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int i = e % NB, j = e / NB;
-    if (i >= j) base[(size_t)j * ld + i] = A[i][j];
-    W[(size_t)j * NB + i] = (i >= j) ? Wm[i][j] : 0.0;
-  }
+}
+
+__global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ S, int ld, int k, double* __restrict__ W,
+                                                   int* status) {
+  __shared__ double colraw[2][NB];
+  __shared__ double wraw[2][NB];
+  const int tid = threadIdx.x, ti = tid & 15, tj = tid >> 4;
+  double* base = S + (size_t)(k * NB) * ld + (size_t)k * NB;
+  double a[4][4], w[4][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = ti + 16 * p, c = tj + 16 * q;
+      a[p][q] = (i >= c) ? base[(size_t)c * ld + i] : 0.0;
+      w[p][q] = (i == c) ? 1.0 : 0.0;
+    }
+  diag_steps<0>(a, w, colraw, wraw, ti, tj, status);
+  diag_steps<1>(a, w, colraw, wraw, ti, tj, status);
+  diag_steps<2>(a, w, colraw, wraw, ti, tj, status);
+  diag_steps<3>(a, w, colraw, wraw, ti, tj, status);
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = ti + 16 * p, c = tj + 16 * q;
+      if (i >= c) base[(size_t)c * ld + i] = a[p][q];
+      W[(size_t)c * NB + i] = (i >= c) ? w[p][q] : 0.0;
+    }
 }
 
 // X = A_ik W^T  for every row tile below the diagonal block (incl. the RHS tile); 16 rows per wave.
@@ -147,29 +177,40 @@ __global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, do
   if (c < T * NB) yv[c] = S[(size_t)c * ld + (size_t)T * NB];
 }
 
-// backward substitution step k:  d_k = W_k^T y_k ;  y_c -= L[k-block, c]^T d_k  for every column c < k*NB
+// backward substitution step k:  d_k = W_k^T y_k ;  y_c -= L[k-block, c]^T d_k  for every column c < k*NB.
+// One workgroup per 64 columns: the 64x64 tile of L is read in whole 512-byte column runs and reduced
+// over rows through an LDS transpose (pad 1), 4 threads per column.
 __global__ __launch_bounds__(256) void k_chol_bwd(const double* __restrict__ S, int ld, int k, const double* __restrict__ W,
                                                   double* __restrict__ yv, double* __restrict__ dp) {
   __shared__ double yk[NB];
   __shared__ double dk[NB];
-  const int tid = threadIdx.x;
+  __shared__ double tile[NB][NB + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < NB) yk[tid] = yv[k * NB + tid];
   __syncthreads();
-  if (tid < NB) {
-    double s = 0.0;
-    const double* w = W + (size_t)tid * NB;   // column tid of W: W[r][tid], r >= tid
-    for (int r = tid; r < NB; ++r) s += w[r] * yk[r];
-    dk[tid] = s;
-    if (blockIdx.x == 0) dp[k * NB + tid] = s;
+  // d_k[c] = sum_r W[r][c] y[r],  W[r][c] at W[c*NB + r]: one wave per column, lanes over r
+  for (int c = wave; c < NB; c += 4) {
+    double v = W[(size_t)c * NB + lane] * yk[lane];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) {
+      dk[c] = v;
+      if (blockIdx.x == 0) dp[k * NB + c] = v;
+    }
+  }
+  const int c0 = blockIdx.x * NB;
+  if (c0 < k * NB) {
+    for (int cc = wave; cc < NB; cc += 4) tile[cc][lane] = S[(size_t)(c0 + cc) * ld + (size_t)k * NB + lane];
   }
   __syncthreads();
-  const int col = blockIdx.x * 256 + tid;
-  if (col < k * NB) {
-    const double* p = S + (size_t)col * ld + (size_t)k * NB;
+  if (c0 < k * NB) {
+    const int c = tid >> 2, part = tid & 3;
     double s = 0.0;
-#pragma unroll 8
-    for (int r = 0; r < NB; ++r) s += p[r] * dk[r];
-    yv[col] -= s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += tile[c][16 * part + r] * dk[16 * part + r];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (part == 0) yv[c0 + c] -= s;
   }
 }
 
@@ -190,8 +231,7 @@ void launch_chol_extract_y(const double* S, int ld, int T, double* yv, hipStream
   hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv);
 }
 void launch_chol_bwd(const double* S, int ld, int k, const double* W, double* yv, double* dp, hipStream_t s) {
-  const int nblk = (k * NB + 255) / 256;
-  hipLaunchKernelGGL(k_chol_bwd, dim3(nblk > 0 ? nblk : 1), dim3(256), 0, s, S, ld, k, W, yv, dp);
+  hipLaunchKernelGGL(k_chol_bwd, dim3(k > 0 ? k : 1), dim3(256), 0, s, S, ld, k, W, yv, dp);
 }
 
 int chol_factor_solve(double* S, int ld, int T, double* W, double* yv, double* dp, int* status, hipStream_t s) {

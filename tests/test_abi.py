@@ -1,0 +1,67 @@
+"""The C-ABI library loads on a GPU-less host and exports every symbol include/slide_gpu.h declares;
+compute entry points fail loudly (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import slide_slam_amd as s
+from slide_slam_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "slide_gpu.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(slide_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported():
+    L = s.lib()
+    declared = _header_functions()
+    assert len(declared) >= 40
+    missing = [f for f in declared if not hasattr(L, f)]
+    assert not missing, missing
+    assert sorted(api.EXPORTS) == declared
+
+
+def test_default_params_mirror_reference_defaults():
+    p = s.default_params()
+    assert p.relinearize_threshold == 0.1 and p.noise_floor == 0.01            # graph.cpp:17, graph.h:125
+    assert list(p.noise_model_prior_first_pose_vec) == [1e-6] * 6              # graphWrapper.cpp:31
+    assert list(p.noise_model_odom_vec) == [0.1] * 6 and list(p.noise_model_cube_vec) == [0.1] * 9
+    assert p.cylinder_sigma == 400.0 and p.bearing_range_sigma == 1.0          # graphWrapper.cpp:60,63
+    assert (p.cylinder_match_thresh, p.cuboid_match_thresh, p.ellipsoid_match_thresh) == (2.0, 2.0, 0.75)
+    assert (p.knn_cylinder, p.knn_cube, p.knn_ellipsoid) == (50, 30, 1000)
+    pp = s.place_default_params()
+    assert pp.search_xy_step_size == 0.5 and pp.min_num_inliers == 5 and pp.dilation_factor == 1.2
+
+
+def test_host_logic_closest_stamp():
+    """GetIndexClosestPoseMstPair (sloam.cpp:428-440) is host logic: usable without a device."""
+    assert s.closest_stamp([5, 15, 12], [0, 0, 0], 13, 500000000) == (1, 1.5)
+    assert s.closest_stamp([], [], 10, 0)[0] == -1
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(s.SlideError):
+        s.device_check()
+    with pytest.raises(s.SlideError):
+        s.SlideGraph(s.default_params())
+    with pytest.raises(s.SlideError):
+        s.dense_spd_solve(np.eye(4), np.ones(4))
+    with pytest.raises(s.SlideError):
+        s.submap_knn(np.zeros((4, 3), np.float32), np.zeros(3), 2)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "slide_slam_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in txt and "liboracle" not in txt and '#include "../oracle' not in txt, f
