@@ -145,7 +145,7 @@ class HostGraph {
   DevArr<int> d_lf_type, d_lf_pose, d_lf_lm, d_lf_slot;
   DevArr<int64_t> d_lf_joff, d_lf_eoff;
   DevArr<double> d_br_z, d_cu_z, d_cu_sigma, d_cy_z, d_jbuf, d_ebuf;
-  DevArr<int> d_lm_ptr, d_lm_fids, d_pose_ptr, d_pose_fids, d_pose_bt_ptr, d_pose_bt;
+  DevArr<int> d_lm_ptr, d_lm_fids, d_pose_ptr, d_pose_fids, d_pose_lms, d_pose_bt_ptr, d_pose_bt;
   DevArr<double> d_lm_Hinv, d_lm_g, d_pose_H, d_pose_g;
   DevArr<double> d_S, d_W, d_yv, d_dp;
   DevArr<int> d_status;

@@ -259,96 +259,110 @@ __global__ __launch_bounds__(128) void k_lin_lf(GraphDev G) {
 
 // ------------------------------------------------------------------------------------------------
 // landmark reduce: H_ll = sum Jl^T Jl, g_l = sum Jl^T r, H_ll^-1, and per factor
-// E = Jp^T Jl, F = E H_ll^-1, u = F g_l.   One thread per landmark, factors gathered in order.
-// ------------------------------------------------------------------------------------------------
-template <int D, int M>
-__device__ inline void landmark_body(const GraphDev& G, int l) {
-  double H[D * D], g[D];
+// E = Jp^T Jl, F = E H_ll^-1, u = F g_l.   One WAVEFRONT per landmark: lanes own factors, the D(D+1)/2 + D
+// partial sums meet in a fixed xor-shuffle tree (deterministic), every lane inverts H_ll redundantly in
+// registers, then each lane finishes its own factors.  (M == D for all three landmark factor kinds.)
+template <int D>
+__device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
+  constexpr int NH = D * (D + 1) / 2;
+  double h[NH], g[D];
 #pragma unroll
-  for (int i = 0; i < D * D; ++i) H[i] = 0.0;
+  for (int i = 0; i < NH; ++i) h[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < D; ++i) g[i] = 0.0;
-  const int f0 = G.lm_ptr[l], f1 = G.lm_ptr[l + 1];
-  for (int q = f0; q < f1; ++q) {
-    const int f = G.lm_fids[q];
+  const int f0 = G.lm_ptr[l], nf = G.lm_ptr[l + 1] - f0;
+  for (int q = lane; q < nf; q += 64) {
+    const int f = G.lm_fids[f0 + q];
     const double* rec = G.jbuf + G.lf_joff[f];
-    const double* r = rec;
-    const double* Jl = rec + M + 6 * M;
+    const double* Jl = rec + D + 6 * D;
 #pragma unroll
-    for (int k = 0; k < M; ++k) {
+    for (int k = 0; k < D; ++k) {
       double row[D];
 #pragma unroll
       for (int a = 0; a < D; ++a) row[a] = Jl[D * k + a];
-      const double rk = r[k];
+      const double rk = rec[k];
 #pragma unroll
       for (int a = 0; a < D; ++a) {
         g[a] += row[a] * rk;
 #pragma unroll
-        for (int b = 0; b <= a; ++b) H[a * D + b] += row[a] * row[b];
+        for (int c = 0; c <= a; ++c) h[a * (a + 1) / 2 + c] += row[a] * row[c];
       }
     }
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int i = 0; i < NH; ++i) h[i] += __shfl_xor(h[i], off);
+#pragma unroll
+    for (int i = 0; i < D; ++i) g[i] += __shfl_xor(g[i], off);
+  }
   double* Hinv = G.lm_Hinv + 81 * (size_t)l;
   double* gout = G.lm_g + 9 * (size_t)l;
+  if (lane == 0) {
 #pragma unroll
-  for (int a = 0; a < D; ++a) gout[a] = g[a];
-  if (f1 == f0) {
+    for (int a = 0; a < D; ++a) gout[a] = g[a];
+  }
+  if (nf == 0) {
+    if (lane == 0) {
 #pragma unroll
-    for (int i = 0; i < D * D; ++i) Hinv[i] = 0.0;
+      for (int i = 0; i < D * D; ++i) Hinv[i] = 0.0;
+    }
     return;
   }
-  // in-register Cholesky H = C C^T (lower), then Hinv = C^-T C^-1
+  // in-register Cholesky H = C C^T, then H^-1 = C^-T C^-1 (all lanes, identical)
+  double Cm[D][D];
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < D; ++j) {
-    double s = H[j * D + j];
+    double s = h[j * (j + 1) / 2 + j];
 #pragma unroll
-    for (int k = 0; k < j; ++k) s -= H[j * D + k] * H[j * D + k];
+    for (int k = 0; k < j; ++k) s -= Cm[j][k] * Cm[j][k];
     if (!(s > 0.0)) { ok = false; s = 1.0; }
     const double dj = sqrt(s);
-    H[j * D + j] = dj;
+    Cm[j][j] = dj;
 #pragma unroll
     for (int i = j + 1; i < D; ++i) {
-      double t = H[i * D + j];
+      double t = h[i * (i + 1) / 2 + j];
 #pragma unroll
-      for (int k = 0; k < j; ++k) t -= H[i * D + k] * H[j * D + k];
-      H[i * D + j] = t / dj;
+      for (int k = 0; k < j; ++k) t -= Cm[i][k] * Cm[j][k];
+      Cm[i][j] = t / dj;
     }
   }
-  if (!ok) atomicOr(&G.status[0], 1);
-  // Ci = C^-1 (lower) in place of the strict upper part's mirror: compute into Ci[]
-  double Ci[D * D];
-#pragma unroll
-  for (int i = 0; i < D * D; ++i) Ci[i] = 0.0;
+  if (!ok && lane == 0) atomicOr(&G.status[0], 1);
+  double Ci[D][D];
 #pragma unroll
   for (int c = 0; c < D; ++c) {
-    Ci[c * D + c] = 1.0 / H[c * D + c];
+    Ci[c][c] = 1.0 / Cm[c][c];
 #pragma unroll
     for (int i = c + 1; i < D; ++i) {
       double s = 0.0;
 #pragma unroll
-      for (int k = c; k < i; ++k) s -= H[i * D + k] * Ci[k * D + c];
-      Ci[i * D + c] = s / H[i * D + i];
+      for (int k = c; k < i; ++k) s -= Cm[i][k] * Ci[k][c];
+      Ci[i][c] = s / Cm[i][i];
     }
   }
-  double Hi[D * D];
+  double Hi[D][D];
 #pragma unroll
   for (int a = 0; a < D; ++a)
 #pragma unroll
-    for (int b = 0; b <= a; ++b) {
+    for (int c = 0; c <= a; ++c) {
       double s = 0.0;
 #pragma unroll
-      for (int k = a; k < D; ++k) s += Ci[k * D + a] * Ci[k * D + b];
-      Hi[a * D + b] = s;
-      Hi[b * D + a] = s;
+      for (int k = a; k < D; ++k) s += Ci[k][a] * Ci[k][c];
+      Hi[a][c] = s;
+      Hi[c][a] = s;
     }
+  if (lane == 0) {
 #pragma unroll
-  for (int i = 0; i < D * D; ++i) Hinv[i] = Hi[i];
-  for (int q = f0; q < f1; ++q) {
-    const int f = G.lm_fids[q];
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int c = 0; c < D; ++c) Hinv[a * D + c] = Hi[a][c];
+  }
+  for (int q = lane; q < nf; q += 64) {
+    const int f = G.lm_fids[f0 + q];
     const double* rec = G.jbuf + G.lf_joff[f];
-    const double* Jp = rec + M;
-    const double* Jl = rec + M + 6 * M;
+    const double* Jp = rec + D;
+    const double* Jl = rec + D + 6 * D;
     double* E = G.ebuf + G.lf_eoff[f];
     double* F = E + 6 * D;
     double* u = F + 6 * D;
@@ -359,7 +373,7 @@ __device__ inline void landmark_body(const GraphDev& G, int l) {
       for (int c = 0; c < D; ++c) {
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < M; ++k) s += Jp[6 * k + a] * Jl[D * k + c];
+        for (int k = 0; k < D; ++k) s += Jp[6 * k + a] * Jl[D * k + c];
         Ea[c] = s;
         E[a * D + c] = s;
       }
@@ -368,7 +382,7 @@ __device__ inline void landmark_body(const GraphDev& G, int l) {
       for (int c = 0; c < D; ++c) {
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < D; ++k) s += Ea[k] * Hi[k * D + c];
+        for (int k = 0; k < D; ++k) s += Ea[k] * Hi[k][c];
         F[a * D + c] = s;
         ua += s * g[c];
       }
@@ -377,13 +391,14 @@ __device__ inline void landmark_body(const GraphDev& G, int l) {
   }
 }
 
-__global__ __launch_bounds__(64) void k_landmark(GraphDev G) {
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_landmark(GraphDev G) {
+  const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (l >= G.L) return;
+  const int lane = threadIdx.x & 63;
   const int type = G.lm_type[l];
-  if (type == VT_POINT) landmark_body<3, 3>(G, l);
-  else if (type == VT_CUBE) landmark_body<9, 9>(G, l);
-  else landmark_body<7, 7>(G, l);
+  if (type == VT_POINT) landmark_wave<3>(G, l, lane);
+  else if (type == VT_CUBE) landmark_wave<9>(G, l, lane);
+  else landmark_wave<7>(G, l, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -457,82 +472,92 @@ __global__ __launch_bounds__(64) void k_pose(GraphDev G) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Schur assemble: one thread per lower block (i >= j) of the reduced pose system
-//   S_ij = [i == j] H_pp,i + sum_between J_i^T J_j - sum_{l seen by i and j} F_fa E_fb^T
-// Co-observed landmarks are found by merging the two poses' landmark-sorted factor lists, so no
-// pair list is ever materialised and every block is written exactly once (S needs no memset).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_schur(GraphDev G) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long nb = (long long)G.P * (G.P + 1) / 2;
-  if (t >= nb) return;
-  long long i = (long long)floor((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-  while (i * (i + 1) / 2 > t) --i;
-  while ((i + 1) * (i + 2) / 2 <= t) ++i;
-  const int pi = (int)i, pj = (int)(t - i * (i + 1) / 2);
-  double acc[36];
-  if (pi == pj) {
-#pragma unroll
-    for (int k = 0; k < 36; ++k) acc[k] = G.pose_H[36 * (size_t)pi + k];
-  } else {
-#pragma unroll
-    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-    for (int q = G.pose_bt_ptr[pi]; q < G.pose_bt_ptr[pi + 1]; ++q) {
-      const int ent = G.pose_bt[q];
-      const int b = ent >> 1, role = ent & 1;
-      const int other = role ? G.bt_i[b] : G.bt_j[b];
-      if (other != pj) continue;
-      const double* J = G.bt_J0 + 36 * (size_t)b;
-      if (role == 1) {   // pose i is the second key: J_i = diag(w), J_j = J0
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          const double w = 1.0 / G.bt_sigma[6 * b + a];
-#pragma unroll
-          for (int c = 0; c < 6; ++c) acc[6 * a + c] += w * J[6 * a + c];
-        }
-      } else {           // pose i is the first key: J_i = J0, J_j = diag(w)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const double w = 1.0 / G.bt_sigma[6 * b + c];
-#pragma unroll
-          for (int a = 0; a < 6; ++a) acc[6 * a + c] += J[6 * c + a] * w;
-        }
-      }
-    }
+// Schur assemble: one WORKGROUP per pose column j, one thread per lower block (i >= j):
+//   S_ij = [i == j] H_pp,i + sum_between J_i^T J_j - sum_{l seen by i and j} F_fa(i) E_fb(j)^T
+// The column pose's landmark list is published as an LDS lookup (landmark id -> first list position), so a
+// thread finds co-observed landmarks with one LDS read per entry of ITS pose's list (no merge, no pair list
+// is ever materialised); consecutive threads write consecutive 48-byte runs of the same S column, and every
+// block is written exactly once (S needs no memset, no atomics -> bit-stable).
+extern __shared__ short schur_slot[];
+
+__global__ __launch_bounds__(256) void k_schur(GraphDev G) {
+  const int pj = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int t = tid; t < G.L; t += 256) schur_slot[t] = -1;
+  __syncthreads();
+  const int b0 = G.pose_ptr[pj], nb = G.pose_ptr[pj + 1] - b0;
+  for (int q = tid; q < nb; q += 256) {
+    const int l = G.pose_lms[b0 + q];
+    if (q == 0 || G.pose_lms[b0 + q - 1] != l) schur_slot[l] = (short)q;
   }
-  int a0 = G.pose_ptr[pi];
-  const int a1 = G.pose_ptr[pi + 1];
-  int b0 = G.pose_ptr[pj];
-  const int b1 = G.pose_ptr[pj + 1];
-  while (a0 < a1 && b0 < b1) {
-    const int la = G.lf_lm[G.pose_fids[a0]], lb = G.lf_lm[G.pose_fids[b0]];
-    if (la < lb) { ++a0; continue; }
-    if (lb < la) { ++b0; continue; }
-    int ae = a0, be = b0;
-    while (ae < a1 && G.lf_lm[G.pose_fids[ae]] == la) ++ae;
-    while (be < b1 && G.lf_lm[G.pose_fids[be]] == la) ++be;
-    const int D = lm_dim(G.lm_type[la]);
-    for (int x = a0; x < ae; ++x) {
-      const double* F = G.ebuf + G.lf_eoff[G.pose_fids[x]] + 6 * D;
-      for (int y = b0; y < be; ++y) {
-        const double* E = G.ebuf + G.lf_eoff[G.pose_fids[y]];
+  __syncthreads();
+  for (int pi = pj + tid; pi < G.P; pi += 256) {
+    double acc[36];
+    if (pi == pj) {
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
+      for (int k = 0; k < 36; ++k) acc[k] = G.pose_H[36 * (size_t)pi + k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+      for (int q = G.pose_bt_ptr[pi]; q < G.pose_bt_ptr[pi + 1]; ++q) {
+        const int ent = G.pose_bt[q];
+        const int b = ent >> 1, role = ent & 1;
+        const int other = role ? G.bt_i[b] : G.bt_j[b];
+        if (other != pj) continue;
+        const double* J = G.bt_J0 + 36 * (size_t)b;
+        if (role == 1) {   // pose i is the second key: J_i = diag(w), J_j = J0
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            const double w = 1.0 / G.bt_sigma[6 * b + a];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[6 * a + c] += w * J[6 * a + c];
+          }
+        } else {           // pose i is the first key: J_i = J0, J_j = diag(w)
 #pragma unroll
           for (int c = 0; c < 6; ++c) {
-            double s = 0.0;
-            for (int k = 0; k < D; ++k) s += F[a * D + k] * E[c * D + k];
-            acc[6 * a + c] -= s;
+            const double w = 1.0 / G.bt_sigma[6 * b + c];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[6 * a + c] += J[6 * c + a] * w;
           }
+        }
       }
     }
-    a0 = ae; b0 = be;
+    const int a0 = G.pose_ptr[pi], a1 = G.pose_ptr[pi + 1];
+    for (int x = a0; x < a1; ++x) {
+      const int l = G.pose_lms[x];
+      const int sl = schur_slot[l];
+      if (sl < 0) continue;
+      const int D = lm_dim(G.lm_type[l]);
+      const double* F = G.ebuf + G.lf_eoff[G.pose_fids[x]] + 6 * D;
+      for (int y = b0 + sl; y < b0 + nb && G.pose_lms[y] == l; ++y) {
+        const double* E = G.ebuf + G.lf_eoff[G.pose_fids[y]];
+        if (D == 3) {
+          double f[18], e[18];
+#pragma unroll
+          for (int k = 0; k < 18; ++k) { f[k] = F[k]; e[k] = E[k]; }
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[6 * a + c] -= f[3 * a] * e[3 * c] + f[3 * a + 1] * e[3 * c + 1] + f[3 * a + 2] * e[3 * c + 2];
+        } else {
+          for (int k = 0; k < D; ++k) {
+            double fk[6], ek[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { fk[a] = F[a * D + k]; ek[a] = E[a * D + k]; }
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+              for (int c = 0; c < 6; ++c) acc[6 * a + c] -= fk[a] * ek[c];
+          }
+        }
+      }
+    }
+    double* Sc = G.S + (size_t)(6 * pj) * G.ld + 6 * (size_t)pi;
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int a = 0; a < 6; ++a) Sc[(size_t)c * G.ld + a] = acc[6 * a + c];
   }
-  double* S = G.S;
-#pragma unroll
-  for (int c = 0; c < 6; ++c)
-#pragma unroll
-    for (int a = 0; a < 6; ++a) S[(size_t)(6 * pj + c) * G.ld + 6 * pi + a] = acc[6 * a + c];
 }
 
 // padding (identity) between 6P and T*NB, and the RHS row (-g) at row T*NB
@@ -606,15 +631,19 @@ void launch_linearize(const GraphDev& G, hipStream_t s) {
   if (G.n_lf > 0) hipLaunchKernelGGL(k_lin_lf, dim3(blocks_for(G.n_lf, 128)), dim3(128), 0, s, G);
 }
 void launch_landmark(const GraphDev& G, hipStream_t s) {
-  if (G.L > 0) hipLaunchKernelGGL(k_landmark, dim3(blocks_for(G.L, 64)), dim3(64), 0, s, G);
+  if (G.L > 0) hipLaunchKernelGGL(k_landmark, dim3(blocks_for(G.L, 4)), dim3(256), 0, s, G);
 }
 void launch_pose(const GraphDev& G, hipStream_t s) {
   if (G.P > 0) hipLaunchKernelGGL(k_pose, dim3(blocks_for(G.P, 64)), dim3(64), 0, s, G);
 }
 void launch_schur(const GraphDev& G, hipStream_t s) {
-  const long long nb = (long long)G.P * (G.P + 1) / 2;
-  if (nb == 0) return;
-  hipLaunchKernelGGL(k_schur, dim3(blocks_for(nb, 128)), dim3(128), 0, s, G);
+  if (G.P == 0) return;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_schur, dim3(G.P), dim3(256), (size_t)((G.L + 7) / 8 * 8) * sizeof(short), s, G);
   const long long NT = (long long)G.T * NB;
   const long long tot = NT + (NT - 6LL * G.P) * NT;
   hipLaunchKernelGGL(k_pad_rhs, dim3(blocks_for(tot, 256)), dim3(256), 0, s, G);
