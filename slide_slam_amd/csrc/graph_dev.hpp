@@ -62,7 +62,8 @@ struct GraphDev {
   double* S;         // column-major, ld rows x (T*NB) columns, lower triangle + RHS row at T*NB
   int ld;            // (T + 1) * NB
   int T;             // ceil(6 P / NB)
-  double* W;         // T * NB*NB : inverse of every diagonal Cholesky block (column-major)
+  double* Ld;        // T * NB*NB : factored diagonal blocks L_kk (column-major)
+  double* Winv;      // T * 4*256 : inverses of the four 16x16 diagonal sub-blocks of every L_kk
   double* yv;        // T*NB  forward-substituted RHS
   double* dp;        // T*NB  reduced solution (delta_p = -dp)
   int* status;       // [0] not-SPD flag (landmark), [1] not-SPD flag (chol), [2] #relinearised

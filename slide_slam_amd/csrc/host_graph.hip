@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 namespace sl {
 
@@ -70,11 +71,17 @@ uint64_t HostGraph::lm_key(int cls, uint64_t idx) {
 
 HostGraph::HostGraph(const slide_params_t& p) : P(p) {}
 HostGraph::~HostGraph() {
+  if (gexec) (void)hipGraphExecDestroy(gexec);
+  for (auto e : ev_dp) (void)hipEventDestroy(e);
+  for (auto e : ev_upd) (void)hipEventDestroy(e);
+  if (stream2) (void)hipStreamDestroy(stream2);
   if (stream) (void)hipStreamDestroy(stream);
 }
 int HostGraph::init() {
   if (P.device >= 0) SL_HIP(hipSetDevice(P.device));
   SL_HIP(hipStreamCreate(&stream));
+  SL_HIP(hipStreamCreate(&stream2));
+  init_solver_kernels();
   if (d_status.ensure(8, 0, stream, true) != SLIDE_OK) return SLIDE_ERR_HIP;
   return SLIDE_OK;
 }
@@ -359,7 +366,8 @@ int HostGraph::upload_new() {
     d_S.cap = 0;
     if (d_S.d) { SL_HIP(hipFree(d_S.d)); d_S.d = nullptr; }
     if (d_S.ensure(ld * (size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
-    if (d_W.ensure((size_t)Tcap * NB * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_Ld.ensure((size_t)Tcap * NB * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_Winv.ensure((size_t)Tcap * 1024, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_yv.ensure((size_t)Tcap * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_dp.ensure((size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
   }
@@ -379,10 +387,56 @@ int HostGraph::upload_new() {
   G.lm_ptr = d_lm_ptr.d; G.lm_fids = d_lm_fids.d; G.pose_ptr = d_pose_ptr.d; G.pose_fids = d_pose_fids.d; G.pose_lms = d_pose_lms.d;
   G.pose_bt_ptr = d_pose_bt_ptr.d; G.pose_bt = d_pose_bt.d;
   G.lm_Hinv = d_lm_Hinv.d; G.lm_g = d_lm_g.d; G.pose_H = d_pose_H.d; G.pose_g = d_pose_g.d;
-  G.S = d_S.d; G.ld = (Tcap + 1) * NB; G.T = T; G.W = d_W.d; G.yv = d_yv.d; G.dp = d_dp.d;
+  G.S = d_S.d; G.ld = (Tcap + 1) * NB; G.T = T; G.Ld = d_Ld.d; G.Winv = d_Winv.d; G.yv = d_yv.d; G.dp = d_dp.d;
   G.status = d_status.d;
   G.chart = P.pose_chart;
   G.bearing_sigma = P.bearing_range_sigma; G.cyl_sigma = P.cylinder_sigma; G.numdiff_delta = P.numdiff_delta;
+  return SLIDE_OK;
+}
+
+int HostGraph::enqueue_iteration(bool lookahead) {
+  hipStream_t s = stream;
+  static const char* kNames[] = {"relin", "linearize", "landmark_reduce", "pose_reduce", "schur_assemble", "chol_diag_panel",
+                                 "chol_update", "chol_extract_y", "chol_bwd", "backsub", "estimate"};
+  int id[11];
+  for (int i = 0; i < 11; ++i) id[i] = prof.id_of(kNames[i]);
+#define STAGE(i, call) do { prof.begin(id[i], s); call; prof.end(s); } while (0)
+  STAGE(0, launch_relin(G, s));
+  STAGE(1, launch_linearize(G, s));
+  STAGE(2, launch_landmark(G, s));
+  STAGE(3, launch_pose(G, s));
+  STAGE(4, launch_schur(G, s));
+  // Look-ahead over two streams: the diag+panel chain (critical path) stays on `s` together with the
+  // update of tile column k+1; the rest of trailing update k runs on stream2 beside diag+panel k+1.
+  while ((int)ev_dp.size() < G.T) {
+    hipEvent_t e1, e2;
+    SL_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    SL_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+    ev_dp.push_back(e1);
+    ev_upd.push_back(e2);
+  }
+  for (int k = 0; k < G.T; ++k) {
+    if (!lookahead) {
+      STAGE(5, launch_chol_dp(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, s));
+      STAGE(6, launch_chol_update(G.S, G.ld, k, G.T, 0, s));
+      continue;
+    }
+    if (k >= 2) SL_HIP(hipStreamWaitEvent(s, ev_upd[k - 2], 0));    // column k complete
+    launch_chol_dp(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, s);
+    SL_HIP(hipEventRecord(ev_dp[k], s));
+    SL_HIP(hipStreamWaitEvent(stream2, ev_dp[k], 0));
+    launch_chol_update(G.S, G.ld, k, G.T, 2, stream2);
+    SL_HIP(hipEventRecord(ev_upd[k], stream2));
+    if (k >= 1) SL_HIP(hipStreamWaitEvent(s, ev_upd[k - 1], 0));    // column k+1 has every earlier update
+    launch_chol_update(G.S, G.ld, k, G.T, 1, s);
+  }
+  if (lookahead) SL_HIP(hipStreamWaitEvent(s, ev_upd[G.T - 1], 0));
+  STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, s));
+  for (int k = G.T - 1; k >= 0; --k)
+    STAGE(8, launch_chol_bwd(G.S, G.ld, k, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.yv, G.dp, s));
+  STAGE(9, launch_backsub(G, s));
+  STAGE(10, launch_estimate(G, s));
+#undef STAGE
   return SLIDE_OK;
 }
 
@@ -391,29 +445,40 @@ int HostGraph::run_update(double relin_thr, int iterations) {
   if (G.P == 0) return SLIDE_OK;
   G.relin_thr = relin_thr;
   SL_HIP(hipMemsetAsync(d_status.d, 0, 8 * sizeof(int), s));
-  static const char* kNames[] = {"relin", "linearize", "landmark_reduce", "pose_reduce", "schur_assemble", "chol_diag",
-                                 "chol_panel", "chol_update", "chol_extract_y", "chol_bwd", "backsub", "estimate"};
-  int id[12];
-  for (int i = 0; i < 12; ++i) id[i] = prof.id_of(kNames[i]);
-#define STAGE(i, call) do { prof.begin(id[i], s); call; prof.end(s); } while (0)
-  for (int it = 0; it < iterations; ++it) {
-    STAGE(0, launch_relin(G, s));
-    STAGE(1, launch_linearize(G, s));
-    STAGE(2, launch_landmark(G, s));
-    STAGE(3, launch_pose(G, s));
-    STAGE(4, launch_schur(G, s));
-    for (int k = 0; k < G.T; ++k) {
-      double* Wk = G.W + (size_t)k * NB * NB;
-      STAGE(5, launch_chol_diag(G.S, G.ld, k, Wk, G.status, s));
-      STAGE(6, launch_chol_panel(G.S, G.ld, k, G.T, Wk, s));
-      STAGE(7, launch_chol_update(G.S, G.ld, k, G.T, s));
+  // Replaying a captured hipGraph removes the host launch cost (~250 launches + event traffic per pass) once the
+  // SAME resident graph is solved again (batch Gauss-Newton, repeated solve() without new factors).
+  const bool same_as_prev = have_prev && std::memcmp(&G_prev, &G, sizeof(GraphDev)) == 0;
+  static const bool env_graph = !(getenv("SLIDE_NO_GRAPH") && getenv("SLIDE_NO_GRAPH")[0] == '1');
+  // two-stream look-ahead is implemented and parity-tested but measured SLOWER than the linear graph on MI355X
+  // (the latency-critical diag+panel blocks queue behind the flood of update workgroups): opt-in only.
+  static const bool env_look = getenv("SLIDE_LOOKAHEAD") && getenv("SLIDE_LOOKAHEAD")[0] == '1';
+  const bool graph_ok = env_graph && !prof.on && G.T > 4;
+  bool use_graph = graph_ok && (iterations > 1 || same_as_prev || (gexec && std::memcmp(&G_cap, &G, sizeof(GraphDev)) == 0));
+  G_prev = G;
+  have_prev = true;
+  if (use_graph && !(gexec && std::memcmp(&G_cap, &G, sizeof(GraphDev)) == 0)) {
+    if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
+    hipGraph_t graph = nullptr;
+    SL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_iteration(env_look);
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc != SLIDE_OK || e != hipSuccess || graph == nullptr) {
+      (void)hipGetLastError();
+      use_graph = false;
+    } else {
+      const hipError_t ei = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ei != hipSuccess) { gexec = nullptr; (void)hipGetLastError(); use_graph = false; }
+      else G_cap = G;
     }
-    STAGE(8, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, s));
-    for (int k = G.T - 1; k >= 0; --k) STAGE(9, launch_chol_bwd(G.S, G.ld, k, G.W + (size_t)k * NB * NB, G.yv, G.dp, s));
-    STAGE(10, launch_backsub(G, s));
-    STAGE(11, launch_estimate(G, s));
   }
-#undef STAGE
+  for (int it = 0; it < iterations; ++it) {
+    if (use_graph) SL_HIP(hipGraphLaunch(gexec, s));
+    else {
+      const int rc = enqueue_iteration(false);
+      if (rc != SLIDE_OK) return rc;
+    }
+  }
   int st[8];
   SL_HIP(hipMemcpyAsync(st, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
   SL_HIP(hipStreamSynchronize(s));

@@ -113,6 +113,8 @@ class HostGraph {
 
   slide_params_t P;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;              // trailing updates of the Cholesky look-ahead
+  std::vector<hipEvent_t> ev_dp, ev_upd;
   std::mutex mtx;
   Profiler prof;
   GraphDev G{};
@@ -121,6 +123,7 @@ class HostGraph {
   int merge_pending();
   int upload_new();
   int run_update(double relin_thr, int iterations);
+  int enqueue_iteration(bool lookahead);      // one GN / iSAM2-equivalent pass on `stream` (+ stream2)
 
   std::vector<PendVar> pend_vars;
   std::vector<PendFac> pend_facs;
@@ -147,9 +150,15 @@ class HostGraph {
   DevArr<double> d_br_z, d_cu_z, d_cu_sigma, d_cy_z, d_jbuf, d_ebuf;
   DevArr<int> d_lm_ptr, d_lm_fids, d_pose_ptr, d_pose_fids, d_pose_lms, d_pose_bt_ptr, d_pose_bt;
   DevArr<double> d_lm_Hinv, d_lm_g, d_pose_H, d_pose_g;
-  DevArr<double> d_S, d_W, d_yv, d_dp;
+  DevArr<double> d_S, d_Ld, d_Winv, d_yv, d_dp;
   DevArr<int> d_status;
   int Tcap = 0;
+  // hipGraph of one pass, captured when the same resident graph is solved repeatedly (kernel arguments are
+  // baked in, so any change of counts / pointers / threshold invalidates it)
+  hipGraphExec_t gexec = nullptr;
+  GraphDev G_cap{};
+  GraphDev G_prev{};
+  bool have_prev = false;
 };
 
 }  // namespace sl

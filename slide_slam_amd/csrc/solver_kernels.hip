@@ -621,6 +621,9 @@ __global__ void k_estimate(GraphDev G) {
 // ------------------------------------------------------------------------------------------------
 static inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
+void init_solver_kernels() {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+}
 void launch_relin(const GraphDev& G, hipStream_t s) {
   if (G.P + G.L == 0) return;
   hipLaunchKernelGGL(k_relin, dim3(blocks_for(G.P + G.L, 256)), dim3(256), 0, s, G);
@@ -638,11 +641,6 @@ void launch_pose(const GraphDev& G, hipStream_t s) {
 }
 void launch_schur(const GraphDev& G, hipStream_t s) {
   if (G.P == 0) return;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_set = true;
-  }
   hipLaunchKernelGGL(k_schur, dim3(G.P), dim3(256), (size_t)((G.L + 7) / 8 * 8) * sizeof(short), s, G);
   const long long NT = (long long)G.T * NB;
   const long long tot = NT + (NT - 6LL * G.P) * NT;
