@@ -72,6 +72,7 @@ const char* slide_version(void);
  * S1 — SemanticFactorGraph (include/factorgraph/graph.h:70-121, src/factorgraph/graph.cpp)
  * ---------------------------------------------------------------------------------------------- */
 typedef struct slide_graph slide_graph_t;
+typedef struct slide_backend slide_backend_t;
 
 slide_graph_t* slide_graph_create(const slide_params_t* p);          /* SemanticFactorGraph() graph.cpp:14-22 */
 void slide_graph_destroy(slide_graph_t* g);
@@ -110,6 +111,22 @@ int slide_graph_stats(slide_graph_t* g, int64_t out5[5]);
 int slide_graph_set_profiling(slide_graph_t* g, int on);
 int slide_graph_get_profile(slide_graph_t* g, char* names, double* ms_total, int64_t* launches, int n_max);
 
+/* ---- one robot per GPU (the reference instead keeps a full replica of every robot's graph in
+ * every sloam_node and gossips packets over ROS topics, databaseManager.cpp:219-279) -------------------------
+ * Slots are a global, rank-independent enumeration of the landmarks observed by more than one robot.
+ * slide_graph_set_shared: slot i is this rank's landmark (cls[i], idx[i]) or none (cls[i] < 0); owner[i] != 0 on
+ * exactly one rank per slot (the rank whose value every replica adopts).
+ * slide_graph_dist_phase: one distributed Gauss-Newton pass is
+ *     phase 0 ; all-reduce(sum) of d_buf[54 * n_slots] ; phase 1 ; all-reduce(sum) of d_buf[9 * n_slots] ; phase 2
+ * and a value broadcast is  phase 10 ; all-reduce(sum) of d_buf[15 * n_slots] ; phase 11.
+ * d_buf is a DEVICE buffer owned by the caller (the collective itself — RCCL over xGMI — runs outside this
+ * library); each call returns after its kernels have completed. */
+int slide_graph_set_shared(slide_graph_t* g, const int32_t* cls, const int64_t* idx, const int32_t* owner, int n_slots);
+int slide_graph_dist_phase(slide_graph_t* g, int phase, double* d_buf);
+/* Landmark table of this rank (input of the cross-robot association): for class cls, positions (xyz of the
+ * current estimate; cylinders: root) and labels of landmarks [0, n).  Returns n (<= cap). */
+int slide_backend_landmark_table(slide_backend_t* b, int cls, double* xyz, int32_t* label, int cap);
+
 /* The dense kernel behind solve(): x = A^-1 b for a symmetric positive definite A (n x n, row- or
  * column-major: only the lower triangle in column-major sense, A[i + j*n] with i >= j, is read) by
  * the blocked FP64-MFMA Cholesky the reduced pose system uses (the reference delegates this to
@@ -145,8 +162,6 @@ int slide_assoc_sweep_batch_device(const float* d_cloud_xyz, const double* d_mod
  * submap gate -> projectModels -> match -> updateMap -> addSLOAMObservation -> solve ->
  * updateFactorGraphMap -> getCurrPose.
  * ---------------------------------------------------------------------------------------------- */
-typedef struct slide_backend slide_backend_t;
-
 /* Body-frame detections of one key frame: field order/precision of sloam_msgs/SemanticMeasSyncOdom
  * (ROSCylinder/ROSCube/ROSEllipsoid; float32 fields already widened to double by the caller). */
 typedef struct slide_detections_t {

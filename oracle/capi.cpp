@@ -176,6 +176,24 @@ void orc_graph_stats(void* h, double* out8) {
   out8[0] = s.n_pose; out8[1] = s.n_lm; out8[2] = s.n_factors; out8[3] = s.n_relin;
   out8[4] = s.t_linearize; out8[5] = s.t_schur; out8[6] = s.t_chol; out8[7] = s.t_total;
 }
+int orc_graph_set_shared(void* h, const int* cls, const int64_t* idx, const int* owner, int n) {
+  return ((Graph*)h)->set_shared(cls, idx, owner, n);
+}
+int orc_graph_dist_phase(void* h, int phase, double* buf) { return ((Graph*)h)->dist_phase(phase, buf); }
+// landmark table of a backend (cls 0 cyl root / 1 cube / 2 point): xyz of the current estimate + label
+int orc_backend_landmark_table(void* h, int cls, double* xyz, int* label, int cap) {
+  Backend* b = (Backend*)h;
+  const uint64_t counters[3] = {b->cyl_counter, b->cube_counter, b->point_counter};
+  const int n = (int)std::min<uint64_t>(counters[cls], (uint64_t)cap);
+  for (int i = 0; i < n; ++i) {
+    const Var* v = b->graph.getLandmark(cls == 0 ? 'l' : (cls == 1 ? 'c' : 'u'), (uint64_t)i);
+    if (!v) return -1;
+    const double* pos = cls == 1 ? v->val + 9 : v->val;
+    xyz[3 * i] = pos[0]; xyz[3 * i + 1] = pos[1]; xyz[3 * i + 2] = pos[2];
+    label[i] = cls == 0 ? b->cylMap.models[i].label : (cls == 1 ? b->cubeMap.models[i].label : b->ellMap.models[i].label);
+  }
+  return n;
+}
 // force a full relinearisation on the next solve (batch Gauss-Newton mode = threshold 0)
 void orc_graph_set_relin_threshold(void* h, double thr) { ((Graph*)h)->P.relin_threshold = thr; }
 

@@ -527,6 +527,20 @@ class Graph {
 
   // graph.cpp:260-272
   int solve();
+
+  // ---- one-robot-per-rank restatement of the distributed Gauss-Newton pass (checker of the multi-GPU path;
+  // the reference has no such mode: every sloam_node holds a full replica) ---------------------
+  std::vector<int> sh_var, sh_owner;   // slot -> variable id (or -1), owner flag
+  struct DLm { double H[81]; double g[9]; double t[9]; std::vector<int> fac; };
+  struct DistState {
+    std::vector<LinFactor> lin;
+    std::vector<int> pidx, lidx, pose_vars, lm_vars;
+    std::vector<DLm> acc;
+    std::vector<double> Hinv_all, dp;
+    std::vector<std::vector<double>> Eall;
+  } D;
+  int set_shared(const int* cls, const int64_t* idx, const int* owner, int n);
+  int dist_phase(int phase, double* buf);
 };
 
 inline double now_sec();
@@ -736,6 +750,244 @@ inline int Graph::solve() {
   const double t4 = now_sec();
   stats.t_linearize = t1 - t0; stats.t_schur = t2 - t1; stats.t_chol = t3 - t2; stats.t_total = t4 - t0;
   return 0;
+}
+
+inline int Graph::set_shared(const int* cls, const int64_t* idx, const int* owner, int n) {
+  sh_var.assign(n, -1);
+  sh_owner.assign(n, 0);
+  for (int i = 0; i < n; ++i) {
+    if (cls[i] < 0) continue;
+    const char c = cls[i] == 0 ? 'l' : (cls[i] == 1 ? 'c' : 'u');
+    auto it = key2var.find(lm_key(c, (uint64_t)idx[i]));
+    if (it == key2var.end()) return -1;
+    sh_var[i] = it->second;
+    sh_owner[i] = owner[i] ? 1 : 0;
+  }
+  return 0;
+}
+
+// phases and buffer layouts identical to slide_graph_dist_phase (include/slide_gpu.h)
+inline int Graph::dist_phase(int phase, double* buf) {
+  const int nslots = (int)sh_var.size();
+  if (phase == 0) {
+    for (auto& v : vars) {   // batch GN: theta <- theta (+) delta for every variable
+      Var nv;
+      var_retract(v, v.delta, P.pose_chart, nv);
+      std::memcpy(v.val, nv.val, sizeof(v.val));
+    }
+    D = DistState();
+    D.pidx.assign(vars.size(), -1);
+    D.lidx.assign(vars.size(), -1);
+    for (size_t i = 0; i < vars.size(); ++i) {
+      if (vars[i].type == V_POSE) { D.pidx[i] = (int)D.pose_vars.size(); D.pose_vars.push_back((int)i); }
+      else { D.lidx[i] = (int)D.lm_vars.size(); D.lm_vars.push_back((int)i); }
+    }
+    D.lin.resize(factors.size());
+    for (size_t i = 0; i < factors.size(); ++i) linearize_factor(factors[i], vars, P, D.lin[i]);
+    D.acc.assign(D.lm_vars.size(), DLm());
+    for (auto& a : D.acc) { std::memset(a.H, 0, sizeof(a.H)); std::memset(a.g, 0, sizeof(a.g)); std::memset(a.t, 0, sizeof(a.t)); }
+    for (size_t i = 0; i < factors.size(); ++i) {
+      const Factor& f = factors[i];
+      if (f.type == F_PRIOR || f.type == F_BETWEEN) continue;
+      const LinFactor& L = D.lin[i];
+      DLm& A = D.acc[D.lidx[f.v1]];
+      const int d = L.d1;
+      for (int a = 0; a < d; ++a) {
+        for (int b = 0; b < d; ++b) {
+          double s2 = 0.0;
+          for (int r = 0; r < L.m; ++r) s2 += L.J1[r * d + a] * L.J1[r * d + b];
+          A.H[a * d + b] += s2;
+        }
+        double s2 = 0.0;
+        for (int r = 0; r < L.m; ++r) s2 += L.J1[r * d + a] * L.r[r];
+        A.g[a] += s2;
+      }
+      A.fac.push_back((int)i);
+    }
+    for (int sidx = 0; sidx < nslots; ++sidx) {
+      double* o = buf + 54 * (size_t)sidx;
+      for (int k = 0; k < 54; ++k) o[k] = 0.0;
+      if (sh_var[sidx] < 0) continue;
+      const DLm& A = D.acc[D.lidx[sh_var[sidx]]];
+      const int d = var_dim(vars[sh_var[sidx]].type);
+      for (int a = 0; a < d; ++a) {
+        for (int c = 0; c <= a; ++c) o[a * (a + 1) / 2 + c] = A.H[a * d + c];
+        o[45 + a] = A.g[a];
+      }
+    }
+    return 0;
+  }
+  if (phase == 1) {
+    for (int sidx = 0; sidx < nslots; ++sidx) {
+      if (sh_var[sidx] < 0) continue;
+      const double* in = buf + 54 * (size_t)sidx;
+      DLm& A = D.acc[D.lidx[sh_var[sidx]]];
+      const int d = var_dim(vars[sh_var[sidx]].type);
+      for (int a = 0; a < d; ++a) {
+        for (int c = 0; c <= a; ++c) { A.H[a * d + c] = in[a * (a + 1) / 2 + c]; A.H[c * d + a] = in[a * (a + 1) / 2 + c]; }
+        A.g[a] = in[45 + a];
+      }
+    }
+    const int np = (int)D.pose_vars.size(), nl = (int)D.lm_vars.size(), n = 6 * np;
+    std::vector<double> S((size_t)n * n, 0.0), g(n, 0.0);
+    auto add_block = [&](int pi, int pj, const double* Ja, const double* Jb, int m) {
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) {
+          double s2 = 0.0;
+          for (int r = 0; r < m; ++r) s2 += Ja[r * 6 + a] * Jb[r * 6 + b];
+          S[(size_t)(6 * pi + a) * n + 6 * pj + b] += s2;
+        }
+    };
+    for (size_t i = 0; i < factors.size(); ++i) {
+      const Factor& f = factors[i];
+      const LinFactor& L = D.lin[i];
+      const int p0 = D.pidx[f.v0];
+      add_block(p0, p0, L.J0, L.J0, L.m);
+      for (int a = 0; a < 6; ++a) {
+        double s2 = 0.0;
+        for (int r = 0; r < L.m; ++r) s2 += L.J0[r * 6 + a] * L.r[r];
+        g[6 * p0 + a] += s2;
+      }
+      if (f.type == F_BETWEEN) {
+        const int p1 = D.pidx[f.v1];
+        add_block(p1, p1, L.J1, L.J1, L.m);
+        if (p1 >= p0) add_block(p1, p0, L.J1, L.J0, L.m); else add_block(p0, p1, L.J0, L.J1, L.m);
+        for (int a = 0; a < 6; ++a) {
+          double s2 = 0.0;
+          for (int r = 0; r < L.m; ++r) s2 += L.J1[r * 6 + a] * L.r[r];
+          g[6 * p1 + a] += s2;
+        }
+      }
+    }
+    D.Hinv_all.assign((size_t)nl * 81, 0.0);
+    D.Eall.assign(nl, {});
+    for (int l = 0; l < nl; ++l) {
+      DLm& A = D.acc[l];
+      const int d = var_dim(vars[D.lm_vars[l]].type);
+      double* Hinv = &D.Hinv_all[(size_t)l * 81];
+      if (A.fac.empty()) continue;
+      if (!spd_inverse(A.H, d, Hinv)) return -2;
+      const int nf = (int)A.fac.size();
+      std::vector<double>& E = D.Eall[l];
+      E.assign((size_t)nf * 6 * d, 0.0);
+      std::vector<double> Fm((size_t)nf * 6 * d);
+      for (int a = 0; a < nf; ++a) {
+        const LinFactor& L = D.lin[A.fac[a]];
+        double* Ea = &E[(size_t)a * 6 * d];
+        double* Fa = &Fm[(size_t)a * 6 * d];
+        for (int r = 0; r < 6; ++r)
+          for (int c = 0; c < d; ++c) {
+            double s2 = 0.0;
+            for (int k = 0; k < L.m; ++k) s2 += L.J0[k * 6 + r] * L.J1[k * d + c];
+            Ea[r * d + c] = s2;
+          }
+        for (int r = 0; r < 6; ++r)
+          for (int c = 0; c < d; ++c) {
+            double s2 = 0.0;
+            for (int k = 0; k < d; ++k) s2 += Ea[r * d + k] * Hinv[k * d + c];
+            Fa[r * d + c] = s2;
+          }
+      }
+      for (int a = 0; a < nf; ++a) {
+        const int pa = D.pidx[factors[A.fac[a]].v0];
+        const double* Fa = &Fm[(size_t)a * 6 * d];
+        for (int r = 0; r < 6; ++r) {
+          double s2 = 0.0;
+          for (int k = 0; k < d; ++k) s2 += Fa[r * d + k] * A.g[k];
+          g[6 * pa + r] -= s2;
+        }
+        for (int b = 0; b < nf; ++b) {
+          const int pb = D.pidx[factors[A.fac[b]].v0];
+          if (pb > pa) continue;
+          const double* Eb = &E[(size_t)b * 6 * d];
+          for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) {
+              double s2 = 0.0;
+              for (int k = 0; k < d; ++k) s2 += Fa[r * d + k] * Eb[c * d + k];
+              S[(size_t)(6 * pa + r) * n + 6 * pb + c] -= s2;
+            }
+        }
+      }
+    }
+    if (chol_lower(S.data(), n, n, P.num_threads) != 0) return -1;
+    D.dp.assign(n, 0.0);
+    for (int i = 0; i < n; ++i) D.dp[i] = -g[i];
+    chol_solve_lower(S.data(), n, n, D.dp.data());
+    for (int p = 0; p < np; ++p)
+      for (int k = 0; k < 6; ++k) vars[D.pose_vars[p]].delta[k] = D.dp[6 * p + k];
+    for (int l = 0; l < nl; ++l) {
+      DLm& A = D.acc[l];
+      const int d = var_dim(vars[D.lm_vars[l]].type);
+      for (int k = 0; k < 9; ++k) A.t[k] = 0.0;
+      for (size_t a = 0; a < A.fac.size(); ++a) {
+        const int pa = D.pidx[factors[A.fac[a]].v0];
+        const double* Ea = &D.Eall[l][a * 6 * d];
+        for (int k = 0; k < d; ++k) {
+          double s2 = 0.0;
+          for (int r = 0; r < 6; ++r) s2 += Ea[r * d + k] * D.dp[6 * pa + r];
+          A.t[k] += s2;
+        }
+      }
+    }
+    for (int sidx = 0; sidx < nslots; ++sidx) {
+      double* o = buf + 9 * (size_t)sidx;
+      for (int k = 0; k < 9; ++k) o[k] = (sh_var[sidx] >= 0) ? D.acc[D.lidx[sh_var[sidx]]].t[k] : 0.0;
+    }
+    return 0;
+  }
+  if (phase == 2) {
+    for (int sidx = 0; sidx < nslots; ++sidx) {
+      if (sh_var[sidx] < 0) continue;
+      DLm& A = D.acc[D.lidx[sh_var[sidx]]];
+      for (int k = 0; k < 9; ++k) A.t[k] = buf[9 * (size_t)sidx + k];
+    }
+    for (size_t l = 0; l < D.lm_vars.size(); ++l) {
+      DLm& A = D.acc[l];
+      Var& v = vars[D.lm_vars[l]];
+      const int d = var_dim(v.type);
+      const double* Hinv = &D.Hinv_all[l * 81];
+      for (int k = 0; k < d; ++k) {
+        double s2 = 0.0;
+        for (int c = 0; c < d; ++c) s2 += Hinv[k * d + c] * (A.g[c] + A.t[c]);
+        v.delta[k] = A.fac.empty() ? 0.0 : -s2;
+      }
+    }
+    estimate.resize(vars.size());
+    for (size_t i = 0; i < vars.size(); ++i) {
+      var_retract(vars[i], vars[i].delta, P.pose_chart, estimate[i]);
+      std::memcpy(estimate[i].delta, vars[i].delta, sizeof(vars[i].delta));
+    }
+    return 0;
+  }
+  if (phase == 10) {
+    for (auto& v : vars) {   // commit: theta <- theta (+) delta, delta <- 0
+      Var nv;
+      var_retract(v, v.delta, P.pose_chart, nv);
+      std::memcpy(v.val, nv.val, sizeof(v.val));
+      for (int k = 0; k < 9; ++k) v.delta[k] = 0.0;
+    }
+    for (int sidx = 0; sidx < nslots; ++sidx) {
+      double* o = buf + 15 * (size_t)sidx;
+      for (int k = 0; k < 15; ++k) o[k] = 0.0;
+      if (sh_var[sidx] >= 0 && sh_owner[sidx]) std::memcpy(o, vars[sh_var[sidx]].val, 15 * sizeof(double));
+    }
+    return 0;
+  }
+  if (phase == 11) {
+    for (int sidx = 0; sidx < nslots; ++sidx) {
+      if (sh_var[sidx] < 0) continue;
+      Var& v = vars[sh_var[sidx]];
+      const int nv = v.type == V_POINT ? 3 : (v.type == V_CUBE ? 15 : 7);
+      std::memcpy(v.val, buf + 15 * (size_t)sidx, nv * sizeof(double));
+    }
+    estimate.resize(vars.size());
+    for (size_t i = 0; i < vars.size(); ++i) {
+      var_retract(vars[i], vars[i].delta, P.pose_chart, estimate[i]);
+      std::memcpy(estimate[i].delta, vars[i].delta, sizeof(vars[i].delta));
+    }
+    return 0;
+  }
+  return -3;
 }
 
 }  // namespace orc

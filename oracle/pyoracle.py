@@ -152,6 +152,20 @@ class OracleGraph:
         st = self.L.orc_graph_get_landmark(self.h, C.c_int(cls), C.c_uint64(idx), _p(out))
         return st, out[: (7, 15, 3)[cls]]
 
+    def set_shared(self, cls, idx, owner):
+        cls, owner = _i(cls), _i(owner)
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        rc = self.L.orc_graph_set_shared(self.h, _p(cls), _p(idx), _p(owner), C.c_int(len(cls)))
+        if rc != 0:
+            raise RuntimeError("set_shared: landmark missing")
+
+    def dist_phase(self, phase, buf):
+        """buf: numpy float64 array (host) — same layout as the product's device buffer."""
+        rc = self.L.orc_graph_dist_phase(self.h, C.c_int(phase), _p(buf))
+        if rc != 0:
+            raise RuntimeError(f"oracle dist_phase {phase} failed: {rc}")
+        return rc
+
     def stats(self):
         out = np.zeros(8)
         self.L.orc_graph_stats(self.h, _p(out))
@@ -204,6 +218,13 @@ class OracleBackend:
         pc = np.zeros(self.n_robots, np.uint64)
         self.L.orc_backend_counts(self.h, _p(out), _p(pc), C.c_int(self.n_robots))
         return dict(cyl=int(out[0]), cube=int(out[1]), point=int(out[2]), factors=int(out[3]), poses=pc.astype(np.int64))
+
+    def landmark_table(self, cls):
+        n = self.counts()[("cyl", "cube", "point")[cls]]
+        xyz = np.zeros((max(n, 1), 3))
+        lab = np.zeros(max(n, 1), np.int32)
+        k = self.L.orc_backend_landmark_table(self.h, C.c_int(cls), _p(xyz), _p(lab), C.c_int(n))
+        return xyz[:k], lab[:k]
 
     def map_model(self, cls, idx):
         out = np.zeros(7)

@@ -28,7 +28,8 @@ EXPORTS = [
     "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
     "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
-    "slide_graph_get_landmark", "slide_graph_stats", "slide_graph_set_profiling", "slide_graph_get_profile",
+    "slide_graph_get_landmark", "slide_graph_stats", "slide_graph_set_shared", "slide_graph_dist_phase",
+    "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
     "slide_dense_spd_solve", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
     "slide_backend_end_frame", "slide_backend_graph", "slide_backend_counts", "slide_backend_map_model",
@@ -209,6 +210,15 @@ class SlideGraph:
         _check(self.L.slide_graph_stats(self.h, _p(out)))
         return dict(n_pose=int(out[0]), n_lm=int(out[1]), n_factors=int(out[2]), n_relin=int(out[3]), chol_dim=int(out[4]))
 
+    def set_shared(self, cls, idx, owner):
+        cls, owner = _i(cls), _i(owner)
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        _check(self.L.slide_graph_set_shared(self.h, _p(cls), _p(idx), _p(owner), C.c_int(len(cls))))
+
+    def dist_phase(self, phase, d_buf_ptr):
+        """d_buf_ptr: integer DEVICE address of the exchange buffer (e.g. torch_tensor.data_ptr())."""
+        return _check(self.L.slide_graph_dist_phase(self.h, C.c_int(phase), C.c_void_p(d_buf_ptr)))
+
     def set_profiling(self, on=True):
         _check(self.L.slide_graph_set_profiling(self.h, C.c_int(int(on))))
 
@@ -274,6 +284,15 @@ class SlideBackend:
         _check(self.L.slide_backend_counts(self.h, _p(out), _p(pc), C.c_int(13)))
         return dict(cyl=int(out[0]), cube=int(out[1]), point=int(out[2]), factors=int(out[3]),
                     poses=pc[: self.n_robots].astype(np.int64))
+
+    def landmark_table(self, cls):
+        n = self.counts()[("cyl", "cube", "point")[cls]]
+        xyz = np.zeros((max(n, 1), 3))
+        lab = np.zeros(max(n, 1), np.int32)
+        k = self.L.slide_backend_landmark_table(self.h, C.c_int(cls), _p(xyz), _p(lab), C.c_int(n))
+        if k < 0:
+            _check(k)
+        return xyz[:k], lab[:k]
 
     def map_model(self, cls, idx):
         out = np.zeros(7)

@@ -55,6 +55,11 @@ struct GraphDev {
   // ---- landmark blocks -------------------------------------------------------------------
   double* lm_Hinv;   // 81 L  (d x d used)
   double* lm_g;      // 9 L
+  double* lm_Hacc;   // 54 L  packed lower H_ll (45) + g_l (9): partial sums exchanged between robots
+  double* lm_t;      // 9 L   sum_f E_f^T delta_p
+  int n_slots;       // shared-landmark slots of the multi-robot exchange (global, identical on every rank)
+  int* sh_lid;       // slot -> local landmark id or -1
+  int* sh_owner;     // slot -> 1 when this rank owns the landmark value
   // ---- pose blocks -----------------------------------------------------------------------
   double* pose_H;    // 36 P
   double* pose_g;    // 6 P   (already reduced: g_p - sum F g_l)

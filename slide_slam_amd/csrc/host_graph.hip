@@ -341,6 +341,8 @@ int HostGraph::upload_new() {
   if (d_ebuf.ensure(std::max<int64_t>(ebuf_used, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_lm_Hinv.ensure(std::max<size_t>(81 * Ln, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_lm_g.ensure(std::max<size_t>(9 * Ln, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_lm_Hacc.ensure(std::max<size_t>(54 * Ln, 1), 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_lm_t.ensure(std::max<size_t>(9 * Ln, 1), 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_pose_H.ensure(std::max<size_t>(36 * Pn, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_pose_g.ensure(std::max<size_t>(6 * Pn, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   std::vector<int> ptr, val;
@@ -386,6 +388,7 @@ int HostGraph::upload_new() {
   G.jbuf = d_jbuf.d; G.ebuf = d_ebuf.d;
   G.lm_ptr = d_lm_ptr.d; G.lm_fids = d_lm_fids.d; G.pose_ptr = d_pose_ptr.d; G.pose_fids = d_pose_fids.d; G.pose_lms = d_pose_lms.d;
   G.pose_bt_ptr = d_pose_bt_ptr.d; G.pose_bt = d_pose_bt.d;
+  G.lm_Hacc = d_lm_Hacc.d; G.lm_t = d_lm_t.d; G.n_slots = (int)h_sh_lid.size(); G.sh_lid = d_sh_lid.d; G.sh_owner = d_sh_owner.d;
   G.lm_Hinv = d_lm_Hinv.d; G.lm_g = d_lm_g.d; G.pose_H = d_pose_H.d; G.pose_g = d_pose_g.d;
   G.S = d_S.d; G.ld = (Tcap + 1) * NB; G.T = T; G.Ld = d_Ld.d; G.Winv = d_Winv.d; G.yv = d_yv.d; G.dp = d_dp.d;
   G.status = d_status.d;
@@ -403,7 +406,7 @@ int HostGraph::enqueue_iteration(bool lookahead) {
 #define STAGE(i, call) do { prof.begin(id[i], s); call; prof.end(s); } while (0)
   STAGE(0, launch_relin(G, s));
   STAGE(1, launch_linearize(G, s));
-  STAGE(2, launch_landmark(G, s));
+  STAGE(2, launch_landmark(G, 0, s));
   STAGE(3, launch_pose(G, s));
   STAGE(4, launch_schur(G, s));
   // Look-ahead over two streams: the diag+panel chain (critical path) stays on `s` together with the
@@ -434,7 +437,7 @@ int HostGraph::enqueue_iteration(bool lookahead) {
   STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, s));
   for (int k = G.T - 1; k >= 0; --k)
     STAGE(8, launch_chol_bwd(G.S, G.ld, k, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.yv, G.dp, s));
-  STAGE(9, launch_backsub(G, s));
+  STAGE(9, launch_backsub(G, 0, s));
   STAGE(10, launch_estimate(G, s));
 #undef STAGE
   return SLIDE_OK;
@@ -489,6 +492,97 @@ int HostGraph::run_update(double relin_thr, int iterations) {
     g_last_error = st[0] ? "landmark block not positive definite" : "reduced pose system not positive definite";
     return SLIDE_ERR_NOT_SPD;
   }
+  return SLIDE_OK;
+}
+
+// ---- one robot per GPU ---------------------------------------------------------------------------------
+// Slots are a global, rank-independent enumeration of the landmarks seen by more than one robot; slot i maps
+// to this rank's landmark (cls[i], idx[i]) or to none (cls[i] < 0).
+int HostGraph::set_shared(const int32_t* cls, const int64_t* idx, const int32_t* owner, int n_slots) {
+  int rc = merge_pending();
+  if (rc != SLIDE_OK) return rc;
+  rc = upload_new();
+  if (rc != SLIDE_OK) return rc;
+  h_sh_lid.assign(n_slots, -1);
+  h_sh_owner.assign(n_slots, 0);
+  for (int i = 0; i < n_slots; ++i) {
+    if (cls[i] < 0) continue;
+    const int lid = lm_lid(cls[i], (uint64_t)idx[i]);
+    if (lid < 0) { g_last_error = "set_shared: landmark is not in the graph"; return SLIDE_ERR_INVALID; }
+    h_sh_lid[i] = lid;
+    h_sh_owner[i] = owner[i] ? 1 : 0;
+  }
+  if (d_sh_lid.ensure(std::max(n_slots, 1), 0, stream) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_sh_owner.ensure(std::max(n_slots, 1), 0, stream) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_sh_lid.upload(h_sh_lid.data(), 0, n_slots, stream) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_sh_owner.upload(h_sh_owner.data(), 0, n_slots, stream) != SLIDE_OK) return SLIDE_ERR_HIP;
+  SL_HIP(hipStreamSynchronize(stream));
+  G.n_slots = n_slots; G.sh_lid = d_sh_lid.d; G.sh_owner = d_sh_owner.d;
+  return SLIDE_OK;
+}
+
+// Distributed Gauss-Newton pass = phase 0, all-reduce(buf: 54/slot), phase 1, all-reduce(buf: 9/slot), phase 2.
+//   0: relinearise (threshold 0), linearise, per-landmark partial sums, pack H_ll / g_l of the shared slots
+//   1: unpack the summed blocks, invert H_ll, pose reduce, Schur, Cholesky, pose solve, t_l, pack t_l
+//   2: unpack summed t_l, landmark back-substitution, estimate
+//  10: pack the owner's landmark values (15/slot)      11: unpack them (every rank adopts the owner's value)
+// Every robot solves its own reduced pose system with the GLOBAL landmark blocks (block-Jacobi over robots on
+// the Schur complement, exact gradient): the fixed point is the joint optimum.
+int HostGraph::dist_phase(int phase, double* d_buf) {
+  hipStream_t s = stream;
+  if (phase == 0) {
+    int rc = merge_pending();
+    if (rc != SLIDE_OK) return rc;
+    rc = upload_new();
+    if (rc != SLIDE_OK) return rc;
+    G.relin_thr = 0.0;
+    SL_HIP(hipMemsetAsync(d_status.d, 0, 8 * sizeof(int), s));
+    launch_relin(G, s);
+    launch_linearize(G, s);
+    launch_landmark(G, 1, s);
+    launch_shared_pack(G, 0, d_buf, s);
+  } else if (phase == 1) {
+    launch_shared_unpack(G, 0, d_buf, s);
+    launch_landmark(G, 2, s);
+    launch_pose(G, s);
+    launch_schur(G, s);
+    for (int k = 0; k < G.T; ++k) {
+      launch_chol_dp(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, s);
+      launch_chol_update(G.S, G.ld, k, G.T, 0, s);
+    }
+    launch_chol_extract_y(G.S, G.ld, G.T, G.yv, s);
+    for (int k = G.T - 1; k >= 0; --k)
+      launch_chol_bwd(G.S, G.ld, k, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.yv, G.dp, s);
+    launch_backsub(G, 1, s);
+    launch_shared_pack(G, 1, d_buf, s);
+  } else if (phase == 2) {
+    launch_shared_unpack(G, 1, d_buf, s);
+    launch_backsub(G, 2, s);
+    launch_estimate(G, s);
+    int st[8];
+    SL_HIP(hipMemcpyAsync(st, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    SL_HIP(hipGetLastError());
+    if (st[0] || st[1]) {
+      g_last_error = st[0] ? "landmark block not positive definite" : "reduced pose system not positive definite";
+      return SLIDE_ERR_NOT_SPD;
+    }
+    return SLIDE_OK;
+  } else if (phase == 10) {
+    // commit every variable (theta <- theta (+) delta, delta <- 0), then publish the owners' values
+    G.relin_thr = 0.0;
+    launch_relin(G, s);
+    if (G.P) SL_HIP(hipMemsetAsync(G.pose_delta, 0, 6 * (size_t)G.P * sizeof(double), s));
+    if (G.L) SL_HIP(hipMemsetAsync(G.lm_delta, 0, 9 * (size_t)G.L * sizeof(double), s));
+    launch_shared_pack(G, 2, d_buf, s);
+  } else if (phase == 11) {
+    launch_shared_unpack(G, 2, d_buf, s);
+    launch_estimate(G, s);
+  } else {
+    return SLIDE_ERR_INVALID;
+  }
+  SL_HIP(hipStreamSynchronize(s));
+  SL_HIP(hipGetLastError());
   return SLIDE_OK;
 }
 

@@ -106,6 +106,9 @@ class HostGraph {
   int get_pose12(int robot, uint64_t idx, double* out12);   // SLIDE_MISSING + identity when absent
   int get_landmark(int cls, uint64_t idx, double* out);
   int lm_lid(int cls, uint64_t idx) const;                   // -1 when not merged yet
+  // one-robot-per-GPU mode: shared-landmark slots + the three phases of a distributed GN pass
+  int set_shared(const int32_t* cls, const int64_t* idx, const int32_t* owner, int n_slots);
+  int dist_phase(int phase, double* d_buf);
   void stats(int64_t* out5) const;
 
   static uint64_t pose_key(int robot, uint64_t idx);
@@ -149,7 +152,9 @@ class HostGraph {
   DevArr<int64_t> d_lf_joff, d_lf_eoff;
   DevArr<double> d_br_z, d_cu_z, d_cu_sigma, d_cy_z, d_jbuf, d_ebuf;
   DevArr<int> d_lm_ptr, d_lm_fids, d_pose_ptr, d_pose_fids, d_pose_lms, d_pose_bt_ptr, d_pose_bt;
-  DevArr<double> d_lm_Hinv, d_lm_g, d_pose_H, d_pose_g;
+  DevArr<double> d_lm_Hinv, d_lm_g, d_pose_H, d_pose_g, d_lm_Hacc, d_lm_t;
+  DevArr<int> d_sh_lid, d_sh_owner;
+  std::vector<int> h_sh_lid, h_sh_owner;
   DevArr<double> d_S, d_Ld, d_Winv, d_yv, d_dp;
   DevArr<int> d_status;
   int Tcap = 0;

@@ -11,10 +11,12 @@ namespace sl {
 void init_solver_kernels();   // one-time kernel attributes (call outside stream capture)
 void launch_relin(const GraphDev& G, hipStream_t s);
 void launch_linearize(const GraphDev& G, hipStream_t s);
-void launch_landmark(const GraphDev& G, hipStream_t s);
+void launch_landmark(const GraphDev& G, int mode, hipStream_t s);      // mode: 0 fused, 1 accumulate, 2 finish from sums
 void launch_pose(const GraphDev& G, hipStream_t s);
 void launch_schur(const GraphDev& G, hipStream_t s);
-void launch_backsub(const GraphDev& G, hipStream_t s);
+void launch_backsub(const GraphDev& G, int mode, hipStream_t s);       // mode: 0 fused, 1 t_l only, 2 delta_l from t_l
+void launch_shared_pack(const GraphDev& G, int what, double* buf, hipStream_t s);
+void launch_shared_unpack(const GraphDev& G, int what, const double* buf, hipStream_t s);
 void launch_estimate(const GraphDev& G, hipStream_t s);
 
 // chol_kernels.hip — blocked right-looking FP64 Cholesky of the (T*NB)^2 lower matrix S (column-major,

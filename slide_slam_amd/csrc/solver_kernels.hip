@@ -262,7 +262,9 @@ __global__ __launch_bounds__(128) void k_lin_lf(GraphDev G) {
 // E = Jp^T Jl, F = E H_ll^-1, u = F g_l.   One WAVEFRONT per landmark: lanes own factors, the D(D+1)/2 + D
 // partial sums meet in a fixed xor-shuffle tree (deterministic), every lane inverts H_ll redundantly in
 // registers, then each lane finishes its own factors.  (M == D for all three landmark factor kinds.)
-template <int D>
+// MODE 0: everything (single GPU).  MODE 1: accumulate only, partial sums -> lm_Hacc (54 per landmark:
+// packed lower H then g) for the cross-robot all-reduce.  MODE 2: start from the (all-reduced) sums in lm_Hacc.
+template <int D, int MODE>
 __device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
   constexpr int NH = D * (D + 1) / 2;
   double h[NH], g[D];
@@ -271,7 +273,14 @@ __device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
 #pragma unroll
   for (int i = 0; i < D; ++i) g[i] = 0.0;
   const int f0 = G.lm_ptr[l], nf = G.lm_ptr[l + 1] - f0;
-  for (int q = lane; q < nf; q += 64) {
+  double* acc = G.lm_Hacc + 54 * (size_t)l;
+  if (MODE == 2) {
+#pragma unroll
+    for (int i = 0; i < NH; ++i) h[i] = acc[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) g[i] = acc[45 + i];
+  }
+  for (int q = lane; MODE != 2 && q < nf; q += 64) {
     const int f = G.lm_fids[f0 + q];
     const double* rec = G.jbuf + G.lf_joff[f];
     const double* Jl = rec + D + 6 * D;
@@ -289,12 +298,23 @@ __device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
       }
     }
   }
+  if (MODE != 2) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-    for (int i = 0; i < NH; ++i) h[i] += __shfl_xor(h[i], off);
+      for (int i = 0; i < NH; ++i) h[i] += __shfl_xor(h[i], off);
 #pragma unroll
-    for (int i = 0; i < D; ++i) g[i] += __shfl_xor(g[i], off);
+      for (int i = 0; i < D; ++i) g[i] += __shfl_xor(g[i], off);
+    }
+  }
+  if (MODE == 1) {
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < NH; ++i) acc[i] = h[i];
+#pragma unroll
+      for (int i = 0; i < D; ++i) acc[45 + i] = g[i];
+    }
+    return;
   }
   double* Hinv = G.lm_Hinv + 81 * (size_t)l;
   double* gout = G.lm_g + 9 * (size_t)l;
@@ -302,7 +322,7 @@ __device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
 #pragma unroll
     for (int a = 0; a < D; ++a) gout[a] = g[a];
   }
-  if (nf == 0) {
+  if (nf == 0 && MODE == 0) {
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < D * D; ++i) Hinv[i] = 0.0;
@@ -391,14 +411,15 @@ __device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
   }
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256) void k_landmark(GraphDev G) {
   const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (l >= G.L) return;
   const int lane = threadIdx.x & 63;
   const int type = G.lm_type[l];
-  if (type == VT_POINT) landmark_wave<3>(G, l, lane);
-  else if (type == VT_CUBE) landmark_wave<9>(G, l, lane);
-  else landmark_wave<7>(G, l, lane);
+  if (type == VT_POINT) landmark_wave<3, MODE>(G, l, lane);
+  else if (type == VT_CUBE) landmark_wave<9, MODE>(G, l, lane);
+  else landmark_wave<7, MODE>(G, l, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -577,34 +598,84 @@ __global__ void k_pad_rhs(GraphDev G) {
   G.S[(size_t)c * G.ld + r] = (c == r) ? 1.0 : 0.0;
 }
 
-// landmark back-substitution  delta_l = -H_ll^-1 (g_l + sum_f E_f^T delta_p), and delta_p = dp
+// landmark back-substitution  delta_l = -H_ll^-1 (g_l + sum_f E_f^T delta_p), and delta_p = dp.
+// MODE 0: everything.  MODE 1: only t_l = sum_f E_f^T delta_p -> lm_t (for the cross-robot all-reduce).
+// MODE 2: delta_l from the (all-reduced) t_l.
+template <int MODE>
 __global__ void k_backsub(GraphDev G) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < G.P) {
-    for (int k = 0; k < 6; ++k) G.pose_delta[6 * (size_t)t + k] = G.dp[6 * (size_t)t + k];
+    if (MODE != 2)
+      for (int k = 0; k < 6; ++k) G.pose_delta[6 * (size_t)t + k] = G.dp[6 * (size_t)t + k];
     return;
   }
   const int l = t - G.P;
   if (l >= G.L) return;
   const int D = lm_dim(G.lm_type[l]);
   double rhs[9];
-  for (int k = 0; k < D; ++k) rhs[k] = G.lm_g[9 * (size_t)l + k];
-  for (int q = G.lm_ptr[l]; q < G.lm_ptr[l + 1]; ++q) {
-    const int f = G.lm_fids[q];
-    const double* E = G.ebuf + G.lf_eoff[f];
-    const double* d = G.dp + 6 * (size_t)G.lf_pose[f];
-    for (int k = 0; k < D; ++k) {
-      double s = 0.0;
-      for (int a = 0; a < 6; ++a) s += E[a * D + k] * d[a];
-      rhs[k] += s;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) rhs[k] = 0.0;
+  if (MODE == 2) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) if (k < D) rhs[k] = G.lm_t[9 * (size_t)l + k];
+  } else {
+    for (int q = G.lm_ptr[l]; q < G.lm_ptr[l + 1]; ++q) {
+      const int f = G.lm_fids[q];
+      const double* E = G.ebuf + G.lf_eoff[f];
+      const double* d = G.dp + 6 * (size_t)G.lf_pose[f];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        if (k < D) {
+          double s = 0.0;
+#pragma unroll
+          for (int a = 0; a < 6; ++a) s += E[a * D + k] * d[a];
+          rhs[k] += s;
+        }
+      }
     }
   }
-  const double* Hi = G.lm_Hinv + 81 * (size_t)l;
-  for (int k = 0; k < D; ++k) {
-    double s = 0.0;
-    for (int c = 0; c < D; ++c) s += Hi[k * D + c] * rhs[c];
-    G.lm_delta[9 * (size_t)l + k] = -s;
+  if (MODE == 1) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) G.lm_t[9 * (size_t)l + k] = rhs[k];
+    return;
   }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) if (k < D) rhs[k] += G.lm_g[9 * (size_t)l + k];
+  const double* Hi = G.lm_Hinv + 81 * (size_t)l;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    if (k < D) {
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) if (c < D) s += Hi[k * D + c] * rhs[c];
+      G.lm_delta[9 * (size_t)l + k] = -s;
+    }
+  }
+}
+
+// ---- cross-robot exchange of shared landmarks (one robot per GPU) --------------------------
+// what 0: normal-equation partial sums (54 per slot: packed lower H_ll, g_l), what 1: t_l (9), what 2: the
+// landmark VALUE from its owner rank (15; other ranks contribute zeros so that an all-reduce(sum) broadcasts it).
+__global__ void k_shared_pack(GraphDev G, int what, double* __restrict__ buf) {
+  const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sidx >= G.n_slots) return;
+  const int l = G.sh_lid[sidx];
+  const int w = what == 0 ? 54 : (what == 1 ? 9 : 15);
+  double* o = buf + (size_t)w * sidx;
+  const bool live = l >= 0 && (what != 2 || G.sh_owner[sidx]);
+  const double* src = what == 0 ? G.lm_Hacc + 54 * (size_t)(l < 0 ? 0 : l) : (what == 1 ? G.lm_t + 9 * (size_t)(l < 0 ? 0 : l) : G.lm_val + 15 * (size_t)(l < 0 ? 0 : l));
+  for (int k = 0; k < w; ++k) o[k] = live ? src[k] : 0.0;
+}
+__global__ void k_shared_unpack(GraphDev G, int what, const double* __restrict__ buf) {
+  const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sidx >= G.n_slots) return;
+  const int l = G.sh_lid[sidx];
+  if (l < 0) return;
+  const int w = what == 0 ? 54 : (what == 1 ? 9 : 15);
+  const double* in = buf + (size_t)w * sidx;
+  double* dst = what == 0 ? G.lm_Hacc + 54 * (size_t)l : (what == 1 ? G.lm_t + 9 * (size_t)l : G.lm_val + 15 * (size_t)l);
+  const int nv = what == 2 ? (G.lm_type[l] == VT_POINT ? 3 : (G.lm_type[l] == VT_CUBE ? 15 : 7)) : w;
+  for (int k = 0; k < nv; ++k) dst[k] = in[k];
 }
 
 // calculateEstimate(): theta (+) delta
@@ -633,8 +704,11 @@ void launch_linearize(const GraphDev& G, hipStream_t s) {
     hipLaunchKernelGGL(k_lin_pose_factors, dim3(blocks_for(G.n_prior + G.n_between, 128)), dim3(128), 0, s, G);
   if (G.n_lf > 0) hipLaunchKernelGGL(k_lin_lf, dim3(blocks_for(G.n_lf, 128)), dim3(128), 0, s, G);
 }
-void launch_landmark(const GraphDev& G, hipStream_t s) {
-  if (G.L > 0) hipLaunchKernelGGL(k_landmark, dim3(blocks_for(G.L, 4)), dim3(256), 0, s, G);
+void launch_landmark(const GraphDev& G, int mode, hipStream_t s) {
+  if (G.L == 0) return;
+  if (mode == 0) hipLaunchKernelGGL(k_landmark<0>, dim3(blocks_for(G.L, 4)), dim3(256), 0, s, G);
+  else if (mode == 1) hipLaunchKernelGGL(k_landmark<1>, dim3(blocks_for(G.L, 4)), dim3(256), 0, s, G);
+  else hipLaunchKernelGGL(k_landmark<2>, dim3(blocks_for(G.L, 4)), dim3(256), 0, s, G);
 }
 void launch_pose(const GraphDev& G, hipStream_t s) {
   if (G.P > 0) hipLaunchKernelGGL(k_pose, dim3(blocks_for(G.P, 64)), dim3(64), 0, s, G);
@@ -646,9 +720,17 @@ void launch_schur(const GraphDev& G, hipStream_t s) {
   const long long tot = NT + (NT - 6LL * G.P) * NT;
   hipLaunchKernelGGL(k_pad_rhs, dim3(blocks_for(tot, 256)), dim3(256), 0, s, G);
 }
-void launch_backsub(const GraphDev& G, hipStream_t s) {
+void launch_backsub(const GraphDev& G, int mode, hipStream_t s) {
   if (G.P + G.L == 0) return;
-  hipLaunchKernelGGL(k_backsub, dim3(blocks_for(G.P + G.L, 128)), dim3(128), 0, s, G);
+  if (mode == 0) hipLaunchKernelGGL(k_backsub<0>, dim3(blocks_for(G.P + G.L, 128)), dim3(128), 0, s, G);
+  else if (mode == 1) hipLaunchKernelGGL(k_backsub<1>, dim3(blocks_for(G.P + G.L, 128)), dim3(128), 0, s, G);
+  else hipLaunchKernelGGL(k_backsub<2>, dim3(blocks_for(G.P + G.L, 128)), dim3(128), 0, s, G);
+}
+void launch_shared_pack(const GraphDev& G, int what, double* buf, hipStream_t s) {
+  if (G.n_slots > 0) hipLaunchKernelGGL(k_shared_pack, dim3(blocks_for(G.n_slots, 128)), dim3(128), 0, s, G, what, buf);
+}
+void launch_shared_unpack(const GraphDev& G, int what, const double* buf, hipStream_t s) {
+  if (G.n_slots > 0) hipLaunchKernelGGL(k_shared_unpack, dim3(blocks_for(G.n_slots, 128)), dim3(128), 0, s, G, what, buf);
 }
 void launch_estimate(const GraphDev& G, hipStream_t s) {
   if (G.P + G.L == 0) return;

@@ -1,0 +1,158 @@
+"""One robot per GPU: cross-robot landmark association and the distributed Gauss-Newton pass.
+
+The reference keeps a FULL replica of every robot's graph in every `sloam_node` and gossips packets over ROS
+topics (databaseManager.cpp:219-279; ingestion sloamNode.cpp:912-1002).  Here robot r's poses, factors and maps
+live on GPU r only; landmarks observed by several robots are replicated, and each Gauss-Newton pass exchanges
+just their normal-equation blocks:
+
+    phase 0 (local)   relinearise, linearise, per-landmark partial sums  H_ll^(r), g_l^(r)
+    all-reduce(sum)   54 doubles per shared landmark                         [RCCL over xGMI]
+    phase 1 (local)   invert the GLOBAL H_ll, Schur-reduce, factor and solve the robot's own pose system,
+                      t_l^(r) = sum_f E_f^T delta_p
+    all-reduce(sum)   9 doubles per shared landmark
+    phase 2 (local)   landmark back-substitution with the global t_l, retract
+
+i.e. block-Jacobi over robots on the reduced pose system with the exact gradient; its fixed point is the joint
+optimum the reference's replica converges to.  (Inter-robot relative-pose factors are not sharded yet.)
+
+`shard` is any object with ``landmark_table(cls)``, ``graph.set_shared``, ``graph.dist_phase`` — the product's
+``SlideBackend`` on a GPU, or (tests only) the oracle wrapper; `comm` moves the exchange buffer.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+CLASS_THRESH = {0: "cylinder_match_thresh", 1: "cuboid_match_thresh", 2: "ellipsoid_match_thresh"}
+
+
+def associate_global(tables, thresh=(2.0, 2.0, 0.75), matcher=None):
+    """Deterministic cross-robot landmark association, identical on every rank.
+
+    tables[r][cls] = (xyz [n,3], label [n]).  Robots are merged in rank order (as a host replica ingests the
+    other robots' packets): each landmark of robot r is matched against the global landmarks created by robots
+    < r of the same class with the reference's matcher rule (nearest, strict '<', label gate for ellipsoids and
+    cylinders) via `matcher(cls, xyz, label, map_xyz, map_label, thresh) -> index or -1`.
+    Returns gid[r][cls] (global id per local landmark) and n_global[cls]."""
+    R = len(tables)
+    gid = [[None] * 3 for _ in range(R)]
+    n_global = [0, 0, 0]
+    for cls in range(3):
+        gxyz = np.zeros((0, 3))
+        glab = np.zeros(0, np.int32)
+        for r in range(R):
+            xyz, lab = tables[r][cls]
+            n = len(lab)
+            ids = np.full(n, -1, np.int64)
+            if n and len(glab):
+                m = matcher(cls, xyz, lab, gxyz, glab, thresh[cls])
+                ids[:] = m
+                # two local landmarks may not collapse onto the same global one: keep the first
+                seen = set()
+                for i in range(n):
+                    if ids[i] >= 0:
+                        if int(ids[i]) in seen:
+                            ids[i] = -1
+                        else:
+                            seen.add(int(ids[i]))
+            new = np.nonzero(ids < 0)[0]
+            ids[new] = len(glab) + np.arange(len(new))
+            gxyz = np.vstack([gxyz, xyz[new]]) if len(new) else gxyz
+            glab = np.concatenate([glab, lab[new]]) if len(new) else glab
+            gid[r][cls] = ids
+        n_global[cls] = len(glab)
+    return gid, n_global
+
+
+def shared_slots(gid, n_global, rank):
+    """Slot table of this rank: slots enumerate (cls, global id) pairs observed by >= 2 robots, in a fixed
+    global order; the owner is the lowest rank observing the landmark."""
+    R = len(gid)
+    cls_out, idx_out, own_out = [], [], []
+    for cls in range(3):
+        count = np.zeros(n_global[cls], np.int32)
+        first = np.full(n_global[cls], -1, np.int32)
+        for r in range(R):
+            g = gid[r][cls]
+            count[g] += 1
+            for gg in g:
+                if first[gg] < 0:
+                    first[gg] = r
+        mine = {int(g): i for i, g in enumerate(gid[rank][cls])}
+        for g in np.nonzero(count >= 2)[0]:
+            if int(g) in mine:
+                cls_out.append(cls); idx_out.append(mine[int(g)]); own_out.append(int(first[g] == rank))
+            else:
+                cls_out.append(-1); idx_out.append(0); own_out.append(0)
+    return np.array(cls_out, np.int32), np.array(idx_out, np.int64), np.array(own_out, np.int32)
+
+
+class DistributedGraph:
+    def __init__(self, shard, comm, rank, world):
+        self.shard, self.comm, self.rank, self.world = shard, comm, rank, world
+        self.n_slots = 0
+
+    def setup(self, matcher, thresh=(2.0, 2.0, 0.75)):
+        """All-gather the landmark tables, associate them globally, install the shared slots and adopt the
+        owners' values for every shared landmark."""
+        mine = [self.shard.landmark_table(cls) for cls in range(3)]
+        tables = self.comm.all_gather_object(mine)
+        gid, n_global = associate_global(tables, thresh, matcher)
+        cls, idx, own = shared_slots(gid, n_global, self.rank)
+        self.n_slots = len(cls)
+        self.shard.graph.set_shared(cls, idx, own)
+        self.buf = self.comm.alloc(max(self.n_slots, 1) * 54)
+        self._phase(10)
+        self.comm.all_reduce(self.buf, self.n_slots * 15)
+        self._phase(11)
+        return dict(n_slots=self.n_slots, n_global=n_global)
+
+    def _phase(self, ph):
+        self.shard.graph.dist_phase(ph, self.comm.handle(self.buf))
+
+    def gauss_newton(self, iterations=1):
+        for _ in range(iterations):
+            self._phase(0)
+            self.comm.all_reduce(self.buf, self.n_slots * 54)
+            self._phase(1)
+            self.comm.all_reduce(self.buf, self.n_slots * 9)
+            self._phase(2)
+
+
+class TorchComm:
+    """torch.distributed plumbing: `nccl` (= RCCL over xGMI) with device buffers, or `gloo` with host buffers
+    (CPU tests; also lets several ranks share one GPU by staging through the host)."""
+
+    def __init__(self, device=None, stage_through_host=False):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.device = device
+        self.stage = stage_through_host
+
+    def all_gather_object(self, obj):
+        out = [None] * self.dist.get_world_size()
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def alloc(self, n):
+        if self.device is None:
+            return np.zeros(n)
+        return self.torch.zeros(n, dtype=self.torch.float64, device=self.device)
+
+    def handle(self, buf):
+        return buf if self.device is None else buf.data_ptr()
+
+    def all_reduce(self, buf, n):
+        if n == 0:
+            return
+        if self.device is None:
+            t = self.torch.from_numpy(buf[:n])
+            self.dist.all_reduce(t)
+        elif self.stage:
+            h = buf[:n].cpu()
+            self.dist.all_reduce(h)
+            buf[:n].copy_(h)
+            self.torch.cuda.synchronize()
+        else:
+            self.dist.all_reduce(buf[:n])
+            self.torch.cuda.synchronize()

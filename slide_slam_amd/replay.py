@@ -44,12 +44,25 @@ def replay_single(backend, log, robot=0, n_frames=None, collect=True):
     return out
 
 
-def replay_multi(backend, data, host=0, n_frames=None):
+def foreign_key_poses(own_backend, log):
+    """What a robot's OWN sloam node publishes for each key frame (PoseMstPair.keyPose, sloamNode.cpp:793-800):
+    poseEstimate = previous optimised key pose * relative raw odometry."""
+    out = replay_single(own_backend, log, robot=0)
+    P = len(log["rel7"])
+    kp = [np.asarray(log["rel7"][0], dtype=np.float64).copy()]
+    for k in range(1, P):
+        kp.append(_compose7(out["pose7"][k - 1], log["rel7"][k]))
+    return kp
+
+
+def replay_multi(backend, data, host=0, n_frames=None, own_node_factory=None):
     """Multi-robot replay on ONE host graph (the reference's per-host replica): per time step the host
     robot's own frame (add + solve), then every other robot's packet of that step is ingested
     (sloamNode.cpp:912-1002: associate against the host's maps, add, one solve per robot), then the
     map refresh + current-pose fetch (:1010-1014).  Inter-robot TFs are known a priori (identity:
-    all odometry is expressed in the common world frame, databaseManager.cpp:22-45 priorTFKnown)."""
+    all odometry is expressed in the common world frame, databaseManager.cpp:22-45 priorTFKnown).
+    The foreign key poses are the ones each robot's own node would publish; `own_node_factory()` builds such a
+    node (a fresh backend of the same kind)."""
     cfg = data["cfg"]
     logs = data["logs"]
     R = cfg.robots
@@ -58,6 +71,12 @@ def replay_multi(backend, data, host=0, n_frames=None):
     rel_by_step = {}
     for (k, a, b, rel) in data["relmeas"]:
         rel_by_step.setdefault(k, []).append((a, b, rel))
+    kposes = {}
+    for o in range(R):
+        if o != host:
+            if own_node_factory is None:
+                raise ValueError("replay_multi needs own_node_factory to produce the foreign robots' key poses")
+            kposes[o] = foreign_key_poses(own_node_factory(), logs[o])
     out = dict(host_pose7=[], ids=[])
     for k in range(P):
         det = frame_detections(logs[host], k)
@@ -68,10 +87,7 @@ def replay_multi(backend, data, host=0, n_frames=None):
         for o in range(R):
             if o == host:
                 continue
-            # foreign key pose = that robot's own dead-reckoned chain (it never sees the host's optimisation)
-            est = _compose7(prev[o], logs[o]["rel7"][k])
-            ro = backend.process_frame(o, logs[o]["rel7"][k], est, frame_detections(logs[o], k), 2)
-            prev[o] = est
+            ro = backend.process_frame(o, logs[o]["rel7"][k], kposes[o][k], frame_detections(logs[o], k), 2)
             ids.append((ro["cyl_id"].copy(), ro["cube_id"].copy(), ro["ell_id"].copy()))
             st = backend.ingest_solve()
             if st != 0:

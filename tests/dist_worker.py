@@ -1,0 +1,80 @@
+"""Worker of the multi-process tests: one robot per rank, distributed Gauss-Newton, results to a .npz.
+
+backend = oracle  -> CPU restatement shards, gloo all-reduce on host buffers   (runs anywhere; -m "not gpu")
+backend = gpu     -> HIP shards (all ranks on the visible GPU), gloo all-reduce staged through the host
+                     (RCCL needs one GPU per rank; the driver exercises that path with bench.py --gpus N)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def oracle_matcher(cls, xyz, lab, gxyz, glab, thresh):
+    import ctypes as C
+    from oracle import pyoracle as po
+    n, m = len(lab), len(glab)
+    out = np.full(max(n, 1), -1, np.int32)
+    P = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+    x, g = np.ascontiguousarray(xyz, dtype=np.float64), np.ascontiguousarray(gxyz, dtype=np.float64)
+    la, gl = np.ascontiguousarray(lab, dtype=np.int32), np.ascontiguousarray(glab, dtype=np.int32)
+    if cls == 0:   # cylinders: roots only are exchanged; vertical rays reproduce the matcher's point-at-height rule
+        ray = np.tile([0.0, 0.0, 1.0], (n, 1)); gray = np.tile([0.0, 0.0, 1.0], (m, 1))
+        rad = np.zeros(max(n, 1)); grad = np.zeros(max(m, 1))
+        po.lib().orc_match_cylinders(C.c_int(n), P(x), P(ray), P(rad), P(la), C.c_int(m), P(g), P(gray), P(grad), P(gl),
+                                     C.c_double(thresh), P(out))
+    else:
+        po.lib().orc_match_boxes(C.c_int(cls), C.c_int(n), P(x), P(la), C.c_int(m), P(g), P(gl), C.c_double(thresh), P(out))
+    return out[:n]
+
+
+def gpu_matcher(cls, xyz, lab, gxyz, glab, thresh):
+    import slide_slam_amd as s
+    if cls == 0:
+        n, m = len(lab), len(glab)
+        return s.match_cylinders(xyz, np.tile([0.0, 0.0, 1.0], (n, 1)), lab, gxyz, np.tile([0.0, 0.0, 1.0], (m, 1)), glab, thresh)
+    return s.match_boxes(cls, xyz, lab, gxyz, glab, thresh)
+
+
+def main():
+    backend, preset, iters, out_path = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from slide_slam_amd.distributed import DistributedGraph, TorchComm
+    from slide_slam_amd.replay import replay_single
+    from slide_slam_amd.synth import SynthConfig, make_robot_log, make_world
+    cfg = SynthConfig.preset(preset)
+    world_map = make_world(cfg)
+    log = make_robot_log(cfg, world_map, rank)
+    if backend == "oracle":
+        from oracle import pyoracle as po
+        shard = po.OracleBackend(po.OrcParams.default(), 1)
+        comm = TorchComm(device=None)
+        matcher = oracle_matcher
+    else:
+        import slide_slam_amd as s
+        torch.cuda.set_device(0)
+        shard = s.SlideBackend(s.default_params(), 1)
+        comm = TorchComm(device=torch.device("cuda", 0), stage_through_host=True)
+        matcher = gpu_matcher
+    # every rank's robot is "robot 0" of its own shard (symbol X); the rank is the robot id of the job
+    replay_single(shard, log, robot=0, collect=False)
+    dg = DistributedGraph(shard, comm, rank, world)
+    info = dg.setup(matcher)
+    dg.gauss_newton(iters)
+    P = len(log["rel7"])
+    poses = np.array([shard.graph.get_pose12(0, k)[1] for k in range(P)])
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (poses, info["n_slots"], info["n_global"]))
+    if rank == 0:
+        np.savez(out_path, poses=np.array([g[0] for g in gathered]), n_slots=gathered[0][1], n_global=np.array(gathered[0][2]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

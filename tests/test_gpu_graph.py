@@ -116,8 +116,8 @@ def test_replay_two_robots_one_host(gpu):
     data = make_dataset(SynthConfig.preset("C3tiny"))
     ob = po.OracleBackend(po.OrcParams.default(), 2)
     gb = gpu.SlideBackend(gpu.default_params(number_of_robots=2), 2)
-    o = replay_multi(ob, data)
-    g = replay_multi(gb, data)
+    o = replay_multi(ob, data, own_node_factory=lambda: po.OracleBackend(po.OrcParams.default(), 1))
+    g = replay_multi(gb, data, own_node_factory=lambda: gpu.SlideBackend(gpu.default_params(), 1))
     a, b = np.array(o["host_pose7"]), np.array(g["host_pose7"])
     assert np.abs(a - b).max() < 1e-4 * max(1.0, np.abs(a).max())
     for so, sg in zip(o["ids"], g["ids"]):
