@@ -88,10 +88,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     import torch
     dist = None
+    # SLIDE_BENCH_BACKEND=gloo rehearses the N > 1 path with every rank on GPU 0 (collectives staged through the
+    # host); the real runs use nccl (= RCCL over xGMI), one GPU per rank.
+    backend = os.environ.get("SLIDE_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else 0
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
     else:
         torch.cuda.set_device(0)
 
@@ -109,6 +116,19 @@ def main():
     t_build = time.perf_counter() - t_b0
     g = gb.graph
     st = g.stats()
+    dg_info = None
+    if world > 1:
+        # one robot per GPU: shared landmarks are associated across ranks once, then every Gauss-Newton pass
+        # exchanges their normal-equation blocks with two all-reduces (slide_slam_amd/distributed.py)
+        from slide_slam_amd.distributed import DistributedGraph, TorchComm
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from dist_worker import gpu_matcher
+        comm = TorchComm(device=torch.device("cuda", dev_index), stage_through_host=(backend != "nccl"))
+        dg = DistributedGraph(gb, comm, rank, world)
+        dg_info = dg.setup(gpu_matcher)
+        step = lambda: dg.gauss_newton(1)
+    else:
+        step = lambda: g.gauss_newton(1)
 
     def barrier():
         torch.cuda.synchronize()
@@ -117,11 +137,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        g.gauss_newton(1)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        g.gauss_newton(1)
+        step()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -163,7 +183,9 @@ def main():
             "data": "synthetic (seeded, slide_slam_amd/synth.py)",
             "config": {"workload": f"{cfg.name}: one robot sub-graph per GPU ({st['n_pose']} poses, {st['n_lm']} landmarks, "
                                    f"{st['n_factors']} factors on rank 0); N=8 is BASELINE configs[3]",
-                       "robots": world, "reduced_system_dim": n, "chol_tile": 64},
+                       "robots": world, "reduced_system_dim": n, "chol_tile": 64,
+                       "collective": None if world == 1 else f"{backend} all-reduce x2 per pass over {dg_info['n_slots']} shared-landmark slots "
+                                                               f"({dg_info['n_slots'] * 63 * 8} B per pass)"},
             "roofline": {"bound": "mfma", "kernel": "k_chol_update (v_mfma_f64_16x16x4_f64)", "achieved": ach,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": None, "flops_per_launch": flops_per_launch, "avg_launch_ms": upd_ms,
