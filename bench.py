@@ -160,9 +160,11 @@ def main():
     if rank == 0:
         T = st["chol_dim"] // 64
         n = st["chol_dim"]
-        # algorithmic FLOPs of the trailing updates of one factorisation (RHS row included): sum_k n_k^2 * 64
-        upd_flops = sum((((T - k - 1) * 64 + 1) ** 2) * 64.0 for k in range(T))
-        upd = prof.get("chol_update", dict(ms=0.0, launches=1))
+        # algorithmic FLOPs of one factorisation (RHS row included), per block column k with n_k rows below it:
+        # trailing update n_k^2 * 64 + triangular solve n_k * 64^2 + diagonal block 64^3 / 3   (= n^3/3 overall)
+        nk = [(T - k - 1) * 64 + 1 for k in range(T)]
+        upd_flops = sum(v * v * 64.0 + v * 64.0 * 64.0 + 64.0 ** 3 / 3.0 for v in nk)
+        upd = prof.get("chol_step", dict(ms=0.0, launches=1))
         upd_ms = upd["ms"] / max(upd["launches"], 1)
         upd_launches_per_iter = upd["launches"] / nprof
         flops_per_launch = upd_flops / max(upd_launches_per_iter, 1)
@@ -186,7 +188,7 @@ def main():
                        "robots": world, "reduced_system_dim": n, "chol_tile": 64,
                        "collective": None if world == 1 else f"{backend} all-reduce x2 per pass over {dg_info['n_slots']} shared-landmark slots "
                                                                f"({dg_info['n_slots'] * 63 * 8} B per pass)"},
-            "roofline": {"bound": "mfma", "kernel": "k_chol_update (v_mfma_f64_16x16x4_f64)", "achieved": ach,
+            "roofline": {"bound": "mfma", "kernel": "k_chol_step (v_mfma_f64_16x16x4_f64)", "achieved": ach,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": None, "flops_per_launch": flops_per_launch, "avg_launch_ms": upd_ms,
                          "launches_per_iter": upd_launches_per_iter, "dominant_by_time": dominant},

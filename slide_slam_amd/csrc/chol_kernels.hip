@@ -33,68 +33,234 @@ __device__ inline v4d mfma_f64(double a, double b, v4d c) { return __builtin_amd
 // Redundant factoring costs no latency (the blocks run concurrently) and removes a kernel boundary and the
 // L / W round trip through L2 from the critical path.  Workgroup 0 also publishes L_kk and the 16x16
 // inverses for the backward substitution.
+__device__ inline double rsqrt_nr(double d) {
+  // 1/sqrt(d): hardware estimate + two Newton steps (full double precision)
+  double y = __builtin_amdgcn_rsq(d);
+#ifndef EXP_NO_NR
+  y = y * (1.5 - 0.5 * d * y * y);
+  y = y * (1.5 - 0.5 * d * y * y);
+#endif
+  return y;
+}
+
+// Rank-4 elimination of the 64x64 diagonal tile held in registers (256 threads as a 16x16 grid, thread (ti, tj)
+// owns A[ti + 16p][tj + 16q]).  Columns j..j+3 are published together through a double-buffered LDS panel
+// (ONE barrier per FOUR columns); every thread redoes the 4x4 pivot Cholesky and the four-term substitution for
+// its own rows / columns.  While block column JQ is eliminated only the register blocks JQ <= q <= p change, and
+// the upper triangle of A is never read for a result, so two masks suffice (rows / columns <= j+3 of the pivot
+// block).  The inverse of the 16x16 diagonal sub-block (needed by the triangular solves) rides along: each
+// thread carries ONE element w of it and applies the same four-term substitution to it.
 template <int JQ>
-__device__ inline void diag_steps(double (&a)[4][4], double (*colraw)[NB], int ti, int tj, int* status) {
-  // Only the 16x16 register blocks with JQ <= q <= p can change while columns 16JQ..16JQ+15 are eliminated
-  // (blocks above / left of it are finished), and the upper triangle of A is never read for a result, so
-  // the update needs just two masks, both inside the pivot block: rows <= j and columns <= j are skipped.
+__device__ inline void diag_steps(double (&a)[4][4], double (&wfin)[4], double (*colraw)[4][NB], double (*wraw)[4][16], int ti,
+                                  int tj, int* status) {
+  double w = (ti == tj) ? 1.0 : 0.0;   // element (ti, tj) of the identity -> of L_bb^-1
 #pragma unroll 1
-  for (int jt = 0; jt < 16; ++jt) {
+  for (int jt = 0; jt < 16; jt += 4) {
     const int j = 16 * JQ + jt;
-    const int buf = j & 1;
-    if (tj == jt) {
+    const int buf = (jt >> 2) & 1;
+    const int rc = tj - jt;            // 0..3 when this thread owns one of the four pivot columns
+    if (rc >= 0 && rc < 4) {
 #pragma unroll
-      for (int p = JQ; p < 4; ++p) colraw[buf][ti + 16 * p] = a[p][JQ];
+      for (int p = JQ; p < 4; ++p) colraw[buf][rc][ti + 16 * p] = a[p][JQ];
     }
+    const int rr = ti - jt;            // 0..3 when this thread owns one of the four pivot rows of W
+    if (rr >= 0 && rr < 4) wraw[buf][rr][tj] = w;
+#ifndef EXP_NO_BARRIER
     __syncthreads();
-    double d = colraw[buf][j];
-    if (!(d > 0.0)) {
-      if (ti == 0 && tj == 0 && blockIdx.x == 0) atomicOr(&status[1], 1);
-      d = 1.0;
+#endif
+    const double* c0 = colraw[buf][0];
+    const double* c1 = colraw[buf][1];
+    const double* c2 = colraw[buf][2];
+    const double* c3 = colraw[buf][3];
+    // 4x4 pivot block (lower part)
+    double P00 = c0[j], P10 = c0[j + 1], P20 = c0[j + 2], P30 = c0[j + 3];
+    double P11 = c1[j + 1], P21 = c1[j + 2], P31 = c1[j + 3];
+    double P22 = c2[j + 2], P32 = c2[j + 3], P33 = c3[j + 3];
+    bool bad = !(P00 > 0.0);
+    if (bad) P00 = 1.0;
+    const double i0 = rsqrt_nr(P00);
+    const double l10 = P10 * i0, l20 = P20 * i0, l30 = P30 * i0;
+    double d1 = P11 - l10 * l10;
+    if (!(d1 > 0.0)) { bad = true; d1 = 1.0; }
+    const double i1 = rsqrt_nr(d1);
+    const double l21 = (P21 - l20 * l10) * i1, l31 = (P31 - l30 * l10) * i1;
+    double d2 = P22 - l20 * l20 - l21 * l21;
+    if (!(d2 > 0.0)) { bad = true; d2 = 1.0; }
+    const double i2 = rsqrt_nr(d2);
+    const double l32 = (P32 - l30 * l20 - l31 * l21) * i2;
+    double d3 = P33 - l30 * l30 - l31 * l31 - l32 * l32;
+    if (!(d3 > 0.0)) { bad = true; d3 = 1.0; }
+    const double i3 = rsqrt_nr(d3);
+    if (bad && ti == 0 && tj == 0 && blockIdx.x == 0) atomicOr(&status[1], 1);
+    // four-term forward substitution  (v0..v3) -> (x0..x3) = L_piv^-1 v
+#define SUBST4(v0, v1, v2, v3, x0, x1, x2, x3)          \
+    const double x0 = (v0) * i0;                          \
+    const double x1 = ((v1) - x0 * l10) * i1;             \
+    const double x2 = ((v2) - x0 * l20 - x1 * l21) * i2;  \
+    const double x3 = ((v3) - x0 * l30 - x1 * l31 - x2 * l32) * i3;
+    double X0[4], X1[4], X2[4], X3[4], Y0[4], Y1[4], Y2[4], Y3[4];
+#pragma unroll
+    for (int p = JQ; p < 4; ++p) {
+      const int i = ti + 16 * p;
+      SUBST4(c0[i], c1[i], c2[i], c3[i], x0, x1, x2, x3)
+      X0[p] = x0; X1[p] = x1; X2[p] = x2; X3[p] = x3;
     }
-    // 1/sqrt(d): hardware estimate + two Newton steps (full double precision)
-    double inv = __builtin_amdgcn_rsq(d);
-    inv = inv * (1.5 - 0.5 * d * inv * inv);
-    inv = inv * (1.5 - 0.5 * d * inv * inv);
-    double li[4], lk[4];
 #pragma unroll
-    for (int p = JQ; p < 4; ++p) li[p] = colraw[buf][ti + 16 * p] * inv;
-#pragma unroll
-    for (int q = JQ; q < 4; ++q) lk[q] = colraw[buf][tj + 16 * q] * inv;
-    const double li0 = (ti > jt) ? li[JQ] : 0.0;      // rows <= j of the pivot block take no update
-    const double lk0 = (tj > jt) ? lk[JQ] : 0.0;      // columns <= j are finished
+    for (int q = JQ; q < 4; ++q) {
+      const int c = tj + 16 * q;
+      SUBST4(c0[c], c1[c], c2[c], c3[c], y0, y1, y2, y3)
+      Y0[q] = y0; Y1[q] = y1; Y2[q] = y2; Y3[q] = y3;
+    }
+    const bool rlive = ti > jt + 3, clive = tj > jt + 3;
+    const double x0m = rlive ? X0[JQ] : 0.0, x1m = rlive ? X1[JQ] : 0.0, x2m = rlive ? X2[JQ] : 0.0, x3m = rlive ? X3[JQ] : 0.0;
+    const double y0m = clive ? Y0[JQ] : 0.0, y1m = clive ? Y1[JQ] : 0.0, y2m = clive ? Y2[JQ] : 0.0, y3m = clive ? Y3[JQ] : 0.0;
 #pragma unroll
     for (int p = JQ; p < 4; ++p)
 #pragma unroll
-      for (int q = JQ; q <= p; ++q) a[p][q] -= (p == JQ ? li0 : li[p]) * (q == JQ ? lk0 : lk[q]);
-    if (tj == jt) {
+      for (int q = JQ; q <= p; ++q) {
+        const double e0 = (p == JQ ? x0m : X0[p]), e1 = (p == JQ ? x1m : X1[p]), e2 = (p == JQ ? x2m : X2[p]), e3 = (p == JQ ? x3m : X3[p]);
+        const double f0 = (q == JQ ? y0m : Y0[q]), f1 = (q == JQ ? y1m : Y1[q]), f2 = (q == JQ ? y2m : Y2[q]), f3 = (q == JQ ? y3m : Y3[q]);
+        a[p][q] -= e0 * f0 + e1 * f1 + e2 * f2 + e3 * f3;
+      }
+    // inverse of the diagonal sub-block: rows j..j+3 of W become L_piv^-1 (rows), rows below take the update
+    {
+      const double* w0 = wraw[buf][0];
+      SUBST4(w0[tj], wraw[buf][1][tj], wraw[buf][2][tj], wraw[buf][3][tj], z0, z1, z2, z3)
+      if (rlive) w -= X0[JQ] * z0 + X1[JQ] * z1 + X2[JQ] * z2 + X3[JQ] * z3;
+      if (rr == 0) w = z0; else if (rr == 1) w = z1; else if (rr == 2) w = z2; else if (rr == 3) w = z3;
+    }
+#undef SUBST4
+    if (rc >= 0 && rc < 4) {
 #pragma unroll
-      for (int p = JQ; p < 4; ++p) a[p][JQ] = li[p];   // column j of L (rows >= j; rows above stay unread)
+      for (int p = JQ; p < 4; ++p) a[p][JQ] = (rc == 0) ? X0[p] : (rc == 1) ? X1[p] : (rc == 2) ? X2[p] : X3[p];   // columns j..j+3 of L
     }
   }
+  wfin[JQ] = w;
 }
 
+#ifdef SLIDE_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i)
+#endif
 constexpr int LSTR = 80;   // LDS column stride of the factored block: two adjacent columns fall in disjoint banks
 
-__global__ __launch_bounds__(256) void k_chol_dp(double* __restrict__ S, int ld, int k, double* __restrict__ Ld,
-                                                 double* __restrict__ Winv, int* status) {
-  __shared__ double colraw[2][NB];
-  __shared__ double Ls[NB * LSTR];        // Ls[c * LSTR + r] = L[r][c]
+// ------------------------------------------------------------------------------------------------
+// ONE kernel per block column k ("step kernel").  Two kinds of workgroups share the launch:
+//  type A (blockIdx < nA = T - k, dispatched first): tile (i, k), i = k+1..T (T = the RHS tile).  It applies
+//     the trailing update of panel k-1 to its own tile AND (redundantly) to the diagonal tile (k, k), factors
+//     the diagonal tile in registers, inverts its four 16x16 diagonal sub-blocks and solves its own 64 rows
+//     X = A L^-T by blocked substitution on v_mfma_f64_16x16x4_f64 — i.e. the whole "look-ahead" chain of
+//     column k without any inter-workgroup dependency.  Redundant factoring costs no latency (the blocks run
+//     concurrently) and keeps L_kk / its inverses out of L2 round trips.
+//  type B: tile (i, j), j >= k+1: plain trailing update with panel k-1 (C_ij -= L_i,k-1 L_j,k-1^T).
+// The long type-A blocks therefore run BESIDE the memory-bound type-B flood inside one launch; the next step
+// needs only the kernel boundary.  MFMA accumulator layout of X_c^T (row (lane>>4) + 4r, column lane&15) is
+// exactly the B-operand layout of k-step r, so chained products need no lane movement.
+__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Ld,
+                                                   double* __restrict__ Winv, int* status) {
+  __shared__ double colraw[2][4][NB];
+  __shared__ double wraw[2][4][16];
+  __shared__ double Ls[NB * LSTR];        // Ls[c * LSTR + r] = L[r][c]  (first used to re-shape the updated diagonal tile)
   __shared__ double Wi[4][16 * 16];       // Wi[b][c * 16 + r] = (L_bb^-1)[r][c]
-  const int tid = threadIdx.x, ti = tid & 15, tj = tid >> 4;
-  const double* dg = S + (size_t)(k * NB) * ld + (size_t)k * NB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int nA = T - k;
+  if ((int)blockIdx.x >= nA) {
+    // ---------------- type B: trailing update of one 64x64 tile with panel k-1 ----------------
+    const long long t = (long long)blockIdx.x - nA;
+    long long ii = (long long)floor((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while (ii * (ii + 1) / 2 > t) --ii;
+    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+    const int jj = (int)(t - ii * (ii + 1) / 2);
+    const int i = k + 1 + (int)ii, j = k + 1 + jj;
+    const int m0 = 32 * (wave >> 1), n0 = 32 * (wave & 1);
+    const double* pj = S + (size_t)((k - 1) * NB) * ld + (size_t)j * NB + n0 + lr;
+    const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)i * NB + m0 + lr;
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const size_t off = (size_t)(4 * ks + lk) * ld;
+      const double a0 = pj[off], a1 = pj[off + 16];
+      const double b0 = pi[off], b1 = pi[off + 16];
+      acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+      acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+      acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+      acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+    }
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double* c = S + (size_t)(j * NB + n0 + 16 * pb + lk + 4 * r) * ld + (size_t)i * NB + m0 + 16 * qb + lr;
+          *c -= acc[pb][qb][r];
+        }
+    return;
+  }
+  // ---------------- type A ----------------
+  STAMP(0);
+  const int it = k + 1 + blockIdx.x;
+  const int ti = tid & 15, tj = tid >> 4;
+  // own rows (16 per wave) of tile (it, k) and of the diagonal tile (k, k), both in the transposed MFMA layout
+  // t[b][r] = A[row 16*wave + lr][col 16b + lk + 4r]
+  double* col = S + (size_t)(k * NB) * ld + (size_t)it * NB + 16 * wave + lr;
+  const double* dcol = S + (size_t)(k * NB) * ld + (size_t)k * NB + 16 * wave + lr;
+  v4d tt[4], dd[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      tt[b][r] = col[(size_t)(16 * b + lk + 4 * r) * ld];
+      dd[b][r] = dcol[(size_t)(16 * b + lk + 4 * r) * ld];
+    }
+  STAMP(1);
+  if (k > 0) {
+    // pending update from panel k-1:  A[m][n] -= sum_kk L[m][kk] * L_k[n][kk]   (L_k = rows of tile row k)
+    const double* pk = S + (size_t)((k - 1) * NB) * ld + (size_t)k * NB + lr;             // + 16 b : L_k[16b + lr][.]
+    const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)it * NB + 16 * wave + lr;   // own rows
+    const double* pd = S + (size_t)((k - 1) * NB) * ld + (size_t)k * NB + 16 * wave + lr;    // diagonal tile's rows
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const size_t off = (size_t)(4 * ks + lk) * ld;
+      const double bi = pi[off], bd = pd[off];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const double aop = -pk[off + 16 * b];
+        tt[b] = mfma_f64(aop, bi, tt[b]);
+        dd[b] = mfma_f64(aop, bd, dd[b]);
+      }
+    }
+  }
+  STAMP(2);
+  // re-shape the (updated) diagonal tile through LDS into the factorisation layout a[p][q] = A[ti + 16p][tj + 16q]
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ls[(16 * b + lk + 4 * r) * LSTR + 16 * wave + lr] = dd[b][r];
+  __syncthreads();
   double a[4][4];
 #pragma unroll
   for (int p = 0; p < 4; ++p)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = ti + 16 * p, c = tj + 16 * q;
-      a[p][q] = (i >= c) ? dg[(size_t)c * ld + i] : 0.0;
+      a[p][q] = (i >= c) ? Ls[c * LSTR + i] : 0.0;
     }
-  diag_steps<0>(a, colraw, ti, tj, status);
-  diag_steps<1>(a, colraw, ti, tj, status);
-  diag_steps<2>(a, colraw, ti, tj, status);
-  diag_steps<3>(a, colraw, ti, tj, status);
+  __syncthreads();
+  STAMP(3);
+  double wfin[4];
+  diag_steps<0>(a, wfin, colraw, wraw, ti, tj, status);
+  diag_steps<1>(a, wfin, colraw, wraw, ti, tj, status);
+  diag_steps<2>(a, wfin, colraw, wraw, ti, tj, status);
+  diag_steps<3>(a, wfin, colraw, wraw, ti, tj, status);
+  STAMP(4);
 #pragma unroll
   for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -104,40 +270,19 @@ __global__ __launch_bounds__(256) void k_chol_dp(double* __restrict__ S, int ld,
       Ls[c * LSTR + i] = v;
       if (blockIdx.x == 0) Ld[(size_t)c * NB + i] = v;
     }
-  __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
-  {
-    // wave b inverts the 16x16 lower-triangular block L_bb: lane c solves L x = e_c (forward substitution,
-    // fully unrolled so x[] stays in registers)
-    const int bb = wave;
-    if (lane < 16) {
-      const int c = lane;
-      double x[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        double s = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int m = 0; m < i; ++m) s -= Ls[(16 * bb + m) * LSTR + 16 * bb + i] * x[m];
-        x[i] = (i >= c) ? s / Ls[(16 * bb + i) * LSTR + 16 * bb + i] : 0.0;
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        Wi[bb][c * 16 + i] = x[i];
-        if (blockIdx.x == 0) Winv[(size_t)bb * 256 + c * 16 + i] = x[i];
-      }
-    }
+  for (int bq = 0; bq < 4; ++bq) {
+    const double v = (ti >= tj) ? wfin[bq] : 0.0;          // (L_bb^-1)[ti][tj]
+    Wi[bq][tj * 16 + ti] = v;
+    if (blockIdx.x == 0) Winv[(size_t)bq * 256 + tj * 16 + ti] = v;
   }
   __syncthreads();
-  // blocked triangular solve of this workgroup's 64 rows (16 per wave)
-  const int it = k + 1 + blockIdx.x;
-  const int lr = lane & 15, lk = lane >> 4;
-  double* col = S + (size_t)(k * NB) * ld + (size_t)it * NB + 16 * wave + lr;
+  STAMP(5);
+  // blocked triangular solve of this workgroup's 64 rows (16 per wave), operands already in registers
   v4d xt[4];
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
-    v4d t;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) t[r] = col[(size_t)(16 * b + lk + 4 * r) * ld];      // Tmp^T[n = lk + 4r][m = lr]
+    v4d t = tt[b];
 #pragma unroll
     for (int c = 0; c < b; ++c)
 #pragma unroll
@@ -155,44 +300,11 @@ __global__ __launch_bounds__(256) void k_chol_dp(double* __restrict__ S, int ld,
 #pragma unroll
     for (int r = 0; r < 4; ++r) col[(size_t)(16 * b + lk + 4 * r) * ld] = x[r];
   }
+  STAMP(6);
 }
-
-// C_ij -= L_ik L_jk^T over trailing tiles: rows i = i0 + blockIdx.x, columns j = j0 + blockIdx.y (i >= j;
-// blocks above the diagonal exit at once).  i == T is the RHS tile.
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int ld, int k, int i0, int j0) {
-  const int i = i0 + blockIdx.x, j = j0 + blockIdx.y;
-  if (i < j) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m0 = 32 * (wave >> 1), n0 = 32 * (wave & 1);
-  const int lr = lane & 15, lk = lane >> 4;
-  const double* pj = S + (size_t)(k * NB) * ld + (size_t)j * NB + n0 + lr;
-  const double* pi = S + (size_t)(k * NB) * ld + (size_t)i * NB + m0 + lr;
-  v4d acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    const size_t off = (size_t)(4 * ks + lk) * ld;
-    const double a0 = pj[off], a1 = pj[off + 16];
-    const double b0 = pi[off], b1 = pi[off + 16];
-    acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
-    acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
-    acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
-    acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
-  }
-  // D[p][q]: C[m = m0 + 16 qb + q][n = n0 + 16 pb + p], p = lk + 4 r, q = lr
-#pragma unroll
-  for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double* c = S + (size_t)(j * NB + n0 + 16 * pb + lk + 4 * r) * ld + (size_t)i * NB + m0 + 16 * qb + lr;
-        *c -= acc[pb][qb][r];
-      }
-}
+#ifdef SLIDE_STAMPS
+extern "C" void slide_debug_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
+#endif
 
 __global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, double* __restrict__ yv) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -253,19 +365,10 @@ __global__ __launch_bounds__(256) void k_chol_bwd(const double* __restrict__ S, 
 }
 
 // ------------------------------------------------------------------------------------------------
-void launch_chol_dp(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, hipStream_t s) {
-  const int nt = T - k;  // row tiles below the diagonal block, incl. the RHS tile (>= 1)
-  hipLaunchKernelGGL(k_chol_dp, dim3(nt), dim3(256), 0, s, S, ld, k, Ld, Winv, status);
-}
-// part 0: every trailing tile; part 1: only column k+1 (what the next diag+panel step needs);
-// part 2: columns >= k+2 (can run beside the next diag+panel step on a second stream)
-void launch_chol_update(double* S, int ld, int k, int T, int part, hipStream_t s) {
-  int j0 = k + 1, j1 = T - 1;            // column tiles [j0, j1]
-  if (part == 1) j1 = k + 1;
-  if (part == 2) j0 = k + 2;
-  if (j0 > j1 || j0 > T - 1) return;
-  const int rows = T - j0 + 1;           // row tiles j0 .. T (RHS tile included)
-  hipLaunchKernelGGL(k_chol_update, dim3(rows, j1 - j0 + 1), dim3(256), 0, s, S, ld, k, j0, j0);
+void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, hipStream_t s) {
+  const long long nA = T - k;                                   // column-k tiles below the diagonal (+ RHS tile)
+  const long long nB = k > 0 ? nA * (nA + 1) / 2 - 1 : 0;       // trailing tiles that still owe the update of panel k-1
+  hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nA + nB)), dim3(256), 0, s, S, ld, k, T, Ld, Winv, status);
 }
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, hipStream_t s) {
   hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv);
@@ -276,10 +379,7 @@ void launch_chol_bwd(const double* S, int ld, int k, const double* Ld, const dou
 }
 
 int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double* yv, double* dp, int* status, hipStream_t s) {
-  for (int k = 0; k < T; ++k) {
-    launch_chol_dp(S, ld, k, T, Ld + (size_t)k * NB * NB, Winv + (size_t)k * 1024, status, s);
-    launch_chol_update(S, ld, k, T, 0, s);
-  }
+  for (int k = 0; k < T; ++k) launch_chol_step(S, ld, k, T, Ld + (size_t)k * NB * NB, Winv + (size_t)k * 1024, status, s);
   launch_chol_extract_y(S, ld, T, yv, s);
   for (int k = T - 1; k >= 0; --k) launch_chol_bwd(S, ld, k, Ld + (size_t)k * NB * NB, Winv + (size_t)k * 1024, yv, dp, s);
   return 0;

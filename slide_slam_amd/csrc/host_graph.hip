@@ -399,8 +399,8 @@ int HostGraph::upload_new() {
 
 int HostGraph::enqueue_iteration(bool lookahead) {
   hipStream_t s = stream;
-  static const char* kNames[] = {"relin", "linearize", "landmark_reduce", "pose_reduce", "schur_assemble", "chol_diag_panel",
-                                 "chol_update", "chol_extract_y", "chol_bwd", "backsub", "estimate"};
+  static const char* kNames[] = {"relin", "linearize", "landmark_reduce", "pose_reduce", "schur_assemble", "chol_step",
+                                 "chol_unused", "chol_extract_y", "chol_bwd", "backsub", "estimate"};
   int id[11];
   for (int i = 0; i < 11; ++i) id[i] = prof.id_of(kNames[i]);
 #define STAGE(i, call) do { prof.begin(id[i], s); call; prof.end(s); } while (0)
@@ -409,31 +409,9 @@ int HostGraph::enqueue_iteration(bool lookahead) {
   STAGE(2, launch_landmark(G, 0, s));
   STAGE(3, launch_pose(G, s));
   STAGE(4, launch_schur(G, s));
-  // Look-ahead over two streams: the diag+panel chain (critical path) stays on `s` together with the
-  // update of tile column k+1; the rest of trailing update k runs on stream2 beside diag+panel k+1.
-  while ((int)ev_dp.size() < G.T) {
-    hipEvent_t e1, e2;
-    SL_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-    SL_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-    ev_dp.push_back(e1);
-    ev_upd.push_back(e2);
-  }
-  for (int k = 0; k < G.T; ++k) {
-    if (!lookahead) {
-      STAGE(5, launch_chol_dp(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, s));
-      STAGE(6, launch_chol_update(G.S, G.ld, k, G.T, 0, s));
-      continue;
-    }
-    if (k >= 2) SL_HIP(hipStreamWaitEvent(s, ev_upd[k - 2], 0));    // column k complete
-    launch_chol_dp(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, s);
-    SL_HIP(hipEventRecord(ev_dp[k], s));
-    SL_HIP(hipStreamWaitEvent(stream2, ev_dp[k], 0));
-    launch_chol_update(G.S, G.ld, k, G.T, 2, stream2);
-    SL_HIP(hipEventRecord(ev_upd[k], stream2));
-    if (k >= 1) SL_HIP(hipStreamWaitEvent(s, ev_upd[k - 1], 0));    // column k+1 has every earlier update
-    launch_chol_update(G.S, G.ld, k, G.T, 1, s);
-  }
-  if (lookahead) SL_HIP(hipStreamWaitEvent(s, ev_upd[G.T - 1], 0));
+  (void)lookahead;
+  for (int k = 0; k < G.T; ++k)
+    STAGE(5, launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, s));
   STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, s));
   for (int k = G.T - 1; k >= 0; --k)
     STAGE(8, launch_chol_bwd(G.S, G.ld, k, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.yv, G.dp, s));
@@ -546,10 +524,8 @@ int HostGraph::dist_phase(int phase, double* d_buf) {
     launch_landmark(G, 2, s);
     launch_pose(G, s);
     launch_schur(G, s);
-    for (int k = 0; k < G.T; ++k) {
-      launch_chol_dp(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, s);
-      launch_chol_update(G.S, G.ld, k, G.T, 0, s);
-    }
+    for (int k = 0; k < G.T; ++k)
+      launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, s);
     launch_chol_extract_y(G.S, G.ld, G.T, G.yv, s);
     for (int k = G.T - 1; k >= 0; --k)
       launch_chol_bwd(G.S, G.ld, k, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.yv, G.dp, s);

@@ -21,8 +21,7 @@ void launch_estimate(const GraphDev& G, hipStream_t s);
 
 // chol_kernels.hip — blocked right-looking FP64 Cholesky of the (T*NB)^2 lower matrix S (column-major,
 // leading dimension ld = (T+1)*NB; the extra row tile carries the right-hand side), tile edge NB = 64.
-void launch_chol_dp(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, hipStream_t s);
-void launch_chol_update(double* S, int ld, int k, int T, int part, hipStream_t s);
+void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, hipStream_t s);
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, hipStream_t s);
 void launch_chol_bwd(const double* S, int ld, int k, const double* Ld, const double* Winv, double* yv, double* dp, hipStream_t s);
 // stand-alone dense SPD solve on device buffers (used by the unit tests and the roofline bench leg)
