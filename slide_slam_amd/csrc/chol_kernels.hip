@@ -311,56 +311,127 @@ __global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, do
   if (c < T * NB) yv[c] = S[(size_t)c * ld + (size_t)T * NB];
 }
 
-// backward substitution step k:  d_k = L_kk^-T y_k (blocked, with the 16x16 inverses) ;
-// y_c -= L[k-block, c]^T d_k for every column c < k*NB.  One workgroup per 64 columns: the 64x64 tile of L is read
-// in whole 512-byte column runs and reduced over rows through an LDS transpose, 4 threads per column.
-__global__ __launch_bounds__(256) void k_chol_bwd(const double* __restrict__ S, int ld, int k, const double* __restrict__ Ld,
-                                                  const double* __restrict__ Winv, double* __restrict__ yv,
-                                                  double* __restrict__ dp) {
-  __shared__ double yk[NB];
-  __shared__ double dk[NB];
+// Backward substitution, BWD_GROUP block steps per launch (blocks kTop, kTop-1, ... in descending order).
+// Every workgroup redundantly solves the small dense chunk of the group (d_kb = L_kb,kb^-T (y_kb - couplings inside
+// the group), with the 16x16 inverses of the factorisation) and then applies the group's L tiles to its own 64
+// columns:  y_c -= L[kb-block, c]^T d_kb.  EVERYTHING the chain needs (coupling tiles, own tiles, the off-diagonal
+// 16x16 blocks of each L_kk and the 16x16 inverses) is fetched up front into registers in one wave of loads, so
+// the dependent phases run from registers / LDS only; tiles are reduced over rows through an LDS transpose.
+constexpr int BWD_GROUP = 3;
+
+__device__ inline double bwd_tile_dot(double (*tile)[NB + 1], const double* d, int tid) {
+  const int c = tid >> 2, part = tid & 3;
+  double s = 0.0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += tile[c][16 * part + r] * d[16 * part + r];
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  return s;   // valid where part == 0
+}
+
+__global__ __launch_bounds__(256) void k_chol_bwd(const double* __restrict__ S, int ld, int kTop, int nsteps,
+                                                  const double* __restrict__ Ld, const double* __restrict__ Winv,
+                                                  double* __restrict__ yv, double* __restrict__ dp) {
+  constexpr int G = BWD_GROUP;
+  __shared__ double yk[G][NB];
+  __shared__ double dk[G][NB];
   __shared__ double tile[NB][NB + 1];
+  __shared__ double Lo[G][6][256];   // off-diagonal 16x16 blocks (b > c) of L_kb,kb : Lo[s][b*(b-1)/2 + c][col*16 + row]
+  __shared__ double Ws[G][4][256];   // 16x16 inverses
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c0 = blockIdx.x * NB;
-  const bool has_cols = c0 < k * NB;
-  if (has_cols) {
-    for (int cc = wave; cc < NB; cc += 4) tile[cc][lane] = S[(size_t)(c0 + cc) * ld + (size_t)k * NB + lane];
-  }
-  if (tid < NB) yk[tid] = yv[k * NB + tid];
-  __syncthreads();
-  if (wave == 0) {
-    // x_b = W_b^T (y_b - sum_{c > b} L_cb^T x_c),  b = 3..0 ;  one wave, LDS traffic only within the wave
-#pragma unroll 1
-    for (int b = 3; b >= 0; --b) {
-      if (lane < 16) {
-        double s = 0.0;
-        const double* w = Winv + (size_t)b * 256 + lane * 16;     // column `lane` of W_b: (W_b)[j][lane]
+  const int cb = blockIdx.x;
+  const bool has_cols = cb < kTop - nsteps + 1;
+  // ---- one wave of loads -------------------------------------------------------------------------------
+  double tc[G][G][16];   // coupling tiles  (rows block kTop - sp, columns block kTop - sI), sp < sI
+  double to[G][16];      // own tiles       (rows block kTop - sI, columns block cb)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) s += w[j] * yk[16 * b + j];
-        dk[16 * b + lane] = s;
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (lane < 16 * b) {
-        // y[m] -= sum_n L[16b + n][m] x_n   (column m of L_kk, rows 16b..16b+15 contiguous)
-        const double* lc = Ld + (size_t)lane * NB + 16 * b;
-        double s = 0.0;
+  for (int sI = 0; sI < G; ++sI) {
 #pragma unroll
-        for (int n = 0; n < 16; ++n) s += lc[n] * dk[16 * b + n];
-        yk[lane] -= s;
+    for (int sp = 0; sp < G; ++sp) {
+      if (sp < sI) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+          tc[sp][sI][m] = (sI < nsteps) ? S[(size_t)((kTop - sI) * NB + wave + 4 * m) * ld + (size_t)(kTop - sp) * NB + lane] : 0.0;
       }
-      __builtin_amdgcn_wave_barrier();
     }
-    if (blockIdx.x == 0) dp[k * NB + lane] = dk[lane];
-  }
-  __syncthreads();
-  if (has_cols) {
-    const int c = tid >> 2, part = tid & 3;
-    double s = 0.0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s += tile[c][16 * part + r] * dk[16 * part + r];
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    if (part == 0) yv[c0 + c] -= s;
+    for (int m = 0; m < 16; ++m)
+      to[sI][m] = (has_cols && sI < nsteps) ? S[(size_t)(cb * NB + wave + 4 * m) * ld + (size_t)(kTop - sI) * NB + lane] : 0.0;
+  }
+#pragma unroll
+  for (int sI = 0; sI < G; ++sI) {
+    if (sI < nsteps) {
+      const int kb = kTop - sI;
+      const double* Ldk = Ld + (size_t)kb * NB * NB;
+      const double* Wk = Winv + (size_t)kb * 1024;
+      // thread tid -> (col = tid >> 4, row = tid & 15) of each 16x16 block
+#pragma unroll
+      for (int b = 1; b < 4; ++b)
+#pragma unroll
+        for (int c = 0; c < b; ++c)
+          Lo[sI][b * (b - 1) / 2 + c][tid] = Ldk[(size_t)(16 * c + (tid >> 4)) * NB + 16 * b + (tid & 15)];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) Ws[sI][b][tid] = Wk[(size_t)b * 256 + tid];
+    }
+  }
+  for (int e = tid; e < nsteps * NB; e += 256) yk[e / NB][e % NB] = yv[(kTop - e / NB) * NB + e % NB];
+  __syncthreads();
+  // ---- dependent chain ---------------------------------------------------------------------------------
+#pragma unroll
+  for (int sI = 0; sI < G; ++sI) {
+    if (sI < nsteps) {
+      const int kb = kTop - sI;
+#pragma unroll
+      for (int sp = 0; sp < G; ++sp) {
+        if (sp < sI) {   // y_kb -= L[kTop - sp, kb]^T d_{kTop - sp}
+#pragma unroll
+          for (int m = 0; m < 16; ++m) tile[wave + 4 * m][lane] = tc[sp][sI][m];
+          __syncthreads();
+          const double v = bwd_tile_dot(tile, dk[sp], tid);
+          if ((tid & 3) == 0) yk[sI][tid >> 2] -= v;
+          __syncthreads();
+        }
+      }
+      if (wave == 0) {
+        // x_b = W_b^T (y_b - sum_{c > b} L_cb^T x_c),  b = 3..0, inside the 64x64 diagonal block kb (LDS only)
+#pragma unroll
+        for (int b = 3; b >= 0; --b) {
+          if (lane < 16) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s += Ws[sI][b][lane * 16 + j] * yk[sI][16 * b + j];   // (W_b)[j][lane]
+            dk[sI][16 * b + lane] = s;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (b > 0 && lane < 16 * b) {
+            // y[m] -= sum_n L[16b + n][m] x_n ,  m = lane in block c = lane >> 4
+            const int c = lane >> 4, cc = lane & 15;
+            double s = 0.0;
+#pragma unroll
+            for (int n = 0; n < 16; ++n) s += Lo[sI][b * (b - 1) / 2 + c][cc * 16 + n] * dk[sI][16 * b + n];
+            yk[sI][lane] -= s;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (blockIdx.x == 0) dp[kb * NB + lane] = dk[sI][lane];
+      }
+      __syncthreads();
+    }
+  }
+  // ---- own 64 columns (all of them lie left of the whole group) ------------------------------------------
+  if (has_cols) {
+    double acc = 0.0;
+#pragma unroll
+    for (int sI = 0; sI < G; ++sI) {
+      if (sI < nsteps) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) tile[wave + 4 * m][lane] = to[sI][m];
+        __syncthreads();
+        acc += bwd_tile_dot(tile, dk[sI], tid);
+        __syncthreads();
+      }
+    }
+    if ((tid & 3) == 0) yv[cb * NB + (tid >> 2)] -= acc;
   }
 }
 
@@ -373,15 +444,19 @@ void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv,
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, hipStream_t s) {
   hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv);
 }
-void launch_chol_bwd(const double* S, int ld, int k, const double* Ld, const double* Winv, double* yv, double* dp,
-                     hipStream_t s) {
-  hipLaunchKernelGGL(k_chol_bwd, dim3(k > 0 ? k : 1), dim3(256), 0, s, S, ld, k, Ld, Winv, yv, dp);
+void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp,
+                         hipStream_t s) {
+  for (int kTop = T - 1; kTop >= 0; kTop -= BWD_GROUP) {
+    const int nsteps = kTop + 1 < BWD_GROUP ? kTop + 1 : BWD_GROUP;
+    const int ncol = kTop - nsteps + 1;          // column blocks left of the group
+    hipLaunchKernelGGL(k_chol_bwd, dim3(ncol > 0 ? ncol : 1), dim3(256), 0, s, S, ld, kTop, nsteps, Ld, Winv, yv, dp);
+  }
 }
 
 int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double* yv, double* dp, int* status, hipStream_t s) {
   for (int k = 0; k < T; ++k) launch_chol_step(S, ld, k, T, Ld + (size_t)k * NB * NB, Winv + (size_t)k * 1024, status, s);
   launch_chol_extract_y(S, ld, T, yv, s);
-  for (int k = T - 1; k >= 0; --k) launch_chol_bwd(S, ld, k, Ld + (size_t)k * NB * NB, Winv + (size_t)k * 1024, yv, dp, s);
+  launch_chol_bwd_all(S, ld, T, Ld, Winv, yv, dp, s);
   return 0;
 }
 

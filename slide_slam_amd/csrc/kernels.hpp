@@ -23,7 +23,7 @@ void launch_estimate(const GraphDev& G, hipStream_t s);
 // leading dimension ld = (T+1)*NB; the extra row tile carries the right-hand side), tile edge NB = 64.
 void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, hipStream_t s);
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, hipStream_t s);
-void launch_chol_bwd(const double* S, int ld, int k, const double* Ld, const double* Winv, double* yv, double* dp, hipStream_t s);
+void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp, hipStream_t s);
 // stand-alone dense SPD solve on device buffers (used by the unit tests and the roofline bench leg)
 int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double* yv, double* dp, int* status, hipStream_t s);
 
