@@ -12,6 +12,7 @@
 // f64 MFMA lane maps (cdna_hip_programming.md §3): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
 // D[row = (lane>>4) + 4*reg][col = lane&15].
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "graph_dev.hpp"
 #include "kernels.hpp"
@@ -23,119 +24,111 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 __device__ inline v4d mfma_f64(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
 // ------------------------------------------------------------------------------------------------
-// Step kernel "diag + panel": every workgroup (one per row tile below the diagonal block, RHS tile included)
-// redundantly factors the 64x64 diagonal block in REGISTERS (256 threads as a 16x16 grid, thread (ti, tj)
-// owns A[ti + 16p][tj + 16q]; per column step the owners of column j publish it through a double-buffered
-// LDS vector: one barrier per step, no integer division, no scratch), inverts its four 16x16 diagonal
-// sub-blocks (one wave each), and then solves its own 64 rows X = A L^-T by blocked substitution on
-// v_mfma_f64_16x16x4_f64.  The MFMA accumulator layout of X_c^T (row (lane>>4) + 4r, column lane&15) is
-// exactly the B-operand layout of k-step r, so the chained products need no lane movement.
-// Redundant factoring costs no latency (the blocks run concurrently) and removes a kernel boundary and the
-// L / W round trip through L2 from the critical path.  Workgroup 0 also publishes L_kk and the 16x16
-// inverses for the backward substitution.
+// Factorisation of the 64x64 diagonal tile ON THE MATRIX CORES, one complete copy per wave (no barrier, no LDS
+// inside the loop).  The tile lives in registers as its ten lower 16x16 sub-tiles in the MFMA accumulator layout
+// of the TRANSPOSE ("T-layout"): lane (lr = lane&15, lk = lane>>4), register r of sub-tile (I, J) holds
+// A[16I + lr][16J + lk + 4r].  In that layout
+//   * register s of a sub-tile IS the B operand "rows lr, four columns 4s..4s+3", so the rank-4 panel step
+//     X = A[:, j..j+3] L_p^-T is ONE v_mfma_f64_16x16x4_f64 per 16 rows (A operand = the 4x4 inverse of the pivot
+//     Cholesky factor, zero-padded to 16x4) and its result register 0 is again "rows lr, four columns";
+//   * the rank-4 trailing update of a sub-tile is ONE MFMA with those X registers as A and B operands.
+// Only the 4x4 pivot Cholesky + inverse (a chain of four rsqrt) runs on the vector ALU, on wave-uniform values
+// fetched with v_readlane.  Left-looking across the four 16-column phases: sub-tiles right of the current phase
+// receive one rank-16 update (four MFMAs) at the end of the phase.  A pseudo row tile that starts as the identity
+// rides along in each phase and ends as L_JJ^-T (the 16x16 inverses the triangular solves use).
 __device__ inline double rsqrt_nr(double d) {
   // 1/sqrt(d): hardware estimate + two Newton steps (full double precision)
   double y = __builtin_amdgcn_rsq(d);
-#ifndef EXP_NO_NR
   y = y * (1.5 - 0.5 * d * y * y);
   y = y * (1.5 - 0.5 * d * y * y);
-#endif
   return y;
 }
 
-// Rank-4 elimination of the 64x64 diagonal tile held in registers (256 threads as a 16x16 grid, thread (ti, tj)
-// owns A[ti + 16p][tj + 16q]).  Columns j..j+3 are published together through a double-buffered LDS panel
-// (ONE barrier per FOUR columns); every thread redoes the 4x4 pivot Cholesky and the four-term substitution for
-// its own rows / columns.  While block column JQ is eliminated only the register blocks JQ <= q <= p change, and
-// the upper triangle of A is never read for a result, so two masks suffice (rows / columns <= j+3 of the pivot
-// block).  The inverse of the 16x16 diagonal sub-block (needed by the triangular solves) rides along: each
-// thread carries ONE element w of it and applies the same four-term substitution to it.
-template <int JQ>
-__device__ inline void diag_steps(double (&a)[4][4], double (&wfin)[4], double (*colraw)[4][NB], double (*wraw)[4][16], int ti,
-                                  int tj, int* status) {
-  double w = (ti == tj) ? 1.0 : 0.0;   // element (ti, tj) of the identity -> of L_bb^-1
-#pragma unroll 1
-  for (int jt = 0; jt < 16; jt += 4) {
-    const int j = 16 * JQ + jt;
-    const int buf = (jt >> 2) & 1;
-    const int rc = tj - jt;            // 0..3 when this thread owns one of the four pivot columns
-    if (rc >= 0 && rc < 4) {
+__device__ __forceinline__ double bcast_lane(double v, int src) {   // src: compile-time lane
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ constexpr int tidx(int I, int J) { return I * (I + 1) / 2 + J; }
+
+// Lt: ten lower sub-tiles (T-layout).  The inverse of diagonal sub-tile JQ leaves for LDS (Wi[JQ][c * 16 + r] =
+// (L_JQ,JQ^-1)[r][c], the A-operand image of the triangular solves) and, when Winv != nullptr, for global memory at
+// the end of its phase.  Returns true when a pivot was not positive (fmin also propagates the NaNs it breeds).
+__device__ __forceinline__ bool factor64_mfma(v4d (&Lt)[10], double (*Wi)[16 * 16], double* __restrict__ Winv, int lr, int lk) {
+  double dmin = 1.0;
+  const v4d zero = v4d{0.0, 0.0, 0.0, 0.0};
+  // lane predicates of the 4x4 inverse inside the 16x4 A operand: row lr < 4, column lk <= lr
+  const bool s00 = lr == 0 && lk == 0, s10 = lr == 1 && lk == 0, s11 = lr == 1 && lk == 1, s20 = lr == 2 && lk == 0,
+             s21 = lr == 2 && lk == 1, s22 = lr == 2 && lk == 2, s30 = lr == 3 && lk == 0, s31 = lr == 3 && lk == 1,
+             s32 = lr == 3 && lk == 2, s33 = lr == 3 && lk == 3;
 #pragma unroll
-      for (int p = JQ; p < 4; ++p) colraw[buf][rc][ti + 16 * p] = a[p][JQ];
-    }
-    const int rr = ti - jt;            // 0..3 when this thread owns one of the four pivot rows of W
-    if (rr >= 0 && rr < 4) wraw[buf][rr][tj] = w;
-#ifndef EXP_NO_BARRIER
-    __syncthreads();
-#endif
-    const double* c0 = colraw[buf][0];
-    const double* c1 = colraw[buf][1];
-    const double* c2 = colraw[buf][2];
-    const double* c3 = colraw[buf][3];
-    // 4x4 pivot block (lower part)
-    double P00 = c0[j], P10 = c0[j + 1], P20 = c0[j + 2], P30 = c0[j + 3];
-    double P11 = c1[j + 1], P21 = c1[j + 2], P31 = c1[j + 3];
-    double P22 = c2[j + 2], P32 = c2[j + 3], P33 = c3[j + 3];
-    bool bad = !(P00 > 0.0);
-    if (bad) P00 = 1.0;
-    const double i0 = rsqrt_nr(P00);
-    const double l10 = P10 * i0, l20 = P20 * i0, l30 = P30 * i0;
-    double d1 = P11 - l10 * l10;
-    if (!(d1 > 0.0)) { bad = true; d1 = 1.0; }
-    const double i1 = rsqrt_nr(d1);
-    const double l21 = (P21 - l20 * l10) * i1, l31 = (P31 - l30 * l10) * i1;
-    double d2 = P22 - l20 * l20 - l21 * l21;
-    if (!(d2 > 0.0)) { bad = true; d2 = 1.0; }
-    const double i2 = rsqrt_nr(d2);
-    const double l32 = (P32 - l30 * l20 - l31 * l21) * i2;
-    double d3 = P33 - l30 * l30 - l31 * l31 - l32 * l32;
-    if (!(d3 > 0.0)) { bad = true; d3 = 1.0; }
-    const double i3 = rsqrt_nr(d3);
-    if (bad && ti == 0 && tj == 0 && blockIdx.x == 0) atomicOr(&status[1], 1);
-    // four-term forward substitution  (v0..v3) -> (x0..x3) = L_piv^-1 v
-#define SUBST4(v0, v1, v2, v3, x0, x1, x2, x3)          \
-    const double x0 = (v0) * i0;                          \
-    const double x1 = ((v1) - x0 * l10) * i1;             \
-    const double x2 = ((v2) - x0 * l20 - x1 * l21) * i2;  \
-    const double x3 = ((v3) - x0 * l30 - x1 * l31 - x2 * l32) * i3;
-    double X0[4], X1[4], X2[4], X3[4], Y0[4], Y1[4], Y2[4], Y3[4];
+  for (int JQ = 0; JQ < 4; ++JQ) {
+    v4d W;
 #pragma unroll
-    for (int p = JQ; p < 4; ++p) {
-      const int i = ti + 16 * p;
-      SUBST4(c0[i], c1[i], c2[i], c3[i], x0, x1, x2, x3)
-      X0[p] = x0; X1[p] = x1; X2[p] = x2; X3[p] = x3;
-    }
+    for (int r = 0; r < 4; ++r) W[r] = (lr == lk + 4 * r) ? 1.0 : 0.0;
+    const int dq = tidx(JQ, JQ);
 #pragma unroll
-    for (int q = JQ; q < 4; ++q) {
-      const int c = tj + 16 * q;
-      SUBST4(c0[c], c1[c], c2[c], c3[c], y0, y1, y2, y3)
-      Y0[q] = y0; Y1[q] = y1; Y2[q] = y2; Y3[q] = y3;
-    }
-    const bool rlive = ti > jt + 3, clive = tj > jt + 3;
-    const double x0m = rlive ? X0[JQ] : 0.0, x1m = rlive ? X1[JQ] : 0.0, x2m = rlive ? X2[JQ] : 0.0, x3m = rlive ? X3[JQ] : 0.0;
-    const double y0m = clive ? Y0[JQ] : 0.0, y1m = clive ? Y1[JQ] : 0.0, y2m = clive ? Y2[JQ] : 0.0, y3m = clive ? Y3[JQ] : 0.0;
+    for (int s = 0; s < 4; ++s) {
+      const double dv = Lt[dq][s];   // columns 4s..4s+3 of the diagonal sub-tile; element (4s+a, 4s+b) sits in lane 4s+a+16b
+      const double P00 = bcast_lane(dv, 4 * s), P10 = bcast_lane(dv, 4 * s + 1), P20 = bcast_lane(dv, 4 * s + 2), P30 = bcast_lane(dv, 4 * s + 3);
+      const double P11 = bcast_lane(dv, 4 * s + 1 + 16), P21 = bcast_lane(dv, 4 * s + 2 + 16), P31 = bcast_lane(dv, 4 * s + 3 + 16);
+      const double P22 = bcast_lane(dv, 4 * s + 2 + 32), P32 = bcast_lane(dv, 4 * s + 3 + 32), P33 = bcast_lane(dv, 4 * s + 3 + 48);
+      // a non-positive pivot only raises the flag: the NaNs it breeds stay inside this (rejected) factorisation
+      const double i0 = rsqrt_nr(P00);
+      const double l10 = P10 * i0, l20 = P20 * i0, l30 = P30 * i0;
+      const double d1 = P11 - l10 * l10;
+      const double i1 = rsqrt_nr(d1);
+      const double l21 = (P21 - l20 * l10) * i1, l31 = (P31 - l30 * l10) * i1;
+      const double d2 = P22 - l20 * l20 - l21 * l21;
+      const double i2 = rsqrt_nr(d2);
+      const double l32 = (P32 - l30 * l20 - l31 * l21) * i2;
+      const double d3 = P33 - l30 * l30 - l31 * l31 - l32 * l32;
+      const double i3 = rsqrt_nr(d3);
+      dmin = fmin(fmin(dmin, fmin(P00, d1)), fmin(d2, d3));
+      // M = L_p^-1 (lower 4x4)
+      const double m10 = -l10 * i0 * i1;
+      const double m21 = -l21 * i1 * i2;
+      const double m20 = -(l20 * i0 + l21 * m10) * i2;
+      const double m32 = -l32 * i2 * i3;
+      const double m31 = -(l31 * i1 + l32 * m21) * i3;
+      const double m30 = -(l30 * i0 + l31 * m10 + l32 * m20) * i3;
+      double mop = 0.0;                       // selected in order of availability: the last link follows m30 directly
+      mop = s00 ? i0 : mop;  mop = s11 ? i1 : mop;  mop = s10 ? m10 : mop;  mop = s22 ? i2 : mop;  mop = s21 ? m21 : mop;
+      mop = s20 ? m20 : mop; mop = s33 ? i3 : mop;  mop = s32 ? m32 : mop;  mop = s31 ? m31 : mop;  mop = s30 ? m30 : mop;
+      // panel: X_I = A_I[:, 4s..4s+3] L_p^-T  (register 0 of the product = X_I[row lr][column lk])
+      double x[4];
 #pragma unroll
-    for (int p = JQ; p < 4; ++p)
+      for (int I = JQ; I < 4; ++I) x[I] = mfma_f64(mop, Lt[tidx(I, JQ)][s], zero)[0];
+      const double xw = mfma_f64(mop, W[s], zero)[0];
 #pragma unroll
-      for (int q = JQ; q <= p; ++q) {
-        const double e0 = (p == JQ ? x0m : X0[p]), e1 = (p == JQ ? x1m : X1[p]), e2 = (p == JQ ? x2m : X2[p]), e3 = (p == JQ ? x3m : X3[p]);
-        const double f0 = (q == JQ ? y0m : Y0[q]), f1 = (q == JQ ? y1m : Y1[q]), f2 = (q == JQ ? y2m : Y2[q]), f3 = (q == JQ ? y3m : Y3[q]);
-        a[p][q] -= e0 * f0 + e1 * f1 + e2 * f2 + e3 * f3;
+      for (int I = JQ; I < 4; ++I) Lt[tidx(I, JQ)][s] = x[I];
+      W[s] = xw;
+      if (s < 3) {
+        // rank-4 update of the columns right of the pivot block inside this 16-column phase
+        const double xm = (lr > 4 * s + 3) ? x[JQ] : 0.0;
+        Lt[dq] = mfma_f64(-xm, xm, Lt[dq]);
+#pragma unroll
+        for (int I = JQ + 1; I < 4; ++I) Lt[tidx(I, JQ)] = mfma_f64(-xm, x[I], Lt[tidx(I, JQ)]);
+        W = mfma_f64(-xm, xw, W);
       }
-    // inverse of the diagonal sub-block: rows j..j+3 of W become L_piv^-1 (rows), rows below take the update
-    {
-      const double* w0 = wraw[buf][0];
-      SUBST4(w0[tj], wraw[buf][1][tj], wraw[buf][2][tj], wraw[buf][3][tj], z0, z1, z2, z3)
-      if (rlive) w -= X0[JQ] * z0 + X1[JQ] * z1 + X2[JQ] * z2 + X3[JQ] * z3;
-      if (rr == 0) w = z0; else if (rr == 1) w = z1; else if (rr == 2) w = z2; else if (rr == 3) w = z3;
     }
-#undef SUBST4
-    if (rc >= 0 && rc < 4) {
 #pragma unroll
-      for (int p = JQ; p < 4; ++p) a[p][JQ] = (rc == 0) ? X0[p] : (rc == 1) ? X1[p] : (rc == 2) ? X2[p] : X3[p];   // columns j..j+3 of L
+    for (int r = 0; r < 4; ++r) {
+      const double v = (lk + 4 * r >= lr) ? W[r] : 0.0;          // W lane (lr, lk) reg r = (L_JQ,JQ^-1)[lk + 4r][lr]
+      Wi[JQ][lr * 16 + lk + 4 * r] = v;
+      if (Winv) Winv[(size_t)JQ * 256 + lr * 16 + lk + 4 * r] = v;
     }
+    // rank-16 update of the sub-tiles right of this phase (diagonal ones first: they head the next chain)
+#pragma unroll
+    for (int J = JQ + 1; J < 4; ++J)
+#pragma unroll
+      for (int I = J; I < 4; ++I)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          Lt[tidx(I, J)] = mfma_f64(-Lt[tidx(J, JQ)][ks], Lt[tidx(I, JQ)][ks], Lt[tidx(I, J)]);
   }
-  wfin[JQ] = w;
+  return !(dmin > 0.0);
 }
 
 #ifdef SLIDE_STAMPS
@@ -144,7 +137,6 @@ __device__ unsigned long long g_stamps[16];
 #else
 #define STAMP(i)
 #endif
-constexpr int LSTR = 80;   // LDS column stride of the factored block: two adjacent columns fall in disjoint banks
 
 // ------------------------------------------------------------------------------------------------
 // ONE kernel per block column k ("step kernel").  Two kinds of workgroups share the launch:
@@ -158,59 +150,84 @@ constexpr int LSTR = 80;   // LDS column stride of the factored block: two adjac
 // The long type-A blocks therefore run BESIDE the memory-bound type-B flood inside one launch; the next step
 // needs only the kernel boundary.  MFMA accumulator layout of X_c^T (row (lane>>4) + 4r, column lane&15) is
 // exactly the B-operand layout of k-step r, so chained products need no lane movement.
-__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Ld,
-                                                   double* __restrict__ Winv, int* status) {
-  __shared__ double colraw[2][4][NB];
-  __shared__ double wraw[2][4][16];
-  __shared__ double Ls[NB * LSTR];        // Ls[c * LSTR + r] = L[r][c]  (first used to re-shape the updated diagonal tile)
-  __shared__ double Wi[4][16 * 16];       // Wi[b][c * 16 + r] = (L_bb^-1)[r][c]
+// ---------------- type B: trailing update with panel k-1, one 2x2 group of 64x64 tiles per workgroup ----------------
+// Wave (wm, wn) owns tile (i, j) = (i0 + wm, j0 + wn) entirely: sixteen 16x16 accumulators initialised with C itself,
+// sixteen k-steps of eight operand loads feeding sixteen MFMAs (the loads run two k-steps ahead of their use), so the
+// wave is paced by the matrix pipe even at one or two waves per SIMD — the occupancy the register-heavy type A
+// leaves to the launch.  No LDS, no barrier: waves whose tile lies outside the lower triangle leave at once.
+__device__ __forceinline__ long long tri_row(long long t) {
+  long long ii = (long long)floor((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (ii * (ii + 1) / 2 > t) --ii;
+  while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+  return ii;
+}
+__device__ __forceinline__ void step_type_b(double* __restrict__ S, int ld, int k, int T, long long t) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  const int nA = T - k;
-  if ((int)blockIdx.x >= nA) {
-    // ---------------- type B: trailing update of one 64x64 tile with panel k-1 ----------------
-    const long long t = (long long)blockIdx.x - nA;
-    long long ii = (long long)floor((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while (ii * (ii + 1) / 2 > t) --ii;
-    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
-    const int jj = (int)(t - ii * (ii + 1) / 2);
-    const int i = k + 1 + (int)ii, j = k + 1 + jj;
-    const int m0 = 32 * (wave >> 1), n0 = 32 * (wave & 1);
-    const double* pj = S + (size_t)((k - 1) * NB) * ld + (size_t)j * NB + n0 + lr;
-    const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)i * NB + m0 + lr;
-    v4d acc[2][2];
+  const long long bi = tri_row(t);
+  const int bj = (int)(t - bi * (bi + 1) / 2);
+  const int i = k + 1 + 2 * (int)bi + (wave >> 1), j = k + 1 + 2 * bj + (wave & 1);
+  if (i > T || j > T - 1 || i < j) return;
+  const double* pj = S + (size_t)((k - 1) * NB) * ld + (size_t)j * NB + lr;   // + 16a : rows 16a + lr of panel tile (j, k-1)
+  const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)i * NB + lr;   // + 16b : rows 16b + lr of panel tile (i, k-1)
+  double* cb = S + (size_t)(j * NB + lk) * ld + (size_t)i * NB + lr;          // + (16a + 4r) ld + 16b
+  // two passes of 32 columns (a = 2h, 2h+1) x 64 rows: eight accumulators live at a time
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    const double* pjh = pj + 32 * h;
+    double* cbh = cb + (size_t)(32 * h) * ld;
+    v4d acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+      for (int b = 0; b < 4; ++b)
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const size_t off = (size_t)(4 * ks + lk) * ld;
-      const double a0 = pj[off], a1 = pj[off + 16];
-      const double b0 = pi[off], b1 = pi[off + 16];
-      acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
-      acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
-      acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
-      acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+        for (int r = 0; r < 4; ++r) acc[a][b][r] = cbh[(size_t)(16 * a + 4 * r) * ld + 16 * b];
+    double pa[3][2], pb[3][4];
+#pragma unroll
+    for (int pre = 0; pre < 2; ++pre) {
+      const size_t off = (size_t)(4 * pre + lk) * ld;
+      pa[pre][0] = pjh[off]; pa[pre][1] = pjh[off + 16];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) pb[pre][b] = pi[off + 16 * b];
     }
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
+    for (int ks = 0; ks < 16; ++ks) {
+      if (ks + 2 < 16) {
+        const size_t off = (size_t)(4 * (ks + 2) + lk) * ld;
+        pa[(ks + 2) % 3][0] = pjh[off]; pa[(ks + 2) % 3][1] = pjh[off + 16];
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
+        for (int b = 0; b < 4; ++b) pb[(ks + 2) % 3][b] = pi[off + 16 * b];
+      }
+      __builtin_amdgcn_sched_barrier(0);      // keep the two-k-step prefetch distance: no further hoisting of loads
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double* c = S + (size_t)(j * NB + n0 + 16 * pb + lk + 4 * r) * ld + (size_t)i * NB + m0 + 16 * qb + lr;
-          *c -= acc[pb][qb][r];
-        }
-    return;
+      for (int a = 0; a < 2; ++a) {
+        const double na = -pa[ks % 3][a];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma_f64(na, pb[ks % 3][b], acc[a][b]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cbh[(size_t)(16 * a + 4 * r) * ld + 16 * b] = acc[a][b][r];
   }
-  // ---------------- type A ----------------
+}
+
+// ---------------- type A: look-ahead chain of block column k for row tile k + 1 + ia ----------------
+__device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int k, int ia, double* __restrict__ Ld,
+                                            double* __restrict__ Winv, int* status, double (*Tx)[4][64], double (*Wi)[16 * 16]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
   STAMP(0);
-  const int it = k + 1 + blockIdx.x;
+  const int it = k + 1 + ia;
   const int ti = tid & 15, tj = tid >> 4;
   // own rows (16 per wave) of tile (it, k) and of the diagonal tile (k, k), both in the transposed MFMA layout
   // t[b][r] = A[row 16*wave + lr][col 16b + lk + 4r]
-  double* col = S + (size_t)(k * NB) * ld + (size_t)it * NB + 16 * wave + lr;
+  const double* col = S + (size_t)(k * NB) * ld + (size_t)it * NB + 16 * wave + lr;
   const double* dcol = S + (size_t)(k * NB) * ld + (size_t)k * NB + 16 * wave + lr;
   v4d tt[4], dd[4];
 #pragma unroll
@@ -226,59 +243,81 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int l
     const double* pk = S + (size_t)((k - 1) * NB) * ld + (size_t)k * NB + lr;             // + 16 b : L_k[16b + lr][.]
     const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)it * NB + 16 * wave + lr;   // own rows
     const double* pd = S + (size_t)((k - 1) * NB) * ld + (size_t)k * NB + 16 * wave + lr;    // diagonal tile's rows
+    double pa[3][4], pb[3][2];               // operands run two k-steps ahead of their MFMAs
+#pragma unroll
+    for (int pre = 0; pre < 2; ++pre) {
+      const size_t off = (size_t)(4 * pre + lk) * ld;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) pa[pre][b] = pk[off + 16 * b];
+      pb[pre][0] = pi[off]; pb[pre][1] = pd[off];
+    }
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      const size_t off = (size_t)(4 * ks + lk) * ld;
-      const double bi = pi[off], bd = pd[off];
+      if (ks + 2 < 16) {
+        const size_t off = (size_t)(4 * (ks + 2) + lk) * ld;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) pa[(ks + 2) % 3][b] = pk[off + 16 * b];
+        pb[(ks + 2) % 3][0] = pi[off]; pb[(ks + 2) % 3][1] = pd[off];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const double aop = -pk[off + 16 * b];
-        tt[b] = mfma_f64(aop, bi, tt[b]);
-        dd[b] = mfma_f64(aop, bd, dd[b]);
+        const double aop = -pa[ks % 3][b];
+        tt[b] = mfma_f64(aop, pb[ks % 3][0], tt[b]);
+        dd[b] = mfma_f64(aop, pb[ks % 3][1], dd[b]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   STAMP(2);
-  // re-shape the (updated) diagonal tile through LDS into the factorisation layout a[p][q] = A[ti + 16p][tj + 16q]
+  // every wave takes a complete copy of the updated diagonal tile: wave w holds sub-tile row w (dd[b] = (w, b))
 #pragma unroll
   for (int b = 0; b < 4; ++b)
+    if (b <= wave) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Ls[(16 * b + lk + 4 * r) * LSTR + 16 * wave + lr] = dd[b][r];
-  __syncthreads();
-  double a[4][4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = ti + 16 * p, c = tj + 16 * q;
-      a[p][q] = (i >= c) ? Ls[c * LSTR + i] : 0.0;
+      for (int r = 0; r < 4; ++r) Tx[wave * (wave + 1) / 2 + b][r][lane] = dd[b][r];
     }
   __syncthreads();
+  v4d Lt[10];
+#pragma unroll
+  for (int t = 0; t < 10; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Lt[t][r] = Tx[t][r][lane];
+#pragma unroll
+  for (int J = 0; J < 4; ++J)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (lr < lk + 4 * r) Lt[tidx(J, J)][r] = 0.0;          // upper triangle: never read for a result, keep it finite
   STAMP(3);
-  double wfin[4];
-  diag_steps<0>(a, wfin, colraw, wraw, ti, tj, status);
-  diag_steps<1>(a, wfin, colraw, wraw, ti, tj, status);
-  diag_steps<2>(a, wfin, colraw, wraw, ti, tj, status);
-  diag_steps<3>(a, wfin, colraw, wraw, ti, tj, status);
+  const bool bad = factor64_mfma(Lt, Wi + 4 * wave, (ia == 0 && wave == 0) ? Winv : nullptr, lr, lk);   // per-wave copies of the inverses
+  if (bad && tid == 0 && ia == 0) atomicOr(&status[1], 1);
   STAMP(4);
+  if (ia == 0) {
+    // L_kk for the backward substitution: wave w writes sub-tile row w (every wave holds the whole factor)
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
+    for (int I = 0; I < 4; ++I)
+      if (I == wave) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = ti + 16 * p, c = tj + 16 * q;
-      const double v = (i >= c) ? a[p][q] : 0.0;
-      Ls[c * LSTR + i] = v;
-      if (blockIdx.x == 0) Ld[(size_t)c * NB + i] = v;
-    }
+        for (int J = 0; J < 4; ++J)
 #pragma unroll
-  for (int bq = 0; bq < 4; ++bq) {
-    const double v = (ti >= tj) ? wfin[bq] : 0.0;          // (L_bb^-1)[ti][tj]
-    Wi[bq][tj * 16 + ti] = v;
-    if (blockIdx.x == 0) Winv[(size_t)bq * 256 + tj * 16 + ti] = v;
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * I + lr, c = 16 * J + lk + 4 * r;
+            double v = 0.0;
+            if (J <= I) v = (i >= c) ? Lt[tidx(I, J <= I ? J : 0)][r] : 0.0;
+            Ld[(size_t)c * NB + i] = v;
+          }
+      }
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   STAMP(5);
-  // blocked triangular solve of this workgroup's 64 rows (16 per wave), operands already in registers
+  // blocked triangular solve of this workgroup's 64 rows (16 per wave); L operands straight from registers.
+  // The store addresses are rebuilt from a laundered copy of ld: sixteen 64-bit addresses kept alive since the loads
+  // at the top would otherwise sit in registers (or spill) through the whole factorisation.
+  int ld2 = ld;
+  asm volatile("" : "+s"(ld2));
+  double* col2 = S + (size_t)(k * NB) * ld2 + (size_t)it * NB + 16 * wave + lr;
   v4d xt[4];
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
@@ -286,22 +325,50 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int l
 #pragma unroll
     for (int c = 0; c < b; ++c)
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const double aop = -Ls[(16 * c + 4 * s4 + lk) * LSTR + 16 * b + lr];       // -L[16b + n][16c + j]
-        t = mfma_f64(aop, xt[c][s4], t);
-      }
+      for (int s4 = 0; s4 < 4; ++s4) t = mfma_f64(-Lt[tidx(b, c)][s4], xt[c][s4], t);   // -L[16b + lr][16c + lk + 4 s4]
     v4d x = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-      const double aop = Wi[b][(4 * s4 + lk) * 16 + lr];                             // (L_bb^-1)[n][j]
+      const double aop = Wi[4 * wave + b][(4 * s4 + lk) * 16 + lr];                       // (L_bb^-1)[lr][4 s4 + lk]
       x = mfma_f64(aop, t[s4], x);
     }
     xt[b] = x;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) col[(size_t)(16 * b + lk + 4 * r) * ld] = x[r];
+    for (int r = 0; r < 4; ++r) col2[(size_t)(16 * b + lk + 4 * r) * ld2] = x[r];
   }
   STAMP(6);
 }
+
+// Work queue of the type-B groups: every workgroup of the launch (the type-A ones after their chain, too) draws group
+// indices from ctr[k] until they run out, so the ~T-k long type-A chains and the flood balance by themselves at the one
+// workgroup per CU the register-heavy kernel gets.  ctr[k+1] is cleared here for the next launch (ctr[0..1] start at 0).
+__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Ld,
+                                                   double* __restrict__ Winv, int* status, int* __restrict__ ctr, int nGroups) {
+  __shared__ double Tx[10][4][64];        // exchange of the updated diagonal tile: sub-tile, register, lane
+  __shared__ double Wi[16][16 * 16];      // per wave w: Wi[4w + b][c * 16 + r] = (L_bb^-1)[r][c]
+  __shared__ int s_g;
+  const int nA = T - k;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctr[k + 1] = 0;
+  if ((int)blockIdx.x < nA) step_type_a(S, ld, k, (int)blockIdx.x, Ld, Winv, status, Tx, Wi);
+  if (nGroups <= 0) return;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_g = atomicAdd(&ctr[k], 1);
+    __syncthreads();
+    const int g = s_g;
+    if (g >= nGroups) break;
+    step_type_b(S, ld, k, T, (long long)g);
+  }
+}
+// diagnostic split (SLIDE_CHOL_SPLIT=1): the two kinds of workgroups as separate launches
+__global__ __launch_bounds__(256) void k_chol_a(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Ld,
+                                                double* __restrict__ Winv, int* status) {
+  __shared__ double Tx[10][4][64];
+  __shared__ double Wi[16][16 * 16];
+  step_type_a(S, ld, k, (int)blockIdx.x, Ld, Winv, status, Tx, Wi);
+}
+__global__ __launch_bounds__(256) void k_chol_b(double* __restrict__ S, int ld, int k, int T) { step_type_b(S, ld, k, T, (long long)blockIdx.x); }
+
 #ifdef SLIDE_STAMPS
 extern "C" void slide_debug_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
 #endif
@@ -436,10 +503,41 @@ __global__ __launch_bounds__(256) void k_chol_bwd(const double* __restrict__ S, 
 }
 
 // ------------------------------------------------------------------------------------------------
-void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, hipStream_t s) {
+void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, hipStream_t s) {
   const long long nA = T - k;                                   // column-k tiles below the diagonal (+ RHS tile)
-  const long long nB = k > 0 ? nA * (nA + 1) / 2 - 1 : 0;       // trailing tiles that still owe the update of panel k-1
-  hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nA + nB)), dim3(256), 0, s, S, ld, k, T, Ld, Winv, status);
+  const long long nP = (nA + 1) / 2;                            // 2x2 tile groups per side of the trailing matrix
+  const long long nB = k > 0 ? nP * (nP + 1) / 2 : 0;           // groups that still owe the update of panel k-1
+  static const int split = getenv("SLIDE_CHOL_SPLIT") ? atoi(getenv("SLIDE_CHOL_SPLIT")) : 0;
+  if (split == 1) {
+    hipLaunchKernelGGL(k_chol_a, dim3((unsigned)nA), dim3(256), 0, s, S, ld, k, T, Ld, Winv, status);
+    if (nB > 0) hipLaunchKernelGGL(k_chol_b, dim3((unsigned)nB), dim3(256), 0, s, S, ld, k, T);
+    return;
+  }
+  if (split == 2) {   // the two kinds as concurrent launches on two streams (fork / join per step)
+    static hipStream_t s2 = nullptr;
+    static hipEvent_t ef = nullptr, ej = nullptr;
+    if (!s2) { (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking); (void)hipEventCreateWithFlags(&ef, hipEventDisableTiming); (void)hipEventCreateWithFlags(&ej, hipEventDisableTiming); }
+    if (nB > 0) {
+      (void)hipEventRecord(ef, s);
+      (void)hipStreamWaitEvent(s2, ef, 0);
+    }
+    hipLaunchKernelGGL(k_chol_a, dim3((unsigned)nA), dim3(256), 0, s, S, ld, k, T, Ld, Winv, status);
+    if (nB > 0) {
+      hipLaunchKernelGGL(k_chol_b, dim3((unsigned)nB), dim3(256), 0, s2, S, ld, k, T);
+      (void)hipEventRecord(ej, s2);
+      (void)hipStreamWaitEvent(s, ej, 0);
+    }
+    return;
+  }
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const long long extra = nB < n_cu ? nB : n_cu;                // queue workers beside the type-A workgroups
+  hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nA + extra)), dim3(256), 0, s, S, ld, k, T, Ld, Winv, status, ctr, (int)nB);
 }
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, hipStream_t s) {
   hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv);
@@ -453,8 +551,8 @@ void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const
   }
 }
 
-int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double* yv, double* dp, int* status, hipStream_t s) {
-  for (int k = 0; k < T; ++k) launch_chol_step(S, ld, k, T, Ld + (size_t)k * NB * NB, Winv + (size_t)k * 1024, status, s);
+int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double* yv, double* dp, int* status, int* ctr, hipStream_t s) {
+  for (int k = 0; k < T; ++k) launch_chol_step(S, ld, k, T, Ld + (size_t)k * NB * NB, Winv + (size_t)k * 1024, status, ctr, s);
   launch_chol_extract_y(S, ld, T, yv, s);
   launch_chol_bwd_all(S, ld, T, Ld, Winv, yv, dp, s);
   return 0;

@@ -71,6 +71,7 @@ struct GraphDev {
   double* Winv;      // T * 4*256 : inverses of the four 16x16 diagonal sub-blocks of every L_kk
   double* yv;        // T*NB  forward-substituted RHS
   double* dp;        // T*NB  reduced solution (delta_p = -dp)
+  int* chol_ctr;     // T + 2 : work counters of the Cholesky step kernels (self-clearing)
   int* status;       // [0] not-SPD flag (landmark), [1] not-SPD flag (chol), [2] #relinearised
   // ---- parameters ------------------------------------------------------------------------
   int chart;

@@ -370,6 +370,7 @@ int HostGraph::upload_new() {
     if (d_S.ensure(ld * (size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_Ld.ensure((size_t)Tcap * NB * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_Winv.ensure((size_t)Tcap * 1024, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_cctr.ensure((size_t)Tcap + 2, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_yv.ensure((size_t)Tcap * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_dp.ensure((size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
   }
@@ -390,7 +391,7 @@ int HostGraph::upload_new() {
   G.pose_bt_ptr = d_pose_bt_ptr.d; G.pose_bt = d_pose_bt.d;
   G.lm_Hacc = d_lm_Hacc.d; G.lm_t = d_lm_t.d; G.n_slots = (int)h_sh_lid.size(); G.sh_lid = d_sh_lid.d; G.sh_owner = d_sh_owner.d;
   G.lm_Hinv = d_lm_Hinv.d; G.lm_g = d_lm_g.d; G.pose_H = d_pose_H.d; G.pose_g = d_pose_g.d;
-  G.S = d_S.d; G.ld = (Tcap + 1) * NB; G.T = T; G.Ld = d_Ld.d; G.Winv = d_Winv.d; G.yv = d_yv.d; G.dp = d_dp.d;
+  G.S = d_S.d; G.ld = (Tcap + 1) * NB; G.T = T; G.Ld = d_Ld.d; G.Winv = d_Winv.d; G.yv = d_yv.d; G.dp = d_dp.d; G.chol_ctr = d_cctr.d;
   G.status = d_status.d;
   G.chart = P.pose_chart;
   G.bearing_sigma = P.bearing_range_sigma; G.cyl_sigma = P.cylinder_sigma; G.numdiff_delta = P.numdiff_delta;
@@ -411,7 +412,7 @@ int HostGraph::enqueue_iteration(bool lookahead) {
   STAGE(4, launch_schur(G, s));
   (void)lookahead;
   for (int k = 0; k < G.T; ++k)
-    STAGE(5, launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, s));
+    STAGE(5, launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, s));
   STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, s));
   STAGE(8, launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, s));
   STAGE(9, launch_backsub(G, 0, s));
@@ -524,7 +525,7 @@ int HostGraph::dist_phase(int phase, double* d_buf) {
     launch_pose(G, s);
     launch_schur(G, s);
     for (int k = 0; k < G.T; ++k)
-      launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, s);
+      launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, s);
     launch_chol_extract_y(G.S, G.ld, G.T, G.yv, s);
     launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, s);
     launch_backsub(G, 1, s);

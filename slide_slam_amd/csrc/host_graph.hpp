@@ -156,6 +156,7 @@ class HostGraph {
   DevArr<int> d_sh_lid, d_sh_owner;
   std::vector<int> h_sh_lid, h_sh_owner;
   DevArr<double> d_S, d_Ld, d_Winv, d_yv, d_dp;
+  DevArr<int> d_cctr;
   DevArr<int> d_status;
   int Tcap = 0;
   // hipGraph of one pass, captured when the same resident graph is solved repeatedly (kernel arguments are

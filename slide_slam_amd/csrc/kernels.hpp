@@ -21,11 +21,12 @@ void launch_estimate(const GraphDev& G, hipStream_t s);
 
 // chol_kernels.hip — blocked right-looking FP64 Cholesky of the (T*NB)^2 lower matrix S (column-major,
 // leading dimension ld = (T+1)*NB; the extra row tile carries the right-hand side), tile edge NB = 64.
-void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, hipStream_t s);
+// ctr: T + 2 ints, zero before the first factorisation (each step clears the next step's work counter itself)
+void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, hipStream_t s);
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, hipStream_t s);
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp, hipStream_t s);
 // stand-alone dense SPD solve on device buffers (used by the unit tests and the roofline bench leg)
-int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double* yv, double* dp, int* status, hipStream_t s);
+int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double* yv, double* dp, int* status, int* ctr, hipStream_t s);
 
 // assoc_kernels.hip
 struct AssocFrameDev {

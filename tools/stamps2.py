@@ -6,4 +6,5 @@ for f in sorted(glob.glob('slide_slam_amd/_lib/exp_*.so')):
     L=C.CDLL(os.path.abspath(f)); x=np.zeros(n); ms=C.c_double(0)
     L.slide_dense_spd_solve(A.ctypes.data_as(C.c_void_p), C.c_int(n), b.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.c_int(3), C.byref(ms))
     out=(C.c_ulonglong*16)(); L.slide_debug_stamps(out)
-    t=np.array(out[:7],dtype=np.float64); print(os.path.basename(f), "factor", int(t[4]-t[3]), "total", int(t[6]-t[0]))
+    t=np.array(out[:7],dtype=np.float64)
+    print(os.path.basename(f), "phases (cycles): loads %d update %d exchange %d factor %d publish %d trsm %d total %d"%tuple(list(np.diff(t))+[t[6]-t[0]]), "err", np.abs(A@x-b).max())
