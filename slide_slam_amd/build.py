@@ -19,7 +19,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # the solver / Cholesky kernels keep hipcc's default contraction.
 SOURCES = [
     ("solver_kernels.hip", []),
-    ("chol_kernels.hip", []),
+    # VGPR-form MFMA: the factorisation edits single registers of accumulator tiles between MFMAs; with the default
+    # AGPR destinations every such edit costs v_accvgpr copies and hazard nops
+    ("chol_kernels.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),
     ("assoc_kernels.hip", ["-ffp-contract=off"]),
     ("place_kernels.hip", ["-ffp-contract=off"]),
     ("host_graph.hip", ["-ffp-contract=off"]),

@@ -20,22 +20,8 @@
 namespace sl {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-
 __device__ inline v4d mfma_f64(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
-// ------------------------------------------------------------------------------------------------
-// Factorisation of the 64x64 diagonal tile ON THE MATRIX CORES, one complete copy per wave (no barrier, no LDS
-// inside the loop).  The tile lives in registers as its ten lower 16x16 sub-tiles in the MFMA accumulator layout
-// of the TRANSPOSE ("T-layout"): lane (lr = lane&15, lk = lane>>4), register r of sub-tile (I, J) holds
-// A[16I + lr][16J + lk + 4r].  In that layout
-//   * register s of a sub-tile IS the B operand "rows lr, four columns 4s..4s+3", so the rank-4 panel step
-//     X = A[:, j..j+3] L_p^-T is ONE v_mfma_f64_16x16x4_f64 per 16 rows (A operand = the 4x4 inverse of the pivot
-//     Cholesky factor, zero-padded to 16x4) and its result register 0 is again "rows lr, four columns";
-//   * the rank-4 trailing update of a sub-tile is ONE MFMA with those X registers as A and B operands.
-// Only the 4x4 pivot Cholesky + inverse (a chain of four rsqrt) runs on the vector ALU, on wave-uniform values
-// fetched with v_readlane.  Left-looking across the four 16-column phases: sub-tiles right of the current phase
-// receive one rank-16 update (four MFMAs) at the end of the phase.  A pseudo row tile that starts as the identity
-// rides along in each phase and ends as L_JJ^-T (the 16x16 inverses the triangular solves use).
 __device__ inline double rsqrt_nr(double d) {
   // 1/sqrt(d): hardware estimate + two Newton steps (full double precision)
   double y = __builtin_amdgcn_rsq(d);
@@ -50,92 +36,13 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {   // src: comp
   return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ constexpr int tidx(int I, int J) { return I * (I + 1) / 2 + J; }
-
-// Lt: ten lower sub-tiles (T-layout).  The inverse of diagonal sub-tile JQ leaves for LDS (Wi[JQ][c * 16 + r] =
-// (L_JQ,JQ^-1)[r][c], the A-operand image of the triangular solves) and, when Winv != nullptr, for global memory at
-// the end of its phase.  Returns true when a pivot was not positive (fmin also propagates the NaNs it breeds).
-__device__ __forceinline__ bool factor64_mfma(v4d (&Lt)[10], double (*Wi)[16 * 16], double* __restrict__ Winv, int lr, int lk) {
-  double dmin = 1.0;
-  const v4d zero = v4d{0.0, 0.0, 0.0, 0.0};
-  // lane predicates of the 4x4 inverse inside the 16x4 A operand: row lr < 4, column lk <= lr
-  const bool s00 = lr == 0 && lk == 0, s10 = lr == 1 && lk == 0, s11 = lr == 1 && lk == 1, s20 = lr == 2 && lk == 0,
-             s21 = lr == 2 && lk == 1, s22 = lr == 2 && lk == 2, s30 = lr == 3 && lk == 0, s31 = lr == 3 && lk == 1,
-             s32 = lr == 3 && lk == 2, s33 = lr == 3 && lk == 3;
-#pragma unroll
-  for (int JQ = 0; JQ < 4; ++JQ) {
-    v4d W;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) W[r] = (lr == lk + 4 * r) ? 1.0 : 0.0;
-    const int dq = tidx(JQ, JQ);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const double dv = Lt[dq][s];   // columns 4s..4s+3 of the diagonal sub-tile; element (4s+a, 4s+b) sits in lane 4s+a+16b
-      const double P00 = bcast_lane(dv, 4 * s), P10 = bcast_lane(dv, 4 * s + 1), P20 = bcast_lane(dv, 4 * s + 2), P30 = bcast_lane(dv, 4 * s + 3);
-      const double P11 = bcast_lane(dv, 4 * s + 1 + 16), P21 = bcast_lane(dv, 4 * s + 2 + 16), P31 = bcast_lane(dv, 4 * s + 3 + 16);
-      const double P22 = bcast_lane(dv, 4 * s + 2 + 32), P32 = bcast_lane(dv, 4 * s + 3 + 32), P33 = bcast_lane(dv, 4 * s + 3 + 48);
-      // a non-positive pivot only raises the flag: the NaNs it breeds stay inside this (rejected) factorisation
-      const double i0 = rsqrt_nr(P00);
-      const double l10 = P10 * i0, l20 = P20 * i0, l30 = P30 * i0;
-      const double d1 = P11 - l10 * l10;
-      const double i1 = rsqrt_nr(d1);
-      const double l21 = (P21 - l20 * l10) * i1, l31 = (P31 - l30 * l10) * i1;
-      const double d2 = P22 - l20 * l20 - l21 * l21;
-      const double i2 = rsqrt_nr(d2);
-      const double l32 = (P32 - l30 * l20 - l31 * l21) * i2;
-      const double d3 = P33 - l30 * l30 - l31 * l31 - l32 * l32;
-      const double i3 = rsqrt_nr(d3);
-      dmin = fmin(fmin(dmin, fmin(P00, d1)), fmin(d2, d3));
-      // M = L_p^-1 (lower 4x4)
-      const double m10 = -l10 * i0 * i1;
-      const double m21 = -l21 * i1 * i2;
-      const double m20 = -(l20 * i0 + l21 * m10) * i2;
-      const double m32 = -l32 * i2 * i3;
-      const double m31 = -(l31 * i1 + l32 * m21) * i3;
-      const double m30 = -(l30 * i0 + l31 * m10 + l32 * m20) * i3;
-      double mop = 0.0;                       // selected in order of availability: the last link follows m30 directly
-      mop = s00 ? i0 : mop;  mop = s11 ? i1 : mop;  mop = s10 ? m10 : mop;  mop = s22 ? i2 : mop;  mop = s21 ? m21 : mop;
-      mop = s20 ? m20 : mop; mop = s33 ? i3 : mop;  mop = s32 ? m32 : mop;  mop = s31 ? m31 : mop;  mop = s30 ? m30 : mop;
-      // panel: X_I = A_I[:, 4s..4s+3] L_p^-T  (register 0 of the product = X_I[row lr][column lk])
-      double x[4];
-#pragma unroll
-      for (int I = JQ; I < 4; ++I) x[I] = mfma_f64(mop, Lt[tidx(I, JQ)][s], zero)[0];
-      const double xw = mfma_f64(mop, W[s], zero)[0];
-#pragma unroll
-      for (int I = JQ; I < 4; ++I) Lt[tidx(I, JQ)][s] = x[I];
-      W[s] = xw;
-      if (s < 3) {
-        // rank-4 update of the columns right of the pivot block inside this 16-column phase
-        const double xm = (lr > 4 * s + 3) ? x[JQ] : 0.0;
-        Lt[dq] = mfma_f64(-xm, xm, Lt[dq]);
-#pragma unroll
-        for (int I = JQ + 1; I < 4; ++I) Lt[tidx(I, JQ)] = mfma_f64(-xm, x[I], Lt[tidx(I, JQ)]);
-        W = mfma_f64(-xm, xw, W);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double v = (lk + 4 * r >= lr) ? W[r] : 0.0;          // W lane (lr, lk) reg r = (L_JQ,JQ^-1)[lk + 4r][lr]
-      Wi[JQ][lr * 16 + lk + 4 * r] = v;
-      if (Winv) Winv[(size_t)JQ * 256 + lr * 16 + lk + 4 * r] = v;
-    }
-    // rank-16 update of the sub-tiles right of this phase (diagonal ones first: they head the next chain)
-#pragma unroll
-    for (int J = JQ + 1; J < 4; ++J)
-#pragma unroll
-      for (int I = J; I < 4; ++I)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          Lt[tidx(I, J)] = mfma_f64(-Lt[tidx(J, JQ)][ks], Lt[tidx(I, JQ)][ks], Lt[tidx(I, J)]);
-  }
-  return !(dmin > 0.0);
-}
-
 #ifdef SLIDE_STAMPS
-__device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_stamps[40];
 #define STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMPW(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)   // no barrier
 #else
 #define STAMP(i)
+#define STAMPW(i)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -151,10 +58,10 @@ __device__ unsigned long long g_stamps[16];
 // needs only the kernel boundary.  MFMA accumulator layout of X_c^T (row (lane>>4) + 4r, column lane&15) is
 // exactly the B-operand layout of k-step r, so chained products need no lane movement.
 // ---------------- type B: trailing update with panel k-1, one 2x2 group of 64x64 tiles per workgroup ----------------
-// Wave (wm, wn) owns tile (i, j) = (i0 + wm, j0 + wn) entirely: sixteen 16x16 accumulators initialised with C itself,
-// sixteen k-steps of eight operand loads feeding sixteen MFMAs (the loads run two k-steps ahead of their use), so the
-// wave is paced by the matrix pipe even at one or two waves per SIMD — the occupancy the register-heavy type A
-// leaves to the launch.  No LDS, no barrier: waves whose tile lies outside the lower triangle leave at once.
+// Eight waves: wave pair (wm, wn) owns tile (i, j) = (i0 + wm, j0 + wn), each wave one 32-column half of it: eight 16x16
+// accumulators initialised with C itself, sixteen k-steps of six operand loads feeding eight MFMAs (the loads run two
+// k-steps ahead of their use), so the wave is paced by the matrix pipe at the two waves per SIMD the register-heavy
+// type A leaves to the launch.  No LDS, no barrier: waves whose tile lies outside the lower triangle leave at once.
 __device__ __forceinline__ long long tri_row(long long t) {
   long long ii = (long long)floor((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while (ii * (ii + 1) / 2 > t) --ii;
@@ -162,194 +69,460 @@ __device__ __forceinline__ long long tri_row(long long t) {
   return ii;
 }
 __device__ __forceinline__ void step_type_b(double* __restrict__ S, int ld, int k, int T, long long t) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // eight waves: tile (wave >> 1), column half (wave & 1)
   const int lr = lane & 15, lk = lane >> 4;
   const long long bi = tri_row(t);
   const int bj = (int)(t - bi * (bi + 1) / 2);
-  const int i = k + 1 + 2 * (int)bi + (wave >> 1), j = k + 1 + 2 * bj + (wave & 1);
+  const int i = k + 1 + 2 * (int)bi + (wave >> 2), j = k + 1 + 2 * bj + ((wave >> 1) & 1), h = wave & 1;
   if (i > T || j > T - 1 || i < j) return;
-  const double* pj = S + (size_t)((k - 1) * NB) * ld + (size_t)j * NB + lr;   // + 16a : rows 16a + lr of panel tile (j, k-1)
-  const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)i * NB + lr;   // + 16b : rows 16b + lr of panel tile (i, k-1)
-  double* cb = S + (size_t)(j * NB + lk) * ld + (size_t)i * NB + lr;          // + (16a + 4r) ld + 16b
-  // two passes of 32 columns (a = 2h, 2h+1) x 64 rows: eight accumulators live at a time
-#pragma unroll 1
-  for (int h = 0; h < 2; ++h) {
-    const double* pjh = pj + 32 * h;
-    double* cbh = cb + (size_t)(32 * h) * ld;
-    v4d acc[2][4];
+  const double* pjh = S + (size_t)((k - 1) * NB) * ld + (size_t)j * NB + 32 * h + lr;   // + 16a : rows 32h + 16a + lr of panel tile (j, k-1)
+  const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)i * NB + lr;             // + 16b : rows 16b + lr of panel tile (i, k-1)
+  double* cbh = S + (size_t)(j * NB + 32 * h + lk) * ld + (size_t)i * NB + lr;          // + (16a + 4r) ld + 16b
+  v4d acc[2][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[a][b][r] = cbh[(size_t)(16 * a + 4 * r) * ld + 16 * b];
-    double pa[3][2], pb[3][4];
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = cbh[(size_t)(16 * a + 4 * r) * ld + 16 * b];
+  double pa[3][2], pb[3][4];
 #pragma unroll
-    for (int pre = 0; pre < 2; ++pre) {
-      const size_t off = (size_t)(4 * pre + lk) * ld;
-      pa[pre][0] = pjh[off]; pa[pre][1] = pjh[off + 16];
+  for (int pre = 0; pre < 2; ++pre) {
+    const size_t off = (size_t)(4 * pre + lk) * ld;
+    pa[pre][0] = pjh[off]; pa[pre][1] = pjh[off + 16];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) pb[pre][b] = pi[off + 16 * b];
+    for (int b = 0; b < 4; ++b) pb[pre][b] = pi[off + 16 * b];
+  }
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    if (ks + 2 < 16) {
+      const size_t off = (size_t)(4 * (ks + 2) + lk) * ld;
+      pa[(ks + 2) % 3][0] = pjh[off]; pa[(ks + 2) % 3][1] = pjh[off + 16];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) pb[(ks + 2) % 3][b] = pi[off + 16 * b];
+    }
+    __builtin_amdgcn_sched_barrier(0);      // keep the two-k-step prefetch distance: no further hoisting of loads
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const double na = -pa[ks % 3][a];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = mfma_f64(na, pb[ks % 3][b], acc[a][b]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cbh[(size_t)(16 * a + 4 * r) * ld + 16 * b] = acc[a][b][r];
+}
+
+// ---------------- type A: look-ahead chain of block column k for row tile it = k + 1 + ia ----------------
+// The 64x64 diagonal tile D = (k, k) is handled as 16x16 sub-tiles in the MFMA accumulator layout of the transpose
+// ("T-layout": lane (lr = lane&15, lk = lane>>4), register r of sub-tile (I, J) holds D[16I + lr][16J + lk + 4r]).
+// In that layout register s of a sub-tile is the B operand "rows lr, columns 4s..4s+3", so
+//   * the rank-4 panel step X = D[:, j..j+3] L_p^-T is ONE v_mfma_f64_16x16x4_f64 per 16 rows: the A operand "mop" is
+//     the 4x4 inverse of the pivot block's Cholesky factor zero-padded to 16x4, and register 0 of the product is X in
+//     the same "rows lr, four columns" form;
+//   * the rank-4 update of a sub-tile is ONE MFMA with two such X registers as A and B operands.
+// Only the 4x4 pivot Cholesky + inverse (four chained rsqrt) runs on the vector ALU, on wave-uniform values fetched
+// with v_readlane.  That serial chain is the critical path of the whole factorisation, so the eight waves specialise:
+//   wave 0 ("chain"): owns the current diagonal sub-tile (J, J); per iteration n = 4 JQ + s it factors the pivot block,
+//       publishes mop and the masked X of its sub-tile (xm) through LDS and raises it_done; its own MFMAs are the
+//       panel step and the in-phase update of that one sub-tile.
+//   waves 1..3 ("workers"): own sub-tile row w of D.  They follow the published (mop, xm) stream one iteration behind:
+//       panel step and in-phase update of (w, JQ), at the end of a 16-column phase the rank-16 updates of (w, J > JQ) —
+//       the neighbours' finished sub-tiles come from LDS — and after phase w-1 they hand the finished diagonal
+//       sub-tile (w, w) to the chain wave.  The update of their sub-tiles with panel k-1 (which commutes with the
+//       rank-16 updates) is spread over the iterations before each sub-tile's own phase.  Worker 2 also carries the
+//       identity pseudo-tile of every phase, which ends as L_JJ^-T (the 16x16 inverses of the triangular solves).
+//   waves 4..7 ("panel"): own 16 rows each of the panel tile (it, k): update with panel k-1 while the factorisation
+//       runs on the other wave of their SIMD, then, after the closing barrier, X = A L^-T for their rows by blocked
+//       substitution with the finished sub-tiles (LDS) and inverses.
+// The panel tile (k, k-1) all of them need as A operand is staged once through LDS.  All hand-offs are LDS flags between
+// resident waves of one workgroup (no cycle: every wait is on an earlier iteration / phase).  Redundant factoring
+// across the T-k workgroups costs no latency and keeps L_kk out of L2.
+constexpr int PSTR = 80;   // LDS column stride of the staged panel tile: the four 16-lane groups of a ds_read_b64 fall in disjoint bank halves
+constexpr int WT = 2;      // the worker that carries the identity pseudo-tiles
+struct ALds {
+  double Pk[NB][PSTR];  // panel tile (k, k-1): Pk[kk][r] = L[k*NB + r][(k-1)*NB + kk]   (rows of the diagonal block)
+  double mop[16][64];   // iteration n: A operand of the panel MFMAs, lane image
+  double xm[16][64];    // iteration n: masked X of the diagonal sub-tile = A operand of the in-phase updates, lane image
+  double Lt[6][4][64];  // finished off-diagonal sub-tiles L(I, J), I > J, at index I (I - 1) / 2 + J, register, lane
+  double Dh[3][4][64];  // hand-off of the updated diagonal sub-tile (J, J), J = 1..3
+  double Wi[4][256];    // Wi[b][c * 16 + r] = (L_bb^-1)[r][c]
+  int it_done;          // iterations published by the chain wave
+  int col_done[4];      // col_done[I]: columns J of row I published in Lt
+  int d_ready[4];       // d_ready[J]: Dh[J - 1] is valid
+  int w_done;           // inverses Wi[0 .. w_done-1] are valid
+};
+
+// Flags between the waves of one workgroup live in LDS.  DS operations of one wave are carried out in issue order,
+// so a flag written after its data is seen after it; only the compiler has to be kept from reordering (no s_waitcnt
+// on the producer: a release fence would also drain the wave's outstanding global loads and stores).
+// Raw DS instructions on the LDS byte offset (the low 32 bits of the generic address): a volatile access through a
+// generic pointer would become a flat store with system scope followed by s_waitcnt vmcnt(0).
+__device__ __forceinline__ void lds_wait(int* f, int v) {
+  const unsigned off = (unsigned)(size_t)f;
+  int cur;
+  for (;;) {
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cur) : "v"(off) : "memory");
+    if (__builtin_amdgcn_readfirstlane(cur) >= v) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+__device__ __forceinline__ void lds_post(int* f, int v, int lane) {
+  const unsigned off = (unsigned)(size_t)f;
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  if (lane == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(off), "v"(v) : "memory");
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+__device__ __forceinline__ constexpr int oidx(int I, int J) { return I * (I - 1) / 2 + J; }   // I > J
+// The flag waits are opaque asm: without a use of the accumulators in front of them the compiler sinks the MFMAs that
+// were meant to run during the wait to behind it.
+__device__ __forceinline__ void pin(v4d& x) { asm volatile("" : "+v"(x)); }
+
+// ---- wave 0 ---------------------------------------------------------------------------------------------------------
+template <bool HASK>
+__device__ __forceinline__ void a_chain_wave(int ia, int* status, ALds& L, int lane, v4d Dt) {
+  const int lr = lane & 15, lk = lane >> 4;
+  const v4d zero = v4d{0.0, 0.0, 0.0, 0.0};
+  // lane predicates of the 4x4 inverse inside the 16x4 A operand: row lr < 4, column lk <= lr
+  const bool s00 = lr == 0 && lk == 0, s10 = lr == 1 && lk == 0, s11 = lr == 1 && lk == 1, s20 = lr == 2 && lk == 0,
+             s21 = lr == 2 && lk == 1, s22 = lr == 2 && lk == 2, s30 = lr == 3 && lk == 0, s31 = lr == 3 && lk == 1,
+             s32 = lr == 3 && lk == 2, s33 = lr == 3 && lk == 3;
+  if (HASK) {
+    // panel k-1 on sub-tile (0, 0): four independent accumulation chains instead of one of sixteen
+    v4d d1 = zero, d2 = zero, d3 = zero;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const double q0 = L.Pk[4 * ks + lk][lr], q1 = L.Pk[16 + 4 * ks + lk][lr], q2 = L.Pk[32 + 4 * ks + lk][lr], q3 = L.Pk[48 + 4 * ks + lk][lr];
+      Dt = mfma_f64(-q0, q0, Dt);
+      d1 = mfma_f64(-q1, q1, d1);
+      d2 = mfma_f64(-q2, q2, d2);
+      d3 = mfma_f64(-q3, q3, d3);
+    }
+    Dt = (Dt + d1) + (d2 + d3);
+  }
+  bool ok = true;
+  STAMPW(3);
+#pragma unroll
+  for (int JQ = 0; JQ < 4; ++JQ) {
+    if (JQ > 0) {
+      STAMPW(3 + 2 * JQ - 1);
+      lds_wait(&L.d_ready[JQ], 1);
+      STAMPW(3 + 2 * JQ);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Dt[r] = L.Dh[JQ - 1][r][lane];
     }
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      if (ks + 2 < 16) {
-        const size_t off = (size_t)(4 * (ks + 2) + lk) * ld;
-        pa[(ks + 2) % 3][0] = pjh[off]; pa[(ks + 2) % 3][1] = pjh[off + 16];
+    for (int r = 0; r < 4; ++r)
+      if (lr < lk + 4 * r) Dt[r] = 0.0;          // upper triangle: never read for a result, keep it finite
 #pragma unroll
-        for (int b = 0; b < 4; ++b) pb[(ks + 2) % 3][b] = pi[off + 16 * b];
-      }
-      __builtin_amdgcn_sched_barrier(0);      // keep the two-k-step prefetch distance: no further hoisting of loads
+    for (int s = 0; s < 4; ++s) {
+      const int n = 4 * JQ + s;
+      const double dv = Dt[s];   // columns 4s..4s+3 of the sub-tile; element (4s+a, 4s+b) sits in lane 4s+a+16b
+      const double P00 = bcast_lane(dv, 4 * s), P10 = bcast_lane(dv, 4 * s + 1), P20 = bcast_lane(dv, 4 * s + 2), P30 = bcast_lane(dv, 4 * s + 3);
+      const double P11 = bcast_lane(dv, 4 * s + 1 + 16), P21 = bcast_lane(dv, 4 * s + 2 + 16), P31 = bcast_lane(dv, 4 * s + 3 + 16);
+      const double P22 = bcast_lane(dv, 4 * s + 2 + 32), P32 = bcast_lane(dv, 4 * s + 3 + 32), P33 = bcast_lane(dv, 4 * s + 3 + 48);
+      // a non-positive pivot only raises the flag: the NaNs it breeds stay inside this (rejected) factorisation
+      const double i0 = rsqrt_nr(P00);
+      const double l10 = P10 * i0, l20 = P20 * i0, l30 = P30 * i0;
+      const double d1 = P11 - l10 * l10;
+      const double i1 = rsqrt_nr(d1);
+      const double l21 = (P21 - l20 * l10) * i1, l31 = (P31 - l30 * l10) * i1;
+      const double d2 = P22 - l20 * l20 - l21 * l21;
+      const double i2 = rsqrt_nr(d2);
+      const double l32 = (P32 - l30 * l20 - l31 * l21) * i2;
+      const double d3 = P33 - l30 * l30 - l31 * l31 - l32 * l32;
+      const double i3 = rsqrt_nr(d3);
+      ok = ok && (P00 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (d3 > 0.0);
+      // M = L_p^-1 (lower 4x4)
+      const double m10 = -l10 * i0 * i1;
+      const double m21 = -l21 * i1 * i2;
+      const double m20 = -(l20 * i0 + l21 * m10) * i2;
+      const double m32 = -l32 * i2 * i3;
+      const double m31 = -(l31 * i1 + l32 * m21) * i3;
+      const double m30 = -(l30 * i0 + l31 * m10 + l32 * m20) * i3;
+      double mop = 0.0;                       // selected in order of availability: the last link follows m30 directly
+      mop = s00 ? i0 : mop;  mop = s11 ? i1 : mop;  mop = s10 ? m10 : mop;  mop = s22 ? i2 : mop;  mop = s21 ? m21 : mop;
+      mop = s20 ? m20 : mop; mop = s33 ? i3 : mop;  mop = s32 ? m32 : mop;  mop = s31 ? m31 : mop;  mop = s30 ? m30 : mop;
+      L.mop[n][lane] = mop;
+      const double xd = mfma_f64(mop, Dt[s], zero)[0];          // X[row lr][column lk] of the diagonal sub-tile
+      Dt[s] = xd;
+      const double xm = (lr > 4 * s + 3) ? xd : 0.0;            // rows below the pivot block only
+      L.xm[n][lane] = xm;
+      lds_post(&L.it_done, n + 1, lane);
+      if (n < 4) STAMPW(32 + n);
+      if (s < 3) Dt = mfma_f64(-xm, xm, Dt);
+    }
+  }
+  STAMPW(10);
+  if (!ok && lane == 0 && ia == 0) atomicOr(&status[1], 1);
+}
+
+// ---- waves 1..3 -----------------------------------------------------------------------------------------------------
+template <int W, bool HASK>
+__device__ __forceinline__ void a_worker_wave(int ia, double* __restrict__ Ld, double* __restrict__ Winv, ALds& L, int lane,
+                                              v4d (&R)[W + 1]) {
+  const int lr = lane & 15, lk = lane >> 4;
+  const v4d zero = v4d{0.0, 0.0, 0.0, 0.0};
+  if (HASK) {
+    // the whole sub-tile row before the first iteration, in the order of need: a worker answers an iteration of the
+    // chain wave in about 500 cycles but needs twice that with a quarter of a sub-tile update on top, so it is better
+    // late for the first iterations (it catches up well before its hand-off) than slow in all of them
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const double na = -pa[ks % 3][a];
+    for (int J = 0; J <= W; ++J) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = mfma_f64(na, pb[ks % 3][b], acc[a][b]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      for (int ks = 0; ks < 16; ++ks) R[J] = mfma_f64(-L.Pk[4 * ks + lk][16 * J + lr], L.Pk[4 * ks + lk][16 * W + lr], R[J]);
+      pin(R[J]);
+    }
+  }
+  v4d Wt = zero;                   // identity pseudo-tile (worker WT only)
+#pragma unroll
+  for (int JQ = 0; JQ < W; ++JQ) {
+    if (W == WT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Wt[r] = (lr == lk + 4 * r) ? 1.0 : 0.0;
     }
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int s = 0; s < 4; ++s) {
+      const int n = 4 * JQ + s;
+      lds_wait(&L.it_done, n + 1);
+      if (W == 1 && n == 3) STAMPW(11);
+      if (W == 1 && n < 3) STAMPW(16 + n);
+      if (W == 3 && n < 12) STAMPW(20 + n);
+      const double mop = L.mop[n][lane], xm = L.xm[n][lane];
+      const double x = mfma_f64(mop, R[JQ][s], zero)[0];
+      double xw = 0.0;
+      if (W == WT) xw = mfma_f64(mop, Wt[s], zero)[0];
+      R[JQ][s] = x;
+      if (W == WT) Wt[s] = xw;
+      if (s < 3) {
+        R[JQ] = mfma_f64(-xm, x, R[JQ]);
+        if (W == WT) Wt = mfma_f64(-xm, xw, Wt);
+      }
+      // the rank-16 update of the diagonal sub-tile one k-step at a time: register s of (W, JQ) is final from here on
+      R[W] = mfma_f64(-R[JQ][s], R[JQ][s], R[W]);
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int J = 0; J <= W; ++J) pin(R[J]);
+      if (W == WT) pin(Wt);
+    }
+    if (JQ == W - 1) {
+      // hand-off first, publication of the finished column block after it
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cbh[(size_t)(16 * a + 4 * r) * ld + 16 * b] = acc[a][b][r];
+      for (int r = 0; r < 4; ++r) L.Dh[W - 1][r][lane] = R[W][r];
+      lds_post(&L.d_ready[W], 1, lane);
+      if (W == 1) STAMPW(13);
+    }
+    // column block JQ of row W is final
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      L.Lt[oidx(W, JQ)][r][lane] = R[JQ][r];
+      if (ia == 0) Ld[(size_t)(16 * JQ + lk + 4 * r) * NB + 16 * W + lr] = R[JQ][r];
+    }
+    lds_post(&L.col_done[W], JQ + 1, lane);
+    if (W == 1) STAMPW(12);
+    // rank-16 updates of the other sub-tiles right of this phase
+#pragma unroll
+    for (int J = JQ + 1; J < W; ++J) {
+      lds_wait(&L.col_done[J], JQ + 1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) R[J] = mfma_f64(-L.Lt[oidx(J, JQ)][ks][lane], R[JQ][ks], R[J]);
+    }
+    if (W == WT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double v = (lk + 4 * r >= lr) ? Wt[r] : 0.0;      // Wt lane (lr, lk) reg r = (L_JQ,JQ^-1)[lk + 4r][lr]
+        L.Wi[JQ][lr * 16 + lk + 4 * r] = v;
+        if (ia == 0) Winv[(size_t)JQ * 256 + lr * 16 + lk + 4 * r] = v;
+      }
+      lds_post(&L.w_done, JQ + 1, lane);
+    }
+  }
+  static_assert(W >= 1 && W <= 3, "worker index");
+  if (W == WT) {
+    // identity pseudo-tiles of the phases after the own ones
+#pragma unroll
+    for (int JQ = WT; JQ < 4; ++JQ) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Wt[r] = (lr == lk + 4 * r) ? 1.0 : 0.0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int n = 4 * JQ + s;
+        lds_wait(&L.it_done, n + 1);
+        const double mop = L.mop[n][lane], xm = L.xm[n][lane];
+        const double xw = mfma_f64(mop, Wt[s], zero)[0];
+        Wt[s] = xw;
+        if (s < 3) Wt = mfma_f64(-xm, xw, Wt);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double v = (lk + 4 * r >= lr) ? Wt[r] : 0.0;
+        L.Wi[JQ][lr * 16 + lk + 4 * r] = v;
+        if (ia == 0) Winv[(size_t)JQ * 256 + lr * 16 + lk + 4 * r] = v;
+      }
+      lds_post(&L.w_done, JQ + 1, lane);
+    }
   }
 }
 
-// ---------------- type A: look-ahead chain of block column k for row tile k + 1 + ia ----------------
-__device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int k, int ia, double* __restrict__ Ld,
-                                            double* __restrict__ Winv, int* status, double (*Tx)[4][64], double (*Wi)[16 * 16]) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// ---- panel rows: 16 rows of tile (it, k), T-layout: Tq[b][r] = A[16 q + lr][16b + lk + 4r] ----------------------------------
+template <bool HASK>
+__device__ __forceinline__ void panel_load(const double* __restrict__ S, int ld, int k, int it, int q, int lr, int lk,
+                                           v4d (&Tq)[4], double (&tb)[16]) {
+  const double* tcol = S + (size_t)(k * NB) * ld + (size_t)it * NB + 16 * q + lr;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Tq[b][r] = tcol[(size_t)(16 * b + lk + 4 * r) * ld];
+  if (HASK) {
+    const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)it * NB + 16 * q + lr;   // own rows of panel tile (it, k-1)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) tb[ks] = pi[(size_t)(4 * ks + lk) * ld];
+  }
+}
+// Column block p of the own rows: pending update from panel k-1, then X_p = (A_p - sum_{c<p} X_c L(p,c)^T) L_pp^-T as soon
+// as phase p of the factorisation has delivered L(p, c) and the inverse of L_pp — only the last block is left when the
+// chain wave finishes.  Nothing before the first phase is through: until then the factor waves are busy with panel k-1
+// themselves and this wave would only compete for the matrix pipe and the LDS.
+template <bool HASK>
+__device__ __forceinline__ void panel_rows(double* __restrict__ S, int ld, int k, int it, int q, int lane, ALds& L, v4d (&Tq)[4],
+                                           const double (&tb)[16]) {
   const int lr = lane & 15, lk = lane >> 4;
-  STAMP(0);
-  const int it = k + 1 + ia;
-  const int ti = tid & 15, tj = tid >> 4;
-  // own rows (16 per wave) of tile (it, k) and of the diagonal tile (k, k), both in the transposed MFMA layout
-  // t[b][r] = A[row 16*wave + lr][col 16b + lk + 4r]
-  const double* col = S + (size_t)(k * NB) * ld + (size_t)it * NB + 16 * wave + lr;
-  const double* dcol = S + (size_t)(k * NB) * ld + (size_t)k * NB + 16 * wave + lr;
-  v4d tt[4], dd[4];
-#pragma unroll
-  for (int b = 0; b < 4; ++b)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      tt[b][r] = col[(size_t)(16 * b + lk + 4 * r) * ld];
-      dd[b][r] = dcol[(size_t)(16 * b + lk + 4 * r) * ld];
-    }
-  STAMP(1);
-  if (k > 0) {
-    // pending update from panel k-1:  A[m][n] -= sum_kk L[m][kk] * L_k[n][kk]   (L_k = rows of tile row k)
-    const double* pk = S + (size_t)((k - 1) * NB) * ld + (size_t)k * NB + lr;             // + 16 b : L_k[16b + lr][.]
-    const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)it * NB + 16 * wave + lr;   // own rows
-    const double* pd = S + (size_t)((k - 1) * NB) * ld + (size_t)k * NB + 16 * wave + lr;    // diagonal tile's rows
-    double pa[3][4], pb[3][2];               // operands run two k-steps ahead of their MFMAs
-#pragma unroll
-    for (int pre = 0; pre < 2; ++pre) {
-      const size_t off = (size_t)(4 * pre + lk) * ld;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) pa[pre][b] = pk[off + 16 * b];
-      pb[pre][0] = pi[off]; pb[pre][1] = pd[off];
-    }
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      if (ks + 2 < 16) {
-        const size_t off = (size_t)(4 * (ks + 2) + lk) * ld;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) pa[(ks + 2) % 3][b] = pk[off + 16 * b];
-        pb[(ks + 2) % 3][0] = pi[off]; pb[(ks + 2) % 3][1] = pd[off];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const double aop = -pa[ks % 3][b];
-        tt[b] = mfma_f64(aop, pb[ks % 3][0], tt[b]);
-        dd[b] = mfma_f64(aop, pb[ks % 3][1], dd[b]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  STAMP(2);
-  // every wave takes a complete copy of the updated diagonal tile: wave w holds sub-tile row w (dd[b] = (w, b))
-#pragma unroll
-  for (int b = 0; b < 4; ++b)
-    if (b <= wave) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Tx[wave * (wave + 1) / 2 + b][r][lane] = dd[b][r];
-    }
-  __syncthreads();
-  v4d Lt[10];
-#pragma unroll
-  for (int t = 0; t < 10; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Lt[t][r] = Tx[t][r][lane];
-#pragma unroll
-  for (int J = 0; J < 4; ++J)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (lr < lk + 4 * r) Lt[tidx(J, J)][r] = 0.0;          // upper triangle: never read for a result, keep it finite
-  STAMP(3);
-  const bool bad = factor64_mfma(Lt, Wi + 4 * wave, (ia == 0 && wave == 0) ? Winv : nullptr, lr, lk);   // per-wave copies of the inverses
-  if (bad && tid == 0 && ia == 0) atomicOr(&status[1], 1);
-  STAMP(4);
-  if (ia == 0) {
-    // L_kk for the backward substitution: wave w writes sub-tile row w (every wave holds the whole factor)
-#pragma unroll
-    for (int I = 0; I < 4; ++I)
-      if (I == wave) {
-#pragma unroll
-        for (int J = 0; J < 4; ++J)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * I + lr, c = 16 * J + lk + 4 * r;
-            double v = 0.0;
-            if (J <= I) v = (i >= c) ? Lt[tidx(I, J <= I ? J : 0)][r] : 0.0;
-            Ld[(size_t)c * NB + i] = v;
-          }
-      }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  STAMP(5);
-  // blocked triangular solve of this workgroup's 64 rows (16 per wave); L operands straight from registers.
-  // The store addresses are rebuilt from a laundered copy of ld: sixteen 64-bit addresses kept alive since the loads
-  // at the top would otherwise sit in registers (or spill) through the whole factorisation.
-  int ld2 = ld;
-  asm volatile("" : "+s"(ld2));
-  double* col2 = S + (size_t)(k * NB) * ld2 + (size_t)it * NB + 16 * wave + lr;
-  v4d xt[4];
+  double* tcol = S + (size_t)(k * NB) * ld + (size_t)it * NB + 16 * q + lr;
+  v4d xt[4], t[4];
+  // order: | T(0) x(0) T(1) t(1) | x(1) T(2) t(2) | x(2) T(3) t(3) | x(3): after the last phase only the four MFMAs with the
+  // last inverse are left.  t(b) = A_b - sum_{c<b} X_c L(b,c)^T needs phase b-1, x(b) = t(b) L_bb^-T the inverse of phase b.
+  // This wave shares its SIMD with a worker that answers the chain wave with two or three MFMAs per iteration: the
+  // throughput work here goes in bursts of four MFMAs with a pause after each, so the matrix pipe is free half the time.
+#define PANEL_YIELD() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_sched_barrier(0); } while (0)
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
-    v4d t = tt[b];
+    if (b == 0) {
+      lds_wait(&L.it_done, 4);
+      if (HASK) {
 #pragma unroll
-    for (int c = 0; c < b; ++c)
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) t = mfma_f64(-Lt[tidx(b, c)][s4], xt[c][s4], t);   // -L[16b + lr][16c + lk + 4 s4]
+        for (int ks = 0; ks < 16; ++ks) {
+          Tq[0] = mfma_f64(-L.Pk[4 * ks + lk][lr], tb[ks], Tq[0]);
+          if ((ks & 3) == 3) PANEL_YIELD();
+        }
+      }
+      t[0] = Tq[0];
+    }
+    lds_wait(&L.w_done, b + 1);
     v4d x = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const double aop = Wi[4 * wave + b][(4 * s4 + lk) * 16 + lr];                       // (L_bb^-1)[lr][4 s4 + lk]
-      x = mfma_f64(aop, t[s4], x);
-    }
+    for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(L.Wi[b][(4 * s4 + lk) * 16 + lr], t[b][s4], x);   // (L_bb^-1)[lr][4 s4 + lk]
     xt[b] = x;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) col2[(size_t)(16 * b + lk + 4 * r) * ld2] = x[r];
+    for (int r = 0; r < 4; ++r) tcol[(size_t)(16 * b + lk + 4 * r) * ld] = x[r];
+    if (b < 3) {
+      PANEL_YIELD();
+      if (HASK) {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          Tq[b + 1] = mfma_f64(-L.Pk[4 * ks + lk][16 * (b + 1) + lr], tb[ks], Tq[b + 1]);
+          if ((ks & 3) == 3) PANEL_YIELD();
+        }
+      }
+      lds_wait(&L.col_done[b + 1], b + 1);
+      v4d tn = Tq[b + 1];
+#pragma unroll
+      for (int c = 0; c <= b; ++c) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) tn = mfma_f64(-L.Lt[oidx(b + 1, c)][s4][lane], xt[c][s4], tn);   // -L[16(b+1) + lr][16c + lk + 4 s4]
+        if (b < 2 || c < b) PANEL_YIELD();        // (not before the closing x(3))
+      }
+      t[b + 1] = tn;
+      pin(t[b + 1]);
+    }
   }
-  STAMP(6);
+#undef PANEL_YIELD
+}
+
+template <bool HASK>
+__device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld, int k, int ia, double* __restrict__ Ld,
+                                                 double* __restrict__ Winv, int* status, ALds& L) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..7
+  const int lr = lane & 15, lk = lane >> 4;
+  const int it = k + 1 + ia;
+  STAMP(0);
+  // ---- prologue: every global load of this workgroup is issued here, in one wave of traffic ----
+  if (HASK) {
+    // one eighth of panel tile (k, k-1) per wave -> LDS
+    const double* pq = S + (size_t)((k - 1) * NB + 8 * wave) * ld + (size_t)k * NB + lane;
+    double stage[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) stage[c] = pq[(size_t)c * ld];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) L.Pk[8 * wave + c][lane] = stage[c];
+  }
+  if (tid == 0) L.it_done = 0;
+  if (tid < 4) { L.col_done[tid] = 0; L.d_ready[tid] = 0; }
+  if (tid == 4) L.w_done = 0;
+  if (wave < 4) {
+    // ---------------- factor waves: own sub-tile row of D ----------------
+    const double* dcol = S + (size_t)(k * NB) * ld + (size_t)k * NB + 16 * wave + lr;
+    v4d R[4];
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) R[J][r] = (J <= wave) ? dcol[(size_t)(16 * J + lk + 4 * r) * ld] : 0.0;
+    v4d Tq[4];
+    double tb[16];
+    if (wave == 1) panel_load<HASK>(S, ld, k, it, 0, lr, lk, Tq, tb);
+    __syncthreads();
+    if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);   // ahead of the panel wave sharing the SIMD
+    if (wave == 0) {
+      a_chain_wave<HASK>(ia, status, L, lane, R[0]);
+    } else if (wave == 1) {
+      v4d R1[2] = {R[0], R[1]};
+      a_worker_wave<1, HASK>(ia, Ld, Winv, L, lane, R1);
+      panel_rows<HASK>(S, ld, k, it, 0, lane, L, Tq, tb);      // idle from here on otherwise
+    } else if (wave == 2) {
+      v4d R2[3] = {R[0], R[1], R[2]};
+      a_worker_wave<2, HASK>(ia, Ld, Winv, L, lane, R2);
+    } else {
+      a_worker_wave<3, HASK>(ia, Ld, Winv, L, lane, R);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+    STAMP(1);
+    STAMP(2);
+  } else {
+    // ---------------- panel waves 5..7: rows 16..63 of tile (it, k); rows 0..15 go to worker 1 (idle after its
+    // hand-off), so that the chain wave has its SIMD to itself (wave 4 only keeps the barriers company) ----------------
+    const int q = wave - 4;
+    v4d Tq[4];
+    double tb[16];
+    if (q > 0) panel_load<HASK>(S, ld, k, it, q, lr, lk, Tq, tb);
+    __syncthreads();
+    if (q > 0) panel_rows<HASK>(S, ld, k, it, q, lane, L, Tq, tb);
+    STAMPW(14);
+    __syncthreads();
+    STAMP(1);
+    STAMP(2);
+  }
+}
+__device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int k, int ia, double* __restrict__ Ld,
+                                            double* __restrict__ Winv, int* status, ALds& L) {
+  if (k > 0) step_type_a_impl<true>(S, ld, k, ia, Ld, Winv, status, L);
+  else step_type_a_impl<false>(S, ld, k, ia, Ld, Winv, status, L);
 }
 
 // Work queue of the type-B groups: every workgroup of the launch (the type-A ones after their chain, too) draws group
 // indices from ctr[k] until they run out, so the ~T-k long type-A chains and the flood balance by themselves at the one
 // workgroup per CU the register-heavy kernel gets.  ctr[k+1] is cleared here for the next launch (ctr[0..1] start at 0).
-__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Ld,
+__global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Ld,
                                                    double* __restrict__ Winv, int* status, int* __restrict__ ctr, int nGroups) {
-  __shared__ double Tx[10][4][64];        // exchange of the updated diagonal tile: sub-tile, register, lane
-  __shared__ double Wi[16][16 * 16];      // per wave w: Wi[4w + b][c * 16 + r] = (L_bb^-1)[r][c]
+  __shared__ ALds L;
   __shared__ int s_g;
   const int nA = T - k;
   if (blockIdx.x == 0 && threadIdx.x == 0) ctr[k + 1] = 0;
-  if ((int)blockIdx.x < nA) step_type_a(S, ld, k, (int)blockIdx.x, Ld, Winv, status, Tx, Wi);
+  if ((int)blockIdx.x < nA) step_type_a(S, ld, k, (int)blockIdx.x, Ld, Winv, status, L);
   if (nGroups <= 0) return;
   for (;;) {
     __syncthreads();
@@ -361,13 +534,12 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int l
   }
 }
 // diagnostic split (SLIDE_CHOL_SPLIT=1): the two kinds of workgroups as separate launches
-__global__ __launch_bounds__(256) void k_chol_a(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Ld,
+__global__ __launch_bounds__(512) void k_chol_a(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Ld,
                                                 double* __restrict__ Winv, int* status) {
-  __shared__ double Tx[10][4][64];
-  __shared__ double Wi[16][16 * 16];
-  step_type_a(S, ld, k, (int)blockIdx.x, Ld, Winv, status, Tx, Wi);
+  __shared__ ALds L;
+  step_type_a(S, ld, k, (int)blockIdx.x, Ld, Winv, status, L);
 }
-__global__ __launch_bounds__(256) void k_chol_b(double* __restrict__ S, int ld, int k, int T) { step_type_b(S, ld, k, T, (long long)blockIdx.x); }
+__global__ __launch_bounds__(512) void k_chol_b(double* __restrict__ S, int ld, int k, int T) { step_type_b(S, ld, k, T, (long long)blockIdx.x); }
 
 #ifdef SLIDE_STAMPS
 extern "C" void slide_debug_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
@@ -509,8 +681,8 @@ void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv,
   const long long nB = k > 0 ? nP * (nP + 1) / 2 : 0;           // groups that still owe the update of panel k-1
   static const int split = getenv("SLIDE_CHOL_SPLIT") ? atoi(getenv("SLIDE_CHOL_SPLIT")) : 0;
   if (split == 1) {
-    hipLaunchKernelGGL(k_chol_a, dim3((unsigned)nA), dim3(256), 0, s, S, ld, k, T, Ld, Winv, status);
-    if (nB > 0) hipLaunchKernelGGL(k_chol_b, dim3((unsigned)nB), dim3(256), 0, s, S, ld, k, T);
+    hipLaunchKernelGGL(k_chol_a, dim3((unsigned)nA), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status);
+    if (nB > 0) hipLaunchKernelGGL(k_chol_b, dim3((unsigned)nB), dim3(512), 0, s, S, ld, k, T);
     return;
   }
   if (split == 2) {   // the two kinds as concurrent launches on two streams (fork / join per step)
@@ -521,9 +693,9 @@ void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv,
       (void)hipEventRecord(ef, s);
       (void)hipStreamWaitEvent(s2, ef, 0);
     }
-    hipLaunchKernelGGL(k_chol_a, dim3((unsigned)nA), dim3(256), 0, s, S, ld, k, T, Ld, Winv, status);
+    hipLaunchKernelGGL(k_chol_a, dim3((unsigned)nA), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status);
     if (nB > 0) {
-      hipLaunchKernelGGL(k_chol_b, dim3((unsigned)nB), dim3(256), 0, s2, S, ld, k, T);
+      hipLaunchKernelGGL(k_chol_b, dim3((unsigned)nB), dim3(512), 0, s2, S, ld, k, T);
       (void)hipEventRecord(ej, s2);
       (void)hipStreamWaitEvent(s, ej, 0);
     }
@@ -536,8 +708,8 @@ void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv,
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
   }
-  const long long extra = nB < n_cu ? nB : n_cu;                // queue workers beside the type-A workgroups
-  hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nA + extra)), dim3(256), 0, s, S, ld, k, T, Ld, Winv, status, ctr, (int)nB);
+  const long long extra = nB < n_cu ? nB : n_cu;                // queue workers beside the type-A workgroups (one 512-thread workgroup per CU)
+  hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nA + extra)), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status, ctr, (int)nB);
 }
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, hipStream_t s) {
   hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv);
