@@ -85,9 +85,10 @@ __device__ __forceinline__ void step_type_b(double* __restrict__ S, int ld, int 
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[a][b][r] = cbh[(size_t)(16 * a + 4 * r) * ld + 16 * b];
-  double pa[3][2], pb[3][4];
+  constexpr int RD = 6;                      // operand ring: loads run RD - 1 k-steps (about 2500 cycles of MFMAs) ahead
+  double pa[RD][2], pb[RD][4];
 #pragma unroll
-  for (int pre = 0; pre < 2; ++pre) {
+  for (int pre = 0; pre < RD - 1; ++pre) {
     const size_t off = (size_t)(4 * pre + lk) * ld;
     pa[pre][0] = pjh[off]; pa[pre][1] = pjh[off + 16];
 #pragma unroll
@@ -95,18 +96,18 @@ __device__ __forceinline__ void step_type_b(double* __restrict__ S, int ld, int 
   }
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
-    if (ks + 2 < 16) {
-      const size_t off = (size_t)(4 * (ks + 2) + lk) * ld;
-      pa[(ks + 2) % 3][0] = pjh[off]; pa[(ks + 2) % 3][1] = pjh[off + 16];
+    if (ks + RD - 1 < 16) {
+      const size_t off = (size_t)(4 * (ks + RD - 1) + lk) * ld;
+      pa[(ks + RD - 1) % RD][0] = pjh[off]; pa[(ks + RD - 1) % RD][1] = pjh[off + 16];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) pb[(ks + 2) % 3][b] = pi[off + 16 * b];
+      for (int b = 0; b < 4; ++b) pb[(ks + RD - 1) % RD][b] = pi[off + 16 * b];
     }
-    __builtin_amdgcn_sched_barrier(0);      // keep the two-k-step prefetch distance: no further hoisting of loads
+    __builtin_amdgcn_sched_barrier(0);      // keep the prefetch distance: no further hoisting of loads
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      const double na = -pa[ks % 3][a];
+      const double na = -pa[ks % RD][a];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = mfma_f64(na, pb[ks % 3][b], acc[a][b]);
+      for (int b = 0; b < 4; ++b) acc[a][b] = mfma_f64(na, pb[ks % RD][b], acc[a][b]);
     }
     __builtin_amdgcn_sched_barrier(0);
   }

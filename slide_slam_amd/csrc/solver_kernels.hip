@@ -5,6 +5,7 @@
 // FP64; the matrix-core work lives in chol_kernels.hip.  All reductions are gathers in a fixed
 // order (no floating-point atomics) so results are bit-stable run to run.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include "graph_dev.hpp"
 #include "kernels.hpp"
@@ -425,71 +426,102 @@ __global__ __launch_bounds__(256) void k_landmark(GraphDev G) {
 // ------------------------------------------------------------------------------------------------
 // pose reduce: H_pp (6x6) and the already-reduced gradient g_p - sum_f F_f g_l
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_pose(GraphDev G) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+// One WAVE per pose, one lane per incident factor (the few priors / odometry factors ride on the first lanes): every lane
+// forms the 21 + 6 numbers of its factor's J^T J and J^T r - u in registers, the 64 partial sums meet in an LDS transpose
+// and lane e < 42 adds column e and writes entry e of (H_pp | g_p) — so the dependent index -> record -> Jacobian loads of
+// all factors of a pose are in flight at once instead of one after the other.
+__global__ __launch_bounds__(256) void k_pose(GraphDev G) {
+  __shared__ double part[4][27][65];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + wave;
   if (p >= G.P) return;
-  double H[36], g[6];
+  double H[21], g[6];       // lower triangle, index a (a + 1) / 2 + c, c <= a
 #pragma unroll
-  for (int i = 0; i < 36; ++i) H[i] = 0.0;
+  for (int i = 0; i < 21; ++i) H[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) g[i] = 0.0;
-  for (int q = 0; q < G.n_prior; ++q) {
-    if (G.pr_pose[q] != p) continue;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const double w = 1.0 / G.pr_sigma[6 * q + k];
-      H[7 * k] += w * w;
-      g[k] += w * G.pr_r[6 * q + k];
-    }
-  }
-  for (int q = G.pose_bt_ptr[p]; q < G.pose_bt_ptr[p + 1]; ++q) {
-    const int ent = G.pose_bt[q];
-    const int b = ent >> 1, role = ent & 1;
-    const double* r = G.bt_r + 6 * (size_t)b;
-    if (role == 1) {
+  const int nbt = G.pose_bt_ptr[p + 1] - G.pose_bt_ptr[p];
+  const int nlf = G.pose_ptr[p + 1] - G.pose_ptr[p];
+  for (int e = lane; e < G.n_prior + nbt + nlf; e += 64) {
+    if (e < G.n_prior) {
+      if (G.pr_pose[e] != p) continue;
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        const double w = 1.0 / G.bt_sigma[6 * b + k];
-        H[7 * k] += w * w;
-        g[k] += w * r[k];
+        const double w = 1.0 / G.pr_sigma[6 * e + k];
+        H[k * (k + 1) / 2 + k] += w * w;
+        g[k] += w * G.pr_r[6 * e + k];
       }
-    } else {
-      const double* J = G.bt_J0 + 36 * (size_t)b;
+    } else if (e < G.n_prior + nbt) {
+      const int ent = G.pose_bt[G.pose_bt_ptr[p] + e - G.n_prior];
+      const int b = ent >> 1, role = ent & 1;
+      const double* r = G.bt_r + 6 * (size_t)b;
+      if (role == 1) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < 6; ++k) {
+          const double w = 1.0 / G.bt_sigma[6 * b + k];
+          H[k * (k + 1) / 2 + k] += w * w;
+          g[k] += w * r[k];
+        }
+      } else {
+        const double* J = G.bt_J0 + 36 * (size_t)b;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          g[a] += J[6 * k + a] * r[k];
+        for (int k = 0; k < 6; ++k) {
+          double jr[6];
 #pragma unroll
-          for (int c = 0; c < 6; ++c) H[6 * a + c] += J[6 * k + a] * J[6 * k + c];
+          for (int a = 0; a < 6; ++a) jr[a] = J[6 * k + a];
+          const double rk = r[k];
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            g[a] += jr[a] * rk;
+#pragma unroll
+            for (int c = 0; c <= a; ++c) H[a * (a + 1) / 2 + c] += jr[a] * jr[c];
+          }
         }
       }
-    }
-  }
-  for (int q = G.pose_ptr[p]; q < G.pose_ptr[p + 1]; ++q) {
-    const int f = G.pose_fids[q];
-    const int type = G.lf_type[f];
-    const int M = lf_rows(type), D = M;  // square landmark blocks: m == d for all three factor kinds
-    const double* rec = G.jbuf + G.lf_joff[f];
-    const double* Jp = rec + M;
-    for (int k = 0; k < M; ++k) {
-      const double rk = rec[k];
+    } else {
+      const int f = G.pose_fids[G.pose_ptr[p] + e - G.n_prior - nbt];
+      const int M = lf_rows(G.lf_type[f]);   // square landmark blocks: m == d for all three factor kinds
+      const double* rec = G.jbuf + G.lf_joff[f];
+      const double* Jp = rec + M;
+      for (int k = 0; k < M; ++k) {
+        const double rk = rec[k];
+        double jr[6];
 #pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        const double ja = Jp[6 * k + a];
-        g[a] += ja * rk;
+        for (int a = 0; a < 6; ++a) jr[a] = Jp[6 * k + a];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) H[6 * a + c] += ja * Jp[6 * k + c];
+        for (int a = 0; a < 6; ++a) {
+          g[a] += jr[a] * rk;
+#pragma unroll
+          for (int c = 0; c <= a; ++c) H[a * (a + 1) / 2 + c] += jr[a] * jr[c];
+        }
       }
-    }
-    const double* u = G.ebuf + G.lf_eoff[f] + 12 * D;
+      const double* u = G.ebuf + G.lf_eoff[f] + 12 * M;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) g[a] -= u[a];
+      for (int a = 0; a < 6; ++a) g[a] -= u[a];
+    }
   }
 #pragma unroll
-  for (int i = 0; i < 36; ++i) G.pose_H[36 * (size_t)p + i] = H[i];
+  for (int i = 0; i < 21; ++i) part[wave][i][lane] = H[i];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) G.pose_g[6 * (size_t)p + i] = g[i];
+  for (int i = 0; i < 6; ++i) part[wave][21 + i][lane] = g[i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < 42) {
+    // entry e: H[a][c] (e = 6a + c) or g[e - 36]
+    int src;
+    if (lane < 36) {
+      const int a = lane / 6, c = lane % 6;
+      src = a >= c ? a * (a + 1) / 2 + c : c * (c + 1) / 2 + a;
+    } else {
+      src = 21 + lane - 36;
+    }
+    double sum = 0.0;
+#pragma unroll 8
+    for (int q = 0; q < 64; ++q) sum += part[wave][src][q];
+    if (lane < 36) G.pose_H[36 * (size_t)p + lane] = sum;
+    else G.pose_g[6 * (size_t)p + lane - 36] = sum;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -601,54 +633,62 @@ __global__ void k_pad_rhs(GraphDev G) {
 // landmark back-substitution  delta_l = -H_ll^-1 (g_l + sum_f E_f^T delta_p), and delta_p = dp.
 // MODE 0: everything.  MODE 1: only t_l = sum_f E_f^T delta_p -> lm_t (for the cross-robot all-reduce).
 // MODE 2: delta_l from the (all-reduced) t_l.
+// One wave per landmark (lanes over its factors, butterfly sum of the <= 9 numbers), four landmarks per workgroup; the
+// pose part is a plain copy by the first blocks' threads.
 template <int MODE>
-__global__ void k_backsub(GraphDev G) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < G.P) {
-    if (MODE != 2)
-      for (int k = 0; k < 6; ++k) G.pose_delta[6 * (size_t)t + k] = G.dp[6 * (size_t)t + k];
-    return;
+__global__ __launch_bounds__(256) void k_backsub(GraphDev G) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (MODE != 2) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < 6 * G.P) G.pose_delta[t] = G.dp[t];
   }
-  const int l = t - G.P;
-  if (l >= G.L) return;
-  const int D = lm_dim(G.lm_type[l]);
-  double rhs[9];
+  for (int l = blockIdx.x * 4 + wave; l < G.L; l += gridDim.x * 4) {
+    const int D = lm_dim(G.lm_type[l]);
+    double rhs[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) rhs[k] = 0.0;
-  if (MODE == 2) {
+    for (int k = 0; k < 9; ++k) rhs[k] = 0.0;
+    if (MODE == 2) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) if (k < D) rhs[k] = G.lm_t[9 * (size_t)l + k];
-  } else {
-    for (int q = G.lm_ptr[l]; q < G.lm_ptr[l + 1]; ++q) {
-      const int f = G.lm_fids[q];
-      const double* E = G.ebuf + G.lf_eoff[f];
-      const double* d = G.dp + 6 * (size_t)G.lf_pose[f];
+      for (int k = 0; k < 9; ++k) if (k < D) rhs[k] = G.lm_t[9 * (size_t)l + k];
+    } else {
+      for (int q = G.lm_ptr[l] + lane; q < G.lm_ptr[l + 1]; q += 64) {
+        const int f = G.lm_fids[q];
+        const double* E = G.ebuf + G.lf_eoff[f];
+        const double* d = G.dp + 6 * (size_t)G.lf_pose[f];
+        double dd[6];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        if (k < D) {
-          double s = 0.0;
+        for (int a = 0; a < 6; ++a) dd[a] = d[a];
 #pragma unroll
-          for (int a = 0; a < 6; ++a) s += E[a * D + k] * d[a];
-          rhs[k] += s;
+        for (int k = 0; k < 9; ++k) {
+          if (k < D) {
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) s += E[a * D + k] * dd[a];
+            rhs[k] += s;
+          }
         }
       }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) rhs[k] += __shfl_xor(rhs[k], m);
+      }
     }
-  }
-  if (MODE == 1) {
+    if (MODE == 1) {
+      if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) G.lm_t[9 * (size_t)l + k] = rhs[k];
-    return;
-  }
+        for (int k = 0; k < 9; ++k) G.lm_t[9 * (size_t)l + k] = rhs[k];
+      }
+      continue;
+    }
 #pragma unroll
-  for (int k = 0; k < 9; ++k) if (k < D) rhs[k] += G.lm_g[9 * (size_t)l + k];
-  const double* Hi = G.lm_Hinv + 81 * (size_t)l;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    if (k < D) {
+    for (int k = 0; k < 9; ++k) if (k < D) rhs[k] += G.lm_g[9 * (size_t)l + k];
+    if (lane < D) {
+      const double* Hi = G.lm_Hinv + 81 * (size_t)l + lane * D;
       double s = 0.0;
 #pragma unroll
-      for (int c = 0; c < 9; ++c) if (c < D) s += Hi[k * D + c] * rhs[c];
-      G.lm_delta[9 * (size_t)l + k] = -s;
+      for (int c = 0; c < 9; ++c) if (c < D) s += Hi[c] * rhs[c];
+      G.lm_delta[9 * (size_t)l + lane] = -s;
     }
   }
 }
@@ -711,7 +751,7 @@ void launch_landmark(const GraphDev& G, int mode, hipStream_t s) {
   else hipLaunchKernelGGL(k_landmark<2>, dim3(blocks_for(G.L, 4)), dim3(256), 0, s, G);
 }
 void launch_pose(const GraphDev& G, hipStream_t s) {
-  if (G.P > 0) hipLaunchKernelGGL(k_pose, dim3(blocks_for(G.P, 64)), dim3(64), 0, s, G);
+  if (G.P > 0) hipLaunchKernelGGL(k_pose, dim3(blocks_for(G.P, 4)), dim3(256), 0, s, G);
 }
 void launch_schur(const GraphDev& G, hipStream_t s) {
   if (G.P == 0) return;
@@ -722,9 +762,10 @@ void launch_schur(const GraphDev& G, hipStream_t s) {
 }
 void launch_backsub(const GraphDev& G, int mode, hipStream_t s) {
   if (G.P + G.L == 0) return;
-  if (mode == 0) hipLaunchKernelGGL(k_backsub<0>, dim3(blocks_for(G.P + G.L, 128)), dim3(128), 0, s, G);
-  else if (mode == 1) hipLaunchKernelGGL(k_backsub<1>, dim3(blocks_for(G.P + G.L, 128)), dim3(128), 0, s, G);
-  else hipLaunchKernelGGL(k_backsub<2>, dim3(blocks_for(G.P + G.L, 128)), dim3(128), 0, s, G);
+  const int nb = std::max(blocks_for(G.L, 4), blocks_for(6 * G.P, 256));
+  if (mode == 0) hipLaunchKernelGGL(k_backsub<0>, dim3(nb), dim3(256), 0, s, G);
+  else if (mode == 1) hipLaunchKernelGGL(k_backsub<1>, dim3(nb), dim3(256), 0, s, G);
+  else hipLaunchKernelGGL(k_backsub<2>, dim3(nb), dim3(256), 0, s, G);
 }
 void launch_shared_pack(const GraphDev& G, int what, double* buf, hipStream_t s) {
   if (G.n_slots > 0) hipLaunchKernelGGL(k_shared_pack, dim3(blocks_for(G.n_slots, 128)), dim3(128), 0, s, G, what, buf);
