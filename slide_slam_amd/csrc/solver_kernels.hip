@@ -140,15 +140,24 @@ __device__ inline void cyl_err(const SE3& X, const double* q, const double* z, d
   e[6] = z[6] - q[6];
 }
 
-__global__ __launch_bounds__(128) void k_lin_lf(GraphDev G) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+// THIRTY-TWO lanes per factor: the cube and cylinder factors differentiate numerically (central differences with
+// delta = 1e-6 through the variables' own retract, as the reference's numericalDerivative21/22 do), i.e. 2 x 15 or 2 x 13
+// evaluations of the error function per factor — one per lane (lane = 2 column + sign; lanes 30/31 evaluate the
+// unperturbed error), paired by a lane swap.  Every lane runs the same code on its own perturbation (a zero tangent
+// retracts to the value itself, exactly), so a thread no longer walks through thirty evaluations one after the other.
+__global__ __launch_bounds__(256) void k_lin_lf(GraphDev G) {
+  const int f = (blockIdx.x * 256 + threadIdx.x) >> 5, j = threadIdx.x & 31;
   if (f >= G.n_lf) return;
   const int type = G.lf_type[f];
   const int p = G.lf_pose[f], l = G.lf_lm[f], slot = G.lf_slot[f];
   double* out = G.jbuf + G.lf_joff[f];
   const SE3 X = from12(G.pose_val + 12 * (size_t)p);
   const double* lv = G.lm_val + 15 * (size_t)l;
+  const int col = j >> 1;                                // 0..14 perturbed tangent component, 15: none
+  const double dl = G.numdiff_delta, fac = 1.0 / (2.0 * dl);
+  const double d = (j & 1) ? -dl : dl;
   if (type == FT_BR) {
+    if (j != 0) return;
     // [GTSAM BearingRangeFactor<Pose3,Point3>] r = [sphere-local(z_b, b) ; rho - z_rho] / sigma
     const double* z = G.br_z + 4 * (size_t)slot;
     const double w = 1.0 / G.bearing_sigma;
@@ -188,72 +197,49 @@ __global__ __launch_bounds__(128) void k_lin_lf(GraphDev G) {
         Jl[3 * r + j] = u * w;
       }
   } else if (type == FT_CUBE) {
-    // numericalDerivative21/22 with delta = 1e-6 through the variables' own retract (cubeFactor.cpp:41-50)
+    // cubeFactor.cpp:41-50; tangent: pose (6), cube pose (6), cube scale (3)
     const double* z = G.cu_z + 15 * (size_t)slot;
     const double* sg = G.cu_sigma + 9 * (size_t)slot;
     const SE3 C = from12(lv);
-    const double cs[3] = {lv[12], lv[13], lv[14]};
-    double hx[9], e1[9], e2[9], w[9];
-    cube_err(X, C, cs, z, hx);
+    double dX[6], dC[6], cs[3];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { w[i] = 1.0 / sg[i]; out[i] = hx[i] * w[i]; }
-    double* Jp = out + 9;
-    double* Jl = out + 63;
-    const double dl = G.numdiff_delta, fac = 1.0 / (2.0 * dl);
-    for (int j = 0; j < 6; ++j) {
-      double dp[6], dm[6];
+    for (int k = 0; k < 6; ++k) { dX[k] = (col == k) ? d : 0.0; dC[k] = (col == 6 + k) ? d : 0.0; }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { dp[k] = (k == j) ? dl : 0.0; dm[k] = (k == j) ? -dl : 0.0; }
-      cube_err(retract(X, dp, G.chart), C, cs, z, e1);
-      cube_err(retract(X, dm, G.chart), C, cs, z, e2);
+    for (int k = 0; k < 3; ++k) cs[k] = lv[12 + k] + ((col == 12 + k) ? d : 0.0);
+    double e[9];
+    cube_err(retract(X, dX, G.chart), retract(C, dC, G.chart), cs, z, e);
 #pragma unroll
-      for (int i = 0; i < 9; ++i) Jp[6 * i + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * fac * w[i];
-      cube_err(X, retract(C, dp, G.chart), cs, z, e1);
-      cube_err(X, retract(C, dm, G.chart), cs, z, e2);
-#pragma unroll
-      for (int i = 0; i < 9; ++i) Jl[9 * i + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * fac * w[i];
-    }
-    for (int j = 0; j < 3; ++j) {
-      double sp[3], sm[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { sp[k] = cs[k] + ((k == j) ? dl : 0.0); sm[k] = cs[k] + ((k == j) ? -dl : 0.0); }
-      cube_err(X, C, sp, z, e1);
-      cube_err(X, C, sm, z, e2);
-#pragma unroll
-      for (int i = 0; i < 9; ++i) Jl[9 * i + 6 + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * fac * w[i];
+    for (int i = 0; i < 9; ++i) {
+      const double hx = __shfl(e[i], 30, 32), eo = __shfl_xor(e[i], 1, 32), w = 1.0 / sg[i];
+      if (j == 30) out[i] = hx * w;
+      if ((j & 1) == 0 && col < 15) {
+        const double v = ((e[i] - hx) - (eo - hx)) * fac * w;
+        if (col < 6) out[9 + 6 * i + col] = v;           // Jp
+        else out[63 + 9 * i + col - 6] = v;               // Jl
+      }
     }
   } else {  // FT_CYL
+    // cylinderFactor.cpp; tangent: pose (6), CylinderMeasurement [ray(3), root(3), radius] onto value [root, ray, radius]
     const double* z = G.cy_z + 7 * (size_t)slot;
     const double w = 1.0 / G.cyl_sigma;
-    double q[7];
+    const int jl = col - 6;
+    const int vi = jl < 0 ? -1 : (jl < 3 ? jl + 3 : (jl < 6 ? jl - 3 : (jl == 6 ? 6 : -1)));
+    double dX[6], q[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) q[i] = lv[i];
-    double hx[7], e1[7], e2[7];
-    cyl_err(X, q, z, hx);
+    for (int k = 0; k < 6; ++k) dX[k] = (col == k) ? d : 0.0;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) out[i] = hx[i] * w;
-    double* Jp = out + 7;
-    double* Jl = out + 49;
-    const double dl = G.numdiff_delta, fac = 1.0 / (2.0 * dl);
-    for (int j = 0; j < 6; ++j) {
-      double dp[6], dm[6];
+    for (int k = 0; k < 7; ++k) q[k] = lv[k] + ((vi == k) ? d : 0.0);
+    double e[7];
+    cyl_err(retract(X, dX, G.chart), q, z, e);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { dp[k] = (k == j) ? dl : 0.0; dm[k] = (k == j) ? -dl : 0.0; }
-      cyl_err(retract(X, dp, G.chart), q, z, e1);
-      cyl_err(retract(X, dm, G.chart), q, z, e2);
-#pragma unroll
-      for (int i = 0; i < 7; ++i) Jp[6 * i + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * fac * w;
-    }
-    for (int j = 0; j < 7; ++j) {
-      // CylinderMeasurement::retract: tangent [ray(3), root(3), radius] onto value [root, ray, radius]
-      const int vi = j < 3 ? j + 3 : (j < 6 ? j - 3 : 6);
-      double qp[7], qm[7];
-#pragma unroll
-      for (int k = 0; k < 7; ++k) { qp[k] = q[k] + ((k == vi) ? dl : 0.0); qm[k] = q[k] + ((k == vi) ? -dl : 0.0); }
-      cyl_err(X, qp, z, e1);
-      cyl_err(X, qm, z, e2);
-#pragma unroll
-      for (int i = 0; i < 7; ++i) Jl[7 * i + j] = ((e1[i] - hx[i]) - (e2[i] - hx[i])) * fac * w;
+    for (int i = 0; i < 7; ++i) {
+      const double hx = __shfl(e[i], 30, 32), eo = __shfl_xor(e[i], 1, 32);
+      if (j == 30) out[i] = hx * w;
+      if ((j & 1) == 0 && col < 13) {
+        const double v = ((e[i] - hx) - (eo - hx)) * fac * w;
+        if (col < 6) out[7 + 6 * i + col] = v;           // Jp
+        else out[49 + 7 * i + jl] = v;                    // Jl
+      }
     }
   }
 }
@@ -525,16 +511,27 @@ __global__ __launch_bounds__(256) void k_pose(GraphDev G) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Schur assemble: one WORKGROUP per pose column j, one thread per lower block (i >= j):
+// Schur assemble: one WORKGROUP per (pose column j, chunk of 32 row poses i >= j), EIGHT lanes per lower block:
 //   S_ij = [i == j] H_pp,i + sum_between J_i^T J_j - sum_{l seen by i and j} F_fa(i) E_fb(j)^T
-// The column pose's landmark list is published as an LDS lookup (landmark id -> first list position), so a
-// thread finds co-observed landmarks with one LDS read per entry of ITS pose's list (no merge, no pair list
-// is ever materialised); consecutive threads write consecutive 48-byte runs of the same S column, and every
-// block is written exactly once (S needs no memset, no atomics -> bit-stable).
+// The column pose's landmark list is published as an LDS lookup (landmark id -> first list position); the eight lanes
+// of a block share out pose i's list (one LDS read per entry, no merge, no pair list is ever materialised), so the
+// dependent index -> record loads of the co-observed landmarks run eight abreast, and a three-step butterfly adds the
+// partial 6x6 blocks.  Lanes 0..5 of a group then write one column of the block each: consecutive groups write
+// consecutive 48-byte runs of the same S column, and every block is written exactly once (S needs no memset, no
+// atomics -> bit-stable).  The finished blocks of a workgroup leave through an LDS tile as 1536-byte runs per S column.
 extern __shared__ short schur_slot[];
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void k_schur(GraphDev G) {
-  const int pj = blockIdx.x;
+  __shared__ double schur_tile[6][192];
+  const int pj = blockIdx.y;
+  if (32 * (int)blockIdx.x > G.P - 1 - pj) return;
   const int tid = threadIdx.x;
   for (int t = tid; t < G.L; t += 256) schur_slot[t] = -1;
   __syncthreads();
@@ -544,39 +541,44 @@ __global__ __launch_bounds__(256) void k_schur(GraphDev G) {
     if (q == 0 || G.pose_lms[b0 + q - 1] != l) schur_slot[l] = (short)q;
   }
   __syncthreads();
-  for (int pi = pj + tid; pi < G.P; pi += 256) {
-    double acc[36];
-    if (pi == pj) {
+  const int sub = tid & 7;
+  const int pi = pj + 32 * (int)blockIdx.x + (tid >> 3);
+  const bool live = pi < G.P;
+  double acc[36];
 #pragma unroll
-      for (int k = 0; k < 36; ++k) acc[k] = G.pose_H[36 * (size_t)pi + k];
-    } else {
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+  if (live) {
+    if (sub == 0) {
+      if (pi == pj) {
 #pragma unroll
-      for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-      for (int q = G.pose_bt_ptr[pi]; q < G.pose_bt_ptr[pi + 1]; ++q) {
-        const int ent = G.pose_bt[q];
-        const int b = ent >> 1, role = ent & 1;
-        const int other = role ? G.bt_i[b] : G.bt_j[b];
-        if (other != pj) continue;
-        const double* J = G.bt_J0 + 36 * (size_t)b;
-        if (role == 1) {   // pose i is the second key: J_i = diag(w), J_j = J0
+        for (int k = 0; k < 36; ++k) acc[k] = G.pose_H[36 * (size_t)pi + k];
+      } else {
+        for (int q = G.pose_bt_ptr[pi]; q < G.pose_bt_ptr[pi + 1]; ++q) {
+          const int ent = G.pose_bt[q];
+          const int b = ent >> 1, role = ent & 1;
+          const int other = role ? G.bt_i[b] : G.bt_j[b];
+          if (other != pj) continue;
+          const double* J = G.bt_J0 + 36 * (size_t)b;
+          if (role == 1) {   // pose i is the second key: J_i = diag(w), J_j = J0
 #pragma unroll
-          for (int a = 0; a < 6; ++a) {
-            const double w = 1.0 / G.bt_sigma[6 * b + a];
+            for (int a = 0; a < 6; ++a) {
+              const double w = 1.0 / G.bt_sigma[6 * b + a];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) acc[6 * a + c] += w * J[6 * a + c];
-          }
-        } else {           // pose i is the first key: J_i = J0, J_j = diag(w)
+              for (int c = 0; c < 6; ++c) acc[6 * a + c] += w * J[6 * a + c];
+            }
+          } else {           // pose i is the first key: J_i = J0, J_j = diag(w)
 #pragma unroll
-          for (int c = 0; c < 6; ++c) {
-            const double w = 1.0 / G.bt_sigma[6 * b + c];
+            for (int c = 0; c < 6; ++c) {
+              const double w = 1.0 / G.bt_sigma[6 * b + c];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) acc[6 * a + c] += J[6 * c + a] * w;
+              for (int a = 0; a < 6; ++a) acc[6 * a + c] += J[6 * c + a] * w;
+            }
           }
         }
       }
     }
     const int a0 = G.pose_ptr[pi], a1 = G.pose_ptr[pi + 1];
-    for (int x = a0; x < a1; ++x) {
+    for (int x = a0 + sub; x < a1; x += 8) {
       const int l = G.pose_lms[x];
       const int sl = schur_slot[l];
       if (sl < 0) continue;
@@ -605,11 +607,28 @@ __global__ __launch_bounds__(256) void k_schur(GraphDev G) {
         }
       }
     }
-    double* Sc = G.S + (size_t)(6 * pj) * G.ld + 6 * (size_t)pi;
+  }
+  // sum over the eight lanes of the group on the vector ALU (DPP: quad butterflies, then the mirrored half row)
 #pragma unroll
-    for (int c = 0; c < 6; ++c)
+  for (int k = 0; k < 36; ++k) {
+    acc[k] += dpp_f64<0xB1>(acc[k]);     // quad_perm [1,0,3,2]
+    acc[k] += dpp_f64<0x4E>(acc[k]);     // quad_perm [2,3,0,1]
+    acc[k] += dpp_f64<0x141>(acc[k]);    // row_half_mirror: lane i <-> 7 - i of each eight
+  }
+  // through an LDS tile to full-line stores: 192 consecutive doubles per S column and workgroup
 #pragma unroll
-      for (int a = 0; a < 6; ++a) Sc[(size_t)c * G.ld + a] = acc[6 * a + c];
+  for (int c = 0; c < 6; ++c)
+    if (sub == c) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) schur_tile[c][6 * (tid >> 3) + a] = acc[6 * a + c];
+    }
+  __syncthreads();
+  const int pi0 = pj + 32 * (int)blockIdx.x;
+  const int nval = 6 * min(32, G.P - pi0);
+  double* Sb = G.S + (size_t)(6 * pj) * G.ld + 6 * (size_t)pi0;
+  for (int e = tid; e < 6 * 192; e += 256) {
+    const int c = e / 192, r = e % 192;
+    if (r < nval) Sb[(size_t)c * G.ld + r] = schur_tile[c][r];
   }
 }
 
@@ -742,7 +761,7 @@ void launch_relin(const GraphDev& G, hipStream_t s) {
 void launch_linearize(const GraphDev& G, hipStream_t s) {
   if (G.n_prior + G.n_between > 0)
     hipLaunchKernelGGL(k_lin_pose_factors, dim3(blocks_for(G.n_prior + G.n_between, 128)), dim3(128), 0, s, G);
-  if (G.n_lf > 0) hipLaunchKernelGGL(k_lin_lf, dim3(blocks_for(G.n_lf, 128)), dim3(128), 0, s, G);
+  if (G.n_lf > 0) hipLaunchKernelGGL(k_lin_lf, dim3(blocks_for(32LL * G.n_lf, 256)), dim3(256), 0, s, G);
 }
 void launch_landmark(const GraphDev& G, int mode, hipStream_t s) {
   if (G.L == 0) return;
@@ -755,7 +774,7 @@ void launch_pose(const GraphDev& G, hipStream_t s) {
 }
 void launch_schur(const GraphDev& G, hipStream_t s) {
   if (G.P == 0) return;
-  hipLaunchKernelGGL(k_schur, dim3(G.P), dim3(256), (size_t)((G.L + 7) / 8 * 8) * sizeof(short), s, G);
+  hipLaunchKernelGGL(k_schur, dim3(blocks_for(G.P, 32), G.P), dim3(256), (size_t)((G.L + 7) / 8 * 8) * sizeof(short), s, G);
   const long long NT = (long long)G.T * NB;
   const long long tot = NT + (NT - 6LL * G.P) * NT;
   hipLaunchKernelGGL(k_pad_rhs, dim3(blocks_for(tot, 256)), dim3(256), 0, s, G);
