@@ -51,6 +51,7 @@ struct GraphDev {
   int* lm_ptr; int* lm_fids;        // landmark -> factor ids (insertion order)
   int* pose_ptr; int* pose_fids;    // pose -> factor ids sorted by (landmark id, factor id)
   int* pose_lms;                    // landmark id of every pose_fids entry (same indexing)
+  long long* pose_ed;               // (lf_eoff << 4) | landmark dimension of every pose_fids entry (same indexing)
   int* pose_bt_ptr; int* pose_bt;   // pose -> (between index << 1 | role), role 1 = second key
   // ---- landmark blocks -------------------------------------------------------------------
   double* lm_Hinv;   // 81 L  (d x d used)

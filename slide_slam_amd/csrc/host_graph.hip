@@ -352,6 +352,14 @@ int HostGraph::upload_new() {
   for (size_t i = 0; i < val.size(); ++i) lms[i] = h_lf_lm[val[i]];
   if (d_pose_lms.ensure(std::max<size_t>(lms.size(), 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_pose_lms.upload(lms.data(), 0, lms.size(), s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  std::vector<long long> ped(val.size());
+  for (size_t i = 0; i < val.size(); ++i) {
+    const int ty = h_lm_type[h_lf_lm[val[i]]];
+    const int dim = ty == VT_POINT ? 3 : (ty == VT_CUBE ? 9 : 7);
+    ped[i] = ((long long)h_lf_eoff[val[i]] << 4) | dim;
+  }
+  if (d_pose_ed.ensure(std::max<size_t>(ped.size(), 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_pose_ed.upload(ped.data(), 0, ped.size(), s) != SLIDE_OK) return SLIDE_ERR_HIP;
   SL_HIP(hipStreamSynchronize(s));
   if (Ln > 60000) { g_last_error = "Schur LDS lookup capacity exceeded (more than 60000 landmarks in one graph)"; return SLIDE_ERR_CAPACITY; }
   if (up_csr(d_pose_bt_ptr, d_pose_bt, pose_bt, ptr, val, s) != SLIDE_OK) return SLIDE_ERR_HIP;
@@ -387,7 +395,7 @@ int HostGraph::upload_new() {
   G.lf_joff = d_lf_joff.d; G.lf_eoff = d_lf_eoff.d;
   G.br_z = d_br_z.d; G.cu_z = d_cu_z.d; G.cu_sigma = d_cu_sigma.d; G.cy_z = d_cy_z.d;
   G.jbuf = d_jbuf.d; G.ebuf = d_ebuf.d;
-  G.lm_ptr = d_lm_ptr.d; G.lm_fids = d_lm_fids.d; G.pose_ptr = d_pose_ptr.d; G.pose_fids = d_pose_fids.d; G.pose_lms = d_pose_lms.d;
+  G.lm_ptr = d_lm_ptr.d; G.lm_fids = d_lm_fids.d; G.pose_ptr = d_pose_ptr.d; G.pose_fids = d_pose_fids.d; G.pose_lms = d_pose_lms.d; G.pose_ed = d_pose_ed.d;
   G.pose_bt_ptr = d_pose_bt_ptr.d; G.pose_bt = d_pose_bt.d;
   G.lm_Hacc = d_lm_Hacc.d; G.lm_t = d_lm_t.d; G.n_slots = (int)h_sh_lid.size(); G.sh_lid = d_sh_lid.d; G.sh_owner = d_sh_owner.d;
   G.lm_Hinv = d_lm_Hinv.d; G.lm_g = d_lm_g.d; G.pose_H = d_pose_H.d; G.pose_g = d_pose_g.d;

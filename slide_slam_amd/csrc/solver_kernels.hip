@@ -528,8 +528,12 @@ __device__ __forceinline__ double dpp_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
+constexpr int SCHUR_PJ_CAP = 256;   // entries of the column pose's factor list kept in LDS (longer lists fall back to global reads)
+
 __global__ __launch_bounds__(256) void k_schur(GraphDev G) {
   __shared__ double schur_tile[6][192];
+  __shared__ long long pj_ed[SCHUR_PJ_CAP];
+  __shared__ int pj_lm[SCHUR_PJ_CAP];
   const int pj = blockIdx.y;
   if (32 * (int)blockIdx.x > G.P - 1 - pj) return;
   const int tid = threadIdx.x;
@@ -539,6 +543,7 @@ __global__ __launch_bounds__(256) void k_schur(GraphDev G) {
   for (int q = tid; q < nb; q += 256) {
     const int l = G.pose_lms[b0 + q];
     if (q == 0 || G.pose_lms[b0 + q - 1] != l) schur_slot[l] = (short)q;
+    if (q < SCHUR_PJ_CAP) { pj_lm[q] = l; pj_ed[q] = G.pose_ed[b0 + q]; }
   }
   __syncthreads();
   const int sub = tid & 7;
@@ -577,32 +582,53 @@ __global__ __launch_bounds__(256) void k_schur(GraphDev G) {
         }
       }
     }
+    // own share of pose i's list, three entries at a time: first all index loads and LDS look-ups, then the records
     const int a0 = G.pose_ptr[pi], a1 = G.pose_ptr[pi + 1];
-    for (int x = a0 + sub; x < a1; x += 8) {
-      const int l = G.pose_lms[x];
-      const int sl = schur_slot[l];
-      if (sl < 0) continue;
-      const int D = lm_dim(G.lm_type[l]);
-      const double* F = G.ebuf + G.lf_eoff[G.pose_fids[x]] + 6 * D;
-      for (int y = b0 + sl; y < b0 + nb && G.pose_lms[y] == l; ++y) {
-        const double* E = G.ebuf + G.lf_eoff[G.pose_fids[y]];
-        if (D == 3) {
-          double f[18], e[18];
+    for (int x0 = a0 + sub; x0 < a1; x0 += 24) {
+      int sl[3];
+      long long ed[3];
 #pragma unroll
-          for (int k = 0; k < 18; ++k) { f[k] = F[k]; e[k] = E[k]; }
+      for (int u = 0; u < 3; ++u) {
+        const int x = x0 + 8 * u;
+        sl[u] = -1;
+        ed[u] = 0;
+        if (x < a1) {
+          const int l = G.pose_lms[x];
+          ed[u] = G.pose_ed[x];
+          sl[u] = schur_slot[l];
+        }
+      }
 #pragma unroll
-          for (int a = 0; a < 6; ++a)
+      for (int u = 0; u < 3; ++u) {
+        if (sl[u] < 0) continue;
+        const int D = (int)(ed[u] & 15);
+        const double* F = G.ebuf + (ed[u] >> 4) + 6 * D;
+        const int l = (sl[u] < SCHUR_PJ_CAP) ? pj_lm[sl[u]] : G.pose_lms[b0 + sl[u]];
+        for (int y = sl[u]; y < nb; ++y) {
+          const int ly = (y < SCHUR_PJ_CAP) ? pj_lm[y] : G.pose_lms[b0 + y];
+          if (ly != l) break;
+          const long long edy = (y < SCHUR_PJ_CAP) ? pj_ed[y] : G.pose_ed[b0 + y];
+          const double* E = G.ebuf + (edy >> 4);
+          if (D == 3) {
+            double e[18];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) acc[6 * a + c] -= f[3 * a] * e[3 * c] + f[3 * a + 1] * e[3 * c + 1] + f[3 * a + 2] * e[3 * c + 2];
-        } else {
-          for (int k = 0; k < D; ++k) {
-            double fk[6], ek[6];
+            for (int k = 0; k < 18; ++k) e[k] = E[k];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) { fk[a] = F[a * D + k]; ek[a] = E[a * D + k]; }
+            for (int a = 0; a < 6; ++a) {
+              const double f0 = F[3 * a], f1 = F[3 * a + 1], f2 = F[3 * a + 2];
 #pragma unroll
-            for (int a = 0; a < 6; ++a)
+              for (int c = 0; c < 6; ++c) acc[6 * a + c] -= f0 * e[3 * c] + f1 * e[3 * c + 1] + f2 * e[3 * c + 2];
+            }
+          } else {
+            for (int k = 0; k < D; ++k) {
+              double fk[6], ek[6];
 #pragma unroll
-              for (int c = 0; c < 6; ++c) acc[6 * a + c] -= fk[a] * ek[c];
+              for (int a = 0; a < 6; ++a) { fk[a] = F[a * D + k]; ek[a] = E[a * D + k]; }
+#pragma unroll
+              for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) acc[6 * a + c] -= fk[a] * ek[c];
+            }
           }
         }
       }
@@ -752,7 +778,7 @@ __global__ void k_estimate(GraphDev G) {
 static inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 void init_solver_kernels() {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);   // 60000 landmarks (the capacity check in HostGraph::upload_new) beside 12 KB of static LDS
 }
 void launch_relin(const GraphDev& G, hipStream_t s) {
   if (G.P + G.L == 0) return;
