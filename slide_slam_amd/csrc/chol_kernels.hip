@@ -58,63 +58,62 @@ __device__ unsigned long long g_stamps[40];
 // needs only the kernel boundary.  MFMA accumulator layout of X_c^T (row (lane>>4) + 4r, column lane&15) is
 // exactly the B-operand layout of k-step r, so chained products need no lane movement.
 // ---------------- type B: trailing update with panel k-1, one 2x2 group of 64x64 tiles per workgroup ----------------
-// Eight waves: wave pair (wm, wn) owns tile (i, j) = (i0 + wm, j0 + wn), each wave one 32-column half of it: eight 16x16
-// accumulators initialised with C itself, sixteen k-steps of six operand loads feeding eight MFMAs (the loads run two
-// k-steps ahead of their use), so the wave is paced by the matrix pipe at the two waves per SIMD the register-heavy
-// type A leaves to the launch.  No LDS, no barrier: waves whose tile lies outside the lower triangle leave at once.
+// A work item is one tile row of a 2x2 group: two tiles (i, j0), (i, j0 + 1); four waves per tile, each a 32x32 quadrant:
+// four 16x16 accumulators initialised with C itself, sixteen k-steps of four operand loads feeding four MFMAs (the loads
+// run five k-steps ahead of their use).  No LDS, no barrier: waves whose tile lies outside the lower triangle leave at once.
 __device__ __forceinline__ long long tri_row(long long t) {
   long long ii = (long long)floor((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while (ii * (ii + 1) / 2 > t) --ii;
   while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
   return ii;
 }
-__device__ __forceinline__ void step_type_b(double* __restrict__ S, int ld, int k, int T, long long t) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // eight waves: tile (wave >> 1), column half (wave & 1)
+__device__ __forceinline__ void step_type_b(double* __restrict__ S, int ld, int k, int T, long long tt) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // eight waves: tile (wave >> 2), 32x32 quadrant (wave & 3)
   const int lr = lane & 15, lk = lane >> 4;
+  const long long t = tt >> 1;
   const long long bi = tri_row(t);
   const int bj = (int)(t - bi * (bi + 1) / 2);
-  const int i = k + 1 + 2 * (int)bi + (wave >> 2), j = k + 1 + 2 * bj + ((wave >> 1) & 1), h = wave & 1;
+  const int i = k + 1 + 2 * (int)bi + (int)(tt & 1), j = k + 1 + 2 * bj + (wave >> 2);
   if (i > T || j > T - 1 || i < j) return;
-  const double* pjh = S + (size_t)((k - 1) * NB) * ld + (size_t)j * NB + 32 * h + lr;   // + 16a : rows 32h + 16a + lr of panel tile (j, k-1)
-  const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)i * NB + lr;             // + 16b : rows 16b + lr of panel tile (i, k-1)
-  double* cbh = S + (size_t)(j * NB + 32 * h + lk) * ld + (size_t)i * NB + lr;          // + (16a + 4r) ld + 16b
-  v4d acc[2][4];
+  const int ch = (wave >> 1) & 1, rh = wave & 1;                      // column half, row half of the tile
+  const double* pjh = S + (size_t)((k - 1) * NB) * ld + (size_t)j * NB + 32 * ch + lr;   // + 16a : rows 32 ch + 16a + lr of panel tile (j, k-1)
+  const double* pih = S + (size_t)((k - 1) * NB) * ld + (size_t)i * NB + 32 * rh + lr;   // + 16b : rows 32 rh + 16b + lr of panel tile (i, k-1)
+  double* cbh = S + (size_t)(j * NB + 32 * ch + lk) * ld + (size_t)i * NB + 32 * rh + lr;   // + (16a + 4r) ld + 16b
+  v4d acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[a][b][r] = cbh[(size_t)(16 * a + 4 * r) * ld + 16 * b];
-  constexpr int RD = 6;                      // operand ring: loads run RD - 1 k-steps (about 2500 cycles of MFMAs) ahead
-  double pa[RD][2], pb[RD][4];
+  constexpr int RD = 6;                      // operand ring: loads run RD - 1 k-steps ahead
+  double pa[RD][2], pb[RD][2];
 #pragma unroll
   for (int pre = 0; pre < RD - 1; ++pre) {
     const size_t off = (size_t)(4 * pre + lk) * ld;
     pa[pre][0] = pjh[off]; pa[pre][1] = pjh[off + 16];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) pb[pre][b] = pi[off + 16 * b];
+    pb[pre][0] = pih[off]; pb[pre][1] = pih[off + 16];
   }
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     if (ks + RD - 1 < 16) {
       const size_t off = (size_t)(4 * (ks + RD - 1) + lk) * ld;
       pa[(ks + RD - 1) % RD][0] = pjh[off]; pa[(ks + RD - 1) % RD][1] = pjh[off + 16];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) pb[(ks + RD - 1) % RD][b] = pi[off + 16 * b];
+      pb[(ks + RD - 1) % RD][0] = pih[off]; pb[(ks + RD - 1) % RD][1] = pih[off + 16];
     }
     __builtin_amdgcn_sched_barrier(0);      // keep the prefetch distance: no further hoisting of loads
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const double na = -pa[ks % RD][a];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = mfma_f64(na, pb[ks % RD][b], acc[a][b]);
+      for (int b = 0; b < 2; ++b) acc[a][b] = mfma_f64(na, pb[ks % RD][b], acc[a][b]);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) cbh[(size_t)(16 * a + 4 * r) * ld + 16 * b] = acc[a][b][r];
 }
@@ -679,7 +678,7 @@ __global__ __launch_bounds__(256) void k_chol_bwd(const double* __restrict__ S, 
 void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, hipStream_t s) {
   const long long nA = T - k;                                   // column-k tiles below the diagonal (+ RHS tile)
   const long long nP = (nA + 1) / 2;                            // 2x2 tile groups per side of the trailing matrix
-  const long long nB = k > 0 ? nP * (nP + 1) / 2 : 0;           // groups that still owe the update of panel k-1
+  const long long nB = k > 0 ? nP * (nP + 1) : 0;               // half groups (one tile row of a 2x2 group each) that still owe the update of panel k-1
   static const int split = getenv("SLIDE_CHOL_SPLIT") ? atoi(getenv("SLIDE_CHOL_SPLIT")) : 0;
   if (split == 1) {
     hipLaunchKernelGGL(k_chol_a, dim3((unsigned)nA), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status);
