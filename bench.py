@@ -169,6 +169,17 @@ def main():
         upd_launches_per_iter = upd["launches"] / nprof
         flops_per_launch = upd_flops / max(upd_launches_per_iter, 1)
         ach = flops_per_launch / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+        # HBM bytes per launch of the same kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+        # passes, gfx950 FETCH_SIZE x2 correction): collected offline with tools/chol_big.py on the same reduced-system size
+        # and committed under profiles/ (a PMC pass cannot run inside the timed bench)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            if pmc.get("kernel") == "k_chol_step" and n == 3776:
+                traffic = pmc["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         kernel_ms = {k: v["ms"] / nprof for k, v in prof.items()}
         dominant = max(kernel_ms, key=kernel_ms.get)
         res = {
@@ -190,7 +201,8 @@ def main():
                                                                f"({dg_info['n_slots'] * 63 * 8} B per pass)"},
             "roofline": {"bound": "mfma", "kernel": "k_chol_step (v_mfma_f64_16x16x4_f64)", "achieved": ach,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "flops_per_launch": flops_per_launch, "avg_launch_ms": upd_ms,
+                         "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
+                         "flops_per_launch": flops_per_launch, "avg_launch_ms": upd_ms,
                          "launches_per_iter": upd_launches_per_iter, "dominant_by_time": dominant},
             "kernel_ms_per_iter": kernel_ms,
             "stream_replay": {"frames": len(rep["t_frame"]), "updates_per_s": len(rep["t_frame"]) / max(sum(rep["t_frame"]), 1e-9),
