@@ -244,6 +244,41 @@ int slide_find_inter_loop_closure(const double* ref7, int nr, const double* qry7
 int slide_clipper_affinity(const double* D1, int n1, const double* D2, int n2, int dim, const int32_t* A, int m,
                            double sigma, double epsilon, double mindist, double affinityeps, double* M_out);
 
+/* CLIPPER solver parameters: clipper.h:27-60 (solver) and invariants/euclidean_distance.h:24-29 (sigma, epsilon, mindist). */
+typedef struct {
+  double tol_u, tol_F;       /* 1e-8, 1e-9 */
+  int maxiniters, maxoliters; /* 200, 1000 */
+  double beta;               /* 0.25 */
+  int maxlsiters;            /* 99 */
+  double eps;                /* 1e-9 */
+  double affinityeps;        /* 1e-4 */
+  int rescale_u0;            /* 1 */
+  double sigma, epsilon, mindist; /* 0.01, 0.06, 0 */
+} slide_clipper_params_t;
+void slide_clipper_default_params(slide_clipper_params_t* p);
+/* CLIPPER::findDenseClique clipper.cpp:172-323 with DSD_HEU rounding (the only mode sloam uses).  M_upper: n x n row-major,
+ * upper triangle filled (slide_clipper_affinity's output).  u0: n start weights; NULL draws them from a fixed-seed
+ * generator (the reference uses a std::random_device-seeded mt19937, utils.cpp:22-29, i.e. is not reproducible).
+ * nodes_out: caller buffer of n entries (selected associations, largest weight first); u_out (n) / score may be NULL.
+ * The two symmetric products of every gradient evaluation run on the GPU; the O(n) control flow stays on the host. */
+int slide_clipper_dense_clique(const double* M_upper, int n, const double* u0, const slide_clipper_params_t* p,
+                               int32_t* nodes_out, int* n_nodes, double* u_out, double* score);
+/* semantic_clipper::match_triangles / compute_triangle_diff semantic_clipper.cpp:49-118.  Triangles: 3 x (x, y) doubles each
+ * (the Delaunay triangulation, observation.cpp:13-88, is the caller's).  pts_out: per matched pair three rows
+ * [model x, model y, data x, data y] in ascending vertex-to-centroid distance; pairs in the reference's loop order
+ * (model-major).  n_pairs returns the total; at most cap_pairs are written. */
+int slide_match_triangles(const double* tri_model, int ntm, const double* tri_data, int ntd, double threshold,
+                          double* pts_out, double* diffs_out, int cap_pairs, int* n_pairs);
+/* semantic_clipper::estimate_tf :122-138 (2-D Kabsch a -> b; tf3 row-major 3x3). */
+int slide_estimate_tf2d(const double* a_xy, const double* b_xy, int n, double tf3[9]);
+/* semantic_clipper::run_semantic_clipper :140-274 from the triangle lists on: triangle matching, identity association
+ * list, affinity, dense clique, min_num_pairs gate, estimate_tf, yaw + xy in a 4x4 row-major tf16 (query -> reference;
+ * the caller inverts as place_recognition.cpp:621-624 does).  u0: start weights for the 3 * n_pairs putative
+ * associations or NULL (fixed-seed generator).  counts: {putative associations, inliers}.  *found = 1 / 0. */
+int slide_semantic_clipper(const double* tri_model, int ntm, const double* tri_data, int ntd, const slide_clipper_params_t* p,
+                           int min_num_pairs, double matching_threshold, const double* u0, int n_u0, double tf16[16],
+                           int counts[2], int32_t* inliers_out, int cap_inliers, int* found);
+
 /* sloam::FindRelativeMeasurementMatch / GetIndexClosestPoseMstPair (src/core/sloam.cpp:321-440).
  * Stamps are (sec, nsec) pairs.  Host-side logic (tiny, sequential): no kernel. */
 int slide_closest_stamp(const int64_t* sec, const int64_t* nsec, int n, int64_t qsec, int64_t qnsec, int* idx, double* diff);

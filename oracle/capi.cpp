@@ -5,6 +5,7 @@
 
 #include "backend.hpp"
 #include "clipper.hpp"
+#include "slidegraph.hpp"
 #include "place.hpp"
 #include "relmeas.hpp"
 
@@ -356,6 +357,29 @@ int orc_clipper_solve(const double* Mup, int n, const double* u0, const OrcClipp
   if (u_out) std::memcpy(u_out, s.u.data(), sizeof(double) * n);
   if (score_out) *score_out = s.score;
   return (int)s.nodes.size();
+}
+
+// ---- SlideGraph triangle matching (A14) -----------------------------------------------------------
+// pts_out: rows [mx, my, dx, dy], three per matched pair; returns the number of matched pairs (writes at most cap_pairs)
+int orc_match_triangles(const double* tm, int ntm, const double* td, int ntd, double thr, double* pts_out, double* diffs_out,
+                        int cap_pairs) {
+  std::vector<double> pts, diffs;
+  const size_t np = match_triangles(tm, ntm, td, ntd, thr, pts, diffs);
+  const size_t w = std::min<size_t>(np, (size_t)cap_pairs);
+  if (pts_out) std::memcpy(pts_out, pts.data(), sizeof(double) * 12 * w);
+  if (diffs_out) std::memcpy(diffs_out, diffs.data(), sizeof(double) * w);
+  return (int)np;
+}
+void orc_estimate_tf2d(const double* a, const double* b, int n, double* tf3) { estimate_tf2d(a, b, n, tf3); }
+// returns 1 when a transform was found; counts[0] = putative associations, counts[1] = inliers
+int orc_semantic_clipper(const double* tm, int ntm, const double* td, int ntd, const OrcClipperParams* p, int min_num_pairs,
+                         double matching_threshold, const double* u0, double* tf16, int* counts, int* inliers_out) {
+  SemanticClipperOut o = semantic_clipper(tm, ntm, td, ntd, cp_from(p), min_num_pairs, matching_threshold, u0);
+  std::memcpy(tf16, o.tf16, sizeof(o.tf16));
+  counts[0] = o.n_putative;
+  counts[1] = o.n_inliers;
+  if (inliers_out) for (size_t i = 0; i < o.inliers.size(); ++i) inliers_out[i] = o.inliers[i];
+  return o.ok ? 1 : 0;
 }
 
 // ---- relative-measurement matching (A16) -----------------------------------------------------

@@ -34,7 +34,8 @@ EXPORTS = [
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
     "slide_backend_end_frame", "slide_backend_graph", "slide_backend_counts", "slide_backend_map_model",
     "slide_place_default_params", "slide_match_maps", "slide_find_inter_loop_closure", "slide_clipper_affinity",
-    "slide_closest_stamp",
+    "slide_closest_stamp", "slide_clipper_default_params", "slide_clipper_dense_clique", "slide_match_triangles",
+    "slide_estimate_tf2d", "slide_semantic_clipper",
 ]
 
 
@@ -382,6 +383,76 @@ def clipper_affinity(D1, D2, A, sigma=0.01, epsilon=0.06, mindist=0.0, affinitye
                                         C.c_int(m), C.c_double(sigma), C.c_double(epsilon), C.c_double(mindist),
                                         C.c_double(affinityeps), _p(M)))
     return M
+
+
+class ClipperParams(C.Structure):
+    """slide_clipper_params_t (clipper.h:27-60, euclidean_distance.h:24-29)."""
+    _fields_ = [("tol_u", C.c_double), ("tol_F", C.c_double), ("maxiniters", C.c_int), ("maxoliters", C.c_int),
+                ("beta", C.c_double), ("maxlsiters", C.c_int), ("eps", C.c_double), ("affinityeps", C.c_double),
+                ("rescale_u0", C.c_int), ("sigma", C.c_double), ("epsilon", C.c_double), ("mindist", C.c_double)]
+
+
+def clipper_params(**kw):
+    p = ClipperParams()
+    lib().slide_clipper_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def clipper_dense_clique(M_upper, u0=None, params=None):
+    """CLIPPER::findDenseClique (clipper.cpp:172-323, DSD_HEU).  Returns (nodes, u, score)."""
+    M = _d(M_upper)
+    n = M.shape[0]
+    p = params or clipper_params()
+    nodes = np.zeros(max(n, 1), np.int32)
+    u = np.zeros(max(n, 1))
+    nn, sc = C.c_int(0), C.c_double(0)
+    u0a = _d(u0) if u0 is not None else None
+    _check(lib().slide_clipper_dense_clique(_p(M), C.c_int(n), _p(u0a) if u0a is not None else None, C.byref(p), _p(nodes),
+                                            C.byref(nn), _p(u), C.byref(sc)))
+    return nodes[:nn.value].copy(), u[:n].copy(), sc.value
+
+
+def match_triangles(tri_model, tri_data, threshold=0.1):
+    """semantic_clipper::match_triangles (semantic_clipper.cpp:49-118).  tri_*: (n, 3, 2).  Returns (pts (n_pairs, 3, 4) with
+    rows [model x, model y, data x, data y], diffs (n_pairs,))."""
+    tm, td = _d(tri_model).reshape(-1, 6), _d(tri_data).reshape(-1, 6)
+    n = C.c_int(0)
+    _check(lib().slide_match_triangles(_p(tm), C.c_int(len(tm)), _p(td), C.c_int(len(td)), C.c_double(threshold), None, None,
+                                       C.c_int(0), C.byref(n)))
+    pts = np.zeros((max(n.value, 1), 3, 4))
+    diffs = np.zeros(max(n.value, 1))
+    _check(lib().slide_match_triangles(_p(tm), C.c_int(len(tm)), _p(td), C.c_int(len(td)), C.c_double(threshold), _p(pts), _p(diffs),
+                                       C.c_int(n.value), C.byref(n)))
+    return pts[:n.value], diffs[:n.value]
+
+
+def estimate_tf2d(a_xy, b_xy):
+    a, b = _d(a_xy), _d(b_xy)
+    tf = np.zeros(9)
+    _check(lib().slide_estimate_tf2d(_p(a), _p(b), C.c_int(len(a)), _p(tf)))
+    return tf.reshape(3, 3)
+
+
+def semantic_clipper(tri_model, tri_data, params=None, min_num_pairs=4, matching_threshold=0.1, u0=None):
+    """semantic_clipper::run_semantic_clipper (semantic_clipper.cpp:140-274) from the triangle lists on.
+    Returns dict(found, tf (4x4 query -> reference), n_putative, n_inliers, inliers)."""
+    tm, td = _d(tri_model).reshape(-1, 6), _d(tri_data).reshape(-1, 6)
+    p = params or clipper_params()
+    tf = np.zeros(16)
+    counts = np.zeros(2, np.int32)
+    cap = 3 * len(tm) * max(len(td), 1)
+    cap = min(cap, 1 << 22)
+    inl = np.zeros(max(cap, 1), np.int32)
+    found = C.c_int(0)
+    u0a = _d(u0) if u0 is not None else None
+    _check(lib().slide_semantic_clipper(_p(tm), C.c_int(len(tm)), _p(td), C.c_int(len(td)), C.byref(p), C.c_int(min_num_pairs),
+                                        C.c_double(matching_threshold), _p(u0a) if u0a is not None else None,
+                                        C.c_int(len(u0a) if u0a is not None else 0), _p(tf), _p(counts), _p(inl), C.c_int(len(inl)),
+                                        C.byref(found)))
+    return dict(found=bool(found.value), tf=tf.reshape(4, 4), n_putative=int(counts[0]), n_inliers=int(counts[1]),
+                inliers=inl[:counts[1]].copy())
 
 
 def closest_stamp(sec, nsec, qsec, qnsec):

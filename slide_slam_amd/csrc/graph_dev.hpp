@@ -68,7 +68,7 @@ struct GraphDev {
   double* S;         // column-major, ld rows x (T*NB) columns, lower triangle + RHS row at T*NB
   int ld;            // (T + 1) * NB
   int T;             // ceil(6 P / NB)
-  double* Ld;        // T * NB*NB : factored diagonal blocks L_kk (column-major)
+  double* Ld;        // T * NB*NB : per diagonal block L_kk (column-major 64x64 slot) its 16x16 sub-tiles BELOW the sub-diagonal blocks (all chol_bwd reads)
   double* Winv;      // T * 4*256 : inverses of the four 16x16 diagonal sub-blocks of every L_kk
   double* yv;        // T*NB  forward-substituted RHS
   double* dp;        // T*NB  reduced solution (delta_p = -dp)

@@ -71,6 +71,10 @@ struct PlaceDev {
 };
 void launch_place_sweep(const PlaceDev& P, hipStream_t s);
 void launch_place_argmax(const int32_t* inliers, long long n, long long* best_idx, int32_t* best_val, hipStream_t s);
+void launch_tri_prepare(const double* tri, int n, double* sdist, double* sxy, hipStream_t s);
+void launch_tri_match(bool emit, const double* dm, const double* xm, int ntm, const double* dd, const double* xd, int ntd, double thr,
+                      int* counts, const long long* offs, double* pts, double* diffs, hipStream_t s);
+void launch_clq_matvec(const double* Mup, int n, const double* v, double* Mu, double* Cu, hipStream_t s);
 void launch_clipper_affinity(const double* D1, const double* D2, int dim, const int32_t* A, int m, double sigma, double eps,
                              double mindist, double affinityeps, double* M, hipStream_t s);
 

@@ -117,6 +117,101 @@ __global__ void k_clipper_affinity(const double* __restrict__ D1, const double* 
   M[(size_t)i * m + j] = out;
 }
 
+// ---- SlideGraph triangle matching (semantic_clipper.cpp:49-118) ------------------------------------------------------
+// Per triangle: centroid, the three vertex-centroid distances, stable ascending argsort (the reference's std::sort on
+// three indices is an insertion sort), vertices re-ordered accordingly.
+__global__ void k_tri_prepare(const double* __restrict__ tri, int n, double* __restrict__ sdist, double* __restrict__ sxy) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const double* v = tri + 6 * (size_t)t;
+  const double x0 = v[0], y0 = v[1], x1 = v[2], y1 = v[3], x2 = v[4], y2 = v[5];
+  const double cx = (x0 + x1 + x2) / 3.0, cy = (y0 + y1 + y2) / 3.0;
+  double d0 = sqrt((x0 - cx) * (x0 - cx) + (y0 - cy) * (y0 - cy));
+  double d1 = sqrt((x1 - cx) * (x1 - cx) + (y1 - cy) * (y1 - cy));
+  double d2 = sqrt((x2 - cx) * (x2 - cx) + (y2 - cy) * (y2 - cy));
+  double ax = x0, ay = y0, bx = x1, by = y1, gx = x2, gy = y2;
+  // insertion sort of (d0, d1, d2) with "<" (stable)
+  if (d1 < d0) { double t0 = d0; d0 = d1; d1 = t0; t0 = ax; ax = bx; bx = t0; t0 = ay; ay = by; by = t0; }
+  if (d2 < d1) {
+    double t0 = d1; d1 = d2; d2 = t0; t0 = bx; bx = gx; gx = t0; t0 = by; by = gy; gy = t0;
+    if (d1 < d0) { t0 = d0; d0 = d1; d1 = t0; t0 = ax; ax = bx; bx = t0; t0 = ay; ay = by; by = t0; }
+  }
+  sdist[3 * (size_t)t] = d0; sdist[3 * (size_t)t + 1] = d1; sdist[3 * (size_t)t + 2] = d2;
+  double* o = sxy + 6 * (size_t)t;
+  o[0] = ax; o[1] = ay; o[2] = bx; o[3] = by; o[4] = gx; o[5] = gy;
+}
+// One wave per model triangle, lanes over the data triangles.  EMIT = false: counts[i] = matches of row i.
+// EMIT = true: rows are written at offs[i] in data order (ballot ranks keep the reference's loop order).
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_tri_match(const double* __restrict__ dm, const double* __restrict__ xm, int ntm,
+                                                   const double* __restrict__ dd, const double* __restrict__ xd, int ntd, double thr,
+                                                   int* __restrict__ counts, const long long* __restrict__ offs,
+                                                   double* __restrict__ pts, double* __restrict__ diffs) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= ntm) return;
+  const double m0 = dm[3 * (size_t)i], m1 = dm[3 * (size_t)i + 1], m2 = dm[3 * (size_t)i + 2];
+  long long base = EMIT ? offs[i] : 0;
+  int cnt = 0;
+  for (int j0 = 0; j0 < ntd; j0 += 64) {
+    const int j = j0 + lane;
+    bool hit = false;
+    double diff = 0.0;
+    if (j < ntd) {
+      const double e0 = m0 - dd[3 * (size_t)j], e1 = m1 - dd[3 * (size_t)j + 1], e2 = m2 - dd[3 * (size_t)j + 2];
+      double sacc = 0.0;
+      sacc += e0 * e0; sacc += e1 * e1; sacc += e2 * e2;
+      diff = sqrt(sacc);
+      hit = diff < thr;
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (EMIT && hit) {
+      const long long row = base + __popcll(mask & ((1ull << lane) - 1ull));
+      diffs[row] = diff;
+      double* o = pts + 12 * row;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        o[4 * k] = xm[6 * (size_t)i + 2 * k]; o[4 * k + 1] = xm[6 * (size_t)i + 2 * k + 1];
+        o[4 * k + 2] = xd[6 * (size_t)j + 2 * k]; o[4 * k + 3] = xd[6 * (size_t)j + 2 * k + 1];
+      }
+    }
+    base += __popcll(mask);
+    cnt += __popcll(mask);
+  }
+  if (!EMIT && lane == 0) counts[i] = cnt;
+}
+
+// ---- CLIPPER dense-clique solver: the two symmetric products of one projected-gradient evaluation ---------------------
+// Mup: n x n row-major, upper triangle filled (slide_clipper_affinity's output).  One wave per row i:
+//   Mu[i] = sum_j M_sym[i][j] v[j],   Cu[i] = sum_{j : M_sym[i][j] != 0} v[j]     (C = sparsity pattern of M, clipper.cpp:60-63)
+__global__ __launch_bounds__(256) void k_clq_matvec(const double* __restrict__ Mup, int n, const double* __restrict__ v,
+                                                    double* __restrict__ Mu, double* __restrict__ Cu) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int j = lane; j < n; j += 64) {
+    const double a = j > i ? Mup[(size_t)i * n + j] : (j < i ? Mup[(size_t)j * n + i] : 0.0);
+    const double x = v[j];
+    s1 += a * x;
+    s2 += (a != 0.0) ? x : 0.0;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+  if (lane == 0) { Mu[i] = s1; Cu[i] = s2; }
+}
+
+void launch_tri_prepare(const double* tri, int n, double* sdist, double* sxy, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_tri_prepare, dim3((n + 255) / 256), dim3(256), 0, s, tri, n, sdist, sxy);
+}
+void launch_tri_match(bool emit, const double* dm, const double* xm, int ntm, const double* dd, const double* xd, int ntd, double thr,
+                      int* counts, const long long* offs, double* pts, double* diffs, hipStream_t s) {
+  if (ntm <= 0) return;
+  if (emit) hipLaunchKernelGGL(k_tri_match<true>, dim3((ntm + 3) / 4), dim3(256), 0, s, dm, xm, ntm, dd, xd, ntd, thr, counts, offs, pts, diffs);
+  else hipLaunchKernelGGL(k_tri_match<false>, dim3((ntm + 3) / 4), dim3(256), 0, s, dm, xm, ntm, dd, xd, ntd, thr, counts, offs, pts, diffs);
+}
+void launch_clq_matvec(const double* Mup, int n, const double* v, double* Mu, double* Cu, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_clq_matvec, dim3((n + 3) / 4), dim3(256), 0, s, Mup, n, v, Mu, Cu);
+}
+
 void launch_place_sweep(const PlaceDev& P, hipStream_t s) {
   // cos/sin tables ride behind the yaw table: yaws[n_yaw .. 3 n_yaw)
   const double* cosv = P.yaws + P.n_yaw;

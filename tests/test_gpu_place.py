@@ -115,3 +115,131 @@ def test_clipper_affinity_matches_golden_and_oracle(gpu):
                                   _p(Ao), C.c_int(m), C.byref(opp), _p(Mo))
     assert np.array_equal(Mg != 0, Mo != 0)                  # sparsity pattern (threshold decisions): identical
     assert np.allclose(Mg, Mo, rtol=1e-14, atol=0)           # exp() is device libm vs glibc: <= 1 ulp
+
+
+# ---- SlideGraph: triangle matching, CLIPPER dense clique, semantic_clipper pipeline -----------------
+def _oracle_clipper_params(**kw):
+    import ctypes as C
+
+    class OCP(C.Structure):
+        _fields_ = [("tol_u", C.c_double), ("tol_F", C.c_double), ("maxiniters", C.c_int), ("maxoliters", C.c_int),
+                    ("beta", C.c_double), ("maxlsiters", C.c_int), ("eps", C.c_double), ("affinityeps", C.c_double),
+                    ("rescale_u0", C.c_int), ("sigma", C.c_double), ("epsilon", C.c_double), ("mindist", C.c_double)]
+    p = OCP()
+    po.lib().orc_clipper_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _triangles(points):
+    from scipy.spatial import Delaunay
+    tri = Delaunay(points, qhull_options="Qt Qbb Qc Qz Q12")       # observation.cpp:25-26 options
+    return points[tri.simplices].astype(np.float64)                 # (n, 3, 2)
+
+
+def _slidegraph_case(seed, n=40, noise=0.01, n_query=25):
+    rng = np.random.default_rng(seed)
+    ref = rng.uniform(-30, 30, (n, 2))
+    yaw = rng.uniform(-np.pi, np.pi)
+    R = np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]])
+    t = rng.uniform(-5, 5, 2)
+    sel = rng.permutation(n)[:n_query]
+    qry = (ref[sel] - t) @ R + rng.normal(0, noise, (n_query, 2))   # ref = R qry + t
+    return _triangles(ref), _triangles(qry), R, t
+
+
+@pytest.mark.gpu
+def test_match_triangles_identical_to_oracle(gpu):
+    import ctypes as C
+    for seed in range(3):
+        tm, td, _, _ = _slidegraph_case(seed)
+        pts, diffs = gpu.match_triangles(tm, td, 0.1)
+        cap = len(tm) * len(td)
+        op = np.zeros((cap, 3, 4)); od = np.zeros(cap)
+        tmf, tdf = np.ascontiguousarray(tm.reshape(-1, 6)), np.ascontiguousarray(td.reshape(-1, 6))
+        n = po.lib().orc_match_triangles(tmf.ctypes.data_as(C.c_void_p), C.c_int(len(tm)), tdf.ctypes.data_as(C.c_void_p),
+                                         C.c_int(len(td)), C.c_double(0.1), op.ctypes.data_as(C.c_void_p),
+                                         od.ctypes.data_as(C.c_void_p), C.c_int(cap))
+        assert n == len(diffs) and n > 0
+        assert np.array_equal(pts, op[:n])            # same pairs, same order, same vertex order: bit-identical rows
+        assert np.array_equal(diffs, od[:n])
+
+
+@pytest.mark.gpu
+def test_dense_clique_matches_oracle(gpu):
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    D1 = rng.uniform(-10, 10, (40, 2))
+    perm = rng.permutation(40)[:25]
+    D2 = D1[perm] + rng.normal(0, 0.02, (25, 2))
+    A = np.array([(i, j) for i in range(40) for j in range(25)], np.int32)[::4].copy()
+    for k, j in enumerate(perm[:12]):                  # make sure true pairs are among the putative ones
+        A[k] = (j, k)
+    M = gpu.clipper_affinity(D1, D2, A, sigma=0.1, epsilon=0.3)
+    m = len(A)
+    p = gpu.clipper_params(sigma=0.1, epsilon=0.3)
+    op = _oracle_clipper_params(sigma=0.1, epsilon=0.3)
+    agree = 0
+    for seed in range(6):
+        u0 = np.random.default_rng(seed).uniform(0, 1, m)
+        nodes, u, score = gpu.clipper_dense_clique(M, u0, p)
+        on = np.zeros(m, np.int32); ou = np.zeros(m); osc = C.c_double(0)
+        n = po.lib().orc_clipper_solve(M.ctypes.data_as(C.c_void_p), C.c_int(m), u0.ctypes.data_as(C.c_void_p), C.byref(op),
+                                       on.ctypes.data_as(C.c_void_p), ou.ctypes.data_as(C.c_void_p), C.byref(osc))
+        # a local solver on a floating-point path: same clique and score as the oracle from the same start
+        assert sorted(nodes.tolist()) == sorted(on[:n].tolist())
+        assert abs(score - osc.value) < 1e-6 * max(1.0, abs(osc.value))
+        assert np.abs(u - ou).max() < 1e-6
+        agree += 1
+    assert agree == 6
+    nodes, _, _ = gpu.clipper_dense_clique(M, None, p)  # library-drawn start weights
+    assert len(nodes) >= 3
+
+
+@pytest.mark.gpu
+def test_semantic_clipper_pipeline(gpu):
+    import ctypes as C
+    found = 0
+    for seed in range(4):
+        tm, td, R, t = _slidegraph_case(100 + seed)
+        pts, _ = gpu.match_triangles(tm, td, 0.1)
+        m = 3 * len(pts)
+        u0 = np.random.default_rng(seed).uniform(0, 1, m)
+        p = gpu.clipper_params(sigma=0.05, epsilon=0.15)
+        r = gpu.semantic_clipper(tm, td, p, min_num_pairs=4, matching_threshold=0.1, u0=u0)
+        op = _oracle_clipper_params(sigma=0.05, epsilon=0.15)
+        tf = np.zeros(16); counts = np.zeros(2, np.int32); inl = np.zeros(max(m, 1), np.int32)
+        tmf, tdf = np.ascontiguousarray(tm.reshape(-1, 6)), np.ascontiguousarray(td.reshape(-1, 6))
+        ok = po.lib().orc_semantic_clipper(tmf.ctypes.data_as(C.c_void_p), C.c_int(len(tm)), tdf.ctypes.data_as(C.c_void_p), C.c_int(len(td)),
+                                           C.byref(op), C.c_int(4), C.c_double(0.1), u0.ctypes.data_as(C.c_void_p),
+                                           tf.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), inl.ctypes.data_as(C.c_void_p))
+        assert r["n_putative"] == counts[0] == m
+        assert r["found"] == bool(ok)
+        # the putative list repeats a vertex pair once per matched triangle pair that contains it; such duplicates carry
+        # equal weights up to rounding, so WHICH copy makes the top-omega cut is not defined: compare counts, the selected
+        # point pairs as a set, and the transform
+        assert r["n_inliers"] == counts[1]
+        rows = pts.reshape(-1, 4)
+        sel_g = {tuple(rows[i]) for i in r["inliers"]}
+        sel_o = {tuple(rows[i]) for i in inl[:counts[1]]}
+        assert len(sel_g ^ sel_o) <= 2
+        assert np.abs(r["tf"].ravel() - tf).max() < 1e-3
+        if r["found"]:
+            found += 1
+            # the recovered transform maps the query frame onto the reference frame (semantic_clipper's "model" = reference):
+            # estimate_tf(model, data) maps model -> data, i.e. reference -> query = (R, t)^-1
+            Rq = r["tf"][:2, :2]; tq = r["tf"][:2, 3]
+            assert np.abs(Rq - R.T).max() < 0.02 and np.abs(tq - (-R.T @ t)).max() < 0.3
+    assert found >= 3
+
+
+@pytest.mark.gpu
+def test_estimate_tf2d(gpu):
+    rng = np.random.default_rng(3)
+    a = rng.uniform(-5, 5, (12, 2))
+    th = 0.7
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    b = a @ R.T + np.array([1.5, -2.0])
+    tf = gpu.estimate_tf2d(a, b)
+    assert np.abs(tf[:2, :2] - R).max() < 1e-12 and np.abs(tf[:2, 2] - [1.5, -2.0]).max() < 1e-12

@@ -247,3 +247,35 @@ def test_analytic_jacobians_match_central_differences():
     r, J0, J1 = _lin(po.F_CYL, x, po.V_CYL, cyl, zc, sig)
     expect = np.eye(7); expect[6, 6] = -1
     assert np.allclose(J1, expect, atol=1e-8)
+
+
+# ---- SlideGraph restatement (oracle/slidegraph.hpp): no reference fixture exists, so these pin its own invariants -------------
+def _tri_case(seed, n=30, nq=20):
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    ref = rng.uniform(-20, 20, (n, 2))
+    yaw = rng.uniform(-np.pi, np.pi)
+    R = np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]])
+    t = rng.uniform(-3, 3, 2)
+    qry = (ref[rng.permutation(n)[:nq]] - t) @ R
+    tri = lambda pts: pts[Delaunay(pts, qhull_options="Qt Qbb Qc Qz Q12").simplices].astype(np.float64)
+    return tri(ref), tri(qry), R, t
+
+
+def test_oracle_triangle_matching_and_tf():
+    tm, td, R, t = _tri_case(2)
+    tmf, tdf = np.ascontiguousarray(tm.reshape(-1, 6)), np.ascontiguousarray(td.reshape(-1, 6))
+    cap = len(tm) * len(td)
+    pts = np.zeros((cap, 3, 4)); diffs = np.zeros(cap)
+    n = po.lib().orc_match_triangles(_p(tmf), C.c_int(len(tm)), _p(tdf), C.c_int(len(td)), C.c_double(1e-6), _p(pts), _p(diffs), C.c_int(cap))
+    assert n > 0 and diffs[:n].max() < 1e-6
+    # noise-free: every matched triangle pair is a congruent pair, and its sorted vertices correspond under the true motion
+    a, b = pts[:n, :, :2].reshape(-1, 2), pts[:n, :, 2:].reshape(-1, 2)
+    assert np.abs((b @ R.T + t) - a).max() < 1e-6          # reference = R query + t
+    tf = np.zeros(9)
+    po.lib().orc_estimate_tf2d(_p(np.ascontiguousarray(b)), _p(np.ascontiguousarray(a)), C.c_int(len(a)), _p(tf))
+    tf = tf.reshape(3, 3)
+    assert np.abs(tf[:2, :2] - R).max() < 1e-9 and np.abs(tf[:2, 2] - t).max() < 1e-8
+    # a reflected point set: the reference's "negate column 1" fix still returns a proper rotation
+    po.lib().orc_estimate_tf2d(_p(np.ascontiguousarray(b * [1, -1])), _p(np.ascontiguousarray(a)), C.c_int(len(a)), _p(tf.reshape(-1)))
+    assert abs(np.linalg.det(tf[:2, :2]) - 1.0) < 1e-12
