@@ -282,6 +282,14 @@ int slide_semantic_clipper(const double* tri_model, int ntm, const double* tri_d
 /* sloam::FindRelativeMeasurementMatch / GetIndexClosestPoseMstPair (src/core/sloam.cpp:321-440).
  * Stamps are (sec, nsec) pairs.  Host-side logic (tiny, sequential): no kernel. */
 int slide_closest_stamp(const int64_t* sec, const int64_t* nsec, int n, int64_t qsec, int64_t qnsec, int* idx, double* diff);
+/* sloam::FindRelativeMeasurementMatch sloam.cpp:321-412.  Packets of all robots concatenated (pk_sec / pk_nsec) with
+ * offsets[n_robots + 1]; pose_counter per robot; pending measurements (stamp, observed robot, onlyUseOdom flag, caller tag) are
+ * compacted IN PLACE exactly as feasible_relative_meas_for_factors is (matched and stale ones erased).  match_out: 4 ints per
+ * match {tag, position in the pending list at match time, host pose index, other pose index}.  *n_matches >= 0; returns
+ * SLIDE_ERR_INVALID where the reference throws std::runtime_error (robotIndex == host, onlyUseOdom measurement). */
+int slide_find_relative_meas_match(int n_robots, const int64_t* pk_sec, const int64_t* pk_nsec, const int32_t* offsets,
+                                   const uint64_t* pose_counter, int host, int* n_pending_io, int64_t* m_sec, int64_t* m_nsec,
+                                   int32_t* m_robot, int32_t* m_only_odom, int32_t* m_tag, int32_t* match_out, int* n_matches);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,7 @@ EXPORTS = [
     "slide_backend_end_frame", "slide_backend_graph", "slide_backend_counts", "slide_backend_map_model",
     "slide_place_default_params", "slide_match_maps", "slide_find_inter_loop_closure", "slide_clipper_affinity",
     "slide_closest_stamp", "slide_clipper_default_params", "slide_clipper_dense_clique", "slide_match_triangles",
-    "slide_estimate_tf2d", "slide_semantic_clipper",
+    "slide_estimate_tf2d", "slide_semantic_clipper", "slide_find_relative_meas_match",
 ]
 
 
@@ -462,3 +462,27 @@ def closest_stamp(sec, nsec, qsec, qnsec):
     lib().slide_closest_stamp(_p(sec), _p(nsec), C.c_int(len(sec)), C.c_int64(qsec), C.c_int64(qnsec), C.byref(idx),
                               C.byref(diff))
     return idx.value, diff.value
+
+
+def find_relative_meas_match(packets, counters, host, pending):
+    """sloam::FindRelativeMeasurementMatch (sloam.cpp:321-412).  packets: per robot list of (sec, nsec); pending: list of
+    ((sec, nsec), robot, only_use_odom).  Returns (matches (n, 4) = [tag, index, host idx, other idx], tags of the
+    measurements still pending); raises SlideError where the reference throws."""
+    sec, ns, off = [], [], [0]
+    for pk in packets:
+        for (a, b) in pk:
+            sec.append(a); ns.append(b)
+        off.append(len(sec))
+    sec = np.array(sec + [0], np.int64); ns = np.array(ns + [0], np.int64); off = np.array(off, np.int32)
+    pc = np.array(counters, np.uint64)
+    npend = C.c_int(len(pending))
+    m_sec = np.array([p[0][0] for p in pending] + [0], np.int64)
+    m_ns = np.array([p[0][1] for p in pending] + [0], np.int64)
+    m_rob = np.array([p[1] for p in pending] + [0], np.int32)
+    m_odo = np.array([int(p[2]) for p in pending] + [0], np.int32)
+    m_tag = np.arange(len(pending) + 1, dtype=np.int32)
+    out = np.zeros(4 * max(len(pending), 1), np.int32)
+    nm = C.c_int(0)
+    _check(lib().slide_find_relative_meas_match(C.c_int(len(packets)), _p(sec), _p(ns), _p(off), _p(pc), C.c_int(host), C.byref(npend),
+                                                _p(m_sec), _p(m_ns), _p(m_rob), _p(m_odo), _p(m_tag), _p(out), C.byref(nm)))
+    return out.reshape(-1, 4)[:nm.value].copy(), m_tag[:npend.value].copy()

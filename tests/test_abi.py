@@ -65,3 +65,37 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in txt and "liboracle" not in txt and '#include "../oracle' not in txt, f
+
+
+def test_find_relative_meas_match_host_logic():
+    """sloam_test.cpp:59-205 through the product's entry point (pure host bookkeeping: runs without a GPU) and against the
+    oracle on random schedules."""
+    import slide_slam_amd as s
+    from slide_slam_amd.api import SlideError
+    import pytest
+    f = s.find_relative_meas_match
+    assert len(f([[], []], [0, 0], 0, [])[0]) == 0
+    with pytest.raises(SlideError):
+        f([[], []], [0, 0], 0, [((0, 0), 0, False)])                 # robotIndex == host -> the reference throws
+    with pytest.raises(SlideError):
+        f([[], []], [0, 0], 0, [((0, 0), 1, True)])                  # onlyUseOdom -> the reference throws
+    m, left = f([[(5, 0)], [(5, 0)]], [1, 1], 0, [((5, 0), 1, False)])
+    assert len(m) == 1 and tuple(m[0][2:]) == (0, 0) and len(left) == 0
+    m, left = f([[(5, 0), (7, 0)], [(5, 0), (7, 0)]], [2, 2], 0, [((5, 0), 1, False), ((7, 1000), 1, False)])
+    assert len(m) == 2 and tuple(m[0][2:]) == (0, 0) and tuple(m[1][2:]) == (1, 1) and len(left) == 0
+    m, left = f([[(5, 0), (7, 0), (9, 8000000)], [(5, 0), (7, 0), (10, 2000000)]], [3, 3], 0, [((10, 0), 1, False)])
+    assert len(m) == 0 and len(left) == 1                            # > 1 ms -> kept, not matched
+    m, left = f([[(4, 0)], [(4, 0)]], [1, 1], 0, [((2, 0), 1, False)])
+    assert len(m) == 0 and len(left) == 0                            # stale -> pruned
+    # random schedules against the oracle
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_pins import _find
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        packets = [[(int(t), int(rng.integers(0, 3)) * 400000) for t in np.sort(rng.integers(0, 30, rng.integers(0, 12)))] for _ in range(3)]
+        counters = [int(rng.integers(0, len(pk) + 1)) for pk in packets]
+        pending = [((int(rng.integers(0, 30)), int(rng.integers(0, 3)) * 400000), int(rng.integers(1, 3)), False) for _ in range(rng.integers(0, 8))]
+        m, left = f(packets, counters, 0, pending)
+        n, mo, nleft = _find(packets, counters, 0, pending)
+        assert n == len(m) and np.array_equal(mo, m) and nleft == len(left)
