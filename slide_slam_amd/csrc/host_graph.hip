@@ -72,6 +72,8 @@ uint64_t HostGraph::lm_key(int cls, uint64_t idx) {
 HostGraph::HostGraph(const slide_params_t& p) : P(p) {}
 HostGraph::~HostGraph() {
   if (gexec) (void)hipGraphExecDestroy(gexec);
+  for (auto& pg : phase_graph)
+    if (pg.exec) (void)hipGraphExecDestroy(pg.exec);
   for (auto e : ev_dp) (void)hipEventDestroy(e);
   for (auto e : ev_upd) (void)hipEventDestroy(e);
   if (stream2) (void)hipStreamDestroy(stream2);
@@ -514,15 +516,9 @@ int HostGraph::set_shared(const int32_t* cls, const int64_t* idx, const int32_t*
 //  10: pack the owner's landmark values (15/slot)      11: unpack them (every rank adopts the owner's value)
 // Every robot solves its own reduced pose system with the GLOBAL landmark blocks (block-Jacobi over robots on
 // the Schur complement, exact gradient): the fixed point is the joint optimum.
-int HostGraph::dist_phase(int phase, double* d_buf) {
+int HostGraph::enqueue_phase(int phase, double* d_buf) {
   hipStream_t s = stream;
   if (phase == 0) {
-    int rc = merge_pending();
-    if (rc != SLIDE_OK) return rc;
-    rc = upload_new();
-    if (rc != SLIDE_OK) return rc;
-    G.relin_thr = 0.0;
-    SL_HIP(hipMemsetAsync(d_status.d, 0, 8 * sizeof(int), s));
     launch_relin(G, s);
     launch_linearize(G, s);
     launch_landmark(G, 1, s);
@@ -538,19 +534,63 @@ int HostGraph::dist_phase(int phase, double* d_buf) {
     launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, s);
     launch_backsub(G, 1, s);
     launch_shared_pack(G, 1, d_buf, s);
-  } else if (phase == 2) {
+  } else {
     launch_shared_unpack(G, 1, d_buf, s);
     launch_backsub(G, 2, s);
     launch_estimate(G, s);
-    int st[8];
-    SL_HIP(hipMemcpyAsync(st, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
-    SL_HIP(hipStreamSynchronize(s));
-    SL_HIP(hipGetLastError());
-    if (st[0] || st[1]) {
-      g_last_error = st[0] ? "landmark block not positive definite" : "reduced pose system not positive definite";
-      return SLIDE_ERR_NOT_SPD;
+  }
+  return SLIDE_OK;
+}
+
+int HostGraph::dist_phase(int phase, double* d_buf) {
+  hipStream_t s = stream;
+  if (phase >= 0 && phase <= 2) {
+    if (phase == 0) {
+      int rc = merge_pending();
+      if (rc != SLIDE_OK) return rc;
+      rc = upload_new();
+      if (rc != SLIDE_OK) return rc;
+      G.relin_thr = 0.0;
+      SL_HIP(hipMemsetAsync(d_status.d, 0, 8 * sizeof(int), s));     // (outside the captured sequence, as in run_update)
     }
-    return SLIDE_OK;
+    // the launch sequence of a phase is replayed as a hipGraph while the resident graph and the exchange buffer stay the
+    // same (every pass of a distributed Gauss-Newton run): ~90 launches per pass otherwise
+    static const bool env_graph = !(getenv("SLIDE_NO_GRAPH") && getenv("SLIDE_NO_GRAPH")[0] == '1');
+    PhaseGraph& pg = phase_graph[phase];
+    static const int env_mask = getenv("SLIDE_PHASE_GRAPH_MASK") ? atoi(getenv("SLIDE_PHASE_GRAPH_MASK")) : 7;
+    bool use_graph = env_graph && !prof.on && G.T > 4 && ((env_mask >> phase) & 1);
+    if (use_graph && !(pg.exec && pg.buf == d_buf && std::memcmp(&pg.G, &G, sizeof(GraphDev)) == 0)) {
+      if (pg.exec) { (void)hipGraphExecDestroy(pg.exec); pg.exec = nullptr; }
+      hipGraph_t graph = nullptr;
+      SL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      const int rc = enqueue_phase(phase, d_buf);
+      const hipError_t e = hipStreamEndCapture(s, &graph);
+      if (rc != SLIDE_OK || e != hipSuccess || graph == nullptr) {
+        (void)hipGetLastError();
+        use_graph = false;
+      } else {
+        const hipError_t ei = hipGraphInstantiate(&pg.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess) { pg.exec = nullptr; (void)hipGetLastError(); use_graph = false; }
+        else { pg.G = G; pg.buf = d_buf; }
+      }
+    }
+    if (use_graph) SL_HIP(hipGraphLaunch(pg.exec, s));
+    else {
+      const int rc = enqueue_phase(phase, d_buf);
+      if (rc != SLIDE_OK) return rc;
+    }
+    if (phase == 2) {
+      int st[8];
+      SL_HIP(hipMemcpyAsync(st, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+      SL_HIP(hipStreamSynchronize(s));
+      SL_HIP(hipGetLastError());
+      if (st[0] || st[1]) {
+        g_last_error = st[0] ? "landmark block not positive definite" : "reduced pose system not positive definite";
+        return SLIDE_ERR_NOT_SPD;
+      }
+      return SLIDE_OK;
+    }
   } else if (phase == 10) {
     // commit every variable (theta <- theta (+) delta, delta <- 0), then publish the owners' values
     G.relin_thr = 0.0;

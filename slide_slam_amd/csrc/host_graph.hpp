@@ -165,6 +165,9 @@ class HostGraph {
   hipGraphExec_t gexec = nullptr;
   GraphDev G_cap{};
   GraphDev G_prev{};
+  struct PhaseGraph { hipGraphExec_t exec = nullptr; GraphDev G{}; double* buf = nullptr; };
+  PhaseGraph phase_graph[3];             // captured launch sequences of dist_phase 0 / 1 / 2
+  int enqueue_phase(int phase, double* d_buf);
   bool have_prev = false;
 };
 
