@@ -123,6 +123,13 @@ int slide_graph_get_profile(slide_graph_t* g, char* names, double* ms_total, int
  * library); each call returns after its kernels have completed. */
 int slide_graph_set_shared(slide_graph_t* g, const int32_t* cls, const int64_t* idx, const int32_t* owner, int n_slots);
 int slide_graph_dist_phase(slide_graph_t* g, int phase, double* d_buf);
+/* Sharded mode, inter-robot relative-pose factors (addRelativeMeasFactor graph.cpp:247-258 between poses of two ranks).
+ * Ghost slots enumerate, identically on every rank, the poses such factors touch; slot i is this rank's pose
+ * (own_robot[i], own_idx[i]) or belongs to another rank (own_robot[i] < 0).  A factor is added on BOTH ranks, each with its
+ * own pose as the variable and the other pose as ghost slot; local_first = 1 when the local pose is the Between's first key.
+ * Per pass, before phase 0: dist_phase 20 (pack 12 doubles per slot), all-reduce(sum), dist_phase 21 (adopt). */
+int slide_graph_set_ghosts(slide_graph_t* g, const int32_t* own_robot, const int64_t* own_idx, int n_slots);
+int slide_graph_add_relative_meas_ghost(slide_graph_t* g, const double rel7[7], uint64_t idx, int robot, int ghost_slot, int local_first);
 /* Landmark table of this rank (input of the cross-robot association): for class cls, positions (xyz of the
  * current estimate; cylinders: root) and labels of landmarks [0, n).  Returns n (<= cap). */
 int slide_backend_landmark_table(slide_backend_t* b, int cls, double* xyz, int32_t* label, int cap);

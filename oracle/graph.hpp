@@ -39,7 +39,7 @@ struct Var {
   double delta[9];
 };
 
-enum FType { F_PRIOR = 0, F_BETWEEN = 1, F_BR = 2, F_CUBE = 3, F_CYL = 4 };
+enum FType { F_PRIOR = 0, F_BETWEEN = 1, F_BR = 2, F_CUBE = 3, F_CYL = 4, F_GHOST = 5 };   // F_GHOST: sharded-mode only
 static inline int fac_dim(int t) { return t == F_BR ? 3 : t == F_CUBE ? 9 : t == F_CYL ? 7 : 6; }
 
 // measurement layouts: PRIOR/BETWEEN pose R(9) t(3); BR bearing(3) range(1);
@@ -189,7 +189,9 @@ struct LinFactor {
   double J1[81];     // m x d1
 };
 
-inline void linearize_factor(const Factor& f, const std::vector<Var>& vars, const GraphParams& P, LinFactor& L) {
+// ghosts: 12 doubles (R row-major, t) per ghost slot — the current value of a pose owned by another rank (sharded mode)
+inline void linearize_factor(const Factor& f, const std::vector<Var>& vars, const GraphParams& P, LinFactor& L,
+                             const double* ghosts = nullptr) {
   const int chart = P.pose_chart;
   L.m = fac_dim(f.type);
   const Var& x0 = vars[f.v0];
@@ -211,6 +213,26 @@ inline void linearize_factor(const Factor& f, const std::vector<Var>& vars, cons
       pose_adjoint(hinv, Ad);
       for (int i = 0; i < 36; ++i) { L.J0[i] = -Ad[i]; L.J1[i] = 0.0; }
       for (int i = 0; i < 6; ++i) L.J1[7 * i] = 1.0;
+      break;
+    }
+    case F_GHOST: {
+      // BetweenFactor<Pose3> (graph.cpp:247-258) whose other pose is a constant of this pass: a unary factor.
+      // z[12] != 0: the local pose is the FIRST key (J = -Ad(h^-1)), else the second (J = I).
+      Var xo{};
+      xo.type = V_POSE;
+      std::memcpy(xo.val, ghosts + 12 * (size_t)f.v1, 96);
+      const bool first = f.z[12] != 0.0;
+      if (first) {
+        err_between(f, x0, xo, chart, L.r);
+        Pose hinv = pose_between(var_pose(xo), var_pose(x0));
+        double Ad[36];
+        pose_adjoint(hinv, Ad);
+        for (int i = 0; i < 36; ++i) L.J0[i] = -Ad[i];
+      } else {
+        err_between(f, xo, x0, chart, L.r);
+        for (int i = 0; i < 36; ++i) L.J0[i] = 0.0;
+        for (int i = 0; i < 6; ++i) L.J0[7 * i] = 1.0;
+      }
       break;
     }
     case F_BR: {
@@ -539,14 +561,41 @@ class Graph {
     std::vector<double> Hinv_all, dp;
     std::vector<std::vector<double>> Eall;
   } D;
+  void merge_pending();
   int set_shared(const int* cls, const int64_t* idx, const int* owner, int n);
   int dist_phase(int phase, double* buf);
+  // sharded mode: inter-robot relative-pose factors.  Ghost slots are a global enumeration of the poses that such
+  // factors touch; own_var[s] = this rank's variable of slot s or -1.  Phase 20 packs the owned poses' estimates
+  // (12 doubles per slot, zeros elsewhere) for an all-reduce(sum), phase 21 adopts the summed buffer.
+  std::vector<double> ghost_val;
+  std::vector<int> ghost_own;
+  int set_ghosts(const int* own_robot, const int64_t* own_idx, int n) {
+    ghost_own.assign(n, -1);
+    ghost_val.assign(12 * (size_t)n, 0.0);
+    for (int i = 0; i < n; ++i) { ghost_val[12 * (size_t)i] = ghost_val[12 * (size_t)i + 4] = ghost_val[12 * (size_t)i + 8] = 1.0; }
+    for (int i = 0; i < n; ++i) {
+      if (own_robot[i] < 0) continue;
+      auto it = key2var.find(pose_key(own_robot[i], (uint64_t)own_idx[i]));
+      if (it == key2var.end()) return -1;
+      ghost_own[i] = it->second;
+    }
+    return 0;
+  }
+  // graph.cpp:247-258 with the other pose on another rank
+  void addRelativeMeasGhost(const Pose& rel, uint64_t idx, int robot, int slot, bool local_first) {
+    Factor f{};
+    f.type = F_GHOST;
+    std::memcpy(f.z, rel.R, 72); std::memcpy(f.z + 9, rel.t, 24);
+    f.z[12] = local_first ? 1.0 : 0.0;
+    const double dist = std::max(norm3(rel.t), P.noise_floor);
+    for (int i = 0; i < 6; ++i) f.sigma[i] = P.relmeas_sigma[i] * dist;
+    add_factor(f, pose_key(robot, idx), (uint64_t)slot);
+  }
 };
 
 inline double now_sec();
 
-inline int Graph::solve() {
-  const double t0 = now_sec();
+inline void Graph::merge_pending() {
   // (1) merge fvalues / fgraph  [GTSAM ISAM2::update: new variables get delta = 0]
   for (size_t i = 0; i < pend_vars.size(); ++i) {
     if (key2var.count(pend_keys[i])) continue;  // GTSAM would throw ValuesKeyAlreadyExists
@@ -562,7 +611,9 @@ inline int Graph::solve() {
     if (a == key2var.end()) continue;
     f.v0 = a->second;
     f.v1 = -1;
-    if (f.type != F_PRIOR) {
+    if (f.type == F_GHOST) {
+      f.v1 = (int)pend_fk1[i];                // ghost slot, not a variable
+    } else if (f.type != F_PRIOR) {
       auto b = key2var.find(pend_fk1[i]);
       if (b == key2var.end()) continue;
       f.v1 = b->second;
@@ -570,6 +621,11 @@ inline int Graph::solve() {
     factors.push_back(f);
   }
   pend_vars.clear(); pend_keys.clear(); pend_factors.clear(); pend_fk0.clear(); pend_fk1.clear();
+}
+
+inline int Graph::solve() {
+  const double t0 = now_sec();
+  merge_pending();
 
   // (2) relinearisation  [GTSAM CheckRelinearizationFull: maxDelta >= threshold]
   stats = SolveStats();
@@ -598,7 +654,7 @@ inline int Graph::solve() {
   std::vector<LinFactor> lin(factors.size());
   const int nthreads = P.num_threads;
 #pragma omp parallel for schedule(static) num_threads(nthreads)
-  for (size_t i = 0; i < factors.size(); ++i) linearize_factor(factors[i], vars, P, lin[i]);
+  for (size_t i = 0; i < factors.size(); ++i) linearize_factor(factors[i], vars, P, lin[i], ghost_val.data());
   const double t1 = now_sec();
 
   std::vector<double> S((size_t)n * n, 0.0), g(n, 0.0);
@@ -635,7 +691,7 @@ inline int Graph::solve() {
         for (int r = 0; r < L.m; ++r) s += L.J1[r * 6 + a] * L.r[r];
         g[6 * p1 + a] += s;
       }
-    } else if (f.type != F_PRIOR) {
+    } else if (f.type != F_PRIOR && f.type != F_GHOST) {
       LmAcc& A = acc[lidx[f.v1]];
       const int d = L.d1;
       for (int a = 0; a < d; ++a) {
@@ -769,7 +825,25 @@ inline int Graph::set_shared(const int* cls, const int64_t* idx, const int* owne
 // phases and buffer layouts identical to slide_graph_dist_phase (include/slide_gpu.h)
 inline int Graph::dist_phase(int phase, double* buf) {
   const int nslots = (int)sh_var.size();
+  if (phase == 20) {
+    merge_pending();
+    for (size_t sidx = 0; sidx < ghost_own.size(); ++sidx) {
+      double* o = buf + 12 * sidx;
+      for (int k = 0; k < 12; ++k) o[k] = 0.0;
+      if (ghost_own[sidx] < 0) continue;
+      const Var& v = vars[ghost_own[sidx]];
+      Var e;
+      var_retract(v, v.delta, P.pose_chart, e);        // current estimate theta (+) delta
+      std::memcpy(o, e.val, 96);
+    }
+    return 0;
+  }
+  if (phase == 21) {
+    std::memcpy(ghost_val.data(), buf, sizeof(double) * ghost_val.size());
+    return 0;
+  }
   if (phase == 0) {
+    merge_pending();
     for (auto& v : vars) {   // batch GN: theta <- theta (+) delta for every variable
       Var nv;
       var_retract(v, v.delta, P.pose_chart, nv);
@@ -783,12 +857,12 @@ inline int Graph::dist_phase(int phase, double* buf) {
       else { D.lidx[i] = (int)D.lm_vars.size(); D.lm_vars.push_back((int)i); }
     }
     D.lin.resize(factors.size());
-    for (size_t i = 0; i < factors.size(); ++i) linearize_factor(factors[i], vars, P, D.lin[i]);
+    for (size_t i = 0; i < factors.size(); ++i) linearize_factor(factors[i], vars, P, D.lin[i], ghost_val.data());
     D.acc.assign(D.lm_vars.size(), DLm());
     for (auto& a : D.acc) { std::memset(a.H, 0, sizeof(a.H)); std::memset(a.g, 0, sizeof(a.g)); std::memset(a.t, 0, sizeof(a.t)); }
     for (size_t i = 0; i < factors.size(); ++i) {
       const Factor& f = factors[i];
-      if (f.type == F_PRIOR || f.type == F_BETWEEN) continue;
+      if (f.type == F_PRIOR || f.type == F_BETWEEN || f.type == F_GHOST) continue;
       const LinFactor& L = D.lin[i];
       DLm& A = D.acc[D.lidx[f.v1]];
       const int d = L.d1;

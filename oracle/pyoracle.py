@@ -166,6 +166,16 @@ class OracleGraph:
             raise RuntimeError(f"oracle dist_phase {phase} failed: {rc}")
         return rc
 
+    def set_ghosts(self, own_robot, own_idx):
+        r = _i(own_robot)
+        i = np.ascontiguousarray(own_idx, dtype=np.int64)
+        if self.L.orc_graph_set_ghosts(self.h, _p(r), _p(i), C.c_int(len(r))) != 0:
+            raise RuntimeError("set_ghosts: pose missing")
+
+    def add_relative_meas_ghost(self, rel7, idx, robot, slot, local_first):
+        self.L.orc_graph_add_relative_meas_ghost(self.h, _p(_d(rel7)), C.c_uint64(idx), C.c_int(robot), C.c_int(slot),
+                                                 C.c_int(int(local_first)))
+
     def stats(self):
         out = np.zeros(8)
         self.L.orc_graph_stats(self.h, _p(out))

@@ -39,6 +39,12 @@ struct GraphDev {
   int n_between;
   int* bt_i; int* bt_j; double* bt_z; double* bt_sigma;   // z: 12, sigma: 6
   double* bt_r; double* bt_J0;                    // 6 ; 36 (J1 = diag(1/sigma))
+  // sharded mode (one robot per GPU): relative-pose factors whose other pose lives on another rank ("ghost")
+  int n_ghost;                                    // factors
+  int* gh_pose; int* gh_slot; int* gh_first;      // local pose, ghost slot, 1 = local pose is the FIRST key of the Between
+  double* gh_z; double* gh_sigma;                 // z: 12, sigma: 6
+  double* gh_r; double* gh_J;                     // 6 whitened residual ; 36 whitened Jacobian w.r.t. the local pose
+  int n_gslots; double* ghost_val; int* gslot_pose;   // 12 per slot (R row-major, t) ; local pose owning the slot or -1
   int n_lf;                                       // landmark factors, unified id space
   int* lf_type; int* lf_pose; int* lf_lm; int* lf_slot;   // slot = index into the per-type z arrays
   int64_t* lf_joff; int64_t* lf_eoff;             // offsets (doubles) into jbuf / ebuf

@@ -146,6 +146,47 @@ int HostGraph::add_relative_meas(const double* rel7, uint64_t i1, int r1, uint64
   for (int i = 0; i < 6; ++i) s[i] = P.noise_model_rel_meas_vec[i] * dist;
   return add_between_sigma(pose_key(r1, i1), pose_key(r2, i2), rel, s);
 }
+// addRelativeMeasFactor (graph.cpp:247-258) in sharded mode: the other pose is owned by another rank and enters as the
+// constant value of ghost slot `slot` (refreshed every pass by dist_phase 20 / 21)
+int HostGraph::add_relative_meas_ghost(const double* rel7, uint64_t idx, int robot, int slot, bool local_first) {
+  if (!robot_ok(robot) || slot < 0) return SLIDE_ERR_INVALID;
+  const SE3 rel = from7(rel7);
+  const double dist = std::max(norm(rel.t), P.noise_floor);
+  PendFac f{};
+  f.type = PF_GHOST;
+  f.k0 = pose_key(robot, idx);
+  f.k1 = (uint64_t)slot;
+  put12(rel, f.z);
+  f.z[12] = local_first ? 1.0 : 0.0;
+  for (int i = 0; i < 6; ++i) f.sigma[i] = P.noise_model_rel_meas_vec[i] * dist;
+  pend_facs.push_back(f);
+  return SLIDE_OK;
+}
+// Ghost slots: a global, rank-independent enumeration of the poses touched by inter-robot relative-pose factors;
+// slot i is this rank's pose (own_robot[i], own_idx[i]) or none (own_robot[i] < 0).
+int HostGraph::set_ghosts(const int32_t* own_robot, const int64_t* own_idx, int n_slots) {
+  int rc = merge_pending();
+  if (rc != SLIDE_OK) return rc;
+  rc = upload_new();
+  if (rc != SLIDE_OK) return rc;
+  h_gslot_pose.assign(n_slots, -1);
+  for (int i = 0; i < n_slots; ++i) {
+    if (own_robot[i] < 0) continue;
+    if (!robot_ok(own_robot[i])) return SLIDE_ERR_INVALID;
+    auto it = key2pose.find(pose_key(own_robot[i], (uint64_t)own_idx[i]));
+    if (it == key2pose.end()) { g_last_error = "set_ghosts: pose is not in the graph"; return SLIDE_ERR_INVALID; }
+    h_gslot_pose[i] = it->second;
+  }
+  std::vector<double> ident(12 * (size_t)std::max(n_slots, 1), 0.0);
+  for (int i = 0; i < n_slots; ++i) ident[12 * (size_t)i] = ident[12 * (size_t)i + 4] = ident[12 * (size_t)i + 8] = 1.0;
+  if (d_gslot_pose.ensure(std::max(n_slots, 1), 0, stream) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_ghost_val.ensure(12 * (size_t)std::max(n_slots, 1), 0, stream) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_gslot_pose.upload(h_gslot_pose.data(), 0, n_slots, stream) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_ghost_val.upload(ident.data(), 0, 12 * (size_t)n_slots, stream) != SLIDE_OK) return SLIDE_ERR_HIP;
+  SL_HIP(hipStreamSynchronize(stream));
+  G.n_gslots = n_slots; G.ghost_val = d_ghost_val.d; G.gslot_pose = d_gslot_pose.d;
+  return SLIDE_OK;
+}
 int HostGraph::add_point_landmark(uint64_t idx, const double* xyz) {
   PendVar v{};
   v.key = lm_key(SLIDE_CLS_ELLIPSOID, idx);
@@ -237,6 +278,12 @@ int HostGraph::merge_pending() {
       h_pr_pose.push_back(a->second);
       h_pr_z.insert(h_pr_z.end(), f.z, f.z + 12);
       h_pr_sigma.insert(h_pr_sigma.end(), f.sigma, f.sigma + 6);
+    } else if (f.type == PF_GHOST) {
+      h_gh_pose.push_back(a->second);
+      h_gh_slot.push_back((int)f.k1);
+      h_gh_first.push_back(f.z[12] != 0.0 ? 1 : 0);
+      h_gh_z.insert(h_gh_z.end(), f.z, f.z + 12);
+      h_gh_sigma.insert(h_gh_sigma.end(), f.sigma, f.sigma + 6);
     } else if (f.type == 1) {
       auto b = key2pose.find(f.k1);
       if (b == key2pose.end()) continue;
@@ -328,6 +375,14 @@ int HostGraph::upload_new() {
   UP(d_bt_sigma, h_bt_sigma, up_bt, 6);
   if (d_bt_r.ensure(std::max<size_t>(6 * nbt, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_bt_J0.ensure(std::max<size_t>(36 * nbt, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  const size_t ngh = h_gh_pose.size();
+  UP(d_gh_pose, h_gh_pose, up_gh, 1);
+  UP(d_gh_slot, h_gh_slot, up_gh, 1);
+  UP(d_gh_first, h_gh_first, up_gh, 1);
+  UP(d_gh_z, h_gh_z, up_gh, 12);
+  UP(d_gh_sigma, h_gh_sigma, up_gh, 6);
+  if (d_gh_r.ensure(std::max<size_t>(6 * ngh, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_gh_J.ensure(std::max<size_t>(36 * ngh, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   UP(d_lf_type, h_lf_type, up_lf, 1);
   UP(d_lf_pose, h_lf_pose, up_lf, 1);
   UP(d_lf_lm, h_lf_lm, up_lf, 1);
@@ -384,7 +439,7 @@ int HostGraph::upload_new() {
     if (d_yv.ensure((size_t)Tcap * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_dp.ensure((size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
   }
-  up_P = Pn; up_L = Ln; up_pr = npr; up_bt = nbt; up_lf = nlf;
+  up_P = Pn; up_L = Ln; up_pr = npr; up_bt = nbt; up_lf = nlf; up_gh = ngh;
   up_br = h_br_z.size() / 4; up_cu = h_cu_z.size() / 15; up_cy = h_cy_z.size() / 7;
 
   G.P = (int)Pn; G.L = (int)Ln;
@@ -393,6 +448,9 @@ int HostGraph::upload_new() {
   G.n_prior = (int)npr; G.pr_pose = d_pr_pose.d; G.pr_z = d_pr_z.d; G.pr_sigma = d_pr_sigma.d; G.pr_r = d_pr_r.d;
   G.n_between = (int)nbt; G.bt_i = d_bt_i.d; G.bt_j = d_bt_j.d; G.bt_z = d_bt_z.d; G.bt_sigma = d_bt_sigma.d;
   G.bt_r = d_bt_r.d; G.bt_J0 = d_bt_J0.d;
+  G.n_ghost = (int)ngh; G.gh_pose = d_gh_pose.d; G.gh_slot = d_gh_slot.d; G.gh_first = d_gh_first.d; G.gh_z = d_gh_z.d;
+  G.gh_sigma = d_gh_sigma.d; G.gh_r = d_gh_r.d; G.gh_J = d_gh_J.d;
+  G.n_gslots = (int)h_gslot_pose.size(); G.ghost_val = d_ghost_val.d; G.gslot_pose = d_gslot_pose.d;
   G.n_lf = (int)nlf; G.lf_type = d_lf_type.d; G.lf_pose = d_lf_pose.d; G.lf_lm = d_lf_lm.d; G.lf_slot = d_lf_slot.d;
   G.lf_joff = d_lf_joff.d; G.lf_eoff = d_lf_eoff.d;
   G.br_z = d_br_z.d; G.cu_z = d_cu_z.d; G.cu_sigma = d_cu_sigma.d; G.cy_z = d_cy_z.d;
@@ -601,6 +659,16 @@ int HostGraph::dist_phase(int phase, double* d_buf) {
   } else if (phase == 11) {
     launch_shared_unpack(G, 2, d_buf, s);
     launch_estimate(G, s);
+  } else if (phase == 20) {
+    // current estimates of the owned ghost poses (12 doubles per slot, zeros elsewhere) for an all-reduce(sum)
+    int rc = merge_pending();
+    if (rc != SLIDE_OK) return rc;
+    rc = upload_new();
+    if (rc != SLIDE_OK) return rc;
+    launch_estimate(G, s);
+    launch_ghost_exchange(G, 0, d_buf, s);
+  } else if (phase == 21) {
+    launch_ghost_exchange(G, 1, d_buf, s);
   } else {
     return SLIDE_ERR_INVALID;
   }

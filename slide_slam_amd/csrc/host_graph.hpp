@@ -76,8 +76,9 @@ struct PendVar {
   int type;
   double val[15];
 };
+constexpr int PF_GHOST = 100;
 struct PendFac {
-  int type;          // 0 prior, 1 between, FT_BR, FT_CUBE, FT_CYL
+  int type;          // 0 prior, 1 between, FT_BR, FT_CUBE, FT_CYL, PF_GHOST (ghost between: k1 = slot, z[12] = local-first flag)
   uint64_t k0, k1;
   double z[15];
   double sigma[9];
@@ -95,6 +96,8 @@ class HostGraph {
   int add_between_sigma(uint64_t k0, uint64_t k1, const SE3& rel, const double* sigma6);
   int add_loop_closure(const double* rel7, uint64_t i1, int r1, uint64_t i2, int r2);
   int add_relative_meas(const double* rel7, uint64_t i1, int r1, uint64_t i2, int r2);
+  int add_relative_meas_ghost(const double* rel7, uint64_t idx, int robot, int slot, bool local_first);
+  int set_ghosts(const int32_t* own_robot, const int64_t* own_idx, int n_slots);
   int add_point_landmark(uint64_t idx, const double* xyz);
   int add_range_bearing(int robot, uint64_t pose_idx, uint64_t lm_idx, const double* bearing, double range);
   int add_cube(int robot, uint64_t pose_idx, uint64_t cube_idx, const SE3& pose, const SE3& cube_world, const double* scale,
@@ -136,6 +139,8 @@ class HostGraph {
   std::vector<int> h_lm_type;
   std::vector<int> h_pr_pose; std::vector<double> h_pr_z, h_pr_sigma;
   std::vector<int> h_bt_i, h_bt_j; std::vector<double> h_bt_z, h_bt_sigma;
+  std::vector<int> h_gh_pose, h_gh_slot, h_gh_first; std::vector<double> h_gh_z, h_gh_sigma;   // ghost-between factors
+  std::vector<int> h_gslot_pose;
   std::vector<int> h_lf_type, h_lf_pose, h_lf_lm, h_lf_slot;
   std::vector<int64_t> h_lf_joff, h_lf_eoff;
   std::vector<double> h_br_z, h_cu_z, h_cu_sigma, h_cy_z;
@@ -148,6 +153,8 @@ class HostGraph {
   DevArr<int> d_lm_type;
   DevArr<int> d_pr_pose; DevArr<double> d_pr_z, d_pr_sigma, d_pr_r;
   DevArr<int> d_bt_i, d_bt_j; DevArr<double> d_bt_z, d_bt_sigma, d_bt_r, d_bt_J0;
+  DevArr<int> d_gh_pose, d_gh_slot, d_gh_first, d_gslot_pose; DevArr<double> d_gh_z, d_gh_sigma, d_gh_r, d_gh_J, d_ghost_val;
+  size_t up_gh = 0;
   DevArr<int> d_lf_type, d_lf_pose, d_lf_lm, d_lf_slot;
   DevArr<int64_t> d_lf_joff, d_lf_eoff;
   DevArr<long long> d_pose_ed;

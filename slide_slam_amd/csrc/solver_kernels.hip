@@ -118,6 +118,25 @@ __global__ __launch_bounds__(128) void k_lin_pose_factors(GraphDev G) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) G.bt_J0[36 * (size_t)b + 6 * r + c] = -Ad[6 * r + c] * w;
     }
+  } else if (t < G.n_prior + G.n_between + G.n_ghost) {
+    // Between factor whose other pose is a ghost (constant of this pass): only the local side is linearised
+    const int q = t - G.n_prior - G.n_between;
+    const SE3 XL = from12(G.pose_val + 12 * (size_t)G.gh_pose[q]);
+    const SE3 XO = from12(G.ghost_val + 12 * (size_t)G.gh_slot[q]);
+    const SE3 Z = from12(G.gh_z + 12 * (size_t)q);
+    const bool first = G.gh_first[q] != 0;
+    const SE3 h = first ? between(XL, XO) : between(XO, XL);
+    double e[6];
+    local(Z, h, e, G.chart);
+    double Ad[36];
+    adjoint(between(XO, XL), Ad);        // used when the local pose is the first key: H1 = -Ad(h^-1), h^-1 = XO^-1 XL
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const double w = 1.0 / G.gh_sigma[6 * q + r];
+      G.gh_r[6 * q + r] = e[r] * w;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) G.gh_J[36 * (size_t)q + 6 * r + c] = first ? -Ad[6 * r + c] * w : (r == c ? w : 0.0);
+    }
   }
 }
 
@@ -428,7 +447,8 @@ __global__ __launch_bounds__(256) void k_pose(GraphDev G) {
   for (int i = 0; i < 6; ++i) g[i] = 0.0;
   const int nbt = G.pose_bt_ptr[p + 1] - G.pose_bt_ptr[p];
   const int nlf = G.pose_ptr[p + 1] - G.pose_ptr[p];
-  for (int e = lane; e < G.n_prior + nbt + nlf; e += 64) {
+  const int nun = G.n_prior + G.n_ghost;       // unary pose factors (priors, ghost betweens): few, every wave scans them all
+  for (int e = lane; e < nun + nbt + nlf; e += 64) {
     if (e < G.n_prior) {
       if (G.pr_pose[e] != p) continue;
 #pragma unroll
@@ -437,8 +457,26 @@ __global__ __launch_bounds__(256) void k_pose(GraphDev G) {
         H[k * (k + 1) / 2 + k] += w * w;
         g[k] += w * G.pr_r[6 * e + k];
       }
-    } else if (e < G.n_prior + nbt) {
-      const int ent = G.pose_bt[G.pose_bt_ptr[p] + e - G.n_prior];
+    } else if (e < nun) {
+      const int q = e - G.n_prior;
+      if (G.gh_pose[q] != p) continue;
+      const double* J = G.gh_J + 36 * (size_t)q;
+      const double* r = G.gh_r + 6 * (size_t)q;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        double jr[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) jr[a] = J[6 * k + a];
+        const double rk = r[k];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          g[a] += jr[a] * rk;
+#pragma unroll
+          for (int c = 0; c <= a; ++c) H[a * (a + 1) / 2 + c] += jr[a] * jr[c];
+        }
+      }
+    } else if (e < nun + nbt) {
+      const int ent = G.pose_bt[G.pose_bt_ptr[p] + e - nun];
       const int b = ent >> 1, role = ent & 1;
       const double* r = G.bt_r + 6 * (size_t)b;
       if (role == 1) {
@@ -465,7 +503,7 @@ __global__ __launch_bounds__(256) void k_pose(GraphDev G) {
         }
       }
     } else {
-      const int f = G.pose_fids[G.pose_ptr[p] + e - G.n_prior - nbt];
+      const int f = G.pose_fids[G.pose_ptr[p] + e - nun - nbt];
       const int M = lf_rows(G.lf_type[f]);   // square landmark blocks: m == d for all three factor kinds
       const double* rec = G.jbuf + G.lf_joff[f];
       const double* Jp = rec + M;
@@ -764,6 +802,19 @@ __global__ void k_shared_unpack(GraphDev G, int what, const double* __restrict__
 }
 
 // calculateEstimate(): theta (+) delta
+// what 0: buf[12 s ..] = estimate of the local pose owning ghost slot s (zeros when another rank owns it)
+// what 1: ghost_val <- buf (after the all-reduce every slot holds its owner's pose)
+__global__ void k_ghost_exchange(GraphDev G, int what, double* __restrict__ buf) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 12 * G.n_gslots) return;
+  if (what == 0) {
+    const int p = G.gslot_pose[t / 12];
+    buf[t] = p >= 0 ? G.pose_est[12 * (size_t)p + t % 12] : 0.0;
+  } else {
+    G.ghost_val[t] = buf[t];
+  }
+}
+
 __global__ void k_estimate(GraphDev G) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < G.P) {
@@ -785,8 +836,8 @@ void launch_relin(const GraphDev& G, hipStream_t s) {
   hipLaunchKernelGGL(k_relin, dim3(blocks_for(G.P + G.L, 256)), dim3(256), 0, s, G);
 }
 void launch_linearize(const GraphDev& G, hipStream_t s) {
-  if (G.n_prior + G.n_between > 0)
-    hipLaunchKernelGGL(k_lin_pose_factors, dim3(blocks_for(G.n_prior + G.n_between, 128)), dim3(128), 0, s, G);
+  if (G.n_prior + G.n_between + G.n_ghost > 0)
+    hipLaunchKernelGGL(k_lin_pose_factors, dim3(blocks_for(G.n_prior + G.n_between + G.n_ghost, 128)), dim3(128), 0, s, G);
   if (G.n_lf > 0) hipLaunchKernelGGL(k_lin_lf, dim3(blocks_for(32LL * G.n_lf, 256)), dim3(256), 0, s, G);
 }
 void launch_landmark(const GraphDev& G, int mode, hipStream_t s) {
@@ -817,6 +868,9 @@ void launch_shared_pack(const GraphDev& G, int what, double* buf, hipStream_t s)
 }
 void launch_shared_unpack(const GraphDev& G, int what, const double* buf, hipStream_t s) {
   if (G.n_slots > 0) hipLaunchKernelGGL(k_shared_unpack, dim3(blocks_for(G.n_slots, 128)), dim3(128), 0, s, G, what, buf);
+}
+void launch_ghost_exchange(const GraphDev& G, int what, double* buf, hipStream_t s) {
+  if (G.n_gslots > 0) hipLaunchKernelGGL(k_ghost_exchange, dim3(blocks_for(12LL * G.n_gslots, 128)), dim3(128), 0, s, G, what, buf);
 }
 void launch_estimate(const GraphDev& G, hipStream_t s) {
   if (G.P + G.L == 0) return;

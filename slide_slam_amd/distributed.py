@@ -13,7 +13,12 @@ just their normal-equation blocks:
     phase 2 (local)   landmark back-substitution with the global t_l, retract
 
 i.e. block-Jacobi over robots on the reduced pose system with the exact gradient; its fixed point is the joint
-optimum the reference's replica converges to.  (Inter-robot relative-pose factors are not sharded yet.)
+optimum the reference's replica converges to.
+
+Inter-robot relative-pose factors (addRelativeMeasFactor, graph.cpp:247-258) couple poses of two ranks: each of the two
+ranks holds the factor with its own pose as the variable and the other pose as a *ghost* — a constant refreshed at the
+start of every pass (phase 20: pack the owned ghost poses' estimates, all-reduce(sum) of 12 doubles per ghost slot,
+phase 21: adopt).  Same block-Jacobi argument: the cross block J_a^T J_b is dropped from the step, the gradient is exact.
 
 `shard` is any object with ``landmark_table(cls)``, ``graph.set_shared``, ``graph.dist_phase`` — the product's
 ``SlideBackend`` on a GPU, or (tests only) the oracle wrapper; `comm` moves the exchange buffer.
@@ -106,11 +111,32 @@ class DistributedGraph:
         self._phase(11)
         return dict(n_slots=self.n_slots, n_global=n_global)
 
+    def setup_ghosts(self, relmeas, local_robot=0):
+        """relmeas: the job's inter-robot measurements [(pose index k, robot a, robot b, rel7 a->b)], identical on every
+        rank.  Ghost slots = the sorted (robot, k) pairs they touch; this rank adds the factors that involve its robot."""
+        keys = sorted({(a, k) for (k, a, b, _) in relmeas} | {(b, k) for (k, a, b, _) in relmeas})
+        slot = {key: i for i, key in enumerate(keys)}
+        self.n_gslots = len(keys)
+        own_robot = np.array([local_robot if r == self.rank else -1 for (r, _) in keys], np.int32)
+        own_idx = np.array([k for (_, k) in keys], np.int64)
+        self.shard.graph.set_ghosts(own_robot, own_idx)
+        for (k, a, b, rel) in relmeas:
+            if a == self.rank:
+                self.shard.graph.add_relative_meas_ghost(rel, k, local_robot, slot[(b, k)], True)
+            if b == self.rank:
+                self.shard.graph.add_relative_meas_ghost(rel, k, local_robot, slot[(a, k)], False)
+        self.gbuf = self.comm.alloc(max(self.n_gslots, 1) * 12)
+        return self.n_gslots
+
     def _phase(self, ph):
         self.shard.graph.dist_phase(ph, self.comm.handle(self.buf))
 
     def gauss_newton(self, iterations=1):
         for _ in range(iterations):
+            if getattr(self, "n_gslots", 0):
+                self.shard.graph.dist_phase(20, self.comm.handle(self.gbuf))
+                self.comm.all_reduce(self.gbuf, self.n_gslots * 12)
+                self.shard.graph.dist_phase(21, self.comm.handle(self.gbuf))
             self._phase(0)
             self.comm.all_reduce(self.buf, self.n_slots * 54)
             self._phase(1)

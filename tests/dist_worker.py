@@ -65,13 +65,19 @@ def main():
     replay_single(shard, log, robot=0, collect=False)
     dg = DistributedGraph(shard, comm, rank, world)
     info = dg.setup(matcher)
+    if len(sys.argv) > 5 and sys.argv[5] == "relmeas":
+        # inter-robot relative-pose measurements of the job (every rank regenerates the same seeded list)
+        from slide_slam_amd.synth import make_relmeas
+        logs = [make_robot_log(cfg, world_map, r) for r in range(world)]
+        info["n_gslots"] = dg.setup_ghosts(make_relmeas(cfg, logs))
     dg.gauss_newton(iters)
     P = len(log["rel7"])
     poses = np.array([shard.graph.get_pose12(0, k)[1] for k in range(P)])
     gathered = [None] * world
-    dist.all_gather_object(gathered, (poses, info["n_slots"], info["n_global"]))
+    dist.all_gather_object(gathered, (poses, info["n_slots"], info["n_global"], info.get("n_gslots", 0)))
     if rank == 0:
-        np.savez(out_path, poses=np.array([g[0] for g in gathered]), n_slots=gathered[0][1], n_global=np.array(gathered[0][2]))
+        np.savez(out_path, poses=np.array([g[0] for g in gathered]), n_slots=gathered[0][1], n_global=np.array(gathered[0][2]),
+                 n_gslots=gathered[0][3])
     dist.barrier()
     dist.destroy_process_group()
 

@@ -22,22 +22,28 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_workers(backend, preset, iters, out, world=2):
+def _run_workers(backend, preset, iters, out, world=2, extra=()):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), backend, preset, str(iters), out]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), backend, preset, str(iters), out,
+           *extra]
     env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return np.load(out)
 
 
-def _joint_optimum(preset, gn_iters=25):
+def _joint_optimum(preset, gn_iters=25, relmeas=False):
     """One host replica holding both robots (replay_multi = sloamNode.cpp:912-1002 order), then batch GN."""
     cfg = SynthConfig.preset(preset)
     data = make_dataset(cfg)
-    data["relmeas"] = []        # inter-robot relative-pose factors are not sharded yet (distributed.py)
+    rel = data["relmeas"]
+    data["relmeas"] = []        # streaming without them: the shards associate without them too (same factor graph)
     ob = po.OracleBackend(po.OrcParams.default(), cfg.robots)
     replay_multi(ob, data, own_node_factory=lambda: po.OracleBackend(po.OrcParams.default(), 1))
+    if relmeas:
+        assert len(rel) > 0
+        for (k, a, b, r7) in rel:
+            ob.graph.add_relative_meas(r7, k, a, k, b)     # ordinary Between factors of the joint replica
     ob.graph.set_relin_threshold(0.0)
     for _ in range(gn_iters):
         assert ob.graph.solve() == 0
@@ -70,4 +76,23 @@ def test_distributed_gn_gpu_shards(tmp_path, gpu):
     host stands in for RCCL, which needs one GPU per rank)."""
     joint, counts = _joint_optimum("C3tiny")
     z = _run_workers("gpu", "C3tiny", 60, str(tmp_path / "g.npz"))
+    _check(z, joint, counts, 1e-4)
+
+
+def test_distributed_relmeas_oracle_shards_gloo(tmp_path):
+    """CPU: inter-robot relative-pose factors sharded with ghost poses (one extra all-reduce of 12 doubles per ghost slot
+    per pass) reach the optimum of the joint replica that holds them as ordinary Between factors."""
+    joint, counts = _joint_optimum("C3rel", relmeas=True)
+    plain, _ = _joint_optimum("C3rel", relmeas=False)
+    assert np.abs(joint - plain).max() > 1e-6            # the factors do move the optimum: the test has teeth
+    z = _run_workers("oracle", "C3rel", 120, str(tmp_path / "or.npz"), extra=("relmeas",))
+    assert int(z["n_gslots"]) > 0
+    _check(z, joint, counts, 1e-5)
+
+
+@pytest.mark.gpu
+def test_distributed_relmeas_gpu_shards(tmp_path, gpu):
+    joint, counts = _joint_optimum("C3rel", relmeas=True)
+    z = _run_workers("gpu", "C3rel", 120, str(tmp_path / "gr.npz"), extra=("relmeas",))
+    assert int(z["n_gslots"]) > 0
     _check(z, joint, counts, 1e-4)
