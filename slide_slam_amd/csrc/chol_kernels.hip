@@ -517,12 +517,15 @@ __device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int 
 // indices from ctr[k] until they run out, so the ~T-k long type-A chains and the flood balance by themselves at the one
 // workgroup per CU the register-heavy kernel gets.  ctr[k+1] is cleared here for the next launch (ctr[0..1] start at 0).
 __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Ld,
-                                                   double* __restrict__ Winv, int* status, int* __restrict__ ctr, int nGroups) {
+                                                   double* __restrict__ Winv, int* status, int* __restrict__ ctr, int nGroups, int a_joins) {
   __shared__ ALds L;
   __shared__ int s_g;
   const int nA = T - k;
   if (blockIdx.x == 0 && threadIdx.x == 0) ctr[k + 1] = 0;
-  if ((int)blockIdx.x < nA) step_type_a(S, ld, k, (int)blockIdx.x, Ld, Winv, status, L);
+  if ((int)blockIdx.x < nA) {
+    step_type_a(S, ld, k, (int)blockIdx.x, Ld, Winv, status, L);
+    if (!a_joins) return;        // the queue workers are through before the chain is: an item taken now would only add a tail
+  }
   if (nGroups <= 0) return;
   for (;;) {
     __syncthreads();
@@ -709,7 +712,10 @@ void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv,
     if (n_cu <= 0) n_cu = 256;
   }
   const long long extra = nB < n_cu ? nB : n_cu;                // queue workers beside the type-A workgroups (one 512-thread workgroup per CU)
-  hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nA + extra)), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status, ctr, (int)nB);
+  // type-A workgroups join the queue only when the flood needs more than two rounds of the other CUs (~ the chain's length)
+  const long long free_cu = n_cu - nA > 8 ? n_cu - nA : 8;
+  const int a_joins = nB > 2 * free_cu ? 1 : 0;
+  hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nA + extra)), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status, ctr, (int)nB, a_joins);
 }
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, hipStream_t s) {
   hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv);
