@@ -286,6 +286,18 @@ int slide_semantic_clipper(const double* tri_model, int ntm, const double* tri_d
                            int min_num_pairs, double matching_threshold, const double* u0, int n_u0, double tf16[16],
                            int counts[2], int32_t* inliers_out, int cap_inliers, int* found);
 
+/* 2-D Delaunay triangulation (replaces the qhull call of DelaunayTriangulation::Observation, triangulation/observation.cpp:13-88,
+ * options "Qt Qbb Qc Qz Q12 d").  Host code (sweep-hull + Lawson flips, long double predicates).  tri_out: vertex-index triples,
+ * ascending inside a triangle, triangles in lexicographic order — the same triangle SET as qhull for points in general position;
+ * the list order (qhull: facet order) only permutes SlideGraph's putative association list.  At most cap triangles are written. */
+int slide_delaunay_2d(const double* xy, int n, int32_t* tri_out, int cap, int* n_tri);
+/* semantic_clipper::run_semantic_clipper semantic_clipper.cpp:140-274 from the two object maps on (rows [label, x, y, z, d1, d2,
+ * d3]; only x, y are used there): Delaunay of both, then slide_semantic_clipper.  sigma / epsilon: the EuclideanDistance
+ * invariant's parameters as passed by the reference's caller. */
+int slide_run_semantic_clipper(const double* ref7, int nr, const double* qry7, int nq, double sigma, double epsilon,
+                               int min_num_pairs, double matching_threshold, const double* u0, int n_u0, double tf16[16],
+                               int counts[2], int* found);
+
 /* sloam::FindRelativeMeasurementMatch / GetIndexClosestPoseMstPair (src/core/sloam.cpp:321-440).
  * Stamps are (sec, nsec) pairs.  Host-side logic (tiny, sequential): no kernel. */
 int slide_closest_stamp(const int64_t* sec, const int64_t* nsec, int n, int64_t qsec, int64_t qnsec, int* idx, double* diff);

@@ -35,7 +35,7 @@ EXPORTS = [
     "slide_backend_end_frame", "slide_backend_graph", "slide_backend_counts", "slide_backend_map_model",
     "slide_place_default_params", "slide_match_maps", "slide_find_inter_loop_closure", "slide_clipper_affinity",
     "slide_closest_stamp", "slide_clipper_default_params", "slide_clipper_dense_clique", "slide_match_triangles",
-    "slide_estimate_tf2d", "slide_semantic_clipper", "slide_find_relative_meas_match",
+    "slide_estimate_tf2d", "slide_semantic_clipper", "slide_find_relative_meas_match", "slide_delaunay_2d", "slide_run_semantic_clipper",
 ]
 
 
@@ -495,3 +495,28 @@ def find_relative_meas_match(packets, counters, host, pending):
     _check(lib().slide_find_relative_meas_match(C.c_int(len(packets)), _p(sec), _p(ns), _p(off), _p(pc), C.c_int(host), C.byref(npend),
                                                 _p(m_sec), _p(m_ns), _p(m_rob), _p(m_odo), _p(m_tag), _p(out), C.byref(nm)))
     return out.reshape(-1, 4)[:nm.value].copy(), m_tag[:npend.value].copy()
+
+
+def delaunay_2d(points_xy):
+    """Triangle index triples (ascending ids, lexicographic order) of the 2-D Delaunay triangulation (host code)."""
+    xy = _d(points_xy)
+    n = len(xy)
+    cap = max(2 * n, 1)
+    tri = np.zeros((cap, 3), np.int32)
+    nt = C.c_int(0)
+    _check(lib().slide_delaunay_2d(_p(xy), C.c_int(n), _p(tri), C.c_int(cap), C.byref(nt)))
+    return tri[:nt.value].copy()
+
+
+def run_semantic_clipper(ref7, qry7, sigma=0.01, epsilon=0.06, min_num_pairs=4, matching_threshold=0.1, u0=None):
+    """semantic_clipper::run_semantic_clipper (semantic_clipper.cpp:140-274) on two object maps (rows [label, x, y, z, d1, d2, d3])."""
+    r, q = _d(ref7), _d(qry7)
+    tf = np.zeros(16)
+    counts = np.zeros(2, np.int32)
+    found = C.c_int(0)
+    u0a = _d(u0) if u0 is not None else None
+    _check(lib().slide_run_semantic_clipper(_p(r), C.c_int(len(r)), _p(q), C.c_int(len(q)), C.c_double(sigma), C.c_double(epsilon),
+                                            C.c_int(min_num_pairs), C.c_double(matching_threshold),
+                                            _p(u0a) if u0a is not None else None, C.c_int(len(u0a) if u0a is not None else 0),
+                                            _p(tf), _p(counts), C.byref(found)))
+    return dict(found=bool(found.value), tf=tf.reshape(4, 4), n_putative=int(counts[0]), n_inliers=int(counts[1]))

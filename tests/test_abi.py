@@ -99,3 +99,19 @@ def test_find_relative_meas_match_host_logic():
         m, left = f(packets, counters, 0, pending)
         n, mo, nleft = _find(packets, counters, 0, pending)
         assert n == len(m) and np.array_equal(mo, m) and nleft == len(left)
+
+
+def test_delaunay_equals_qhull():
+    """the triangle SET equals qhull's (scipy wraps qhull; the reference's options, observation.cpp:25-26)."""
+    from scipy.spatial import Delaunay
+    for seed in range(12):
+        rng = np.random.default_rng(seed)
+        n = int(rng.integers(3, 600))
+        pts = rng.uniform(-80, 80, (n, 2))
+        if seed % 4 == 0:
+            pts = np.round(pts) + rng.normal(0, 1e-3, (n, 2))      # near-lattice: long thin triangles, near-cocircular quadruples
+        mine = [tuple(t) for t in s.delaunay_2d(pts)]
+        ref = sorted(tuple(sorted(int(v) for v in simplex)) for simplex in Delaunay(pts, qhull_options="Qt Qbb Qc Qz Q12").simplices)
+        assert mine == ref
+    assert len(s.delaunay_2d(np.zeros((2, 2)))) == 0
+    assert len(s.delaunay_2d(np.array([[0.0, 0], [1, 1], [2, 2], [3, 3]]))) == 0     # collinear

@@ -243,3 +243,24 @@ def test_estimate_tf2d(gpu):
     b = a @ R.T + np.array([1.5, -2.0])
     tf = gpu.estimate_tf2d(a, b)
     assert np.abs(tf[:2, :2] - R).max() < 1e-12 and np.abs(tf[:2, 2] - [1.5, -2.0]).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_run_semantic_clipper_from_maps(gpu):
+    """The whole SlideGraph call (semantic_clipper.cpp:140-274) from two object maps: own Delaunay + GPU matching + CLIPPER."""
+    found = 0
+    for seed in range(4):
+        rng = np.random.default_rng(200 + seed)
+        n, nq = 45, 28
+        ref = np.zeros((n, 7)); ref[:, 0] = 1; ref[:, 1:3] = rng.uniform(-30, 30, (n, 2))
+        yaw = rng.uniform(-np.pi, np.pi)
+        R = np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]])
+        t = rng.uniform(-5, 5, 2)
+        sel = rng.permutation(n)[:nq]
+        qry = np.zeros((nq, 7)); qry[:, 0] = 1
+        qry[:, 1:3] = (ref[sel, 1:3] - t) @ R + rng.normal(0, 0.01, (nq, 2))
+        r = gpu.run_semantic_clipper(ref, qry, sigma=0.05, epsilon=0.15, min_num_pairs=4, matching_threshold=0.1)
+        if r["found"]:
+            found += 1
+            assert np.abs(r["tf"][:2, :2] - R.T).max() < 0.02 and np.abs(r["tf"][:2, 3] - (-R.T @ t)).max() < 0.3
+    assert found >= 3
