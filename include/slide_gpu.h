@@ -104,6 +104,10 @@ int slide_graph_get_all_poses(slide_graph_t* g, int robot, double* out7N, uint64
 /* cls = SLIDE_CLS_*: cylinder -> 7 (root, ray, radius), cube -> 15 (R, t, scale), ellipsoid/point -> 3.
  * getCylinder / getCube / getCentroidLandmark graph.cpp:274-288 (absent key: zeros + SLIDE_MISSING). */
 int slide_graph_get_landmark(slide_graph_t* g, int cls, uint64_t idx, double* out);
+/* getPoseCovariance graph.cpp:314-323 (isam->marginalCovariance(X(idx))): 6x6 row-major, tangent order [rot, trans], at the
+ * linearisation point of the last solve (a forward substitution with six right-hand sides on the resident Cholesky factor).
+ * SLIDE_MISSING for an unknown pose, SLIDE_ERR_INVALID before the first solve. */
+int slide_graph_get_pose_covariance(slide_graph_t* g, int robot, uint64_t idx, double cov36[36]);
 /* counts: [poses, landmarks, factors, relinearised vars in the last solve, chol dim] */
 int slide_graph_stats(slide_graph_t* g, int64_t out5[5]);
 /* Per-kernel device timings (HIP events on the launch stream) of the solves since the last reset.

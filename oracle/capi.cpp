@@ -181,6 +181,10 @@ int orc_graph_set_shared(void* h, const int* cls, const int64_t* idx, const int*
   return ((Graph*)h)->set_shared(cls, idx, owner, n);
 }
 int orc_graph_dist_phase(void* h, int phase, double* buf) { return ((Graph*)h)->dist_phase(phase, buf); }
+void orc_graph_keep_factor(void* h, int on) { ((Graph*)h)->keep_factor = on != 0; }
+int orc_graph_pose_covariance(void* h, int robot, uint64_t idx, double* cov36) {
+  return ((Graph*)h)->pose_covariance(Graph::pose_key(robot, idx), cov36);
+}
 int orc_graph_set_ghosts(void* h, const int* own_robot, const int64_t* own_idx, int n) { return ((Graph*)h)->set_ghosts(own_robot, own_idx, n); }
 void orc_graph_add_relative_meas_ghost(void* h, const double* rel7, uint64_t idx, int robot, int slot, int local_first) {
   ((Graph*)h)->addRelativeMeasGhost(pose_from7(rel7), idx, robot, slot, local_first != 0);

@@ -561,6 +561,32 @@ class Graph {
     std::vector<double> Hinv_all, dp;
     std::vector<std::vector<double>> Eall;
   } D;
+  // graph.cpp:314-323  isam->marginalCovariance(X(idx)): the (pose, pose) block of the inverse information matrix at the
+  // current linearisation = the pose's block of S^-1 (S = landmark-eliminated pose system) = Y^T Y with L Y = E_pose.
+  bool keep_factor = false;
+  std::vector<double> last_L;
+  std::vector<int> last_pidx;
+  int last_n = 0;
+  int pose_covariance(uint64_t key, double* cov36) const {
+    auto it = key2var.find(key);
+    if (it == key2var.end() || last_n == 0 || (size_t)it->second >= last_pidx.size() || last_pidx[it->second] < 0) return 1;
+    const int n = last_n, p0 = 6 * last_pidx[it->second];
+    std::vector<double> Y((size_t)n * 6, 0.0);              // Y[row * 6 + c]
+    for (int c = 0; c < 6; ++c) {
+      for (int i = p0; i < n; ++i) {
+        double s = (i == p0 + c) ? 1.0 : 0.0;
+        for (int k = p0; k < i; ++k) s -= last_L[(size_t)i * n + k] * Y[(size_t)k * 6 + c];
+        Y[(size_t)i * 6 + c] = s / last_L[(size_t)i * n + i];
+      }
+    }
+    for (int a = 0; a < 6; ++a)
+      for (int b = 0; b < 6; ++b) {
+        double s = 0.0;
+        for (int i = p0; i < n; ++i) s += Y[(size_t)i * 6 + a] * Y[(size_t)i * 6 + b];
+        cov36[6 * a + b] = s;
+      }
+    return 0;
+  }
   void merge_pending();
   int set_shared(const int* cls, const int64_t* idx, const int* owner, int n);
   int dist_phase(int phase, double* buf);
@@ -772,6 +798,7 @@ inline int Graph::solve() {
   for (int i = 0; i < n; ++i) dp[i] = -g[i];
   chol_solve_lower(S.data(), n, n, dp.data());
   const double t3 = now_sec();
+  if (keep_factor) { last_L = S; last_n = n; last_pidx = pidx; }   // for getPoseCovariance (test sizes only: n^2 doubles)
   for (int p = 0; p < np; ++p)
     for (int k = 0; k < 6; ++k) vars[pose_vars[p]].delta[k] = dp[6 * p + k];
   for (int l = 0; l < nl; ++l) {

@@ -166,6 +166,15 @@ class OracleGraph:
             raise RuntimeError(f"oracle dist_phase {phase} failed: {rc}")
         return rc
 
+    def keep_factor(self, on=True):
+        self.L.orc_graph_keep_factor(self.h, C.c_int(int(on)))
+
+    def pose_covariance(self, robot, idx):
+        """getPoseCovariance (graph.cpp:314-323) at the linearisation point of the last solve()."""
+        out = np.zeros(36)
+        st = self.L.orc_graph_pose_covariance(self.h, C.c_int(robot), C.c_uint64(idx), _p(out))
+        return st, out.reshape(6, 6)
+
     def set_ghosts(self, own_robot, own_idx):
         r = _i(own_robot)
         i = np.ascontiguousarray(own_idx, dtype=np.int64)

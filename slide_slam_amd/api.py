@@ -28,7 +28,7 @@ EXPORTS = [
     "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
     "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
-    "slide_graph_get_landmark", "slide_graph_stats", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
+    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
     "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
     "slide_dense_spd_solve", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
@@ -215,6 +215,14 @@ class SlideGraph:
         cls, owner = _i(cls), _i(owner)
         idx = np.ascontiguousarray(idx, dtype=np.int64)
         _check(self.L.slide_graph_set_shared(self.h, _p(cls), _p(idx), _p(owner), C.c_int(len(cls))))
+
+    def get_pose_covariance(self, robot, idx):
+        """getPoseCovariance (graph.cpp:314-323).  Returns (status, 6x6)."""
+        out = np.zeros(36)
+        st = self.L.slide_graph_get_pose_covariance(self.h, C.c_int(robot), C.c_uint64(idx), _p(out))
+        if st < 0:
+            _check(st)
+        return st, out.reshape(6, 6)
 
     def set_ghosts(self, own_robot, own_idx):
         r = _i(own_robot)

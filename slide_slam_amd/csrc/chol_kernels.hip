@@ -677,6 +677,84 @@ __global__ __launch_bounds__(256) void k_chol_bwd(const double* __restrict__ S, 
   }
 }
 
+// ---- marginal covariance of one pose (getPoseCovariance graph.cpp:314-323) ---------------------------------------------------
+// Cov = E^T S^-1 E = Y^T Y with L Y = E (E = the six unit columns of the pose): a forward substitution with six right-hand
+// sides on the finished factor (panel tiles in S, diagonal blocks as their off-diagonal 16x16 sub-tiles in Ld plus the 16x16
+// inverses in Winv), one launch per block row k from the pose's block on: every workgroup redoes the 64 x 6 solve of block
+// k, workgroup 0 stores it, workgroup b > 0 applies tile (k + b, k) to its own rows of Y.   Y: 6 columns of nT = T * 64 rows.
+__global__ __launch_bounds__(256) void k_cov_fwd(const double* __restrict__ S, int ld, int k, const double* __restrict__ Ldk,
+                                                 const double* __restrict__ Wk, double* __restrict__ Y, int nT) {
+  __shared__ double yk[6][NB];
+  __shared__ double xk[6][NB];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 6 * NB; e += 256) yk[e / NB][e % NB] = Y[(size_t)(e / NB) * nT + (size_t)k * NB + e % NB];
+  __syncthreads();
+  const int c = tid >> 4, r = tid & 15;            // column c < 6 of the right-hand sides, row r of a 16-block
+#pragma unroll 1
+  for (int b = 0; b < 4; ++b) {
+    if (c < 6) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s += Wk[(size_t)b * 256 + j * 16 + r] * yk[c][16 * b + j];     // (L_bb^-1)[r][j]
+      xk[c][16 * b + r] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < 6 * 16 * (3 - b); e += 256) {      // rows below block b: y[m] -= sum_n L[m][16b + n] x_b[n]
+      const int cc = e / (16 * (3 - b)), m = 16 * (b + 1) + e % (16 * (3 - b));
+      double s = 0.0;
+#pragma unroll
+      for (int n = 0; n < 16; ++n) s += Ldk[(size_t)(16 * b + n) * NB + m] * xk[cc][16 * b + n];
+      yk[cc][m] -= s;
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {
+    for (int e = tid; e < 6 * NB; e += 256) Y[(size_t)(e / NB) * nT + (size_t)k * NB + e % NB] = xk[e / NB][e % NB];
+    return;
+  }
+  const int i = k + (int)blockIdx.x;               // row tile below
+  const double* tile = S + (size_t)(k * NB) * ld + (size_t)i * NB;
+  for (int e = tid; e < 6 * NB; e += 256) {
+    const int cc = e / NB, row = e % NB;
+    double s = 0.0;
+#pragma unroll 8
+    for (int q = 0; q < NB; ++q) s += tile[(size_t)q * ld + row] * xk[cc][q];
+    Y[(size_t)cc * nT + (size_t)i * NB + row] -= s;
+  }
+}
+__global__ __launch_bounds__(256) void k_cov_gram(const double* __restrict__ Y, int nT, int row0, double* __restrict__ cov36) {
+  __shared__ double part[36][257];
+  const int tid = threadIdx.x;
+  double acc[36];
+#pragma unroll
+  for (int e = 0; e < 36; ++e) acc[e] = 0.0;
+  for (int row = row0 + tid; row < nT; row += 256) {
+    double y[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) y[c] = Y[(size_t)c * nT + row];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) acc[6 * a + b] += y[a] * y[b];
+  }
+#pragma unroll
+  for (int e = 0; e < 36; ++e) part[e][tid] = acc[e];
+  __syncthreads();
+  if (tid < 36) {
+    double s = 0.0;
+    for (int q = 0; q < 256; ++q) s += part[tid][q];
+    cov36[tid] = s;
+  }
+}
+// Y (6 * T * NB doubles) must hold the six unit columns of rows row0 .. row0 + 5 (zero elsewhere); cov36 device
+void launch_pose_covariance(const double* S, int ld, int T, const double* Ld, const double* Winv, double* Y, int row0, double* cov36,
+                            hipStream_t s) {
+  const int nT = T * NB;
+  for (int k = row0 / NB; k < T; ++k)
+    hipLaunchKernelGGL(k_cov_fwd, dim3((unsigned)(T - k)), dim3(256), 0, s, S, ld, k, Ld + (size_t)k * NB * NB, Winv + (size_t)k * 1024, Y, nT);
+  hipLaunchKernelGGL(k_cov_gram, dim3(1), dim3(256), 0, s, Y, nT, row0 / NB * NB, cov36);
+}
+
 // ------------------------------------------------------------------------------------------------
 void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, hipStream_t s) {
   const long long nA = T - k;                                   // column-k tiles below the diagonal (+ RHS tile)

@@ -534,10 +534,12 @@ int HostGraph::run_update(double relin_thr, int iterations) {
   SL_HIP(hipGetLastError());
   if (prof.on) prof.collect();
   last_relin = st[2];
+  factor_valid = false;
   if (st[0] || st[1]) {
     g_last_error = st[0] ? "landmark block not positive definite" : "reduced pose system not positive definite";
     return SLIDE_ERR_NOT_SPD;
   }
+  factor_valid = true;
   return SLIDE_OK;
 }
 
@@ -672,6 +674,27 @@ int HostGraph::dist_phase(int phase, double* d_buf) {
   } else {
     return SLIDE_ERR_INVALID;
   }
+  SL_HIP(hipStreamSynchronize(s));
+  SL_HIP(hipGetLastError());
+  return SLIDE_OK;
+}
+
+// getPoseCovariance graph.cpp:314-323: marginal covariance of one pose at the linearisation point of the last solve
+int HostGraph::pose_covariance(int robot, uint64_t idx, double* cov36) {
+  if (!robot_ok(robot)) return SLIDE_ERR_INVALID;
+  auto it = key2pose.find(pose_key(robot, idx));
+  if (it == key2pose.end() || (size_t)it->second >= up_P) return SLIDE_MISSING;
+  if (!factor_valid || G.T == 0) { g_last_error = "pose_covariance: no factorisation yet (call solve first)"; return SLIDE_ERR_INVALID; }
+  hipStream_t s = stream;
+  const size_t nT = (size_t)G.T * NB;
+  if (d_covY.ensure(6 * nT + 36, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  SL_HIP(hipMemsetAsync(d_covY.d, 0, (6 * nT + 36) * sizeof(double), s));
+  const int row0 = 6 * it->second;
+  const double one = 1.0;
+  for (int c = 0; c < 6; ++c)
+    SL_HIP(hipMemcpyAsync(d_covY.d + (size_t)c * nT + row0 + c, &one, sizeof(double), hipMemcpyHostToDevice, s));
+  launch_pose_covariance(G.S, G.ld, G.T, G.Ld, G.Winv, d_covY.d, row0, d_covY.d + 6 * nT, s);
+  SL_HIP(hipMemcpyAsync(cov36, d_covY.d + 6 * nT, 36 * sizeof(double), hipMemcpyDeviceToHost, s));
   SL_HIP(hipStreamSynchronize(s));
   SL_HIP(hipGetLastError());
   return SLIDE_OK;

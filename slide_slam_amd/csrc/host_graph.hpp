@@ -98,6 +98,7 @@ class HostGraph {
   int add_relative_meas(const double* rel7, uint64_t i1, int r1, uint64_t i2, int r2);
   int add_relative_meas_ghost(const double* rel7, uint64_t idx, int robot, int slot, bool local_first);
   int set_ghosts(const int32_t* own_robot, const int64_t* own_idx, int n_slots);
+  int pose_covariance(int robot, uint64_t idx, double* cov36);
   int add_point_landmark(uint64_t idx, const double* xyz);
   int add_range_bearing(int robot, uint64_t pose_idx, uint64_t lm_idx, const double* bearing, double range);
   int add_cube(int robot, uint64_t pose_idx, uint64_t cube_idx, const SE3& pose, const SE3& cube_world, const double* scale,
@@ -165,6 +166,8 @@ class HostGraph {
   std::vector<int> h_sh_lid, h_sh_owner;
   DevArr<double> d_S, d_Ld, d_Winv, d_yv, d_dp;
   DevArr<int> d_cctr;
+  DevArr<double> d_covY;
+  bool factor_valid = false;            // S / Ld / Winv hold the factor of the system of the last solve
   DevArr<int> d_status;
   int Tcap = 0;
   // hipGraph of one pass, captured when the same resident graph is solved repeatedly (kernel arguments are

@@ -26,6 +26,9 @@ void launch_ghost_exchange(const GraphDev& G, int what, double* buf, hipStream_t
 void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, hipStream_t s);
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, hipStream_t s);
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp, hipStream_t s);
+// marginal covariance of the pose whose first tangent row is row0 (Y: 6 * T * NB scratch doubles holding the six unit columns)
+void launch_pose_covariance(const double* S, int ld, int T, const double* Ld, const double* Winv, double* Y, int row0, double* cov36,
+                            hipStream_t s);
 // stand-alone dense SPD solve on device buffers (used by the unit tests and the roofline bench leg)
 int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double* yv, double* dp, int* status, int* ctr, hipStream_t s);
 

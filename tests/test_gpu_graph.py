@@ -129,3 +129,28 @@ def test_replay_two_robots_one_host(gpu):
             _, pa = ob.graph.get_pose12(r, k)
             _, pb = gb.graph.get_pose12(r, k)
             assert _rel_err(pb, pa) < REL_TOL
+
+
+@pytest.mark.gpu
+def test_pose_covariance_matches_oracle(gpu):
+    """getPoseCovariance (graph.cpp:314-323) = the pose's block of the inverse reduced system, from the
+    resident Cholesky factor; oracle = the same block from its dense factor."""
+    from slide_slam_amd.replay import replay_single
+    from slide_slam_amd.synth import SynthConfig, make_robot_log, make_world
+    cfg = SynthConfig.preset("small")
+    log = make_robot_log(cfg, make_world(cfg), 0)
+    nfr = 60
+    gb = gpu.SlideBackend(gpu.default_params(), 1)
+    ob = po.OracleBackend(po.OrcParams.default(), 1)
+    ob.graph.keep_factor(True)
+    replay_single(gb, log, robot=0, n_frames=nfr, collect=False)
+    replay_single(ob, log, robot=0, n_frames=nfr, collect=False)
+    assert gb.graph.solve() == 0 and ob.graph.solve() == 0
+    for idx in (0, 1, 17, nfr // 2, nfr - 1):
+        st, cg = gb.graph.get_pose_covariance(0, idx)
+        so, co = ob.graph.pose_covariance(0, idx)
+        assert st == 0 and so == 0
+        assert np.abs(cg - cg.T).max() < 1e-12 * np.abs(cg).max()
+        assert np.abs(cg - co).max() < 1e-7 * np.abs(co).max(), (idx, np.abs(cg - co).max(), np.abs(co).max())
+    st, _ = gb.graph.get_pose_covariance(0, 10 ** 6)
+    assert st == 1          # SLIDE_MISSING
