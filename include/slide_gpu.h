@@ -290,6 +290,21 @@ int slide_semantic_clipper(const double* tri_model, int ntm, const double* tri_d
                            int min_num_pairs, double matching_threshold, const double* u0, int n_u0, double tf16[16],
                            int counts[2], int32_t* inliers_out, int cap_inliers, int* found);
 
+/* Input::PickNextMeasurementToAdd backend/sloam/src/core/input.cpp:26-108 (chronological measurement picker + key-frame
+ * distance gate; pinned by src/test/input_test.cpp).  Queues are flat arrays with the front at index 0; stamps are (sec, nsec).
+ * out4 = {meas_to_add (0 none, 1 odometry, 2 observation, 3 relative measurement), entries the reference pops from the front
+ * of the odometry / observation / relative-measurement queue}.  Host bookkeeping, no kernel. */
+int slide_pick_next_measurement(const int64_t* odom_sec, const int64_t* odom_nsec, const double* odom_pose7, int n_odom,
+                                const int64_t* obs_sec, const int64_t* obs_nsec, int n_obs, const int64_t* rel_sec,
+                                const int64_t* rel_nsec, int n_rel, int64_t latest_sec, int64_t latest_nsec,
+                                const double latest_pose7[7], double current_time, double msg_delay_tolerance,
+                                float min_odom_distance, int out4[4]);
+/* CylinderMapManager::InLoopClosureRegion cylinderMapManager.cpp:115-160: is any key pose older than
+ * at_least_num_of_poses_old within (max_dist_xy, max_dist_z) of the pose?  cloud: float32 xyz of the key poses
+ * (robotPoseCloud_).  *inside = 0 / 1.  Host bookkeeping (a few thousand points per call). */
+int slide_in_loop_closure_region(const float* cloud_xyz, int n, const double pose_xyz[3], double max_dist_xy, double max_dist_z,
+                                 uint64_t at_least_num_of_poses_old, int* inside);
+
 /* 2-D Delaunay triangulation (replaces the qhull call of DelaunayTriangulation::Observation, triangulation/observation.cpp:13-88,
  * options "Qt Qbb Qc Qz Q12 d").  Host code (sweep-hull + Lawson flips, long double predicates).  tri_out: vertex-index triples,
  * ascending inside a triangle, triangles in lexicographic order — the same triangle SET as qhull for points in general position;

@@ -6,6 +6,7 @@
 #include "backend.hpp"
 #include "clipper.hpp"
 #include "slidegraph.hpp"
+#include "input.hpp"
 #include "place.hpp"
 #include "relmeas.hpp"
 
@@ -388,6 +389,24 @@ int orc_semantic_clipper(const double* tm, int ntm, const double* td, int ntd, c
   counts[1] = o.n_inliers;
   if (inliers_out) for (size_t i = 0; i < o.inliers.size(); ++i) inliers_out[i] = o.inliers[i];
   return o.ok ? 1 : 0;
+}
+
+// ---- key-frame gating (N3) -----------------------------------------------------------------------
+void orc_pick_next_measurement(const int64_t* odom_sec, const int64_t* odom_nsec, const double* odom_pose7, int n_odom,
+                               const int64_t* obs_sec, const int64_t* obs_nsec, int n_obs, const int64_t* rel_sec,
+                               const int64_t* rel_nsec, int n_rel, int64_t latest_sec, int64_t latest_nsec,
+                               const double* latest7, double current_time, double msg_delay_tolerance, float min_odom_distance,
+                               int* out4) {
+  std::vector<double> p12(12 * (size_t)std::max(n_odom, 1));
+  for (int i = 0; i < n_odom; ++i) pose_to12(pose_from7(odom_pose7 + 7 * (size_t)i), p12.data() + 12 * (size_t)i);
+  double l12[12];
+  pose_to12(pose_from7(latest7), l12);
+  const PickResult r = pick_next_measurement(odom_sec, odom_nsec, p12.data(), n_odom, obs_sec, obs_nsec, n_obs, rel_sec, rel_nsec, n_rel,
+                                             latest_sec, latest_nsec, l12, current_time, msg_delay_tolerance, min_odom_distance);
+  out4[0] = r.meas_to_add; out4[1] = r.pop_odom; out4[2] = r.pop_obs; out4[3] = r.pop_rel;
+}
+int orc_in_loop_closure_region(const float* cloud, int n, const double* pose_t, double max_xy, double max_z, uint64_t at_least) {
+  return in_loop_closure_region(cloud, n, pose_t, max_xy, max_z, at_least) ? 1 : 0;
 }
 
 // ---- relative-measurement matching (A16) -----------------------------------------------------

@@ -36,6 +36,7 @@ EXPORTS = [
     "slide_place_default_params", "slide_match_maps", "slide_find_inter_loop_closure", "slide_clipper_affinity",
     "slide_closest_stamp", "slide_clipper_default_params", "slide_clipper_dense_clique", "slide_match_triangles",
     "slide_estimate_tf2d", "slide_semantic_clipper", "slide_find_relative_meas_match", "slide_delaunay_2d", "slide_run_semantic_clipper",
+    "slide_pick_next_measurement", "slide_in_loop_closure_region",
 ]
 
 
@@ -528,3 +529,29 @@ def run_semantic_clipper(ref7, qry7, sigma=0.01, epsilon=0.06, min_num_pairs=4, 
                                             _p(u0a) if u0a is not None else None, C.c_int(len(u0a) if u0a is not None else 0),
                                             _p(tf), _p(counts), C.byref(found)))
     return dict(found=bool(found.value), tf=tf.reshape(4, 4), n_putative=int(counts[0]), n_inliers=int(counts[1]))
+
+
+def pick_next_measurement(odom, obs, rel, latest, current_time, msg_delay_tolerance, min_odom_distance):
+    """Input::PickNextMeasurementToAdd (input.cpp:26-108).  odom: list of ((sec, nsec), pose7); obs / rel: lists of (sec, nsec);
+    latest: ((sec, nsec), pose7).  Returns (meas_to_add, pop_odom, pop_obs, pop_rel)."""
+    def stamps(lst):
+        a = np.array([[x[0], x[1]] for x in lst] + [[0, 0]], np.int64)
+        return np.ascontiguousarray(a[:, 0]), np.ascontiguousarray(a[:, 1])
+    os_, on_ = stamps([o[0] for o in odom])
+    op = _d(np.array([o[1] for o in odom] + [[0, 0, 0, 0, 0, 0, 1.0]]))
+    bs, bn = stamps(obs)
+    rs, rn = stamps(rel)
+    out = np.zeros(4, np.int32)
+    _check(lib().slide_pick_next_measurement(_p(os_), _p(on_), _p(op), C.c_int(len(odom)), _p(bs), _p(bn), C.c_int(len(obs)), _p(rs), _p(rn),
+                                             C.c_int(len(rel)), C.c_int64(latest[0][0]), C.c_int64(latest[0][1]), _p(_d(latest[1])),
+                                             C.c_double(current_time), C.c_double(msg_delay_tolerance), C.c_float(min_odom_distance),
+                                             _p(out)))
+    return tuple(int(v) for v in out)
+
+
+def in_loop_closure_region(cloud_xyz, pose_xyz, max_dist_xy=10.0, max_dist_z=2.0, at_least_num_of_poses_old=30):
+    cloud = np.ascontiguousarray(cloud_xyz, dtype=np.float32).reshape(-1, 3)
+    inside = C.c_int(0)
+    _check(lib().slide_in_loop_closure_region(_p(cloud), C.c_int(len(cloud)), _p(_d(pose_xyz)), C.c_double(max_dist_xy),
+                                              C.c_double(max_dist_z), C.c_uint64(at_least_num_of_poses_old), C.byref(inside)))
+    return bool(inside.value)

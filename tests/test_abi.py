@@ -115,3 +115,71 @@ def test_delaunay_equals_qhull():
         assert mine == ref
     assert len(s.delaunay_2d(np.zeros((2, 2)))) == 0
     assert len(s.delaunay_2d(np.array([[0.0, 0], [1, 1], [2, 2], [3, 3]]))) == 0     # collinear
+
+
+def _pick_both(odom, obs, rel, latest, now, tol, mind):
+    """product + oracle on the same queues; they must agree, the tuple is returned"""
+    import ctypes as C
+    from oracle import pyoracle as po
+    got = s.pick_next_measurement(odom, obs, rel, latest, now, tol, mind)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    def st(lst):
+        a = np.array([[x[0], x[1]] for x in lst] + [[0, 0]], np.int64)
+        return np.ascontiguousarray(a[:, 0]), np.ascontiguousarray(a[:, 1])
+    os_, on_ = st([o[0] for o in odom]); bs, bn = st(obs); rs, rn = st(rel)
+    op = np.ascontiguousarray(np.array([o[1] for o in odom] + [[0, 0, 0, 0, 0, 0, 1.0]], np.float64))
+    out = np.zeros(4, np.int32)
+    po.lib().orc_pick_next_measurement(P(os_), P(on_), P(op), C.c_int(len(odom)), P(bs), P(bn), C.c_int(len(obs)), P(rs), P(rn),
+                                       C.c_int(len(rel)), C.c_int64(latest[0][0]), C.c_int64(latest[0][1]),
+                                       P(np.ascontiguousarray(latest[1], dtype=np.float64)), C.c_double(now), C.c_double(tol),
+                                       C.c_float(mind), P(out))
+    assert got == tuple(int(v) for v in out)
+    return got
+
+
+def test_pick_next_measurement_reference_scenarios():
+    """src/test/input_test.cpp:92-149, every expectation in order (queue sizes / fronts via the returned pop counts)."""
+    I = [0, 0, 0, 0, 0, 0, 1.0]
+    one = [1.0, 0, 0, 0, 0, 0, 1.0]
+    latest0 = ((0, 0), I)
+    odom1, obs1, rel1 = [((1, 0), one)], [(1, 0)], [(1, 0)]
+    odom10, obs10, rel10 = [((10, 0), one)], [(10, 0)], [(10, 0)]
+    assert _pick_both([], [], [], latest0, 1000.0, 3.0, 0.5)[0] == 0
+    assert _pick_both(odom1, [], [], latest0, 1000.0, 3.0, 0.5)[0] == 1
+    assert _pick_both([], obs1, [], latest0, 1000.0, 3.0, 0.5)[0] == 2
+    assert _pick_both([], [], rel1, latest0, 1000.0, 3.0, 0.5)[0] == 3
+    assert _pick_both([], obs1, rel10, latest0, 1000.0, 3.0, 0.5)[0] == 2
+    assert _pick_both([], obs10, rel1, latest0, 1000.0, 3.0, 0.5)[0] == 3
+    large = [((i, 0), one) for i in range(100)]
+    m, po_, _, _ = _pick_both(large, [], [], latest0, 76.0, 3.0, 0.5)
+    assert m == 1 and len(large) - po_ == 27 and large[po_][0][0] == 73
+    large = large[po_:]
+    m, po_, _, _ = _pick_both(large, [], [], latest0, 76.0, 3.0, 1.5)
+    assert m == 0 and po_ == 0 and len(large) == 27 and large[0][0][0] == 73
+    assert _pick_both(odom1, obs10, rel10, latest0, 10.0, 8.0, 0.5)[0] == 1
+    assert _pick_both(odom1, obs1, rel10, latest0, 10.0, 8.0, 0.5)[0] == 2
+    assert _pick_both(odom1, obs10, rel1, latest0, 10.0, 8.0, 0.5)[0] == 3
+    q_odom = [((i, 0), one) for i in range(12)]
+    q_obs = [(i, 0) for i in range(12)]
+    q_rel = [(i, 0) for i in range(12)]
+    m, a, b, c = _pick_both(q_odom, q_obs, q_rel, ((10, 0), I), 12.0, 3.0, 0.5)
+    assert m == 0 and 12 - a == 2 and 12 - b == 2 and 12 - c == 2 and q_odom[a][0][0] == 10
+
+
+def test_in_loop_closure_region_matches_oracle():
+    import ctypes as C
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(4)
+    hits = 0
+    for _ in range(200):
+        n = int(rng.integers(0, 120))
+        cloud = np.cumsum(rng.normal(0, 1.5, (n, 3)), axis=0).astype(np.float32)
+        cloud[:, 2] *= 0.2
+        q = cloud[-1].astype(np.float64) + rng.normal(0, 2.0, 3) if n else rng.normal(0, 1, 3)
+        got = s.in_loop_closure_region(cloud, q, 10.0, 2.0, 30)
+        c32 = np.ascontiguousarray(cloud.reshape(-1) if n else np.zeros(3, np.float32))
+        ref = po.lib().orc_in_loop_closure_region(c32.ctypes.data_as(C.c_void_p), C.c_int(n), np.ascontiguousarray(q).ctypes.data_as(C.c_void_p),
+                                                  C.c_double(10.0), C.c_double(2.0), C.c_uint64(30))
+        assert got == bool(ref)
+        hits += int(got)
+    assert 10 < hits < 190
