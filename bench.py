@@ -41,8 +41,8 @@ def build_graph(s, data, robot_log_idx, frames=None):
 
 def cpu_baseline(data, robot_log_idx, frames, threads):
     """The oracle (CPU restatement, C++ -O3 -march=native, `threads` OpenMP threads) timed on the same graph:
-    all frames are ingested without solving (association against the un-refined map), then ONE full
-    linearise + Schur + Cholesky + back-substitution pass is timed twice (second one = threshold 0)."""
+    all frames are ingested without solving (association against the un-refined map), then full
+    linearise + Schur + Cholesky + back-substitution passes (threshold 0) are timed for about 12 s; median."""
     from oracle import pyoracle as po
     from slide_slam_amd.synth import frame_detections
     L = po.lib(native=True)
@@ -52,19 +52,20 @@ def cpu_baseline(data, robot_log_idx, frames, threads):
     gt = log["gt7"]
     for k in range(P):
         ob.process_frame(0, log["rel7"][k], gt[k], frame_detections(log, k), 2)
-    t0 = time.perf_counter()
-    st = ob.ingest_solve()
-    t1 = time.perf_counter()
     ob.graph.set_relin_threshold(0.0)
-    st2 = ob.ingest_solve()
-    t2 = time.perf_counter()
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 2 or (time.perf_counter() - t_start < 12.0 and len(times) < 60):     # bounded: about 12 s of CPU work
+        t0 = time.perf_counter()
+        st = ob.ingest_solve()
+        times.append(time.perf_counter() - t0)
+        if st != 0:
+            raise RuntimeError("oracle solve failed")
     stats = ob.graph.stats()
-    if st != 0 or st2 != 0:
-        raise RuntimeError("oracle solve failed")
-    per_iter = min(t1 - t0, t2 - t1)
+    per_iter = float(np.median(times))
     return dict(value=1.0 / per_iter, unit="pose-graph updates/s", cores=threads, kind="port",
-                sample=f"2 full Gauss-Newton iterations of the same {stats['n_pose']}-pose / {stats['n_lm']}-landmark / "
-                       f"{stats['n_factors']}-factor graph (oracle = CPU restatement of the reference, not GTSAM), best of 2",
+                sample=f"{len(times)} full Gauss-Newton iterations (about 12 s) of the same {stats['n_pose']}-pose / {stats['n_lm']}-landmark / "
+                       f"{stats['n_factors']}-factor graph (oracle = CPU restatement of the reference, not GTSAM), median",
                 ms_per_iter=per_iter * 1e3, t_linearize_s=stats["t_linearize"], t_schur_s=stats["t_schur"],
                 t_chol_s=stats["t_chol"])
 
