@@ -57,7 +57,7 @@ __device__ unsigned long long g_stamps[40];
 // The long type-A blocks therefore run BESIDE the memory-bound type-B flood inside one launch; the next step
 // needs only the kernel boundary.  MFMA accumulator layout of X_c^T (row (lane>>4) + 4r, column lane&15) is
 // exactly the B-operand layout of k-step r, so chained products need no lane movement.
-// ---------------- type B: trailing update with panel k-1, one 2x2 group of 64x64 tiles per workgroup ----------------
+// ---------------- type B: trailing update with two panels, one 2x2 group of 64x64 tiles per workgroup ----------------
 // A work item is one tile row of a 2x2 group: two tiles (i, j0), (i, j0 + 1); four waves per tile, each a 32x32 quadrant:
 // four 16x16 accumulators initialised with C itself, sixteen k-steps of four operand loads feeding four MFMAs (the loads
 // run five k-steps ahead of their use).  No LDS, no barrier: waves whose tile lies outside the lower triangle leave at once.
@@ -67,39 +67,49 @@ __device__ __forceinline__ long long tri_row(long long t) {
   while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
   return ii;
 }
-__device__ __forceinline__ void step_type_b(double* __restrict__ S, int ld, int k, int T, long long tt) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // eight waves: tile (wave >> 2), 32x32 quadrant (wave & 3)
-  const int lr = lane & 15, lk = lane >> 4;
-  const long long t = tt >> 1;
-  const long long bi = tri_row(t);
-  const int bj = (int)(t - bi * (bi + 1) / 2);
-  const int i = k + 1 + 2 * (int)bi + (int)(tt & 1), j = k + 1 + 2 * bj + (wave >> 2);
-  if (i > T || j > T - 1 || i < j) return;
-  const int ch = (wave >> 1) & 1, rh = wave & 1;                      // column half, row half of the tile
-  const double* pjh = S + (size_t)((k - 1) * NB) * ld + (size_t)j * NB + 32 * ch + lr;   // + 16a : rows 32 ch + 16a + lr of panel tile (j, k-1)
-  const double* pih = S + (size_t)((k - 1) * NB) * ld + (size_t)i * NB + 32 * rh + lr;   // + 16b : rows 32 rh + 16b + lr of panel tile (i, k-1)
-  double* cbh = S + (size_t)(j * NB + 32 * ch + lk) * ld + (size_t)i * NB + 32 * rh + lr;   // + (16a + 4r) ld + 16b
+// Pair schedule (rank-128 trailing update): the panels of two consecutive block columns are applied in ONE pass over the
+// trailing matrix, so every C tile is read and written once per two columns.  kb (even) is the base of the pair: panels
+// kb-2 and kb-1 go onto the tiles (i, j >= kb+1); the first part of the item list (which holds all of tile columns kb+1,
+// kb+2) runs in launch kb, the rest in launch kb+1.  Items are enumerated column-major over the 2x2 groups.  Launch kb+1
+// also brings tile column kb+2 up to panel kb (rank 64, "column items"), so that every type-A column has ONE pending panel.
+// The row <-> lane map of the quadrant is permuted (lane lr owns rows 2 lr, 2 lr + 1 of its 32-row half instead of lr, lr + 16)
+// so that every operand / C access is 16 contiguous bytes per lane: half the vector-memory instructions of the natural map,
+// which is what bounds an item next to the matrix pipe (tools/b_bench.hip: latency hiding across items gains nothing).
+struct BItem {
+  int i, j, pcb, ks;   // tile (i, j); first panel column block; k-steps of four columns: 16 = one panel, 32 = two
+  bool ok;
+};
+typedef double v2d __attribute__((ext_vector_type(2)));
+template <int KS>
+__device__ __forceinline__ void b_quadrant(double* __restrict__ S, int ld, const BItem& it, int wq) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  const int ch = (wq >> 1) & 1, rh = wq & 1;      // column half, row half of the tile
+  const double* pjh = S + (size_t)(it.pcb * NB + lk) * ld + (size_t)it.j * NB + 32 * ch + 2 * lr;   // rows 32 ch + 2 lr + a of panel tiles (j, pcb ..)
+  const double* pih = S + (size_t)(it.pcb * NB + lk) * ld + (size_t)it.i * NB + 32 * rh + 2 * lr;   // rows 32 rh + 2 lr + b of panel tiles (i, pcb ..)
+  // acc[a][b] register r of lane (lr, lk) = C[row 32 rh + 2 lr + b][column 32 ch + 2 (lk + 4 r) + a]
+  double* cbh = S + (size_t)(it.j * NB + 32 * ch + 2 * lk) * ld + (size_t)it.i * NB + 32 * rh + 2 * lr;   // + (8 r + a) ld + b
   v4d acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[a][b][r] = cbh[(size_t)(16 * a + 4 * r) * ld + 16 * b];
+    for (int r = 0; r < 4; ++r) {
+      const v2d c2 = *(const v2d*)(cbh + (size_t)(8 * r + a) * ld);
+      acc[a][0][r] = c2[0]; acc[a][1][r] = c2[1];
+    }
   constexpr int RD = 6;                      // operand ring: loads run RD - 1 k-steps ahead
-  double pa[RD][2], pb[RD][2];
+  v2d pa[RD], pb[RD];
 #pragma unroll
   for (int pre = 0; pre < RD - 1; ++pre) {
-    const size_t off = (size_t)(4 * pre + lk) * ld;
-    pa[pre][0] = pjh[off]; pa[pre][1] = pjh[off + 16];
-    pb[pre][0] = pih[off]; pb[pre][1] = pih[off + 16];
+    const size_t off = (size_t)(4 * pre) * ld;
+    pa[pre] = *(const v2d*)(pjh + off);
+    pb[pre] = *(const v2d*)(pih + off);
   }
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    if (ks + RD - 1 < 16) {
-      const size_t off = (size_t)(4 * (ks + RD - 1) + lk) * ld;
-      pa[(ks + RD - 1) % RD][0] = pjh[off]; pa[(ks + RD - 1) % RD][1] = pjh[off + 16];
-      pb[(ks + RD - 1) % RD][0] = pih[off]; pb[(ks + RD - 1) % RD][1] = pih[off + 16];
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ks + RD - 1 < KS) {
+      const size_t off = (size_t)(4 * (ks + RD - 1)) * ld;
+      pa[(ks + RD - 1) % RD] = *(const v2d*)(pjh + off);
+      pb[(ks + RD - 1) % RD] = *(const v2d*)(pih + off);
     }
     __builtin_amdgcn_sched_barrier(0);      // keep the prefetch distance: no further hoisting of loads
 #pragma unroll
@@ -113,9 +123,37 @@ __device__ __forceinline__ void step_type_b(double* __restrict__ S, int ld, int 
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cbh[(size_t)(16 * a + 4 * r) * ld + 16 * b] = acc[a][b][r];
+    for (int r = 0; r < 4; ++r) {
+      v2d c2;
+      c2[0] = acc[a][0][r]; c2[1] = acc[a][1][r];
+      *(v2d*)(cbh + (size_t)(8 * r + a) * ld) = c2;
+    }
+}
+// item g of launch k.  g < nR: item g0 + g of the rank-128 pass of pair base kb = tile row i of a 2x2 group, tiles (i, j0),
+// (i, j0 + 1).  Then the column items c = g - nR of an odd launch: tiles (k+1 + 2c, k+1), (k+2 + 2c, k+1) take panel k-1.
+// Eight waves: tile (wave >> 2), 32x32 quadrant (wave & 3).
+__device__ __forceinline__ BItem b_decode(int g, int nItems, int nR, int g0, int k, int kb, int T, int nP, long long nG, int wave) {
+  BItem it;
+  it.ok = false; it.i = it.j = it.pcb = 0; it.ks = 32;
+  if (g >= nItems) return it;
+  if (g < nR) {
+    const long long tt = (long long)g0 + g;
+    const long long t = nG - 1 - (tt >> 1);
+    const long long u = tri_row(t);
+    const int v = (int)(t - u * (u + 1) / 2);
+    const int bi = nP - 1 - v, bj = nP - 1 - (int)u;
+    it.i = kb + 1 + 2 * bi + (int)(tt & 1);
+    it.j = kb + 1 + 2 * bj + (wave >> 2);
+    it.pcb = kb - 2;
+    it.ok = !(it.i > T || it.j > T - 1 || it.i < it.j);
+  } else {
+    const int c = g - nR;
+    it.j = k + 1;
+    it.i = k + 1 + 2 * c + (wave >> 2);
+    it.pcb = k - 1; it.ks = 16;
+    it.ok = !(it.i > T || it.j > T - 1);
+  }
+  return it;
 }
 
 // ---------------- type A: look-ahead chain of block column k for row tile it = k + 1 + ia ----------------
@@ -146,7 +184,7 @@ __device__ __forceinline__ void step_type_b(double* __restrict__ S, int ld, int 
 constexpr int PSTR = 80;   // LDS column stride of the staged panel tile: the four 16-lane groups of a ds_read_b64 fall in disjoint bank halves
 constexpr int WT = 2;      // the worker that carries the identity pseudo-tiles
 struct ALds {
-  double Pk[NB][PSTR];  // panel tile (k, k-1): Pk[kk][r] = L[k*NB + r][(k-1)*NB + kk]   (rows of the diagonal block)
+  double Pk[NB][PSTR];  // pending panel tiles (k, k-NPAN .. k-1): Pk[kk][r] = L[k*NB + r][(k-NPAN)*NB + kk]   (rows of the diagonal block)
   double mop[16][64];   // iteration n: A operand of the panel MFMAs, lane image
   double xm[16][64];    // iteration n: masked X of the diagonal sub-tile = A operand of the in-phase updates, lane image
   double Lt[6][4][64];  // finished off-diagonal sub-tiles L(I, J), I > J, at index I (I - 1) / 2 + J, register, lane
@@ -184,7 +222,7 @@ __device__ __forceinline__ constexpr int oidx(int I, int J) { return I * (I - 1)
 __device__ __forceinline__ void pin(v4d& x) { asm volatile("" : "+v"(x)); }
 
 // ---- wave 0 ---------------------------------------------------------------------------------------------------------
-template <bool HASK>
+template <int NPAN>
 __device__ __forceinline__ void a_chain_wave(int ia, int* status, ALds& L, int lane, v4d Dt) {
   const int lr = lane & 15, lk = lane >> 4;
   const v4d zero = v4d{0.0, 0.0, 0.0, 0.0};
@@ -192,12 +230,13 @@ __device__ __forceinline__ void a_chain_wave(int ia, int* status, ALds& L, int l
   const bool s00 = lr == 0 && lk == 0, s10 = lr == 1 && lk == 0, s11 = lr == 1 && lk == 1, s20 = lr == 2 && lk == 0,
              s21 = lr == 2 && lk == 1, s22 = lr == 2 && lk == 2, s30 = lr == 3 && lk == 0, s31 = lr == 3 && lk == 1,
              s32 = lr == 3 && lk == 2, s33 = lr == 3 && lk == 3;
-  if (HASK) {
+  if (NPAN > 0) {
     // panel k-1 on sub-tile (0, 0): four independent accumulation chains instead of one of sixteen
     v4d d1 = zero, d2 = zero, d3 = zero;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const double q0 = L.Pk[4 * ks + lk][lr], q1 = L.Pk[16 + 4 * ks + lk][lr], q2 = L.Pk[32 + 4 * ks + lk][lr], q3 = L.Pk[48 + 4 * ks + lk][lr];
+    for (int ks = 0; ks < 4 * NPAN; ++ks) {
+      const double q0 = L.Pk[4 * ks + lk][lr], q1 = L.Pk[16 * NPAN + 4 * ks + lk][lr], q2 = L.Pk[32 * NPAN + 4 * ks + lk][lr],
+                   q3 = L.Pk[48 * NPAN + 4 * ks + lk][lr];
       Dt = mfma_f64(-q0, q0, Dt);
       d1 = mfma_f64(-q1, q1, d1);
       d2 = mfma_f64(-q2, q2, d2);
@@ -263,19 +302,19 @@ __device__ __forceinline__ void a_chain_wave(int ia, int* status, ALds& L, int l
 }
 
 // ---- waves 1..3 -----------------------------------------------------------------------------------------------------
-template <int W, bool HASK>
+template <int W, int NPAN>
 __device__ __forceinline__ void a_worker_wave(int ia, double* __restrict__ Ld, double* __restrict__ Winv, ALds& L, int lane,
                                               v4d (&R)[W + 1]) {
   const int lr = lane & 15, lk = lane >> 4;
   const v4d zero = v4d{0.0, 0.0, 0.0, 0.0};
-  if (HASK) {
+  if (NPAN > 0) {
     // the whole sub-tile row before the first iteration, in the order of need: a worker answers an iteration of the
     // chain wave in about 500 cycles but needs twice that with a quarter of a sub-tile update on top, so it is better
     // late for the first iterations (it catches up well before its hand-off) than slow in all of them
 #pragma unroll
     for (int J = 0; J <= W; ++J) {
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) R[J] = mfma_f64(-L.Pk[4 * ks + lk][16 * J + lr], L.Pk[4 * ks + lk][16 * W + lr], R[J]);
+      for (int ks = 0; ks < 16 * NPAN; ++ks) R[J] = mfma_f64(-L.Pk[4 * ks + lk][16 * J + lr], L.Pk[4 * ks + lk][16 * W + lr], R[J]);
       pin(R[J]);
     }
   }
@@ -369,7 +408,7 @@ __device__ __forceinline__ void a_worker_wave(int ia, double* __restrict__ Ld, d
 }
 
 // ---- panel rows: 16 rows of tile (it, k), T-layout: Tq[b][r] = A[16 q + lr][16b + lk + 4r] ----------------------------------
-template <bool HASK>
+template <int NPAN>
 __device__ __forceinline__ void panel_load(const double* __restrict__ S, int ld, int k, int it, int q, int lr, int lk,
                                            v4d (&Tq)[4], double (&tb)[16]) {
   const double* tcol = S + (size_t)(k * NB) * ld + (size_t)it * NB + 16 * q + lr;
@@ -377,17 +416,17 @@ __device__ __forceinline__ void panel_load(const double* __restrict__ S, int ld,
   for (int b = 0; b < 4; ++b)
 #pragma unroll
     for (int r = 0; r < 4; ++r) Tq[b][r] = tcol[(size_t)(16 * b + lk + 4 * r) * ld];
-  if (HASK) {
-    const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)it * NB + 16 * q + lr;   // own rows of panel tile (it, k-1)
+  if (NPAN > 0) {
+    const double* pi = S + (size_t)((k - NPAN) * NB) * ld + (size_t)it * NB + 16 * q + lr;   // own rows of panel tiles (it, k-NPAN .. k-1)
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) tb[ks] = pi[(size_t)(4 * ks + lk) * ld];
+    for (int ks = 0; ks < 16 * NPAN; ++ks) tb[ks] = pi[(size_t)(4 * ks + lk) * ld];
   }
 }
 // Column block p of the own rows: pending update from panel k-1, then X_p = (A_p - sum_{c<p} X_c L(p,c)^T) L_pp^-T as soon
 // as phase p of the factorisation has delivered L(p, c) and the inverse of L_pp — only the last block is left when the
 // chain wave finishes.  Nothing before the first phase is through: until then the factor waves are busy with panel k-1
 // themselves and this wave would only compete for the matrix pipe and the LDS.
-template <bool HASK>
+template <int NPAN>
 __device__ __forceinline__ void panel_rows(double* __restrict__ S, int ld, int k, int it, int q, int lane, ALds& L, v4d (&Tq)[4],
                                            const double (&tb)[16]) {
   const int lr = lane & 15, lk = lane >> 4;
@@ -402,9 +441,9 @@ __device__ __forceinline__ void panel_rows(double* __restrict__ S, int ld, int k
   for (int b = 0; b < 4; ++b) {
     if (b == 0) {
       lds_wait(&L.it_done, 4);
-      if (HASK) {
+      if (NPAN > 0) {
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
+        for (int ks = 0; ks < 16 * NPAN; ++ks) {
           Tq[0] = mfma_f64(-L.Pk[4 * ks + lk][lr], tb[ks], Tq[0]);
           if ((ks & 3) == 3) PANEL_YIELD();
         }
@@ -420,9 +459,9 @@ __device__ __forceinline__ void panel_rows(double* __restrict__ S, int ld, int k
     for (int r = 0; r < 4; ++r) tcol[(size_t)(16 * b + lk + 4 * r) * ld] = x[r];
     if (b < 3) {
       PANEL_YIELD();
-      if (HASK) {
+      if (NPAN > 0) {
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
+        for (int ks = 0; ks < 16 * NPAN; ++ks) {
           Tq[b + 1] = mfma_f64(-L.Pk[4 * ks + lk][16 * (b + 1) + lr], tb[ks], Tq[b + 1]);
           if ((ks & 3) == 3) PANEL_YIELD();
         }
@@ -442,7 +481,7 @@ __device__ __forceinline__ void panel_rows(double* __restrict__ S, int ld, int k
 #undef PANEL_YIELD
 }
 
-template <bool HASK>
+template <int NPAN>
 __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld, int k, int ia, double* __restrict__ Ld,
                                                  double* __restrict__ Winv, int* status, ALds& L) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -451,14 +490,15 @@ __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld,
   const int it = k + 1 + ia;
   STAMP(0);
   // ---- prologue: every global load of this workgroup is issued here, in one wave of traffic ----
-  if (HASK) {
-    // one eighth of panel tile (k, k-1) per wave -> LDS
-    const double* pq = S + (size_t)((k - 1) * NB + 8 * wave) * ld + (size_t)k * NB + lane;
-    double stage[8];
+  if (NPAN > 0) {
+    // one eighth of the pending panel tiles (k, k-NPAN .. k-1) per wave -> LDS
+    constexpr int NC = 8 * (NPAN > 0 ? NPAN : 1);
+    const double* pq = S + (size_t)((k - NPAN) * NB + NC * wave) * ld + (size_t)k * NB + lane;
+    double stage[NC];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) stage[c] = pq[(size_t)c * ld];
+    for (int c = 0; c < NC; ++c) stage[c] = pq[(size_t)c * ld];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) L.Pk[8 * wave + c][lane] = stage[c];
+    for (int c = 0; c < NC; ++c) L.Pk[NC * wave + c][lane] = stage[c];
   }
   if (tid == 0) L.it_done = 0;
   if (tid < 4) { L.col_done[tid] = 0; L.d_ready[tid] = 0; }
@@ -473,20 +513,20 @@ __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld,
       for (int r = 0; r < 4; ++r) R[J][r] = (J <= wave) ? dcol[(size_t)(16 * J + lk + 4 * r) * ld] : 0.0;
     v4d Tq[4];
     double tb[16];
-    if (wave == 1) panel_load<HASK>(S, ld, k, it, 0, lr, lk, Tq, tb);
+    if (wave == 1) panel_load<NPAN>(S, ld, k, it, 0, lr, lk, Tq, tb);
     __syncthreads();
     if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);   // ahead of the panel wave sharing the SIMD
     if (wave == 0) {
-      a_chain_wave<HASK>(ia, status, L, lane, R[0]);
+      a_chain_wave<NPAN>(ia, status, L, lane, R[0]);
     } else if (wave == 1) {
       v4d R1[2] = {R[0], R[1]};
-      a_worker_wave<1, HASK>(ia, Ld, Winv, L, lane, R1);
-      panel_rows<HASK>(S, ld, k, it, 0, lane, L, Tq, tb);      // idle from here on otherwise
+      a_worker_wave<1, NPAN>(ia, Ld, Winv, L, lane, R1);
+      panel_rows<NPAN>(S, ld, k, it, 0, lane, L, Tq, tb);      // idle from here on otherwise
     } else if (wave == 2) {
       v4d R2[3] = {R[0], R[1], R[2]};
-      a_worker_wave<2, HASK>(ia, Ld, Winv, L, lane, R2);
+      a_worker_wave<2, NPAN>(ia, Ld, Winv, L, lane, R2);
     } else {
-      a_worker_wave<3, HASK>(ia, Ld, Winv, L, lane, R);
+      a_worker_wave<3, NPAN>(ia, Ld, Winv, L, lane, R);
     }
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();
@@ -498,9 +538,9 @@ __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld,
     const int q = wave - 4;
     v4d Tq[4];
     double tb[16];
-    if (q > 0) panel_load<HASK>(S, ld, k, it, q, lr, lk, Tq, tb);
+    if (q > 0) panel_load<NPAN>(S, ld, k, it, q, lr, lk, Tq, tb);
     __syncthreads();
-    if (q > 0) panel_rows<HASK>(S, ld, k, it, q, lane, L, Tq, tb);
+    if (q > 0) panel_rows<NPAN>(S, ld, k, it, q, lane, L, Tq, tb);
     STAMPW(14);
     __syncthreads();
     STAMP(1);
@@ -509,15 +549,17 @@ __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld,
 }
 __device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int k, int ia, double* __restrict__ Ld,
                                             double* __restrict__ Winv, int* status, ALds& L) {
-  if (k > 0) step_type_a_impl<true>(S, ld, k, ia, Ld, Winv, status, L);
-  else step_type_a_impl<false>(S, ld, k, ia, Ld, Winv, status, L);
+  if (k > 0) step_type_a_impl<1>(S, ld, k, ia, Ld, Winv, status, L);
+  else step_type_a_impl<0>(S, ld, k, ia, Ld, Winv, status, L);
 }
 
-// Work queue of the type-B groups: every workgroup of the launch (the type-A ones after their chain, too) draws group
-// indices from ctr[k] until they run out, so the ~T-k long type-A chains and the flood balance by themselves at the one
-// workgroup per CU the register-heavy kernel gets.  ctr[k+1] is cleared here for the next launch (ctr[0..1] start at 0).
+// One launch per block column k.  Workgroups 0 .. T-k-1 are type A (column k with its pending panel k-1); every workgroup of
+// the launch (the type-A ones after their chain, too, when a_joins) then draws items from the work queue ctr[k]: rank-128 items
+// g0 <= g < g1 of the pair base kb, then nX column items — so the ~T-k long type-A chains and the flood balance by themselves at
+// the one workgroup per CU the register-heavy kernel gets.  ctr[k+1] is cleared here for the next launch (ctr[0..1] start at 0).
 __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Ld,
-                                                   double* __restrict__ Winv, int* status, int* __restrict__ ctr, int nGroups, int a_joins) {
+                                                   double* __restrict__ Winv, int* status, int* __restrict__ ctr, int kb, int nP,
+                                                   int g0, int g1, int nX, int a_joins) {
   __shared__ ALds L;
   __shared__ int s_g;
   const int nA = T - k;
@@ -526,23 +568,22 @@ __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ S, int l
     step_type_a(S, ld, k, (int)blockIdx.x, Ld, Winv, status, L);
     if (!a_joins) return;        // the queue workers are through before the chain is: an item taken now would only add a tail
   }
-  if (nGroups <= 0) return;
+  const int nR = g1 - g0, nItems = nR + nX;
+  if (nItems <= 0) return;
+  const long long nG = (long long)nP * (nP + 1) / 2;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) s_g = atomicAdd(&ctr[k], 1);
     __syncthreads();
-    const int g = s_g;
-    if (g >= nGroups) break;
-    step_type_b(S, ld, k, T, (long long)g);
+    const int g = __builtin_amdgcn_readfirstlane(s_g);
+    if (g >= nItems) break;
+    const BItem it = b_decode(g, nItems, nR, g0, k, kb, T, nP, nG, wave);
+    if (!it.ok) continue;
+    if (it.ks == 32) b_quadrant<32>(S, ld, it, wave & 3);
+    else b_quadrant<16>(S, ld, it, wave & 3);
   }
 }
-// diagnostic split (SLIDE_CHOL_SPLIT=1): the two kinds of workgroups as separate launches
-__global__ __launch_bounds__(512) void k_chol_a(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Ld,
-                                                double* __restrict__ Winv, int* status) {
-  __shared__ ALds L;
-  step_type_a(S, ld, k, (int)blockIdx.x, Ld, Winv, status, L);
-}
-__global__ __launch_bounds__(512) void k_chol_b(double* __restrict__ S, int ld, int k, int T) { step_type_b(S, ld, k, T, (long long)blockIdx.x); }
 
 #ifdef SLIDE_STAMPS
 extern "C" void slide_debug_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
@@ -756,44 +797,39 @@ void launch_pose_covariance(const double* S, int ld, int T, const double* Ld, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Schedule (see step_type_b): launch 0 factors column 0, launch 1 column 1 with panel 0 (and brings column 2 up to panel 0);
+// from then on every launch k takes the one pending panel k-1 in its column, even launches start the rank-128 pass of panels
+// k-2, k-1 over the trailing matrix, odd launches finish the pass their predecessor started and bring column k+1 up to panel k-1.
 void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, hipStream_t s) {
-  const long long nA = T - k;                                   // column-k tiles below the diagonal (+ RHS tile)
-  const long long nP = (nA + 1) / 2;                            // 2x2 tile groups per side of the trailing matrix
-  const long long nB = k > 0 ? nP * (nP + 1) : 0;               // half groups (one tile row of a 2x2 group each) that still owe the update of panel k-1
-  static const int split = getenv("SLIDE_CHOL_SPLIT") ? atoi(getenv("SLIDE_CHOL_SPLIT")) : 0;
-  if (split == 1) {
-    hipLaunchKernelGGL(k_chol_a, dim3((unsigned)nA), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status);
-    if (nB > 0) hipLaunchKernelGGL(k_chol_b, dim3((unsigned)nB), dim3(512), 0, s, S, ld, k, T);
-    return;
-  }
-  if (split == 2) {   // the two kinds as concurrent launches on two streams (fork / join per step)
-    static hipStream_t s2 = nullptr;
-    static hipEvent_t ef = nullptr, ej = nullptr;
-    if (!s2) { (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking); (void)hipEventCreateWithFlags(&ef, hipEventDisableTiming); (void)hipEventCreateWithFlags(&ej, hipEventDisableTiming); }
-    if (nB > 0) {
-      (void)hipEventRecord(ef, s);
-      (void)hipStreamWaitEvent(s2, ef, 0);
-    }
-    hipLaunchKernelGGL(k_chol_a, dim3((unsigned)nA), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status);
-    if (nB > 0) {
-      hipLaunchKernelGGL(k_chol_b, dim3((unsigned)nB), dim3(512), 0, s2, S, ld, k, T);
-      (void)hipEventRecord(ej, s2);
-      (void)hipStreamWaitEvent(s, ej, 0);
-    }
-    return;
-  }
   static int n_cu = 0;
+  static double frac = 0.5;
   if (!n_cu) {
     int dev = 0;
     hipDeviceProp_t pr;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
+    if (const char* e = getenv("SLIDE_CHOL_FRAC")) frac = atof(e);     // diagnostic: share of a pass done by its first launch
   }
+  const long long nA = T - k;                                   // column-k tiles below the diagonal (+ RHS tile)
+  const int kb = k & ~1;                                        // base of the pair
+  long long nP = 0, g0 = 0, g1 = 0;
+  if (k >= 2) {
+    nP = (T - kb + 1) / 2;                                      // 2x2 tile groups per side of the trailing matrix of the pair
+    const long long nG = nP * (nP + 1) / 2;
+    long long first = (long long)(frac * (double)nG + 0.5);
+    if (first < nP) first = nP;                                 // the group column with tile columns kb+1, kb+2 entirely
+    if (first > nG) first = nG;
+    if (k & 1) { g0 = 2 * first; g1 = 2 * nG; } else { g0 = 0; g1 = 2 * first; }   // items = half groups (one tile row of a 2x2 group)
+  }
+  const long long nX = (k & 1) && k + 1 < T ? (T - k + 1) / 2 : 0;   // column items: tile rows k+1 .. T of column k+1, two per item
+  const long long nB = g1 - g0 + nX;
   const long long extra = nB < n_cu ? nB : n_cu;                // queue workers beside the type-A workgroups (one 512-thread workgroup per CU)
-  // type-A workgroups join the queue only when the flood needs more than two rounds of the other CUs (~ the chain's length)
+  // type-A workgroups join the queue only when the flood needs more than a round of the other CUs (~ the chain's length)
   const long long free_cu = n_cu - nA > 8 ? n_cu - nA : 8;
-  const int a_joins = nB > 2 * free_cu ? 1 : 0;
-  hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nA + extra)), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status, ctr, (int)nB, a_joins);
+  static const int join_mul = getenv("SLIDE_CHOL_JOIN") ? atoi(getenv("SLIDE_CHOL_JOIN")) : 1;
+  const int a_joins = nB > join_mul * free_cu ? 1 : 0;
+  hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nA + extra)), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status, ctr, kb, (int)nP,
+                     (int)g0, (int)g1, (int)nX, a_joins);
 }
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, hipStream_t s) {
   hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv);
