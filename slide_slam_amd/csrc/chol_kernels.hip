@@ -183,6 +183,7 @@ __device__ __forceinline__ BItem b_decode(int g, int nItems, int nR, int g0, int
 // across the T-k workgroups costs no latency and keeps L_kk out of L2.
 constexpr int PSTR = 80;   // LDS column stride of the staged panel tile: the four 16-lane groups of a ds_read_b64 fall in disjoint bank halves
 constexpr int WT = 2;      // the worker that carries the identity pseudo-tiles
+constexpr bool W4ROWS = false;   // rows 0..15 of the panel tile on wave 4 (beside the chain wave) instead of worker 1 after its hand-off
 struct ALds {
   double Pk[NB][PSTR];  // pending panel tiles (k, k-NPAN .. k-1): Pk[kk][r] = L[k*NB + r][(k-NPAN)*NB + kk]   (rows of the diagonal block)
   double mop[16][64];   // iteration n: A operand of the panel MFMAs, lane image
@@ -311,13 +312,26 @@ __device__ __forceinline__ void a_worker_wave(int ia, double* __restrict__ Ld, d
     // the whole sub-tile row before the first iteration, in the order of need: a worker answers an iteration of the
     // chain wave in about 500 cycles but needs twice that with a quarter of a sub-tile update on top, so it is better
     // late for the first iterations (it catches up well before its hand-off) than slow in all of them
+    // (a chain of dependent MFMAs fed from LDS runs at ~150 cycles per link: 2 (W + 1) independent chains, k-steps outermost)
+    v4d e[W + 1];
+#pragma unroll
+    for (int J = 0; J <= W; ++J) e[J] = zero;
+#pragma unroll
+    for (int ks = 0; ks < 16 * NPAN; ks += 2) {
+      const double w0 = L.Pk[4 * ks + lk][16 * W + lr], w1 = L.Pk[4 * ks + 4 + lk][16 * W + lr];
+#pragma unroll
+      for (int J = 0; J <= W; ++J) {
+        R[J] = mfma_f64(-L.Pk[4 * ks + lk][16 * J + lr], w0, R[J]);
+        e[J] = mfma_f64(-L.Pk[4 * ks + 4 + lk][16 * J + lr], w1, e[J]);
+      }
+    }
 #pragma unroll
     for (int J = 0; J <= W; ++J) {
-#pragma unroll
-      for (int ks = 0; ks < 16 * NPAN; ++ks) R[J] = mfma_f64(-L.Pk[4 * ks + lk][16 * J + lr], L.Pk[4 * ks + lk][16 * W + lr], R[J]);
+      R[J] += e[J];
       pin(R[J]);
     }
   }
+  if (W == 1) STAMPW(37);
   v4d Wt = zero;                   // identity pseudo-tile (worker WT only)
 #pragma unroll
   for (int JQ = 0; JQ < W; ++JQ) {
@@ -331,7 +345,7 @@ __device__ __forceinline__ void a_worker_wave(int ia, double* __restrict__ Ld, d
       lds_wait(&L.it_done, n + 1);
       if (W == 1 && n == 3) STAMPW(11);
       if (W == 1 && n < 3) STAMPW(16 + n);
-      if (W == 3 && n < 12) STAMPW(20 + n);
+      if (W == 2 && n < 12) STAMPW(20 + n);
       const double mop = L.mop[n][lane], xm = L.xm[n][lane];
       const double x = mfma_f64(mop, R[JQ][s], zero)[0];
       double xw = 0.0;
@@ -354,6 +368,7 @@ __device__ __forceinline__ void a_worker_wave(int ia, double* __restrict__ Ld, d
       for (int r = 0; r < 4; ++r) L.Dh[W - 1][r][lane] = R[W][r];
       lds_post(&L.d_ready[W], 1, lane);
       if (W == 1) STAMPW(13);
+      if (W == 2) STAMPW(36);
     }
     // column block JQ of row W is final
 #pragma unroll
@@ -426,7 +441,7 @@ __device__ __forceinline__ void panel_load(const double* __restrict__ S, int ld,
 // as phase p of the factorisation has delivered L(p, c) and the inverse of L_pp — only the last block is left when the
 // chain wave finishes.  Nothing before the first phase is through: until then the factor waves are busy with panel k-1
 // themselves and this wave would only compete for the matrix pipe and the LDS.
-template <int NPAN>
+template <int NPAN, bool EARLY>
 __device__ __forceinline__ void panel_rows(double* __restrict__ S, int ld, int k, int it, int q, int lane, ALds& L, v4d (&Tq)[4],
                                            const double (&tb)[16]) {
   const int lr = lane & 15, lk = lane >> 4;
@@ -440,8 +455,21 @@ __device__ __forceinline__ void panel_rows(double* __restrict__ S, int ld, int k
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     if (b == 0) {
+      if (NPAN > 0 && EARLY) {
+        if (q == 1) lds_wait(&L.d_ready[1], 1);      // shares its SIMD with worker 1 / 2: not before that one's hand-off
+        if (q == 2) lds_wait(&L.d_ready[2], 1);      // (worker 3 has two phases of slack: wave 7 starts at once)
+        // the whole pending update at once, while the factor waves are in their own: the phases that follow then see
+        // only the short substitution bursts of this wave on their SIMD
+#pragma unroll
+        for (int ks = 0; ks < 16 * NPAN; ++ks) {
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) Tq[bb] = mfma_f64(-L.Pk[4 * ks + lk][16 * bb + lr], tb[ks], Tq[bb]);
+        }
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) pin(Tq[bb]);
+      }
       lds_wait(&L.it_done, 4);
-      if (NPAN > 0) {
+      if (NPAN > 0 && !EARLY) {
 #pragma unroll
         for (int ks = 0; ks < 16 * NPAN; ++ks) {
           Tq[0] = mfma_f64(-L.Pk[4 * ks + lk][lr], tb[ks], Tq[0]);
@@ -459,7 +487,7 @@ __device__ __forceinline__ void panel_rows(double* __restrict__ S, int ld, int k
     for (int r = 0; r < 4; ++r) tcol[(size_t)(16 * b + lk + 4 * r) * ld] = x[r];
     if (b < 3) {
       PANEL_YIELD();
-      if (NPAN > 0) {
+      if (NPAN > 0 && !EARLY) {
 #pragma unroll
         for (int ks = 0; ks < 16 * NPAN; ++ks) {
           Tq[b + 1] = mfma_f64(-L.Pk[4 * ks + lk][16 * (b + 1) + lr], tb[ks], Tq[b + 1]);
@@ -503,6 +531,7 @@ __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld,
   if (tid == 0) L.it_done = 0;
   if (tid < 4) { L.col_done[tid] = 0; L.d_ready[tid] = 0; }
   if (tid == 4) L.w_done = 0;
+  if (wave == 1) STAMPW(38);
   if (wave < 4) {
     // ---------------- factor waves: own sub-tile row of D ----------------
     const double* dcol = S + (size_t)(k * NB) * ld + (size_t)k * NB + 16 * wave + lr;
@@ -513,15 +542,16 @@ __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld,
       for (int r = 0; r < 4; ++r) R[J][r] = (J <= wave) ? dcol[(size_t)(16 * J + lk + 4 * r) * ld] : 0.0;
     v4d Tq[4];
     double tb[16];
-    if (wave == 1) panel_load<NPAN>(S, ld, k, it, 0, lr, lk, Tq, tb);
+    if (wave == 1 && !W4ROWS) panel_load<NPAN>(S, ld, k, it, 0, lr, lk, Tq, tb);
     __syncthreads();
+    if (wave == 1) STAMPW(39);
     if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);   // ahead of the panel wave sharing the SIMD
     if (wave == 0) {
       a_chain_wave<NPAN>(ia, status, L, lane, R[0]);
     } else if (wave == 1) {
       v4d R1[2] = {R[0], R[1]};
       a_worker_wave<1, NPAN>(ia, Ld, Winv, L, lane, R1);
-      panel_rows<NPAN>(S, ld, k, it, 0, lane, L, Tq, tb);      // idle from here on otherwise
+      if (!W4ROWS) panel_rows<NPAN, false>(S, ld, k, it, 0, lane, L, Tq, tb);      // idle from here on otherwise
     } else if (wave == 2) {
       v4d R2[3] = {R[0], R[1], R[2]};
       a_worker_wave<2, NPAN>(ia, Ld, Winv, L, lane, R2);
@@ -538,9 +568,9 @@ __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld,
     const int q = wave - 4;
     v4d Tq[4];
     double tb[16];
-    if (q > 0) panel_load<NPAN>(S, ld, k, it, q, lr, lk, Tq, tb);
+    if (q > 0 || W4ROWS) panel_load<NPAN>(S, ld, k, it, q, lr, lk, Tq, tb);
     __syncthreads();
-    if (q > 0) panel_rows<NPAN>(S, ld, k, it, q, lane, L, Tq, tb);
+    if (q > 0 || W4ROWS) panel_rows<NPAN, true>(S, ld, k, it, q, lane, L, Tq, tb);
     STAMPW(14);
     __syncthreads();
     STAMP(1);
