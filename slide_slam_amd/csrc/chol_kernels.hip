@@ -619,134 +619,134 @@ __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ S, int l
 extern "C" void slide_debug_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
 #endif
 
-__global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, double* __restrict__ yv) {
+// A quiet-NaN payload no solution value can equal bit for bit: dp[] is filled with it before the backward substitution,
+// whose workgroups poll the entries of the blocks they depend on ("flag in data": one round trip per link of the chain).
+constexpr unsigned long long BWD_SENT = 0x7FF8DEADBEEF0BADull;
+
+__global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, double* __restrict__ yv, double* __restrict__ dp) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < T * NB) yv[c] = S[(size_t)c * ld + (size_t)T * NB];
+  if (c < T * NB) {
+    yv[c] = S[(size_t)c * ld + (size_t)T * NB];
+    dp[c] = __longlong_as_double((long long)BWD_SENT);
+  }
 }
 
-// Backward substitution, BWD_GROUP block steps per launch (blocks kTop, kTop-1, ... in descending order).
-// Every workgroup redundantly solves the small dense chunk of the group (d_kb = L_kb,kb^-T (y_kb - couplings inside
-// the group), with the 16x16 inverses of the factorisation) and then applies the group's L tiles to its own 64
-// columns:  y_c -= L[kb-block, c]^T d_kb.  EVERYTHING the chain needs (coupling tiles, own tiles, the off-diagonal
-// 16x16 blocks of each L_kk and the 16x16 inverses) is fetched up front into registers in one wave of loads, so
-// the dependent phases run from registers / LDS only; tiles are reduced over rows through an LDS transpose.
-constexpr int BWD_GROUP = 3;
-
-__device__ inline double bwd_tile_dot(double (*tile)[NB + 1], const double* d, int tid) {
-  const int c = tid >> 2, part = tid & 3;
-  double s = 0.0;
+// Backward substitution L^T x = y as ONE launch: workgroup b owns block c = T-1-b.  It accumulates
+//   y_c - sum_{j > c} L(j, c)^T x_j
+// in descending j as the x_j appear in dp (published by the workgroups of LOWER index, which the dispatcher starts first, so
+// every wait is on a workgroup that is resident or finished), then x_c = (L_cc^-1)^T (.) and publishes it.  The tiles L(j, c)
+// do not depend on x and are prefetched three ahead; the explicit 64x64 inverse of L_cc is assembled from the 16x16 inverses
+// and sub-tiles of the factorisation while the workgroup would otherwise wait.  Polling loads and publishing stores are
+// relaxed device-scope atomics (they bypass the non-coherent cache levels between XCDs); the data is its own flag.
+__global__ __launch_bounds__(256) void k_chol_bwd_chain(const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
+                                                        const double* __restrict__ Winv, const double* __restrict__ yv, double* dp, int* status) {
+  __shared__ double Ms[NB][NB + 1];     // M = L_cc^-1 (lower triangle), Ms[row][col]
+  __shared__ double Lo[6][256];         // off-diagonal 16x16 blocks (b > a) of L_cc: Lo[b (b-1)/2 + a][col * 16 + row]
+  __shared__ double Ws[4][256];         // 16x16 inverses: Ws[b][col * 16 + row]
+  __shared__ double tmp[256];
+  __shared__ double xs[2][NB];
+  __shared__ double ys[NB];
+  const int tid = threadIdx.x;
+  const int c = T - 1 - (int)blockIdx.x;
+  const int col = tid >> 2, part = tid & 3;            // tile work: column col, rows 16 part .. 16 part + 15
+  const int nj = T - 1 - c;                            // tiles (j, c), j = T-1-q, q = 0 .. nj-1
+  constexpr int RB = 3;
+  double tr[RB][16];
+  const double* tcol = S + (size_t)(c * NB + col) * ld + 16 * part;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) s += tile[c][16 * part + r] * d[16 * part + r];
-  s += __shfl_xor(s, 1);
-  s += __shfl_xor(s, 2);
-  return s;   // valid where part == 0
-}
-
-__global__ __launch_bounds__(256) void k_chol_bwd(const double* __restrict__ S, int ld, int kTop, int nsteps,
-                                                  const double* __restrict__ Ld, const double* __restrict__ Winv,
-                                                  double* __restrict__ yv, double* __restrict__ dp) {
-  constexpr int G = BWD_GROUP;
-  __shared__ double yk[G][NB];
-  __shared__ double dk[G][NB];
-  __shared__ double tile[NB][NB + 1];
-  __shared__ double Lo[G][6][256];   // off-diagonal 16x16 blocks (b > c) of L_kb,kb : Lo[s][b*(b-1)/2 + c][col*16 + row]
-  __shared__ double Ws[G][4][256];   // 16x16 inverses
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cb = blockIdx.x;
-  const bool has_cols = cb < kTop - nsteps + 1;
-  // ---- one wave of loads -------------------------------------------------------------------------------
-  double tc[G][G][16];   // coupling tiles  (rows block kTop - sp, columns block kTop - sI), sp < sI
-  double to[G][16];      // own tiles       (rows block kTop - sI, columns block cb)
+  for (int q = 0; q < RB; ++q) {
+    if (q < nj) {
+      const double* tp = tcol + (size_t)(T - 1 - q) * NB;
 #pragma unroll
-  for (int sI = 0; sI < G; ++sI) {
-#pragma unroll
-    for (int sp = 0; sp < G; ++sp) {
-      if (sp < sI) {
-#pragma unroll
-        for (int m = 0; m < 16; ++m)
-          tc[sp][sI][m] = (sI < nsteps) ? S[(size_t)((kTop - sI) * NB + wave + 4 * m) * ld + (size_t)(kTop - sp) * NB + lane] : 0.0;
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < 16; ++m)
-      to[sI][m] = (has_cols && sI < nsteps) ? S[(size_t)(cb * NB + wave + 4 * m) * ld + (size_t)(kTop - sI) * NB + lane] : 0.0;
-  }
-#pragma unroll
-  for (int sI = 0; sI < G; ++sI) {
-    if (sI < nsteps) {
-      const int kb = kTop - sI;
-      const double* Ldk = Ld + (size_t)kb * NB * NB;
-      const double* Wk = Winv + (size_t)kb * 1024;
-      // thread tid -> (col = tid >> 4, row = tid & 15) of each 16x16 block
-#pragma unroll
-      for (int b = 1; b < 4; ++b)
-#pragma unroll
-        for (int c = 0; c < b; ++c)
-          Lo[sI][b * (b - 1) / 2 + c][tid] = Ldk[(size_t)(16 * c + (tid >> 4)) * NB + 16 * b + (tid & 15)];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) Ws[sI][b][tid] = Wk[(size_t)b * 256 + tid];
+      for (int r = 0; r < 16; ++r) tr[q][r] = tp[r];
     }
   }
-  for (int e = tid; e < nsteps * NB; e += 256) yk[e / NB][e % NB] = yv[(kTop - e / NB) * NB + e % NB];
+  const double y0 = yv[c * NB + col];
+  {
+    const double* Ldk = Ld + (size_t)c * NB * NB;
+    const double* Wk = Winv + (size_t)c * 1024;
+#pragma unroll
+    for (int b = 1; b < 4; ++b)
+#pragma unroll
+      for (int a = 0; a < b; ++a) Lo[b * (b - 1) / 2 + a][tid] = Ldk[(size_t)(16 * a + (tid >> 4)) * NB + 16 * b + (tid & 15)];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) Ws[b][tid] = Wk[(size_t)b * 256 + tid];
+  }
   __syncthreads();
-  // ---- dependent chain ---------------------------------------------------------------------------------
+  {
+    // M_bb = W_b ; M_ba = -W_b sum_{m = a}^{b-1} L_bm M_ma  (b > a), by distance from the diagonal; thread = element (r, cc)
+    const int r = tid & 15, cc = tid >> 4;
 #pragma unroll
-  for (int sI = 0; sI < G; ++sI) {
-    if (sI < nsteps) {
-      const int kb = kTop - sI;
+    for (int b = 0; b < 4; ++b) Ms[16 * b + r][16 * b + cc] = Ws[b][cc * 16 + r];
+    __syncthreads();
 #pragma unroll
-      for (int sp = 0; sp < G; ++sp) {
-        if (sp < sI) {   // y_kb -= L[kTop - sp, kb]^T d_{kTop - sp}
+    for (int d = 1; d < 4; ++d) {
 #pragma unroll
-          for (int m = 0; m < 16; ++m) tile[wave + 4 * m][lane] = tc[sp][sI][m];
-          __syncthreads();
-          const double v = bwd_tile_dot(tile, dk[sp], tid);
-          if ((tid & 3) == 0) yk[sI][tid >> 2] -= v;
-          __syncthreads();
-        }
-      }
-      if (wave == 0) {
-        // x_b = W_b^T (y_b - sum_{c > b} L_cb^T x_c),  b = 3..0, inside the 64x64 diagonal block kb (LDS only)
+      for (int a = 0; a + d < 4; ++a) {
+        const int b = a + d;
+        double t = 0.0;
 #pragma unroll
-        for (int b = 3; b >= 0; --b) {
-          if (lane < 16) {
-            double s = 0.0;
+        for (int m = a; m < b; ++m)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) s += Ws[sI][b][lane * 16 + j] * yk[sI][16 * b + j];   // (W_b)[j][lane]
-            dk[sI][16 * b + lane] = s;
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (b > 0 && lane < 16 * b) {
-            // y[m] -= sum_n L[16b + n][m] x_n ,  m = lane in block c = lane >> 4
-            const int c = lane >> 4, cc = lane & 15;
-            double s = 0.0;
-#pragma unroll
-            for (int n = 0; n < 16; ++n) s += Lo[sI][b * (b - 1) / 2 + c][cc * 16 + n] * dk[sI][16 * b + n];
-            yk[sI][lane] -= s;
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-        if (blockIdx.x == 0) dp[kb * NB + lane] = dk[sI][lane];
-      }
-      __syncthreads();
-    }
-  }
-  // ---- own 64 columns (all of them lie left of the whole group) ------------------------------------------
-  if (has_cols) {
-    double acc = 0.0;
-#pragma unroll
-    for (int sI = 0; sI < G; ++sI) {
-      if (sI < nsteps) {
-#pragma unroll
-        for (int m = 0; m < 16; ++m) tile[wave + 4 * m][lane] = to[sI][m];
+          for (int n = 0; n < 16; ++n) t += Lo[b * (b - 1) / 2 + m][n * 16 + r] * Ms[16 * m + n][16 * a + cc];
+        tmp[cc * 16 + r] = t;
         __syncthreads();
-        acc += bwd_tile_dot(tile, dk[sI], tid);
+        double v = 0.0;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) v += Ws[b][n * 16 + r] * tmp[cc * 16 + n];
+        Ms[16 * b + r][16 * a + cc] = -v;
         __syncthreads();
       }
     }
-    if ((tid & 3) == 0) yv[cb * NB + (tid >> 2)] -= acc;
   }
+  double acc = 0.0;
+  for (int q0 = 0; q0 < nj; q0 += RB) {
+#pragma unroll
+    for (int qq = 0; qq < RB; ++qq) {
+      const int q = q0 + qq;
+      if (q < nj) {
+        const int j = T - 1 - q;
+        if (tid < NB) {
+          double v;
+          int spins = 0;
+          for (;;) {
+            v = __hip_atomic_load(dp + (size_t)j * NB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned long long)__double_as_longlong(v) != BWD_SENT) break;
+            if (++spins > (1 << 21)) {          // exit condition every wave reaches: give up (seconds), flag the solve as failed
+              v = __builtin_nan("");
+              atomicOr(&status[1], 2);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          xs[q & 1][tid] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc += tr[qq][r] * xs[q & 1][16 * part + r];
+        if (q + RB < nj) {
+          const double* tp = tcol + (size_t)(T - 1 - (q + RB)) * NB;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tr[qq][r] = tp[r];
+        }
+      }
+    }
+  }
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  if (part == 0) ys[col] = y0 - acc;
+  __syncthreads();
+  double x = 0.0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = 16 * part + r;
+    x += (row >= col) ? Ms[row][col] * ys[row] : 0.0;
+  }
+  x += __shfl_xor(x, 1);
+  x += __shfl_xor(x, 2);
+  if (part == 0) __hip_atomic_store(dp + (size_t)c * NB + col, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
 
 // ---- marginal covariance of one pose (getPoseCovariance graph.cpp:314-323) ---------------------------------------------------
 // Cov = E^T S^-1 E = Y^T Y with L Y = E (E = the six unit columns of the pose): a forward substitution with six right-hand
@@ -861,22 +861,18 @@ void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv,
   hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nA + extra)), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status, ctr, kb, (int)nP,
                      (int)g0, (int)g1, (int)nX, a_joins);
 }
-void launch_chol_extract_y(const double* S, int ld, int T, double* yv, hipStream_t s) {
-  hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv);
+void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, hipStream_t s) {
+  hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv, dp);
 }
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp,
-                         hipStream_t s) {
-  for (int kTop = T - 1; kTop >= 0; kTop -= BWD_GROUP) {
-    const int nsteps = kTop + 1 < BWD_GROUP ? kTop + 1 : BWD_GROUP;
-    const int ncol = kTop - nsteps + 1;          // column blocks left of the group
-    hipLaunchKernelGGL(k_chol_bwd, dim3(ncol > 0 ? ncol : 1), dim3(256), 0, s, S, ld, kTop, nsteps, Ld, Winv, yv, dp);
-  }
+                         int* status, hipStream_t s) {
+  hipLaunchKernelGGL(k_chol_bwd_chain, dim3(T), dim3(256), 0, s, S, ld, T, Ld, Winv, yv, dp, status);
 }
 
 int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double* yv, double* dp, int* status, int* ctr, hipStream_t s) {
   for (int k = 0; k < T; ++k) launch_chol_step(S, ld, k, T, Ld + (size_t)k * NB * NB, Winv + (size_t)k * 1024, status, ctr, s);
-  launch_chol_extract_y(S, ld, T, yv, s);
-  launch_chol_bwd_all(S, ld, T, Ld, Winv, yv, dp, s);
+  launch_chol_extract_y(S, ld, T, yv, dp, s);
+  launch_chol_bwd_all(S, ld, T, Ld, Winv, yv, dp, status, s);
   return 0;
 }
 

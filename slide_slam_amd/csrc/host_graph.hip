@@ -481,8 +481,8 @@ int HostGraph::enqueue_iteration(bool lookahead) {
   (void)lookahead;
   for (int k = 0; k < G.T; ++k)
     STAGE(5, launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, s));
-  STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, s));
-  STAGE(8, launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, s));
+  STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, s));
+  STAGE(8, launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, s));
   STAGE(9, launch_backsub(G, 0, s));
   STAGE(10, launch_estimate(G, s));
 #undef STAGE
@@ -590,8 +590,8 @@ int HostGraph::enqueue_phase(int phase, double* d_buf) {
     launch_schur(G, s);
     for (int k = 0; k < G.T; ++k)
       launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, s);
-    launch_chol_extract_y(G.S, G.ld, G.T, G.yv, s);
-    launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, s);
+    launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, s);
+    launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, s);
     launch_backsub(G, 1, s);
     launch_shared_pack(G, 1, d_buf, s);
   } else {

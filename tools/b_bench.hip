@@ -381,6 +381,84 @@ __global__ __launch_bounds__(512) void k_v4(double* __restrict__ S, int ld, int 
   }
 }
 
+// ---- V5: V4 with the C loads issued after the last operand refill of the item (next item's operand ring filled in the tail, C added at the end) --------------------
+template <int KS, int RD, bool XPF>
+__global__ __launch_bounds__(512) void k_v5(double* __restrict__ S, int ld, int kb, int T, int nP, int g0, int g1) {
+  static_assert(KS % RD == 0, "ring slots must line up across items");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lk = lane >> 4;
+  const long long nG = (long long)nP * (nP + 1) / 2;
+  const int ch = (wave >> 1) & 1, rh = wave & 1;
+  auto dec = [&](int g, int& i, int& j, bool& ok) {
+    if (g >= g1) { ok = false; i = j = 0; return; }
+    int j0;
+    decode(g, kb, nP, nG, i, j0);
+    j = j0 + (wave >> 2);
+    ok = !(i > T || j > T - 1 || i < j);
+  };
+  v2dd pa[RD], pb[RD];
+  int g = g0 + blockIdx.x, ci, cj; bool cok;
+  dec(g, ci, cj, cok);
+  auto pjp = [&](int j) { return S + (size_t)((kb - 2) * NB + lk) * ld + (size_t)j * NB + 32 * ch + 2 * lr; };
+  auto pip = [&](int i) { return S + (size_t)((kb - 2) * NB + lk) * ld + (size_t)i * NB + 32 * rh + 2 * lr; };
+  if (cok && XPF) {
+    const double* pjh = pjp(cj); const double* pih = pip(ci);
+#pragma unroll
+    for (int pre = 0; pre < RD - 1; ++pre) { pa[pre] = *(const v2dd*)(pjh + (size_t)(4 * pre) * ld); pb[pre] = *(const v2dd*)(pih + (size_t)(4 * pre) * ld); }
+  }
+  while (g < g1) {
+    const int gn = g + gridDim.x;
+    int ni, nj; bool nok;
+    dec(gn, ni, nj, nok);
+    const double* npjh = pjp(nj); const double* npih = pip(ni);
+    if (cok) {
+      const double* pjh = pjp(cj); const double* pih = pip(ci);
+      double* cbh = S + (size_t)(cj * NB + 32 * ch + 2 * lk) * ld + (size_t)ci * NB + 32 * rh + 2 * lr;
+      if (!XPF) {
+#pragma unroll
+        for (int pre = 0; pre < RD - 1; ++pre) { pa[pre] = *(const v2dd*)(pjh + (size_t)(4 * pre) * ld); pb[pre] = *(const v2dd*)(pih + (size_t)(4 * pre) * ld); }
+      }
+      v2dd cin[2][4];
+      v4d acc[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) { acc[a][0] = v4d{0.0, 0.0, 0.0, 0.0}; acc[a][1] = v4d{0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int f = ks + RD - 1;
+        if (f == KS) {
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cin[a][r] = *(const v2dd*)(cbh + (size_t)(8 * r + a) * ld);
+        }
+        if (f < KS) {
+          pa[f % RD] = *(const v2dd*)(pjh + (size_t)(4 * f) * ld); pb[f % RD] = *(const v2dd*)(pih + (size_t)(4 * f) * ld);
+        } else if (XPF && nok) {
+          pa[f % RD] = *(const v2dd*)(npjh + (size_t)(4 * (f - KS)) * ld); pb[f % RD] = *(const v2dd*)(npih + (size_t)(4 * (f - KS)) * ld);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const double na = -pa[ks % RD][a];
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = mfma_f64(na, pb[ks % RD][b], acc[a][b]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v2dd c2; c2[0] = cin[a][r][0] + acc[a][0][r]; c2[1] = cin[a][r][1] + acc[a][1][r];
+          *(v2dd*)(cbh + (size_t)(8 * r + a) * ld) = c2;
+        }
+    } else if (nok && XPF) {
+#pragma unroll
+      for (int pre = 0; pre < RD - 1; ++pre) { pa[pre] = *(const v2dd*)(npjh + (size_t)(4 * pre) * ld); pb[pre] = *(const v2dd*)(npih + (size_t)(4 * pre) * ld); }
+    }
+    g = gn; ci = ni; cj = nj; cok = nok;
+  }
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
 int main(int argc, char** argv) {
@@ -465,6 +543,20 @@ int main(int argc, char** argv) {
     run("v4 16B pipelined RD4", [&] { hipLaunchKernelGGL((k_v4<32, 4, true>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1); }, nullptr);
     run("v4 16B C-at-end RD4", [&] { hipLaunchKernelGGL((k_v4<32, 4, false>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1); }, nullptr);
     run("v4 16B C-at-end RD8", [&] { hipLaunchKernelGGL((k_v4<32, 8, false>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1); }, nullptr);
+    run("v5 late C RD8", [&] { hipLaunchKernelGGL((k_v5<32, 8, true>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1); }, nullptr);
+    {
+      std::vector<double> a(n), b(n);
+      CK(hipMemcpy(S, h.data(), n * 8, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL((k_v5<32, 8, true>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(a.data(), S, n * 8, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(b.data(), S2, n * 8, hipMemcpyDeviceToHost));
+      double md = 0; size_t nd = 0;
+      for (size_t i = 0; i < n; ++i) { double d = fabs(a[i] - b[i]); if (d > md) md = d; if (d != 0) ++nd; }
+      printf("   v5 vs v0: max |diff| %.3e, %zu differing\n", md, nd);
+    }
+    run("v5 late C RD4", [&] { hipLaunchKernelGGL((k_v5<32, 4, true>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1); }, nullptr);
+    run("v5 late C RD16", [&] { hipLaunchKernelGGL((k_v5<32, 16, true>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1); }, nullptr);
     run("v1 lds no C", [&] { hipLaunchKernelGGL((k_v1<32, true>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1); }, nullptr);
   }
   return 0;
