@@ -183,7 +183,6 @@ __device__ __forceinline__ BItem b_decode(int g, int nItems, int nR, int g0, int
 // across the T-k workgroups costs no latency and keeps L_kk out of L2.
 constexpr int PSTR = 80;   // LDS column stride of the staged panel tile: the four 16-lane groups of a ds_read_b64 fall in disjoint bank halves
 constexpr int WT = 2;      // the worker that carries the identity pseudo-tiles
-constexpr bool W4ROWS = false;   // rows 0..15 of the panel tile on wave 4 (beside the chain wave) instead of worker 1 after its hand-off
 struct ALds {
   double Pk[NB][PSTR];  // pending panel tiles (k, k-NPAN .. k-1): Pk[kk][r] = L[k*NB + r][(k-NPAN)*NB + kk]   (rows of the diagonal block)
   double mop[16][64];   // iteration n: A operand of the panel MFMAs, lane image
@@ -442,7 +441,7 @@ __device__ __forceinline__ void panel_load(const double* __restrict__ S, int ld,
 // chain wave finishes.  Nothing before the first phase is through: until then the factor waves are busy with panel k-1
 // themselves and this wave would only compete for the matrix pipe and the LDS.
 template <int NPAN, bool EARLY>
-__device__ __forceinline__ void panel_rows(double* __restrict__ S, int ld, int k, int it, int q, int lane, ALds& L, v4d (&Tq)[4],
+__device__ __forceinline__ void panel_rows(double* __restrict__ S, int ld, int k, int it, int q, int gate, int lane, ALds& L, v4d (&Tq)[4],
                                            const double (&tb)[16]) {
   const int lr = lane & 15, lk = lane >> 4;
   double* tcol = S + (size_t)(k * NB) * ld + (size_t)it * NB + 16 * q + lr;
@@ -456,8 +455,8 @@ __device__ __forceinline__ void panel_rows(double* __restrict__ S, int ld, int k
   for (int b = 0; b < 4; ++b) {
     if (b == 0) {
       if (NPAN > 0 && EARLY) {
-        if (q == 1) lds_wait(&L.d_ready[1], 1);      // shares its SIMD with worker 1 / 2: not before that one's hand-off
-        if (q == 2) lds_wait(&L.d_ready[2], 1);      // (worker 3 has two phases of slack: wave 7 starts at once)
+        if (gate == 1) lds_wait(&L.d_ready[1], 1);   // wave 5 / 6 share their SIMD with worker 1 / 2: not before that one's hand-off
+        if (gate == 2) lds_wait(&L.d_ready[2], 1);   // (worker 3 has two phases of slack: wave 7 starts at once)
         // the whole pending update at once, while the factor waves are in their own: the phases that follow then see
         // only the short substitution bursts of this wave on their SIMD
 #pragma unroll
@@ -510,7 +509,7 @@ __device__ __forceinline__ void panel_rows(double* __restrict__ S, int ld, int k
 }
 
 template <int NPAN>
-__device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld, int k, int ia, double* __restrict__ Ld,
+__device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld, int k, int ia, int half, double* __restrict__ Ld,
                                                  double* __restrict__ Winv, int* status, ALds& L) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..7
@@ -542,7 +541,7 @@ __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld,
       for (int r = 0; r < 4; ++r) R[J][r] = (J <= wave) ? dcol[(size_t)(16 * J + lk + 4 * r) * ld] : 0.0;
     v4d Tq[4];
     double tb[16];
-    if (wave == 1 && !W4ROWS) panel_load<NPAN>(S, ld, k, it, 0, lr, lk, Tq, tb);
+    if (wave == 1 && half < 0) panel_load<NPAN>(S, ld, k, it, 0, lr, lk, Tq, tb);
     __syncthreads();
     if (wave == 1) STAMPW(39);
     if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);   // ahead of the panel wave sharing the SIMD
@@ -551,7 +550,7 @@ __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld,
     } else if (wave == 1) {
       v4d R1[2] = {R[0], R[1]};
       a_worker_wave<1, NPAN>(ia, Ld, Winv, L, lane, R1);
-      if (!W4ROWS) panel_rows<NPAN, false>(S, ld, k, it, 0, lane, L, Tq, tb);      // idle from here on otherwise
+      if (half < 0) panel_rows<NPAN, false>(S, ld, k, it, 0, 0, lane, L, Tq, tb);      // idle from here on otherwise
     } else if (wave == 2) {
       v4d R2[3] = {R[0], R[1], R[2]};
       a_worker_wave<2, NPAN>(ia, Ld, Winv, L, lane, R2);
@@ -565,22 +564,25 @@ __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld,
   } else {
     // ---------------- panel waves 5..7: rows 16..63 of tile (it, k); rows 0..15 go to worker 1 (idle after its
     // hand-off), so that the chain wave has its SIMD to itself (wave 4 only keeps the barriers company) ----------------
-    const int q = wave - 4;
+    // rows of the panel tile: 16 (wave - 4) .. ; with two workgroups per tile (half = 0 / 1) waves 5, 6 take rows 32 half + 0 / 16,
+    // wave 7 and worker 1 none
+    const int q = half < 0 ? wave - 4 : (wave == 5 ? 2 * half : (wave == 6 ? 2 * half + 1 : -1));
+    const bool rows = half < 0 ? q > 0 : q >= 0;
     v4d Tq[4];
     double tb[16];
-    if (q > 0 || W4ROWS) panel_load<NPAN>(S, ld, k, it, q, lr, lk, Tq, tb);
+    if (rows) panel_load<NPAN>(S, ld, k, it, q, lr, lk, Tq, tb);
     __syncthreads();
-    if (q > 0 || W4ROWS) panel_rows<NPAN, true>(S, ld, k, it, q, lane, L, Tq, tb);
+    if (rows) panel_rows<NPAN, true>(S, ld, k, it, q, wave - 4, lane, L, Tq, tb);
     STAMPW(14);
     __syncthreads();
     STAMP(1);
     STAMP(2);
   }
 }
-__device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int k, int ia, double* __restrict__ Ld,
+__device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int k, int ia, int half, double* __restrict__ Ld,
                                             double* __restrict__ Winv, int* status, ALds& L) {
-  if (k > 0) step_type_a_impl<1>(S, ld, k, ia, Ld, Winv, status, L);
-  else step_type_a_impl<0>(S, ld, k, ia, Ld, Winv, status, L);
+  if (k > 0) step_type_a_impl<1>(S, ld, k, ia, half, Ld, Winv, status, L);
+  else step_type_a_impl<0>(S, ld, k, ia, half, Ld, Winv, status, L);
 }
 
 // One launch per block column k.  Workgroups 0 .. T-k-1 are type A (column k with its pending panel k-1); every workgroup of
@@ -589,13 +591,13 @@ __device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int 
 // the one workgroup per CU the register-heavy kernel gets.  ctr[k+1] is cleared here for the next launch (ctr[0..1] start at 0).
 __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Ld,
                                                    double* __restrict__ Winv, int* status, int* __restrict__ ctr, int kb, int nP,
-                                                   int g0, int g1, int nX, int a_joins) {
+                                                   int g0, int g1, int nX, int a_joins, int a_split) {
   __shared__ ALds L;
   __shared__ int s_g;
-  const int nA = T - k;
+  const int nA = (T - k) << a_split;      // a_split: two type-A workgroups per tile, 32 panel rows each (A-bound launches: the CUs are there)
   if (blockIdx.x == 0 && threadIdx.x == 0) ctr[k + 1] = 0;
   if ((int)blockIdx.x < nA) {
-    step_type_a(S, ld, k, (int)blockIdx.x, Ld, Winv, status, L);
+    step_type_a(S, ld, k, (int)blockIdx.x >> a_split, a_split ? (int)(blockIdx.x & 1) : -1, Ld, Winv, status, L);
     if (!a_joins) return;        // the queue workers are through before the chain is: an item taken now would only add a tail
   }
   const int nR = g1 - g0, nItems = nR + nX;
@@ -853,13 +855,17 @@ void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv,
   }
   const long long nX = (k & 1) && k + 1 < T ? (T - k + 1) / 2 : 0;   // column items: tile rows k+1 .. T of column k+1, two per item
   const long long nB = g1 - g0 + nX;
+  static const int split_pct = getenv("SLIDE_CHOL_ASPLIT") ? atoi(getenv("SLIDE_CHOL_ASPLIT")) : 100;   // diagnostic: 0 = never
+  // two workgroups per type-A tile once the launch is bound by the chain, not by the flood
+  const int a_split = (k > 0 && (2 * nA + nB) * 100 <= (long long)n_cu * split_pct) ? 1 : 0;
+  const long long nAw = nA << a_split;
   const long long extra = nB < n_cu ? nB : n_cu;                // queue workers beside the type-A workgroups (one 512-thread workgroup per CU)
   // type-A workgroups join the queue only when the flood needs more than a round of the other CUs (~ the chain's length)
-  const long long free_cu = n_cu - nA > 8 ? n_cu - nA : 8;
+  const long long free_cu = n_cu - nAw > 8 ? n_cu - nAw : 8;
   static const int join_mul = getenv("SLIDE_CHOL_JOIN") ? atoi(getenv("SLIDE_CHOL_JOIN")) : 1;
   const int a_joins = nB > join_mul * free_cu ? 1 : 0;
-  hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nA + extra)), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status, ctr, kb, (int)nP,
-                     (int)g0, (int)g1, (int)nX, a_joins);
+  hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nAw + extra)), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status, ctr, kb, (int)nP,
+                     (int)g0, (int)g1, (int)nX, a_joins, a_split);
 }
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, hipStream_t s) {
   hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv, dp);
