@@ -1,6 +1,6 @@
 # Dense SPD solve at the bench's reduced-system size through the C-ABI (diagnostic for rocprofv3 kernel traces).
 import sys, os, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import slide_slam_amd as s
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3776
 rng = np.random.default_rng(0)
