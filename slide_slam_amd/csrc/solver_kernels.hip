@@ -572,10 +572,14 @@ __global__ __launch_bounds__(256) void k_schur(GraphDev G) {
   __shared__ double schur_tile[6][192];
   __shared__ long long pj_ed[SCHUR_PJ_CAP];
   __shared__ int pj_lm[SCHUR_PJ_CAP];
-  const int pj = blockIdx.y;
-  if (32 * (int)blockIdx.x > G.P - 1 - pj) return;
+  const int pj = blockIdx.x;
   const int tid = threadIdx.x;
+  // dynamic LDS: landmark -> first entry of pose j's list (shorts), then the bitmap of the poses >= j that share a landmark or a
+  // relative-pose factor with pose j — only those blocks of the strip are non-zero, all others are written as zeros unseen
+  unsigned* adj = reinterpret_cast<unsigned*>(schur_slot + (G.L + 7) / 8 * 8);
+  const int adj_words = (G.P + 31) / 32 + 1;
   for (int t = tid; t < G.L; t += 256) schur_slot[t] = -1;
+  for (int t = tid; t < adj_words; t += 256) adj[t] = 0u;
   __syncthreads();
   const int b0 = G.pose_ptr[pj], nb = G.pose_ptr[pj + 1] - b0;
   for (int q = tid; q < nb; q += 256) {
@@ -583,10 +587,39 @@ __global__ __launch_bounds__(256) void k_schur(GraphDev G) {
     if (q == 0 || G.pose_lms[b0 + q - 1] != l) schur_slot[l] = (short)q;
     if (q < SCHUR_PJ_CAP) { pj_lm[q] = l; pj_ed[q] = G.pose_ed[b0 + q]; }
   }
+  // every pose that observes one of pose j's landmarks: eight lanes per list entry, strided over that landmark's factors
+  for (int q = tid >> 3; q < nb; q += 32) {
+    const int l = G.pose_lms[b0 + q];
+    if (q > 0 && G.pose_lms[b0 + q - 1] == l) continue;
+    const int f1 = G.lm_ptr[l + 1];
+    for (int f = G.lm_ptr[l] + (tid & 7); f < f1; f += 8) {
+      const int p = G.lf_pose[G.lm_fids[f]];
+      if (p >= pj) atomicOr(&adj[p >> 5], 1u << (p & 31));
+    }
+  }
+  for (int q = G.pose_bt_ptr[pj] + tid; q < G.pose_bt_ptr[pj + 1]; q += 256) {
+    const int ent = G.pose_bt[q];
+    const int b = ent >> 1;
+    const int other = (ent & 1) ? G.bt_i[b] : G.bt_j[b];
+    if (other >= pj) atomicOr(&adj[other >> 5], 1u << (other & 31));
+  }
+  if (tid == 0) atomicOr(&adj[pj >> 5], 1u << (pj & 31));
   __syncthreads();
   const int sub = tid & 7;
-  const int pi = pj + 32 * (int)blockIdx.x + (tid >> 3);
-  const bool live = pi < G.P;
+  for (int pi0 = pj; pi0 < G.P; pi0 += 32) {
+    const int nval = 6 * min(32, G.P - pi0);
+    double* Sb = G.S + (size_t)(6 * pj) * G.ld + 6 * (size_t)pi0;
+    const int w = pi0 >> 5, sh = pi0 & 31;
+    const unsigned m = sh ? ((adj[w] >> sh) | (adj[w + 1] << (32 - sh))) : adj[w];      // poses pi0 .. pi0 + 31
+    if (m == 0u) {
+      for (int e = tid; e < 6 * 192; e += 256) {
+        const int c = e / 192, r = e % 192;
+        if (r < nval) Sb[(size_t)c * G.ld + r] = 0.0;
+      }
+      continue;
+    }
+  const int pi = pi0 + (tid >> 3);
+  const bool live = pi < G.P && ((m >> (tid >> 3)) & 1u);
   double acc[36];
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
@@ -687,12 +720,11 @@ __global__ __launch_bounds__(256) void k_schur(GraphDev G) {
       for (int a = 0; a < 6; ++a) schur_tile[c][6 * (tid >> 3) + a] = acc[6 * a + c];
     }
   __syncthreads();
-  const int pi0 = pj + 32 * (int)blockIdx.x;
-  const int nval = 6 * min(32, G.P - pi0);
-  double* Sb = G.S + (size_t)(6 * pj) * G.ld + 6 * (size_t)pi0;
   for (int e = tid; e < 6 * 192; e += 256) {
     const int c = e / 192, r = e % 192;
     if (r < nval) Sb[(size_t)c * G.ld + r] = schur_tile[c][r];
+  }
+  __syncthreads();      // the tile is reused by the next chunk
   }
 }
 
@@ -851,7 +883,7 @@ void launch_pose(const GraphDev& G, hipStream_t s) {
 }
 void launch_schur(const GraphDev& G, hipStream_t s) {
   if (G.P == 0) return;
-  hipLaunchKernelGGL(k_schur, dim3(blocks_for(G.P, 32), G.P), dim3(256), (size_t)((G.L + 7) / 8 * 8) * sizeof(short), s, G);
+  hipLaunchKernelGGL(k_schur, dim3(G.P), dim3(256), (size_t)((G.L + 7) / 8 * 8) * sizeof(short) + (size_t)((G.P + 31) / 32 + 1) * sizeof(unsigned), s, G);
   const long long NT = (long long)G.T * NB;
   const long long tot = NT + (NT - 6LL * G.P) * NT;
   hipLaunchKernelGGL(k_pad_rhs, dim3(blocks_for(tot, 256)), dim3(256), 0, s, G);
