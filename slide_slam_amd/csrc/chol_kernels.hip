@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256) void k_chol_bwd_chain(const double* __restrict
   __shared__ double Ms[NB][NB + 1];     // M = L_cc^-1 (lower triangle), Ms[row][col]
   __shared__ double Lo[6][256];         // off-diagonal 16x16 blocks (b > a) of L_cc: Lo[b (b-1)/2 + a][col * 16 + row]
   __shared__ double Ws[4][256];         // 16x16 inverses: Ws[b][col * 16 + row]
-  __shared__ double tmp[256];
+  __shared__ double tmp[3][256];
   __shared__ double xs[2][NB];
   __shared__ double ys[NB];
   const int tid = threadIdx.x;
@@ -691,16 +691,23 @@ __global__ __launch_bounds__(256) void k_chol_bwd_chain(const double* __restrict
         for (int m = a; m < b; ++m)
 #pragma unroll
           for (int n = 0; n < 16; ++n) t += Lo[b * (b - 1) / 2 + m][n * 16 + r] * Ms[16 * m + n][16 * a + cc];
-        tmp[cc * 16 + r] = t;
-        __syncthreads();
+        tmp[a][cc * 16 + r] = t;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int a = 0; a + d < 4; ++a) {
+        const int b = a + d;
         double v = 0.0;
 #pragma unroll
-        for (int n = 0; n < 16; ++n) v += Ws[b][n * 16 + r] * tmp[cc * 16 + n];
+        for (int n = 0; n < 16; ++n) v += Ws[b][n * 16 + r] * tmp[a][cc * 16 + n];
         Ms[16 * b + r][16 * a + cc] = -v;
-        __syncthreads();
       }
+      __syncthreads();
     }
   }
+  double mreg[16];                       // own column of M^T: rows 16 part .. of column col (zero above the diagonal)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mreg[r] = (16 * part + r >= col) ? Ms[16 * part + r][col] : 0.0;
   double acc = 0.0;
   for (int q0 = 0; q0 < nj; q0 += RB) {
 #pragma unroll
@@ -740,10 +747,7 @@ __global__ __launch_bounds__(256) void k_chol_bwd_chain(const double* __restrict
   __syncthreads();
   double x = 0.0;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = 16 * part + r;
-    x += (row >= col) ? Ms[row][col] * ys[row] : 0.0;
-  }
+  for (int r = 0; r < 16; ++r) x += mreg[r] * ys[16 * part + r];
   x += __shfl_xor(x, 1);
   x += __shfl_xor(x, 2);
   if (part == 0) __hip_atomic_store(dp + (size_t)c * NB + col, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
