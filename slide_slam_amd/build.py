@@ -27,6 +27,7 @@ SOURCES = [
     ("host_graph.hip", ["-ffp-contract=off"]),
     ("host_backend.hip", ["-ffp-contract=off"]),
     ("capi.hip", ["-ffp-contract=off"]),
+    ("wire.hip", ["-ffp-contract=off"]),     # host code only: sloam_msgs wire codec + rosbag reader (include/slide_wire.h)
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-invalid-offsetof",
           "-Wno-unused-result"]
@@ -38,6 +39,7 @@ def _deps_newer(obj: str, src: str) -> bool:
     t = os.path.getmtime(obj)
     deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     deps.append(os.path.join(HERE, "..", "include", "slide_gpu.h"))
+    deps.append(os.path.join(HERE, "..", "include", "slide_wire.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 

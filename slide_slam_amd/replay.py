@@ -99,3 +99,64 @@ def replay_multi(backend, data, host=0, n_frames=None, own_node_factory=None):
         out["host_pose7"].append(pose.copy())
         out["ids"].append(ids)
     return out
+
+
+def _inverse7(a):
+    Ra, ta = pose7_to_Rt(a)
+    return pose7(Ra.T, -Ra.T @ ta)
+
+
+def replay_bag(backend, bag_path, robot=0, topic=None, n_frames=None, collect=True):
+    """ROS-free replay of a processed bag (rosbag v2.0, include/slide_wire.h): every `sloam_msgs/SemanticMeasSyncOdom` message
+    (optionally only those on `topic`) becomes one frame, converted as Robot::RobotObservationCb does (robot.cpp:100-137); the
+    relative raw odometry between consecutive observations is what SLOAMNode::runSLOAMNode feeds the graph
+    (sloamNode.cpp:770-800: relativeMotion = prevOdom^-1 * currOdom)."""
+    from . import wire
+    prev_est = IDENT7.copy()
+    prev_odom = None
+    out = dict(pose7=[], cyl_id=[], cube_id=[], ell_id=[], t_frame=[], stamp=[])
+    with wire.Bag(bag_path) as bag:
+        for tpc, dtype, _, payload in bag:
+            if dtype != "sloam_msgs/SemanticMeasSyncOdom" or (topic is not None and tpc != topic):
+                continue
+            if n_frames is not None and len(out["t_frame"]) >= n_frames:
+                break
+            odom7, det, hdr = wire.sync_odom_to_frame(payload)
+            rel = odom7 if prev_odom is None else _compose7(_inverse7(prev_odom), odom7)
+            t0 = time.perf_counter()
+            r = backend.process_frame(robot, rel, prev_est, det, 0)
+            t1 = time.perf_counter()
+            if r["status"] != 0:
+                raise RuntimeError(f"solve failed at frame {len(out['t_frame'])}: status {r['status']}")
+            prev_est = r["pose7"].copy()
+            prev_odom = odom7
+            out["t_frame"].append(t1 - t0)
+            out["stamp"].append(hdr["stamp"])
+            if collect:
+                out["pose7"].append(prev_est.copy())
+                out["cyl_id"].append(r["cyl_id"].copy()); out["cube_id"].append(r["cube_id"].copy())
+                out["ell_id"].append(r["ell_id"].copy())
+    return out
+
+
+def log_to_sync_odom_messages(log, n_frames=None, t0=1700000000, dt=0.5, frame_id="quadrotor/base_link"):
+    """A synthetic robot log as the message stream its process node would publish: one SemanticMeasSyncOdom dict per frame with
+    the integrated raw odometry (body-frame objects as they are in the log)."""
+    P = len(log["rel7"]) if n_frames is None else n_frames
+    odom = IDENT7.copy()
+    msgs = []
+    for k in range(P):
+        odom = np.asarray(log["rel7"][k], np.float64).copy() if k == 0 else _compose7(odom, log["rel7"][k])
+        d = frame_detections(log, k)
+        t = t0 + k * dt
+        msgs.append(dict(
+            header=dict(seq=k, stamp=(int(t), int(round((t - int(t)) * 1e9))), frame_id=frame_id),
+            ellipsoid_factors=[dict(scale=d["ell_scale"][i], semantic_label=int(d["ell_label"][i]), pose=d["ell_pose7"][i])
+                               for i in range(len(d["ell_label"]))],
+            cylinder_factors=[dict(root=d["cyl_root"][i], ray=d["cyl_ray"][i], radii=[], radius=d["cyl_radius"][i], id=0,
+                                   semantic_label=int(d["cyl_label"][i])) for i in range(len(d["cyl_label"]))],
+            cuboid_factors=[dict(dim=d["cube_scale"][i], semantic_label=int(d["cube_label"][i]), pose=d["cube_pose7"][i])
+                            for i in range(len(d["cube_label"]))],
+            odometry=dict(header=dict(seq=k, stamp=(int(t), int(round((t - int(t)) * 1e9))), frame_id="world"),
+                          child_frame_id=frame_id, pose=odom)))
+    return msgs

@@ -12,8 +12,8 @@ from slide_slam_amd import api
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
-    txt = open(os.path.join(ROOT, "include", "slide_gpu.h")).read()
+def _header_functions(name="slide_gpu.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(slide_[a-z0-9_]+)\s*\(", txt)))
 
@@ -25,6 +25,9 @@ def test_every_declared_symbol_is_exported():
     missing = [f for f in declared if not hasattr(L, f)]
     assert not missing, missing
     assert sorted(api.EXPORTS) == declared
+    wire_declared = _header_functions("slide_wire.h")                 # include/slide_wire.h: wire codec + bag reader (host code)
+    assert len(wire_declared) == 14
+    assert not [f for f in wire_declared if not hasattr(L, f)]
 
 
 def test_default_params_mirror_reference_defaults():

@@ -197,3 +197,26 @@ def test_full_size_properties(gpu):
     d = ((cloud[idx].astype(np.float32) - q.astype(np.float32)) ** 2).sum(axis=1)
     assert len(idx) == 1000 and np.all(np.diff(d) >= 0)
     assert d[-1] <= np.partition(((cloud - q.astype(np.float32)) ** 2).sum(axis=1), 999)[999] * (1 + 1e-6)
+
+
+def test_replay_from_bag_equals_direct_replay(gpu, tmp_path):
+    """N1: the same frames through the wire codec + rosbag reader (SemanticMeasSyncOdom messages in a v2.0 bag written by the
+    oracle's writer) give the associations and poses of the direct replay; the oracle replays the bag's frames too."""
+    from oracle import wire_oracle as wo
+    from slide_slam_amd.replay import replay_bag, log_to_sync_odom_messages
+    data = make_dataset(SynthConfig.preset("small"))
+    log = data["logs"][0]
+    msgs = log_to_sync_odom_messages(log)
+    conns = {3: ("/quadrotor/semantic_meas_sync_odom", "sloam_msgs/SemanticMeasSyncOdom", "0" * 32)}
+    path = tmp_path / "small.bag"
+    wo.write_bag(str(path), conns, [(3, m["header"]["stamp"], wo.sync_odom(m)) for m in msgs], chunk_messages=16)
+    g_direct = replay_single(gpu.SlideBackend(gpu.default_params(), 1), log)
+    g_bag = replay_bag(gpu.SlideBackend(gpu.default_params(), 1), path)
+    assert len(g_bag["pose7"]) == len(g_direct["pose7"]) == len(log["rel7"])
+    for k in range(len(log["rel7"])):
+        for key in ("cyl_id", "cube_id", "ell_id"):
+            assert np.array_equal(g_bag[key][k], g_direct[key][k]), (k, key)
+    a, b = np.array(g_bag["pose7"]), np.array(g_direct["pose7"])
+    assert np.abs(a[:, :3] - b[:, :3]).max() < 1e-6          # the relative odometry is recomposed from the absolute one
+    o_bag = replay_bag(po.OracleBackend(po.OrcParams.default(), 1), path)
+    _compare_replay(o_bag, g_bag, log)
