@@ -270,6 +270,8 @@ __global__ __launch_bounds__(256) void k_lin_lf(GraphDev G) {
 // registers, then each lane finishes its own factors.  (M == D for all three landmark factor kinds.)
 // MODE 0: everything (single GPU).  MODE 1: accumulate only, partial sums -> lm_Hacc (54 per landmark:
 // packed lower H then g) for the cross-robot all-reduce.  MODE 2: start from the (all-reduced) sums in lm_Hacc.
+__shared__ double lm_hs[4][96];   // per wave of k_landmark: H_ll^-1 (81) + g_l (9)
+
 template <int D, int MODE>
 __device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
   constexpr int NH = D * (D + 1) / 2;
@@ -384,7 +386,21 @@ __device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
 #pragma unroll
       for (int c = 0; c < D; ++c) Hinv[a * D + c] = Hi[a][c];
   }
-  for (int q = lane; q < nf; q += 64) {
+  // E = Jp^T Jl, F = E H^-1, u = F g per factor: one lane per (factor, pose row a) pair — 6 nf items over the 64 lanes instead of
+  // one lane per factor with the other ~50 idle; H^-1 and g go through LDS (every lane holds the same copy)
+  double* hs = lm_hs[threadIdx.x >> 6];
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+#pragma unroll
+      for (int c = 0; c < D; ++c) hs[a * D + c] = Hi[a][c];
+      hs[81 + a] = g[a];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the LDS copy is written before any lane reads it
+  for (int it = lane; it < 6 * nf; it += 64) {
+    const int q = it / 6, a = it - 6 * q;
     const int f = G.lm_fids[f0 + q];
     const double* rec = G.jbuf + G.lf_joff[f];
     const double* Jp = rec + D;
@@ -392,28 +408,27 @@ __device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
     double* E = G.ebuf + G.lf_eoff[f];
     double* F = E + 6 * D;
     double* u = F + 6 * D;
+    double Ea[D];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      double Ea[D];
+    for (int c = 0; c < D; ++c) Ea[c] = 0.0;
 #pragma unroll
-      for (int c = 0; c < D; ++c) {
-        double s = 0.0;
+    for (int k = 0; k < D; ++k) {
+      const double jp = Jp[6 * k + a];
 #pragma unroll
-        for (int k = 0; k < D; ++k) s += Jp[6 * k + a] * Jl[D * k + c];
-        Ea[c] = s;
-        E[a * D + c] = s;
-      }
-      double ua = 0.0;
-#pragma unroll
-      for (int c = 0; c < D; ++c) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < D; ++k) s += Ea[k] * Hi[k][c];
-        F[a * D + c] = s;
-        ua += s * g[c];
-      }
-      u[a] = ua;
+      for (int c = 0; c < D; ++c) Ea[c] += jp * Jl[D * k + c];
     }
+#pragma unroll
+    for (int c = 0; c < D; ++c) E[a * D + c] = Ea[c];
+    double ua = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double sF = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) sF += Ea[k] * hs[k * D + c];
+      F[a * D + c] = sF;
+      ua += sF * hs[81 + c];
+    }
+    u[a] = ua;
   }
 }
 

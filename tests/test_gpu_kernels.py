@@ -15,7 +15,7 @@ def _spd(n, rng, cond=1e4):
     return (Q * d) @ Q.T
 
 
-@pytest.mark.parametrize("n", [6, 64, 65, 200, 1000])
+@pytest.mark.parametrize("n", [6, 64, 65, 130, 150, 200, 1000, 1990])   # T = 1, 1, 2, 3, 3, 4, 16, 32 block columns (odd and even, with and without padding)
 def test_dense_spd_solve(gpu, n):
     """FP64-MFMA blocked Cholesky + substitutions vs numpy (fp64): relative 1e-9 on a cond-1e4 system."""
     rng = np.random.default_rng(n)
