@@ -52,6 +52,8 @@ int HostBackend::associate(const SE3& poseEstimate, const slide_detections_t& de
   for (int i = 0; i < det.n_ell; ++i) to12(from7(det.ell_pose7 + 7 * (size_t)i), &A.det_body[2][12 * (size_t)i]);
 
   AssocFrameDev F[3];
+  if (ub.begin() != SLIDE_OK) return SLIDE_ERR_HIP;
+  struct BatchGuard { ~BatchGuard() { UploadBatch::current = nullptr; } } batch_guard;      // an error return abandons the batch
   for (int c = 0; c < 3; ++c) {
     ClassMap& M = maps[c];
     if (M.n() > ASSOC_MAX_N) {
@@ -82,25 +84,27 @@ int HostBackend::associate(const SE3& poseEstimate, const slide_detections_t& de
   to12(poseEstimate, pose12);
   if (d_pose12.upload(pose12, 0, 12, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_cls3.upload(F, 0, 3, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (ub.flush(s) != SLIDE_OK) return SLIDE_ERR_HIP;
   SL_HIP(hipMemsetAsync(d_status.d, 0, 4 * sizeof(int), s));
   launch_assoc_frame(d_cls3.d, d_pose12.d, d_status.d, s);
   int nsub[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
-  SL_HIP(hipMemcpyAsync(nsub, d_nsub.d, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
-  SL_HIP(hipMemcpyAsync(st, d_status.d, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  std::vector<int> sub_all[3];                     // the whole submap table comes along: its length is only known afterwards
+  db.add(nsub, d_nsub.d, 3 * sizeof(int));
+  db.add(st, d_status.d, 4 * sizeof(int));
   for (int c = 0; c < 3; ++c) {
+    sub_all[c].resize(std::max(maps[c].K, 1));
+    db.add(sub_all[c].data(), d_submap[c].d, sub_all[c].size() * sizeof(int));
     if (!nd[c]) continue;
-    SL_HIP(hipMemcpyAsync(A.det_world[c].data(), d_det_world[c].d, A.det_world[c].size() * sizeof(double),
-                          hipMemcpyDeviceToHost, s));
-    SL_HIP(hipMemcpyAsync(A.match_sub[c].data(), d_match_sub[c].d, nd[c] * sizeof(int), hipMemcpyDeviceToHost, s));
-    SL_HIP(hipMemcpyAsync(A.match_map[c].data(), d_match_map[c].d, nd[c] * sizeof(int), hipMemcpyDeviceToHost, s));
+    db.add(A.det_world[c].data(), d_det_world[c].d, A.det_world[c].size() * sizeof(double));
+    db.add(A.match_sub[c].data(), d_match_sub[c].d, nd[c] * sizeof(int));
+    db.add(A.match_map[c].data(), d_match_map[c].d, nd[c] * sizeof(int));
   }
-  SL_HIP(hipStreamSynchronize(s));
+  if (db.run(s) != SLIDE_OK) return SLIDE_ERR_HIP;
   SL_HIP(hipGetLastError());
   if (st[0]) return SLIDE_ERR_CAPACITY;
   for (int c = 0; c < 3; ++c) {
     // matchesMap_: submap index -> map index (std::map<int,int> in the reference)
-    maps[c].matchesMap.resize(nsub[c]);
-    if (nsub[c]) SL_HIP(hipMemcpy(maps[c].matchesMap.data(), d_submap[c].d, nsub[c] * sizeof(int), hipMemcpyDeviceToHost));
+    maps[c].matchesMap.assign(sub_all[c].begin(), sub_all[c].begin() + std::min<size_t>(nsub[c], sub_all[c].size()));
   }
   if (first_scan_shortcut && firstScan) {   // sloam.cpp:235-248: the first scan is never matched
     firstScan = false;

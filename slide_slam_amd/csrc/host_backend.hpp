@@ -53,6 +53,8 @@ class HostBackend {
   int refresh_maps();
   DevArr<double> d_det[3], d_det_world[3], d_pose12;
   DevArr<int> d_det_label[3], d_match_sub[3], d_match_map[3], d_submap[3], d_nsub, d_status;
+  UploadBatch ub;          // the ~17 uploads and ~14 downloads of one association step as one copy each
+  DownloadBatch db;
   DevArr<AssocFrameDev> d_cls3;
 };
 

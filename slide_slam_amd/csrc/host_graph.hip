@@ -329,6 +329,103 @@ int HostGraph::merge_pending() {
   return SLIDE_OK;
 }
 
+thread_local UploadBatch* UploadBatch::current = nullptr;
+UploadBatch::~UploadBatch() {
+  if (current == this) current = nullptr;
+  if (ev) (void)hipEventDestroy(ev);
+  if (h_pin) (void)hipHostFree(h_pin);
+  if (d_stage) (void)hipFree(d_stage);
+}
+int UploadBatch::begin() {
+  if (!ev) SL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  if (in_flight) { SL_HIP(hipEventSynchronize(ev)); in_flight = false; }
+  segs.clear();
+  used = 0;
+  current = this;
+  return SLIDE_OK;
+}
+int UploadBatch::reserve(size_t need) {
+  if (need <= h_cap) return SLIDE_OK;
+  size_t nc = h_cap ? h_cap : (1u << 16);
+  while (nc < need) nc *= 2;
+  unsigned char* np = nullptr;
+  SL_HIP(hipHostMalloc(reinterpret_cast<void**>(&np), nc, hipHostMallocDefault));
+  if (used) std::memcpy(np, h_pin, used);
+  if (h_pin) SL_HIP(hipHostFree(h_pin));
+  h_pin = np;
+  h_cap = nc;
+  return SLIDE_OK;
+}
+int UploadBatch::add(void* dst, const void* src, size_t bytes) {
+  const size_t off = (used + 15) & ~(size_t)15;
+  if (reserve(off + bytes) != SLIDE_OK) return SLIDE_ERR_HIP;
+  std::memcpy(h_pin + off, src, bytes);
+  segs.push_back({(unsigned long long)(uintptr_t)dst, (unsigned)off, (unsigned)bytes});
+  used = off + bytes;
+  return SLIDE_OK;
+}
+int UploadBatch::flush(hipStream_t s) {
+  current = nullptr;
+  if (segs.empty()) return SLIDE_OK;
+  const size_t desc_off = (used + 15) & ~(size_t)15;
+  const size_t total = desc_off + segs.size() * sizeof(Seg);
+  if (reserve(total) != SLIDE_OK) return SLIDE_ERR_HIP;          // the descriptors ride at the end of the same buffer
+  std::memcpy(h_pin + desc_off, segs.data(), segs.size() * sizeof(Seg));
+  if (total > d_cap) {
+    size_t nc = d_cap ? d_cap : (1u << 16);
+    while (nc < total) nc *= 2;
+    if (d_stage) { SL_HIP(hipStreamSynchronize(s)); SL_HIP(hipFree(d_stage)); d_stage = nullptr; }
+    SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_stage), nc));
+    d_cap = nc;
+  }
+  SL_HIP(hipMemcpyAsync(d_stage, h_pin, total, hipMemcpyHostToDevice, s));
+  SL_HIP(hipEventRecord(ev, s));
+  in_flight = true;
+  launch_scatter(d_stage, (unsigned)desc_off, (int)segs.size(), s);
+  segs.clear();
+  used = 0;
+  return SLIDE_OK;
+}
+
+DownloadBatch::~DownloadBatch() {
+  if (h_pin) (void)hipHostFree(h_pin);
+  if (d_stage) (void)hipFree(d_stage);
+}
+void DownloadBatch::add(void* host, const void* dev, size_t bytes) {
+  if (bytes == 0) return;
+  const size_t off = (used + 15) & ~(size_t)15;
+  segs.push_back({(unsigned long long)(uintptr_t)dev, (unsigned)off, (unsigned)bytes});
+  host_dst.push_back(host);
+  used = off + bytes;
+}
+int DownloadBatch::run(hipStream_t s) {
+  if (segs.empty()) { SL_HIP(hipStreamSynchronize(s)); return SLIDE_OK; }
+  const size_t desc_off = (used + 15) & ~(size_t)15;
+  const size_t total = desc_off + segs.size() * sizeof(Seg);
+  if (total > h_cap) {
+    size_t nc = h_cap ? h_cap : (1u << 16);
+    while (nc < total) nc *= 2;
+    if (h_pin) SL_HIP(hipHostFree(h_pin));
+    SL_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_pin), nc, hipHostMallocDefault));
+    h_cap = nc;
+  }
+  if (total > d_cap) {
+    if (d_stage) { SL_HIP(hipStreamSynchronize(s)); SL_HIP(hipFree(d_stage)); d_stage = nullptr; }
+    SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_stage), h_cap));
+    d_cap = h_cap;
+  }
+  std::memcpy(h_pin + desc_off, segs.data(), segs.size() * sizeof(Seg));
+  SL_HIP(hipMemcpyAsync(d_stage + desc_off, h_pin + desc_off, segs.size() * sizeof(Seg), hipMemcpyHostToDevice, s));
+  launch_gather(d_stage, (unsigned)desc_off, (int)segs.size(), s);
+  SL_HIP(hipMemcpyAsync(h_pin, d_stage, used, hipMemcpyDeviceToHost, s));
+  SL_HIP(hipStreamSynchronize(s));
+  for (size_t i = 0; i < segs.size(); ++i) std::memcpy(host_dst[i], h_pin + segs[i].off, segs[i].bytes);
+  segs.clear();
+  host_dst.clear();
+  used = 0;
+  return SLIDE_OK;
+}
+
 template <class T>
 static int up_tail(DevArr<T>& d, const std::vector<T>& h, size_t old_n, size_t per, hipStream_t s) {
   const size_t n = h.size();
@@ -352,6 +449,8 @@ static int up_csr(DevArr<int>& dptr, DevArr<int>& dval, const std::vector<std::v
 
 int HostGraph::upload_new() {
   hipStream_t s = stream;
+  if (ub.begin() != SLIDE_OK) return SLIDE_ERR_HIP;
+  struct BatchGuard { ~BatchGuard() { UploadBatch::current = nullptr; } } batch_guard;      // an error return abandons the batch
   const size_t Pn = h_pose_val.size() / 12, Ln = h_lm_type.size();
   const size_t npr = h_pr_pose.size(), nbt = h_bt_i.size(), nlf = h_lf_type.size();
 #define UP(dev, host, oldn, per) \
@@ -417,10 +516,9 @@ int HostGraph::upload_new() {
   }
   if (d_pose_ed.ensure(std::max<size_t>(ped.size(), 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_pose_ed.upload(ped.data(), 0, ped.size(), s) != SLIDE_OK) return SLIDE_ERR_HIP;
-  SL_HIP(hipStreamSynchronize(s));
-  if (Ln > 60000) { g_last_error = "Schur LDS lookup capacity exceeded (more than 60000 landmarks in one graph)"; return SLIDE_ERR_CAPACITY; }
+  if (Ln > 60000) { (void)ub.flush(s); g_last_error = "Schur LDS lookup capacity exceeded (more than 60000 landmarks in one graph)"; return SLIDE_ERR_CAPACITY; }
   if (up_csr(d_pose_bt_ptr, d_pose_bt, pose_bt, ptr, val, s) != SLIDE_OK) return SLIDE_ERR_HIP;
-  SL_HIP(hipStreamSynchronize(s));   // ptr / val are host temporaries
+  if (ub.flush(s) != SLIDE_OK) return SLIDE_ERR_HIP;   // (the host temporaries were copied into the pinned staging buffer)
   // dense reduced system
   const int T = (int)((6 * Pn + NB - 1) / NB);
   if (T > Tcap) {

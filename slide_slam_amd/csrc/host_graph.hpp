@@ -26,6 +26,37 @@ bool hip_ok(hipError_t e, const char* what);
     if (!::sl::hip_ok((x), #x)) return SLIDE_ERR_HIP; \
   } while (0)
 
+// Host -> device uploads of one graph update, batched: while a batch is open (thread-local), DevArr::upload copies into one
+// pinned staging buffer instead of issuing a hipMemcpyAsync per array (~35 small copies per frame otherwise, each a few
+// microseconds of host and copy-engine time); flush() sends the buffer with ONE copy and scatters it on the device.
+struct UploadBatch {
+  struct Seg { unsigned long long dst; unsigned off, bytes; };
+  std::vector<Seg> segs;
+  unsigned char* h_pin = nullptr; size_t h_cap = 0, used = 0;
+  unsigned char* d_stage = nullptr; size_t d_cap = 0;
+  hipEvent_t ev = nullptr;
+  bool in_flight = false;
+  static thread_local UploadBatch* current;
+  ~UploadBatch();
+  int begin();                                     // waits for the previous flush's copy before the pinned buffer is reused
+  int reserve(size_t need);
+  int add(void* dst, const void* src, size_t bytes);
+  int flush(hipStream_t s);                        // closes the batch
+};
+
+// Device -> host results of one step, batched the same way: gathered on the device, ONE copy into pinned memory, then
+// handed out to their host destinations.  run() synchronises the stream.
+struct DownloadBatch {
+  struct Seg { unsigned long long src; unsigned off, bytes; };
+  std::vector<Seg> segs;
+  std::vector<void*> host_dst;
+  unsigned char* h_pin = nullptr; size_t h_cap = 0, used = 0;
+  unsigned char* d_stage = nullptr; size_t d_cap = 0;
+  ~DownloadBatch();
+  void add(void* host, const void* dev, size_t bytes);     // bytes: multiple of 4
+  int run(hipStream_t s);
+};
+
 // growable device array; contents below `used` survive a growth
 template <class T>
 struct DevArr {
@@ -50,6 +81,7 @@ struct DevArr {
   }
   int upload(const T* h, size_t off, size_t count, hipStream_t s) {
     if (count == 0) return SLIDE_OK;
+    if (UploadBatch::current && sizeof(T) % 4 == 0) return UploadBatch::current->add(d + off, h, count * sizeof(T));
     SL_HIP(hipMemcpyAsync(d + off, h, count * sizeof(T), hipMemcpyHostToDevice, s));
     return SLIDE_OK;
   }
@@ -169,6 +201,7 @@ class HostGraph {
   DevArr<double> d_covY;
   bool factor_valid = false;            // S / Ld / Winv hold the factor of the system of the last solve
   DevArr<int> d_status;
+  UploadBatch ub;
   int Tcap = 0;
   // hipGraph of one pass, captured when the same resident graph is solved repeatedly (kernel arguments are
   // baked in, so any change of counts / pointers / threshold invalidates it)

@@ -744,6 +744,32 @@ __global__ __launch_bounds__(256) void k_schur(GraphDev G) {
 }
 
 // padding (identity) between 6P and T*NB, and the RHS row (-g) at row T*NB
+// One staged host -> device upload scattered to its destinations: descriptor i = (dst pointer, byte offset in the staging
+// buffer, byte count), all multiples of 4 bytes (host_graph.hpp UploadBatch)
+struct ScatterSeg { unsigned long long dst; unsigned off, bytes; };
+__global__ __launch_bounds__(256) void k_scatter(const unsigned char* __restrict__ stage, unsigned desc_off) {
+  const ScatterSeg sg = reinterpret_cast<const ScatterSeg*>(stage + desc_off)[blockIdx.x];
+  const unsigned* src = reinterpret_cast<const unsigned*>(stage + sg.off);
+  unsigned* dst = reinterpret_cast<unsigned*>(sg.dst);
+  const unsigned n = sg.bytes >> 2;
+  for (unsigned i = blockIdx.y * 256 + threadIdx.x; i < n; i += 256 * gridDim.y) dst[i] = src[i];
+}
+// the reverse: device arrays gathered into one staging buffer for ONE device -> host copy (DownloadBatch); `dst` of a
+// descriptor is the source pointer here
+__global__ __launch_bounds__(256) void k_gather(unsigned char* __restrict__ stage, unsigned desc_off) {
+  const ScatterSeg sg = reinterpret_cast<const ScatterSeg*>(stage + desc_off)[blockIdx.x];
+  unsigned* dst = reinterpret_cast<unsigned*>(stage + sg.off);
+  const unsigned* src = reinterpret_cast<const unsigned*>(sg.dst);
+  const unsigned n = sg.bytes >> 2;
+  for (unsigned i = blockIdx.y * 256 + threadIdx.x; i < n; i += 256 * gridDim.y) dst[i] = src[i];
+}
+void launch_gather(void* stage, unsigned desc_off, int nseg, hipStream_t s) {
+  if (nseg > 0) hipLaunchKernelGGL(k_gather, dim3(nseg, 4), dim3(256), 0, s, static_cast<unsigned char*>(stage), desc_off);
+}
+void launch_scatter(const void* stage, unsigned desc_off, int nseg, hipStream_t s) {
+  if (nseg > 0) hipLaunchKernelGGL(k_scatter, dim3(nseg, 8), dim3(256), 0, s, static_cast<const unsigned char*>(stage), desc_off);
+}
+
 __global__ void k_pad_rhs(GraphDev G) {
   const int n = 6 * G.P, NT = G.T * NB;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
