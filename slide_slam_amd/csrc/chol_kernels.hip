@@ -5,9 +5,9 @@
 // backend/sloam/src/factorgraph/graph.cpp:15).  Layout: S column-major, leading dimension
 // ld = (T+1)*64, lower triangle of the (T*64)^2 system plus ONE extra row tile whose first row is
 // the right-hand side, so the forward substitution L y = b falls out of the panel/update steps.
-// Per step k:  diag (POTRF 64x64 + explicit inverse W_k, LDS, one workgroup)
-//              panel (X = A W_k^T on v_mfma_f64_16x16x4_f64, operands straight from L2)
-//              update (C_ij -= L_ik L_jk^T on v_mfma_f64_16x16x4_f64, 64x64 tile per workgroup)
+// One launch per block column k (k_chol_step): the look-ahead chain of column k (type-A workgroups: pending panel, diagonal
+// factor, triangular solve — all on v_mfma_f64_16x16x4_f64) runs beside the trailing update of earlier panels (type-B work
+// queue, rank-128 passes); then ONE launch for the backward substitution (k_chol_bwd_chain).
 // MFMA operand orientation is chosen so that every global access is a 128-byte run down a column.
 // f64 MFMA lane maps (cdna_hip_programming.md §3): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
 // D[row = (lane>>4) + 4*reg][col = lane&15].
@@ -53,13 +53,14 @@ __device__ unsigned long long g_stamps[40];
 //     X = A L^-T by blocked substitution on v_mfma_f64_16x16x4_f64 — i.e. the whole "look-ahead" chain of
 //     column k without any inter-workgroup dependency.  Redundant factoring costs no latency (the blocks run
 //     concurrently) and keeps L_kk / its inverses out of L2 round trips.
-//  type B: tile (i, j), j >= k+1: plain trailing update with panel k-1 (C_ij -= L_i,k-1 L_j,k-1^T).
-// The long type-A blocks therefore run BESIDE the memory-bound type-B flood inside one launch; the next step
-// needs only the kernel boundary.  MFMA accumulator layout of X_c^T (row (lane>>4) + 4r, column lane&15) is
-// exactly the B-operand layout of k-step r, so chained products need no lane movement.
+//  type B (work queue): the trailing update in rank-128 passes — panels kb-2, kb-1 of a pair base kb go onto every tile
+//     (i, j >= kb+1) in one visit, half of the pass in launch kb, half in launch kb+1 (see b_decode / launch_chol_step).
+// The long type-A blocks therefore run BESIDE the type-B flood inside one launch; the next step needs only the kernel
+// boundary.  MFMA accumulator layout of X_c^T (row (lane>>4) + 4r, column lane&15) is exactly the B-operand layout of
+// k-step r, so chained products need no lane movement.
 // ---------------- type B: trailing update with two panels, one 2x2 group of 64x64 tiles per workgroup ----------------
 // A work item is one tile row of a 2x2 group: two tiles (i, j0), (i, j0 + 1); four waves per tile, each a 32x32 quadrant:
-// four 16x16 accumulators initialised with C itself, sixteen k-steps of four operand loads feeding four MFMAs (the loads
+// four 16x16 accumulators initialised with C itself, 16 k-steps per panel of two 16-byte operand loads feeding four MFMAs (the loads
 // run five k-steps ahead of their use).  No LDS, no barrier: waves whose tile lies outside the lower triangle leave at once.
 __device__ __forceinline__ long long tri_row(long long t) {
   long long ii = (long long)floor((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
