@@ -516,7 +516,12 @@ int HostGraph::upload_new() {
   }
   if (d_pose_ed.ensure(std::max<size_t>(ped.size(), 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_pose_ed.upload(ped.data(), 0, ped.size(), s) != SLIDE_OK) return SLIDE_ERR_HIP;
-  if (Ln > 60000) { (void)ub.flush(s); g_last_error = "Schur LDS lookup capacity exceeded (more than 60000 landmarks in one graph)"; return SLIDE_ERR_CAPACITY; }
+  // k_schur keeps a landmark -> slot table (2 B per landmark) and a pose adjacency bitmap (1 bit per pose) in dynamic LDS
+  if ((Ln + 7) / 8 * 8 * sizeof(short) + ((Pn + 31) / 32 + 1) * sizeof(unsigned) > 120 * 1024) {
+    (void)ub.flush(s);
+    g_last_error = "Schur LDS lookup capacity exceeded (about 60000 landmarks in one graph)";
+    return SLIDE_ERR_CAPACITY;
+  }
   if (up_csr(d_pose_bt_ptr, d_pose_bt, pose_bt, ptr, val, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (ub.flush(s) != SLIDE_OK) return SLIDE_ERR_HIP;   // (the host temporaries were copied into the pinned staging buffer)
   // dense reduced system
