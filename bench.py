@@ -73,8 +73,8 @@ def cpu_baseline(data, robot_log_idx, frames, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--preset", default="C4")
     ap.add_argument("--frames", type=int, default=None, help="truncate each robot's log (debug)")
     ap.add_argument("--no-cpu", action="store_true")
