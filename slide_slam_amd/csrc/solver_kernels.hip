@@ -621,7 +621,8 @@ __global__ __launch_bounds__(256) void k_schur(GraphDev G) {
   if (tid == 0) atomicOr(&adj[pj >> 5], 1u << (pj & 31));
   __syncthreads();
   const int sub = tid & 7;
-  for (int pi0 = pj; pi0 < G.P; pi0 += 32) {
+  // the chunks of the strip are dealt out to the gridDim.y workgroups of this pose column (each builds the two tables itself)
+  for (int pi0 = pj + 32 * (int)blockIdx.y; pi0 < G.P; pi0 += 32 * (int)gridDim.y) {
     const int nval = 6 * min(32, G.P - pi0);
     double* Sb = G.S + (size_t)(6 * pj) * G.ld + 6 * (size_t)pi0;
     const int w = pi0 >> 5, sh = pi0 & 31;
@@ -924,7 +925,8 @@ void launch_pose(const GraphDev& G, hipStream_t s) {
 }
 void launch_schur(const GraphDev& G, hipStream_t s) {
   if (G.P == 0) return;
-  hipLaunchKernelGGL(k_schur, dim3(G.P), dim3(256), (size_t)((G.L + 7) / 8 * 8) * sizeof(short) + (size_t)((G.P + 31) / 32 + 1) * sizeof(unsigned), s, G);
+  static const int split = getenv("SLIDE_SCHUR_SPLIT") ? atoi(getenv("SLIDE_SCHUR_SPLIT")) : 2;     // diagnostic
+  hipLaunchKernelGGL(k_schur, dim3(G.P, split > 0 ? split : 1), dim3(256), (size_t)((G.L + 7) / 8 * 8) * sizeof(short) + (size_t)((G.P + 31) / 32 + 1) * sizeof(unsigned), s, G);
   const long long NT = (long long)G.T * NB;
   const long long tot = NT + (NT - 6LL * G.P) * NT;
   hipLaunchKernelGGL(k_pad_rhs, dim3(blocks_for(tot, 256)), dim3(256), 0, s, G);
