@@ -115,7 +115,11 @@ def write_bag(path, connections, messages, chunk_messages=3, compression="none")
             index.setdefault(conn, []).append((sec, nsec, len(chunk)))
             chunk += _record({"op": b"\x02", "conn": struct.pack("<I", conn), "time": struct.pack("<2I", sec, nsec)}, payload)
         pos = 13 + 4096 + len(body)
-        body += _record({"op": b"\x05", "compression": compression.encode(), "size": struct.pack("<I", len(chunk))}, chunk)
+        stored = chunk
+        if compression == "bz2":
+            import bz2
+            stored = bz2.compress(chunk)
+        body += _record({"op": b"\x05", "compression": compression.encode(), "size": struct.pack("<I", len(chunk))}, stored)
         for conn, ent in index.items():
             body += _record({"op": b"\x04", "ver": struct.pack("<I", 1), "conn": struct.pack("<I", conn),
                              "count": struct.pack("<I", len(ent))}, b"".join(struct.pack("<3I", *e) for e in ent))

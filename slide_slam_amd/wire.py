@@ -335,3 +335,42 @@ class Bag:
 
     def __exit__(self, *a):
         self.close()
+
+
+def inflate_bag(src, dst):
+    """Rewrite a rosbag v2.0 file with bz2-compressed chunks as one with uncompressed chunks (what `rosbag decompress` does), so
+    that `Bag` can read it.  Host-side convenience in Python (the C++ reader links no decompressor); lz4 chunks are refused.
+    The index / chunk-info records are carried over unchanged — their file offsets are stale, this library's reader walks the
+    records and never uses them."""
+    import bz2
+    import struct
+    data = open(src, "rb").read()
+    magic = b"#ROSBAG V2.0\n"
+    if not data.startswith(magic):
+        raise ValueError("not a rosbag v2.0 file")
+    out = [magic]
+    n = len(magic)
+    while n < len(data):
+        hl, = struct.unpack_from("<I", data, n)
+        hdr = data[n + 4:n + 4 + hl]
+        dl, = struct.unpack_from("<I", data, n + 4 + hl)
+        body = data[n + 8 + hl:n + 8 + hl + dl]
+        if len(hdr) != hl or len(body) != dl:
+            raise ValueError("truncated bag")
+        n += 8 + hl + dl
+        fields, m = {}, 0
+        while m < hl:
+            fl, = struct.unpack_from("<I", hdr, m)
+            k, _, v = hdr[m + 4:m + 4 + fl].partition(b"=")
+            fields[k] = v
+            m += 4 + fl
+        if fields.get(b"op") == b"\x05" and fields.get(b"compression", b"none") != b"none":
+            if fields[b"compression"] != b"bz2":
+                raise ValueError("unsupported chunk compression " + fields[b"compression"].decode())
+            body = bz2.decompress(body)
+            fields[b"compression"] = b"none"
+            fields[b"size"] = struct.pack("<I", len(body))
+            hdr = b"".join(struct.pack("<I", len(k) + 1 + len(v)) + k + b"=" + v for k, v in fields.items())
+        out.append(struct.pack("<I", len(hdr)) + hdr + struct.pack("<I", len(body)) + body)
+    with open(dst, "wb") as fh:
+        fh.write(b"".join(out))

@@ -189,6 +189,11 @@ def test_bag_reader(tmp_path):
     with pytest.raises(wire.WireError) as e:
         wire.Bag(tmp_path / "c.bag")
     assert e.value.code == -5
+    # ... and readable after inflate_bag (the `rosbag decompress` step, host side)
+    wire.inflate_bag(tmp_path / "c.bag", tmp_path / "ci.bag")
+    with wire.Bag(tmp_path / "ci.bag") as bag:
+        again = list(bag)
+    assert [(t, s_, p) for t, _, s_, p in again] == [(t, s_, p) for t, _, s_, p in got]
     (tmp_path / "x.bag").write_bytes(b"#ROSBAG V1.2\n" + b"\0" * 100)
     with pytest.raises(wire.WireError):
         wire.Bag(tmp_path / "x.bag")
