@@ -26,6 +26,19 @@ def test_dense_spd_solve(gpu, n):
     assert np.linalg.norm(x - ref) <= 1e-9 * np.linalg.norm(ref)
 
 
+def test_dense_spd_solve_more_block_columns_than_cus(gpu):
+    """T = 261 block columns: more workgroups in the chained backward substitution than the part has CUs (its waits are on
+    workgroups of lower index only) and several rounds of type-A workgroups in the first step kernels; residual check."""
+    n = 16700
+    rng = np.random.default_rng(1)
+    B = rng.normal(size=(n, 64))
+    A = B @ B.T / 64.0
+    A[np.diag_indices(n)] += 2.0 + rng.uniform(0, 1, n)
+    b = rng.normal(size=n)
+    x, _ = gpu.dense_spd_solve(A, b)
+    assert np.linalg.norm(A @ x - b) <= 1e-12 * np.linalg.norm(b)
+
+
 def test_dense_spd_solve_rejects_indefinite(gpu):
     A = np.eye(70)
     A[40, 40] = -1.0
