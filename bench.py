@@ -31,12 +31,26 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak, public spec (MI355X_MI
 HBM_PEAK_GBS = 8000.0
 
 
-def build_graph(s, data, robot_log_idx, frames=None):
-    """Stream one robot's frame log through the per-frame path (association + add + iSAM2-equivalent update)."""
+def build_graph(s, data, robot_log_idx, frames=None, ingest_only=False):
+    """Stream one robot's frame log through the per-frame path (association + add + iSAM2-equivalent update).
+    ingest_only (profiling aid): add every frame without solving (association against the un-refined map at the ground-truth
+    poses, as the cpu_baseline leg does), then one solve — every k_chol_step launch of the run is then full-size."""
     from slide_slam_amd.replay import replay_single
     gb = s.SlideBackend(s.default_params(), 1)
-    out = replay_single(gb, data["logs"][robot_log_idx], n_frames=frames, collect=False)
-    return gb, out
+    if not ingest_only:
+        out = replay_single(gb, data["logs"][robot_log_idx], n_frames=frames, collect=False)
+        return gb, out
+    from slide_slam_amd.synth import frame_detections
+    log = data["logs"][robot_log_idx]
+    P = len(log["rel7"]) if frames is None else frames
+    t_frame = []
+    for k in range(P):
+        t0 = time.perf_counter()
+        gb.process_frame(0, log["rel7"][k], log["gt7"][k], frame_detections(log, k), s.FRAME_FOREIGN)
+        t_frame.append(time.perf_counter() - t0)
+    if gb.ingest_solve() != 0:
+        raise RuntimeError("ingest solve failed")
+    return gb, dict(t_frame=t_frame)
 
 
 def cpu_baseline(data, robot_log_idx, frames, threads):
@@ -78,6 +92,7 @@ def main():
     ap.add_argument("--preset", default="C4")
     ap.add_argument("--frames", type=int, default=None, help="truncate each robot's log (debug)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--ingest-only", action="store_true", help="build the graph without per-frame solves (profiling aid)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -113,7 +128,7 @@ def main():
     world_map = make_world(cfg)
     data = dict(cfg=cfg, world=world_map, logs={robot: make_robot_log(cfg, world_map, robot)})
     t_b0 = time.perf_counter()
-    gb, rep = build_graph(s, data, robot, args.frames)
+    gb, rep = build_graph(s, data, robot, args.frames, args.ingest_only)
     t_build = time.perf_counter() - t_b0
     g = gb.graph
     st = g.stats()
