@@ -182,3 +182,82 @@ class TorchComm:
         else:
             self.dist.all_reduce(buf[:n])
             self.torch.cuda.synchronize()
+
+
+class ThreadGroup:
+    """Several robot shards in ONE process (one thread each, all on the process's GPU or host): the communicator of the
+    BASELINE "8-robot graph at 1/2/4/8 GPUs" layout, 8 / N robots per GPU.  Virtual rank of thread t = rank * n_local + t.
+    The group leader (thread 0) adds the local shards' buffers and, when the job spans processes, all-reduces the sum with
+    torch.distributed (`base`, a TorchComm); the shards' HIP streams run their phases concurrently on the one GPU."""
+
+    def __init__(self, n_local, base=None, rank=0, world=1):
+        import threading
+        self.n, self.base, self.rank, self.world = n_local, base, rank, world
+        self.barrier = threading.Barrier(n_local)
+        self.slots = [None] * n_local
+        self.result = None
+
+    def comm(self, t, device=None):
+        return ThreadComm(self, t, device)
+
+
+class ThreadComm:
+    def __init__(self, group, t, device=None):
+        self.g, self.t, self.device = group, t, device
+        if device is not None:
+            import torch
+            self.torch = torch
+
+    @property
+    def vrank(self):
+        return self.g.rank * self.g.n + self.t
+
+    @property
+    def vworld(self):
+        return self.g.world * self.g.n
+
+    def all_gather_object(self, obj):
+        g = self.g
+        g.slots[self.t] = obj
+        g.barrier.wait()
+        if self.t == 0:
+            local = list(g.slots)
+            if g.world > 1:
+                parts = g.base.all_gather_object(local)
+                g.result = [o for part in parts for o in part]
+            else:
+                g.result = local
+        g.barrier.wait()
+        out = list(g.result)
+        g.barrier.wait()
+        return out
+
+    def alloc(self, n):
+        if self.device is None:
+            return np.zeros(n)
+        return self.torch.zeros(n, dtype=self.torch.float64, device=self.device)
+
+    def handle(self, buf):
+        return buf if self.device is None else buf.data_ptr()
+
+    def all_reduce(self, buf, n):
+        if n == 0:
+            return
+        g = self.g
+        g.slots[self.t] = buf
+        g.barrier.wait()
+        if self.t == 0:
+            if self.device is None:
+                total = np.sum([b[:n] for b in g.slots], axis=0)
+                if g.world > 1:
+                    g.base.all_reduce(total, n)
+                for b in g.slots:
+                    b[:n] = total
+            else:
+                total = self.torch.stack([b[:n] for b in g.slots]).sum(0)
+                if g.world > 1:
+                    g.base.all_reduce(total, n)
+                for b in g.slots:
+                    b[:n].copy_(total)
+                self.torch.cuda.synchronize()
+        g.barrier.wait()

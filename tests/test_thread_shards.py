@@ -1,0 +1,77 @@
+"""Several robot shards in one process (ThreadGroup / ThreadComm, slide_slam_amd/distributed.py): the 8 / N-robots-per-GPU
+layout of BASELINE's "8-robot graph at 1/2/4/8 GPUs".  CPU: oracle shards in threads; GPU: HIP shards on concurrent streams."""
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from slide_slam_amd.distributed import DistributedGraph, ThreadGroup      # noqa: E402
+from slide_slam_amd.replay import replay_single                           # noqa: E402
+from slide_slam_amd.synth import SynthConfig, make_robot_log, make_world   # noqa: E402
+from test_distributed import _check, _joint_optimum                       # noqa: E402
+from dist_worker import gpu_matcher, oracle_matcher                       # noqa: E402
+
+
+def _run_threads(make_shard, matcher, preset, iters, device=None):
+    cfg = SynthConfig.preset(preset)
+    world_map = make_world(cfg)
+    R = cfg.robots
+    group = ThreadGroup(R)
+    out, err = [None] * R, []
+
+    def work(t):
+        try:
+            shard = make_shard()
+            log = make_robot_log(cfg, world_map, t)
+            replay_single(shard, log, robot=0, collect=False)
+            dg = DistributedGraph(shard, group.comm(t, device), t, R)
+            info = dg.setup(matcher)
+            dg.gauss_newton(iters)
+            P = len(log["rel7"])
+            out[t] = (np.array([shard.graph.get_pose12(0, k)[1] for k in range(P)]), info)
+        except BaseException as e:      # a dead thread would leave the others at the barrier
+            err.append(e)
+            group.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(R)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not err, err
+    return dict(poses=np.array([o[0] for o in out]), n_slots=out[0][1]["n_slots"], n_global=np.array(out[0][1]["n_global"]))
+
+
+def test_thread_shards_oracle():
+    from oracle import pyoracle as po
+    joint, counts = _joint_optimum("C3tiny")
+    z = _run_threads(lambda: po.OracleBackend(po.OrcParams.default(), 1), oracle_matcher, "C3tiny", 60)
+    _check(z, joint, counts, 1e-5)
+
+
+@pytest.mark.gpu
+def test_thread_shards_gpu(gpu, tmp_path):
+    """HIP shards of two robots on concurrent streams of the one GPU.  Runs in a fresh process: torch has to initialise the
+    device before this library's HIP runtime is loaded (the other order leaves torch without a GPU in this image)."""
+    import subprocess
+    joint, counts = _joint_optimum("C3tiny")
+    out = str(tmp_path / "t.npz")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), out], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    _check(np.load(out), joint, counts, 1e-4)
+
+
+if __name__ == "__main__":
+    import torch
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")
+    import slide_slam_amd as s
+    s.device_check()
+    z = _run_threads(lambda: s.SlideBackend(s.default_params(), 1), gpu_matcher, "C3tiny", 60, device=torch.device("cuda", 0))
+    np.savez(sys.argv[1], **z)
