@@ -6,12 +6,13 @@ landmark-eliminated (Schur) pose system, factor + solve it (FP64-MFMA Cholesky),
 landmarks and retract — i.e. one Gauss-Newton iteration = one pose-graph update
 (reference: SemanticFactorGraph::solve, backend/sloam/src/factorgraph/graph.cpp:260-272).
 
-Workload (BASELINE.json): the 8-robot / 10 k-landmark / 5 k-pose synthetic graph sharded one robot per GPU
-(configs[3]); at N GPUs the job is N robots of that graph (625 poses, ~1250 landmarks, ~12.5 k landmark
-factors each), so N = 8 is exactly configs[3] and N = 1 is one robot's shard.  Inputs are resident in
-HBM before the timed region.  Synthetic, seeded data (slide_slam_amd/synth.py).
+Workload (BASELINE.json configs[3]): the 8-robot / 10 k-landmark / 5 k-pose synthetic graph, one sub-graph per robot (625 poses,
+~1250 landmarks, ~12.5 k landmark factors each), 8 / N robots per GPU — the SAME graph at N = 1, 2, 4, 8 (strong scaling).
+Robots that share a GPU run on concurrent HIP streams (one host thread each); a step = one distributed Gauss-Newton pass of all
+eight robots, value = robot pose-graph updates/s = 8 * steps / time.  `--robots-per-gpu 1` is the weak-scaling variant (one robot
+per GPU at every N).  Inputs are resident in HBM before the timed region.  Synthetic, seeded data (slide_slam_amd/synth.py).
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--preset C4shard] [--no-cpu] [--frames F]
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--robots-per-gpu R] [--no-cpu] [--frames F] [--ingest-only]
 Multi-GPU: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
 """
 from __future__ import annotations
@@ -84,7 +85,7 @@ def cpu_baseline(data, robot_log_idx, frames, threads):
                 t_chol_s=stats["t_chol"])
 
 
-def run_local_robots(args, s, torch, dist, rank, world, dev_index, backend):
+def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
     """--robots-per-gpu R > 1: R robot shards per process, one thread and one HIP stream each, exchanging through
     ThreadGroup (local sum, then RCCL across processes).  With R = 8 / N this is BASELINE's "8-robot graph at 1/2/4/8 GPUs"
     (total work fixed); a step = one distributed Gauss-Newton pass of all robots."""
@@ -93,21 +94,20 @@ def run_local_robots(args, s, torch, dist, rank, world, dev_index, backend):
     from slide_slam_amd.synth import SynthConfig, make_robot_log, make_world
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from dist_worker import gpu_matcher
-    R = args.robots_per_gpu
     cfg = SynthConfig.preset(args.preset)
     world_map = make_world(cfg)
     device = torch.device("cuda", dev_index)
     base = TorchComm(device=device, stage_through_host=(backend != "nccl")) if world > 1 else None
     group = ThreadGroup(R, base=base, rank=rank, world=world)
     sync = threading.Barrier(R + 1)
-    shards, infos, errs = [None] * R, [None] * R, []
+    shards, infos, reps, errs = [None] * R, [None] * R, [None] * R, []
 
     def work(t):
         try:
             torch.cuda.set_device(dev_index)
             robot = (rank * R + t) % cfg.robots
             data = dict(cfg=cfg, world=world_map, logs={robot: make_robot_log(cfg, world_map, robot)})
-            gb, _ = build_graph(s, data, robot, args.frames, args.ingest_only)
+            gb, reps[t] = build_graph(s, data, robot, args.frames, args.ingest_only)
             dg = DistributedGraph(gb, group.comm(t, device), rank * R + t, world * R)
             infos[t] = dg.setup(gpu_matcher)
             shards[t] = gb
@@ -151,29 +151,7 @@ def run_local_robots(args, s, torch, dist, rank, world, dev_index, backend):
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if rank == 0:
-        st = shards[0].graph.stats()
-        res = {
-            "metric": "pose-graph updates/sec + ms/Gauss-Newton iter, 8-robot 10k-landmark graph",
-            "value": world * R * args.steps / dt,
-            "unit": "pose-graph updates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "ms_per_gn_iter": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong" if world * R == cfg.robots else "weak",
-            "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic (seeded, slide_slam_amd/synth.py)",
-            "config": {"workload": f"{cfg.name}: {world * R} robot sub-graphs, {R} per GPU on concurrent streams ({st['n_pose']} poses, "
-                                   f"{st['n_lm']} landmarks, {st['n_factors']} factors in robot 0's); a step = one distributed "
-                                   f"Gauss-Newton pass of all of them",
-                       "robots": world * R, "robots_per_gpu": R, "reduced_system_dim": st["chol_dim"], "chol_tile": 64,
-                       "collective": f"local sum + {backend if world > 1 else 'none'} all-reduce x2 per pass over {infos[0]['n_slots']} "
-                                     f"shared-landmark slots"},
-        }
-        print(json.dumps(res))
-    if dist is not None:
-        dist.destroy_process_group()
+    return dt, shards[0], reps[0], infos[0]
 
 
 def main():
@@ -185,8 +163,9 @@ def main():
     ap.add_argument("--frames", type=int, default=None, help="truncate each robot's log (debug)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--ingest-only", action="store_true", help="build the graph without per-frame solves (profiling aid)")
-    ap.add_argument("--robots-per-gpu", type=int, default=1,
-                    help="R > 1: R robot shards per GPU on concurrent streams (8 / N = BASELINE's 8-robot graph on N GPUs)")
+    ap.add_argument("--robots-per-gpu", type=int, default=0,
+                    help="robot shards per GPU, on concurrent streams; 0 = the preset's robots / N when that divides (the SAME "
+                         "8-robot graph at every N: strong scaling), else 1; 1 = one robot per GPU at every N (weak scaling)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -215,10 +194,14 @@ def main():
     import slide_slam_amd as s
     from slide_slam_amd.synth import SynthConfig, make_robot_log, make_world
     s.device_check()
-    if args.robots_per_gpu > 1:
-        return run_local_robots(args, s, torch, dist, rank, world, dev_index, backend)
-
     cfg = SynthConfig.preset(args.preset)
+    R = args.robots_per_gpu if args.robots_per_gpu > 0 else (cfg.robots // world if cfg.robots % world == 0 else 1)
+    if R > 1:
+        # several robot shards on this GPU (one thread + one HIP stream each); everything below reports on robot 0's shard
+        t_b0 = time.perf_counter()
+        dt, gb, rep, dg_info = run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend)
+        data = dict(cfg=cfg, logs={0: make_robot_log(cfg, make_world(cfg), 0)}) if rank == 0 and not args.no_cpu else None
+        return report(args, s, cfg, rank, world, R, backend, dt, gb, rep, dg_info, dist, data, 0, time.perf_counter() - t_b0 - dt)
     # one robot per GPU: rank r replays robot r of the shared world (weak scaling; N = cfg.robots is the full config)
     robot = rank % cfg.robots
     world_map = make_world(cfg)
@@ -261,6 +244,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    return report(args, s, cfg, rank, world, 1, backend, dt, gb, rep, dg_info, dist, data, robot, t_build)
+
+
+def report(args, s, cfg, rank, world, R, backend, dt, gb, rep, dg_info, dist, data, robot, t_build):
+    """Profile pass on this rank's first shard + the JSON line (rank 0)."""
+    g = gb.graph
+    st = g.stats()
+    robots = world * R
     # per-kernel device time (HIP events on the launch stream) over a separate profiled pass
     g.set_profiling(True)
     nprof = max(3, min(args.steps, 5))
@@ -296,21 +287,25 @@ def main():
         dominant = max(kernel_ms, key=kernel_ms.get)
         res = {
             "metric": "pose-graph updates/sec + ms/Gauss-Newton iter, 8-robot 10k-landmark graph",
-            "value": world * args.steps / dt,
+            "value": robots * args.steps / dt,
             "unit": "pose-graph updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "ms_per_gn_iter": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            # the preset's robots over N GPUs (total work fixed) -> strong; a fixed number of robots per GPU -> weak
+            "scaling": "strong" if (args.robots_per_gpu == 0 and robots == cfg.robots) else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (seeded, slide_slam_amd/synth.py)",
-            "config": {"workload": f"{cfg.name}: one robot sub-graph per GPU ({st['n_pose']} poses, {st['n_lm']} landmarks, "
-                                   f"{st['n_factors']} factors on rank 0); N=8 is BASELINE configs[3]",
-                       "robots": world, "reduced_system_dim": n, "chol_tile": 64,
-                       "collective": None if world == 1 else f"{backend} all-reduce x2 per pass over {dg_info['n_slots']} shared-landmark slots "
-                                                               f"({dg_info['n_slots'] * 63 * 8} B per pass)"},
+            "config": {"workload": f"{cfg.name} (BASELINE configs[3]): {robots} robot sub-graphs, {R} per GPU"
+                                   + (" on concurrent HIP streams" if R > 1 else "")
+                                   + f" ({st['n_pose']} poses, {st['n_lm']} landmarks, {st['n_factors']} factors in robot 0's); "
+                                     "a step = one Gauss-Newton pass of all of them, value = robot pose-graph updates/s",
+                       "robots": robots, "robots_per_gpu": R, "reduced_system_dim": n, "chol_tile": 64,
+                       "collective": None if dg_info is None else
+                       (("local sum + " if R > 1 else "") + (f"{backend} " if world > 1 else "no inter-GPU ") +
+                        f"all-reduce x2 per pass over {dg_info['n_slots']} shared-landmark slots ({dg_info['n_slots'] * 63 * 8} B per pass)")},
             "roofline": {"bound": "mfma", "kernel": "k_chol_step (v_mfma_f64_16x16x4_f64)", "achieved": ach,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
