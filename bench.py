@@ -100,6 +100,8 @@ def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
     base = TorchComm(device=device, stage_through_host=(backend != "nccl")) if world > 1 else None
     group = ThreadGroup(R, base=base, rank=rank, world=world)
     sync = threading.Barrier(R + 1)
+    conc = int(os.environ.get("SLIDE_BENCH_CONCURRENCY", "0"))
+    sem = threading.Semaphore(conc) if conc > 0 else None
     shards, infos, reps, errs = [None] * R, [None] * R, [None] * R, []
 
     def work(t):
@@ -108,6 +110,13 @@ def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
             robot = (rank * R + t) % cfg.robots
             data = dict(cfg=cfg, world=world_map, logs={robot: make_robot_log(cfg, world_map, robot)})
             gb, reps[t] = build_graph(s, data, robot, args.frames, args.ingest_only)
+            if sem is not None:        # diagnostic: at most SLIDE_BENCH_CONCURRENCY shards inside a phase at a time
+                orig = gb.graph.dist_phase
+
+                def limited(ph, buf, orig=orig):
+                    with sem:
+                        return orig(ph, buf)
+                gb.graph.dist_phase = limited
             dg = DistributedGraph(gb, group.comm(t, device), rank * R + t, world * R)
             infos[t] = dg.setup(gpu_matcher)
             shards[t] = gb
