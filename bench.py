@@ -102,6 +102,8 @@ def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
     sync = threading.Barrier(R + 1)
     conc = int(os.environ.get("SLIDE_BENCH_CONCURRENCY", "0"))
     sem = threading.Semaphore(conc) if conc > 0 else None
+    batch = s.CholBatch(R) if os.environ.get("SLIDE_BENCH_BATCH", "0") == "1" else None      # opt-in: not faster than streams yet
+    timing = [None]
     shards, infos, reps, errs = [None] * R, [None] * R, [None] * R, []
 
     def work(t):
@@ -120,13 +122,27 @@ def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
             dg = DistributedGraph(gb, group.comm(t, device), rank * R + t, world * R)
             infos[t] = dg.setup(gpu_matcher)
             shards[t] = gb
+            if batch is not None:      # the dense factor + solve of all local robots as one launch sequence per pass
+                gb.graph.join_chol_batch(batch, t)
             for _ in range(args.warmup):
                 dg.gauss_newton(1)
+            if t == 0 and os.environ.get("SLIDE_BENCH_TIMING") == "1":      # diagnostic: wall time per call of the pass, thread 0
+                acc = {}
+                def timed(name, fn):
+                    def w(*a):
+                        t0 = time.perf_counter(); r = fn(*a); acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0; return r
+                    return w
+                orig_phase = gb.graph.dist_phase
+                gb.graph.dist_phase = lambda ph, buf: timed(f"phase{ph}", orig_phase)(ph, buf)
+                dg.comm.all_reduce = timed("all_reduce", dg.comm.all_reduce)
+                timing[0] = acc
             sync.wait()          # warm-up done
             sync.wait()          # go
             for _ in range(args.steps):
                 dg.gauss_newton(1)
             sync.wait()          # done
+            if batch is not None:
+                gb.graph.join_chol_batch(None)
         except BaseException as e:
             errs.append(e)
             group.barrier.abort()
@@ -156,6 +172,8 @@ def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
         x.join()
     if errs:
         raise errs[0]
+    if timing[0] and rank == 0:
+        sys.stderr.write("per-pass wall ms (thread 0): " + ", ".join(f"{k} {v / args.steps * 1e3:.3f}" for k, v in sorted(timing[0].items())) + "\n")
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -127,6 +127,15 @@ int slide_graph_get_profile(slide_graph_t* g, char* names, double* ms_total, int
  * library); each call returns after its kernels have completed. */
 int slide_graph_set_shared(slide_graph_t* g, const int32_t* cls, const int64_t* idx, const int32_t* owner, int n_slots);
 int slide_graph_dist_phase(slide_graph_t* g, int phase, double* d_buf);
+
+/* Several robot graphs on ONE GPU (the 8 / N-robots-per-GPU layout; no counterpart in the reference, whose replica solves one joint
+ * graph): the dense factor + solve of phase 1 of all joined graphs runs as one launch sequence, one launch per block column for
+ * all of them.  Every joined graph must then run its passes in lockstep from its own host thread (slide_graph_dist_phase(g, 1, ..)
+ * returns when all have arrived; SLIDE_ERR_RUNTIME after 60 s).  slide_graph_join_chol_batch(g, NULL, 0) leaves the batch. */
+typedef struct slide_chol_batch slide_chol_batch_t;
+slide_chol_batch_t* slide_chol_batch_create(int n_graphs);      /* 1 .. 8 */
+void slide_chol_batch_destroy(slide_chol_batch_t* b);
+int slide_graph_join_chol_batch(slide_graph_t* g, slide_chol_batch_t* b, int slot);
 /* Sharded mode, inter-robot relative-pose factors (addRelativeMeasFactor graph.cpp:247-258 between poses of two ranks).
  * Ghost slots enumerate, identically on every rank, the poses such factors touch; slot i is this rank's pose
  * (own_robot[i], own_idx[i]) or belongs to another rank (own_robot[i] < 0).  A factor is added on BOTH ranks, each with its

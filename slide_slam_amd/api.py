@@ -28,7 +28,7 @@ EXPORTS = [
     "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
     "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
-    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
+    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
     "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
     "slide_dense_spd_solve", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
@@ -88,6 +88,9 @@ def lib():
         L.slide_graph_create.restype = C.c_void_p
         L.slide_backend_create.restype = C.c_void_p
         L.slide_backend_graph.restype = C.c_void_p
+        L.slide_chol_batch_create.restype = C.c_void_p
+        L.slide_chol_batch_destroy.argtypes = [C.c_void_p]
+        L.slide_chol_batch_destroy.restype = None
         _LIB = L
     return _LIB
 
@@ -234,6 +237,10 @@ class SlideGraph:
         _check(self.L.slide_graph_add_relative_meas_ghost(self.h, _p(_d(rel7)), C.c_uint64(idx), C.c_int(robot), C.c_int(slot),
                                                           C.c_int(int(local_first))))
 
+    def join_chol_batch(self, batch, slot=0):
+        """Share the dense factor + solve of phase 1 with the other graphs of `batch` (CholBatch; None leaves it)."""
+        _check(self.L.slide_graph_join_chol_batch(self.h, C.c_void_p(batch.h if batch is not None else None), C.c_int(slot)))
+
     def dist_phase(self, phase, d_buf_ptr):
         """d_buf_ptr: integer DEVICE address of the exchange buffer (e.g. torch_tensor.data_ptr())."""
         return _check(self.L.slide_graph_dist_phase(self.h, C.c_int(phase), C.c_void_p(d_buf_ptr)))
@@ -251,6 +258,24 @@ class SlideGraph:
             nm = names.raw[32 * i: 32 * i + 32].split(b"\0")[0].decode()
             out[nm] = dict(ms=float(ms[i]), launches=int(cnt[i]))
         return out
+
+
+class CholBatch:
+    """slide_chol_batch_t: the graphs of several robots on one GPU factor and solve their pose systems in one launch sequence."""
+
+    def __init__(self, n_graphs):
+        self.L = lib()
+        self.h = self.L.slide_chol_batch_create(C.c_int(n_graphs))
+        if not self.h:
+            raise ValueError("CholBatch: 1 .. 8 graphs")
+
+    def close(self):
+        if self.h:
+            self.L.slide_chol_batch_destroy(C.c_void_p(self.h))
+            self.h = None
+
+    def __del__(self):
+        self.close()
 
 
 class SlideBackend:

@@ -20,6 +20,7 @@
 namespace sl {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int CHOL_BATCH_MAX = 8;    // systems per batched launch (robots sharing one GPU)
 __device__ inline v4d mfma_f64(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
 __device__ inline double rsqrt_nr(double d) {
@@ -618,6 +619,49 @@ __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ S, int l
   }
 }
 
+// Several factorisations (the robots that share a GPU) in ONE launch per block column: the type-A workgroups of every system,
+// then one work queue over the type-B items of all of them.  Same device code as k_chol_step, per-system parameters by value.
+struct CholBatchArgs {
+  int n;
+  double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX];
+  double* Ld[CHOL_BATCH_MAX]; double* Winv[CHOL_BATCH_MAX]; int* status[CHOL_BATCH_MAX];
+  int nP[CHOL_BATCH_MAX], g0[CHOL_BATCH_MAX], g1[CHOL_BATCH_MAX], nX[CHOL_BATCH_MAX], a_split[CHOL_BATCH_MAX];
+  int a_base[CHOL_BATCH_MAX + 1];      // prefix sums of the type-A workgroup counts
+  int b_base[CHOL_BATCH_MAX + 1];      // prefix sums of the type-B item counts
+};
+__global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int k, int kb, int* __restrict__ ctr, int a_joins) {
+  __shared__ ALds L;
+  __shared__ int s_g;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctr[k + 1] = 0;
+  const int bid = (int)blockIdx.x;
+  if (bid < A.a_base[A.n]) {
+    int r = 0;
+    while (bid >= A.a_base[r + 1]) ++r;
+    const int local = bid - A.a_base[r], sp = A.a_split[r];
+    step_type_a(A.S[r], A.ld[r], k, local >> sp, sp ? (local & 1) : -1, A.Ld[r] + (size_t)k * NB * NB, A.Winv[r] + (size_t)k * 1024,
+                A.status[r], L);
+    if (!a_joins) return;
+  }
+  const int nItems = A.b_base[A.n];
+  if (nItems <= 0) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_g = atomicAdd(&ctr[k], 1);
+    __syncthreads();
+    const int g = __builtin_amdgcn_readfirstlane(s_g);
+    if (g >= nItems) break;
+    int r = 0;
+    while (g >= A.b_base[r + 1]) ++r;
+    const int gl = g - A.b_base[r], nR = A.g1[r] - A.g0[r];
+    const long long nG = (long long)A.nP[r] * (A.nP[r] + 1) / 2;
+    const BItem it = b_decode(gl, nR + A.nX[r], nR, A.g0[r], k, kb, A.T[r], A.nP[r], nG, wave);
+    if (!it.ok) continue;
+    if (it.ks == 32) b_quadrant<32>(A.S[r], A.ld[r], it, wave & 3);
+    else b_quadrant<16>(A.S[r], A.ld[r], it, wave & 3);
+  }
+}
+
 #ifdef SLIDE_STAMPS
 extern "C" void slide_debug_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
 #endif
@@ -641,8 +685,8 @@ __global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, do
 // do not depend on x and are prefetched three ahead; the explicit 64x64 inverse of L_cc is assembled from the 16x16 inverses
 // and sub-tiles of the factorisation while the workgroup would otherwise wait.  Polling loads and publishing stores are
 // relaxed device-scope atomics (they bypass the non-coherent cache levels between XCDs); the data is its own flag.
-__global__ __launch_bounds__(256) void k_chol_bwd_chain(const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
-                                                        const double* __restrict__ Winv, const double* __restrict__ yv, double* dp, int* status) {
+__device__ __forceinline__ void bwd_chain_body(const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
+                                               const double* __restrict__ Winv, const double* __restrict__ yv, double* dp, int* status, int bidx) {
   __shared__ double Ms[NB][NB + 1];     // M = L_cc^-1 (lower triangle), Ms[row][col]
   __shared__ double Lo[6][256];         // off-diagonal 16x16 blocks (b > a) of L_cc: Lo[b (b-1)/2 + a][col * 16 + row]
   __shared__ double Ws[4][256];         // 16x16 inverses: Ws[b][col * 16 + row]
@@ -650,7 +694,7 @@ __global__ __launch_bounds__(256) void k_chol_bwd_chain(const double* __restrict
   __shared__ double xs[2][NB];
   __shared__ double ys[NB];
   const int tid = threadIdx.x;
-  const int c = T - 1 - (int)blockIdx.x;
+  const int c = T - 1 - bidx;
   const int col = tid >> 2, part = tid & 3;            // tile work: column col, rows 16 part .. 16 part + 15
   const int nj = T - 1 - c;                            // tiles (j, c), j = T-1-q, q = 0 .. nj-1
   constexpr int RB = 3;
@@ -753,6 +797,22 @@ __global__ __launch_bounds__(256) void k_chol_bwd_chain(const double* __restrict
   x += __shfl_xor(x, 2);
   if (part == 0) __hip_atomic_store(dp + (size_t)c * NB + col, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__global__ __launch_bounds__(256) void k_chol_bwd_chain(const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
+                                                        const double* __restrict__ Winv, const double* __restrict__ yv, double* dp, int* status) {
+  bwd_chain_body(S, ld, T, Ld, Winv, yv, dp, status, (int)blockIdx.x);
+}
+struct BwdBatchArgs {
+  int n;
+  const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX];
+  const double* Ld[CHOL_BATCH_MAX]; const double* Winv[CHOL_BATCH_MAX]; const double* yv[CHOL_BATCH_MAX]; double* dp[CHOL_BATCH_MAX];
+  int* status[CHOL_BATCH_MAX];
+  int base[CHOL_BATCH_MAX + 1];        // prefix sums of T: workgroups of one system are contiguous and in its own order
+};
+__global__ __launch_bounds__(256) void k_chol_bwd_chain_batched(BwdBatchArgs A) {
+  int r = 0;
+  while ((int)blockIdx.x >= A.base[r + 1]) ++r;
+  bwd_chain_body(A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.yv[r], A.dp[r], A.status[r], (int)blockIdx.x - A.base[r]);
+}
 
 
 // ---- marginal covariance of one pose (getPoseCovariance graph.cpp:314-323) ---------------------------------------------------
@@ -837,29 +897,41 @@ void launch_pose_covariance(const double* S, int ld, int T, const double* Ld, co
 // Schedule (see step_type_b): launch 0 factors column 0, launch 1 column 1 with panel 0 (and brings column 2 up to panel 0);
 // from then on every launch k takes the one pending panel k-1 in its column, even launches start the rank-128 pass of panels
 // k-2, k-1 over the trailing matrix, odd launches finish the pass their predecessor started and bring column k+1 up to panel k-1.
-void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, hipStream_t s) {
+void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, hipStream_t s) {
+  hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv, dp);
+}
+struct StepPlan { int kb, nP, g0, g1, nX; long long nA, nB; };
+static int chol_n_cu() {
   static int n_cu = 0;
-  static double frac = 0.5;
   if (!n_cu) {
     int dev = 0;
     hipDeviceProp_t pr;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
-    if (const char* e = getenv("SLIDE_CHOL_FRAC")) frac = atof(e);     // diagnostic: share of a pass done by its first launch
   }
-  const long long nA = T - k;                                   // column-k tiles below the diagonal (+ RHS tile)
-  const int kb = k & ~1;                                        // base of the pair
-  long long nP = 0, g0 = 0, g1 = 0;
-  if (k >= 2) {
-    nP = (T - kb + 1) / 2;                                      // 2x2 tile groups per side of the trailing matrix of the pair
-    const long long nG = nP * (nP + 1) / 2;
+  return n_cu;
+}
+static StepPlan plan_step(int k, int T) {
+  static const double frac = getenv("SLIDE_CHOL_FRAC") ? atof(getenv("SLIDE_CHOL_FRAC")) : 0.5;   // diagnostic: share of a pass done by its first launch
+  StepPlan p{};
+  p.nA = k < T ? T - k : 0;                                     // column-k tiles below the diagonal (+ RHS tile)
+  p.kb = k & ~1;                                                // base of the pair
+  if (k >= 2 && k < T) {
+    p.nP = (T - p.kb + 1) / 2;                                  // 2x2 tile groups per side of the trailing matrix of the pair
+    const long long nG = (long long)p.nP * (p.nP + 1) / 2;
     long long first = (long long)(frac * (double)nG + 0.5);
-    if (first < nP) first = nP;                                 // the group column with tile columns kb+1, kb+2 entirely
+    if (first < p.nP) first = p.nP;                             // the group column with tile columns kb+1, kb+2 entirely
     if (first > nG) first = nG;
-    if (k & 1) { g0 = 2 * first; g1 = 2 * nG; } else { g0 = 0; g1 = 2 * first; }   // items = half groups (one tile row of a 2x2 group)
+    if (k & 1) { p.g0 = (int)(2 * first); p.g1 = (int)(2 * nG); } else { p.g0 = 0; p.g1 = (int)(2 * first); }   // items = half groups
   }
-  const long long nX = (k & 1) && k + 1 < T ? (T - k + 1) / 2 : 0;   // column items: tile rows k+1 .. T of column k+1, two per item
-  const long long nB = g1 - g0 + nX;
+  p.nX = (k & 1) && k + 1 < T ? (T - k + 1) / 2 : 0;            // column items: tile rows k+1 .. T of column k+1, two per item
+  p.nB = p.g1 - p.g0 + p.nX;
+  return p;
+}
+void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, hipStream_t s) {
+  const int n_cu = chol_n_cu();
+  const StepPlan p = plan_step(k, T);
+  const long long nA = p.nA, nB = p.nB;
   static const int split_pct = getenv("SLIDE_CHOL_ASPLIT") ? atoi(getenv("SLIDE_CHOL_ASPLIT")) : 100;   // diagnostic: 0 = never
   // two workgroups per type-A tile once the launch is bound by the chain, not by the flood
   const int a_split = (k > 0 && (2 * nA + nB) * 100 <= (long long)n_cu * split_pct) ? 1 : 0;
@@ -869,11 +941,45 @@ void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv,
   const long long free_cu = n_cu - nAw > 8 ? n_cu - nAw : 8;
   static const int join_mul = getenv("SLIDE_CHOL_JOIN") ? atoi(getenv("SLIDE_CHOL_JOIN")) : 1;
   const int a_joins = nB > join_mul * free_cu ? 1 : 0;
-  hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nAw + extra)), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status, ctr, kb, (int)nP,
-                     (int)g0, (int)g1, (int)nX, a_joins, a_split);
+  hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nAw + extra)), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status, ctr, p.kb, p.nP,
+                     p.g0, p.g1, p.nX, a_joins, a_split);
 }
-void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, hipStream_t s) {
-  hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv, dp);
+// The factorisations + solves of several systems as one launch sequence (max T step launches, the extractions, one chained backward
+// substitution): d[i] describes system i; ctr is the work counter array of the batch (max T + 2 ints, zeroed once).
+void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s) {
+  const int n_cu = chol_n_cu();
+  int Tmax = 0;
+  for (int i = 0; i < n; ++i) Tmax = d[i].T > Tmax ? d[i].T : Tmax;
+  for (int k = 0; k < Tmax; ++k) {
+    CholBatchArgs A{};
+    A.n = n;
+    long long nA2 = 0, nBt = 0;
+    StepPlan pl[CHOL_BATCH_MAX];
+    for (int i = 0; i < n; ++i) { pl[i] = plan_step(k, d[i].T); nA2 += 2 * pl[i].nA; nBt += pl[i].nB; }
+    const int a_split = (k > 0 && nA2 + nBt <= n_cu) ? 1 : 0;
+    A.a_base[0] = A.b_base[0] = 0;
+    for (int i = 0; i < n; ++i) {
+      A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.Ld[i] = d[i].Ld; A.Winv[i] = d[i].Winv; A.status[i] = d[i].status;
+      A.nP[i] = pl[i].nP; A.g0[i] = pl[i].g0; A.g1[i] = pl[i].g1; A.nX[i] = pl[i].nX; A.a_split[i] = a_split;
+      A.a_base[i + 1] = A.a_base[i] + (int)(pl[i].nA << a_split);
+      A.b_base[i + 1] = A.b_base[i] + (int)pl[i].nB;
+    }
+    const long long nAw = A.a_base[n], nB = A.b_base[n];
+    const long long extra = nB < n_cu ? nB : n_cu;
+    const long long free_cu = n_cu - nAw > 8 ? n_cu - nAw : 8;
+    const int a_joins = nB > free_cu ? 1 : 0;
+    hipLaunchKernelGGL(k_chol_step_batched, dim3((unsigned)(nAw + extra)), dim3(512), 0, s, A, k, k & ~1, ctr, a_joins);
+  }
+  BwdBatchArgs B{};
+  B.n = n;
+  B.base[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    launch_chol_extract_y(d[i].S, d[i].ld, d[i].T, d[i].yv, d[i].dp, s);
+    B.S[i] = d[i].S; B.ld[i] = d[i].ld; B.T[i] = d[i].T; B.Ld[i] = d[i].Ld; B.Winv[i] = d[i].Winv; B.yv[i] = d[i].yv; B.dp[i] = d[i].dp;
+    B.status[i] = d[i].status;
+    B.base[i + 1] = B.base[i] + d[i].T;
+  }
+  if (B.base[n] > 0) hipLaunchKernelGGL(k_chol_bwd_chain_batched, dim3(B.base[n]), dim3(256), 0, s, B);
 }
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp,
                          int* status, hipStream_t s) {

@@ -1,4 +1,6 @@
 // Host side of the device-resident factor graph (see host_graph.hpp).
+#include <chrono>
+
 #include "host_graph.hpp"
 
 #include <algorithm>
@@ -326,6 +328,65 @@ int HostGraph::merge_pending() {
     }
   }
   pend_facs.clear();
+  return SLIDE_OK;
+}
+
+CholBatch::CholBatch(int n_) : n(n_ < 1 ? 1 : (n_ > 8 ? 8 : n_)), sys(n), ev_in(n, nullptr) {}
+CholBatch::~CholBatch() {
+  for (hipEvent_t e : ev_in) if (e) (void)hipEventDestroy(e);
+  if (ev_out) (void)hipEventDestroy(ev_out);
+  if (master) (void)hipStreamDestroy(master);
+  if (d_ctr) (void)hipFree(d_ctr);
+}
+int CholBatch::factor_solve(int slot, const GraphDev& G, hipStream_t s) {
+  if (slot < 0 || slot >= n) return SLIDE_ERR_INVALID;
+  std::unique_lock<std::mutex> lk(mtx);
+  if (!master) {
+    SL_HIP(hipStreamCreateWithFlags(&master, hipStreamNonBlocking));
+    SL_HIP(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+  }
+  if (!ev_in[slot]) SL_HIP(hipEventCreateWithFlags(&ev_in[slot], hipEventDisableTiming));
+  sys[slot] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status};
+  SL_HIP(hipEventRecord(ev_in[slot], s));
+  const unsigned long long my_gen = generation;
+  if (++arrived == n) {
+    int rc = SLIDE_OK;
+    int Tmax = 0;
+    for (const CholSystem& c : sys) Tmax = c.T > Tmax ? c.T : Tmax;
+    if (Tmax + 2 > ctr_cap) {
+      if (d_ctr) { (void)hipStreamSynchronize(master); (void)hipFree(d_ctr); d_ctr = nullptr; }
+      ctr_cap = 2 * (Tmax + 2);
+      if (hipMalloc(reinterpret_cast<void**>(&d_ctr), ctr_cap * sizeof(int)) != hipSuccess) rc = SLIDE_ERR_HIP;
+      else if (hipMemsetAsync(d_ctr, 0, ctr_cap * sizeof(int), master) != hipSuccess) rc = SLIDE_ERR_HIP;
+    }
+    for (int i = 0; rc == SLIDE_OK && i < n; ++i)
+      if (hipStreamWaitEvent(master, ev_in[i], 0) != hipSuccess) rc = SLIDE_ERR_HIP;
+    if (rc == SLIDE_OK) {
+      launch_chol_batch(sys.data(), n, d_ctr, master);
+      if (hipEventRecord(ev_out, master) != hipSuccess) rc = SLIDE_ERR_HIP;
+    }
+    gen_status = rc;
+    arrived = 0;
+    ++generation;
+    cv.notify_all();
+  } else {
+    if (!cv.wait_for(lk, std::chrono::seconds(60), [&] { return generation != my_gen; })) {
+      --arrived;
+      g_last_error = "batched factorisation: the other graphs of the batch did not arrive";
+      return SLIDE_ERR_RUNTIME;
+    }
+  }
+  if (gen_status != SLIDE_OK) return gen_status;
+  SL_HIP(hipStreamWaitEvent(s, ev_out, 0));
+  return SLIDE_OK;
+}
+
+int HostGraph::factor_and_solve(hipStream_t s) {
+  if (batch) return batch->factor_solve(batch_slot, G, s);
+  for (int k = 0; k < G.T; ++k)
+    launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, s);
+  launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, s);
+  launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, s);
   return SLIDE_OK;
 }
 
@@ -691,10 +752,10 @@ int HostGraph::enqueue_phase(int phase, double* d_buf) {
     launch_landmark(G, 2, s);
     launch_pose(G, s);
     launch_schur(G, s);
-    for (int k = 0; k < G.T; ++k)
-      launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, s);
-    launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, s);
-    launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, s);
+    {
+      const int rc = factor_and_solve(s);
+      if (rc != SLIDE_OK) return rc;
+    }
     launch_backsub(G, 1, s);
     launch_shared_pack(G, 1, d_buf, s);
   } else {
@@ -721,7 +782,7 @@ int HostGraph::dist_phase(int phase, double* d_buf) {
     static const bool env_graph = !(getenv("SLIDE_NO_GRAPH") && getenv("SLIDE_NO_GRAPH")[0] == '1');
     PhaseGraph& pg = phase_graph[phase];
     static const int env_mask = getenv("SLIDE_PHASE_GRAPH_MASK") ? atoi(getenv("SLIDE_PHASE_GRAPH_MASK")) : 7;
-    bool use_graph = env_graph && !prof.on && G.T > 4 && ((env_mask >> phase) & 1);
+    bool use_graph = env_graph && !prof.on && G.T > 4 && ((env_mask >> phase) & 1) && !(batch && phase == 1);   // (the batch spans streams)
     if (use_graph && !(pg.exec && pg.buf == d_buf && std::memcmp(&pg.G, &G, sizeof(GraphDev)) == 0)) {
       if (pg.exec) { (void)hipGraphExecDestroy(pg.exec); pg.exec = nullptr; }
       hipGraph_t graph = nullptr;

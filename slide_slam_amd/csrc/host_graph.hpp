@@ -7,6 +7,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -116,6 +117,32 @@ struct PendFac {
   double sigma[9];
 };
 
+// The dense factor + solve of several graphs that share a GPU as ONE launch sequence (launch_chol_batch): every graph's thread
+// arrives with its system assembled on its own stream, the last one enqueues the batched launches on the batch's stream behind
+// all of them, and every graph's stream continues behind the batch.  All joined graphs must solve in lockstep (the distributed
+// pass does); a rendezvous that is not completed within 60 s returns SLIDE_ERR_RUNTIME.
+class CholBatch {
+ public:
+  explicit CholBatch(int n);
+  ~CholBatch();
+  int n_slots() const { return n; }
+  int factor_solve(int slot, const GraphDev& G, hipStream_t s);
+
+ private:
+  int n;
+  std::mutex mtx;
+  std::condition_variable cv;
+  int arrived = 0;
+  unsigned long long generation = 0;
+  int gen_status = SLIDE_OK;
+  std::vector<CholSystem> sys;
+  std::vector<hipEvent_t> ev_in;
+  hipEvent_t ev_out = nullptr;
+  hipStream_t master = nullptr;
+  int* d_ctr = nullptr;
+  int ctr_cap = 0;
+};
+
 class HostGraph {
  public:
   explicit HostGraph(const slide_params_t& p);
@@ -131,6 +158,7 @@ class HostGraph {
   int add_relative_meas_ghost(const double* rel7, uint64_t idx, int robot, int slot, bool local_first);
   int set_ghosts(const int32_t* own_robot, const int64_t* own_idx, int n_slots);
   int pose_covariance(int robot, uint64_t idx, double* cov36);
+  void join_batch(CholBatch* b, int slot) { batch = b; batch_slot = slot; }
   int add_point_landmark(uint64_t idx, const double* xyz);
   int add_range_bearing(int robot, uint64_t pose_idx, uint64_t lm_idx, const double* bearing, double range);
   int add_cube(int robot, uint64_t pose_idx, uint64_t cube_idx, const SE3& pose, const SE3& cube_world, const double* scale,
@@ -202,6 +230,9 @@ class HostGraph {
   bool factor_valid = false;            // S / Ld / Winv hold the factor of the system of the last solve
   DevArr<int> d_status;
   UploadBatch ub;
+  CholBatch* batch = nullptr;           // shared factor + solve with the other graphs of this GPU (not owned)
+  int batch_slot = 0;
+  int factor_and_solve(hipStream_t s);  // the Cholesky part of a pass: own launches, or the batch's
   int Tcap = 0;
   // hipGraph of one pass, captured when the same resident graph is solved repeatedly (kernel arguments are
   // baked in, so any change of counts / pointers / threshold invalidates it)

@@ -18,7 +18,7 @@ from test_distributed import _check, _joint_optimum                       # noqa
 from dist_worker import gpu_matcher, oracle_matcher                       # noqa: E402
 
 
-def _run_threads(make_shard, matcher, preset, iters, device=None):
+def _run_threads(make_shard, matcher, preset, iters, device=None, batch=None):
     cfg = SynthConfig.preset(preset)
     world_map = make_world(cfg)
     R = cfg.robots
@@ -32,7 +32,11 @@ def _run_threads(make_shard, matcher, preset, iters, device=None):
             replay_single(shard, log, robot=0, collect=False)
             dg = DistributedGraph(shard, group.comm(t, device), t, R)
             info = dg.setup(matcher)
+            if batch is not None:
+                shard.graph.join_chol_batch(batch, t)
             dg.gauss_newton(iters)
+            if batch is not None:
+                shard.graph.join_chol_batch(None)
             P = len(log["rel7"])
             out[t] = (np.array([shard.graph.get_pose12(0, k)[1] for k in range(P)]), info)
         except BaseException as e:      # a dead thread would leave the others at the barrier
@@ -56,13 +60,15 @@ def test_thread_shards_oracle():
 
 
 @pytest.mark.gpu
-def test_thread_shards_gpu(gpu, tmp_path):
-    """HIP shards of two robots on concurrent streams of the one GPU.  Runs in a fresh process: torch has to initialise the
+@pytest.mark.parametrize("mode", ["streams", "batch"])
+def test_thread_shards_gpu(gpu, tmp_path, mode):
+    """HIP shards of two robots on the one GPU: on concurrent streams, or with their dense factor + solve batched into one launch
+    sequence (slide_chol_batch_*).  Runs in a fresh process: torch has to initialise the
     device before this library's HIP runtime is loaded (the other order leaves torch without a GPU in this image)."""
     import subprocess
     joint, counts = _joint_optimum("C3tiny")
     out = str(tmp_path / "t.npz")
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), out], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), out, mode], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     _check(np.load(out), joint, counts, 1e-4)
 
@@ -73,5 +79,7 @@ if __name__ == "__main__":
     torch.zeros(1, device="cuda")
     import slide_slam_amd as s
     s.device_check()
-    z = _run_threads(lambda: s.SlideBackend(s.default_params(), 1), gpu_matcher, "C3tiny", 60, device=torch.device("cuda", 0))
+    use_batch = len(sys.argv) > 2 and sys.argv[2] == "batch"
+    z = _run_threads(lambda: s.SlideBackend(s.default_params(), 1), gpu_matcher, "C3tiny", 60, device=torch.device("cuda", 0),
+                     batch=s.CholBatch(2) if use_batch else None)
     np.savez(sys.argv[1], **z)
