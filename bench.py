@@ -102,7 +102,10 @@ def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
     sync = threading.Barrier(R + 1)
     conc = int(os.environ.get("SLIDE_BENCH_CONCURRENCY", "0"))
     sem = threading.Semaphore(conc) if conc > 0 else None
-    batch = s.CholBatch(R) if os.environ.get("SLIDE_BENCH_BATCH", "0") == "1" else None      # opt-in: not faster than streams yet
+    # one launch sequence for the factorisations of all local robots pays off from about eight robots per GPU on (measured: 2 / 4 /
+    # 8 robots 1.91 / 3.32 / 6.10 ms per pass batched, 1.78 / 3.03 / 6.92 ms on independent streams); SLIDE_BENCH_BATCH=0|1 forces
+    use_batch = os.environ.get("SLIDE_BENCH_BATCH", "1" if R > 4 else "0") == "1"
+    batch = s.CholBatch(R) if use_batch else None
     timing = [None]
     shards, infos, reps, errs = [None] * R, [None] * R, [None] * R, []
 
@@ -124,6 +127,7 @@ def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
             shards[t] = gb
             if batch is not None:      # the dense factor + solve of all local robots as one launch sequence per pass
                 gb.graph.join_chol_batch(batch, t)
+                dg.local_batch = world == 1     # all robots of the job on this GPU: exchanges as device-side sums, one sync per pass
             for _ in range(args.warmup):
                 dg.gauss_newton(1)
             if t == 0 and os.environ.get("SLIDE_BENCH_TIMING") == "1":      # diagnostic: wall time per call of the pass, thread 0

@@ -136,6 +136,10 @@ typedef struct slide_chol_batch slide_chol_batch_t;
 slide_chol_batch_t* slide_chol_batch_create(int n_graphs);      /* 1 .. 8 */
 void slide_chol_batch_destroy(slide_chol_batch_t* b);
 int slide_graph_join_chol_batch(slide_graph_t* g, slide_chol_batch_t* b, int slot);
+/* One distributed pass (phases 0, 1, 2 of slide_graph_dist_phase) when the batch holds every robot of the job: the two exchanges are
+ * device-side sums between the joined graphs' buffers (d_buf: this graph's exchange buffer, 54 doubles per shared slot), no host
+ * synchronisation inside the pass.  Called from every joined graph's thread in lockstep. */
+int slide_graph_dist_pass_local(slide_graph_t* g, double* d_buf);
 /* Sharded mode, inter-robot relative-pose factors (addRelativeMeasFactor graph.cpp:247-258 between poses of two ranks).
  * Ghost slots enumerate, identically on every rank, the poses such factors touch; slot i is this rank's pose
  * (own_robot[i], own_idx[i]) or belongs to another rank (own_robot[i] < 0).  A factor is added on BOTH ranks, each with its

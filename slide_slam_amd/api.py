@@ -28,7 +28,7 @@ EXPORTS = [
     "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
     "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
-    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
+    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
     "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
     "slide_dense_spd_solve", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
@@ -240,6 +240,10 @@ class SlideGraph:
     def join_chol_batch(self, batch, slot=0):
         """Share the dense factor + solve of phase 1 with the other graphs of `batch` (CholBatch; None leaves it)."""
         _check(self.L.slide_graph_join_chol_batch(self.h, C.c_void_p(batch.h if batch is not None else None), C.c_int(slot)))
+
+    def dist_pass_local(self, d_buf_ptr):
+        """One distributed pass with device-side exchanges: every robot of the job must be in this graph's CholBatch."""
+        return _check(self.L.slide_graph_dist_pass_local(self.h, C.c_void_p(d_buf_ptr)))
 
     def dist_phase(self, phase, d_buf_ptr):
         """d_buf_ptr: integer DEVICE address of the exchange buffer (e.g. torch_tensor.data_ptr())."""

@@ -167,6 +167,7 @@ int HostGraph::add_relative_meas_ghost(const double* rel7, uint64_t idx, int rob
 // Ghost slots: a global, rank-independent enumeration of the poses touched by inter-robot relative-pose factors;
 // slot i is this rank's pose (own_robot[i], own_idx[i]) or none (own_robot[i] < 0).
 int HostGraph::set_ghosts(const int32_t* own_robot, const int64_t* own_idx, int n_slots) {
+  topo_dirty = true;      // the slot tables are part of the device view upload_new assembles
   int rc = merge_pending();
   if (rc != SLIDE_OK) return rc;
   rc = upload_new();
@@ -257,6 +258,7 @@ int HostGraph::add_cylinder(int robot, uint64_t pose_idx, uint64_t cyl_idx, cons
 
 // ---- merge fgraph / fvalues into the resident arrays (what isam->update(fgraph, fvalues) ingests) ------
 int HostGraph::merge_pending() {
+  if (!pend_vars.empty() || !pend_facs.empty()) topo_dirty = true;
   for (const PendVar& v : pend_vars) {
     if (v.type == VT_POSE) {
       if (key2pose.count(v.key)) continue;   // GTSAM would throw ValuesKeyAlreadyExists
@@ -331,7 +333,7 @@ int HostGraph::merge_pending() {
   return SLIDE_OK;
 }
 
-CholBatch::CholBatch(int n_) : n(n_ < 1 ? 1 : (n_ > 8 ? 8 : n_)), sys(n), ev_in(n, nullptr) {}
+CholBatch::CholBatch(int n_) : n(n_ < 1 ? 1 : (n_ > 8 ? 8 : n_)), sys(n), bufs(n, nullptr), ev_in(n, nullptr) {}
 CholBatch::~CholBatch() {
   for (hipEvent_t e : ev_in) if (e) (void)hipEventDestroy(e);
   if (ev_out) (void)hipEventDestroy(ev_out);
@@ -340,29 +342,48 @@ CholBatch::~CholBatch() {
 }
 int CholBatch::factor_solve(int slot, const GraphDev& G, hipStream_t s) {
   if (slot < 0 || slot >= n) return SLIDE_ERR_INVALID;
+  {
+    std::lock_guard<std::mutex> lk(mtx);
+    sys[slot] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status};
+  }
+  return rendezvous(slot, s, false, 0);
+}
+int CholBatch::all_reduce(int slot, double* d_buf, int count, hipStream_t s) {
+  if (slot < 0 || slot >= n) return SLIDE_ERR_INVALID;
+  {
+    std::lock_guard<std::mutex> lk(mtx);
+    bufs[slot] = d_buf;
+  }
+  return rendezvous(slot, s, true, count);
+}
+// Every joined graph's thread arrives with its work enqueued on its own stream `s`; the last one enqueues the joint work on the
+// batch's stream behind all of them; every stream continues behind that.
+int CholBatch::rendezvous(int slot, hipStream_t s, bool reduce, int count) {
   std::unique_lock<std::mutex> lk(mtx);
   if (!master) {
     SL_HIP(hipStreamCreateWithFlags(&master, hipStreamNonBlocking));
     SL_HIP(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
   }
   if (!ev_in[slot]) SL_HIP(hipEventCreateWithFlags(&ev_in[slot], hipEventDisableTiming));
-  sys[slot] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status};
   SL_HIP(hipEventRecord(ev_in[slot], s));
   const unsigned long long my_gen = generation;
   if (++arrived == n) {
     int rc = SLIDE_OK;
-    int Tmax = 0;
-    for (const CholSystem& c : sys) Tmax = c.T > Tmax ? c.T : Tmax;
-    if (Tmax + 2 > ctr_cap) {
-      if (d_ctr) { (void)hipStreamSynchronize(master); (void)hipFree(d_ctr); d_ctr = nullptr; }
-      ctr_cap = 2 * (Tmax + 2);
-      if (hipMalloc(reinterpret_cast<void**>(&d_ctr), ctr_cap * sizeof(int)) != hipSuccess) rc = SLIDE_ERR_HIP;
-      else if (hipMemsetAsync(d_ctr, 0, ctr_cap * sizeof(int), master) != hipSuccess) rc = SLIDE_ERR_HIP;
+    if (!reduce) {
+      int Tmax = 0;
+      for (const CholSystem& c : sys) Tmax = c.T > Tmax ? c.T : Tmax;
+      if (Tmax + 2 > ctr_cap) {
+        if (d_ctr) { (void)hipStreamSynchronize(master); (void)hipFree(d_ctr); d_ctr = nullptr; }
+        ctr_cap = 2 * (Tmax + 2);
+        if (hipMalloc(reinterpret_cast<void**>(&d_ctr), ctr_cap * sizeof(int)) != hipSuccess) rc = SLIDE_ERR_HIP;
+        else if (hipMemsetAsync(d_ctr, 0, ctr_cap * sizeof(int), master) != hipSuccess) rc = SLIDE_ERR_HIP;
+      }
     }
     for (int i = 0; rc == SLIDE_OK && i < n; ++i)
       if (hipStreamWaitEvent(master, ev_in[i], 0) != hipSuccess) rc = SLIDE_ERR_HIP;
     if (rc == SLIDE_OK) {
-      launch_chol_batch(sys.data(), n, d_ctr, master);
+      if (reduce) launch_sum_bcast(bufs.data(), n, count, master);
+      else launch_chol_batch(sys.data(), n, d_ctr, master);
       if (hipEventRecord(ev_out, master) != hipSuccess) rc = SLIDE_ERR_HIP;
     }
     gen_status = rc;
@@ -372,7 +393,7 @@ int CholBatch::factor_solve(int slot, const GraphDev& G, hipStream_t s) {
   } else {
     if (!cv.wait_for(lk, std::chrono::seconds(60), [&] { return generation != my_gen; })) {
       --arrived;
-      g_last_error = "batched factorisation: the other graphs of the batch did not arrive";
+      g_last_error = "batch rendezvous: the other graphs of the batch did not arrive";
       return SLIDE_ERR_RUNTIME;
     }
   }
@@ -510,6 +531,7 @@ static int up_csr(DevArr<int>& dptr, DevArr<int>& dval, const std::vector<std::v
 
 int HostGraph::upload_new() {
   hipStream_t s = stream;
+  if (!topo_dirty && uploaded_once) return SLIDE_OK;      // nothing was added since the last upload: values and topology are resident
   if (ub.begin() != SLIDE_OK) return SLIDE_ERR_HIP;
   struct BatchGuard { ~BatchGuard() { UploadBatch::current = nullptr; } } batch_guard;      // an error return abandons the batch
   const size_t Pn = h_pose_val.size() / 12, Ln = h_lm_type.size();
@@ -603,6 +625,8 @@ int HostGraph::upload_new() {
     if (d_yv.ensure((size_t)Tcap * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_dp.ensure((size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
   }
+  topo_dirty = false;
+  uploaded_once = true;
   up_P = Pn; up_L = Ln; up_pr = npr; up_bt = nbt; up_lf = nlf; up_gh = ngh;
   up_br = h_br_z.size() / 4; up_cu = h_cu_z.size() / 15; up_cy = h_cy_z.size() / 7;
 
@@ -711,6 +735,7 @@ int HostGraph::run_update(double relin_thr, int iterations) {
 // Slots are a global, rank-independent enumeration of the landmarks seen by more than one robot; slot i maps
 // to this rank's landmark (cls[i], idx[i]) or to none (cls[i] < 0).
 int HostGraph::set_shared(const int32_t* cls, const int64_t* idx, const int32_t* owner, int n_slots) {
+  topo_dirty = true;      // the slot tables are part of the device view upload_new assembles
   int rc = merge_pending();
   if (rc != SLIDE_OK) return rc;
   rc = upload_new();
@@ -840,6 +865,33 @@ int HostGraph::dist_phase(int phase, double* d_buf) {
   }
   SL_HIP(hipStreamSynchronize(s));
   SL_HIP(hipGetLastError());
+  return SLIDE_OK;
+}
+
+// One distributed Gauss-Newton pass of a graph whose batch holds EVERY robot of the job (all on this GPU): phases 0 / 1 / 2 with
+// the two exchanges as device-side sums between the batch's buffers — stream-ordered, one host synchronisation at the end.
+int HostGraph::dist_pass_local(double* d_buf) {
+  if (!batch) { g_last_error = "dist_pass_local: the graph is in no batch"; return SLIDE_ERR_INVALID; }
+  hipStream_t s = stream;
+  int rc = merge_pending();
+  if (rc != SLIDE_OK) return rc;
+  rc = upload_new();
+  if (rc != SLIDE_OK) return rc;
+  G.relin_thr = 0.0;
+  SL_HIP(hipMemsetAsync(d_status.d, 0, 8 * sizeof(int), s));
+  if ((rc = enqueue_phase(0, d_buf)) != SLIDE_OK) return rc;
+  if ((rc = batch->all_reduce(batch_slot, d_buf, 54 * G.n_slots, s)) != SLIDE_OK) return rc;
+  if ((rc = enqueue_phase(1, d_buf)) != SLIDE_OK) return rc;
+  if ((rc = batch->all_reduce(batch_slot, d_buf, 9 * G.n_slots, s)) != SLIDE_OK) return rc;
+  if ((rc = enqueue_phase(2, d_buf)) != SLIDE_OK) return rc;
+  int st[8];
+  SL_HIP(hipMemcpyAsync(st, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+  SL_HIP(hipStreamSynchronize(s));
+  SL_HIP(hipGetLastError());
+  if (st[0] || st[1]) {
+    g_last_error = st[0] ? "landmark block not positive definite" : "reduced pose system not positive definite";
+    return SLIDE_ERR_NOT_SPD;
+  }
   return SLIDE_OK;
 }
 

@@ -127,6 +127,7 @@ class CholBatch {
   ~CholBatch();
   int n_slots() const { return n; }
   int factor_solve(int slot, const GraphDev& G, hipStream_t s);
+  int all_reduce(int slot, double* d_buf, int count, hipStream_t s);     // sum over the joined graphs' buffers, stream-ordered
 
  private:
   int n;
@@ -136,6 +137,8 @@ class CholBatch {
   unsigned long long generation = 0;
   int gen_status = SLIDE_OK;
   std::vector<CholSystem> sys;
+  std::vector<double*> bufs;
+  int rendezvous(int slot, hipStream_t s, bool reduce, int count);
   std::vector<hipEvent_t> ev_in;
   hipEvent_t ev_out = nullptr;
   hipStream_t master = nullptr;
@@ -159,6 +162,7 @@ class HostGraph {
   int set_ghosts(const int32_t* own_robot, const int64_t* own_idx, int n_slots);
   int pose_covariance(int robot, uint64_t idx, double* cov36);
   void join_batch(CholBatch* b, int slot) { batch = b; batch_slot = slot; }
+  int dist_pass_local(double* d_buf);     // one distributed pass when every robot of the job is in this graph's batch (no host syncs inside)
   int add_point_landmark(uint64_t idx, const double* xyz);
   int add_range_bearing(int robot, uint64_t pose_idx, uint64_t lm_idx, const double* bearing, double range);
   int add_cube(int robot, uint64_t pose_idx, uint64_t cube_idx, const SE3& pose, const SE3& cube_world, const double* scale,
@@ -209,6 +213,7 @@ class HostGraph {
   std::vector<std::vector<int>> lm_fids, pose_fids, pose_bt;
   size_t up_P = 0, up_L = 0, up_pr = 0, up_bt = 0, up_lf = 0, up_br = 0, up_cu = 0, up_cy = 0;
   int last_relin = 0;
+  bool topo_dirty = true, uploaded_once = false;      // upload_new has work only after merge_pending consumed something
 
   DevArr<double> d_pose_val, d_pose_delta, d_pose_est, d_lm_val, d_lm_delta, d_lm_est;
   DevArr<int> d_lm_type;

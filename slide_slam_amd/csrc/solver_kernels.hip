@@ -755,6 +755,23 @@ __global__ __launch_bounds__(256) void k_scatter(const unsigned char* __restrict
   const unsigned n = sg.bytes >> 2;
   for (unsigned i = blockIdx.y * 256 + threadIdx.x; i < n; i += 256 * gridDim.y) dst[i] = src[i];
 }
+// all-reduce(sum) between the exchange buffers of the robots that share this GPU: every buffer ends up with the sum
+struct SumBcastArgs { int n; double* buf[8]; };
+__global__ __launch_bounds__(256) void k_sum_bcast(SumBcastArgs A, int count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  double s = 0.0;
+  for (int r = 0; r < A.n; ++r) s += A.buf[r][i];        // fixed order: the result does not depend on arrival order
+  for (int r = 0; r < A.n; ++r) A.buf[r][i] = s;
+}
+void launch_sum_bcast(double* const* bufs, int n, int count, hipStream_t s) {
+  if (count <= 0 || n <= 0) return;
+  SumBcastArgs A{};
+  A.n = n;
+  for (int r = 0; r < n; ++r) A.buf[r] = bufs[r];
+  hipLaunchKernelGGL(k_sum_bcast, dim3((count + 255) / 256), dim3(256), 0, s, A, count);
+}
+
 // the reverse: device arrays gathered into one staging buffer for ONE device -> host copy (DownloadBatch); `dst` of a
 // descriptor is the source pointer here
 __global__ __launch_bounds__(256) void k_gather(unsigned char* __restrict__ stage, unsigned desc_off) {

@@ -18,7 +18,7 @@ from test_distributed import _check, _joint_optimum                       # noqa
 from dist_worker import gpu_matcher, oracle_matcher                       # noqa: E402
 
 
-def _run_threads(make_shard, matcher, preset, iters, device=None, batch=None):
+def _run_threads(make_shard, matcher, preset, iters, device=None, batch=None, local_pass=False):
     cfg = SynthConfig.preset(preset)
     world_map = make_world(cfg)
     R = cfg.robots
@@ -34,6 +34,7 @@ def _run_threads(make_shard, matcher, preset, iters, device=None, batch=None):
             info = dg.setup(matcher)
             if batch is not None:
                 shard.graph.join_chol_batch(batch, t)
+                dg.local_batch = local_pass
             dg.gauss_newton(iters)
             if batch is not None:
                 shard.graph.join_chol_batch(None)
@@ -60,7 +61,7 @@ def test_thread_shards_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["streams", "batch"])
+@pytest.mark.parametrize("mode", ["streams", "batch", "batch-local"])
 def test_thread_shards_gpu(gpu, tmp_path, mode):
     """HIP shards of two robots on the one GPU: on concurrent streams, or with their dense factor + solve batched into one launch
     sequence (slide_chol_batch_*).  Runs in a fresh process: torch has to initialise the
@@ -79,7 +80,7 @@ if __name__ == "__main__":
     torch.zeros(1, device="cuda")
     import slide_slam_amd as s
     s.device_check()
-    use_batch = len(sys.argv) > 2 and sys.argv[2] == "batch"
+    mode = sys.argv[2] if len(sys.argv) > 2 else "streams"
     z = _run_threads(lambda: s.SlideBackend(s.default_params(), 1), gpu_matcher, "C3tiny", 60, device=torch.device("cuda", 0),
-                     batch=s.CholBatch(2) if use_batch else None)
+                     batch=s.CholBatch(2) if mode != "streams" else None, local_pass=(mode == "batch-local"))
     np.savez(sys.argv[1], **z)
