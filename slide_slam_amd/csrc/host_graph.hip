@@ -772,21 +772,57 @@ int HostGraph::enqueue_phase(int phase, double* d_buf) {
     launch_linearize(G, s);
     launch_landmark(G, 1, s);
     launch_shared_pack(G, 0, d_buf, s);
-  } else if (phase == 1) {
-    launch_shared_unpack(G, 0, d_buf, s);
-    launch_landmark(G, 2, s);
-    launch_pose(G, s);
-    launch_schur(G, s);
-    {
+  } else if (phase == 1 || phase == 3 || phase == 4) {      // 3 / 4: the parts of phase 1 before / after the factor + solve
+    if (phase != 4) {
+      launch_shared_unpack(G, 0, d_buf, s);
+      launch_landmark(G, 2, s);
+      launch_pose(G, s);
+      launch_schur(G, s);
+    }
+    if (phase == 1) {
       const int rc = factor_and_solve(s);
       if (rc != SLIDE_OK) return rc;
     }
-    launch_backsub(G, 1, s);
-    launch_shared_pack(G, 1, d_buf, s);
+    if (phase != 3) {
+      launch_backsub(G, 1, s);
+      launch_shared_pack(G, 1, d_buf, s);
+    }
   } else {
     launch_shared_unpack(G, 1, d_buf, s);
     launch_backsub(G, 2, s);
     launch_estimate(G, s);
+  }
+  return SLIDE_OK;
+}
+
+// The launch sequence of a phase (0, 1, 2; 3 / 4 = phase 1 before / after the factor + solve) is replayed as a hipGraph while the
+// resident graph and the exchange buffer stay the same (every pass of a distributed Gauss-Newton run): ~90 launches per pass otherwise
+int HostGraph::launch_phase(int phase, double* d_buf) {
+  hipStream_t s = stream;
+  static const bool env_graph = !(getenv("SLIDE_NO_GRAPH") && getenv("SLIDE_NO_GRAPH")[0] == '1');
+  PhaseGraph& pg = phase_graph[phase];
+  static const int env_mask = getenv("SLIDE_PHASE_GRAPH_MASK") ? atoi(getenv("SLIDE_PHASE_GRAPH_MASK")) : 31;
+  bool use_graph = env_graph && !prof.on && G.T > 4 && ((env_mask >> phase) & 1) && !(batch && phase == 1);   // (the batch spans streams)
+  if (use_graph && !(pg.exec && pg.buf == d_buf && std::memcmp(&pg.G, &G, sizeof(GraphDev)) == 0)) {
+    if (pg.exec) { (void)hipGraphExecDestroy(pg.exec); pg.exec = nullptr; }
+    hipGraph_t graph = nullptr;
+    SL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_phase(phase, d_buf);
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc != SLIDE_OK || e != hipSuccess || graph == nullptr) {
+      (void)hipGetLastError();
+      use_graph = false;
+    } else {
+      const hipError_t ei = hipGraphInstantiate(&pg.exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ei != hipSuccess) { pg.exec = nullptr; (void)hipGetLastError(); use_graph = false; }
+      else { pg.G = G; pg.buf = d_buf; }
+    }
+  }
+  if (use_graph) SL_HIP(hipGraphLaunch(pg.exec, s));
+  else {
+    const int rc = enqueue_phase(phase, d_buf);
+    if (rc != SLIDE_OK) return rc;
   }
   return SLIDE_OK;
 }
@@ -802,31 +838,8 @@ int HostGraph::dist_phase(int phase, double* d_buf) {
       G.relin_thr = 0.0;
       SL_HIP(hipMemsetAsync(d_status.d, 0, 8 * sizeof(int), s));     // (outside the captured sequence, as in run_update)
     }
-    // the launch sequence of a phase is replayed as a hipGraph while the resident graph and the exchange buffer stay the
-    // same (every pass of a distributed Gauss-Newton run): ~90 launches per pass otherwise
-    static const bool env_graph = !(getenv("SLIDE_NO_GRAPH") && getenv("SLIDE_NO_GRAPH")[0] == '1');
-    PhaseGraph& pg = phase_graph[phase];
-    static const int env_mask = getenv("SLIDE_PHASE_GRAPH_MASK") ? atoi(getenv("SLIDE_PHASE_GRAPH_MASK")) : 7;
-    bool use_graph = env_graph && !prof.on && G.T > 4 && ((env_mask >> phase) & 1) && !(batch && phase == 1);   // (the batch spans streams)
-    if (use_graph && !(pg.exec && pg.buf == d_buf && std::memcmp(&pg.G, &G, sizeof(GraphDev)) == 0)) {
-      if (pg.exec) { (void)hipGraphExecDestroy(pg.exec); pg.exec = nullptr; }
-      hipGraph_t graph = nullptr;
-      SL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      const int rc = enqueue_phase(phase, d_buf);
-      const hipError_t e = hipStreamEndCapture(s, &graph);
-      if (rc != SLIDE_OK || e != hipSuccess || graph == nullptr) {
-        (void)hipGetLastError();
-        use_graph = false;
-      } else {
-        const hipError_t ei = hipGraphInstantiate(&pg.exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (ei != hipSuccess) { pg.exec = nullptr; (void)hipGetLastError(); use_graph = false; }
-        else { pg.G = G; pg.buf = d_buf; }
-      }
-    }
-    if (use_graph) SL_HIP(hipGraphLaunch(pg.exec, s));
-    else {
-      const int rc = enqueue_phase(phase, d_buf);
+    {
+      const int rc = launch_phase(phase, d_buf);
       if (rc != SLIDE_OK) return rc;
     }
     if (phase == 2) {
@@ -879,11 +892,13 @@ int HostGraph::dist_pass_local(double* d_buf) {
   if (rc != SLIDE_OK) return rc;
   G.relin_thr = 0.0;
   SL_HIP(hipMemsetAsync(d_status.d, 0, 8 * sizeof(int), s));
-  if ((rc = enqueue_phase(0, d_buf)) != SLIDE_OK) return rc;
+  if ((rc = launch_phase(0, d_buf)) != SLIDE_OK) return rc;
   if ((rc = batch->all_reduce(batch_slot, d_buf, 54 * G.n_slots, s)) != SLIDE_OK) return rc;
-  if ((rc = enqueue_phase(1, d_buf)) != SLIDE_OK) return rc;
+  if ((rc = launch_phase(3, d_buf)) != SLIDE_OK) return rc;
+  if ((rc = factor_and_solve(s)) != SLIDE_OK) return rc;
+  if ((rc = launch_phase(4, d_buf)) != SLIDE_OK) return rc;
   if ((rc = batch->all_reduce(batch_slot, d_buf, 9 * G.n_slots, s)) != SLIDE_OK) return rc;
-  if ((rc = enqueue_phase(2, d_buf)) != SLIDE_OK) return rc;
+  if ((rc = launch_phase(2, d_buf)) != SLIDE_OK) return rc;
   int st[8];
   SL_HIP(hipMemcpyAsync(st, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
   SL_HIP(hipStreamSynchronize(s));

@@ -245,8 +245,9 @@ class HostGraph {
   GraphDev G_cap{};
   GraphDev G_prev{};
   struct PhaseGraph { hipGraphExec_t exec = nullptr; GraphDev G{}; double* buf = nullptr; };
-  PhaseGraph phase_graph[3];             // captured launch sequences of dist_phase 0 / 1 / 2
+  PhaseGraph phase_graph[5];             // captured launch sequences of dist_phase 0 / 1 / 2 and of phase 1's halves (3, 4)
   int enqueue_phase(int phase, double* d_buf);
+  int launch_phase(int phase, double* d_buf);      // hipGraph replay of enqueue_phase when nothing changed
   bool have_prev = false;
 };
 

@@ -870,26 +870,26 @@ __global__ __launch_bounds__(256) void k_backsub(GraphDev G) {
 // ---- cross-robot exchange of shared landmarks (one robot per GPU) --------------------------
 // what 0: normal-equation partial sums (54 per slot: packed lower H_ll, g_l), what 1: t_l (9), what 2: the
 // landmark VALUE from its owner rank (15; other ranks contribute zeros so that an all-reduce(sum) broadcasts it).
-__global__ void k_shared_pack(GraphDev G, int what, double* __restrict__ buf) {
-  const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_shared_pack(GraphDev G, int what, double* __restrict__ buf) {       // one thread per (slot, element)
+  const int w = what == 0 ? 54 : (what == 1 ? 9 : 15);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int sidx = t / w, k = t - sidx * w;
   if (sidx >= G.n_slots) return;
   const int l = G.sh_lid[sidx];
-  const int w = what == 0 ? 54 : (what == 1 ? 9 : 15);
-  double* o = buf + (size_t)w * sidx;
   const bool live = l >= 0 && (what != 2 || G.sh_owner[sidx]);
   const double* src = what == 0 ? G.lm_Hacc + 54 * (size_t)(l < 0 ? 0 : l) : (what == 1 ? G.lm_t + 9 * (size_t)(l < 0 ? 0 : l) : G.lm_val + 15 * (size_t)(l < 0 ? 0 : l));
-  for (int k = 0; k < w; ++k) o[k] = live ? src[k] : 0.0;
+  buf[t] = live ? src[k] : 0.0;
 }
 __global__ void k_shared_unpack(GraphDev G, int what, const double* __restrict__ buf) {
-  const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = what == 0 ? 54 : (what == 1 ? 9 : 15);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int sidx = t / w, k = t - sidx * w;
   if (sidx >= G.n_slots) return;
   const int l = G.sh_lid[sidx];
   if (l < 0) return;
-  const int w = what == 0 ? 54 : (what == 1 ? 9 : 15);
-  const double* in = buf + (size_t)w * sidx;
   double* dst = what == 0 ? G.lm_Hacc + 54 * (size_t)l : (what == 1 ? G.lm_t + 9 * (size_t)l : G.lm_val + 15 * (size_t)l);
   const int nv = what == 2 ? (G.lm_type[l] == VT_POINT ? 3 : (G.lm_type[l] == VT_CUBE ? 15 : 7)) : w;
-  for (int k = 0; k < nv; ++k) dst[k] = in[k];
+  if (k < nv) dst[k] = buf[t];
 }
 
 // calculateEstimate(): theta (+) delta
@@ -956,10 +956,10 @@ void launch_backsub(const GraphDev& G, int mode, hipStream_t s) {
   else hipLaunchKernelGGL(k_backsub<2>, dim3(nb), dim3(256), 0, s, G);
 }
 void launch_shared_pack(const GraphDev& G, int what, double* buf, hipStream_t s) {
-  if (G.n_slots > 0) hipLaunchKernelGGL(k_shared_pack, dim3(blocks_for(G.n_slots, 128)), dim3(128), 0, s, G, what, buf);
+  if (G.n_slots > 0) hipLaunchKernelGGL(k_shared_pack, dim3(blocks_for(54LL * G.n_slots, 128)), dim3(128), 0, s, G, what, buf);
 }
 void launch_shared_unpack(const GraphDev& G, int what, const double* buf, hipStream_t s) {
-  if (G.n_slots > 0) hipLaunchKernelGGL(k_shared_unpack, dim3(blocks_for(G.n_slots, 128)), dim3(128), 0, s, G, what, buf);
+  if (G.n_slots > 0) hipLaunchKernelGGL(k_shared_unpack, dim3(blocks_for(54LL * G.n_slots, 128)), dim3(128), 0, s, G, what, buf);
 }
 void launch_ghost_exchange(const GraphDev& G, int what, double* buf, hipStream_t s) {
   if (G.n_gslots > 0) hipLaunchKernelGGL(k_ghost_exchange, dim3(blocks_for(12LL * G.n_gslots, 128)), dim3(128), 0, s, G, what, buf);
