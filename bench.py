@@ -107,6 +107,8 @@ def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
     use_batch = os.environ.get("SLIDE_BENCH_BATCH", "1" if R > 4 else "0") == "1"
     batch = s.CholBatch(R) if use_batch else None
     timing = [None]
+    bufs = [None] * R
+    one_driver = batch is not None and world == 1 and os.environ.get("SLIDE_BENCH_ONE_DRIVER", "1") == "1"
     shards, infos, reps, errs = [None] * R, [None] * R, [None] * R, []
 
     def work(t):
@@ -128,6 +130,13 @@ def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
             if batch is not None:      # the dense factor + solve of all local robots as one launch sequence per pass
                 gb.graph.join_chol_batch(batch, t)
                 dg.local_batch = world == 1     # all robots of the job on this GPU: exchanges as device-side sums, one sync per pass
+                bufs[t] = dg.buf
+            if one_driver:
+                # the whole pass of all robots is one captured graph replayed by the main thread (slide_chol_batch_pass)
+                sync.wait()          # ready
+                sync.wait()          # main thread is through
+                gb.graph.join_chol_batch(None)
+                return
             for _ in range(args.warmup):
                 dg.gauss_newton(1)
             if t == 0 and os.environ.get("SLIDE_BENCH_TIMING") == "1":      # diagnostic: wall time per call of the pass, thread 0
@@ -163,13 +172,26 @@ def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
         torch.cuda.synchronize()
 
     try:
-        sync.wait()
-        barrier()
-        t0 = time.perf_counter()
-        sync.wait()
-        sync.wait()
-        barrier()
-        dt = time.perf_counter() - t0
+        if one_driver:
+            sync.wait()          # every robot built, associated and joined
+            ptrs = [b.data_ptr() for b in bufs]
+            for _ in range(args.warmup):
+                batch.pass_all(ptrs)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                batch.pass_all(ptrs)
+            barrier()
+            dt = time.perf_counter() - t0
+            sync.wait()
+        else:
+            sync.wait()
+            barrier()
+            t0 = time.perf_counter()
+            sync.wait()
+            sync.wait()
+            barrier()
+            dt = time.perf_counter() - t0
     except threading.BrokenBarrierError:
         dt = float("nan")
     for x in th:

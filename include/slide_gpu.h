@@ -140,6 +140,10 @@ int slide_graph_join_chol_batch(slide_graph_t* g, slide_chol_batch_t* b, int slo
  * device-side sums between the joined graphs' buffers (d_buf: this graph's exchange buffer, 54 doubles per shared slot), no host
  * synchronisation inside the pass.  Called from every joined graph's thread in lockstep. */
 int slide_graph_dist_pass_local(slide_graph_t* g, double* d_buf);
+/* The same pass for ALL graphs of the batch from ONE host thread: every robot's phases on its own stream, forked from and joined to
+ * the batch's stream around the exchanges and the batched factor + solve, captured once and replayed as one hipGraph per pass.
+ * d_bufs[i] = exchange buffer (device) of the graph in slot i. */
+int slide_chol_batch_pass(slide_chol_batch_t* b, double* const* d_bufs);
 /* Sharded mode, inter-robot relative-pose factors (addRelativeMeasFactor graph.cpp:247-258 between poses of two ranks).
  * Ghost slots enumerate, identically on every rank, the poses such factors touch; slot i is this rank's pose
  * (own_robot[i], own_idx[i]) or belongs to another rank (own_robot[i] < 0).  A factor is added on BOTH ranks, each with its

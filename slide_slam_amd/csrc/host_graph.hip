@@ -333,10 +333,13 @@ int HostGraph::merge_pending() {
   return SLIDE_OK;
 }
 
-CholBatch::CholBatch(int n_) : n(n_ < 1 ? 1 : (n_ > 8 ? 8 : n_)), sys(n), bufs(n, nullptr), ev_in(n, nullptr) {}
+constexpr int CHOL_BATCH_HOST_MAX = 8;
+CholBatch::CholBatch(int n_) : n(n_ < 1 ? 1 : (n_ > 8 ? 8 : n_)), sys(n), ev_in(n, nullptr), bufs(n, nullptr), graphs(n, nullptr) {}
 CholBatch::~CholBatch() {
   for (hipEvent_t e : ev_in) if (e) (void)hipEventDestroy(e);
   if (ev_out) (void)hipEventDestroy(ev_out);
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
+  if (pass_exec) (void)hipGraphExecDestroy(pass_exec);
   if (master) (void)hipStreamDestroy(master);
   if (d_ctr) (void)hipFree(d_ctr);
 }
@@ -399,6 +402,101 @@ int CholBatch::rendezvous(int slot, hipStream_t s, bool reduce, int count) {
   }
   if (gen_status != SLIDE_OK) return gen_status;
   SL_HIP(hipStreamWaitEvent(s, ev_out, 0));
+  return SLIDE_OK;
+}
+
+// ---- the whole pass of all joined graphs as one captured graph ------------------------------------------------------------------
+int CholBatch::capture_pass(double* const* d_bufs) {
+  if (pass_exec) { (void)hipGraphExecDestroy(pass_exec); pass_exec = nullptr; }
+  for (int i = 0; i < n; ++i)
+    if (!ev_in[i]) SL_HIP(hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming));
+  if (!ev_fork) SL_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+  int Tmax = 0;
+  for (int i = 0; i < n; ++i) {
+    const GraphDev& G = graphs[i]->G;
+    sys[i] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status};
+    Tmax = G.T > Tmax ? G.T : Tmax;
+  }
+  if (Tmax + 2 > ctr_cap) {
+    if (d_ctr) { SL_HIP(hipStreamSynchronize(master)); SL_HIP(hipFree(d_ctr)); d_ctr = nullptr; }
+    ctr_cap = 2 * (Tmax + 2);
+    SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_ctr), ctr_cap * sizeof(int)));
+    SL_HIP(hipMemsetAsync(d_ctr, 0, ctr_cap * sizeof(int), master));
+    SL_HIP(hipStreamSynchronize(master));
+  }
+  hipGraph_t graph = nullptr;
+  SL_HIP(hipStreamBeginCapture(master, hipStreamCaptureModeThreadLocal));
+  int rc = SLIDE_OK;
+  // every robot's stream joins the capture behind the batch's stream, runs `phase`, and is joined back
+  auto each = [&](int phase) {
+    if (hipEventRecord(ev_fork, master) != hipSuccess) { rc = SLIDE_ERR_HIP; return; }
+    for (int i = 0; i < n && rc == SLIDE_OK; ++i) {
+      HostGraph* g = graphs[i];
+      if (hipStreamWaitEvent(g->stream, ev_fork, 0) != hipSuccess) { rc = SLIDE_ERR_HIP; break; }
+      rc = g->enqueue_phase(phase, d_bufs[i]);
+      if (rc == SLIDE_OK && (hipEventRecord(ev_in[i], g->stream) != hipSuccess || hipStreamWaitEvent(master, ev_in[i], 0) != hipSuccess))
+        rc = SLIDE_ERR_HIP;
+    }
+  };
+  const int n_slots = graphs[0]->G.n_slots;
+  each(0);
+  if (rc == SLIDE_OK) launch_sum_bcast(d_bufs, n, 54 * n_slots, master);
+  if (rc == SLIDE_OK) each(3);
+  if (rc == SLIDE_OK) launch_chol_batch(sys.data(), n, d_ctr, master);
+  if (rc == SLIDE_OK) each(4);
+  if (rc == SLIDE_OK) launch_sum_bcast(d_bufs, n, 9 * n_slots, master);
+  if (rc == SLIDE_OK) each(2);
+  const hipError_t e = hipStreamEndCapture(master, &graph);
+  if (rc != SLIDE_OK || e != hipSuccess || graph == nullptr) {
+    (void)hipGetLastError();
+    if (graph) (void)hipGraphDestroy(graph);
+    g_last_error = "batched pass: stream capture failed";
+    return rc != SLIDE_OK ? rc : SLIDE_ERR_HIP;
+  }
+  const hipError_t ei = hipGraphInstantiate(&pass_exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess) { pass_exec = nullptr; (void)hipGetLastError(); g_last_error = "batched pass: graph instantiation failed"; return SLIDE_ERR_HIP; }
+  pass_G.resize(n);
+  pass_bufs.assign(d_bufs, d_bufs + n);
+  for (int i = 0; i < n; ++i) pass_G[i] = graphs[i]->G;
+  return SLIDE_OK;
+}
+
+int CholBatch::pass_all(double* const* d_bufs) {
+  std::lock_guard<std::mutex> lk(mtx);
+  for (int i = 0; i < n; ++i)
+    if (!graphs[i] || !d_bufs[i]) { g_last_error = "batched pass: a slot of the batch is empty"; return SLIDE_ERR_INVALID; }
+  if (!master) {
+    SL_HIP(hipStreamCreateWithFlags(&master, hipStreamNonBlocking));
+    SL_HIP(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+  }
+  bool same = pass_exec != nullptr && (int)pass_G.size() == n;
+  for (int i = 0; i < n; ++i) {
+    HostGraph* g = graphs[i];
+    std::lock_guard<std::mutex> gl(g->mtx);
+    int rc = g->merge_pending();
+    if (rc == SLIDE_OK) rc = g->upload_new();
+    if (rc != SLIDE_OK) return rc;
+    g->G.relin_thr = 0.0;
+    if (g->G.n_slots != graphs[0]->G.n_slots) { g_last_error = "batched pass: the graphs disagree on the shared slots"; return SLIDE_ERR_INVALID; }
+    SL_HIP(hipStreamSynchronize(g->stream));                       // (uploads of a changed graph; idle otherwise)
+    SL_HIP(hipMemsetAsync(g->G.status, 0, 8 * sizeof(int), master));
+    same = same && std::memcmp(&pass_G[i], &g->G, sizeof(GraphDev)) == 0 && pass_bufs[i] == d_bufs[i];
+  }
+  if (!same) {
+    const int rc = capture_pass(d_bufs);
+    if (rc != SLIDE_OK) return rc;
+  }
+  SL_HIP(hipGraphLaunch(pass_exec, master));
+  int st[CHOL_BATCH_HOST_MAX][8];
+  for (int i = 0; i < n; ++i) SL_HIP(hipMemcpyAsync(st[i], graphs[i]->G.status, 8 * sizeof(int), hipMemcpyDeviceToHost, master));
+  SL_HIP(hipStreamSynchronize(master));
+  SL_HIP(hipGetLastError());
+  for (int i = 0; i < n; ++i)
+    if (st[i][0] || st[i][1]) {
+      g_last_error = st[i][0] ? "landmark block not positive definite" : "reduced pose system not positive definite";
+      return SLIDE_ERR_NOT_SPD;
+    }
   return SLIDE_OK;
 }
 

@@ -121,6 +121,7 @@ struct PendFac {
 // arrives with its system assembled on its own stream, the last one enqueues the batched launches on the batch's stream behind
 // all of them, and every graph's stream continues behind the batch.  All joined graphs must solve in lockstep (the distributed
 // pass does); a rendezvous that is not completed within 60 s returns SLIDE_ERR_RUNTIME.
+class HostGraph;
 class CholBatch {
  public:
   explicit CholBatch(int n);
@@ -128,6 +129,11 @@ class CholBatch {
   int n_slots() const { return n; }
   int factor_solve(int slot, const GraphDev& G, hipStream_t s);
   int all_reduce(int slot, double* d_buf, int count, hipStream_t s);     // sum over the joined graphs' buffers, stream-ordered
+  void set_graph(int slot, HostGraph* g) { if (slot >= 0 && slot < n) graphs[slot] = g; }
+  // One distributed pass of ALL joined graphs from one host thread: the phases of every robot on its own stream, forked from and
+  // joined to the batch's stream around the two device-side exchanges and the batched factor + solve, captured once and replayed
+  // as ONE hipGraph per pass.  bufs[i]: exchange buffer of the graph in slot i.
+  int pass_all(double* const* d_bufs);
 
  private:
   int n;
@@ -138,6 +144,12 @@ class CholBatch {
   int gen_status = SLIDE_OK;
   std::vector<CholSystem> sys;
   std::vector<double*> bufs;
+  std::vector<HostGraph*> graphs;
+  hipGraphExec_t pass_exec = nullptr;
+  std::vector<GraphDev> pass_G;
+  std::vector<double*> pass_bufs;
+  hipEvent_t ev_fork = nullptr;
+  int capture_pass(double* const* d_bufs);
   int rendezvous(int slot, hipStream_t s, bool reduce, int count);
   std::vector<hipEvent_t> ev_in;
   hipEvent_t ev_out = nullptr;
@@ -147,6 +159,7 @@ class CholBatch {
 };
 
 class HostGraph {
+  friend class CholBatch;
  public:
   explicit HostGraph(const slide_params_t& p);
   ~HostGraph();
@@ -161,7 +174,11 @@ class HostGraph {
   int add_relative_meas_ghost(const double* rel7, uint64_t idx, int robot, int slot, bool local_first);
   int set_ghosts(const int32_t* own_robot, const int64_t* own_idx, int n_slots);
   int pose_covariance(int robot, uint64_t idx, double* cov36);
-  void join_batch(CholBatch* b, int slot) { batch = b; batch_slot = slot; }
+  void join_batch(CholBatch* b, int slot) {
+    if (batch && batch != b) batch->set_graph(batch_slot, nullptr);
+    batch = b; batch_slot = slot;
+    if (b) b->set_graph(slot, this);
+  }
   int dist_pass_local(double* d_buf);     // one distributed pass when every robot of the job is in this graph's batch (no host syncs inside)
   int add_point_landmark(uint64_t idx, const double* xyz);
   int add_range_bearing(int robot, uint64_t pose_idx, uint64_t lm_idx, const double* bearing, double range);

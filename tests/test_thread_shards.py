@@ -23,7 +23,7 @@ def _run_threads(make_shard, matcher, preset, iters, device=None, batch=None, lo
     world_map = make_world(cfg)
     R = cfg.robots
     group = ThreadGroup(R)
-    out, err = [None] * R, []
+    out, err, bufs = [None] * R, [], [None] * R
 
     def work(t):
         try:
@@ -34,8 +34,16 @@ def _run_threads(make_shard, matcher, preset, iters, device=None, batch=None, lo
             info = dg.setup(matcher)
             if batch is not None:
                 shard.graph.join_chol_batch(batch, t)
-                dg.local_batch = local_pass
-            dg.gauss_newton(iters)
+                dg.local_batch = local_pass == "local"
+                bufs[t] = dg.buf
+            if local_pass == "one-driver":
+                group.barrier.wait()
+                if t == 0:                       # one thread replays the captured pass of all robots
+                    for _ in range(iters):
+                        batch.pass_all([b.data_ptr() for b in bufs])
+                group.barrier.wait()
+            else:
+                dg.gauss_newton(iters)
             if batch is not None:
                 shard.graph.join_chol_batch(None)
             P = len(log["rel7"])
@@ -61,7 +69,7 @@ def test_thread_shards_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["streams", "batch", "batch-local"])
+@pytest.mark.parametrize("mode", ["streams", "batch", "batch-local", "batch-pass"])
 def test_thread_shards_gpu(gpu, tmp_path, mode):
     """HIP shards of two robots on the one GPU: on concurrent streams, or with their dense factor + solve batched into one launch
     sequence (slide_chol_batch_*).  Runs in a fresh process: torch has to initialise the
@@ -82,5 +90,6 @@ if __name__ == "__main__":
     s.device_check()
     mode = sys.argv[2] if len(sys.argv) > 2 else "streams"
     z = _run_threads(lambda: s.SlideBackend(s.default_params(), 1), gpu_matcher, "C3tiny", 60, device=torch.device("cuda", 0),
-                     batch=s.CholBatch(2) if mode != "streams" else None, local_pass=(mode == "batch-local"))
+                     batch=s.CholBatch(2) if mode != "streams" else None,
+                     local_pass={"batch-local": "local", "batch-pass": "one-driver"}.get(mode, False))
     np.savez(sys.argv[1], **z)
