@@ -204,6 +204,8 @@ def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    infos[0]["mode"] = ("one replayed hipGraph per pass, factorisations batched" if one_driver else
+                        ("factorisations batched, one host thread per robot" if batch is not None else "concurrent HIP streams, one host thread per robot"))
     return dt, shards[0], reps[0], infos[0]
 
 
@@ -352,7 +354,7 @@ def report(args, s, cfg, rank, world, R, backend, dt, gb, rep, dg_info, dist, da
             "dtype": "f64",
             "data": "synthetic (seeded, slide_slam_amd/synth.py)",
             "config": {"workload": f"{cfg.name} (BASELINE configs[3]): {robots} robot sub-graphs, {R} per GPU"
-                                   + (" on concurrent HIP streams" if R > 1 else "")
+                                   + (f" ({dg_info['mode']})" if R > 1 and dg_info and "mode" in dg_info else "")
                                    + f" ({st['n_pose']} poses, {st['n_lm']} landmarks, {st['n_factors']} factors in robot 0's); "
                                      "a step = one Gauss-Newton pass of all of them, value = robot pose-graph updates/s",
                        "robots": robots, "robots_per_gpu": R, "reduced_system_dim": n, "chol_tile": 64,
