@@ -59,6 +59,7 @@ struct GraphDev {
   int* pose_lms;                    // landmark id of every pose_fids entry (same indexing)
   long long* pose_ed;               // (lf_eoff << 4) | landmark dimension of every pose_fids entry (same indexing)
   int* pose_bt_ptr; int* pose_bt;   // pose -> (between index << 1 | role), role 1 = second key
+  unsigned* pose_adj; int adj_words; // per pose j a bitmap (adj_words words) of the poses >= j sharing a landmark / relative-pose factor with it
   // ---- landmark blocks -------------------------------------------------------------------
   double* lm_Hinv;   // 81 L  (d x d used)
   double* lm_g;      // 9 L

@@ -340,6 +340,7 @@ CholBatch::~CholBatch() {
   if (ev_out) (void)hipEventDestroy(ev_out);
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (pass_exec) (void)hipGraphExecDestroy(pass_exec);
+  if (d_Gs) (void)hipFree(d_Gs);
   if (master) (void)hipStreamDestroy(master);
   if (d_ctr) (void)hipFree(d_ctr);
 }
@@ -424,6 +425,11 @@ int CholBatch::capture_pass(double* const* d_bufs) {
     SL_HIP(hipMemsetAsync(d_ctr, 0, ctr_cap * sizeof(int), master));
     SL_HIP(hipStreamSynchronize(master));
   }
+  std::vector<GraphDev> hG(n);
+  for (int i = 0; i < n; ++i) hG[i] = graphs[i]->G;
+  if (!d_Gs) SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_Gs), CHOL_BATCH_HOST_MAX * sizeof(GraphDev)));
+  SL_HIP(hipMemcpy(d_Gs, hG.data(), n * sizeof(GraphDev), hipMemcpyHostToDevice));
+  static const bool batch_p3 = !(getenv("SLIDE_BATCH_PHASE3") && getenv("SLIDE_BATCH_PHASE3")[0] == '0');     // diagnostic
   hipGraph_t graph = nullptr;
   SL_HIP(hipStreamBeginCapture(master, hipStreamCaptureModeThreadLocal));
   int rc = SLIDE_OK;
@@ -441,7 +447,10 @@ int CholBatch::capture_pass(double* const* d_bufs) {
   const int n_slots = graphs[0]->G.n_slots;
   each(0);
   if (rc == SLIDE_OK) launch_sum_bcast(d_bufs, n, 54 * n_slots, master);
-  if (rc == SLIDE_OK) each(3);
+  if (rc == SLIDE_OK) {
+    if (batch_p3) launch_phase3_batched(d_Gs, hG.data(), n, d_bufs, master);      // five launches for all robots (blockIdx.z = robot)
+    else each(3);
+  }
   if (rc == SLIDE_OK) launch_chol_batch(sys.data(), n, d_ctr, master);
   if (rc == SLIDE_OK) each(4);
   if (rc == SLIDE_OK) launch_sum_bcast(d_bufs, n, 9 * n_slots, master);
@@ -743,12 +752,16 @@ int HostGraph::upload_new() {
   G.jbuf = d_jbuf.d; G.ebuf = d_ebuf.d;
   G.lm_ptr = d_lm_ptr.d; G.lm_fids = d_lm_fids.d; G.pose_ptr = d_pose_ptr.d; G.pose_fids = d_pose_fids.d; G.pose_lms = d_pose_lms.d; G.pose_ed = d_pose_ed.d;
   G.pose_bt_ptr = d_pose_bt_ptr.d; G.pose_bt = d_pose_bt.d;
+  G.adj_words = (int)((Pn + 31) / 32 + 1);
+  if (d_pose_adj.ensure(std::max<size_t>(Pn * (size_t)G.adj_words, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  G.pose_adj = d_pose_adj.d;
   G.lm_Hacc = d_lm_Hacc.d; G.lm_t = d_lm_t.d; G.n_slots = (int)h_sh_lid.size(); G.sh_lid = d_sh_lid.d; G.sh_owner = d_sh_owner.d;
   G.lm_Hinv = d_lm_Hinv.d; G.lm_g = d_lm_g.d; G.pose_H = d_pose_H.d; G.pose_g = d_pose_g.d;
   G.S = d_S.d; G.ld = (Tcap + 1) * NB; G.T = T; G.Ld = d_Ld.d; G.Winv = d_Winv.d; G.yv = d_yv.d; G.dp = d_dp.d; G.chol_ctr = d_cctr.d;
   G.status = d_status.d;
   G.chart = P.pose_chart;
   G.bearing_sigma = P.bearing_range_sigma; G.cyl_sigma = P.cylinder_sigma; G.numdiff_delta = P.numdiff_delta;
+  launch_pose_adj(G, s);             // the topology changed: rebuild the pose adjacency of the Schur assembly
   return SLIDE_OK;
 }
 

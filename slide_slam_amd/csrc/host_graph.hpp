@@ -149,6 +149,7 @@ class CholBatch {
   std::vector<GraphDev> pass_G;
   std::vector<double*> pass_bufs;
   hipEvent_t ev_fork = nullptr;
+  GraphDev* d_Gs = nullptr;              // the joined graphs' device views, for the kernels batched over blockIdx.z
   int capture_pass(double* const* d_bufs);
   int rendezvous(int slot, hipStream_t s, bool reduce, int count);
   std::vector<hipEvent_t> ev_in;
@@ -241,6 +242,7 @@ class HostGraph {
   DevArr<int> d_lf_type, d_lf_pose, d_lf_lm, d_lf_slot;
   DevArr<int64_t> d_lf_joff, d_lf_eoff;
   DevArr<long long> d_pose_ed;
+  DevArr<unsigned> d_pose_adj;
   DevArr<double> d_br_z, d_cu_z, d_cu_sigma, d_cy_z, d_jbuf, d_ebuf;
   DevArr<int> d_lm_ptr, d_lm_fids, d_pose_ptr, d_pose_fids, d_pose_lms, d_pose_bt_ptr, d_pose_bt;
   DevArr<double> d_lm_Hinv, d_lm_g, d_pose_H, d_pose_g, d_lm_Hacc, d_lm_t;

@@ -18,9 +18,11 @@ void launch_backsub(const GraphDev& G, int mode, hipStream_t s);       // mode: 
 void launch_shared_pack(const GraphDev& G, int what, double* buf, hipStream_t s);
 void launch_shared_unpack(const GraphDev& G, int what, const double* buf, hipStream_t s);
 void launch_estimate(const GraphDev& G, hipStream_t s);
+void launch_pose_adj(const GraphDev& G, hipStream_t s);        // pose adjacency bitmap of the Schur assembly (topology only)
 void launch_scatter(const void* stage, unsigned desc_off, int nseg, hipStream_t s);
 void launch_gather(void* stage, unsigned desc_off, int nseg, hipStream_t s);
-void launch_sum_bcast(double* const* bufs, int n, int count, hipStream_t s);               // local all-reduce(sum) of up to 8 buffers             // device arrays -> one staging buffer (DownloadBatch)   // staged upload -> destinations (UploadBatch)
+void launch_sum_bcast(double* const* bufs, int n, int count, hipStream_t s);
+void launch_phase3_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s);   // blockIdx.z = robot               // local all-reduce(sum) of up to 8 buffers             // device arrays -> one staging buffer (DownloadBatch)   // staged upload -> destinations (UploadBatch)
 void launch_ghost_exchange(const GraphDev& G, int what, double* buf, hipStream_t s);   // what: 0 pack owned poses, 1 adopt
 
 // chol_kernels.hip — blocked right-looking FP64 Cholesky of the (T*NB)^2 lower matrix S (column-major,

@@ -433,7 +433,7 @@ __device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_landmark(GraphDev G) {
+__device__ __forceinline__ void k_landmark_body(const GraphDev& G) {
   const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (l >= G.L) return;
   const int lane = threadIdx.x & 63;
@@ -441,6 +441,13 @@ __global__ __launch_bounds__(256) void k_landmark(GraphDev G) {
   if (type == VT_POINT) landmark_wave<3, MODE>(G, l, lane);
   else if (type == VT_CUBE) landmark_wave<9, MODE>(G, l, lane);
   else landmark_wave<7, MODE>(G, l, lane);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_landmark(GraphDev G) { k_landmark_body<MODE>(G); }
+template <int MODE>
+__global__ __launch_bounds__(256) void k_landmark_b(const GraphDev* __restrict__ Gs) {
+  const GraphDev G = Gs[blockIdx.z];
+  k_landmark_body<MODE>(G);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(256) void k_landmark(GraphDev G) {
 // forms the 21 + 6 numbers of its factor's J^T J and J^T r - u in registers, the 64 partial sums meet in an LDS transpose
 // and lane e < 42 adds column e and writes entry e of (H_pp | g_p) — so the dependent index -> record -> Jacobian loads of
 // all factors of a pose are in flight at once instead of one after the other.
-__global__ __launch_bounds__(256) void k_pose(GraphDev G) {
+__device__ __forceinline__ void k_pose_body(const GraphDev& G) {
   __shared__ double part[4][27][65];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int p = blockIdx.x * 4 + wave;
@@ -562,6 +569,11 @@ __global__ __launch_bounds__(256) void k_pose(GraphDev G) {
     else G.pose_g[6 * (size_t)p + lane - 36] = sum;
   }
 }
+__global__ __launch_bounds__(256) void k_pose(GraphDev G) { k_pose_body(G); }
+__global__ __launch_bounds__(256) void k_pose_b(const GraphDev* __restrict__ Gs) {
+  const GraphDev G = Gs[blockIdx.z];
+  k_pose_body(G);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Schur assemble: one WORKGROUP per (pose column j, chunk of 32 row poses i >= j), EIGHT lanes per lower block:
@@ -583,42 +595,59 @@ __device__ __forceinline__ double dpp_f64(double v) {
 
 constexpr int SCHUR_PJ_CAP = 256;   // entries of the column pose's factor list kept in LDS (longer lists fall back to global reads)
 
-__global__ __launch_bounds__(256) void k_schur(GraphDev G) {
-  __shared__ double schur_tile[6][192];
-  __shared__ long long pj_ed[SCHUR_PJ_CAP];
-  __shared__ int pj_lm[SCHUR_PJ_CAP];
-  const int pj = blockIdx.x;
-  const int tid = threadIdx.x;
-  // dynamic LDS: landmark -> first entry of pose j's list (shorts), then the bitmap of the poses >= j that share a landmark or a
-  // relative-pose factor with pose j — only those blocks of the strip are non-zero, all others are written as zeros unseen
-  unsigned* adj = reinterpret_cast<unsigned*>(schur_slot + (G.L + 7) / 8 * 8);
-  const int adj_words = (G.P + 31) / 32 + 1;
-  for (int t = tid; t < G.L; t += 256) schur_slot[t] = -1;
-  for (int t = tid; t < adj_words; t += 256) adj[t] = 0u;
+// Pose adjacency for the Schur assembly: bit p of row j = pose p >= j observes one of pose j's landmarks, or shares a relative-pose
+// factor with it, or is j itself.  Topology only: rebuilt when the graph changes (HostGraph::upload_new).
+__global__ __launch_bounds__(256) void k_pose_adj(GraphDev G) {
+  extern __shared__ unsigned adj_lds[];
+  const int pj = blockIdx.x, tid = threadIdx.x;
+  for (int t = tid; t < G.adj_words; t += 256) adj_lds[t] = 0u;
   __syncthreads();
   const int b0 = G.pose_ptr[pj], nb = G.pose_ptr[pj + 1] - b0;
-  for (int q = tid; q < nb; q += 256) {
-    const int l = G.pose_lms[b0 + q];
-    if (q == 0 || G.pose_lms[b0 + q - 1] != l) schur_slot[l] = (short)q;
-    if (q < SCHUR_PJ_CAP) { pj_lm[q] = l; pj_ed[q] = G.pose_ed[b0 + q]; }
-  }
-  // every pose that observes one of pose j's landmarks: eight lanes per list entry, strided over that landmark's factors
+  // eight lanes per list entry, strided over that landmark's factors
   for (int q = tid >> 3; q < nb; q += 32) {
     const int l = G.pose_lms[b0 + q];
     if (q > 0 && G.pose_lms[b0 + q - 1] == l) continue;
     const int f1 = G.lm_ptr[l + 1];
     for (int f = G.lm_ptr[l] + (tid & 7); f < f1; f += 8) {
       const int p = G.lf_pose[G.lm_fids[f]];
-      if (p >= pj) atomicOr(&adj[p >> 5], 1u << (p & 31));
+      if (p >= pj) atomicOr(&adj_lds[p >> 5], 1u << (p & 31));
     }
   }
   for (int q = G.pose_bt_ptr[pj] + tid; q < G.pose_bt_ptr[pj + 1]; q += 256) {
     const int ent = G.pose_bt[q];
     const int b = ent >> 1;
     const int other = (ent & 1) ? G.bt_i[b] : G.bt_j[b];
-    if (other >= pj) atomicOr(&adj[other >> 5], 1u << (other & 31));
+    if (other >= pj) atomicOr(&adj_lds[other >> 5], 1u << (other & 31));
   }
-  if (tid == 0) atomicOr(&adj[pj >> 5], 1u << (pj & 31));
+  if (tid == 0) atomicOr(&adj_lds[pj >> 5], 1u << (pj & 31));
+  __syncthreads();
+  for (int t = tid; t < G.adj_words; t += 256) G.pose_adj[(size_t)pj * G.adj_words + t] = adj_lds[t];
+}
+void launch_pose_adj(const GraphDev& G, hipStream_t s) {
+  if (G.P > 0) hipLaunchKernelGGL(k_pose_adj, dim3(G.P), dim3(256), (size_t)G.adj_words * sizeof(unsigned), s, G);
+}
+
+__device__ __forceinline__ void k_schur_body(const GraphDev& G) {
+  __shared__ double schur_tile[6][192];
+  __shared__ long long pj_ed[SCHUR_PJ_CAP];
+  __shared__ int pj_lm[SCHUR_PJ_CAP];
+  const int pj = blockIdx.x;
+  if (pj >= G.P) return;            // (a batched launch covers the largest graph)
+  const int tid = threadIdx.x;
+  // dynamic LDS: landmark -> first entry of pose j's list (shorts), then the bitmap of the poses >= j that share a landmark or a
+  // relative-pose factor with pose j — only those blocks of the strip are non-zero, all others are written as zeros unseen
+  unsigned* adj = reinterpret_cast<unsigned*>(schur_slot + (G.L + 7) / 8 * 8);
+  const int adj_words = (G.P + 31) / 32 + 1;
+  for (int t = tid; t < G.L; t += 256) schur_slot[t] = -1;
+  __syncthreads();
+  // (the bitmap depends on the topology only: k_pose_adj builds it once per change of the graph, not in every pass)
+  for (int t = tid; t < adj_words; t += 256) adj[t] = G.pose_adj[(size_t)pj * G.adj_words + t];
+  const int b0 = G.pose_ptr[pj], nb = G.pose_ptr[pj + 1] - b0;
+  for (int q = tid; q < nb; q += 256) {
+    const int l = G.pose_lms[b0 + q];
+    if (q == 0 || G.pose_lms[b0 + q - 1] != l) schur_slot[l] = (short)q;
+    if (q < SCHUR_PJ_CAP) { pj_lm[q] = l; pj_ed[q] = G.pose_ed[b0 + q]; }
+  }
   __syncthreads();
   const int sub = tid & 7;
   // the chunks of the strip are dealt out to the gridDim.y workgroups of this pose column (each builds the two tables itself)
@@ -743,6 +772,11 @@ __global__ __launch_bounds__(256) void k_schur(GraphDev G) {
   __syncthreads();      // the tile is reused by the next chunk
   }
 }
+__global__ __launch_bounds__(256) void k_schur(GraphDev G) { k_schur_body(G); }
+__global__ __launch_bounds__(256) void k_schur_b(const GraphDev* __restrict__ Gs) {
+  const GraphDev G = Gs[blockIdx.z];
+  k_schur_body(G);
+}
 
 // padding (identity) between 6P and T*NB, and the RHS row (-g) at row T*NB
 // One staged host -> device upload scattered to its destinations: descriptor i = (dst pointer, byte offset in the staging
@@ -788,7 +822,7 @@ void launch_scatter(const void* stage, unsigned desc_off, int nseg, hipStream_t 
   if (nseg > 0) hipLaunchKernelGGL(k_scatter, dim3(nseg, 8), dim3(256), 0, s, static_cast<const unsigned char*>(stage), desc_off);
 }
 
-__global__ void k_pad_rhs(GraphDev G) {
+__device__ __forceinline__ void k_pad_rhs_body(const GraphDev& G) {
   const int n = 6 * G.P, NT = G.T * NB;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < NT) {
@@ -802,6 +836,11 @@ __global__ void k_pad_rhs(GraphDev G) {
   const int r = n + (int)(u / NT), c = (int)(u % NT);
   if (c > r) return;
   G.S[(size_t)c * G.ld + r] = (c == r) ? 1.0 : 0.0;
+}
+__global__ void k_pad_rhs(GraphDev G) { k_pad_rhs_body(G); }
+__global__ void k_pad_rhs_b(const GraphDev* __restrict__ Gs) {
+  const GraphDev G = Gs[blockIdx.z];
+  k_pad_rhs_body(G);
 }
 
 // landmark back-substitution  delta_l = -H_ll^-1 (g_l + sum_f E_f^T delta_p), and delta_p = dp.
@@ -920,6 +959,7 @@ __global__ void k_estimate(GraphDev G) {
 static inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 void init_solver_kernels() {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_b), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);   // 60000 landmarks (the capacity check in HostGraph::upload_new) beside 12 KB of static LDS
 }
 void launch_relin(const GraphDev& G, hipStream_t s) {
@@ -954,6 +994,41 @@ void launch_backsub(const GraphDev& G, int mode, hipStream_t s) {
   if (mode == 0) hipLaunchKernelGGL(k_backsub<0>, dim3(nb), dim3(256), 0, s, G);
   else if (mode == 1) hipLaunchKernelGGL(k_backsub<1>, dim3(nb), dim3(256), 0, s, G);
   else hipLaunchKernelGGL(k_backsub<2>, dim3(nb), dim3(256), 0, s, G);
+}
+struct BufPtrs { double* p[8]; };
+__global__ void k_shared_unpack_b(const GraphDev* __restrict__ Gs, int what, BufPtrs B) {
+  const GraphDev G = Gs[blockIdx.z];
+  const int w = what == 0 ? 54 : (what == 1 ? 9 : 15);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int sidx = t / w, k = t - sidx * w;
+  if (sidx >= G.n_slots) return;
+  const int l = G.sh_lid[sidx];
+  if (l < 0) return;
+  double* dst = what == 0 ? G.lm_Hacc + 54 * (size_t)l : (what == 1 ? G.lm_t + 9 * (size_t)l : G.lm_val + 15 * (size_t)l);
+  const int nv = what == 2 ? (G.lm_type[l] == VT_POINT ? 3 : (G.lm_type[l] == VT_CUBE ? 15 : 7)) : w;
+  if (k < nv) dst[k] = B.p[blockIdx.z][t];
+}
+// Phase 1 up to the factorisation (unpack the exchanged H_ll / g_l, invert, Schur records, pose blocks, reduced system) for ALL the
+// robots of a GPU in five launches: blockIdx.z = robot, every grid sized for the largest graph.  h[i] = host copy of d[i].
+void launch_phase3_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s) {
+  int L = 0, P = 0, slots = 0;
+  long long pad = 0;
+  for (int i = 0; i < n; ++i) {
+    L = std::max(L, h[i].L); P = std::max(P, h[i].P); slots = std::max(slots, h[i].n_slots);
+    const long long NT = (long long)h[i].T * NB;
+    pad = std::max(pad, NT + (NT - 6LL * h[i].P) * NT);
+  }
+  BufPtrs B{};
+  for (int i = 0; i < n; ++i) B.p[i] = bufs[i];
+  if (slots > 0) hipLaunchKernelGGL(k_shared_unpack_b, dim3(blocks_for(54LL * slots, 128), 1, n), dim3(128), 0, s, d, 0, B);
+  if (L > 0) hipLaunchKernelGGL(k_landmark_b<2>, dim3(blocks_for(L, 4), 1, n), dim3(256), 0, s, d);
+  if (P > 0) {
+    hipLaunchKernelGGL(k_pose_b, dim3(blocks_for(P, 4), 1, n), dim3(256), 0, s, d);
+    static const int split = getenv("SLIDE_SCHUR_SPLIT") ? atoi(getenv("SLIDE_SCHUR_SPLIT")) : 2;
+    hipLaunchKernelGGL(k_schur_b, dim3(P, split > 0 ? split : 1, n), dim3(256),
+                       (size_t)((L + 7) / 8 * 8) * sizeof(short) + (size_t)((P + 31) / 32 + 1) * sizeof(unsigned), s, d);
+    hipLaunchKernelGGL(k_pad_rhs_b, dim3(blocks_for(pad, 256), 1, n), dim3(256), 0, s, d);
+  }
 }
 void launch_shared_pack(const GraphDev& G, int what, double* buf, hipStream_t s) {
   if (G.n_slots > 0) hipLaunchKernelGGL(k_shared_pack, dim3(blocks_for(54LL * G.n_slots, 128)), dim3(128), 0, s, G, what, buf);
