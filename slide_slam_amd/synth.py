@@ -60,6 +60,9 @@ class SynthConfig:
         if name == "C3rel":    # C3tiny with an inter-robot relative-pose measurement every 8 frames
             return SynthConfig(name="C3rel", robots=2, poses_per_robot=40, landmarks=110, grid=(1, 2), cell=34.0,
                                overlap=8.0, relmeas_every=8)
+        if name == "C4tiny":   # four robots on a 2 x 2 grid: CPU-test size for several robots per process x several processes
+            return SynthConfig(name="C4tiny", robots=4, poses_per_robot=30, landmarks=200, grid=(2, 2), cell=30.0,
+                               overlap=8.0)
         if name == "C4":       # configs[3]: 8 robots, 10 k landmarks, 5 k poses
             return SynthConfig(name="C4", robots=8, poses_per_robot=625, landmarks=10000, grid=(2, 4), cell=110.0,
                                overlap=15.0)

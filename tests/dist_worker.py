@@ -38,7 +38,55 @@ def gpu_matcher(cls, xyz, lab, gxyz, glab, thresh):
     return s.match_boxes(cls, xyz, lab, gxyz, glab, thresh)
 
 
+def main_threads(R):
+    """R robot shards per process (threads), several processes: ThreadGroup over a gloo TorchComm (oracle shards, CPU)."""
+    import threading
+    backend, preset, iters, out_path = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    assert backend == "oracle"
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from oracle import pyoracle as po
+    from slide_slam_amd.distributed import DistributedGraph, ThreadGroup, TorchComm
+    from slide_slam_amd.replay import replay_single
+    from slide_slam_amd.synth import SynthConfig, make_robot_log, make_world
+    cfg = SynthConfig.preset(preset)
+    assert cfg.robots == world * R
+    world_map = make_world(cfg)
+    group = ThreadGroup(R, base=TorchComm(device=None), rank=rank, world=world)
+    out, err = [None] * R, []
+
+    def work(t):
+        try:
+            v = rank * R + t
+            shard = po.OracleBackend(po.OrcParams.default(), 1)
+            log = make_robot_log(cfg, world_map, v)
+            replay_single(shard, log, robot=0, collect=False)
+            dg = DistributedGraph(shard, group.comm(t, None), v, world * R)
+            info = dg.setup(oracle_matcher)
+            dg.gauss_newton(iters)
+            out[t] = (np.array([shard.graph.get_pose12(0, k)[1] for k in range(len(log["rel7"]))]), info)
+        except BaseException as e:
+            err.append(e)
+            group.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(R)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    if err:
+        raise err[0]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [o[0] for o in out])
+    if rank == 0:
+        np.savez(out_path, poses=np.array([p for part in gathered for p in part]), n_slots=out[0][1]["n_slots"],
+                 n_global=np.array(out[0][1]["n_global"]), n_gslots=0)
+
+
 def main():
+    if len(sys.argv) > 5 and sys.argv[5].startswith("threads="):
+        return main_threads(int(sys.argv[5].split("=")[1]))
     backend, preset, iters, out_path = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     import torch
     import torch.distributed as dist

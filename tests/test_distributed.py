@@ -96,3 +96,14 @@ def test_distributed_relmeas_gpu_shards(tmp_path, gpu):
     z = _run_workers("gpu", "C3rel", 120, str(tmp_path / "gr.npz"), extra=("relmeas",))
     assert int(z["n_gslots"]) > 0
     _check(z, joint, counts, 1e-4)
+
+
+def test_threads_times_processes_oracle_shards_gloo(tmp_path):
+    """CPU: 2 processes x 2 robot shards each (ThreadGroup: local sum in the process, gloo between the processes) — the layout of
+    the 8-robot graph on 2 or 4 GPUs — give what 4 processes with one shard each give (same association, same passes; only the
+    order of the floating-point sums of the exchange differs)."""
+    a = _run_workers("oracle", "C4tiny", 40, str(tmp_path / "t22.npz"), world=2, extra=("threads=2",))
+    b = _run_workers("oracle", "C4tiny", 40, str(tmp_path / "t41.npz"), world=4)
+    assert int(a["n_slots"]) == int(b["n_slots"]) > 0 and list(a["n_global"]) == list(b["n_global"])
+    assert a["poses"].shape == b["poses"].shape == (4, 30, 12)
+    assert np.abs(a["poses"] - b["poses"]).max() < 1e-9
