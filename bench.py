@@ -365,7 +365,9 @@ def report(args, s, cfg, rank, world, R, backend, dt, gb, rep, dg_info, dist, da
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": upd_ms,
-                         "launches_per_iter": upd_launches_per_iter, "dominant_by_time": dominant},
+                         "launches_per_iter": upd_launches_per_iter, "dominant_by_time": dominant,
+                         "scope": "profiled passes of robot 0's sub-graph alone after the timed region (the per-GPU load of the N = 8 run); "
+                                  "with several robots per GPU the timed region runs k_chol_step_batched / concurrent streams"},
             "kernel_ms_per_iter": kernel_ms,
             "stream_replay": {"frames": len(rep["t_frame"]), "updates_per_s": len(rep["t_frame"]) / max(sum(rep["t_frame"]), 1e-9),
                               "ms_last_frame": rep["t_frame"][-1] * 1e3, "build_s": t_build},
