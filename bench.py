@@ -107,6 +107,7 @@ def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
     use_batch = os.environ.get("SLIDE_BENCH_BATCH", "1" if R > 4 else "0") == "1"
     batch = s.CholBatch(R) if use_batch else None
     timing = [None]
+    batched_prof = [None]
     bufs = [None] * R
     one_driver = batch is not None and world == 1 and os.environ.get("SLIDE_BENCH_ONE_DRIVER", "1") == "1"
     shards, infos, reps, errs = [None] * R, [None] * R, [None] * R, []
@@ -183,6 +184,9 @@ def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
                 batch.pass_all(ptrs)
             barrier()
             dt = time.perf_counter() - t0
+            # device time of the batched step kernels (HIP events on the batch's stream, un-captured passes) for the roofline
+            pr = sorted(batch.profile(ptrs) for _ in range(5))
+            batched_prof[0] = dict(ms_steps=pr[len(pr) // 2][0], launches=pr[0][1])
             sync.wait()
         else:
             sync.wait()
@@ -206,6 +210,8 @@ def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
         dt = float(t.item())
     infos[0]["mode"] = ("one replayed hipGraph per pass, factorisations batched" if one_driver else
                         ("factorisations batched, one host thread per robot" if batch is not None else "concurrent HIP streams, one host thread per robot"))
+    if batched_prof[0]:
+        infos[0]["batched"] = dict(batched_prof[0], robots=R)
     return dt, shards[0], reps[0], infos[0]
 
 
@@ -338,6 +344,25 @@ def report(args, s, cfg, rank, world, R, backend, dt, gb, rep, dg_info, dist, da
                 traffic = pmc["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             traffic = None
+        single = dict(kernel="k_chol_step (one robot alone)", achieved=ach, frac=ach / FP64_MFMA_PEAK_TFLOPS, flops_per_launch=flops_per_launch,
+                      avg_launch_ms=upd_ms, traffic=traffic)
+        roof_kernel = "k_chol_step (v_mfma_f64_16x16x4_f64)"
+        bt = dg_info.get("batched") if dg_info else None
+        if bt:
+            # the timed region ran k_chol_step_batched: all robots of the GPU per launch
+            roof_kernel = f"k_chol_step_batched (v_mfma_f64_16x16x4_f64, {bt['robots']} factorisations per launch)"
+            upd_launches_per_iter = bt["launches"]
+            upd_ms = bt["ms_steps"] / max(bt["launches"], 1)
+            flops_per_launch = bt["robots"] * upd_flops / max(bt["launches"], 1)
+            ach = flops_per_launch / (upd_ms * 1e-3) / 1e12
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_batched.json")) as fh:
+                    pmc = json.load(fh)
+                if pmc.get("kernel") == "k_chol_step_batched" and n == 3776 and pmc.get("robots") == bt["robots"]:
+                    traffic = pmc["hbm_bytes_per_launch"]
+            except (OSError, ValueError, KeyError):
+                traffic = None
         kernel_ms = {k: v["ms"] / nprof for k, v in prof.items()}
         dominant = max(kernel_ms, key=kernel_ms.get)
         res = {
@@ -361,13 +386,14 @@ def report(args, s, cfg, rank, world, R, backend, dt, gb, rep, dg_info, dist, da
                        "collective": None if dg_info is None else
                        (("local sum + " if R > 1 else "") + (f"{backend} " if world > 1 else "no inter-GPU ") +
                         f"all-reduce x2 per pass over {dg_info['n_slots']} shared-landmark slots ({dg_info['n_slots'] * 63 * 8} B per pass)")},
-            "roofline": {"bound": "mfma", "kernel": "k_chol_step (v_mfma_f64_16x16x4_f64)", "achieved": ach,
+            "roofline": {"bound": "mfma", "kernel": roof_kernel, "achieved": ach,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
+                         "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r01_pmc_traffic*.json)",
+                         "one_robot_alone": single,
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": upd_ms,
                          "launches_per_iter": upd_launches_per_iter, "dominant_by_time": dominant,
-                         "scope": "profiled passes of robot 0's sub-graph alone after the timed region (the per-GPU load of the N = 8 run); "
-                                  "with several robots per GPU the timed region runs k_chol_step_batched / concurrent streams"},
+                         "scope": ("HIP events on the launch stream around the step launches of un-captured passes after the timed region; "
+                                   "one_robot_alone = robot 0's sub-graph by itself (the per-GPU load of the N = 8 run)")},
             "kernel_ms_per_iter": kernel_ms,
             "stream_replay": {"frames": len(rep["t_frame"]), "updates_per_s": len(rep["t_frame"]) / max(sum(rep["t_frame"]), 1e-9),
                               "ms_last_frame": rep["t_frame"][-1] * 1e3, "build_s": t_build},

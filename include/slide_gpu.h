@@ -144,6 +144,9 @@ int slide_graph_dist_pass_local(slide_graph_t* g, double* d_buf);
  * the batch's stream around the exchanges and the batched factor + solve, captured once and replayed as one hipGraph per pass.
  * d_bufs[i] = exchange buffer (device) of the graph in slot i. */
 int slide_chol_batch_pass(slide_chol_batch_t* b, double* const* d_bufs);
+/* Measurement aid: the same pass issued without the graph, HIP events around the batched step kernels; *ms_steps = their device time
+ * (launch gaps included), *n_launches = their number. */
+int slide_chol_batch_profile(slide_chol_batch_t* b, double* const* d_bufs, double* ms_steps, int* n_launches);
 /* Sharded mode, inter-robot relative-pose factors (addRelativeMeasFactor graph.cpp:247-258 between poses of two ranks).
  * Ghost slots enumerate, identically on every rank, the poses such factors touch; slot i is this rank's pose
  * (own_robot[i], own_idx[i]) or belongs to another rank (own_robot[i] < 0).  A factor is added on BOTH ranks, each with its

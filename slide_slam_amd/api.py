@@ -28,7 +28,7 @@ EXPORTS = [
     "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
     "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
-    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
+    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
     "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
     "slide_dense_spd_solve", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
@@ -277,6 +277,13 @@ class CholBatch:
         """One distributed pass of all joined graphs from this thread; buf_ptrs[i] = device address of slot i's exchange buffer."""
         arr = (C.c_void_p * len(buf_ptrs))(*[int(p) for p in buf_ptrs])
         return _check(self.L.slide_chol_batch_pass(C.c_void_p(self.h), arr))
+
+    def profile(self, buf_ptrs):
+        """(ms of the batched step kernels of one un-captured pass, number of step launches)."""
+        arr = (C.c_void_p * len(buf_ptrs))(*[int(p) for p in buf_ptrs])
+        ms, nl = C.c_double(0), C.c_int(0)
+        _check(self.L.slide_chol_batch_profile(C.c_void_p(self.h), arr, C.byref(ms), C.byref(nl)))
+        return ms.value, nl.value
 
     def close(self):
         if self.h:

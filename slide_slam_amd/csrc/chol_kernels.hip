@@ -946,7 +946,7 @@ void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv,
 }
 // The factorisations + solves of several systems as one launch sequence (max T step launches, the extractions, one chained backward
 // substitution): d[i] describes system i; ctr is the work counter array of the batch (max T + 2 ints, zeroed once).
-void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s) {
+void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps) {
   const int n_cu = chol_n_cu();
   int Tmax = 0;
   for (int i = 0; i < n; ++i) Tmax = d[i].T > Tmax ? d[i].T : Tmax;
@@ -970,6 +970,7 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s) {
     const int a_joins = nB > free_cu ? 1 : 0;
     hipLaunchKernelGGL(k_chol_step_batched, dim3((unsigned)(nAw + extra)), dim3(512), 0, s, A, k, k & ~1, ctr, a_joins);
   }
+  if (after_steps) (void)hipEventRecord(after_steps, s);
   BwdBatchArgs B{};
   B.n = n;
   B.base[0] = 0;

@@ -407,16 +407,18 @@ int CholBatch::rendezvous(int slot, hipStream_t s, bool reduce, int count) {
 }
 
 // ---- the whole pass of all joined graphs as one captured graph ------------------------------------------------------------------
-int CholBatch::capture_pass(double* const* d_bufs) {
-  if (pass_exec) { (void)hipGraphExecDestroy(pass_exec); pass_exec = nullptr; }
+// device-side tables of a pass (systems of the batched factorisation, the graphs' device views, the work counters)
+int CholBatch::prepare_pass() {
   for (int i = 0; i < n; ++i)
     if (!ev_in[i]) SL_HIP(hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming));
   if (!ev_fork) SL_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
   int Tmax = 0;
+  hG.resize(n);
   for (int i = 0; i < n; ++i) {
     const GraphDev& G = graphs[i]->G;
     sys[i] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status};
     Tmax = G.T > Tmax ? G.T : Tmax;
+    hG[i] = G;
   }
   if (Tmax + 2 > ctr_cap) {
     if (d_ctr) { SL_HIP(hipStreamSynchronize(master)); SL_HIP(hipFree(d_ctr)); d_ctr = nullptr; }
@@ -425,15 +427,16 @@ int CholBatch::capture_pass(double* const* d_bufs) {
     SL_HIP(hipMemsetAsync(d_ctr, 0, ctr_cap * sizeof(int), master));
     SL_HIP(hipStreamSynchronize(master));
   }
-  std::vector<GraphDev> hG(n);
-  for (int i = 0; i < n; ++i) hG[i] = graphs[i]->G;
   if (!d_Gs) SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_Gs), CHOL_BATCH_HOST_MAX * sizeof(GraphDev)));
   SL_HIP(hipMemcpy(d_Gs, hG.data(), n * sizeof(GraphDev), hipMemcpyHostToDevice));
+  return SLIDE_OK;
+}
+// the launches of one pass of all joined graphs (captured by capture_pass, or issued directly by profile_pass with events e0 / e1
+// around the batched step kernels)
+int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1) {
   static const bool batch_p3 = !(getenv("SLIDE_BATCH_PHASE3") && getenv("SLIDE_BATCH_PHASE3")[0] == '0');     // diagnostic
-  hipGraph_t graph = nullptr;
-  SL_HIP(hipStreamBeginCapture(master, hipStreamCaptureModeThreadLocal));
   int rc = SLIDE_OK;
-  // every robot's stream joins the capture behind the batch's stream, runs `phase`, and is joined back
+  // every robot's stream continues behind the batch's stream, runs `phase`, and is joined back
   auto each = [&](int phase) {
     if (hipEventRecord(ev_fork, master) != hipSuccess) { rc = SLIDE_ERR_HIP; return; }
     for (int i = 0; i < n && rc == SLIDE_OK; ++i) {
@@ -451,10 +454,20 @@ int CholBatch::capture_pass(double* const* d_bufs) {
     if (batch_p3) launch_phase3_batched(d_Gs, hG.data(), n, d_bufs, master);      // five launches for all robots (blockIdx.z = robot)
     else each(3);
   }
-  if (rc == SLIDE_OK) launch_chol_batch(sys.data(), n, d_ctr, master);
+  if (rc == SLIDE_OK && e0) (void)hipEventRecord(e0, master);
+  if (rc == SLIDE_OK) launch_chol_batch(sys.data(), n, d_ctr, master, e1);
   if (rc == SLIDE_OK) each(4);
   if (rc == SLIDE_OK) launch_sum_bcast(d_bufs, n, 9 * n_slots, master);
   if (rc == SLIDE_OK) each(2);
+  return rc;
+}
+int CholBatch::capture_pass(double* const* d_bufs) {
+  if (pass_exec) { (void)hipGraphExecDestroy(pass_exec); pass_exec = nullptr; }
+  int rc = prepare_pass();
+  if (rc != SLIDE_OK) return rc;
+  hipGraph_t graph = nullptr;
+  SL_HIP(hipStreamBeginCapture(master, hipStreamCaptureModeThreadLocal));
+  rc = enqueue_pass(d_bufs, nullptr, nullptr);
   const hipError_t e = hipStreamEndCapture(master, &graph);
   if (rc != SLIDE_OK || e != hipSuccess || graph == nullptr) {
     (void)hipGetLastError();
@@ -469,6 +482,45 @@ int CholBatch::capture_pass(double* const* d_bufs) {
   pass_bufs.assign(d_bufs, d_bufs + n);
   for (int i = 0; i < n; ++i) pass_G[i] = graphs[i]->G;
   return SLIDE_OK;
+}
+// One pass issued directly (no graph), with HIP events on the batch's stream around the batched step kernels: their total device
+// time and launch count (the bench's roofline of k_chol_step_batched).
+int CholBatch::profile_pass(double* const* d_bufs, double* ms_steps, int* n_launches) {
+  std::lock_guard<std::mutex> lk(mtx);
+  for (int i = 0; i < n; ++i)
+    if (!graphs[i] || !d_bufs[i]) { g_last_error = "batched pass: a slot of the batch is empty"; return SLIDE_ERR_INVALID; }
+  if (!master) {
+    SL_HIP(hipStreamCreateWithFlags(&master, hipStreamNonBlocking));
+    SL_HIP(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+  }
+  for (int i = 0; i < n; ++i) {
+    HostGraph* g = graphs[i];
+    std::lock_guard<std::mutex> gl(g->mtx);
+    int rc = g->merge_pending();
+    if (rc == SLIDE_OK) rc = g->upload_new();
+    if (rc != SLIDE_OK) return rc;
+    g->G.relin_thr = 0.0;
+    SL_HIP(hipStreamSynchronize(g->stream));
+    SL_HIP(hipMemsetAsync(g->G.status, 0, 8 * sizeof(int), master));
+  }
+  int rc = prepare_pass();
+  if (rc != SLIDE_OK) return rc;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  SL_HIP(hipEventCreate(&e0));
+  SL_HIP(hipEventCreate(&e1));
+  rc = enqueue_pass(d_bufs, e0, e1);
+  const hipError_t es = hipStreamSynchronize(master);
+  for (int i = 0; i < n; ++i) (void)hipStreamSynchronize(graphs[i]->stream);
+  float ms = 0.f;
+  if (rc == SLIDE_OK && es == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+    if (ms_steps) *ms_steps = ms;
+    int Tmax = 0;
+    for (const CholSystem& c : sys) Tmax = c.T > Tmax ? c.T : Tmax;
+    if (n_launches) *n_launches = Tmax;
+  } else if (rc == SLIDE_OK) rc = SLIDE_ERR_HIP;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
 }
 
 int CholBatch::pass_all(double* const* d_bufs) {

@@ -134,6 +134,7 @@ class CholBatch {
   // joined to the batch's stream around the two device-side exchanges and the batched factor + solve, captured once and replayed
   // as ONE hipGraph per pass.  bufs[i]: exchange buffer of the graph in slot i.
   int pass_all(double* const* d_bufs);
+  int profile_pass(double* const* d_bufs, double* ms_steps, int* n_launches);
 
  private:
   int n;
@@ -151,6 +152,9 @@ class CholBatch {
   hipEvent_t ev_fork = nullptr;
   GraphDev* d_Gs = nullptr;              // the joined graphs' device views, for the kernels batched over blockIdx.z
   int capture_pass(double* const* d_bufs);
+  int prepare_pass();
+  int enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1);
+  std::vector<GraphDev> hG;
   int rendezvous(int slot, hipStream_t s, bool reduce, int count);
   std::vector<hipEvent_t> ev_in;
   hipEvent_t ev_out = nullptr;

@@ -31,7 +31,7 @@ void launch_ghost_exchange(const GraphDev& G, int what, double* buf, hipStream_t
 void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, hipStream_t s);
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, hipStream_t s);
 struct CholSystem { double* S; int ld, T; double* Ld; double* Winv; double* yv; double* dp; int* status; };
-void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s);            // up to 8 systems, one launch per block column
+void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps = nullptr);            // up to 8 systems, one launch per block column
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp, int* status, hipStream_t s);
 // marginal covariance of the pose whose first tangent row is row0 (Y: 6 * T * NB scratch doubles holding the six unit columns)
 void launch_pose_covariance(const double* S, int ld, int T, const double* Ld, const double* Winv, double* Y, int row0, double* cov36,
