@@ -249,10 +249,15 @@ __global__ __launch_bounds__(512) void k_v2(double* __restrict__ S, int ld, int 
 
 // ---- V3: V0 with the row <-> lane map permuted so that every access is 16 B per lane (rows 2 lr, 2 lr + 1) --------------
 typedef double v2dd __attribute__((ext_vector_type(2)));
+__device__ unsigned long long g_clk[2];
+__device__ unsigned long long g_span[3] = {~0ull, 0ull, 0ull};   // min start, max start, max end (100 MHz ticks)      // summed shader cycles (s_memtime) and 100 MHz wall ticks (s_memrealtime) of wave 0 of every workgroup
 template <int KS, int RD>
 __global__ __launch_bounds__(512) void k_v3(double* __restrict__ S, int ld, int kb, int T, int nP, int g0, int g1) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
   const long long nG = (long long)nP * (nP + 1) / 2;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0) { atomicMin(&g_span[0], w0); atomicMax(&g_span[1], w0); }
+  struct Fin { unsigned long long c0, w0; int tid; __device__ ~Fin() { if (tid == 0) { const unsigned long long w1 = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_clk[0], __builtin_amdgcn_s_memtime() - c0); atomicAdd(&g_clk[1], w1 - w0); atomicMax(&g_span[2], w1); } } } fin{c0, w0, tid};
   for (int g = g0 + blockIdx.x; g < g1; g += gridDim.x) {
     int i, j0;
     decode(g, kb, nP, nG, i, j0);
@@ -524,6 +529,20 @@ int main(int argc, char** argv) {
     }
     run("v2 pipelined RD16", [&] { hipLaunchKernelGGL((k_v2<32, 16>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1); }, nullptr);
     run("v2 pipelined RD4", [&] { hipLaunchKernelGGL((k_v2<32, 4>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1); }, nullptr);
+    {
+      unsigned long long z[2] = {0, 0}, o[2];
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z, sizeof(z)));
+      { unsigned long long init0[3] = {~0ull, 0ull, 0ull}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_span), init0, sizeof(init0))); }
+      hipLaunchKernelGGL((k_v3<32, 6>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpyFromSymbol(o, HIP_SYMBOL(g_clk), sizeof(o)));
+      unsigned long long sp[3], init[3] = {~0ull, 0ull, 0ull};
+      CK(hipMemcpyFromSymbol(sp, HIP_SYMBOL(g_span), sizeof(sp)));
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_span), init, sizeof(init)));
+      printf("   v3 spans: last workgroup starts %.2f us after the first, last end %.2f us after the first start\n", (sp[1] - sp[0]) / 100.0, (sp[2] - sp[0]) / 100.0);
+      printf("   v3 clocks: %.0f shader cycles per workgroup, %.2f us wall (100 MHz ticks) -> %.2f GHz effective\n", (double)o[0] / grid,
+             (double)o[1] / grid / 100.0, (double)o[0] / ((double)o[1] * 10.0));
+    }
     run("v3 16B RD6", [&] { hipLaunchKernelGGL((k_v3<32, 6>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1); }, nullptr);
     {
       std::vector<double> a(n), b(n);
