@@ -464,6 +464,180 @@ __global__ __launch_bounds__(512) void k_v5(double* __restrict__ S, int ld, int 
   }
 }
 
+
+// ---- V6: V3 with 1024-thread workgroups (four waves per SIMD): a whole 2x2 group per workgroup ---------------------------
+template <int KS, int RD>
+__global__ __launch_bounds__(1024) void k_v6(double* __restrict__ S, int ld, int kb, int T, int nP, int g0, int g1) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+  const long long nG = (long long)nP * (nP + 1) / 2;
+  for (int gg = g0 / 2 + blockIdx.x; gg < g1 / 2; gg += gridDim.x) {
+    int i, j0;
+    decode(2 * gg + ((wave >> 3) & 1), kb, nP, nG, i, j0);
+    const int j = j0 + ((wave >> 2) & 1);
+    if (i > T || j > T - 1 || i < j) continue;
+    const int ch = (wave >> 1) & 1, rh = wave & 1;
+    const double* pjh = S + (size_t)((kb - 2) * NB + lk) * ld + (size_t)j * NB + 32 * ch + 2 * lr;
+    const double* pih = S + (size_t)((kb - 2) * NB + lk) * ld + (size_t)i * NB + 32 * rh + 2 * lr;
+    double* cbh = S + (size_t)(j * NB + 32 * ch + 2 * lk) * ld + (size_t)i * NB + 32 * rh + 2 * lr;
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const v2dd c2 = *(const v2dd*)(cbh + (size_t)(8 * r + a) * ld);
+        acc[a][0][r] = c2[0]; acc[a][1][r] = c2[1];
+      }
+    v2dd pa[RD], pb[RD];
+#pragma unroll
+    for (int pre = 0; pre < RD - 1; ++pre) {
+      pa[pre] = *(const v2dd*)(pjh + (size_t)(4 * pre) * ld);
+      pb[pre] = *(const v2dd*)(pih + (size_t)(4 * pre) * ld);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + RD - 1 < KS) {
+        pa[(ks + RD - 1) % RD] = *(const v2dd*)(pjh + (size_t)(4 * (ks + RD - 1)) * ld);
+        pb[(ks + RD - 1) % RD] = *(const v2dd*)(pih + (size_t)(4 * (ks + RD - 1)) * ld);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const double na = -pa[ks % RD][a];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = mfma_f64(na, pb[ks % RD][b], acc[a][b]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v2dd c2; c2[0] = acc[a][0][r]; c2[1] = acc[a][1][r];
+        *(v2dd*)(cbh + (size_t)(8 * r + a) * ld) = c2;
+      }
+  }
+}
+
+
+// ---- V7: operands through LDS (each panel element fetched once per workgroup), 16-byte LDS reads, cross-item software pipeline:
+//          the next item's C and first operand chunk are requested while the current item's last chunk is in the matrix pipe -----
+constexpr int KC7 = 4;                  // k-steps per chunk (16 panel columns)
+constexpr int RS7 = 192 + 8;            // LDS column stride in doubles (rows 0..63 tile row i, 64..127 j0, 128..191 j0 + 1)
+template <int KS>
+__global__ __launch_bounds__(512) void k_v7(double* __restrict__ S, int ld, int kb, int T, int nP, int g0, int g1) {
+  __shared__ __attribute__((aligned(16))) double Bs[2][4 * KC7][RS7];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lk = lane >> 4;
+  const long long nG = (long long)nP * (nP + 1) / 2;
+  const int t = wave >> 2, ch = (wave >> 1) & 1, rh = wave & 1;
+  constexpr int NCH = KS / KC7;
+  // staging map: element pair e = tid + 512 q, q = 0..2: column e / 96, row pair e % 96 of the 192 staged rows
+  int scol[3], srow[3], sblk[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) { const int e = tid + 512 * q; scol[q] = e / 96; const int rp = e % 96; sblk[q] = rp >> 5; srow[q] = (rp & 31) * 2; }
+  auto item = [&](int g, int& i, int& j0, bool& any) {
+    any = false; i = j0 = 0;
+    if (g >= g1) return;
+    decode(g, kb, nP, nG, i, j0);
+    any = !(i > T || j0 > T - 1 || i < j0);
+  };
+  auto gsrc = [&](int q, int i, int j0, int c) {
+    const int tile = sblk[q] == 0 ? i : (j0 + sblk[q] - 1);
+    return S + (size_t)((kb - 2) * NB + 4 * KC7 * c + scol[q]) * ld + (size_t)tile * NB + srow[q];
+  };
+  int g = g0 + blockIdx.x, ci, cj0; bool cany;
+  item(g, ci, cj0, cany);
+  v2dd st[3], cin[2][4];
+  bool cok = false;
+  auto load_c = [&](int i, int j0, bool any) {
+    const int j = j0 + t;
+    cok = any && !(j > T - 1 || i < j);
+    if (cok) {
+      const double* cbh = S + (size_t)(j * NB + 32 * ch + 2 * lk) * ld + (size_t)i * NB + 32 * rh + 2 * lr;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cin[a][r] = *(const v2dd*)(cbh + (size_t)(8 * r + a) * ld);
+    }
+  };
+  // prologue of the first item: chunk 0 -> LDS buffer 0
+  if (cany) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) st[q] = *(const v2dd*)gsrc(q, ci, cj0, 0);
+    load_c(ci, cj0, cany);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *(v2dd*)(&Bs[0][scol[q]][sblk[q] * 64 + srow[q]]) = st[q];
+  }
+  __syncthreads();
+  int buf = 0;
+  while (g < g1) {
+    const int gn = g + gridDim.x;
+    int ni, nj0; bool nany;
+    item(gn, ni, nj0, nany);
+    if (cany) {
+      const bool my = cok;
+      const int j = cj0 + t;
+      v4d acc[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) { acc[a][0] = v4d{0, 0, 0, 0}; acc[a][1] = v4d{0, 0, 0, 0}; }
+      v2dd cmine[2][4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cmine[a][r] = cin[a][r];
+      const int arow = 64 * (1 + t) + 32 * ch + 2 * lr, brow = 32 * rh + 2 * lr;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        // request the next chunk (of this item, or the first of the next item together with its C)
+        const bool more = c + 1 < NCH;
+        if (more) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) st[q] = *(const v2dd*)gsrc(q, ci, cj0, c + 1);
+        } else if (nany) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) st[q] = *(const v2dd*)gsrc(q, ni, nj0, 0);
+          load_c(ni, nj0, nany);
+        }
+        const double* B = &Bs[buf][0][0];
+        if (my) {
+#pragma unroll
+          for (int ks = 0; ks < KC7; ++ks) {
+            const v2dd a2 = *(const v2dd*)(B + (4 * ks + lk) * RS7 + arow);
+            const v2dd b2 = *(const v2dd*)(B + (4 * ks + lk) * RS7 + brow);
+            acc[0][0] = mfma_f64(-a2[0], b2[0], acc[0][0]);
+            acc[0][1] = mfma_f64(-a2[0], b2[1], acc[0][1]);
+            acc[1][0] = mfma_f64(-a2[1], b2[0], acc[1][0]);
+            acc[1][1] = mfma_f64(-a2[1], b2[1], acc[1][1]);
+          }
+        }
+        if (more || nany) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) *(v2dd*)(&Bs[buf ^ 1][scol[q]][sblk[q] * 64 + srow[q]]) = st[q];
+        }
+        __syncthreads();
+        buf ^= 1;
+      }
+      if (my) {
+        double* cbh = S + (size_t)(j * NB + 32 * ch + 2 * lk) * ld + (size_t)ci * NB + 32 * rh + 2 * lr;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v2dd c2; c2[0] = cmine[a][r][0] + acc[a][0][r]; c2[1] = cmine[a][r][1] + acc[a][1][r];
+            *(v2dd*)(cbh + (size_t)(8 * r + a) * ld) = c2;
+          }
+      }
+    } else if (nany) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) st[q] = *(const v2dd*)gsrc(q, ni, nj0, 0);
+      load_c(ni, nj0, nany);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *(v2dd*)(&Bs[buf][scol[q]][sblk[q] * 64 + srow[q]]) = st[q];
+      __syncthreads();
+    }
+    g = gn; ci = ni; cj0 = nj0; cany = nany;
+  }
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
 int main(int argc, char** argv) {
@@ -576,6 +750,31 @@ int main(int argc, char** argv) {
     }
     run("v5 late C RD4", [&] { hipLaunchKernelGGL((k_v5<32, 4, true>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1); }, nullptr);
     run("v5 late C RD16", [&] { hipLaunchKernelGGL((k_v5<32, 16, true>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1); }, nullptr);
+    run("v6 1024 threads RD4", [&] { hipLaunchKernelGGL((k_v6<32, 4>), dim3(grid), dim3(1024), 0, 0, S, ld, kb, T, nP, g0, g1); }, nullptr);
+    {
+      std::vector<double> a(n), b(n);
+      CK(hipMemcpy(S, h.data(), n * 8, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL((k_v6<32, 4>), dim3(grid), dim3(1024), 0, 0, S, ld, kb, T, nP, g0, g1);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(a.data(), S, n * 8, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(b.data(), S2, n * 8, hipMemcpyDeviceToHost));
+      double md = 0; size_t nd = 0;
+      for (size_t i = 0; i < n; ++i) { double d = fabs(a[i] - b[i]); if (d > md) md = d; if (d != 0) ++nd; }
+      printf("   v6 vs v0: max |diff| %.3e, %zu differing\n", md, nd);
+    }
+    run("v6 1024 threads RD6", [&] { hipLaunchKernelGGL((k_v6<32, 6>), dim3(grid), dim3(1024), 0, 0, S, ld, kb, T, nP, g0, g1); }, nullptr);
+    run("v7 lds pipelined", [&] { hipLaunchKernelGGL((k_v7<32>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1); }, nullptr);
+    {
+      std::vector<double> a(n), b(n);
+      CK(hipMemcpy(S, h.data(), n * 8, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL((k_v7<32>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(a.data(), S, n * 8, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(b.data(), S2, n * 8, hipMemcpyDeviceToHost));
+      double md = 0; size_t nd = 0;
+      for (size_t i = 0; i < n; ++i) { double d = fabs(a[i] - b[i]); if (d > md) md = d; if (d != 0) ++nd; }
+      printf("   v7 vs v0: max |diff| %.3e, %zu differing\n", md, nd);
+    }
     run("v1 lds no C", [&] { hipLaunchKernelGGL((k_v1<32, true>), dim3(grid), dim3(512), 0, 0, S, ld, kb, T, nP, g0, g1); }, nullptr);
   }
   return 0;
