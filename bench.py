@@ -90,10 +90,8 @@ def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
     ThreadGroup (local sum, then RCCL across processes).  With R = 8 / N this is BASELINE's "8-robot graph at 1/2/4/8 GPUs"
     (total work fixed); a step = one distributed Gauss-Newton pass of all robots."""
     import threading
-    from slide_slam_amd.distributed import DistributedGraph, ThreadGroup, TorchComm
+    from slide_slam_amd.distributed import DistributedGraph, ThreadGroup, TorchComm, gpu_matcher
     from slide_slam_amd.synth import SynthConfig, make_robot_log, make_world
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from dist_worker import gpu_matcher
     cfg = SynthConfig.preset(args.preset)
     world_map = make_world(cfg)
     device = torch.device("cuda", dev_index)
@@ -276,9 +274,7 @@ def main():
     if world > 1:
         # one robot per GPU: shared landmarks are associated across ranks once, then every Gauss-Newton pass
         # exchanges their normal-equation blocks with two all-reduces (slide_slam_amd/distributed.py)
-        from slide_slam_amd.distributed import DistributedGraph, TorchComm
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from dist_worker import gpu_matcher
+        from slide_slam_amd.distributed import DistributedGraph, TorchComm, gpu_matcher
         comm = TorchComm(device=torch.device("cuda", dev_index), stage_through_host=(backend != "nccl"))
         dg = DistributedGraph(gb, comm, rank, world)
         dg_info = dg.setup(gpu_matcher)

@@ -29,7 +29,7 @@ extern "C" {
 #define SLIDE_ERR_NOT_SPD (-2)   /* a landmark block or the reduced pose system is not positive definite */
 #define SLIDE_ERR_CAPACITY (-3)  /* a fixed on-chip capacity was exceeded (e.g. > 16384 landmarks of one class in the K-NN gate) */
 #define SLIDE_ERR_HIP (-4)       /* HIP runtime error or no gfx950 device */
-#define SLIDE_ERR_RUNTIME (-5)   /* the reference would throw std::runtime_error here (sloam.cpp:349,355) */
+#define SLIDE_ERR_RUNTIME (-5)   /* the reference would throw std::runtime_error here (sloam.cpp:349,355); also: a device-side wait gave up (scheduling stall) */
 
 #define SLIDE_MAX_ROBOTS 13      /* include/factorgraph/graph.h:11 */
 
@@ -110,6 +110,11 @@ int slide_graph_get_landmark(slide_graph_t* g, int cls, uint64_t idx, double* ou
 int slide_graph_get_pose_covariance(slide_graph_t* g, int robot, uint64_t idx, double cov36[36]);
 /* counts: [poses, landmarks, factors, relinearised vars in the last solve, chol dim] */
 int slide_graph_stats(slide_graph_t* g, int64_t out5[5]);
+/* isam->update(fgraph, fvalues) (graph.cpp:262) throws when a factor names a key that is in neither the graph nor fvalues, and when a
+ * value is inserted under a key that exists already.  Here such an entry is refused, the rest of the update is merged, and the call
+ * that consumed it (solve, gauss_newton, dist_phase 0 / 20, set_shared, set_ghosts, chol_batch_pass) returns SLIDE_ERR_INVALID with the
+ * first offending key in slide_last_error().  This returns the number of entries refused since the graph was created (0 in a healthy run). */
+int64_t slide_graph_rejected_count(slide_graph_t* g);
 /* Per-kernel device timings (HIP events on the launch stream) of the solves since the last reset.
  * names: caller buffer of n_max * 32 chars; ms_total / launches: n_max entries.  Returns #entries. */
 int slide_graph_set_profiling(slide_graph_t* g, int on);
@@ -132,6 +137,9 @@ int slide_graph_dist_phase(slide_graph_t* g, int phase, double* d_buf);
  * graph): the dense factor + solve of phase 1 of all joined graphs runs as one launch sequence, one launch per block column for
  * all of them.  Every joined graph must then run its passes in lockstep from its own host thread (slide_graph_dist_phase(g, 1, ..)
  * returns when all have arrived; SLIDE_ERR_RUNTIME after 60 s).  slide_graph_join_chol_batch(g, NULL, 0) leaves the batch. */
+/* Ownership: a batch does not own its graphs, a graph does not own its batch.  slide_graph_destroy / slide_backend_destroy leave the
+ * batch first; slide_chol_batch_destroy sends every joined graph back to its own launches.  Neither may run while a pass of the batch
+ * is executing on another thread. */
 typedef struct slide_chol_batch slide_chol_batch_t;
 slide_chol_batch_t* slide_chol_batch_create(int n_graphs);      /* 1 .. 8 */
 void slide_chol_batch_destroy(slide_chol_batch_t* b);
@@ -269,6 +277,18 @@ int slide_match_maps(const double* ref7, int nr, const double* qry7, int nq, con
 int slide_find_inter_loop_closure(const double* ref7, int nr, const double* qry7, int nq, const slide_place_params_t* p,
                                   double tf16[16], int* inliers, double xyzyaw[4]);
 
+/* PlaceRecognition::findIntraLoopClosure :389-496 (same-robot loop closure: the object detections around the query key pose against
+ * the submap around an older candidate key pose).  meas7: detections in the query pose's LOCAL frame, submap7: map objects in the
+ * map frame (rows [label, x, y, z, d1, d2, d3]).  The detections go into the map frame with the (drifted) query pose, then
+ * findTransformation runs with inter_loop_closure == false (:801-816): no centring, the search window is the three intra half
+ * ranges (match_{x,y,yaw}_half_range_intra, defaults 5 m / 5 m / 10 deg :53-63; yaw in radians here).  tf16 (row-major 4x4) =
+ * candidate^-1 * query * [Rz(yaw) | (x, y, 0)] = tfFromQuery2Candidate.  Returns 1 found / 0 not found (fewer than 4 detections,
+ * an empty input, too few inliers) / negative error. */
+int slide_find_intra_loop_closure(const double* meas7, int nm, const double* submap7, int ns, const double query_pose7[7],
+                                  const double candidate_pose7[7], const slide_place_params_t* p, double x_half_range_intra,
+                                  double y_half_range_intra, double yaw_half_range_intra, double tf16[16], int* inliers,
+                                  double xyzyaw[4]);
+
 /* CLIPPER pairwise-consistency affinity (clipper_semantic_object/src/clipper.cpp:21-65 with the
  * EuclideanDistance invariant src/invariants/euclidean_distance.cpp:13-31).  D1: n1 points of `dim`
  * doubles (point-major), A: m x 2 association list.  M_out: m x m row-major, upper triangle filled. */
@@ -324,6 +344,14 @@ int slide_pick_next_measurement(const int64_t* odom_sec, const int64_t* odom_nse
  * (robotPoseCloud_).  *inside = 0 / 1.  Host bookkeeping (a few thousand points per call). */
 int slide_in_loop_closure_region(const float* cloud_xyz, int n, const double pose_xyz[3], double max_dist_xy, double max_dist_z,
                                  uint64_t at_least_num_of_poses_old, int* inside);
+
+/* CylinderMapManager::getLoopCandidateIdx cylinderMapManager.cpp:160-184: the first key pose, in FLANN's nearest-first order, within
+ * max_dist (float32 squared distances, strict '<') of key pose pose_idx that is not pose_idx itself and has
+ * pose_idx - idx > at_least_num_of_poses_old in size_t arithmetic (so an index ABOVE pose_idx wraps around and qualifies, as in the
+ * reference).  Equidistant neighbours are ordered by index (FLANN leaves that order unspecified).  Fewer than 50 key poses: not found.
+ * Host bookkeeping. */
+int slide_loop_candidate_idx(const float* cloud_xyz, int n, double max_dist, uint64_t pose_idx, uint64_t at_least_num_of_poses_old,
+                             uint64_t* candidate_idx, int* found);
 
 /* 2-D Delaunay triangulation (replaces the qhull call of DelaunayTriangulation::Observation, triangulation/observation.cpp:13-88,
  * options "Qt Qbb Qc Qz Q12 d").  Host code (sweep-hull + Lawson flips, long double predicates).  tri_out: vertex-index triples,

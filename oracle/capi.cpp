@@ -405,6 +405,9 @@ void orc_pick_next_measurement(const int64_t* odom_sec, const int64_t* odom_nsec
                                              latest_sec, latest_nsec, l12, current_time, msg_delay_tolerance, min_odom_distance);
   out4[0] = r.meas_to_add; out4[1] = r.pop_odom; out4[2] = r.pop_obs; out4[3] = r.pop_rel;
 }
+int orc_loop_candidate_idx(const float* cloud, int n, double max_dist, uint64_t pose_idx, uint64_t at_least, uint64_t* cand) {
+  return loop_candidate_idx(cloud, n, max_dist, pose_idx, at_least, cand) ? 1 : 0;
+}
 int orc_in_loop_closure_region(const float* cloud, int n, const double* pose_t, double max_xy, double max_z, uint64_t at_least) {
   return in_loop_closure_region(cloud, n, pose_t, max_xy, max_z, at_least) ? 1 : 0;
 }
@@ -461,5 +464,12 @@ int orc_find_transformation(const double* ref7, int nr, const double* qry7, int 
   return find_inter_loop_closure(ref7, nr, qry7, nq, P, tf16, inliers, xyzyaw) ? 1 : 0;
 }
 void orc_place_default_params(OrcPlaceParams* p) { place_default_params(p); }
+int orc_find_intra_loop_closure(const double* meas7, int nm, const double* submap7, int ns, const double* query7, const double* cand7,
+                                const OrcPlaceParams* p, double x_half, double y_half, double yaw_half, double* tf16, int* inliers,
+                                double* xyzyaw) {
+  PlaceParams P = place_params_from(p);
+  return find_intra_loop_closure(meas7, nm, submap7, ns, pose_from7(query7), pose_from7(cand7), P, x_half, y_half, yaw_half, tf16,
+                                 inliers, xyzyaw) ? 1 : 0;
+}
 
 }  // extern "C"

@@ -6,6 +6,9 @@
 // Queues are flat arrays (front = index 0); the function returns how many entries the reference pops from each front.
 // ros::Time: (sec, nsec), operator< lexicographic, toSec() = sec + 1e-9 nsec.
 #pragma once
+#include <algorithm>
+#include <utility>
+#include <vector>
 #include <cmath>
 #include <cstdint>
 
@@ -77,6 +80,29 @@ inline bool in_loop_closure_region(const float* cloud, int n, const double* pose
     const double dzz = std::fabs((double)(cloud[3 * i + 2] - sz));
     if (dxy > max_dist_xy || dzz > max_dist_z) continue;
     if ((uint64_t)(n - 1) - (uint64_t)i > at_least_num_of_poses_old) return true;
+  }
+  return false;
+}
+
+// CylinderMapManager::getLoopCandidateIdx cylinderMapManager.cpp:160-184.  kdtree.radiusSearch returns the neighbours sorted by
+// squared float distance; the loop takes the first one with nnIdx != poseIdx && poseIdx - nnIdx > at_least (size_t arithmetic: an
+// index above poseIdx wraps around and passes).  Order among exactly equidistant neighbours: by index (FLANN: unspecified).
+inline bool loop_candidate_idx(const float* cloud, int n, double max_dist, uint64_t pose_idx, uint64_t at_least, uint64_t* cand) {
+  if (n < 50) return false;
+  const float* sp = cloud + 3 * pose_idx;
+  const float r2 = (float)(max_dist * max_dist);
+  std::vector<std::pair<float, int>> nn;
+  for (int i = 0; i < n; ++i) {
+    const float dx = cloud[3 * i] - sp[0], dy = cloud[3 * i + 1] - sp[1], dz = cloud[3 * i + 2] - sp[2];
+    float d2 = dx * dx;
+    d2 += dy * dy;
+    d2 += dz * dz;
+    if (d2 < r2) nn.push_back({d2, i});
+  }
+  std::stable_sort(nn.begin(), nn.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first < b.first; });
+  for (const auto& e : nn) {
+    const uint64_t idx = (uint64_t)e.second;
+    if (idx != pose_idx && pose_idx - idx > at_least) { *cand = idx; return true; }
   }
   return false;
 }

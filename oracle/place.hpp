@@ -14,6 +14,8 @@
 #include <cmath>
 #include <vector>
 
+#include "lie.hpp"
+
 namespace orc {
 
 struct OrcPlaceParams {
@@ -225,26 +227,28 @@ inline void solve_lsq(const std::vector<double>& map_xyz, const std::vector<doub
   xyzyaw[3] = std::atan2(R[3], R[0]);
 }
 
-// findInterLoopClosure :498-538 -> findTransformation :736-945 (inter_loop_closure branch).
-// tf16_out = yaw + xyz transform "from query to reference" composed as :528-535.
-inline bool find_inter_loop_closure(const double* ref7_in, int nr, const double* qry7_in, int nq, const PlaceParams& P,
-                                    double* tf16_out, int* inliers_out, double* xyzyaw_out) {
-  if (inliers_out) *inliers_out = 0;
-  if (nr < P.min_num_map_objects_to_start || nq < P.min_num_map_objects_to_start || nr == 0 || nq == 0) return false;
+// findTransformation :736-945.  inter (inter_loop_closure == true, :745-800): both maps centred on their XY centroids, ranges from
+// the extents (inside match_maps).  intra (:801-816): maps as they are, the three intra half ranges.
+inline bool find_transformation(const double* ref7_in, int nr, const double* qry7_in, int nq, PlaceParams P, bool inter,
+                                double x_half_intra, double y_half_intra, double yaw_half_intra, int* inliers_out, double* xyzyaw) {
   std::vector<double> ref(ref7_in, ref7_in + 7 * (size_t)nr), qry(qry7_in, qry7_in + 7 * (size_t)nq);
   double cr[2] = {0, 0}, cq[2] = {0, 0};
-  for (int i = 0; i < nr; ++i) { cr[0] += ref[7 * i + 1]; cr[1] += ref[7 * i + 2]; }
-  for (int i = 0; i < nq; ++i) { cq[0] += qry[7 * i + 1]; cq[1] += qry[7 * i + 2]; }
-  cr[0] /= nr; cr[1] /= nr; cq[0] /= nq; cq[1] /= nq;
-  for (int i = 0; i < nr; ++i) { ref[7 * i + 1] -= cr[0]; ref[7 * i + 2] -= cr[1]; }
-  for (int i = 0; i < nq; ++i) { qry[7 * i + 1] -= cq[0]; qry[7 * i + 2] -= cq[1]; }
   MatchMapsResult R;
-  match_maps(ref.data(), nr, qry.data(), nq, P, R);
+  if (inter) {
+    for (int i = 0; i < nr; ++i) { cr[0] += ref[7 * i + 1]; cr[1] += ref[7 * i + 2]; }
+    for (int i = 0; i < nq; ++i) { cq[0] += qry[7 * i + 1]; cq[1] += qry[7 * i + 2]; }
+    cr[0] /= nr; cr[1] /= nr; cq[0] /= nq; cq[1] /= nq;
+    for (int i = 0; i < nr; ++i) { ref[7 * i + 1] -= cr[0]; ref[7 * i + 2] -= cr[1]; }
+    for (int i = 0; i < nq; ++i) { qry[7 * i + 1] -= cq[0]; qry[7 * i + 2] -= cq[1]; }
+    match_maps(ref.data(), nr, qry.data(), nq, P, R);
+  } else {
+    P.yaw_half_range = yaw_half_intra;
+    match_maps_ranges(ref.data(), nr, qry.data(), nq, x_half_intra, y_half_intra, P, R);
+  }
   if (inliers_out) *inliers_out = R.best_inliers;
   if (R.best_inliers < P.min_num_inliers) return false;
-  double xyzyaw[4];
   if (!P.use_lsq) {
-    // revertCentroidShift :947-967: T(c_ref) * [Rz(yaw) | (x,y,0)] * T(-c_query)
+    // revertCentroidShift :947-967: T(c_ref) * [Rz(yaw) | (x,y,0)] * T(-c_query)   (zero centroids for intra: the raw transform)
     const double c = std::cos(R.yaw), s = std::sin(R.yaw);
     xyzyaw[0] = cr[0] + R.x + (c * (-cq[0]) - s * (-cq[1]));
     xyzyaw[1] = cr[1] + R.y + (s * (-cq[0]) + c * (-cq[1]));
@@ -261,11 +265,49 @@ inline bool find_inter_loop_closure(const double* ref7_in, int nr, const double*
     double tf[16];
     solve_lsq(mp, dt, tf, xyzyaw);
   }
+  return true;
+}
+
+// findInterLoopClosure :498-538.  tf16_out = yaw + xyz transform "from query to reference" composed as :528-535.
+inline bool find_inter_loop_closure(const double* ref7_in, int nr, const double* qry7_in, int nq, const PlaceParams& P,
+                                    double* tf16_out, int* inliers_out, double* xyzyaw_out) {
+  if (inliers_out) *inliers_out = 0;
+  if (nr < P.min_num_map_objects_to_start || nq < P.min_num_map_objects_to_start || nr == 0 || nq == 0) return false;
+  double xyzyaw[4];
+  if (!find_transformation(ref7_in, nr, qry7_in, nq, P, true, 0, 0, 0, inliers_out, xyzyaw)) return false;
   for (int i = 0; i < 16; ++i) tf16_out[i] = 0;
   tf16_out[0] = std::cos(xyzyaw[3]); tf16_out[1] = -std::sin(xyzyaw[3]);
   tf16_out[4] = std::sin(xyzyaw[3]); tf16_out[5] = std::cos(xyzyaw[3]);
   tf16_out[10] = 1; tf16_out[15] = 1;
   tf16_out[3] = xyzyaw[0]; tf16_out[7] = xyzyaw[1]; tf16_out[11] = xyzyaw[2];
+  if (xyzyaw_out) for (int i = 0; i < 4; ++i) xyzyaw_out[i] = xyzyaw[i];
+  return true;
+}
+
+// findIntraLoopClosure :389-496: measurements (local frame of the query pose) -> map frame with the drifted query pose (:418-440),
+// findTransformation with inter_loop_closure == false, tfFromQuery2Candidate = candidate^-1 * query * [Rz(yaw) | (x, y, 0)] (:456-492)
+inline bool find_intra_loop_closure(const double* meas7, int nm, const double* submap7, int ns, const Pose& query, const Pose& candidate,
+                                    const PlaceParams& P, double x_half, double y_half, double yaw_half, double* tf16_out,
+                                    int* inliers_out, double* xyzyaw_out) {
+  if (inliers_out) *inliers_out = 0;
+  if (nm == 0 || ns == 0) return false;
+  if (nm < 4) return false;
+  std::vector<double> mw(meas7, meas7 + 7 * (size_t)nm);
+  for (int i = 0; i < nm; ++i) pose_transform_from(query, meas7 + 7 * (size_t)i + 1, &mw[7 * (size_t)i + 1]);
+  double xyzyaw[4];
+  if (!find_transformation(submap7, ns, mw.data(), nm, P, false, x_half, y_half, yaw_half, inliers_out, xyzyaw)) return false;
+  Pose Lc;
+  const double c = std::cos(xyzyaw[3]), s = std::sin(xyzyaw[3]);
+  const double Rz[9] = {c, -s, 0, s, c, 0, 0, 0, 1};
+  for (int i = 0; i < 9; ++i) Lc.R[i] = Rz[i];
+  Lc.t[0] = xyzyaw[0]; Lc.t[1] = xyzyaw[1]; Lc.t[2] = 0.0;
+  const Pose out = pose_compose(pose_compose(pose_inverse(candidate), query), Lc);
+  for (int r = 0; r < 3; ++r) {
+    for (int k = 0; k < 3; ++k) tf16_out[4 * r + k] = out.R[3 * r + k];
+    tf16_out[4 * r + 3] = out.t[r];
+    tf16_out[12 + r] = 0.0;
+  }
+  tf16_out[15] = 1.0;
   if (xyzyaw_out) for (int i = 0; i < 4; ++i) xyzyaw_out[i] = xyzyaw[i];
   return true;
 }

@@ -28,12 +28,13 @@ EXPORTS = [
     "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
     "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
-    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
+    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
     "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
     "slide_dense_spd_solve", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
     "slide_backend_end_frame", "slide_backend_graph", "slide_backend_counts", "slide_backend_map_model",
-    "slide_place_default_params", "slide_match_maps", "slide_find_inter_loop_closure", "slide_clipper_affinity",
+    "slide_place_default_params", "slide_match_maps", "slide_find_inter_loop_closure", "slide_find_intra_loop_closure",
+    "slide_loop_candidate_idx", "slide_clipper_affinity",
     "slide_closest_stamp", "slide_clipper_default_params", "slide_clipper_dense_clique", "slide_match_triangles",
     "slide_estimate_tf2d", "slide_semantic_clipper", "slide_find_relative_meas_match", "slide_delaunay_2d", "slide_run_semantic_clipper",
     "slide_pick_next_measurement", "slide_in_loop_closure_region",
@@ -89,6 +90,8 @@ def lib():
         L.slide_backend_create.restype = C.c_void_p
         L.slide_backend_graph.restype = C.c_void_p
         L.slide_chol_batch_create.restype = C.c_void_p
+        L.slide_graph_rejected_count.restype = C.c_int64
+        L.slide_graph_rejected_count.argtypes = [C.c_void_p]
         L.slide_chol_batch_destroy.argtypes = [C.c_void_p]
         L.slide_chol_batch_destroy.restype = None
         _LIB = L
@@ -214,6 +217,10 @@ class SlideGraph:
         out = np.zeros(5, np.int64)
         _check(self.L.slide_graph_stats(self.h, _p(out)))
         return dict(n_pose=int(out[0]), n_lm=int(out[1]), n_factors=int(out[2]), n_relin=int(out[3]), chol_dim=int(out[4]))
+
+    def rejected_count(self):
+        """Entries (factors on unknown keys, values inserted twice) refused since creation; the reference's isam->update throws there."""
+        return int(self.L.slide_graph_rejected_count(self.h))
 
     def set_shared(self, cls, idx, owner):
         cls, owner = _i(cls), _i(owner)
@@ -431,6 +438,30 @@ def find_inter_loop_closure(ref7, qry7, params: PlaceParams):
     if rc < 0:
         _check(rc)
     return dict(found=bool(rc), tf=tf.reshape(4, 4), inliers=inl.value, xyzyaw=xyzyaw)
+
+
+def find_intra_loop_closure(meas7, submap7, query_pose7, candidate_pose7, params: PlaceParams, x_half=5.0, y_half=5.0,
+                            yaw_half=10.0 * np.pi / 180.0):
+    """PlaceRecognition::findIntraLoopClosure (place_recognition.cpp:389-496); intra half ranges default as :53-63."""
+    m, sm = _d(meas7).reshape(-1, 7), _d(submap7).reshape(-1, 7)
+    tf = np.zeros(16)
+    inl = C.c_int(0)
+    xyzyaw = np.zeros(4)
+    rc = lib().slide_find_intra_loop_closure(_p(m), C.c_int(len(m)), _p(sm), C.c_int(len(sm)), _p(_d(query_pose7)),
+                                             _p(_d(candidate_pose7)), C.byref(params), C.c_double(x_half), C.c_double(y_half),
+                                             C.c_double(yaw_half), _p(tf), C.byref(inl), _p(xyzyaw))
+    if rc < 0:
+        _check(rc)
+    return dict(found=bool(rc), tf=tf.reshape(4, 4), inliers=inl.value, xyzyaw=xyzyaw)
+
+
+def loop_candidate_idx(cloud_xyz, max_dist, pose_idx, at_least_num_of_poses_old):
+    """CylinderMapManager::getLoopCandidateIdx (cylinderMapManager.cpp:160-184).  Returns the candidate index or None."""
+    cloud = np.ascontiguousarray(cloud_xyz, dtype=np.float32).reshape(-1, 3)
+    cand, found = C.c_uint64(0), C.c_int(0)
+    _check(lib().slide_loop_candidate_idx(_p(cloud), C.c_int(len(cloud)), C.c_double(max_dist), C.c_uint64(pose_idx),
+                                          C.c_uint64(at_least_num_of_poses_old), C.byref(cand), C.byref(found)))
+    return int(cand.value) if found.value else None
 
 
 def clipper_affinity(D1, D2, A, sigma=0.01, epsilon=0.06, mindist=0.0, affinityeps=1e-4):

@@ -670,8 +670,9 @@ extern "C" void slide_debug_stamps(unsigned long long* out) { (void)hipMemcpyFro
 // whose workgroups poll the entries of the blocks they depend on ("flag in data": one round trip per link of the chain).
 constexpr unsigned long long BWD_SENT = 0x7FF8DEADBEEF0BADull;
 
-__global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, double* __restrict__ yv, double* __restrict__ dp) {
+__global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, double* __restrict__ yv, double* __restrict__ dp, int* status) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) status[4] = 0;            // ticket counter of the chained backward substitution that follows
   if (c < T * NB) {
     yv[c] = S[(size_t)c * ld + (size_t)T * NB];
     dp[c] = __longlong_as_double((long long)BWD_SENT);
@@ -680,8 +681,10 @@ __global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, do
 
 // Backward substitution L^T x = y as ONE launch: workgroup b owns block c = T-1-b.  It accumulates
 //   y_c - sum_{j > c} L(j, c)^T x_j
-// in descending j as the x_j appear in dp (published by the workgroups of LOWER index, which the dispatcher starts first, so
-// every wait is on a workgroup that is resident or finished), then x_c = (L_cc^-1)^T (.) and publishes it.  The tiles L(j, c)
+// in descending j as the x_j appear in dp, then x_c = (L_cc^-1)^T (.) and publishes it.  Block ids are TICKETS drawn from an
+// atomic counter (status[4], cleared by k_chol_extract_y) when a workgroup starts, not blockIdx: a block only ever waits for blocks
+// with lower tickets, i.e. for workgroups that have started already (resident or finished) — the order is enforced, not assumed
+// from the dispatcher.  The tiles L(j, c)
 // do not depend on x and are prefetched three ahead; the explicit 64x64 inverse of L_cc is assembled from the 16x16 inverses
 // and sub-tiles of the factorisation while the workgroup would otherwise wait.  Polling loads and publishing stores are
 // relaxed device-scope atomics (they bypass the non-coherent cache levels between XCDs); the data is its own flag.
@@ -797,21 +800,39 @@ __device__ __forceinline__ void bwd_chain_body(const double* __restrict__ S, int
   x += __shfl_xor(x, 2);
   if (part == 0) __hip_atomic_store(dp + (size_t)c * NB + col, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ int bwd_ticket(int* ctr) {
+  __shared__ int s_t;
+  if (threadIdx.x == 0) s_t = atomicAdd(ctr, 1);
+  __syncthreads();
+  const int t = s_t;
+  __syncthreads();
+  return t;
+}
 __global__ __launch_bounds__(256) void k_chol_bwd_chain(const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
                                                         const double* __restrict__ Winv, const double* __restrict__ yv, double* dp, int* status) {
-  bwd_chain_body(S, ld, T, Ld, Winv, yv, dp, status, (int)blockIdx.x);
+  const int t = bwd_ticket(&status[4]);
+  if (t >= T) return;
+  bwd_chain_body(S, ld, T, Ld, Winv, yv, dp, status, t);
 }
 struct BwdBatchArgs {
   int n;
   const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX];
   const double* Ld[CHOL_BATCH_MAX]; const double* Winv[CHOL_BATCH_MAX]; const double* yv[CHOL_BATCH_MAX]; double* dp[CHOL_BATCH_MAX];
   int* status[CHOL_BATCH_MAX];
-  int base[CHOL_BATCH_MAX + 1];        // prefix sums of T: workgroups of one system are contiguous and in its own order
+  int base[CHOL_BATCH_MAX + 1];        // prefix sums of T (grid size = base[n])
+  int Tmax;
 };
+// ticket t -> system t % n, block t / n of it: the chains of all systems advance side by side; a ticket beyond a shorter system's
+// end is void and the workgroup draws again (there are exactly as many valid tickets as workgroups)
 __global__ __launch_bounds__(256) void k_chol_bwd_chain_batched(BwdBatchArgs A) {
-  int r = 0;
-  while ((int)blockIdx.x >= A.base[r + 1]) ++r;
-  bwd_chain_body(A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.yv[r], A.dp[r], A.status[r], (int)blockIdx.x - A.base[r]);
+  for (;;) {
+    const int t = bwd_ticket(&A.status[0][4]);
+    if (t >= A.n * A.Tmax) return;
+    const int r = t % A.n, b = t / A.n;
+    if (b >= A.T[r]) continue;
+    bwd_chain_body(A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.yv[r], A.dp[r], A.status[r], b);
+    return;
+  }
 }
 
 
@@ -897,8 +918,8 @@ void launch_pose_covariance(const double* S, int ld, int T, const double* Ld, co
 // Schedule (see step_type_b): launch 0 factors column 0, launch 1 column 1 with panel 0 (and brings column 2 up to panel 0);
 // from then on every launch k takes the one pending panel k-1 in its column, even launches start the rank-128 pass of panels
 // k-2, k-1 over the trailing matrix, odd launches finish the pass their predecessor started and bring column k+1 up to panel k-1.
-void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, hipStream_t s) {
-  hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv, dp);
+void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s) {
+  hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv, dp, status);
 }
 struct StepPlan { int kb, nP, g0, g1, nX; long long nA, nB; };
 static int chol_n_cu() {
@@ -975,11 +996,12 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
   B.n = n;
   B.base[0] = 0;
   for (int i = 0; i < n; ++i) {
-    launch_chol_extract_y(d[i].S, d[i].ld, d[i].T, d[i].yv, d[i].dp, s);
+    launch_chol_extract_y(d[i].S, d[i].ld, d[i].T, d[i].yv, d[i].dp, d[i].status, s);
     B.S[i] = d[i].S; B.ld[i] = d[i].ld; B.T[i] = d[i].T; B.Ld[i] = d[i].Ld; B.Winv[i] = d[i].Winv; B.yv[i] = d[i].yv; B.dp[i] = d[i].dp;
     B.status[i] = d[i].status;
     B.base[i + 1] = B.base[i] + d[i].T;
   }
+  B.Tmax = Tmax;
   if (B.base[n] > 0) hipLaunchKernelGGL(k_chol_bwd_chain_batched, dim3(B.base[n]), dim3(256), 0, s, B);
 }
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp,
@@ -989,7 +1011,7 @@ void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const
 
 int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double* yv, double* dp, int* status, int* ctr, hipStream_t s) {
   for (int k = 0; k < T; ++k) launch_chol_step(S, ld, k, T, Ld + (size_t)k * NB * NB, Winv + (size_t)k * 1024, status, ctr, s);
-  launch_chol_extract_y(S, ld, T, yv, dp, s);
+  launch_chol_extract_y(S, ld, T, yv, dp, status, s);
   launch_chol_bwd_all(S, ld, T, Ld, Winv, yv, dp, status, s);
   return 0;
 }

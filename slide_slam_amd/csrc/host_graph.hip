@@ -18,6 +18,15 @@ bool hip_ok(hipError_t e, const char* what) {
   return false;
 }
 
+// status words of a pass: [0] a landmark block, [1] bit 0 the reduced pose system is not positive definite; [1] bit 1: a workgroup of
+// the chained backward substitution gave up waiting for its predecessors — a scheduling stall, not a numerical failure
+int decode_status(const int* st) {
+  if (st[0]) { g_last_error = "landmark block not positive definite"; return SLIDE_ERR_NOT_SPD; }
+  if (st[1] & 1) { g_last_error = "reduced pose system not positive definite"; return SLIDE_ERR_NOT_SPD; }
+  if (st[1] & 2) { g_last_error = "backward substitution: a workgroup waited too long for the blocks it depends on (scheduling stall, the update was rejected)"; return SLIDE_ERR_RUNTIME; }
+  return SLIDE_OK;
+}
+
 // ---- profiler ----------------------------------------------------------------------------------
 int Profiler::id_of(const char* name) {
   for (size_t i = 0; i < names.size(); ++i)
@@ -73,6 +82,7 @@ uint64_t HostGraph::lm_key(int cls, uint64_t idx) {
 
 HostGraph::HostGraph(const slide_params_t& p) : P(p) {}
 HostGraph::~HostGraph() {
+  if (batch) batch->detach(this);         // the batch must not keep a pointer to a dead graph
   if (gexec) (void)hipGraphExecDestroy(gexec);
   for (auto& pg : phase_graph)
     if (pg.exec) (void)hipGraphExecDestroy(pg.exec);
@@ -257,17 +267,28 @@ int HostGraph::add_cylinder(int robot, uint64_t pose_idx, uint64_t cyl_idx, cons
 }
 
 // ---- merge fgraph / fvalues into the resident arrays (what isam->update(fgraph, fvalues) ingests) ------
+// isam->update(fgraph, fvalues) throws on a factor whose key is in neither the graph nor fvalues and on a value whose key exists
+// already; here such an entry is refused (counted in n_rejected, named in the error text), everything else of the batch is merged,
+// and the call returns SLIDE_ERR_INVALID so that the caller's solve() does not pass silently.
+static std::string key_name(uint64_t k) {
+  return std::string(1, (char)(k >> 56)) + std::to_string((unsigned long long)(k & 0x00ffffffffffffffull));
+}
 int HostGraph::merge_pending() {
   if (!pend_vars.empty() || !pend_facs.empty()) topo_dirty = true;
+  int refused = 0;
+  std::string first;
+  auto refuse = [&](const char* what, uint64_t key) {
+    if (!refused++) first = std::string(what) + " " + key_name(key);
+  };
   for (const PendVar& v : pend_vars) {
     if (v.type == VT_POSE) {
-      if (key2pose.count(v.key)) continue;   // GTSAM would throw ValuesKeyAlreadyExists
+      if (key2pose.count(v.key)) { refuse("value inserted twice:", v.key); continue; }   // GTSAM: ValuesKeyAlreadyExists
       key2pose[v.key] = (int)(h_pose_val.size() / 12);
       h_pose_val.insert(h_pose_val.end(), v.val, v.val + 12);
       pose_fids.emplace_back();
       pose_bt.emplace_back();
     } else {
-      if (key2lm.count(v.key)) continue;
+      if (key2lm.count(v.key)) { refuse("value inserted twice:", v.key); continue; }
       key2lm[v.key] = (int)h_lm_type.size();
       h_lm_type.push_back(v.type);
       h_lm_val.insert(h_lm_val.end(), v.val, v.val + 15);
@@ -277,7 +298,7 @@ int HostGraph::merge_pending() {
   pend_vars.clear();
   for (const PendFac& f : pend_facs) {
     auto a = key2pose.find(f.k0);
-    if (a == key2pose.end()) continue;
+    if (a == key2pose.end()) { refuse("factor on a pose that is not in the graph:", f.k0); continue; }
     if (f.type == 0) {
       h_pr_pose.push_back(a->second);
       h_pr_z.insert(h_pr_z.end(), f.z, f.z + 12);
@@ -290,7 +311,7 @@ int HostGraph::merge_pending() {
       h_gh_sigma.insert(h_gh_sigma.end(), f.sigma, f.sigma + 6);
     } else if (f.type == 1) {
       auto b = key2pose.find(f.k1);
-      if (b == key2pose.end()) continue;
+      if (b == key2pose.end()) { refuse("factor on a pose that is not in the graph:", f.k1); continue; }
       const int bi = (int)h_bt_i.size();
       h_bt_i.push_back(a->second);
       h_bt_j.push_back(b->second);
@@ -300,7 +321,7 @@ int HostGraph::merge_pending() {
       pose_bt[b->second].push_back((bi << 1) | 1);
     } else {
       auto b = key2lm.find(f.k1);
-      if (b == key2lm.end()) continue;
+      if (b == key2lm.end()) { refuse("factor on a landmark that is not in the graph:", f.k1); continue; }
       const int fid = (int)h_lf_type.size();
       h_lf_type.push_back(f.type);
       h_lf_pose.push_back(a->second);
@@ -330,12 +351,41 @@ int HostGraph::merge_pending() {
     }
   }
   pend_facs.clear();
+  if (refused) {
+    n_rejected += refused;
+    g_last_error = "graph update refused " + std::to_string(refused) + " entr" + (refused == 1 ? "y" : "ies") + " (" + first + ")";
+    return SLIDE_ERR_INVALID;
+  }
   return SLIDE_OK;
 }
 
 constexpr int CHOL_BATCH_HOST_MAX = 8;
 CholBatch::CholBatch(int n_) : n(n_ < 1 ? 1 : (n_ > 8 ? 8 : n_)), sys(n), ev_in(n, nullptr), bufs(n, nullptr), graphs(n, nullptr) {}
+void CholBatch::set_graph(int slot, HostGraph* g) {
+  std::lock_guard<std::mutex> lk(mtx);
+  if (slot < 0 || slot >= n) return;
+  graphs[slot] = g;
+  pass_dirty = true;
+}
+void CholBatch::detach(HostGraph* g) {
+  std::lock_guard<std::mutex> lk(mtx);
+  for (auto& p : graphs)
+    if (p == g) { p = nullptr; pass_dirty = true; }
+}
+void HostGraph::join_batch(CholBatch* b, int slot) {
+  CholBatch* old = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(mtx);
+    old = batch;
+    batch = b;
+    batch_slot = slot;
+  }
+  if (old && old != b) old->detach(this);
+  if (b) b->set_graph(slot, this);
+}
 CholBatch::~CholBatch() {
+  for (HostGraph* g : graphs)
+    if (g) { std::lock_guard<std::mutex> gl(g->mtx); if (g->batch == this) g->batch = nullptr; }
   for (hipEvent_t e : ev_in) if (e) (void)hipEventDestroy(e);
   if (ev_out) (void)hipEventDestroy(ev_out);
   if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -486,9 +536,12 @@ int CholBatch::capture_pass(double* const* d_bufs) {
 // One pass issued directly (no graph), with HIP events on the batch's stream around the batched step kernels: their total device
 // time and launch count (the bench's roofline of k_chol_step_batched).
 int CholBatch::profile_pass(double* const* d_bufs, double* ms_steps, int* n_launches) {
-  std::lock_guard<std::mutex> lk(mtx);
-  for (int i = 0; i < n; ++i)
-    if (!graphs[i] || !d_bufs[i]) { g_last_error = "batched pass: a slot of the batch is empty"; return SLIDE_ERR_INVALID; }
+  std::lock_guard<std::mutex> pl(pass_mtx);
+  {
+    std::lock_guard<std::mutex> lk(mtx);
+    for (int i = 0; i < n; ++i)
+      if (!graphs[i] || !d_bufs[i]) { g_last_error = "batched pass: a slot of the batch is empty"; return SLIDE_ERR_INVALID; }
+  }
   if (!master) {
     SL_HIP(hipStreamCreateWithFlags(&master, hipStreamNonBlocking));
     SL_HIP(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
@@ -524,14 +577,20 @@ int CholBatch::profile_pass(double* const* d_bufs, double* ms_steps, int* n_laun
 }
 
 int CholBatch::pass_all(double* const* d_bufs) {
-  std::lock_guard<std::mutex> lk(mtx);
-  for (int i = 0; i < n; ++i)
-    if (!graphs[i] || !d_bufs[i]) { g_last_error = "batched pass: a slot of the batch is empty"; return SLIDE_ERR_INVALID; }
+  std::lock_guard<std::mutex> pl(pass_mtx);
+  bool dirty;
+  {
+    std::lock_guard<std::mutex> lk(mtx);
+    for (int i = 0; i < n; ++i)
+      if (!graphs[i] || !d_bufs[i]) { g_last_error = "batched pass: a slot of the batch is empty"; return SLIDE_ERR_INVALID; }
+    dirty = pass_dirty;
+    pass_dirty = false;
+  }
   if (!master) {
     SL_HIP(hipStreamCreateWithFlags(&master, hipStreamNonBlocking));
     SL_HIP(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
   }
-  bool same = pass_exec != nullptr && (int)pass_G.size() == n;
+  bool same = !dirty && pass_exec != nullptr && (int)pass_G.size() == n;
   for (int i = 0; i < n; ++i) {
     HostGraph* g = graphs[i];
     std::lock_guard<std::mutex> gl(g->mtx);
@@ -553,11 +612,10 @@ int CholBatch::pass_all(double* const* d_bufs) {
   for (int i = 0; i < n; ++i) SL_HIP(hipMemcpyAsync(st[i], graphs[i]->G.status, 8 * sizeof(int), hipMemcpyDeviceToHost, master));
   SL_HIP(hipStreamSynchronize(master));
   SL_HIP(hipGetLastError());
-  for (int i = 0; i < n; ++i)
-    if (st[i][0] || st[i][1]) {
-      g_last_error = st[i][0] ? "landmark block not positive definite" : "reduced pose system not positive definite";
-      return SLIDE_ERR_NOT_SPD;
-    }
+  for (int i = 0; i < n; ++i) {
+    const int rc = decode_status(st[i]);
+    if (rc != SLIDE_OK) return rc;
+  }
   return SLIDE_OK;
 }
 
@@ -565,7 +623,7 @@ int HostGraph::factor_and_solve(hipStream_t s) {
   if (batch) return batch->factor_solve(batch_slot, G, s);
   for (int k = 0; k < G.T; ++k)
     launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, s);
-  launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, s);
+  launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, G.status, s);
   launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, s);
   return SLIDE_OK;
 }
@@ -832,7 +890,7 @@ int HostGraph::enqueue_iteration(bool lookahead) {
   (void)lookahead;
   for (int k = 0; k < G.T; ++k)
     STAGE(5, launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, s));
-  STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, s));
+  STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, G.status, s));
   STAGE(8, launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, s));
   STAGE(9, launch_backsub(G, 0, s));
   STAGE(10, launch_estimate(G, s));
@@ -886,9 +944,9 @@ int HostGraph::run_update(double relin_thr, int iterations) {
   if (prof.on) prof.collect();
   last_relin = st[2];
   factor_valid = false;
-  if (st[0] || st[1]) {
-    g_last_error = st[0] ? "landmark block not positive definite" : "reduced pose system not positive definite";
-    return SLIDE_ERR_NOT_SPD;
+  {
+    const int rc = decode_status(st);
+    if (rc != SLIDE_OK) return rc;
   }
   factor_valid = true;
   return SLIDE_OK;
@@ -1010,11 +1068,7 @@ int HostGraph::dist_phase(int phase, double* d_buf) {
       SL_HIP(hipMemcpyAsync(st, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
       SL_HIP(hipStreamSynchronize(s));
       SL_HIP(hipGetLastError());
-      if (st[0] || st[1]) {
-        g_last_error = st[0] ? "landmark block not positive definite" : "reduced pose system not positive definite";
-        return SLIDE_ERR_NOT_SPD;
-      }
-      return SLIDE_OK;
+      return decode_status(st);
     }
   } else if (phase == 10) {
     // commit every variable (theta <- theta (+) delta, delta <- 0), then publish the owners' values
@@ -1066,11 +1120,7 @@ int HostGraph::dist_pass_local(double* d_buf) {
   SL_HIP(hipMemcpyAsync(st, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
   SL_HIP(hipStreamSynchronize(s));
   SL_HIP(hipGetLastError());
-  if (st[0] || st[1]) {
-    g_last_error = st[0] ? "landmark block not positive definite" : "reduced pose system not positive definite";
-    return SLIDE_ERR_NOT_SPD;
-  }
-  return SLIDE_OK;
+  return decode_status(st);
 }
 
 // getPoseCovariance graph.cpp:314-323: marginal covariance of one pose at the linearisation point of the last solve
@@ -1137,5 +1187,6 @@ void HostGraph::stats(int64_t* o) const {
   o[0] = (int64_t)up_P; o[1] = (int64_t)up_L; o[2] = (int64_t)(up_pr + up_bt + up_lf); o[3] = last_relin;
   o[4] = (int64_t)G.T * NB;
 }
+int64_t HostGraph::rejected() const { return n_rejected; }
 
 }  // namespace sl

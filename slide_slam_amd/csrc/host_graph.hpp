@@ -22,6 +22,7 @@ namespace sl {
 
 extern thread_local std::string g_last_error;
 bool hip_ok(hipError_t e, const char* what);
+int decode_status(const int* st8);      // status words of a pass -> SLIDE_OK / SLIDE_ERR_NOT_SPD / SLIDE_ERR_RUNTIME (+ g_last_error)
 #define SL_HIP(x)                                     \
   do {                                                \
     if (!::sl::hip_ok((x), #x)) return SLIDE_ERR_HIP; \
@@ -129,7 +130,10 @@ class CholBatch {
   int n_slots() const { return n; }
   int factor_solve(int slot, const GraphDev& G, hipStream_t s);
   int all_reduce(int slot, double* d_buf, int count, hipStream_t s);     // sum over the joined graphs' buffers, stream-ordered
-  void set_graph(int slot, HostGraph* g) { if (slot >= 0 && slot < n) graphs[slot] = g; }
+  // Ownership: a batch does not own its graphs and a graph does not own its batch.  ~HostGraph leaves its batch (detach), ~CholBatch
+  // sends every joined graph back to its own launches; either invalidates the captured pass.  Lock order: pass_mtx -> graph -> mtx.
+  void set_graph(int slot, HostGraph* g);
+  void detach(HostGraph* g);
   // One distributed pass of ALL joined graphs from one host thread: the phases of every robot on its own stream, forked from and
   // joined to the batch's stream around the two device-side exchanges and the batched factor + solve, captured once and replayed
   // as ONE hipGraph per pass.  bufs[i]: exchange buffer of the graph in slot i.
@@ -138,7 +142,9 @@ class CholBatch {
 
  private:
   int n;
-  std::mutex mtx;
+  std::mutex mtx;                        // rendezvous state + the graphs[] table
+  std::mutex pass_mtx;                   // pass_all / profile_pass (the captured pass and its device tables)
+  bool pass_dirty = false;               // graphs[] changed since the pass was captured (under mtx)
   std::condition_variable cv;
   int arrived = 0;
   unsigned long long generation = 0;
@@ -179,11 +185,7 @@ class HostGraph {
   int add_relative_meas_ghost(const double* rel7, uint64_t idx, int robot, int slot, bool local_first);
   int set_ghosts(const int32_t* own_robot, const int64_t* own_idx, int n_slots);
   int pose_covariance(int robot, uint64_t idx, double* cov36);
-  void join_batch(CholBatch* b, int slot) {
-    if (batch && batch != b) batch->set_graph(batch_slot, nullptr);
-    batch = b; batch_slot = slot;
-    if (b) b->set_graph(slot, this);
-  }
+  void join_batch(CholBatch* b, int slot);      // takes the graph's lock itself (never while the batch's is held the other way round)
   int dist_pass_local(double* d_buf);     // one distributed pass when every robot of the job is in this graph's batch (no host syncs inside)
   int add_point_landmark(uint64_t idx, const double* xyz);
   int add_range_bearing(int robot, uint64_t pose_idx, uint64_t lm_idx, const double* bearing, double range);
@@ -200,6 +202,7 @@ class HostGraph {
   int set_shared(const int32_t* cls, const int64_t* idx, const int32_t* owner, int n_slots);
   int dist_phase(int phase, double* d_buf);
   void stats(int64_t* out5) const;
+  int64_t rejected() const;               // entries merge_pending refused since creation
 
   static uint64_t pose_key(int robot, uint64_t idx);
   static uint64_t lm_key(int cls, uint64_t idx);
@@ -214,6 +217,7 @@ class HostGraph {
 
  private:
   int merge_pending();
+  int64_t n_rejected = 0;                 // factors / variables refused by merge_pending since creation (slide_graph_stats)
   int upload_new();
   int run_update(double relin_thr, int iterations);
   int enqueue_iteration(bool lookahead);      // one GN / iSAM2-equivalent pass on `stream` (+ stream2)

@@ -29,7 +29,7 @@ void launch_ghost_exchange(const GraphDev& G, int what, double* buf, hipStream_t
 // leading dimension ld = (T+1)*NB; the extra row tile carries the right-hand side), tile edge NB = 64.
 // ctr: T + 2 ints, zero before the first factorisation (each step clears the next step's work counter itself)
 void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, hipStream_t s);
-void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, hipStream_t s);
+void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s);   // also clears status[4], the ticket counter of launch_chol_bwd_all
 struct CholSystem { double* S; int ld, T; double* Ld; double* Winv; double* yv; double* dp; int* status; };
 void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps = nullptr);            // up to 8 systems, one launch per block column
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp, int* status, hipStream_t s);

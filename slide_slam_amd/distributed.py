@@ -30,6 +30,16 @@ import numpy as np
 CLASS_THRESH = {0: "cylinder_match_thresh", 1: "cuboid_match_thresh", 2: "ellipsoid_match_thresh"}
 
 
+def gpu_matcher(cls, xyz, lab, gxyz, glab, thresh):
+    """The cross-robot merge's matcher on the device: the stand-alone HIP matchers of the C-ABI (sloam::match*Models rule,
+    sloam.cpp:73-203).  Cylinders exchange their roots only; vertical rays reproduce the matcher's point-at-height rule."""
+    from . import api as s
+    if cls == 0:
+        n, m = len(lab), len(glab)
+        return s.match_cylinders(xyz, np.tile([0.0, 0.0, 1.0], (n, 1)), lab, gxyz, np.tile([0.0, 0.0, 1.0], (m, 1)), glab, thresh)
+    return s.match_boxes(cls, xyz, lab, gxyz, glab, thresh)
+
+
 def associate_global(tables, thresh=(2.0, 2.0, 0.75), matcher=None):
     """Deterministic cross-robot landmark association, identical on every rank.
 

@@ -30,12 +30,7 @@ def oracle_matcher(cls, xyz, lab, gxyz, glab, thresh):
     return out[:n]
 
 
-def gpu_matcher(cls, xyz, lab, gxyz, glab, thresh):
-    import slide_slam_amd as s
-    if cls == 0:
-        n, m = len(lab), len(glab)
-        return s.match_cylinders(xyz, np.tile([0.0, 0.0, 1.0], (n, 1)), lab, gxyz, np.tile([0.0, 0.0, 1.0], (m, 1)), glab, thresh)
-    return s.match_boxes(cls, xyz, lab, gxyz, glab, thresh)
+from slide_slam_amd.distributed import gpu_matcher      # noqa: E402  (the product's matcher; re-exported for the tests)
 
 
 def main_threads(R):

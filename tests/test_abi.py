@@ -186,3 +186,47 @@ def test_in_loop_closure_region_matches_oracle():
         assert got == bool(ref)
         hits += int(got)
     assert 10 < hits < 190
+
+
+def test_loop_candidate_idx_matches_oracle():
+    """CylinderMapManager::getLoopCandidateIdx (cylinderMapManager.cpp:160-184): product (host code) vs the oracle's
+    sort-then-scan restatement, incl. the < 50 poses gate, the 'older than' rule, exact distance ties (by index) and the
+    reference's size_t wrap-around for an index above pose_idx."""
+    import ctypes as C
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(12)
+
+    def oracle(cloud, max_dist, pose_idx, at_least):
+        cand = C.c_uint64(0)
+        c32 = np.ascontiguousarray(cloud.reshape(-1))
+        ok = po.lib().orc_loop_candidate_idx(c32.ctypes.data_as(C.c_void_p), C.c_int(len(cloud)), C.c_double(max_dist),
+                                             C.c_uint64(pose_idx), C.c_uint64(at_least), C.byref(cand))
+        return int(cand.value) if ok else None
+    found = 0
+    for trial in range(300):
+        n = int(rng.integers(40, 400))
+        # a loopy walk, so that old poses come back into range
+        t = np.linspace(0, rng.uniform(2, 9), n)
+        cloud = np.column_stack([20 * np.cos(t), 20 * np.sin(t), 0.1 * t]).astype(np.float32)
+        cloud += rng.normal(0, 0.3, cloud.shape).astype(np.float32)
+        if trial % 7 == 0:
+            cloud[n // 3] = cloud[n // 4]          # exactly equidistant neighbours
+        pose_idx = n - 1 if trial % 3 else int(rng.integers(0, n))
+        got = s.loop_candidate_idx(cloud, 5.0, pose_idx, 30)
+        assert got == oracle(cloud, 5.0, pose_idx, 30), (trial, n, pose_idx)
+        if n < 50:
+            assert got is None
+        found += got is not None
+    assert 30 < found < 290
+    # size_t wrap-around: from pose 10 of 60, pose 11 (a LATER pose, 0.1 m away) qualifies in the reference
+    line = np.column_stack([0.1 * np.arange(60), np.zeros(60), np.zeros(60)]).astype(np.float32)
+    assert s.loop_candidate_idx(line, 0.15, 10, 30) == 11 == oracle(line, 0.15, 10, 30)
+    with pytest.raises(s.SlideError):
+        s.loop_candidate_idx(line, 1.0, 60, 30)
+
+
+def test_merge_refuses_unknown_keys_loudly():
+    """a factor on a key that is in neither the graph nor the pending values is refused with an error (isam->update throws
+    there), not dropped silently.  Host logic up to the upload, which needs a device: without one the call fails earlier with
+    SLIDE_ERR_HIP, so only the symbol / counter plumbing is checked here; the behaviour itself is tested under -m gpu."""
+    assert "slide_graph_rejected_count" in s.api.EXPORTS

@@ -65,6 +65,24 @@ def test_small_graph_matches_oracle(gpu, chart):
     assert st["n_pose"] == 4 and st["n_lm"] == 4
 
 
+@pytest.mark.parametrize("chart", [0, 1])
+def test_cube_factor_graph_known_answer_gpu(gpu, chart):
+    """The reference-held FactorGraph scenario (src/test/deprecated/cube_factor_test.cpp:229-260) through the product: the
+    optimised cube scale equals the analytic weighted mean (1e-9), the oracle (1e-9) and the reference's 0.1 within 1e-4 (why not
+    1e-5: tests/test_oracle_pins.py::test_cube_factor_graph_known_answer)."""
+    from test_oracle_pins import cube_factor_graph_expected, cube_factor_graph_scenario
+    og = po.OracleGraph(po.OrcParams.default(pose_chart=chart))
+    gg = gpu.SlideGraph(gpu.default_params(pose_chart=chart))
+    so, cube_t = cube_factor_graph_scenario(og, chart)
+    sg, _ = cube_factor_graph_scenario(gg, chart)
+    e2, e3 = cube_factor_graph_expected(cube_t)
+    assert np.allclose(sg[0], e2, atol=1e-9, rtol=0) and np.allclose(sg[1], e3, atol=1e-9, rtol=0)
+    assert np.allclose(sg[0], so[0], atol=1e-9, rtol=0) and np.allclose(sg[1], so[1], atol=1e-9, rtol=0)
+    assert abs(sg[1][0] - 0.1) < 1e-4
+    for k in range(3):
+        assert _rel_err(gg.get_pose12(0, k)[1], og.get_pose12(0, k)[1]) < 1e-9
+
+
 def test_missing_keys(gpu):
     gg = gpu.SlideGraph(gpu.default_params())
     gg.set_prior(0, np.array([0, 0, 0, 0, 0, 0, 1.0]))

@@ -91,6 +91,50 @@ def test_find_inter_loop_closure_recovers_transform(gpu):
     assert abs(g["xyzyaw"][3] - 0.35) < np.deg2rad(3) and np.allclose(g["xyzyaw"][:2], [2.5, -1.75], atol=0.5)
 
 
+def _quat_z(yaw):
+    return np.array([0, 0, np.sin(yaw / 2), np.cos(yaw / 2)])
+
+
+@pytest.mark.parametrize("use_lsq", [1, 0])
+def test_find_intra_loop_closure_matches_oracle(gpu, use_lsq):
+    """PlaceRecognition::findIntraLoopClosure (place_recognition.cpp:389-496): a submap around an old key pose, the same objects
+    detected again from a query pose that has DRIFTED by (0.8, -0.6) m and 4 deg — product vs oracle (identical inliers, transform to
+    1e-9), and the recovered correction undoes the drift."""
+    rng = np.random.default_rng(5)
+    n = 45
+    submap = np.zeros((n, 7))
+    submap[:, 0] = rng.integers(1, 4, n)
+    submap[:, 1:3] = rng.uniform(-12, 12, (n, 2)) + np.array([30.0, 10.0])
+    submap[:, 3] = rng.normal(0, 0.2, n)
+    submap[:, 4:7] = rng.uniform(0.3, 2.0, (n, 3))
+    true_q = np.concatenate([[31.0, 9.0, 1.0], _quat_z(0.6)])
+    drift_q = np.concatenate([[31.8, 8.4, 1.0], _quat_z(0.6 + np.deg2rad(4.0))])
+    cand = np.concatenate([[29.0, 11.0, 1.0], _quat_z(-0.2)])
+    # detections in the TRUE local frame of the query pose
+    c, s_ = np.cos(0.6), np.sin(0.6)
+    Rq = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]])
+    seen = rng.permutation(n)[:30]
+    meas = submap[seen].copy()
+    meas[:, 1:4] = (submap[seen, 1:4] - true_q[:3]) @ Rq + rng.normal(0, 0.03, (30, 3))
+    gp, op = _both_params(gpu, search_yaw_step_size=np.deg2rad(1.0), ignore_dimension=1, use_nonlinear_least_squares=use_lsq,
+                          search_xy_step_size=0.25)
+    g = gpu.find_intra_loop_closure(meas, submap, drift_q, cand, gp)
+    tf = np.zeros(16); inl = C.c_int(0); xyz = np.zeros(4)
+    ok = po.lib().orc_find_intra_loop_closure(_p(np.ascontiguousarray(meas)), C.c_int(len(meas)), _p(np.ascontiguousarray(submap)),
+                                              C.c_int(n), _p(drift_q), _p(cand), C.byref(op), C.c_double(5.0), C.c_double(5.0),
+                                              C.c_double(np.deg2rad(10.0)), _p(tf), C.byref(inl), _p(xyz))
+    assert g["found"] and ok == 1
+    assert g["inliers"] == inl.value >= 20
+    assert np.allclose(g["xyzyaw"], xyz, atol=1e-9) and np.allclose(g["tf"], tf.reshape(4, 4), atol=1e-9)
+    # guards of :396-405: empty inputs and fewer than four detections are "not found", not errors
+    assert not gpu.find_intra_loop_closure(meas[:3], submap, drift_q, cand, gp)["found"]
+    assert not gpu.find_intra_loop_closure(meas[:0], submap, drift_q, cand, gp)["found"]
+    assert not gpu.find_intra_loop_closure(meas, submap[:0], drift_q, cand, gp)["found"]
+    if use_lsq:
+        # the correction maps drifted-frame map coordinates onto the map: yaw ~ -4 deg
+        assert abs(g["xyzyaw"][3] + np.deg2rad(4.0)) < np.deg2rad(1.0)
+
+
 def test_clipper_affinity_matches_golden_and_oracle(gpu):
     import sys
     sys.path.insert(0, HERE)

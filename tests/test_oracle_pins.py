@@ -2,7 +2,8 @@
 path.  The cases are transcribed as DATA from the reference's test files:
   clipper_semantic_object/test/affinity_test.cpp:33-107, clipper_test.cpp:14-67,
   backend/sloam/src/test/sloam_test.cpp:20-205, utils_test.cpp:4-25,
-  src/test/deprecated/cube_factor_test.cpp:156-227 (non-building upstream; identities transcribed by hand).
+  src/test/deprecated/cube_factor_test.cpp:156-260 (non-building upstream; identities, the Retract vector and the
+  FactorGraph scenario transcribed by hand).
 The GTSAM boundary itself (ISAM2, BetweenFactor, BearingRangeFactor, numericalDerivative) is pinned by NO
 reference test -> 'parity unpinned' there (oracle headers)."""
 import ctypes as C
@@ -183,6 +184,87 @@ def test_cube_measurement_identities():
     L.orc_pose_logmap(_p(out[:12].copy()), _p(la)); L.orc_pose_logmap(_p(out_c[:12].copy()), _p(lb))
     assert np.abs(la - lb).max() < 0.01
     assert np.allclose(out_c[12:], 1e-3)
+
+
+def retract_vector_unscaled(chart):
+    """deprecated/cube_factor_test.cpp:201-227 AS WRITTEN: cube pose = Expmap(0.5, 0.8, 0.3, 100, 12, 10.5), scale (2, 3.5, 0.5);
+    v = (1.8, 0.2, 1.0, 30, 100, 2.5, 1, 1, 1); expectation Logmap(retract(v).pose) == Logmap(pose * Expmap(v[0:6])) within
+    0.01 per coordinate and scale + 1 within 0.01.  Returns (max |Logmap difference|, max |scale difference|)."""
+    L = po.lib()
+    xi0 = np.array([0.5, 0.8, 0.3, 100.0, 12.0, 10.5])
+    pose = np.zeros(12); L.orc_pose_expmap(_p(xi0), _p(pose))
+    m15 = np.concatenate([pose, [2.0, 3.5, 0.5]])
+    v = np.array([1.8, 0.2, 1.0, 30.0, 100.0, 2.5, 1.0, 1.0, 1.0])
+    out = np.zeros(15)
+    L.orc_cube_retract(_p(m15), _p(v), C.c_int(chart), _p(out))
+    ex = np.zeros(12); L.orc_pose_expmap(_p(np.ascontiguousarray(v[:6])), _p(ex))
+    comp = np.zeros(12); L.orc_pose_compose(_p(pose), _p(ex), _p(comp))
+    la, lb = np.zeros(6), np.zeros(6)
+    L.orc_pose_logmap(_p(comp), _p(la)); L.orc_pose_logmap(_p(out[:12].copy()), _p(lb))
+    return float(np.abs(la - lb).max()), float(np.abs(out[12:] - (m15[12:] + 1.0)).max())
+
+
+def test_cube_retract_reference_vector_unscaled_both_charts():
+    """The only chart evidence the reference tree holds (cube_factor_test.cpp:201-227, |omega| ~ 2 rad, tolerance 0.01), run
+    UNSCALED under both charts.  Recorded outcome: the Expmap chart passes (it is the identity the test writes
+    down), the Cayley chart — the default here, named by the reference's own comment cubeFactor.h:96-97 — misses by far more than
+    0.01.  That test is under src/test/deprecated/ and is not built (CMakeLists.txt), so it cannot decide which chart the shipped
+    GTSAM build uses; both stay selectable (SLIDE_CHART_*)."""
+    d_exp, s_exp = retract_vector_unscaled(po.CHART_EXPMAP)
+    d_cay, s_cay = retract_vector_unscaled(po.CHART_CAYLEY)
+    assert d_exp < 1e-9 and s_exp < 1e-12                  # passes the reference's 0.01 with all the margin there is
+    assert d_cay > 0.01 and s_cay < 1e-12                  # would FAIL the reference's expectation: recorded, not hidden
+
+
+def cube_factor_graph_scenario(G, chart=0):
+    """deprecated/cube_factor_test.cpp:229-260 (TEST_F FactorGraph), transcribed: prior on pose A; two addKeyPoseAndBetween calls
+    whose relativeMotion arguments are poseA / poseB and whose estimates are poseB / poseC (as written there); one cube at
+    Expmap(0.5, 0.8, 0.3, 100, 12, 10.5) observed from the three poses with scales 0.1 / 0.15 / 0.05; solve() after the second and
+    after the third observation.  G: any object with the SemanticFactorGraph seam (oracle or product).  Returns the optimised
+    scale after each solve."""
+    L = po.lib()
+    xi0 = np.array([0.5, 0.8, 0.3, 100.0, 12.0, 10.5])
+    pose = np.zeros(12); L.orc_pose_expmap(_p(xi0), _p(pose))
+    cube7 = np.zeros(7); L.orc_pose12_to7(_p(pose), _p(cube7))
+    A = np.array([0, 0, 0, 0, 0, 0, 1.0]); B = A.copy(); B[0] = 0.1; Cc = A.copy(); Cc[0] = -0.1
+    G.set_prior(0, A)
+    G.add_keypose_between(0, 0, 1, A, B)
+    G.add_keypose_between(0, 1, 2, B, Cc)
+    G.add_cube(0, 0, 0, A, cube7, [0.1] * 3, False)
+    G.add_cube(0, 1, 0, B, cube7, [0.15] * 3, True)
+    out = []
+    assert G.solve() == 0
+    out.append(G.get_landmark(1, 0)[1][12:15].copy())
+    G.add_cube(0, 2, 0, Cc, cube7, [0.05] * 3, True)
+    assert G.solve() == 0
+    out.append(G.get_landmark(1, 0)[1][12:15].copy())
+    return out, pose[9:12].copy()
+
+
+def cube_factor_graph_expected(cube_t):
+    """The scale rows of a cube factor are linear and decoupled from every pose (cubeFactor.h:46-87: m.scale - q.scale), so the
+    optimum is the mean of the measured scales weighted by 1 / sigma^2 with sigma = noise_model_cube_vec * max(|t_cube_local|, 0.1)
+    (graph.cpp:213-218)."""
+    d = np.array([np.linalg.norm(cube_t - np.array([x, 0, 0])) for x in (0.0, 0.1, -0.1)])
+    w = 1.0 / np.maximum(d, 0.1) ** 2
+    s = np.array([0.1, 0.15, 0.05])
+    return (w[:2] * s[:2]).sum() / w[:2].sum(), (w * s).sum() / w.sum()
+
+
+@pytest.mark.parametrize("chart", [po.CHART_CAYLEY, po.CHART_EXPMAP])
+def test_cube_factor_graph_known_answer(chart):
+    """The one reference-held end-to-end answer for cube factor + solve(): `getCube(0).scale[0] == 0.1 +- 1e-5`
+    (cube_factor_test.cpp:260).  With the distance-proportional cube noise of the CURRENT graph.cpp:213-218 the three
+    observations (|t_local| = 98.80 / 98.71 / 98.89 m) no longer weigh the same, and the exact optimum is the weighted mean
+    0.1000626 — 6.3e-5 from 0.1: the deprecated test (not built, CMakeLists.txt) predates the noise shaping and its 1e-5 cannot
+    hold against the shipped code.  Pinned here: the analytic optimum to 1e-9 and the reference's number to 1e-4."""
+    G = po.OracleGraph(po.OrcParams.default(pose_chart=chart))
+    scales, cube_t = cube_factor_graph_scenario(G, chart)
+    e2, e3 = cube_factor_graph_expected(cube_t)
+    assert np.allclose(scales[0], e2, atol=1e-9, rtol=0)
+    assert np.allclose(scales[1], e3, atol=1e-9, rtol=0)
+    assert abs(scales[1][0] - 0.1) < 1e-4
+    assert abs(e3 - 0.1000625857) < 1e-9
 
 
 def test_lie_identities():
