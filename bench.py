@@ -8,11 +8,18 @@ landmarks and retract — i.e. one Gauss-Newton iteration = one pose-graph updat
 
 Workload (BASELINE.json configs[3]): the 8-robot / 10 k-landmark / 5 k-pose synthetic graph, one sub-graph per robot (625 poses,
 ~1250 landmarks, ~12.5 k landmark factors each), 8 / N robots per GPU — the SAME graph at N = 1, 2, 4, 8 (strong scaling).
-Robots that share a GPU run on concurrent HIP streams (one host thread each); a step = one distributed Gauss-Newton pass of all
-eight robots, value = robot pose-graph updates/s = 8 * steps / time.  `--robots-per-gpu 1` is the weak-scaling variant (one robot
-per GPU at every N).  Inputs are resident in HBM before the timed region.  Synthetic, seeded data (slide_slam_amd/synth.py).
+All robots of a GPU sit in one CholBatch and ONE host thread drives the pass: at N = 1 the whole pass of all eight robots is one
+replayed hipGraph; at N > 1 it is three replayed parts with the two shared-landmark all-reduces (RCCL over xGMI) issued on the
+same HIP stream between them — one host synchronisation per pass.  value = robot pose-graph updates/s = 8 * steps / time.
+`--robots-per-gpu 1` is the weak-scaling variant (one robot per GPU at every N).  Inputs are resident in HBM before the timed
+region.  Synthetic, seeded data (slide_slam_amd/synth.py).
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--robots-per-gpu R] [--no-cpu] [--frames F] [--ingest-only]
+After the timed region the bench (a) re-runs the same number of passes on identically built shards through the UN-batched path
+(one dist_phase call per robot and phase, host-side sums) and reports the largest relative pose difference (`parity`; exit code 1
+when it is not finite or above 1e-6), (b) reports how many passes the block-Jacobi iteration needed to come within 1e-4 of its
+fixed point (`convergence`), (c) times the association sweep (`roofline.assoc`, HBM) and the CPU restatement beside it.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--robots-per-gpu R] [--no-cpu] [--frames F] [--ingest-only] [--no-parity]
 Multi-GPU: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
 """
 from __future__ import annotations
@@ -21,6 +28,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -29,20 +37,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak, public spec (MI355X_MICROARCH.md lists no f64 row)
-HBM_PEAK_GBS = 8000.0
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-def build_graph(s, data, robot_log_idx, frames=None, ingest_only=False):
+def build_shard(s, log, frames=None, ingest_only=False):
     """Stream one robot's frame log through the per-frame path (association + add + iSAM2-equivalent update).
     ingest_only (profiling aid): add every frame without solving (association against the un-refined map at the ground-truth
     poses, as the cpu_baseline leg does), then one solve — every k_chol_step launch of the run is then full-size."""
     from slide_slam_amd.replay import replay_single
     gb = s.SlideBackend(s.default_params(), 1)
     if not ingest_only:
-        out = replay_single(gb, data["logs"][robot_log_idx], n_frames=frames, collect=False)
+        out = replay_single(gb, log, n_frames=frames, collect=False)
         return gb, out
     from slide_slam_amd.synth import frame_detections
-    log = data["logs"][robot_log_idx]
     P = len(log["rel7"]) if frames is None else frames
     t_frame = []
     for k in range(P):
@@ -54,163 +61,138 @@ def build_graph(s, data, robot_log_idx, frames=None, ingest_only=False):
     return gb, dict(t_frame=t_frame)
 
 
-def cpu_baseline(data, robot_log_idx, frames, threads):
-    """The oracle (CPU restatement, C++ -O3 -march=native, `threads` OpenMP threads) timed on the same graph:
-    all frames are ingested without solving (association against the un-refined map), then full
-    linearise + Schur + Cholesky + back-substitution passes (threshold 0) are timed for about 12 s; median."""
-    from oracle import pyoracle as po
+def all_poses(gb, P):
+    return np.array([gb.graph.get_pose12(0, k)[1] for k in range(P)])
+
+
+def _oracle_shard(L, po, log, frames, threads):
     from slide_slam_amd.synth import frame_detections
-    L = po.lib(native=True)
     ob = po.OracleBackend(po.OrcParams.default(num_threads=threads), 1, L=L)
-    log = data["logs"][robot_log_idx]
     P = len(log["rel7"]) if frames is None else frames
-    gt = log["gt7"]
     for k in range(P):
-        ob.process_frame(0, log["rel7"][k], gt[k], frame_detections(log, k), 2)
+        ob.process_frame(0, log["rel7"][k], log["gt7"][k], frame_detections(log, k), 2)
     ob.graph.set_relin_threshold(0.0)
-    times = []
-    t_start = time.perf_counter()
-    while len(times) < 2 or (time.perf_counter() - t_start < 12.0 and len(times) < 60):     # bounded: about 12 s of CPU work
+    return ob
+
+
+def _time_iters(ob, budget_s, cap=40):
+    times, t_start = [], time.perf_counter()
+    while len(times) < 2 or (time.perf_counter() - t_start < budget_s and len(times) < cap):
         t0 = time.perf_counter()
-        st = ob.ingest_solve()
-        times.append(time.perf_counter() - t0)
-        if st != 0:
+        if ob.ingest_solve() != 0:
             raise RuntimeError("oracle solve failed")
-    stats = ob.graph.stats()
-    per_iter = float(np.median(times))
-    return dict(value=1.0 / per_iter, unit="pose-graph updates/s", cores=threads, kind="port",
-                sample=f"{len(times)} full Gauss-Newton iterations (about 12 s) of the same {stats['n_pose']}-pose / {stats['n_lm']}-landmark / "
-                       f"{stats['n_factors']}-factor graph (oracle = CPU restatement of the reference, not GTSAM), median",
-                ms_per_iter=per_iter * 1e3, t_linearize_s=stats["t_linearize"], t_schur_s=stats["t_schur"],
-                t_chol_s=stats["t_chol"])
+        times.append(time.perf_counter() - t0)
+    return times
 
 
-def run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend):
-    """--robots-per-gpu R > 1: R robot shards per process, one thread and one HIP stream each, exchanging through
-    ThreadGroup (local sum, then RCCL across processes).  With R = 8 / N this is BASELINE's "8-robot graph at 1/2/4/8 GPUs"
-    (total work fixed); a step = one distributed Gauss-Newton pass of all robots."""
-    import threading
-    from slide_slam_amd.distributed import DistributedGraph, ThreadGroup, TorchComm, gpu_matcher
-    from slide_slam_amd.synth import SynthConfig, make_robot_log, make_world
-    cfg = SynthConfig.preset(args.preset)
-    world_map = make_world(cfg)
-    device = torch.device("cuda", dev_index)
-    base = TorchComm(device=device, stage_through_host=(backend != "nccl")) if world > 1 else None
-    group = ThreadGroup(R, base=base, rank=rank, world=world)
-    sync = threading.Barrier(R + 1)
-    conc = int(os.environ.get("SLIDE_BENCH_CONCURRENCY", "0"))
-    sem = threading.Semaphore(conc) if conc > 0 else None
-    # one launch sequence for the factorisations of all local robots pays off from about eight robots per GPU on (measured: 2 / 4 /
-    # 8 robots 1.91 / 3.32 / 6.10 ms per pass batched, 1.78 / 3.03 / 6.92 ms on independent streams); SLIDE_BENCH_BATCH=0|1 forces
-    use_batch = os.environ.get("SLIDE_BENCH_BATCH", "1" if R > 4 else "0") == "1"
-    batch = s.CholBatch(R) if use_batch else None
-    timing = [None]
-    batched_prof = [None]
-    bufs = [None] * R
-    one_driver = batch is not None and world == 1 and os.environ.get("SLIDE_BENCH_ONE_DRIVER", "1") == "1"
-    shards, infos, reps, errs = [None] * R, [None] * R, [None] * R, []
+def cpu_baselines(logs, frames, budget_s=10.0):
+    """The oracle (CPU restatement of the reference, C++ -O3 -march=native; NOT GTSAM) timed on the same graph on this box's
+    host cores.  Every shard ingests its frames without solving (association against the un-refined map), then full
+    linearise + Schur + Cholesky + back-substitution passes (threshold 0) are timed.  Three variants:
+      robots_as_threads  the job's robots as independent host threads, one core each ("one sloam_node per robot on one PC",
+                         README.md:238 of the reference) — the whole-job figure that stands beside `value`;
+      single_thread      one robot's shard on one core (the reference's runSLOAMNode is single-threaded);
+      omp                one robot's shard with OpenMP over all cores (the best this restatement can do for one robot)."""
+    from oracle import pyoracle as po
+    L = po.lib(native=True)
+    ncpu = os.cpu_count() or 1
+    out = {}
+    ob = _oracle_shard(L, po, logs[0], frames, 1)
+    times = _time_iters(ob, budget_s)
+    st = ob.graph.stats()
+    desc = f"{st['n_pose']}-pose / {st['n_lm']}-landmark / {st['n_factors']}-factor robot sub-graph"
+    it1 = float(np.median(times))
+    out["single_thread"] = dict(value=1.0 / it1, unit="pose-graph updates/s", cores=1, kind="port", ms_per_iter=it1 * 1e3,
+                                sample=f"{len(times)} full Gauss-Newton iterations (about {budget_s:.0f} s) of one {desc}, median",
+                                t_linearize_s=st["t_linearize"], t_schur_s=st["t_schur"], t_chol_s=st["t_chol"])
+    del ob
+    thr = min(ncpu, 16)
+    ob = _oracle_shard(L, po, logs[0], frames, thr)
+    times = _time_iters(ob, 0.5 * budget_s)
+    itn = float(np.median(times))
+    out["omp"] = dict(value=1.0 / itn, unit="pose-graph updates/s", cores=thr, kind="port", ms_per_iter=itn * 1e3,
+                      sample=f"{len(times)} full Gauss-Newton iterations of one {desc}, {thr} OpenMP threads, median")
+    del ob
+    # the robots as independent threads, one core each (ctypes releases the GIL inside the oracle)
+    R = min(len(logs), ncpu)
+    shards = [_oracle_shard(L, po, logs[r], frames, 1) for r in range(R)]
+    iters = min(max(2, int(budget_s / max(it1, 1e-3))), 8)
+    err = []
 
-    def work(t):
+    def work(ob):
         try:
-            torch.cuda.set_device(dev_index)
-            robot = (rank * R + t) % cfg.robots
-            data = dict(cfg=cfg, world=world_map, logs={robot: make_robot_log(cfg, world_map, robot)})
-            gb, reps[t] = build_graph(s, data, robot, args.frames, args.ingest_only)
-            if sem is not None:        # diagnostic: at most SLIDE_BENCH_CONCURRENCY shards inside a phase at a time
-                orig = gb.graph.dist_phase
-
-                def limited(ph, buf, orig=orig):
-                    with sem:
-                        return orig(ph, buf)
-                gb.graph.dist_phase = limited
-            dg = DistributedGraph(gb, group.comm(t, device), rank * R + t, world * R)
-            infos[t] = dg.setup(gpu_matcher)
-            shards[t] = gb
-            if batch is not None:      # the dense factor + solve of all local robots as one launch sequence per pass
-                gb.graph.join_chol_batch(batch, t)
-                dg.local_batch = world == 1     # all robots of the job on this GPU: exchanges as device-side sums, one sync per pass
-                bufs[t] = dg.buf
-            if one_driver:
-                # the whole pass of all robots is one captured graph replayed by the main thread (slide_chol_batch_pass)
-                sync.wait()          # ready
-                sync.wait()          # main thread is through
-                gb.graph.join_chol_batch(None)
-                return
-            for _ in range(args.warmup):
-                dg.gauss_newton(1)
-            if t == 0 and os.environ.get("SLIDE_BENCH_TIMING") == "1":      # diagnostic: wall time per call of the pass, thread 0
-                acc = {}
-                def timed(name, fn):
-                    def w(*a):
-                        t0 = time.perf_counter(); r = fn(*a); acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0; return r
-                    return w
-                orig_phase = gb.graph.dist_phase
-                gb.graph.dist_phase = lambda ph, buf: timed(f"phase{ph}", orig_phase)(ph, buf)
-                dg.comm.all_reduce = timed("all_reduce", dg.comm.all_reduce)
-                timing[0] = acc
-            sync.wait()          # warm-up done
-            sync.wait()          # go
-            for _ in range(args.steps):
-                dg.gauss_newton(1)
-            sync.wait()          # done
-            if batch is not None:
-                gb.graph.join_chol_batch(None)
-        except BaseException as e:
-            errs.append(e)
-            group.barrier.abort()
-            sync.abort()
-
-    th = [threading.Thread(target=work, args=(t,)) for t in range(R)]
+            for _ in range(iters):
+                if ob.ingest_solve() != 0:
+                    raise RuntimeError("oracle solve failed")
+        except BaseException as e:      # noqa: BLE001
+            err.append(e)
+    th = [threading.Thread(target=work, args=(ob,), daemon=True) for ob in shards]
+    t0 = time.perf_counter()
     for x in th:
         x.start()
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    try:
-        if one_driver:
-            sync.wait()          # every robot built, associated and joined
-            ptrs = [b.data_ptr() for b in bufs]
-            for _ in range(args.warmup):
-                batch.pass_all(ptrs)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                batch.pass_all(ptrs)
-            barrier()
-            dt = time.perf_counter() - t0
-            # device time of the batched step kernels (HIP events on the batch's stream, un-captured passes) for the roofline
-            pr = sorted(batch.profile(ptrs) for _ in range(5))
-            batched_prof[0] = dict(ms_steps=pr[len(pr) // 2][0], launches=pr[0][1])
-            sync.wait()
-        else:
-            sync.wait()
-            barrier()
-            t0 = time.perf_counter()
-            sync.wait()
-            sync.wait()
-            barrier()
-            dt = time.perf_counter() - t0
-    except threading.BrokenBarrierError:
-        dt = float("nan")
     for x in th:
         x.join()
-    if errs:
-        raise errs[0]
-    if timing[0] and rank == 0:
-        sys.stderr.write("per-pass wall ms (thread 0): " + ", ".join(f"{k} {v / args.steps * 1e3:.3f}" for k, v in sorted(timing[0].items())) + "\n")
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    infos[0]["mode"] = ("one replayed hipGraph per pass, factorisations batched" if one_driver else
-                        ("factorisations batched, one host thread per robot" if batch is not None else "concurrent HIP streams, one host thread per robot"))
-    if batched_prof[0]:
-        infos[0]["batched"] = dict(batched_prof[0], robots=R)
-    return dt, shards[0], reps[0], infos[0]
+    wall = time.perf_counter() - t0
+    if err:
+        raise err[0]
+    out["robots_as_threads"] = dict(value=R * iters / wall, unit="pose-graph updates/s", cores=R, kind="port",
+                                    ms_per_iter=wall / iters * 1e3,
+                                    sample=f"{R} robot sub-graphs ({desc} each) as {R} host threads with one core each, {iters} full "
+                                           f"Gauss-Newton iterations per robot ({wall:.1f} s)")
+    return out
+
+
+def assoc_roofline(s, n_map=10000, K=1000, n_obs=20, n_query=8192, repeats=5):
+    """Association sweep (getSubmap K-NN gate + matchEllipsoidModels) at the headline sizes, batched over query frames against one
+    resident map: algorithmic bytes per frame = 12 N_map + 28 K_eff + 36 N_obs over the device time per frame
+    (HIP events on the launch stream around `repeats` launches on resident inputs)."""
+    rng = np.random.default_rng(2024)
+    model = np.column_stack([rng.uniform(0, 440, n_map), rng.uniform(0, 220, n_map), rng.normal(0, 0.3, n_map)])
+    cloud = (model + rng.normal(0, 0.05, model.shape)).astype(np.float32)
+    label = rng.integers(1, 7, n_map).astype(np.int32)
+    # every query frame: a robot position next to a random landmark, detections = noisy copies of random landmarks near it
+    pick = rng.integers(0, n_map, (n_query, n_obs))
+    qpos = np.column_stack([model[pick[:, 0], :2] + rng.normal(0, 3.0, (n_query, 2)), np.full(n_query, 2.0)])
+    obs = model[pick] + rng.normal(0, 0.1, (n_query, n_obs, 3))
+    olab = label[pick]
+    out, ms = s.assoc_sweep_batch(cloud, model, label, qpos, obs, olab, K, 0.75, repeats=repeats)
+    k_eff = min(K, n_map)
+    bytes_per_frame = 12 * n_map + 28 * k_eff + 36 * n_obs
+    per_launch_s = ms * 1e-3 / repeats
+    ach = bytes_per_frame * n_query / per_launch_s / 1e9
+    return {"bound": "hbm", "kernel": "k_assoc_sweep (float32 K-NN scan + radix K-select + label-gated nearest neighbour)",
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "bytes_per_frame": bytes_per_frame, "frames_per_launch": n_query, "avg_launch_ms": per_launch_s * 1e3,
+            "frames_per_s": n_query / per_launch_s, "matched_fraction": float((out >= 0).mean()),
+            "traffic": _pmc_traffic("k_assoc_sweep"),
+            "config": {"n_map": n_map, "K": K, "n_obs": n_obs, "n_query": n_query},
+            "note": "algorithmic bytes: every frame is charged the whole float32 cloud although the 120 KB map stays in L2 / "
+                    "Infinity Cache across the frames of a launch (SURVEY.md 8d caveat); traffic = HBM-side bytes per launch (PMC)"}
+
+
+def _pmc_traffic(kernel, **match):
+    """HBM-side bytes per launch of `kernel` from the committed PMC summaries (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    passes, gfx950 corrections applied; a PMC pass cannot run inside the timed bench): newest round first."""
+    pdir = os.path.join(ROOT, "profiles")
+    for rnd in ("r02", "r01"):
+        for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+            if not (name.startswith(rnd + "_pmc_traffic") and name.endswith(".json")):
+                continue
+            try:
+                with open(os.path.join(pdir, name)) as fh:
+                    pmc = json.load(fh)
+            except (OSError, ValueError):
+                continue
+            if pmc.get("kernel") == kernel and all(pmc.get(k) == v for k, v in match.items()):
+                return pmc.get("hbm_bytes_per_launch")
+    return None
+
+
+def chol_flops(T):
+    """Algorithmic FLOPs of one factorisation with the RHS row: per block column k with n_k rows below it, trailing update
+    n_k^2 * 64 + triangular solve n_k * 64^2 + diagonal block 64^3 / 3   (= n^3 / 3 overall)."""
+    nk = [(T - k - 1) * 64 + 1 for k in range(T)]
+    return sum(v * v * 64.0 + v * 64.0 * 64.0 + 64.0 ** 3 / 3.0 for v in nk)
 
 
 def main():
@@ -221,73 +203,95 @@ def main():
     ap.add_argument("--preset", default="C4")
     ap.add_argument("--frames", type=int, default=None, help="truncate each robot's log (debug)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the un-batched re-run and the convergence probe")
     ap.add_argument("--ingest-only", action="store_true", help="build the graph without per-frame solves (profiling aid)")
     ap.add_argument("--robots-per-gpu", type=int, default=0,
-                    help="robot shards per GPU, on concurrent streams; 0 = the preset's robots / N when that divides (the SAME "
-                         "8-robot graph at every N: strong scaling), else 1; 1 = one robot per GPU at every N (weak scaling)")
-    ap.add_argument("--cpu-threads", type=int, default=0)
+                    help="robot shards per GPU; 0 = the preset's robots / N when that divides (the SAME 8-robot graph at every N: "
+                         "strong scaling), else 1; 1 = one robot per GPU at every N (weak scaling)")
+    ap.add_argument("--probe", type=int, default=40, help="passes recorded one by one for the convergence figure")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    import torch
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch            # torch first: it must initialise the device before this library's HIP runtime is loaded
     dist = None
     # SLIDE_BENCH_BACKEND=gloo rehearses the N > 1 path with every rank on GPU 0 (collectives staged through the
     # host); the real runs use nccl (= RCCL over xGMI), one GPU per rank.
     backend = os.environ.get("SLIDE_BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else 0
-    if world > 1:
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if world > 1 or os.environ.get("SLIDE_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
-        torch.cuda.set_device(dev_index)
+        if "MASTER_ADDR" not in os.environ:      # SLIDE_BENCH_FORCE_DIST on a plain `python bench.py`: a one-rank RCCL group
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend=backend)
-    else:
-        torch.cuda.set_device(0)
 
     import slide_slam_amd as s
+    from slide_slam_amd.distributed import PassDriver, TorchComm, gpu_matcher, setup_local_shards
     from slide_slam_amd.synth import SynthConfig, make_robot_log, make_world
     s.device_check()
     cfg = SynthConfig.preset(args.preset)
     R = args.robots_per_gpu if args.robots_per_gpu > 0 else (cfg.robots // world if cfg.robots % world == 0 else 1)
-    if R > 1:
-        # several robot shards on this GPU (one thread + one HIP stream each); everything below reports on robot 0's shard
-        t_b0 = time.perf_counter()
-        dt, gb, rep, dg_info = run_local_robots(args, R, s, torch, dist, rank, world, dev_index, backend)
-        data = dict(cfg=cfg, logs={0: make_robot_log(cfg, make_world(cfg), 0)}) if rank == 0 and not args.no_cpu else None
-        return report(args, s, cfg, rank, world, R, backend, dt, gb, rep, dg_info, dist, data, 0, time.perf_counter() - t_b0 - dt)
-    # one robot per GPU: rank r replays robot r of the shared world (weak scaling; N = cfg.robots is the full config)
-    robot = rank % cfg.robots
+    robots = world * R
     world_map = make_world(cfg)
-    data = dict(cfg=cfg, world=world_map, logs={robot: make_robot_log(cfg, world_map, robot)})
-    t_b0 = time.perf_counter()
-    gb, rep = build_graph(s, data, robot, args.frames, args.ingest_only)
-    t_build = time.perf_counter() - t_b0
-    g = gb.graph
-    st = g.stats()
-    dg_info = None
-    if world > 1:
-        # one robot per GPU: shared landmarks are associated across ranks once, then every Gauss-Newton pass
-        # exchanges their normal-equation blocks with two all-reduces (slide_slam_amd/distributed.py)
-        from slide_slam_amd.distributed import DistributedGraph, TorchComm, gpu_matcher
-        comm = TorchComm(device=torch.device("cuda", dev_index), stage_through_host=(backend != "nccl"))
-        dg = DistributedGraph(gb, comm, rank, world)
-        dg_info = dg.setup(gpu_matcher)
-        step = lambda: dg.gauss_newton(1)
-    else:
-        step = lambda: g.gauss_newton(1)
+    logs = [make_robot_log(cfg, world_map, (rank * R + t) % cfg.robots) for t in range(R)]
+    P = len(logs[0]["rel7"]) if args.frames is None else args.frames
+    multi = robots > 1          # several sub-graphs with shared landmarks: the distributed pass; else one robot's own joint graph
+    use_dist = dist is not None
+    wdev = world if use_dist else 1
+    base = TorchComm(device=device, stage_through_host=(backend != "nccl")) if use_dist else None
+    sync_coll = os.environ.get("SLIDE_BENCH_SYNC_COLLECTIVES") == "1"     # diagnostic: host-synchronous collectives
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
+        if use_dist and world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def build_all():
+        shards, reps = [], []
+        t0 = time.perf_counter()
+        for lg in logs:
+            gb, rep = build_shard(s, lg, args.frames, args.ingest_only)
+            shards.append(gb)
+            reps.append(rep)
+        return shards, reps, time.perf_counter() - t0
+
+    shards, reps, t_build = build_all()
+    rep = reps[0]
+    st = shards[0].graph.stats()
+    T = st["chol_dim"] // 64
+    info, parity, conv, batched_prof = {}, None, None, None
+
+    if multi:
+        batch = s.CholBatch(R)
+        for t, gb in enumerate(shards):
+            gb.graph.join_chol_batch(batch, t)
+        bufs, info = setup_local_shards(shards, gpu_matcher, base=base, rank=rank, world=wdev, device=device)
+        drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, base=base, world=wdev, device=device)
+        if sync_coll:
+            drv.stream_ordered = False
+        step = drv.one_pass
+        mode = ("one replayed hipGraph per pass, factorisations batched" if wdev == 1 else
+                f"three replayed hipGraph parts per pass, {backend} all-reduce of the shared-landmark blocks on the same stream between them")
+    else:
+        g = shards[0].graph
+        step = lambda: g.gauss_newton(1)
+        mode = "one robot, its own joint graph"
+
+    # ---- convergence probe: the first passes one by one, poses kept (not timed) ----
+    probe = []
+    n_probe = 0 if args.no_parity or not multi else max(0, args.probe)
+    for _ in range(n_probe):
+        step()
+        probe.append(np.stack([all_poses(gb, P) for gb in shards]))
     for _ in range(args.warmup):
         step()
     barrier()
@@ -296,113 +300,162 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    if use_dist and world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    n_passes = n_probe + args.warmup + args.steps
+    final = np.stack([all_poses(gb, P) for gb in shards])
+    finite = bool(np.isfinite(final).all())
 
-    return report(args, s, cfg, rank, world, 1, backend, dt, gb, rep, dg_info, dist, data, robot, t_build)
+    if multi:
+        ptrs = [b.data_ptr() for b in bufs]
+        if wdev == 1:
+            # device time of the batched step kernels (HIP events on the batch's stream, un-captured passes) for the roofline
+            pr = sorted(batch.profile(ptrs) for _ in range(5))
+            batched_prof = dict(ms_steps=pr[len(pr) // 2][0], launches=pr[0][1], robots=R)
+        if n_probe:
+            # passes needed to come within 1e-4 (relative, per robot) of the fixed point the timed passes ended at
+            ref = np.linalg.norm(final.reshape(R, -1), axis=1)
+            errs = [float((np.linalg.norm((p - final).reshape(R, -1), axis=1) / ref).max()) for p in probe]
+            hit = [i + 1 for i, e in enumerate(errs) if e < 1e-4]
+            first = float(hit[0]) if hit else 1e9
+            if use_dist and world > 1:
+                tt = torch.tensor([first], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                first = float(tt.item())
+            conv = {"passes_to_1e-4": int(first) if first < 1e9 else None, "probe_passes": n_probe,
+                    "rel_err_after": {str(k): errs[k - 1] for k in (1, 2, 3, 5, 10, 20, 40) if k <= n_probe},
+                    "note": "block-Jacobi over robots on the reduced pose system with the exact gradient (its fixed point is the joint "
+                            f"optimum); error relative to the state after all {n_passes} passes of this run, largest over the robots"}
+        if not args.no_parity:
+            # ---- parity of what was timed: identically built shards, the same number of passes through the UN-batched path ----
+            for gb in shards:
+                gb.graph.join_chol_batch(None)
+            ref_shards, _, _ = build_all()
+            rbufs, rinfo = setup_local_shards(ref_shards, gpu_matcher, base=base, rank=rank, world=wdev, device=device)
+            rdrv = PassDriver(ref_shards, rbufs, rinfo["n_slots"], batch=None, base=base, world=wdev, device=device)
+            rdrv.gauss_newton(n_passes)
+            ref_final = np.stack([all_poses(gb, P) for gb in ref_shards])
+            rel = float(np.abs(final - ref_final).max() / max(np.abs(ref_final).max(), 1.0))
+            if use_dist and world > 1:
+                tt = torch.tensor([rel if np.isfinite(rel) else 1e30], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                rel = float(tt.item())
+            same_slots = rinfo["n_slots"] == info["n_slots"]
+            parity = {"batched_vs_unbatched_max_rel": rel, "passes_compared": n_passes, "slots_equal": same_slots, "finite": finite,
+                      "ok": bool(finite and np.isfinite(rel) and rel < 1e-6 and same_slots),
+                      "what": "poses of every robot after the probe + warm-up + timed passes vs identically built shards driven the same "
+                              "number of passes through slide_graph_dist_phase (no batch, no captured graph, host-side sums); tolerance "
+                              "1e-6 relative (only the summation order of the exchange differs)"}
+            del ref_shards, rdrv, rbufs
+    report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build, info, mode, batched_prof, parity, conv, finite, dist, T)
+    if use_dist:
+        dist.destroy_process_group()
+    if rank == 0 and ((parity is not None and not parity["ok"]) or not finite):
+        raise SystemExit(1)
 
 
-def report(args, s, cfg, rank, world, R, backend, dt, gb, rep, dg_info, dist, data, robot, t_build):
-    """Profile pass on this rank's first shard + the JSON line (rank 0)."""
-    g = gb.graph
-    st = g.stats()
+def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build, info, mode, bt, parity, conv, finite, dist, T):
+    """Profile pass on this rank's first shard alone + the JSON line (rank 0)."""
+    import torch
+    g = shards[0].graph
     robots = world * R
-    # per-kernel device time (HIP events on the launch stream) over a separate profiled pass
+    for sh in shards:
+        sh.graph.join_chol_batch(None)
+    st = g.stats()
+    # per-kernel device time (HIP events on the launch stream) over a separate profiled pass of robot 0's sub-graph by itself
     g.set_profiling(True)
     nprof = max(3, min(args.steps, 5))
     for _ in range(nprof):
         g.gauss_newton(1)
     prof = g.get_profile()
     g.set_profiling(False)
-
-    if rank == 0:
-        T = st["chol_dim"] // 64
-        n = st["chol_dim"]
-        # algorithmic FLOPs of one factorisation (RHS row included), per block column k with n_k rows below it:
-        # trailing update n_k^2 * 64 + triangular solve n_k * 64^2 + diagonal block 64^3 / 3   (= n^3/3 overall)
-        nk = [(T - k - 1) * 64 + 1 for k in range(T)]
-        upd_flops = sum(v * v * 64.0 + v * 64.0 * 64.0 + 64.0 ** 3 / 3.0 for v in nk)
-        upd = prof.get("chol_step", dict(ms=0.0, launches=1))
-        upd_ms = upd["ms"] / max(upd["launches"], 1)
-        upd_launches_per_iter = upd["launches"] / nprof
-        flops_per_launch = upd_flops / max(upd_launches_per_iter, 1)
-        ach = flops_per_launch / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
-        # HBM bytes per launch of the same kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-        # passes, gfx950 FETCH_SIZE x2 correction): collected offline with tools/chol_big.py on the same reduced-system size
-        # and committed under profiles/ (a PMC pass cannot run inside the timed bench)
-        traffic = None
+    devs = [f"cuda:{torch.cuda.current_device()} {torch.cuda.get_device_name()}"]
+    if dist is not None and world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devs[0])
+        devs = gathered
+    if rank != 0:
+        return
+    n = st["chol_dim"]
+    upd_flops = chol_flops(T)
+    upd = prof.get("chol_step", dict(ms=0.0, launches=1))
+    upd_ms = upd["ms"] / max(upd["launches"], 1)
+    upd_launches_per_iter = upd["launches"] / nprof
+    flops_per_launch = upd_flops / max(upd_launches_per_iter, 1)
+    ach = flops_per_launch / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+    traffic = _pmc_traffic("k_chol_step") if n == 3776 else None
+    single = dict(kernel="k_chol_step (one robot alone)", achieved=ach, frac=ach / FP64_MFMA_PEAK_TFLOPS, flops_per_launch=flops_per_launch,
+                  avg_launch_ms=upd_ms, traffic=traffic)
+    roof_kernel = "k_chol_step (v_mfma_f64_16x16x4_f64)"
+    if bt:
+        # the timed region ran k_chol_step_batched: all robots of the GPU per launch
+        roof_kernel = f"k_chol_step_batched (v_mfma_f64_16x16x4_f64, {bt['robots']} factorisations per launch)"
+        upd_launches_per_iter = bt["launches"]
+        upd_ms = bt["ms_steps"] / max(bt["launches"], 1)
+        flops_per_launch = bt["robots"] * upd_flops / max(bt["launches"], 1)
+        ach = flops_per_launch / (upd_ms * 1e-3) / 1e12
+        traffic = _pmc_traffic("k_chol_step_batched", robots=bt["robots"]) if n == 3776 else None
+    kernel_ms = {k: v["ms"] / nprof for k, v in prof.items()}
+    dominant = max(kernel_ms, key=kernel_ms.get)
+    n_slots = info.get("n_slots", 0) if info else 0
+    res = {
+        "metric": "pose-graph updates/sec + ms/Gauss-Newton iter, 8-robot 10k-landmark graph",
+        "value": robots * args.steps / dt,
+        "unit": "pose-graph updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_gn_iter": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        # the preset's robots over N GPUs (total work fixed) -> strong; a fixed number of robots per GPU -> weak
+        "scaling": "strong" if (args.robots_per_gpu == 0 and robots == cfg.robots) else "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic (seeded, slide_slam_amd/synth.py)",
+        "config": {"workload": f"{cfg.name} (BASELINE configs[3]): {robots} robot sub-graphs, {R} per GPU ({mode}) "
+                               f"({st['n_pose']} poses, {st['n_lm']} landmarks, {st['n_factors']} factors in robot 0's); "
+                               "a step = one Gauss-Newton pass of all of them, value = robot pose-graph updates/s",
+                   "robots": robots, "robots_per_gpu": R, "reduced_system_dim": n, "chol_tile": 64,
+                   "world_size": (dist.get_world_size() if dist is not None else 1), "backend": (backend if dist is not None else None),
+                   "devices": devs,
+                   "collective": None if not n_slots else
+                   ((f"{backend} " if wdev > 1 else "device-side local sum, no inter-GPU ") +
+                    f"all-reduce x2 per pass over {n_slots} shared-landmark slots ({n_slots * 63 * 8} B per pass)")},
+        "roofline": {"bound": "mfma", "kernel": roof_kernel, "achieved": ach,
+                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                     "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r0x_pmc_traffic*.json)",
+                     "one_robot_alone": single,
+                     "flops_per_launch": flops_per_launch, "avg_launch_ms": upd_ms,
+                     "launches_per_iter": upd_launches_per_iter, "dominant_by_time": dominant,
+                     "scope": ("HIP events on the launch stream around the step launches of un-captured passes after the timed region; "
+                               "one_robot_alone = robot 0's sub-graph by itself (the per-GPU load of the N = 8 run)")},
+        "kernel_ms_per_iter": kernel_ms,
+        "stream_replay": {"frames": len(rep["t_frame"]), "updates_per_s": len(rep["t_frame"]) / max(sum(rep["t_frame"]), 1e-9),
+                          "ms_last_frame": rep["t_frame"][-1] * 1e3, "ms_max_frame": max(rep["t_frame"]) * 1e3,
+                          "build_s_all_local_robots": t_build,
+                          "what": "robot 0's streaming build alone on the GPU: associate + add + iSAM2-equivalent update per frame, PCIe included"},
+        "finite": finite,
+    }
+    if parity is not None:
+        res["parity"] = parity
+    if conv is not None:
+        res["convergence"] = conv
+    try:
+        res["roofline"]["assoc"] = assoc_roofline(s)
+    except Exception as e:      # noqa: BLE001  (the headline number stands on its own)
+        res["roofline"]["assoc"] = {"error": repr(e)}
+    if not args.no_cpu:
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                pmc = json.load(fh)
-            if pmc.get("kernel") == "k_chol_step" and n == 3776:
-                traffic = pmc["hbm_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            traffic = None
-        single = dict(kernel="k_chol_step (one robot alone)", achieved=ach, frac=ach / FP64_MFMA_PEAK_TFLOPS, flops_per_launch=flops_per_launch,
-                      avg_launch_ms=upd_ms, traffic=traffic)
-        roof_kernel = "k_chol_step (v_mfma_f64_16x16x4_f64)"
-        bt = dg_info.get("batched") if dg_info else None
-        if bt:
-            # the timed region ran k_chol_step_batched: all robots of the GPU per launch
-            roof_kernel = f"k_chol_step_batched (v_mfma_f64_16x16x4_f64, {bt['robots']} factorisations per launch)"
-            upd_launches_per_iter = bt["launches"]
-            upd_ms = bt["ms_steps"] / max(bt["launches"], 1)
-            flops_per_launch = bt["robots"] * upd_flops / max(bt["launches"], 1)
-            ach = flops_per_launch / (upd_ms * 1e-3) / 1e12
-            traffic = None
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_batched.json")) as fh:
-                    pmc = json.load(fh)
-                if pmc.get("kernel") == "k_chol_step_batched" and n == 3776 and pmc.get("robots") == bt["robots"]:
-                    traffic = pmc["hbm_bytes_per_launch"]
-            except (OSError, ValueError, KeyError):
-                traffic = None
-        kernel_ms = {k: v["ms"] / nprof for k, v in prof.items()}
-        dominant = max(kernel_ms, key=kernel_ms.get)
-        res = {
-            "metric": "pose-graph updates/sec + ms/Gauss-Newton iter, 8-robot 10k-landmark graph",
-            "value": robots * args.steps / dt,
-            "unit": "pose-graph updates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "ms_per_gn_iter": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            # the preset's robots over N GPUs (total work fixed) -> strong; a fixed number of robots per GPU -> weak
-            "scaling": "strong" if (args.robots_per_gpu == 0 and robots == cfg.robots) else "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic (seeded, slide_slam_amd/synth.py)",
-            "config": {"workload": f"{cfg.name} (BASELINE configs[3]): {robots} robot sub-graphs, {R} per GPU"
-                                   + (f" ({dg_info['mode']})" if R > 1 and dg_info and "mode" in dg_info else "")
-                                   + f" ({st['n_pose']} poses, {st['n_lm']} landmarks, {st['n_factors']} factors in robot 0's); "
-                                     "a step = one Gauss-Newton pass of all of them, value = robot pose-graph updates/s",
-                       "robots": robots, "robots_per_gpu": R, "reduced_system_dim": n, "chol_tile": 64,
-                       "collective": None if dg_info is None else
-                       (("local sum + " if R > 1 else "") + (f"{backend} " if world > 1 else "no inter-GPU ") +
-                        f"all-reduce x2 per pass over {dg_info['n_slots']} shared-landmark slots ({dg_info['n_slots'] * 63 * 8} B per pass)")},
-            "roofline": {"bound": "mfma", "kernel": roof_kernel, "achieved": ach,
-                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r01_pmc_traffic*.json)",
-                         "one_robot_alone": single,
-                         "flops_per_launch": flops_per_launch, "avg_launch_ms": upd_ms,
-                         "launches_per_iter": upd_launches_per_iter, "dominant_by_time": dominant,
-                         "scope": ("HIP events on the launch stream around the step launches of un-captured passes after the timed region; "
-                                   "one_robot_alone = robot 0's sub-graph by itself (the per-GPU load of the N = 8 run)")},
-            "kernel_ms_per_iter": kernel_ms,
-            "stream_replay": {"frames": len(rep["t_frame"]), "updates_per_s": len(rep["t_frame"]) / max(sum(rep["t_frame"]), 1e-9),
-                              "ms_last_frame": rep["t_frame"][-1] * 1e3, "build_s": t_build},
-        }
-        if not args.no_cpu:
-            thr = args.cpu_threads or min(os.cpu_count() or 1, 16)
-            try:
-                res["cpu_baseline"] = cpu_baseline(data, robot, args.frames, thr)
-            except Exception as e:  # the GPU number stands on its own
-                res["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(res))
-    if dist is not None:
-        dist.destroy_process_group()
+            from slide_slam_amd.synth import make_robot_log, make_world
+            wm = make_world(cfg)
+            all_logs = [make_robot_log(cfg, wm, r) for r in range(min(cfg.robots, os.cpu_count() or 1, 8))]
+            v = cpu_baselines(all_logs, args.frames)
+            res["cpu_baseline"] = v["robots_as_threads"]
+            res["cpu_baseline_variants"] = {k: v[k] for k in ("single_thread", "omp")}
+        except Exception as e:  # noqa: BLE001  (the GPU number stands on its own)
+            res["cpu_baseline"] = {"error": repr(e)}
+    print(json.dumps(res))
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@ extern "C" {
 #define SLIDE_MISSING 1          /* key absent: getPose() == false semantics (graph.cpp:297-311) */
 #define SLIDE_ERR_INVALID (-1)   /* bad argument / robot id outside [0, SLIDE_MAX_ROBOTS) */
 #define SLIDE_ERR_NOT_SPD (-2)   /* a landmark block or the reduced pose system is not positive definite */
-#define SLIDE_ERR_CAPACITY (-3)  /* a fixed on-chip capacity was exceeded (e.g. > 16384 landmarks of one class in the K-NN gate) */
+#define SLIDE_ERR_CAPACITY (-3)  /* a fixed on-chip capacity was exceeded (e.g. K > 16384 neighbours in the K-NN gate; the map itself is unbounded) */
 #define SLIDE_ERR_HIP (-4)       /* HIP runtime error or no gfx950 device */
 #define SLIDE_ERR_RUNTIME (-5)   /* the reference would throw std::runtime_error here (sloam.cpp:349,355); also: a device-side wait gave up (scheduling stall) */
 
@@ -152,6 +152,16 @@ int slide_graph_dist_pass_local(slide_graph_t* g, double* d_buf);
  * the batch's stream around the exchanges and the batched factor + solve, captured once and replayed as one hipGraph per pass.
  * d_bufs[i] = exchange buffer (device) of the graph in slot i. */
 int slide_chol_batch_pass(slide_chol_batch_t* b, double* const* d_bufs);
+/* The same pass for a job that spans GPUs, cut at its two exchanges (8 / N robots on each of N GPUs): every part is a captured
+ * hipGraph replayed on the batch's stream.
+ *   part 0: phase 0 of every robot + the local sum -> every local buffer holds this GPU's sum of the 54-doubles-per-slot blocks;
+ *           the caller all-reduces d_bufs[0][0 .. 54 n_slots) across the ranks ON slide_chol_batch_stream() (RCCL), no host sync;
+ *   part 1: d_bufs[0] back to the other local buffers, Schur + batched factor + solve + t_l, local sum of 9 doubles per slot;
+ *           the caller all-reduces d_bufs[0][0 .. 9 n_slots);
+ *   part 2: d_bufs[0] back to the others, landmark back-substitution, retract; ONE host synchronisation, status decoded.
+ * slide_chol_batch_stream: the hipStream_t (as void*) the parts run on. */
+int slide_chol_batch_pass_part(slide_chol_batch_t* b, double* const* d_bufs, int part);
+void* slide_chol_batch_stream(slide_chol_batch_t* b);
 /* Measurement aid: the same pass issued without the graph, HIP events around the batched step kernels; *ms_steps = their device time
  * (launch gaps included), *n_launches = their number. */
 int slide_chol_batch_profile(slide_chol_batch_t* b, double* const* d_bufs, double* ms_steps, int* n_launches);
@@ -189,12 +199,22 @@ int slide_assoc_match_cylinders(int n_cur, const double* root, const double* ray
 int slide_assoc_match_boxes(int cls, int n_cur, const double* xyz, const int32_t* label, int n_map, const double* map_xyz,
                             const int32_t* map_label, double thresh, int32_t* out_idx);
 /* Batched association sweep (roofline leg): n_query independent frames, each n_obs ellipsoid detections
- * (xyz + label) against ONE resident map of n_map landmarks: K-NN gate to each query's robot position,
- * then label-gated nearest neighbour.  Inputs are DEVICE pointers (already resident in HBM); runs on
- * `stream` (a hipStream_t cast to void*, NULL = default stream).  out_map_idx: n_query * n_obs. */
-int slide_assoc_sweep_batch_device(const float* d_cloud_xyz, const double* d_model_xyz, const int32_t* d_label, int n_map,
-                                   const double* d_query_pos, const double* d_obs_xyz, const int32_t* d_obs_label,
-                                   int n_query, int n_obs, int K, double thresh, int32_t* d_out_map_idx, void* stream);
+ * (xyz + label) against ONE resident map of n_map landmarks: K-NN gate to each query's robot position
+ * (ellipsoidMapManager.cpp:40-80), then label-gated nearest neighbour (sloam.cpp:158-203).  Inputs are DEVICE pointers (already
+ * resident in HBM); the first-seen cloud is SoA (x[], y[], z[]: three coalesced float32 streams).  Runs on `stream` (a hipStream_t
+ * cast to void*, NULL = default stream).  out_map_idx: n_query * n_obs map indices or -1.  The map may be of any size;
+ * SLIDE_ERR_CAPACITY when min(K, n_map) exceeds the on-chip sort buffer (16384). */
+int slide_assoc_sweep_batch_device(const float* d_cloud_x, const float* d_cloud_y, const float* d_cloud_z, const double* d_model_xyz,
+                                   const int32_t* d_label, int n_map, const double* d_query_pos, const double* d_obs_xyz,
+                                   const int32_t* d_obs_label, int n_query, int n_obs, int K, double thresh, int32_t* d_out_map_idx,
+                                   void* stream);
+
+/* The same sweep on caller-provided HOST buffers (cloud_xyz: AoS float32 as for slide_submap_knn): inputs are uploaded once, then
+ * `repeats` launches run on the resident inputs; *ms_out (may be NULL) = their device time measured with HIP events on the launch
+ * stream (uploads and the result copy excluded). */
+int slide_assoc_sweep_batch(const float* cloud_xyz, const double* model_xyz, const int32_t* label, int n_map, const double* query_pos,
+                            const double* obs_xyz, const int32_t* obs_label, int n_query, int n_obs, int K, double thresh,
+                            int32_t* out_map_idx, int repeats, double* ms_out);
 
 /* ------------------------------------------------------------------------------------------------
  * S2 + runSLOAMNode — the per-key-frame update (src/core/sloamNode.cpp:762-1036 without ROS):

@@ -28,9 +28,9 @@ EXPORTS = [
     "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
     "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
-    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
+    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
     "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
-    "slide_dense_spd_solve", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device",
+    "slide_dense_spd_solve", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device", "slide_assoc_sweep_batch",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
     "slide_backend_end_frame", "slide_backend_graph", "slide_backend_counts", "slide_backend_map_model",
     "slide_place_default_params", "slide_match_maps", "slide_find_inter_loop_closure", "slide_find_intra_loop_closure",
@@ -94,6 +94,8 @@ def lib():
         L.slide_graph_rejected_count.argtypes = [C.c_void_p]
         L.slide_chol_batch_destroy.argtypes = [C.c_void_p]
         L.slide_chol_batch_destroy.restype = None
+        L.slide_chol_batch_stream.restype = C.c_void_p
+        L.slide_chol_batch_stream.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -285,6 +287,16 @@ class CholBatch:
         arr = (C.c_void_p * len(buf_ptrs))(*[int(p) for p in buf_ptrs])
         return _check(self.L.slide_chol_batch_pass(C.c_void_p(self.h), arr))
 
+    def pass_part(self, buf_ptrs, part):
+        """Part 0 / 1 / 2 of the pass cut at its two exchanges (jobs that span GPUs): the caller's all-reduce of buffer 0 goes onto
+        stream() between the parts; only part 2 synchronises with the host."""
+        arr = (C.c_void_p * len(buf_ptrs))(*[int(p) for p in buf_ptrs])
+        return _check(self.L.slide_chol_batch_pass_part(C.c_void_p(self.h), arr, C.c_int(part)))
+
+    def stream(self):
+        """hipStream_t (integer) the passes run on."""
+        return int(self.L.slide_chol_batch_stream(C.c_void_p(self.h)) or 0)
+
     def profile(self, buf_ptrs):
         """(ms of the batched step kernels of one un-captured pass, number of step launches)."""
         arr = (C.c_void_p * len(buf_ptrs))(*[int(p) for p in buf_ptrs])
@@ -404,6 +416,25 @@ def match_boxes(cls, xyz, label, map_xyz, map_label, thresh):
     _check(lib().slide_assoc_match_boxes(C.c_int(cls), C.c_int(n), _p(_d(xyz)), _p(_i(label)), C.c_int(m), _p(_d(map_xyz)),
                                          _p(_i(map_label)), C.c_double(thresh), _p(out)))
     return out[:n]
+
+
+def assoc_sweep_batch(cloud_xyz_f32, model_xyz, label, query_pos, obs_xyz, obs_label, K, thresh, repeats=1):
+    """Batched association sweep (getSubmap K-NN gate + matchEllipsoidModels) of n_query frames against one resident map.
+    obs_xyz: (n_query, n_obs, 3), obs_label: (n_query, n_obs).  Returns (map index or -1 per observation, device ms of `repeats`
+    launches on resident inputs)."""
+    cloud = np.ascontiguousarray(cloud_xyz_f32, dtype=np.float32).reshape(-1, 3)
+    model = _d(model_xyz).reshape(-1, 3)
+    lab = _i(label)
+    qp = _d(query_pos).reshape(-1, 3)
+    ox = _d(obs_xyz)
+    ol = _i(obs_label)
+    nq = qp.shape[0]
+    n_obs = ol.shape[1] if ol.ndim == 2 else 0
+    out = np.full((nq, max(n_obs, 1)), -1, np.int32)
+    ms = C.c_double(0)
+    _check(lib().slide_assoc_sweep_batch(_p(cloud), _p(model), _p(lab), C.c_int(len(lab)), _p(qp), _p(ox), _p(ol), C.c_int(nq),
+                                         C.c_int(n_obs), C.c_int(K), C.c_double(thresh), _p(out), C.c_int(repeats), C.byref(ms)))
+    return out[:, :n_obs], ms.value
 
 
 def place_default_params(**kw) -> PlaceParams:

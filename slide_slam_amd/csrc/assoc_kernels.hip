@@ -4,12 +4,14 @@
 // (src/core/sloam.cpp:73-217), object distances (src/objects/cube.cpp:22-24, ellipsoid.cpp:24-26,
 // cylinder.cpp:187-224).
 //
-// One workgroup per (frame, class).  The K-NN gate is an exact float32 brute-force scan of the
-// first-seen cloud (coalesced SoA stream from HBM/L2) followed by an in-LDS bitonic sort of
-// (distance bits, map index) keys, which reproduces the reference's nearest-first submap order; the
-// nearest-neighbour match is one wavefront per detection with a lexicographic (distance, submap index)
-// shuffle reduction, which reproduces the reference's strict-'<' first-index-wins rule.
-// This file is compiled with -ffp-contract=off: distances are compared against thresholds, so the
+// One workgroup per (frame, class).  The K-NN gate is an exact float32 brute-force scan of the first-seen cloud — three SoA
+// float streams, read once, coalesced — whose squared distances stay in LDS, followed by a K-SELECT, not a sort of the whole
+// cloud: an MSD radix select (8-bit digits, LDS histogram with wave-aggregated atomics) finds the K-th smallest
+// (distance bits, map index) key, the K keys at or below it are compacted into LDS and only those are sorted (bitonic, K padded to
+// a power of two) — the reference's nearest-first submap order, ties by map index.  The nearest-neighbour match is one wavefront
+// per detection with a lexicographic (distance, submap index) shuffle reduction = the reference's strict-'<' first-index-wins rule.
+// The cloud may be of any size (beyond the LDS cache the distances are recomputed per select pass); K is bounded by the sort
+// buffer (ASSOC_MAX_K).  This file is compiled with -ffp-contract=off: distances are compared against thresholds, so the
 // arithmetic must round exactly like the reference's un-fused x86-64 build.
 #include <hip/hip_runtime.h>
 #include <limits.h>
@@ -38,50 +40,153 @@ __device__ inline double cyl_distance(const double* model, int mlabel, const dou
 }
 
 struct AssocCore {
-  const float* cloud; const double* model; const int32_t* label; int n; int K;
+  const float *cx, *cy, *cz; const double* model; const int32_t* label; int n; int K;
+  int gate;                  // 1: K-NN gate (getSubmap); 0: the submap is the map itself in the caller's order (pure matcher)
+  int Kp;                    // sort buffer length: power of two >= min(K, n)   (gate only)
+  int cached;                // the n distance words fit in LDS next to the sort buffer
   double thresh, best_init; int label_gate, is_cyl;
   const double* qpos;        // 3: robot position (double; narrowed to float like PointT)
   const double* det_world;   // cyl: 7 per ; box: xyz taken at stride `det_stride` offset `det_off`
   int det_stride, det_off;
   const int32_t* det_label; int n_det;
-  int32_t* match_sub; int32_t* match_map; int32_t* submap; int32_t* n_sub;
+  int32_t* match_sub; int32_t* match_map; int32_t* submap; int32_t* n_sub;      // match_sub / submap / n_sub may be null
 };
 
-// keys: dynamic LDS, capacity Np (power of two >= n)
-__device__ inline void assoc_core(const AssocCore& C, unsigned long long* keys, int Np) {
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int Ksub = C.K < C.n ? C.K : C.n;
-  if (C.n > 0) {
-    const float qx = (float)C.qpos[0], qy = (float)C.qpos[1], qz = (float)C.qpos[2];
-    for (int i = tid; i < Np; i += nthr) {
-      unsigned long long key = ~0ull;
-      if (i < C.n) {
-        const float dx = C.cloud[3 * i] - qx, dy = C.cloud[3 * i + 1] - qy, dz = C.cloud[3 * i + 2] - qz;
-        float r = dx * dx;
-        r += dy * dy;
-        r += dz * dz;
-        key = ((unsigned long long)__float_as_uint(r) << 32) | (unsigned)i;
-      }
-      keys[i] = key;
-    }
-    __syncthreads();
-    for (int k = 2; k <= Np; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < Np; i += nthr) {
-          const int ixj = i ^ j;
-          if (ixj > i) {
-            const unsigned long long a = keys[i], b = keys[ixj];
-            const bool asc = (i & k) == 0;
-            if ((a > b) == asc) { keys[i] = b; keys[ixj] = a; }
-          }
-        }
-        __syncthreads();
-      }
-    }
-    for (int s = tid; s < Ksub; s += nthr) C.submap[s] = (int32_t)(keys[s] & 0xffffffffull);
-  }
-  if (tid == 0) *C.n_sub = Ksub;
+// dynamic LDS: [sel: Kp x 8 B][hist: 256 x 4 B][distance cache: n x 4 B when cached]
+extern __shared__ unsigned long long assoc_lds[];
+
+__device__ __forceinline__ unsigned dist_bits(const AssocCore& C, int i, float qx, float qy, float qz) {
+  const float dx = C.cx[i] - qx, dy = C.cy[i] - qy, dz = C.cz[i] - qz;
+  float r = dx * dx;
+  r += dy * dy;
+  r += dz * dz;
+  return __float_as_uint(r);       // r >= 0: the bit pattern orders like the value
+}
+
+// The K smallest (distance bits << 32 | index) keys of the cloud, ascending, into sel[0 .. Ksub).  Returns Ksub.
+__device__ inline int knn_select(const AssocCore& C, unsigned long long* sel, unsigned* hist, unsigned* dcache) {
+  __shared__ unsigned long long s_prefix;
+  __shared__ int s_krem, s_stop, s_cnt;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+  const int n = C.n, Ksub = C.K < n ? C.K : n;
+  const float qx = (float)C.qpos[0], qy = (float)C.qpos[1], qz = (float)C.qpos[2];
+  const int n_up = (n + nthr - 1) / nthr * nthr;
+  if (C.cached)
+    for (int i = tid; i < n; i += nthr) dcache[i] = dist_bits(C, i, qx, qy, qz);
+  if (tid == 0) { s_prefix = 0ull; s_krem = Ksub; s_stop = 0; s_cnt = 0; }
   __syncthreads();
+  auto key_at = [&](int i) -> unsigned long long {
+    const unsigned b = C.cached ? dcache[i] : dist_bits(C, i, qx, qy, qz);
+    return ((unsigned long long)b << 32) | (unsigned)i;
+  };
+  int shift = 64;                   // selected <=> (key >> shift) <= (prefix >> shift); 64 = everything (K >= n)
+  if (Ksub < n) {
+    for (int byte = 7; byte >= 0; --byte) {
+      shift = 8 * byte;
+      for (int b = tid; b < 256; b += nthr) hist[b] = 0u;
+      __syncthreads();
+      const unsigned long long prefix = s_prefix;
+      for (int i = tid; i < n_up; i += nthr) {
+        bool act = i < n;
+        unsigned digit = 0;
+        if (act) {
+          const unsigned long long key = key_at(i);
+          act = byte == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8));
+          digit = (unsigned)(key >> shift) & 255u;
+        }
+        // the top bytes of a float land in a handful of bins: lanes with the same digit add once (at most four rounds), the
+        // stragglers of a spread-out pass fall back to one atomic each
+        unsigned long long m = __ballot(act);
+#pragma unroll 1
+        for (int r = 0; r < 4 && m; ++r) {
+          const int leader = __ffsll((long long)m) - 1;
+          const unsigned d0 = (unsigned)__shfl((int)digit, leader);
+          const unsigned long long same = __ballot(act && digit == d0);
+          if (lane == leader) atomicAdd(&hist[d0], (unsigned)__popcll(same));
+          if (digit == d0) act = false;
+          m &= ~same;
+        }
+        if (act) atomicAdd(&hist[digit], 1u);
+      }
+      __syncthreads();
+      if (tid < 64) {
+        // bins 4 lane .. 4 lane + 3: the first bin at which the running count reaches the wanted rank
+        const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+        const unsigned own = h0 + h1 + h2 + h3;
+        unsigned inc = own;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const unsigned o = (unsigned)__shfl_up((int)inc, off);
+          if (lane >= off) inc += o;
+        }
+        const unsigned krem = (unsigned)s_krem;
+        const unsigned long long reach = __ballot(inc >= krem);
+        const int first = __ffsll((long long)reach) - 1;        // exists: the matching keys number at least krem
+        if (lane == first) {
+          unsigned before = inc - own;
+          unsigned d = 4 * lane, cnt = h0;
+          if (before + h0 < krem) { before += h0; d += 1; cnt = h1;
+            if (before + h1 < krem) { before += h1; d += 1; cnt = h2;
+              if (before + h2 < krem) { before += h2; d += 1; cnt = h3; } } }
+          s_prefix = prefix | ((unsigned long long)d << shift);
+          s_krem = (int)(krem - before);
+          s_stop = (before + cnt == krem) ? 1 : 0;      // the whole bin goes: nothing left to decide below this byte
+        }
+      }
+      __syncthreads();
+      if (s_stop) break;
+    }
+  }
+  // compaction of the selected keys (any order), then the sort that orders them
+  {
+    const unsigned long long lim = shift < 64 ? (s_prefix >> shift) : 0ull;
+    for (int i = tid; i < n_up; i += nthr) {
+      unsigned long long key = 0ull;
+      bool take = false;
+      if (i < n) {
+        key = key_at(i);
+        take = shift >= 64 || (key >> shift) <= lim;
+      }
+      const unsigned long long m = __ballot(take);
+      if (m) {
+        int base = 0;
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) base = atomicAdd(&s_cnt, __popcll(m));
+        base = __shfl(base, leader);
+        if (take) sel[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+      }
+    }
+  }
+  for (int i = Ksub + tid; i < C.Kp; i += nthr) sel[i] = ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= C.Kp; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < C.Kp; i += nthr) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = sel[i], b = sel[ixj];
+          const bool asc = (i & k) == 0;
+          if ((a > b) == asc) { sel[i] = b; sel[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  return Ksub;
+}
+
+__device__ inline void assoc_core(const AssocCore& C) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  unsigned long long* sel = assoc_lds;
+  unsigned* hist = reinterpret_cast<unsigned*>(assoc_lds + (C.gate ? C.Kp : 0));
+  unsigned* dcache = hist + 256;
+  int Ksub = C.n;
+  if (C.gate) {
+    Ksub = C.n > 0 ? knn_select(C, sel, hist, dcache) : 0;
+    if (C.submap)
+      for (int s = tid; s < Ksub; s += nthr) C.submap[s] = (int32_t)(sel[s] & 0xffffffffull);
+  }
+  if (tid == 0 && C.n_sub) *C.n_sub = Ksub;
   // one wavefront per detection
   const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
   for (int o = wave; o < C.n_det; o += nwave) {
@@ -90,7 +195,7 @@ __device__ inline void assoc_core(const AssocCore& C, unsigned long long* keys, 
     const int ol = C.det_label[o];
     const double* dw = C.det_world + (size_t)o * C.det_stride + C.det_off;
     for (int s = lane; s < Ksub; s += 64) {
-      const int mi = (int)(keys[s] & 0xffffffffull);
+      const int mi = C.gate ? (int)(sel[s] & 0xffffffffull) : s;
       double d;
       bool consider = true;
       if (C.is_cyl) {
@@ -113,23 +218,14 @@ __device__ inline void assoc_core(const AssocCore& C, unsigned long long* keys, 
     }
     if (lane == 0) {
       const bool ok = (bests != INT_MAX) && (best < C.thresh);
-      C.match_sub[o] = ok ? bests : -1;
-      C.match_map[o] = ok ? (int32_t)(keys[bests] & 0xffffffffull) : -1;
+      if (C.match_sub) C.match_sub[o] = ok ? bests : -1;
+      C.match_map[o] = ok ? (C.gate ? (int32_t)(sel[bests] & 0xffffffffull) : bests) : -1;
     }
   }
 }
 
-extern __shared__ unsigned long long dyn_keys[];
-
-__device__ inline int pow2_at_least(int n) {
-  int p = 64;
-  while (p < n) p <<= 1;
-  return p;
-}
-
 // grid = 3 (cylinders, cubes, ellipsoids of ONE key frame)
-__global__ __launch_bounds__(1024) void k_assoc_frame(const AssocFrameDev* __restrict__ cls3, const double* __restrict__ pose12,
-                                                      int* status) {
+__global__ __launch_bounds__(1024) void k_assoc_frame(const AssocFrameDev* __restrict__ cls3, const double* __restrict__ pose12) {
   const AssocFrameDev F = cls3[blockIdx.x];
   const int tid = threadIdx.x;
   const SE3 T = from12(pose12);
@@ -149,12 +245,9 @@ __global__ __launch_bounds__(1024) void k_assoc_frame(const AssocFrameDev* __res
     }
   }
   __syncthreads();
-  if (F.n > ASSOC_MAX_N) {
-    if (tid == 0) atomicOr(status, 1);
-    return;
-  }
   AssocCore C;
-  C.cloud = F.cloud; C.model = F.model; C.label = F.label; C.n = F.n; C.K = F.K;
+  C.cx = F.cx; C.cy = F.cy; C.cz = F.cz; C.model = F.model; C.label = F.label; C.n = F.n; C.K = F.K;
+  C.gate = F.gate; C.Kp = F.Kp; C.cached = F.cached;
   C.thresh = F.thresh; C.best_init = F.best_init; C.label_gate = F.label_gate; C.is_cyl = F.is_cyl;
   C.qpos = pose12 + 9;
   C.det_world = F.det_world;
@@ -162,30 +255,28 @@ __global__ __launch_bounds__(1024) void k_assoc_frame(const AssocFrameDev* __res
   C.det_off = F.is_cyl ? 0 : 9;
   C.det_label = F.det_label; C.n_det = F.n_det;
   C.match_sub = F.match_sub; C.match_map = F.match_map; C.submap = F.submap; C.n_sub = F.n_sub;
-  assoc_core(C, dyn_keys, pow2_at_least(F.n));
+  assoc_core(C);
 }
 
 // Batched sweep: one workgroup per independent query frame against one resident map
 // (label-gated points, i.e. the ellipsoid / point-landmark class of the headline graph).
-__global__ __launch_bounds__(1024) void k_assoc_sweep(const float* __restrict__ cloud, const double* __restrict__ model_xyz,
-                                                      const int32_t* __restrict__ label, int n_map,
+__global__ __launch_bounds__(1024) void k_assoc_sweep(const float* __restrict__ cx, const float* __restrict__ cy, const float* __restrict__ cz,
+                                                      const double* __restrict__ model_xyz, const int32_t* __restrict__ label, int n_map,
                                                       const double* __restrict__ query_pos, const double* __restrict__ obs_xyz,
-                                                      const int32_t* __restrict__ obs_label, int n_obs, int K, double thresh,
-                                                      int32_t* __restrict__ out_map_idx, int32_t* __restrict__ scratch) {
+                                                      const int32_t* __restrict__ obs_label, int n_obs, int K, int Kp, int cached,
+                                                      double thresh, int32_t* __restrict__ out_map_idx) {
   const int q = blockIdx.x;
   AssocCore C;
-  C.cloud = cloud; C.model = model_xyz; C.label = label; C.n = n_map; C.K = K;
+  C.cx = cx; C.cy = cy; C.cz = cz; C.model = model_xyz; C.label = label; C.n = n_map; C.K = K;
+  C.gate = 1; C.Kp = Kp; C.cached = cached;
   C.thresh = thresh; C.best_init = 1000.0; C.label_gate = 1; C.is_cyl = 0;
   C.qpos = query_pos + 3 * (size_t)q;
   C.det_world = obs_xyz + 3 * (size_t)q * n_obs;
   C.det_stride = 3; C.det_off = 0;
   C.det_label = obs_label + (size_t)q * n_obs; C.n_det = n_obs;
-  const int Ksub = K < n_map ? K : n_map;
-  // per-query scratch: [match_sub (n_obs) | submap (Ksub) | n_sub (1)]
-  int32_t* sc = scratch + (size_t)q * (n_obs + Ksub + 1);
-  C.match_sub = sc; C.submap = sc + n_obs; C.n_sub = sc + n_obs + Ksub;
+  C.match_sub = nullptr; C.submap = nullptr; C.n_sub = nullptr;
   C.match_map = out_map_idx + (size_t)q * n_obs;
-  assoc_core(C, dyn_keys, pow2_at_least(n_map));
+  assoc_core(C);
 }
 
 // updateFactorGraphMap (graphWrapper.cpp:239-275): optimised landmarks -> map models
@@ -209,40 +300,41 @@ __global__ void k_map_refresh(double* cyl_model, int n_cyl, const int* cyl_lid, 
 static bool g_attr_set = false;
 static void ensure_lds_attr() {
   if (g_attr_set) return;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_frame), hipFuncAttributeMaxDynamicSharedMemorySize,
-                      ASSOC_MAX_N * 8);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_sweep), hipFuncAttributeMaxDynamicSharedMemorySize,
-                      ASSOC_MAX_N * 8);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_frame), hipFuncAttributeMaxDynamicSharedMemorySize, ASSOC_LDS_BUDGET);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, ASSOC_LDS_BUDGET);
   g_attr_set = true;
 }
-static int host_pow2(int n) {
+
+// LDS plan of one class: sort buffer length, whether the distance words are cached, bytes.  false: K exceeds the sort buffer.
+bool assoc_plan(int n, int K, int gate, int* Kp, int* cached, size_t* bytes) {
+  *Kp = 0; *cached = 0; *bytes = 0;
+  if (!gate || n <= 0) return true;
+  const int Ksub = K < n ? K : n;
+  if (Ksub > ASSOC_MAX_K) return false;
   int p = 64;
-  while (p < n) p <<= 1;
-  return p;
+  while (p < Ksub) p <<= 1;
+  *Kp = p;
+  const size_t fixed = (size_t)p * 8 + 256 * 4;
+  *cached = fixed + (size_t)n * 4 <= (size_t)ASSOC_LDS_BUDGET ? 1 : 0;
+  *bytes = fixed + (*cached ? (size_t)n * 4 : 0);
+  return true;
 }
 
-void launch_assoc_frame(const AssocFrameDev* classes3, const double* pose12, int* status, hipStream_t s) {
+void launch_assoc_frame(const AssocFrameDev* classes3, size_t lds_bytes, const double* pose12, hipStream_t s) {
   ensure_lds_attr();
-  // LDS sized for the largest class; the host guarantees n <= ASSOC_MAX_N before calling
-  hipLaunchKernelGGL(k_assoc_frame, dim3(3), dim3(1024), ASSOC_MAX_N * 8, s, classes3, pose12, status);
+  hipLaunchKernelGGL(k_assoc_frame, dim3(3), dim3(1024), lds_bytes, s, classes3, pose12);
 }
 
-static int32_t* g_sweep_scratch = nullptr;
-static size_t g_sweep_scratch_n = 0;
-
-void launch_assoc_sweep(const float* cloud, const double* model_xyz, const int32_t* label, int n_map,
-                        const double* query_pos, const double* obs_xyz, const int32_t* obs_label, int n_query, int n_obs,
-                        int K, double thresh, int32_t* out_map_idx, hipStream_t s) {
+int launch_assoc_sweep(const float* cx, const float* cy, const float* cz, const double* model_xyz, const int32_t* label, int n_map,
+                       const double* query_pos, const double* obs_xyz, const int32_t* obs_label, int n_query, int n_obs,
+                       int K, double thresh, int32_t* out_map_idx, hipStream_t s) {
   ensure_lds_attr();
-  const int Ksub = K < n_map ? K : n_map;
-  const size_t need = (size_t)n_query * (n_obs + Ksub + 1);
-  if (need > g_sweep_scratch_n) {
-    if (g_sweep_scratch) hipFree(g_sweep_scratch);
-    hipMalloc(&g_sweep_scratch, need * sizeof(int32_t));
-    g_sweep_scratch_n = need;
-  }
-  hipLaunchKernelGGL(k_assoc_sweep, dim3(n_query), dim3(1024), (size_t)host_pow2(n_map) * 8, s, cloud, model_xyz, label, n_map,
-                     query_pos, obs_xyz, obs_label, n_obs, K, thresh, out_map_idx, g_sweep_scratch);
+  int Kp, cached;
+  size_t bytes;
+  if (!assoc_plan(n_map, K, 1, &Kp, &cached, &bytes)) return -1;
+  hipLaunchKernelGGL(k_assoc_sweep, dim3(n_query), dim3(1024), bytes, s, cx, cy, cz, model_xyz, label, n_map, query_pos, obs_xyz,
+                     obs_label, n_obs, K, Kp, cached, thresh, out_map_idx);
+  return 0;
 }
 
 void launch_map_refresh(double* cyl_model, int n_cyl, const int* cyl_lid, double* cube_xyz, int n_cube, const int* cube_lid,

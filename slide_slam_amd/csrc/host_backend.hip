@@ -26,7 +26,6 @@ int HostBackend::init() {
   if (d_pose12.ensure(12, 0, g.stream) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_cls3.ensure(3, 0, g.stream) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_nsub.ensure(4, 0, g.stream, true) != SLIDE_OK) return SLIDE_ERR_HIP;
-  if (d_status.ensure(4, 0, g.stream, true) != SLIDE_OK) return SLIDE_ERR_HIP;
   return SLIDE_OK;
 }
 
@@ -54,12 +53,16 @@ int HostBackend::associate(const SE3& poseEstimate, const slide_detections_t& de
   AssocFrameDev F[3];
   if (ub.begin() != SLIDE_OK) return SLIDE_ERR_HIP;
   struct BatchGuard { ~BatchGuard() { UploadBatch::current = nullptr; } } batch_guard;      // an error return abandons the batch
+  size_t lds_bytes = 0;
   for (int c = 0; c < 3; ++c) {
     ClassMap& M = maps[c];
-    if (M.n() > ASSOC_MAX_N) {
-      g_last_error = "K-NN gate capacity exceeded (more than 16384 landmarks of one class)";
+    size_t lb = 0;
+    if (!assoc_plan(M.n(), M.K, 1, &F[c].Kp, &F[c].cached, &lb)) {
+      g_last_error = "K-NN gate: K exceeds the on-chip sort buffer (16384 neighbours)";
       return SLIDE_ERR_CAPACITY;
     }
+    lds_bytes = std::max(lds_bytes, lb);
+    F[c].gate = 1;
     const size_t n1 = std::max<size_t>(nd[c], 1);
     if (d_det[c].ensure(n1 * dstride[c], 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_det_world[c].ensure(n1 * dstride[c], 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
@@ -70,7 +73,7 @@ int HostBackend::associate(const SE3& poseEstimate, const slide_detections_t& de
     if (d_det[c].upload(A.det_body[c].data(), 0, A.det_body[c].size(), s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (nd[c] && d_det_label[c].upload(labels[c], 0, nd[c], s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (M.sync_device(s) != SLIDE_OK) return SLIDE_ERR_HIP;
-    F[c].cloud = M.d_cloud.d; F[c].model = M.d_model.d; F[c].label = M.d_label.d; F[c].n = M.n(); F[c].K = M.K;
+    F[c].cx = M.d_cx.d; F[c].cy = M.d_cy.d; F[c].cz = M.d_cz.d; F[c].model = M.d_model.d; F[c].label = M.d_label.d; F[c].n = M.n(); F[c].K = M.K;
     F[c].is_cyl = (c == 0);
     // thresholds / initial bestDist of sloam.cpp:90,104 / :128-136,150 / :174-180,198
     if (c == 0) { F[c].thresh = P.cylinder_match_thresh; F[c].best_init = P.cylinder_match_thresh + 100; F[c].label_gate = 2; }
@@ -85,12 +88,10 @@ int HostBackend::associate(const SE3& poseEstimate, const slide_detections_t& de
   if (d_pose12.upload(pose12, 0, 12, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_cls3.upload(F, 0, 3, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (ub.flush(s) != SLIDE_OK) return SLIDE_ERR_HIP;
-  SL_HIP(hipMemsetAsync(d_status.d, 0, 4 * sizeof(int), s));
-  launch_assoc_frame(d_cls3.d, d_pose12.d, d_status.d, s);
-  int nsub[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
+  launch_assoc_frame(d_cls3.d, lds_bytes, d_pose12.d, s);
+  int nsub[4] = {0, 0, 0, 0};
   std::vector<int> sub_all[3];                     // the whole submap table comes along: its length is only known afterwards
   db.add(nsub, d_nsub.d, 3 * sizeof(int));
-  db.add(st, d_status.d, 4 * sizeof(int));
   for (int c = 0; c < 3; ++c) {
     sub_all[c].resize(std::max(maps[c].K, 1));
     db.add(sub_all[c].data(), d_submap[c].d, sub_all[c].size() * sizeof(int));
@@ -101,7 +102,6 @@ int HostBackend::associate(const SE3& poseEstimate, const slide_detections_t& de
   }
   if (db.run(s) != SLIDE_OK) return SLIDE_ERR_HIP;
   SL_HIP(hipGetLastError());
-  if (st[0]) return SLIDE_ERR_CAPACITY;
   for (int c = 0; c < 3; ++c) {
     // matchesMap_: submap index -> map index (std::map<int,int> in the reference)
     maps[c].matchesMap.assign(sub_all[c].begin(), sub_all[c].begin() + std::min<size_t>(nsub[c], sub_all[c].size()));
@@ -118,7 +118,7 @@ int HostBackend::associate(const SE3& poseEstimate, const slide_detections_t& de
       const double* w = &A.det_world[c][(size_t)i * dstride[c]];
       if (A.match_sub[c][i] == -1) {
         const double* pos = c == 0 ? w : w + 9;
-        M.h_cloud.push_back((float)pos[0]); M.h_cloud.push_back((float)pos[1]); M.h_cloud.push_back((float)pos[2]);
+        M.h_cx.push_back((float)pos[0]); M.h_cy.push_back((float)pos[1]); M.h_cz.push_back((float)pos[2]);
         if (c == 0) M.h_model.insert(M.h_model.end(), w, w + 7);
         else {
           M.h_model.insert(M.h_model.end(), pos, pos + 3);
@@ -196,11 +196,15 @@ int HostBackend::add_observation(const FrameAssoc& A, const slide_detections_t& 
 
 int ClassMap::sync_device(hipStream_t s) {
   const size_t nn = h_label.size();
-  if (d_cloud.ensure(std::max<size_t>(3 * nn, 1), 3 * up_n, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_cx.ensure(std::max<size_t>(nn, 1), up_n, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_cy.ensure(std::max<size_t>(nn, 1), up_n, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_cz.ensure(std::max<size_t>(nn, 1), up_n, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_model.ensure(std::max<size_t>(stride * nn, 1), stride * up_n, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_label.ensure(std::max<size_t>(nn, 1), up_n, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (nn > up_n) {
-    if (d_cloud.upload(h_cloud.data() + 3 * up_n, 3 * up_n, 3 * (nn - up_n), s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_cx.upload(h_cx.data() + up_n, up_n, nn - up_n, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_cy.upload(h_cy.data() + up_n, up_n, nn - up_n, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_cz.upload(h_cz.data() + up_n, up_n, nn - up_n, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_model.upload(h_model.data() + stride * up_n, stride * up_n, stride * (nn - up_n), s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_label.upload(h_label.data() + up_n, up_n, nn - up_n, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     up_n = nn;

@@ -10,12 +10,12 @@ namespace sl {
 // models + hit counts + float32 cloud of first-seen positions, cubeMapManager.cpp:116-120).
 struct ClassMap {
   int cls = 0, K = 0, stride = 3;
-  std::vector<float> h_cloud;
+  std::vector<float> h_cx, h_cy, h_cz;     // first-seen positions, SoA (three coalesced streams for the K-NN scan)
   std::vector<double> h_model;   // values at insertion; the live models are refreshed in HBM
   std::vector<int> h_label, hits, lid;
   std::vector<double> scale;     // boxes only (ellipsoid EMA lives here)
   std::vector<int> matchesMap;   // submap index -> map index of the latest getSubmap
-  DevArr<float> d_cloud;
+  DevArr<float> d_cx, d_cy, d_cz;
   DevArr<double> d_model;
   DevArr<int> d_label, d_lid;
   size_t up_n = 0, up_lid = 0;

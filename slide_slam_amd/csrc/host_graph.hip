@@ -384,6 +384,7 @@ void HostGraph::join_batch(CholBatch* b, int slot) {
   if (b) b->set_graph(slot, this);
 }
 CholBatch::~CholBatch() {
+  for (auto& e : part_exec) if (e) (void)hipGraphExecDestroy(e);
   for (HostGraph* g : graphs)
     if (g) { std::lock_guard<std::mutex> gl(g->mtx); if (g->batch == this) g->batch = nullptr; }
   for (hipEvent_t e : ev_in) if (e) (void)hipEventDestroy(e);
@@ -483,7 +484,11 @@ int CholBatch::prepare_pass() {
 }
 // the launches of one pass of all joined graphs (captured by capture_pass, or issued directly by profile_pass with events e0 / e1
 // around the batched step kernels)
-int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1) {
+// part: -1 = the whole pass (every robot of the job is in this batch); 0 / 1 / 2 = the pass cut at its two exchanges, for a job that
+// spans GPUs: after part 0 every local buffer holds the LOCAL sum of the 54-doubles-per-slot blocks and the caller all-reduces
+// bufs[0] across the ranks on the batch's stream (RCCL); part 1 hands bufs[0] back to the other local buffers, runs up to the local
+// sum of the 9-doubles-per-slot t_l; the caller all-reduces bufs[0] again; part 2 hands it back and finishes the pass.
+int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1, int part) {
   static const bool batch_p3 = !(getenv("SLIDE_BATCH_PHASE3") && getenv("SLIDE_BATCH_PHASE3")[0] == '0');     // diagnostic
   int rc = SLIDE_OK;
   // every robot's stream continues behind the batch's stream, runs `phase`, and is joined back
@@ -498,26 +503,33 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1)
     }
   };
   const int n_slots = graphs[0]->G.n_slots;
-  each(0);
-  if (rc == SLIDE_OK) launch_sum_bcast(d_bufs, n, 54 * n_slots, master);
-  if (rc == SLIDE_OK) {
-    if (batch_p3) launch_phase3_batched(d_Gs, hG.data(), n, d_bufs, master);      // five launches for all robots (blockIdx.z = robot)
-    else each(3);
+  const bool whole = part < 0;
+  if (whole || part == 0) {
+    each(0);
+    if (rc == SLIDE_OK) launch_sum_bcast(d_bufs, n, 54 * n_slots, master);
   }
-  if (rc == SLIDE_OK && e0) (void)hipEventRecord(e0, master);
-  if (rc == SLIDE_OK) launch_chol_batch(sys.data(), n, d_ctr, master, e1);
-  if (rc == SLIDE_OK) each(4);
-  if (rc == SLIDE_OK) launch_sum_bcast(d_bufs, n, 9 * n_slots, master);
-  if (rc == SLIDE_OK) each(2);
+  if (whole || part == 1) {
+    if (rc == SLIDE_OK && !whole) launch_bcast(d_bufs, n, 54 * n_slots, master);
+    if (rc == SLIDE_OK) {
+      if (batch_p3) launch_phase3_batched(d_Gs, hG.data(), n, d_bufs, master);      // five launches for all robots (blockIdx.z = robot)
+      else each(3);
+    }
+    if (rc == SLIDE_OK && e0) (void)hipEventRecord(e0, master);
+    if (rc == SLIDE_OK) launch_chol_batch(sys.data(), n, d_ctr, master, e1);
+    if (rc == SLIDE_OK) each(4);
+    if (rc == SLIDE_OK) launch_sum_bcast(d_bufs, n, 9 * n_slots, master);
+  }
+  if (whole || part == 2) {
+    if (rc == SLIDE_OK && !whole) launch_bcast(d_bufs, n, 9 * n_slots, master);
+    if (rc == SLIDE_OK) each(2);
+  }
   return rc;
 }
-int CholBatch::capture_pass(double* const* d_bufs) {
-  if (pass_exec) { (void)hipGraphExecDestroy(pass_exec); pass_exec = nullptr; }
-  int rc = prepare_pass();
-  if (rc != SLIDE_OK) return rc;
+int CholBatch::capture_pass(double* const* d_bufs, int part, hipGraphExec_t* exec) {
+  if (*exec) { (void)hipGraphExecDestroy(*exec); *exec = nullptr; }
   hipGraph_t graph = nullptr;
   SL_HIP(hipStreamBeginCapture(master, hipStreamCaptureModeThreadLocal));
-  rc = enqueue_pass(d_bufs, nullptr, nullptr);
+  const int rc = enqueue_pass(d_bufs, nullptr, nullptr, part);
   const hipError_t e = hipStreamEndCapture(master, &graph);
   if (rc != SLIDE_OK || e != hipSuccess || graph == nullptr) {
     (void)hipGetLastError();
@@ -525,12 +537,9 @@ int CholBatch::capture_pass(double* const* d_bufs) {
     g_last_error = "batched pass: stream capture failed";
     return rc != SLIDE_OK ? rc : SLIDE_ERR_HIP;
   }
-  const hipError_t ei = hipGraphInstantiate(&pass_exec, graph, nullptr, nullptr, 0);
+  const hipError_t ei = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);
-  if (ei != hipSuccess) { pass_exec = nullptr; (void)hipGetLastError(); g_last_error = "batched pass: graph instantiation failed"; return SLIDE_ERR_HIP; }
-  pass_G.resize(n);
-  pass_bufs.assign(d_bufs, d_bufs + n);
-  for (int i = 0; i < n; ++i) pass_G[i] = graphs[i]->G;
+  if (ei != hipSuccess) { *exec = nullptr; (void)hipGetLastError(); g_last_error = "batched pass: graph instantiation failed"; return SLIDE_ERR_HIP; }
   return SLIDE_OK;
 }
 // One pass issued directly (no graph), with HIP events on the batch's stream around the batched step kernels: their total device
@@ -561,7 +570,7 @@ int CholBatch::profile_pass(double* const* d_bufs, double* ms_steps, int* n_laun
   hipEvent_t e0 = nullptr, e1 = nullptr;
   SL_HIP(hipEventCreate(&e0));
   SL_HIP(hipEventCreate(&e1));
-  rc = enqueue_pass(d_bufs, e0, e1);
+  rc = enqueue_pass(d_bufs, e0, e1, -1);
   const hipError_t es = hipStreamSynchronize(master);
   for (int i = 0; i < n; ++i) (void)hipStreamSynchronize(graphs[i]->stream);
   float ms = 0.f;
@@ -576,8 +585,9 @@ int CholBatch::profile_pass(double* const* d_bufs, double* ms_steps, int* n_laun
   return rc;
 }
 
-int CholBatch::pass_all(double* const* d_bufs) {
-  std::lock_guard<std::mutex> pl(pass_mtx);
+// Brings every joined graph up to date, clears the status words and decides whether the captured launch sequences still fit
+// (same device views, same exchange buffers, same set of graphs).  Called at the start of a pass (whole, or part 0).
+int CholBatch::begin_pass(double* const* d_bufs, bool* same) {
   bool dirty;
   {
     std::lock_guard<std::mutex> lk(mtx);
@@ -590,7 +600,7 @@ int CholBatch::pass_all(double* const* d_bufs) {
     SL_HIP(hipStreamCreateWithFlags(&master, hipStreamNonBlocking));
     SL_HIP(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
   }
-  bool same = !dirty && pass_exec != nullptr && (int)pass_G.size() == n;
+  *same = !dirty && (int)pass_G.size() == n;
   for (int i = 0; i < n; ++i) {
     HostGraph* g = graphs[i];
     std::lock_guard<std::mutex> gl(g->mtx);
@@ -601,13 +611,21 @@ int CholBatch::pass_all(double* const* d_bufs) {
     if (g->G.n_slots != graphs[0]->G.n_slots) { g_last_error = "batched pass: the graphs disagree on the shared slots"; return SLIDE_ERR_INVALID; }
     SL_HIP(hipStreamSynchronize(g->stream));                       // (uploads of a changed graph; idle otherwise)
     SL_HIP(hipMemsetAsync(g->G.status, 0, 8 * sizeof(int), master));
-    same = same && std::memcmp(&pass_G[i], &g->G, sizeof(GraphDev)) == 0 && pass_bufs[i] == d_bufs[i];
+    *same = *same && std::memcmp(&pass_G[i], &g->G, sizeof(GraphDev)) == 0 && pass_bufs[i] == d_bufs[i];
   }
-  if (!same) {
-    const int rc = capture_pass(d_bufs);
+  if (!*same) {
+    // every captured sequence is stale: drop them, refresh the device-side tables once
+    if (pass_exec) { (void)hipGraphExecDestroy(pass_exec); pass_exec = nullptr; }
+    for (auto& e : part_exec) if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }
+    const int rc = prepare_pass();
     if (rc != SLIDE_OK) return rc;
+    pass_G.resize(n);
+    pass_bufs.assign(d_bufs, d_bufs + n);
+    for (int i = 0; i < n; ++i) pass_G[i] = graphs[i]->G;
   }
-  SL_HIP(hipGraphLaunch(pass_exec, master));
+  return SLIDE_OK;
+}
+int CholBatch::end_pass() {
   int st[CHOL_BATCH_HOST_MAX][8];
   for (int i = 0; i < n; ++i) SL_HIP(hipMemcpyAsync(st[i], graphs[i]->G.status, 8 * sizeof(int), hipMemcpyDeviceToHost, master));
   SL_HIP(hipStreamSynchronize(master));
@@ -617,6 +635,43 @@ int CholBatch::pass_all(double* const* d_bufs) {
     if (rc != SLIDE_OK) return rc;
   }
   return SLIDE_OK;
+}
+
+hipStream_t CholBatch::pass_stream() {
+  std::lock_guard<std::mutex> pl(pass_mtx);
+  if (!master) {
+    if (hipStreamCreateWithFlags(&master, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return master;
+}
+
+int CholBatch::pass_all(double* const* d_bufs) {
+  std::lock_guard<std::mutex> pl(pass_mtx);
+  bool same = false;
+  int rc = begin_pass(d_bufs, &same);
+  if (rc != SLIDE_OK) return rc;
+  if (!pass_exec && (rc = capture_pass(d_bufs, -1, &pass_exec)) != SLIDE_OK) return rc;
+  SL_HIP(hipGraphLaunch(pass_exec, master));
+  return end_pass();
+}
+
+// The pass in three stream-ordered parts for a job that spans GPUs (see enqueue_pass): parts 0 and 1 return without a host
+// synchronisation — the caller's collective goes onto stream() behind them — part 2 ends with the one synchronisation of the pass.
+int CholBatch::pass_part(double* const* d_bufs, int part) {
+  if (part < 0 || part > 2) return SLIDE_ERR_INVALID;
+  std::lock_guard<std::mutex> pl(pass_mtx);
+  int rc;
+  if (part == 0) {
+    bool same = false;
+    if ((rc = begin_pass(d_bufs, &same)) != SLIDE_OK) return rc;
+  } else if ((int)pass_G.size() != n || !master) {
+    g_last_error = "batched pass: part 0 has not run";
+    return SLIDE_ERR_INVALID;
+  }
+  if (!part_exec[part] && (rc = capture_pass(d_bufs, part, &part_exec[part])) != SLIDE_OK) return rc;
+  SL_HIP(hipGraphLaunch(part_exec[part], master));
+  return part == 2 ? end_pass() : SLIDE_OK;
 }
 
 int HostGraph::factor_and_solve(hipStream_t s) {

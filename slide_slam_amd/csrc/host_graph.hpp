@@ -138,6 +138,8 @@ class CholBatch {
   // joined to the batch's stream around the two device-side exchanges and the batched factor + solve, captured once and replayed
   // as ONE hipGraph per pass.  bufs[i]: exchange buffer of the graph in slot i.
   int pass_all(double* const* d_bufs);
+  int pass_part(double* const* d_bufs, int part);       // the same pass cut at its two exchanges (multi-GPU jobs); part 0, 1, 2
+  hipStream_t pass_stream();                             // the stream the passes run on (created on first use)
   int profile_pass(double* const* d_bufs, double* ms_steps, int* n_launches);
 
  private:
@@ -153,13 +155,16 @@ class CholBatch {
   std::vector<double*> bufs;
   std::vector<HostGraph*> graphs;
   hipGraphExec_t pass_exec = nullptr;
+  hipGraphExec_t part_exec[3] = {nullptr, nullptr, nullptr};
   std::vector<GraphDev> pass_G;
   std::vector<double*> pass_bufs;
   hipEvent_t ev_fork = nullptr;
   GraphDev* d_Gs = nullptr;              // the joined graphs' device views, for the kernels batched over blockIdx.z
-  int capture_pass(double* const* d_bufs);
+  int capture_pass(double* const* d_bufs, int part, hipGraphExec_t* exec);
   int prepare_pass();
-  int enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1);
+  int begin_pass(double* const* d_bufs, bool* same);
+  int end_pass();
+  int enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1, int part);
   std::vector<GraphDev> hG;
   int rendezvous(int slot, hipStream_t s, bool reduce, int count);
   std::vector<hipEvent_t> ev_in;

@@ -21,7 +21,8 @@ void launch_estimate(const GraphDev& G, hipStream_t s);
 void launch_pose_adj(const GraphDev& G, hipStream_t s);        // pose adjacency bitmap of the Schur assembly (topology only)
 void launch_scatter(const void* stage, unsigned desc_off, int nseg, hipStream_t s);
 void launch_gather(void* stage, unsigned desc_off, int nseg, hipStream_t s);
-void launch_sum_bcast(double* const* bufs, int n, int count, hipStream_t s);
+void launch_sum_bcast(double* const* bufs, int n, int count, hipStream_t s);   // local all-reduce(sum) of up to 8 buffers
+void launch_bcast(double* const* bufs, int n, int count, hipStream_t s);       // bufs[0] -> the others
 void launch_phase3_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s);   // blockIdx.z = robot               // local all-reduce(sum) of up to 8 buffers             // device arrays -> one staging buffer (DownloadBatch)   // staged upload -> destinations (UploadBatch)
 void launch_ghost_exchange(const GraphDev& G, int what, double* buf, hipStream_t s);   // what: 0 pack owned poses, 1 adopt
 
@@ -42,11 +43,13 @@ int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double
 // assoc_kernels.hip
 struct AssocFrameDev {
   // map of one class, resident in HBM
-  const float* cloud;        // 3 n   first-seen float32 positions (K-NN gate)
+  const float *cx, *cy, *cz; // n each: first-seen float32 positions, SoA (K-NN gate)
   const double* model;       // cyl: 7 n (root ray radius) ; box: 3 n (xyz)
   const int32_t* label;      // n
   int n;
   int K;
+  int gate;                  // 1: K-NN gate; 0: the submap is the whole map in the caller's order (stand-alone matchers)
+  int Kp, cached;            // LDS plan of the gate (assoc_plan)
   double thresh;
   double best_init;          // sloam.cpp:90 / :128,136 / :176,180
   int label_gate;            // 0 none (cubes), 1 skip unless equal (ellipsoids), 2 distance = 1000 (cylinders)
@@ -62,13 +65,17 @@ struct AssocFrameDev {
   int32_t* submap;           // K entries: map indices nearest first (matchesMap_)
   int32_t* n_sub;            // 1
 };
-void launch_assoc_frame(const AssocFrameDev* classes3, const double* pose12, int* status, hipStream_t s);
-void launch_assoc_sweep(const float* cloud, const double* model_xyz, const int32_t* label, int n_map,
-                        const double* query_pos, const double* obs_xyz, const int32_t* obs_label, int n_query,
-                        int n_obs, int K, double thresh, int32_t* out_map_idx, hipStream_t s);
+// LDS plan of one class for the K-NN gate: sort buffer length Kp (power of two >= min(K, n)), whether the n distance words are cached
+// in LDS, dynamic LDS bytes.  false: min(K, n) exceeds ASSOC_MAX_K.  The cloud itself may be of any size.
+bool assoc_plan(int n, int K, int gate, int* Kp, int* cached, size_t* bytes);
+void launch_assoc_frame(const AssocFrameDev* classes3, size_t lds_bytes /* max over the three classes */, const double* pose12, hipStream_t s);
+int launch_assoc_sweep(const float* cx, const float* cy, const float* cz, const double* model_xyz, const int32_t* label, int n_map,
+                       const double* query_pos, const double* obs_xyz, const int32_t* obs_label, int n_query,
+                       int n_obs, int K, double thresh, int32_t* out_map_idx, hipStream_t s);     // -1: K beyond ASSOC_MAX_K
 void launch_map_refresh(double* cyl_model, int n_cyl, const int* cyl_lid, double* cube_xyz, int n_cube, const int* cube_lid,
                         double* ell_xyz, int n_ell, const int* ell_lid, const double* lm_est, hipStream_t s);
-constexpr int ASSOC_MAX_N = 16384;
+constexpr int ASSOC_MAX_K = 16384;                 // neighbours kept by the K-NN gate (LDS sort buffer); the cloud is unbounded
+constexpr int ASSOC_LDS_BUDGET = 144 * 1024;
 
 // place_kernels.hip
 struct PlaceDev {

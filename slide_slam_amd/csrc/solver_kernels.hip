@@ -806,6 +806,21 @@ void launch_sum_bcast(double* const* bufs, int n, int count, hipStream_t s) {
   hipLaunchKernelGGL(k_sum_bcast, dim3((count + 255) / 256), dim3(256), 0, s, A, count);
 }
 
+// buf[0] -> buf[1 .. n-1]: hands the result of a cross-GPU all-reduce (done on buf[0]) to the other robots of this GPU
+__global__ __launch_bounds__(256) void k_bcast(SumBcastArgs A, int count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const double v = A.buf[0][i];
+  for (int r = 1; r < A.n; ++r) A.buf[r][i] = v;
+}
+void launch_bcast(double* const* bufs, int n, int count, hipStream_t s) {
+  if (count <= 0 || n <= 1) return;
+  SumBcastArgs A{};
+  A.n = n;
+  for (int r = 0; r < n; ++r) A.buf[r] = bufs[r];
+  hipLaunchKernelGGL(k_bcast, dim3((count + 255) / 256), dim3(256), 0, s, A, count);
+}
+
 // the reverse: device arrays gathered into one staging buffer for ONE device -> host copy (DownloadBatch); `dst` of a
 // descriptor is the source pointer here
 __global__ __launch_bounds__(256) void k_gather(unsigned char* __restrict__ stage, unsigned desc_off) {

@@ -159,6 +159,112 @@ class DistributedGraph:
             self._phase(2)
 
 
+def setup_local_shards(shards, matcher, base=None, rank=0, world=1, thresh=(2.0, 2.0, 0.75), device=None):
+    """Cross-robot association for ALL robot shards of this process from one host thread (virtual rank of local shard t =
+    rank * len(shards) + t; every process holds the same number of shards): all-gather the landmark tables, run the
+    deterministic merge, install the shared slots of every local shard and adopt the owners' values.  `base` (a TorchComm) joins
+    the processes of a multi-GPU job; None = single process.  Returns (exchange buffers [one per shard], info)."""
+    R = len(shards)
+    mine = [[sh.landmark_table(cls) for cls in range(3)] for sh in shards]
+    parts = base.all_gather_object(mine) if (base is not None and world > 1) else [mine]
+    tables = [t for part in parts for t in part]
+    gid, n_global = associate_global(tables, thresh, matcher)
+    bufs, n_slots = [], 0
+    if device is not None:
+        import torch
+        alloc = lambda n: torch.zeros(n, dtype=torch.float64, device=device)
+        handle = lambda b: b.data_ptr()
+    else:
+        alloc = lambda n: np.zeros(n)
+        handle = lambda b: b
+    for t, sh in enumerate(shards):
+        cls, idx, own = shared_slots(gid, n_global, rank * R + t)
+        n_slots = len(cls)
+        sh.graph.set_shared(cls, idx, own)
+        bufs.append(alloc(max(n_slots, 1) * 54))
+    # value broadcast: every replica of a shared landmark adopts its owner's value (phase 10, all-reduce(sum) of 15 / slot, phase 11)
+    for t, sh in enumerate(shards):
+        sh.graph.dist_phase(10, handle(bufs[t]))          # (returns after its kernels have completed)
+    if n_slots:
+        n15 = n_slots * 15
+        if device is None:
+            total = np.sum([b[:n15] for b in bufs], axis=0)
+        else:
+            total = torch.stack([b[:n15] for b in bufs]).sum(0)
+        if base is not None and world > 1:
+            base.all_reduce(total, n15)
+        for b in bufs:
+            b[:n15] = total
+        if device is not None:
+            torch.cuda.synchronize()
+    for t, sh in enumerate(shards):
+        sh.graph.dist_phase(11, handle(bufs[t]))
+    return bufs, dict(n_slots=n_slots, n_global=n_global)
+
+
+class PassDriver:
+    """One distributed Gauss-Newton pass of all robot shards of this process, driven by ONE host thread.
+
+    With a CholBatch (`batch`, HIP shards): the pass is the batch's captured launch sequences — the whole pass as one hipGraph when
+    the job is this process alone, or its three parts with the two cross-GPU all-reduces of buffer 0 issued ON THE BATCH'S STREAM
+    between them (RCCL through torch.distributed on an ExternalStream: stream-ordered, no host synchronisation until the end of the
+    pass).  Without one (oracle shards on the CPU, or un-batched HIP shards): the same sequence spelled out with dist_phase calls
+    and host-side sums — the CPU rehearsal of exactly this control flow."""
+
+    def __init__(self, shards, bufs, n_slots, batch=None, base=None, world=1, device=None):
+        self.shards, self.bufs, self.n_slots, self.batch, self.base, self.world, self.device = shards, bufs, n_slots, batch, base, world, device
+        self.ptrs = [b.data_ptr() for b in bufs] if device is not None else None
+        self.passes = 0
+        self.stream_ordered = True      # False (diagnostic): host-synchronous collectives
+
+    def _exchange(self, count):
+        """all-reduce(sum) of buffer 0's first `count` doubles across the processes, ordered behind the batch's stream."""
+        if self.world > 1 and count:
+            self.base.all_reduce_on(self.bufs[0], count, self.batch.stream() if (self.batch is not None and self.stream_ordered) else None)
+
+    def _local_sum(self, count):
+        if not count:
+            return
+        tot = self.bufs[0][:count].copy() if self.device is None else self.bufs[0][:count].clone()
+        for b in self.bufs[1:]:
+            tot += b[:count]
+        self.bufs[0][:count] = tot
+
+    def _local_bcast(self, count):
+        for b in self.bufs[1:]:
+            b[:count] = self.bufs[0][:count]
+        if self.device is not None:          # (torch's stream; the shards' own streams read the buffers next)
+            import torch
+            torch.cuda.synchronize()
+
+    def one_pass(self):
+        n54, n9 = 54 * self.n_slots, 9 * self.n_slots
+        if self.batch is not None:
+            if self.world == 1:
+                self.batch.pass_all(self.ptrs)
+            else:
+                self.batch.pass_part(self.ptrs, 0)
+                self._exchange(n54)
+                self.batch.pass_part(self.ptrs, 1)
+                self._exchange(n9)
+                self.batch.pass_part(self.ptrs, 2)
+        else:
+            h = (lambda b: b.data_ptr()) if self.device is not None else (lambda b: b)
+            for sh, b in zip(self.shards, self.bufs):
+                sh.graph.dist_phase(0, h(b))
+            self._local_sum(n54); self._exchange(n54); self._local_bcast(n54)
+            for sh, b in zip(self.shards, self.bufs):
+                sh.graph.dist_phase(1, h(b))
+            self._local_sum(n9); self._exchange(n9); self._local_bcast(n9)
+            for sh, b in zip(self.shards, self.bufs):
+                sh.graph.dist_phase(2, h(b))
+        self.passes += 1
+
+    def gauss_newton(self, iterations=1):
+        for _ in range(iterations):
+            self.one_pass()
+
+
 class TorchComm:
     """torch.distributed plumbing: `nccl` (= RCCL over xGMI) with device buffers, or `gloo` with host buffers
     (CPU tests; also lets several ranks share one GPU by staging through the host)."""
@@ -169,6 +275,7 @@ class TorchComm:
         self.torch, self.dist = torch, dist
         self.device = device
         self.stage = stage_through_host
+        self._ext = {}
 
     def all_gather_object(self, obj):
         out = [None] * self.dist.get_world_size()
@@ -197,6 +304,23 @@ class TorchComm:
         else:
             self.dist.all_reduce(buf[:n])
             self.torch.cuda.synchronize()
+
+
+    def all_reduce_on(self, buf, n, stream_ptr=None):
+        """all-reduce(sum) of buf[:n] ordered behind the work already queued on the HIP stream `stream_ptr` (and ahead of what
+        is queued on it afterwards).  nccl (RCCL over xGMI): issued under torch's ExternalStream of that stream — no host
+        synchronisation.  gloo / host staging (CPU tests, several ranks on one GPU): synchronous."""
+        if n == 0:
+            return
+        if self.device is None or self.stage or stream_ptr is None:
+            if self.device is not None:
+                self.torch.cuda.synchronize()
+            return self.all_reduce(buf, n)
+        ext = self._ext.get(stream_ptr)
+        if ext is None:
+            ext = self._ext[stream_ptr] = self.torch.cuda.ExternalStream(stream_ptr, device=self.device)
+        with self.torch.cuda.stream(ext):
+            self.dist.all_reduce(buf[:n])
 
 
 class ThreadGroup:

@@ -79,9 +79,60 @@ def main_threads(R):
                  n_global=np.array(out[0][1]["n_global"]), n_gslots=0)
 
 
+def main_driver(R):
+    """R robot shards per process, ONE driver thread (setup_local_shards + PassDriver), several processes.
+    backend oracle: CPU shards, gloo.  backend gpu: HIP shards in a CholBatch on the one visible GPU, the pass in its three captured
+    parts with the gloo all-reduce staged through the host between them (stands in for RCCL, which needs one GPU per rank)."""
+    backend, preset, iters, out_path = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from slide_slam_amd.distributed import PassDriver, TorchComm, setup_local_shards
+    from slide_slam_amd.replay import replay_single
+    from slide_slam_amd.synth import SynthConfig, make_robot_log, make_world
+    cfg = SynthConfig.preset(preset)
+    assert cfg.robots == world * R
+    world_map = make_world(cfg)
+    logs = [make_robot_log(cfg, world_map, rank * R + t) for t in range(R)]
+    if backend == "oracle":
+        from oracle import pyoracle as po
+        shards = [po.OracleBackend(po.OrcParams.default(), 1) for _ in range(R)]
+        base, device, batch, matcher = TorchComm(device=None), None, None, oracle_matcher
+    else:
+        import slide_slam_amd as s
+        torch.cuda.set_device(0)
+        device = torch.device("cuda", 0)
+        shards = [s.SlideBackend(s.default_params(), 1) for _ in range(R)]
+        base, matcher = TorchComm(device=device, stage_through_host=True), gpu_matcher
+        batch = s.CholBatch(R)
+    for sh, lg in zip(shards, logs):
+        replay_single(sh, lg, robot=0, collect=False)
+    if batch is not None:
+        for t, sh in enumerate(shards):
+            sh.graph.join_chol_batch(batch, t)
+    bufs, info = setup_local_shards(shards, matcher, base=base, rank=rank, world=world, device=device)
+    drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, base=base, world=world, device=device)
+    drv.gauss_newton(iters)
+    P = cfg.poses_per_robot
+    mine = [np.array([sh.graph.get_pose12(0, k)[1] for k in range(P)]) for sh in shards]
+    if batch is not None:
+        for sh in shards:
+            sh.graph.join_chol_batch(None)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    if rank == 0:
+        np.savez(out_path, poses=np.array([p for part in gathered for p in part]), n_slots=info["n_slots"],
+                 n_global=np.array(info["n_global"]), n_gslots=0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     if len(sys.argv) > 5 and sys.argv[5].startswith("threads="):
         return main_threads(int(sys.argv[5].split("=")[1]))
+    if len(sys.argv) > 5 and sys.argv[5].startswith("driver="):
+        return main_driver(int(sys.argv[5].split("=")[1]))
     backend, preset, iters, out_path = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     import torch
     import torch.distributed as dist

@@ -1,0 +1,153 @@
+"""GPU scenarios of the BASELINE configs that need torch for device buffers (run in a fresh process: torch has to initialise the
+device before this library's HIP runtime is loaded).  usage: gpu_scenarios.py <scenario> <out.json> [args]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def ingest(shard, log, mode):
+    """All frames at their ground-truth poses without per-frame solves (association against the un-refined map), one solve at the
+    end: the same graph on the product and on the oracle in seconds (what bench.py --ingest-only and its cpu_baseline leg do)."""
+    from slide_slam_amd.synth import frame_detections
+    for k in range(len(log["rel7"])):
+        shard.process_frame(0, log["rel7"][k], log["gt7"][k], frame_detections(log, k), mode)
+    assert shard.ingest_solve() == 0
+
+
+def poses_of(shards, P):
+    return np.array([[sh.graph.get_pose12(0, k)[1] for k in range(P)] for sh in shards])
+
+
+def c4_parity(out, preset="C4", passes=3):
+    """BASELINE configs[3] as bench.py times it: eight robot sub-graphs in one CholBatch, the whole pass one replayed hipGraph —
+    against (a) the un-batched path (slide_graph_dist_phase per robot, host-side sums) and (b) eight oracle shards, pass by pass."""
+    import torch
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)
+    import slide_slam_amd as s
+    from oracle import pyoracle as po
+    from dist_worker import oracle_matcher
+    from slide_slam_amd.distributed import PassDriver, gpu_matcher, setup_local_shards
+    from slide_slam_amd.synth import SynthConfig, make_robot_log, make_world
+    cfg = SynthConfig.preset(preset)
+    wm = make_world(cfg)
+    logs = [make_robot_log(cfg, wm, r) for r in range(cfg.robots)]
+    R, P = cfg.robots, cfg.poses_per_robot
+
+    def gpu_shards():
+        sh = [s.SlideBackend(s.default_params(), 1) for _ in range(R)]
+        for a, lg in zip(sh, logs):
+            ingest(a, lg, s.FRAME_FOREIGN)
+        return sh
+    A, B = gpu_shards(), gpu_shards()
+    batch = s.CholBatch(R)
+    for t, a in enumerate(A):
+        a.graph.join_chol_batch(batch, t)
+    bufA, infoA = setup_local_shards(A, gpu_matcher, device=dev)
+    bufB, infoB = setup_local_shards(B, gpu_matcher, device=dev)
+    dA = PassDriver(A, bufA, infoA["n_slots"], batch=batch, device=dev)
+    dB = PassDriver(B, bufB, infoB["n_slots"], device=dev)
+    L = po.lib(native=True)
+    O = [po.OracleBackend(po.OrcParams.default(num_threads=min(os.cpu_count() or 1, 16)), 1, L=L) for _ in range(R)]
+    for o, lg in zip(O, logs):
+        ingest(o, lg, 2)
+    bufO, infoO = setup_local_shards(O, oracle_matcher)
+    dO = PassDriver(O, bufO, infoO["n_slots"])
+    res = dict(n_slots=[infoA["n_slots"], infoB["n_slots"], infoO["n_slots"]], n_global=[list(map(int, infoA["n_global"])), list(map(int, infoO["n_global"]))],
+               batched_vs_unbatched=[], batched_vs_oracle=[], chol_dim=A[0].graph.stats()["chol_dim"], t_pass_batched_ms=[])
+    for _ in range(passes):
+        t0 = time.perf_counter()
+        dA.one_pass()
+        res["t_pass_batched_ms"].append((time.perf_counter() - t0) * 1e3)
+        dB.one_pass()
+        dO.one_pass()
+        a, b, o = poses_of(A, P), poses_of(B, P), poses_of(O, P)
+        res["batched_vs_unbatched"].append(float(np.abs(a - b).max() / np.abs(b).max()))
+        nrm = np.linalg.norm(o.reshape(R, -1), axis=1)
+        res["batched_vs_oracle"].append(float((np.linalg.norm((a - o).reshape(R, -1), axis=1) / nrm).max()))
+    res["finite"] = bool(np.isfinite(poses_of(A, P)).all())
+    for a in A:
+        a.graph.join_chol_batch(None)
+    json.dump(res, open(out, "w"))
+
+
+def c3_joint(out, preset="C3", gn=12):
+    """The joint optimum of BASELINE configs[2] on ONE GPU: a single host replica ingesting both robots (the reference's own
+    arrangement, sloamNode.cpp:912-1002), then batch Gauss-Newton — what the two sharded ranks have to converge to."""
+    import torch
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")
+    import slide_slam_amd as s
+    from slide_slam_amd.replay import replay_multi
+    from slide_slam_amd.synth import SynthConfig, make_dataset
+    cfg = SynthConfig.preset(preset)
+    data = make_dataset(cfg)
+    data["relmeas"] = []
+    gb = s.SlideBackend(s.default_params(number_of_robots=cfg.robots), cfg.robots)
+    t0 = time.perf_counter()
+    replay_multi(gb, data, own_node_factory=lambda: s.SlideBackend(s.default_params(), 1))
+    t_replay = time.perf_counter() - t0
+    gb.graph.gauss_newton(gn)
+    P = cfg.poses_per_robot
+    poses = np.array([[gb.graph.get_pose12(r, k)[1] for k in range(P)] for r in range(cfg.robots)])
+    c = gb.counts()
+    np.savez(out, poses=poses, counts=np.array([c["cyl"], c["cube"], c["point"]]), t_replay=t_replay, chol_dim=gb.graph.stats()["chol_dim"])
+
+
+def c5_stream(out, preset="C4", ticks=None, budget_ms=100.0):
+    """BASELINE configs[4]: eight robots streaming key frames; every robot's node runs its own frame (associate + add +
+    iSAM2-equivalent update), ingests the packet its neighbour published for the same tick (sloamNode.cpp:912-1002: associate
+    against the host's maps, add, one solve) and refreshes its map — the per-update latency of every node is measured against the
+    100 ms budget of a 10 Hz key-frame rate.  One GPU hosts the eight nodes here, one after the other per tick; on the 8-GPU node
+    each has its own."""
+    import torch
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")
+    import slide_slam_amd as s
+    from slide_slam_amd.replay import IDENT7, foreign_key_poses
+    from slide_slam_amd.synth import SynthConfig, frame_detections, make_robot_log, make_world
+    cfg = SynthConfig.preset(preset)
+    wm = make_world(cfg)
+    R = cfg.robots
+    logs = [make_robot_log(cfg, wm, r) for r in range(R)]
+    T = cfg.poses_per_robot if ticks is None else ticks
+    # what every robot's own node publishes per key frame (PoseMstPair.keyPose, sloamNode.cpp:793-800)
+    kposes = [foreign_key_poses(s.SlideBackend(s.default_params(), 1), lg) for lg in logs]
+    cols = cfg.grid[1]
+    nbr = [(r + 1) if (r % cols) + 1 < cols else (r - 1) for r in range(R)]       # the neighbour in the same row of the grid
+    nodes = [s.SlideBackend(s.default_params(number_of_robots=2), 2) for _ in range(R)]
+    prev = [IDENT7.copy() for _ in range(R)]
+    lat = np.zeros((T, R))
+    for k in range(T):
+        for r in range(R):
+            nd, o = nodes[r], nbr[r]
+            t0 = time.perf_counter()
+            rr = nd.process_frame(0, logs[r]["rel7"][k], prev[r], frame_detections(logs[r], k), s.FRAME_HOST_DEFERRED)
+            assert rr["status"] == 0
+            nd.process_frame(1, logs[o]["rel7"][k], kposes[o][k], frame_detections(logs[o], k), s.FRAME_FOREIGN)
+            assert nd.ingest_solve() == 0
+            st, pose = nd.end_frame(0)
+            assert st == 0
+            lat[k, r] = (time.perf_counter() - t0) * 1e3
+            prev[r] = pose.copy()
+    stats = [nd.graph.stats() for nd in nodes]
+    res = dict(ticks=T, robots=R, budget_ms=budget_ms, max_ms=float(lat.max()), p50_ms=float(np.median(lat)), p99_ms=float(np.percentile(lat, 99)),
+               last_tick_ms=[float(v) for v in lat[-1]], over_budget=int((lat > budget_ms).sum()),
+               n_pose=[st["n_pose"] for st in stats], chol_dim=[st["chol_dim"] for st in stats],
+               rejected=[int(nd.graph.rejected_count()) for nd in nodes],
+               finite=bool(all(np.isfinite(p).all() for p in prev)))
+    json.dump(res, open(out, "w"))
+
+
+if __name__ == "__main__":
+    fn = {"c4_parity": c4_parity, "c3_joint": c3_joint, "c5_stream": c5_stream}[sys.argv[1]]
+    extra = [int(a) if a.lstrip("-").isdigit() else a for a in sys.argv[3:]]
+    fn(sys.argv[2], *extra)

@@ -46,9 +46,11 @@ def test_dense_spd_solve_rejects_indefinite(gpu):
         gpu.dense_spd_solve(A, np.ones(70))
 
 
-@pytest.mark.parametrize("n,K", [(1, 30), (29, 30), (700, 1000), (5000, 1000), (16384, 50)])
+@pytest.mark.parametrize("n,K", [(1, 30), (29, 30), (700, 1000), (5000, 1000), (16384, 50), (10000, 1), (30000, 1000), (50000, 1000),
+                                 (20000, 16384), (3000, 3000)])
 def test_submap_knn_matches_oracle(gpu, n, K):
-    """Exact float32 K-NN gate: identical index lists (nearest first, ties by index)."""
+    """Exact float32 K-NN gate (radix K-select + sort of the K survivors): identical index lists (nearest first, ties by index).
+    30000 points: the distance words still fit in LDS; 50000: recomputed per select pass; K >= n: no selection at all."""
     rng = np.random.default_rng(n + K)
     cloud = rng.uniform(-60, 60, (n, 3)).astype(np.float32)
     if n > 10:
@@ -62,10 +64,76 @@ def test_submap_knn_matches_oracle(gpu, n, K):
     assert np.array_equal(got, out[:k])
 
 
+@pytest.mark.parametrize("case", ["all_equal", "two_shells", "tie_across_the_cut"])
+def test_submap_knn_ties_at_the_selection_boundary(gpu, case):
+    """Many exactly equidistant points around the K-th neighbour: the select has to go on into the index bits (lowest indices
+    win), which is the reference order the oracle defines for FLANN's unspecified tie order."""
+    rng = np.random.default_rng(3)
+    n, K = 6000, 1000
+    if case == "all_equal":
+        cloud = np.tile(np.array([[3.0, 4.0, 0.0]], np.float32), (n, 1))
+    elif case == "two_shells":
+        ang = rng.uniform(0, 2 * np.pi, n)
+        r = np.where(np.arange(n) % 3 == 0, 5.0, 9.0)
+        cloud = np.zeros((n, 3), np.float32)
+        cloud[:, 0] = 0.0; cloud[:, 1] = 0.0; cloud[:, 2] = r          # two distinct distances, thousands of ties each
+    else:
+        cloud = rng.uniform(-60, 60, (n, 3)).astype(np.float32)
+        d = ((cloud.astype(np.float64)) ** 2).sum(1)
+        kth = np.argsort(d, kind="stable")[K - 1]
+        for j in rng.permutation(n)[:40]:
+            cloud[j] = cloud[kth]                                       # 40 copies of the K-th neighbour itself
+    q = np.zeros(3)
+    got = gpu.submap_knn(cloud, q, K)
+    out = np.zeros(K, np.int32)
+    k = po.lib().orc_knn_f32(cloud.ctypes.data_as(C.c_void_p), C.c_int(n), q.ctypes.data_as(C.c_void_p), C.c_int(K),
+                             out.ctypes.data_as(C.c_void_p))
+    assert k == K == len(got)
+    assert np.array_equal(got, out)
+
+
 def test_knn_capacity_error(gpu):
-    cloud = np.zeros((16385, 3), np.float32)
-    with pytest.raises(gpu.SlideError):
-        gpu.submap_knn(cloud, np.zeros(3), 10)
+    """The map is unbounded; only K (a configuration constant: 50 / 30 / 1000 in the reference) is limited by the LDS sort buffer."""
+    cloud = np.zeros((20000, 3), np.float32)
+    assert len(gpu.submap_knn(cloud, np.zeros(3), 10)) == 10
+    with pytest.raises(gpu.SlideError, match="sort buffer"):
+        gpu.submap_knn(cloud, np.zeros(3), 16385)
+
+
+def test_assoc_sweep_batch_matches_oracle(gpu):
+    """The batched association sweep at the headline sizes (BASELINE configs[3]: N_map = 10 k, K = 1000, N_obs = 20) over 5000 query
+    frames: identical map indices to the oracle's getSubmap + matchEllipsoidModels per frame."""
+    rng = np.random.default_rng(77)
+    n_map, K, n_obs, n_q = 10000, 1000, 20, 5000
+    model = np.column_stack([rng.uniform(0, 440, n_map), rng.uniform(0, 220, n_map), rng.normal(0, 0.3, n_map)])
+    cloud = (model + rng.normal(0, 0.05, model.shape)).astype(np.float32)        # first-seen positions differ from the refined models
+    label = rng.integers(1, 7, n_map).astype(np.int32)
+    qpos = np.column_stack([rng.uniform(0, 440, n_q), rng.uniform(0, 220, n_q), np.full(n_q, 2.0)])
+    obs = np.zeros((n_q, n_obs, 3)); olab = np.zeros((n_q, n_obs), np.int32)
+    d2 = None
+    for i in range(n_q):
+        d2 = ((model[:, :2] - qpos[i, :2]) ** 2).sum(1)
+        near = np.argpartition(d2, n_obs)[:n_obs]
+        obs[i] = model[near] + rng.normal(0, 0.1, (n_obs, 3))
+        olab[i] = label[near]
+        olab[i, ::7] = (olab[i, ::7] % 6) + 1                                    # some detections carry the wrong label
+        obs[i, 3] += 5.0                                                         # and one is off by more than the threshold
+    got, ms = gpu.assoc_sweep_batch(cloud, model, label, qpos, obs, olab, K, 0.75)
+    assert got.shape == (n_q, n_obs) and ms > 0
+    L = po.lib()
+    sub = np.zeros(K, np.int32)
+    exp = np.full(n_obs, -1, np.int32)
+    n_match = 0
+    for i in range(0, n_q, 5):                                                   # every fifth frame through the oracle (seconds)
+        k = L.orc_knn_f32(_p(cloud), C.c_int(n_map), _p(qpos[i]), C.c_int(K), _p(sub))
+        assert k == K
+        sm = np.ascontiguousarray(model[sub]); sl = np.ascontiguousarray(label[sub])
+        L.orc_match_boxes(C.c_int(2), C.c_int(n_obs), _p(np.ascontiguousarray(obs[i])), _p(np.ascontiguousarray(olab[i])), C.c_int(K),
+                          _p(sm), _p(sl), C.c_double(0.75), _p(exp))
+        want = np.where(exp >= 0, sub[np.maximum(exp, 0)], -1)
+        assert np.array_equal(got[i], want), i
+        n_match += int((want >= 0).sum())
+    assert n_match > 0.5 * (n_q // 5) * n_obs
 
 
 def _p(a):
