@@ -12,6 +12,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+T0 = time.perf_counter()
+
+
+def say(*a):
+    print(f"[{time.perf_counter() - T0:7.1f}s]", *a, file=sys.stderr, flush=True)
+
+
 def ingest(shard, log, mode):
     """All frames at their ground-truth poses without per-frame solves (association against the un-refined map), one solve at the
     end: the same graph on the product and on the oracle in seconds (what bench.py --ingest-only and its cpu_baseline leg do)."""
@@ -47,7 +54,9 @@ def c4_parity(out, preset="C4", passes=3):
         for a, lg in zip(sh, logs):
             ingest(a, lg, s.FRAME_FOREIGN)
         return sh
+    say("building 2 x", R, "GPU shards")
     A, B = gpu_shards(), gpu_shards()
+    say("GPU shards built")
     batch = s.CholBatch(R)
     for t, a in enumerate(A):
         a.graph.join_chol_batch(batch, t)
@@ -55,20 +64,26 @@ def c4_parity(out, preset="C4", passes=3):
     bufB, infoB = setup_local_shards(B, gpu_matcher, device=dev)
     dA = PassDriver(A, bufA, infoA["n_slots"], batch=batch, device=dev)
     dB = PassDriver(B, bufB, infoB["n_slots"], device=dev)
+    say("GPU shards associated:", infoA["n_slots"], "slots")
     L = po.lib(native=True)
     O = [po.OracleBackend(po.OrcParams.default(num_threads=min(os.cpu_count() or 1, 16)), 1, L=L) for _ in range(R)]
     for o, lg in zip(O, logs):
         ingest(o, lg, 2)
+    say("oracle shards built")
     bufO, infoO = setup_local_shards(O, oracle_matcher)
     dO = PassDriver(O, bufO, infoO["n_slots"])
+    say("oracle shards associated:", infoO["n_slots"], "slots")
     res = dict(n_slots=[infoA["n_slots"], infoB["n_slots"], infoO["n_slots"]], n_global=[list(map(int, infoA["n_global"])), list(map(int, infoO["n_global"]))],
                batched_vs_unbatched=[], batched_vs_oracle=[], chol_dim=A[0].graph.stats()["chol_dim"], t_pass_batched_ms=[])
     for _ in range(passes):
         t0 = time.perf_counter()
         dA.one_pass()
         res["t_pass_batched_ms"].append((time.perf_counter() - t0) * 1e3)
+        say("batched pass done")
         dB.one_pass()
+        say("un-batched pass done")
         dO.one_pass()
+        say("oracle pass done")
         a, b, o = poses_of(A, P), poses_of(B, P), poses_of(O, P)
         res["batched_vs_unbatched"].append(float(np.abs(a - b).max() / np.abs(b).max()))
         nrm = np.linalg.norm(o.reshape(R, -1), axis=1)
@@ -95,6 +110,7 @@ def c3_joint(out, preset="C3", gn=12):
     t0 = time.perf_counter()
     replay_multi(gb, data, own_node_factory=lambda: s.SlideBackend(s.default_params(), 1))
     t_replay = time.perf_counter() - t0
+    say("joint replica replayed", t_replay)
     gb.graph.gauss_newton(gn)
     P = cfg.poses_per_robot
     poses = np.array([[gb.graph.get_pose12(r, k)[1] for k in range(P)] for r in range(cfg.robots)])
@@ -126,14 +142,18 @@ def c5_stream(out, preset="C4", ticks=None, budget_ms=100.0):
     nodes = [s.SlideBackend(s.default_params(number_of_robots=2), 2) for _ in range(R)]
     prev = [IDENT7.copy() for _ in range(R)]
     lat = np.zeros((T, R))
+    say("key poses of the", R, "own nodes replayed")
     for k in range(T):
+        if k % 100 == 0:
+            say("tick", k, "max latency so far", float(lat.max()), "ms")
         for r in range(R):
             nd, o = nodes[r], nbr[r]
             t0 = time.perf_counter()
             rr = nd.process_frame(0, logs[r]["rel7"][k], prev[r], frame_detections(logs[r], k), s.FRAME_HOST_DEFERRED)
-            assert rr["status"] == 0
+            assert rr["status"] == 0, (k, r, "host frame", rr["status"], s.api.last_error(), nd.graph.stats())
             nd.process_frame(1, logs[o]["rel7"][k], kposes[o][k], frame_detections(logs[o], k), s.FRAME_FOREIGN)
-            assert nd.ingest_solve() == 0
+            st_i = nd.ingest_solve()
+            assert st_i == 0, (k, r, "ingest", st_i, s.api.last_error(), nd.graph.stats())
             st, pose = nd.end_frame(0)
             assert st == 0
             lat[k, r] = (time.perf_counter() - t0) * 1e3
@@ -147,7 +167,52 @@ def c5_stream(out, preset="C4", ticks=None, budget_ms=100.0):
     json.dump(res, open(out, "w"))
 
 
+def c3_converge(out, preset="C3", passes=400, every=20):
+    """Convergence of the sharded block-Jacobi passes to the joint replica's optimum (diagnostic)."""
+    import torch
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)
+    import slide_slam_amd as s
+    from slide_slam_amd.distributed import PassDriver, gpu_matcher, setup_local_shards
+    from slide_slam_amd.replay import replay_multi, replay_single
+    from slide_slam_amd.synth import SynthConfig, make_dataset
+    cfg = SynthConfig.preset(preset)
+    data = make_dataset(cfg)
+    data["relmeas"] = []
+    R, P = cfg.robots, cfg.poses_per_robot
+    gb = s.SlideBackend(s.default_params(number_of_robots=R), R)
+    replay_multi(gb, data, own_node_factory=lambda: s.SlideBackend(s.default_params(), 1))
+    prevj = None
+    for it in range(30):
+        gb.graph.gauss_newton(1)
+        joint = np.array([[gb.graph.get_pose12(r, k)[1] for k in range(P)] for r in range(R)])
+        if prevj is not None:
+            say("joint GN", it, "step", float(np.abs(joint - prevj).max()))
+        prevj = joint
+    shards = [s.SlideBackend(s.default_params(), 1) for _ in range(R)]
+    for sh, lg in zip(shards, data["logs"]):
+        replay_single(sh, lg, collect=False)
+    batch = s.CholBatch(R)
+    for t, sh in enumerate(shards):
+        sh.graph.join_chol_batch(batch, t)
+    bufs, info = setup_local_shards(shards, gpu_matcher, device=dev)
+    drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, device=dev)
+    nrm = np.linalg.norm(joint.reshape(R, -1), axis=1)
+    hist = []
+    for p in range(passes):
+        drv.one_pass()
+        if (p + 1) % every == 0 or p < 5:
+            d = poses_of(shards, P)
+            e = float((np.linalg.norm((d - joint).reshape(R, -1), axis=1) / nrm).max())
+            hist.append((p + 1, e))
+            say("pass", p + 1, "rel err vs joint", e)
+    for sh in shards:
+        sh.graph.join_chol_batch(None)
+    json.dump(dict(hist=hist, n_slots=info["n_slots"]), open(out, "w"))
+
+
 if __name__ == "__main__":
-    fn = {"c4_parity": c4_parity, "c3_joint": c3_joint, "c5_stream": c5_stream}[sys.argv[1]]
+    fn = {"c4_parity": c4_parity, "c3_joint": c3_joint, "c5_stream": c5_stream, "c3_converge": c3_converge}[sys.argv[1]]
     extra = [int(a) if a.lstrip("-").isdigit() else a for a in sys.argv[3:]]
     fn(sys.argv[2], *extra)
