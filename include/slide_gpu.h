@@ -110,6 +110,10 @@ int slide_graph_get_landmark(slide_graph_t* g, int cls, uint64_t idx, double* ou
 int slide_graph_get_pose_covariance(slide_graph_t* g, int robot, uint64_t idx, double cov36[36]);
 /* counts: [poses, landmarks, factors, relinearised vars in the last solve, chol dim] */
 int slide_graph_stats(slide_graph_t* g, int64_t out5[5]);
+/* Sum of squared whitened residuals of every factor at the current estimate (= 2 x gtsam::NonlinearFactorGraph::error of the graph
+ * ISAM2 holds): out4 = {total, prior factors, Between factors, landmark factors}.  Commits delta into the linearisation point and
+ * relinearises (the estimate itself does not move); pending factors are merged first. */
+int slide_graph_chi2(slide_graph_t* g, double out4[4]);
 /* isam->update(fgraph, fvalues) (graph.cpp:262) throws when a factor names a key that is in neither the graph nor fvalues, and when a
  * value is inserted under a key that exists already.  Here such an entry is refused, the rest of the update is merged, and the call
  * that consumed it (solve, gauss_newton, dist_phase 0 / 20, set_shared, set_ghosts, chol_batch_pass) returns SLIDE_ERR_INVALID with the
@@ -162,6 +166,22 @@ int slide_chol_batch_pass(slide_chol_batch_t* b, double* const* d_bufs);
  * slide_chol_batch_stream: the hipStream_t (as void*) the parts run on. */
 int slide_chol_batch_pass_part(slide_chol_batch_t* b, double* const* d_bufs, int part);
 void* slide_chol_batch_stream(slide_chol_batch_t* b);
+/* Joint Gauss-Newton step over the robots (what the reference's replica computes: solve() on ONE graph holding every robot,
+ * graph.cpp:260-272 + sloamNode.cpp:912-1002).  With iterations = 0 a pass solves every robot's own reduced pose system only — block
+ * Jacobi over robots, which stops converging once the robots share more than a few landmarks.  With iterations > 0 the pass runs
+ * that many preconditioned conjugate-gradient iterations on the GLOBAL reduced system after the factorisations (the robots' factors
+ * are the preconditioner; the coupling through the shared landmarks is applied matrix-free), two all-reduces per iteration
+ * (9 doubles per shared slot, then 2 scalars).  A cut pass then reads
+ *     part 0 | AR 54 n | part 1 | { AR 9 n | part 10 | AR 2 | part 11 (12 on the last iteration) } x iterations | AR 9 n | part 2
+ * and the un-batched path (slide_graph_set_pcg on every graph)
+ *     phase 0 | AR 54 n | phase 1 | { AR 9 n | phase 31 | AR 2 | phase 32 (33 last) } x iterations | AR 9 n | phase 2
+ * with every all-reduce on the first max(1, ..) doubles of the exchange buffer. */
+int slide_chol_batch_set_pcg(slide_chol_batch_t* b, int iterations);
+int slide_graph_set_pcg(slide_graph_t* g, int iterations);
+/* Scalars of the last joint solve this graph took part in: out8 = {gamma of the last but one iteration, alpha of it, alpha, beta of the
+ * last iteration, gamma of the FIRST iteration, gamma of the last; 0, 0} with gamma = r^T M^-1 r (M = the robots' own factors), summed
+ * over all robots: gamma_last / gamma_first is the squared reduction of the preconditioned residual. */
+int slide_graph_get_pcg_stats(slide_graph_t* g, double out8[8]);
 /* Measurement aid: the same pass issued without the graph, HIP events around the batched step kernels; *ms_steps = their device time
  * (launch gaps included), *n_launches = their number. */
 int slide_chol_batch_profile(slide_chol_batch_t* b, double* const* d_bufs, double* ms_steps, int* n_launches);

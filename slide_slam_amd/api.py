@@ -28,7 +28,7 @@ EXPORTS = [
     "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
     "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
-    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
+    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_graph_get_pcg_stats", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
     "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
     "slide_dense_spd_solve", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device", "slide_assoc_sweep_batch",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
@@ -250,6 +250,21 @@ class SlideGraph:
         """Share the dense factor + solve of phase 1 with the other graphs of `batch` (CholBatch; None leaves it)."""
         _check(self.L.slide_graph_join_chol_batch(self.h, C.c_void_p(batch.h if batch is not None else None), C.c_int(slot)))
 
+    def set_pcg(self, iterations):
+        """Un-batched passes: PCG iterations of the joint solve (dist_phase 31 / 32 / 33 between phases 1 and 2); 0 = block solves only."""
+        _check(self.L.slide_graph_set_pcg(self.h, C.c_int(iterations)))
+
+    def chi2(self):
+        """Sum of squared whitened residuals at the current estimate: dict(total, prior, between, landmark)."""
+        out = np.zeros(4)
+        _check(self.L.slide_graph_chi2(self.h, _p(out)))
+        return dict(total=out[0], prior=out[1], between=out[2], landmark=out[3])
+
+    def pcg_stats(self):
+        out = np.zeros(8)
+        _check(self.L.slide_graph_get_pcg_stats(self.h, _p(out)))
+        return dict(alpha=out[2], beta=out[3], gamma_first=out[4], gamma_last=out[5])
+
     def dist_pass_local(self, d_buf_ptr):
         """One distributed pass with device-side exchanges: every robot of the job must be in this graph's CholBatch."""
         return _check(self.L.slide_graph_dist_pass_local(self.h, C.c_void_p(d_buf_ptr)))
@@ -286,6 +301,10 @@ class CholBatch:
         """One distributed pass of all joined graphs from this thread; buf_ptrs[i] = device address of slot i's exchange buffer."""
         arr = (C.c_void_p * len(buf_ptrs))(*[int(p) for p in buf_ptrs])
         return _check(self.L.slide_chol_batch_pass(C.c_void_p(self.h), arr))
+
+    def set_pcg(self, iterations):
+        """PCG iterations of the joint solve after the factorisations (0 = every robot's own block solve only)."""
+        _check(self.L.slide_chol_batch_set_pcg(C.c_void_p(self.h), C.c_int(iterations)))
 
     def pass_part(self, buf_ptrs, part):
         """Part 0 / 1 / 2 of the pass cut at its two exchanges (jobs that span GPUs): the caller's all-reduce of buffer 0 goes onto

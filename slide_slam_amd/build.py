@@ -22,6 +22,7 @@ SOURCES = [
     # VGPR-form MFMA: the factorisation edits single registers of accumulator tiles between MFMAs; with the default
     # AGPR destinations every such edit costs v_accvgpr copies and hazard nops
     ("chol_kernels.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),
+    ("pcg_kernels.hip", []),
     ("assoc_kernels.hip", ["-ffp-contract=off"]),
     ("place_kernels.hip", ["-ffp-contract=off"]),
     ("host_graph.hip", ["-ffp-contract=off"]),
@@ -43,13 +44,18 @@ def _deps_newer(obj: str, src: str) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, stamps: bool = False) -> str:
+    """stamps: an EXPERIMENT copy of the library (_lib/exp_stamps.so, -DSLIDE_STAMPS: in-kernel time stamps read back through
+    slide_debug_*_stamps; tools/stamps2.py, tools/assoc_stamps.py) — never loaded by the package."""
     os.makedirs(OUT_DIR, exist_ok=True)
     objs = []
     procs = []
+    lib_path = os.path.join(OUT_DIR, "exp_stamps.so") if stamps else LIB
     for name, extra in SOURCES:
         src = os.path.join(CSRC, name)
-        obj = os.path.join(OUT_DIR, name.replace(".hip", ".o"))
+        obj = os.path.join(OUT_DIR, name.replace(".hip", ".stamps.o" if stamps else ".o"))
+        if stamps:
+            extra = [*extra, "-DSLIDE_STAMPS"]
         objs.append(obj)
         if force or _deps_newer(obj, src):
             cmd = [HIPCC, *COMMON, *extra, "-c", src, "-o", obj]
@@ -66,11 +72,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(f"--- {name} ---\n{out}")
     if failed:
         raise RuntimeError("hipcc failed")
-    if procs or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB, *objs]
+    if procs or not os.path.exists(lib_path):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", lib_path, *objs]
         subprocess.run(cmd, check=True)
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, stamps="--stamps" in sys.argv))

@@ -16,10 +16,20 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 
+#include <algorithm>
+
 #include "kernels.hpp"
 #include "sl_math.hpp"
 
 namespace sl {
+
+#ifdef SLIDE_STAMPS
+// experiment builds (python -m slide_slam_amd.build --stamps): phase time stamps of workgroup 0 (100 MHz wall clock)
+__device__ unsigned long long g_assoc_stamps[16];
+#define ASTAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) g_assoc_stamps[i] = wall_clock64(); } while (0)
+#else
+#define ASTAMP(i)
+#endif
 
 __device__ inline double cyl_distance(const double* model, int mlabel, const double* tgt, int tlabel) {
   // Cylinder::distance cylinder.cpp:187-224 (model = map object, tgt = detection)
@@ -44,6 +54,7 @@ struct AssocCore {
   int gate;                  // 1: K-NN gate (getSubmap); 0: the submap is the map itself in the caller's order (pure matcher)
   int Kp;                    // sort buffer length: power of two >= min(K, n)   (gate only)
   int cached;                // the n distance words fit in LDS next to the sort buffer
+  int staged;                // the K survivors' models + labels fit in LDS (same region as the distance words, which are dead by then)
   double thresh, best_init; int label_gate, is_cyl;
   const double* qpos;        // 3: robot position (double; narrowed to float like PointT)
   const double* det_world;   // cyl: 7 per ; box: xyz taken at stride `det_stride` offset `det_off`
@@ -52,7 +63,8 @@ struct AssocCore {
   int32_t* match_sub; int32_t* match_map; int32_t* submap; int32_t* n_sub;      // match_sub / submap / n_sub may be null
 };
 
-// dynamic LDS: [sel: Kp x 8 B][hist: 256 x 4 B][distance cache: n x 4 B when cached]
+// dynamic LDS: [sel: Kp x 8 B][hist: 256 x 4 B][region: distance cache (n x 4 B, during the select) / the survivors' models
+// (Ksub x stride doubles) + labels (Ksub x 4 B) for the matching]
 extern __shared__ unsigned long long assoc_lds[];
 
 __device__ __forceinline__ unsigned dist_bits(const AssocCore& C, int i, float qx, float qy, float qz) {
@@ -75,6 +87,7 @@ __device__ inline int knn_select(const AssocCore& C, unsigned long long* sel, un
     for (int i = tid; i < n; i += nthr) dcache[i] = dist_bits(C, i, qx, qy, qz);
   if (tid == 0) { s_prefix = 0ull; s_krem = Ksub; s_stop = 0; s_cnt = 0; }
   __syncthreads();
+  ASTAMP(1);
   auto key_at = [&](int i) -> unsigned long long {
     const unsigned b = C.cached ? dcache[i] : dist_bits(C, i, qx, qy, qz);
     return ((unsigned long long)b << 32) | (unsigned)i;
@@ -137,6 +150,7 @@ __device__ inline int knn_select(const AssocCore& C, unsigned long long* sel, un
       if (s_stop) break;
     }
   }
+  ASTAMP(2);
   // compaction of the selected keys (any order), then the sort that orders them
   {
     const unsigned long long lim = shift < 64 ? (s_prefix >> shift) : 0ull;
@@ -159,6 +173,7 @@ __device__ inline int knn_select(const AssocCore& C, unsigned long long* sel, un
   }
   for (int i = Ksub + tid; i < C.Kp; i += nthr) sel[i] = ~0ull;
   __syncthreads();
+  ASTAMP(3);
   for (int k = 2; k <= C.Kp; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int i = tid; i < C.Kp; i += nthr) {
@@ -172,11 +187,13 @@ __device__ inline int knn_select(const AssocCore& C, unsigned long long* sel, un
       __syncthreads();
     }
   }
+  ASTAMP(4);
   return Ksub;
 }
 
 __device__ inline void assoc_core(const AssocCore& C) {
   const int tid = threadIdx.x, nthr = blockDim.x;
+  ASTAMP(0);
   unsigned long long* sel = assoc_lds;
   unsigned* hist = reinterpret_cast<unsigned*>(assoc_lds + (C.gate ? C.Kp : 0));
   unsigned* dcache = hist + 256;
@@ -187,6 +204,22 @@ __device__ inline void assoc_core(const AssocCore& C) {
       for (int s = tid; s < Ksub; s += nthr) C.submap[s] = (int32_t)(sel[s] & 0xffffffffull);
   }
   if (tid == 0 && C.n_sub) *C.n_sub = Ksub;
+  // the submap's models and labels into LDS, gathered by all threads at once: the matching below would otherwise walk them with
+  // one dependent global gather per candidate and lane (latency-bound: ~16 round trips per detection)
+  const int ms = C.is_cyl ? 7 : 3;
+  double* cand = reinterpret_cast<double*>(dcache);
+  int* cand_lab = reinterpret_cast<int*>(cand + (size_t)Ksub * ms);
+  const bool staged = C.gate && C.staged;
+  if (staged) {
+    __syncthreads();                      // (the select's last reads of the distance words are done)
+    for (int s = tid; s < Ksub; s += nthr) {
+      const int mi = (int)(sel[s] & 0xffffffffull);
+      for (int k = 0; k < ms; ++k) cand[(size_t)s * ms + k] = C.model[(size_t)ms * mi + k];
+      cand_lab[s] = C.label[mi];
+    }
+    __syncthreads();
+  }
+  ASTAMP(5);
   // one wavefront per detection
   const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
   for (int o = wave; o < C.n_det; o += nwave) {
@@ -196,14 +229,15 @@ __device__ inline void assoc_core(const AssocCore& C) {
     const double* dw = C.det_world + (size_t)o * C.det_stride + C.det_off;
     for (int s = lane; s < Ksub; s += 64) {
       const int mi = C.gate ? (int)(sel[s] & 0xffffffffull) : s;
+      const double* mm = staged ? cand + (size_t)s * ms : C.model + (size_t)ms * mi;
+      const int ml = staged ? cand_lab[s] : C.label[mi];
       double d;
       bool consider = true;
       if (C.is_cyl) {
-        d = cyl_distance(C.model + 7 * (size_t)mi, C.label[mi], dw - C.det_off, ol);
+        d = cyl_distance(mm, ml, dw - C.det_off, ol);
       } else {
-        if (C.label_gate == 1 && C.label[mi] != ol) consider = false;
-        const double dx = dw[0] - C.model[3 * (size_t)mi], dy = dw[1] - C.model[3 * (size_t)mi + 1],
-                     dz = dw[2] - C.model[3 * (size_t)mi + 2];
+        if (C.label_gate == 1 && ml != ol) consider = false;
+        const double dx = dw[0] - mm[0], dy = dw[1] - mm[1], dz = dw[2] - mm[2];
         d = sqrt(dx * dx + dy * dy + dz * dz);
       }
       // sequential rule: "if (d < bestDist)" scanning s upward -> lexicographic min over (d, s) of the
@@ -222,7 +256,11 @@ __device__ inline void assoc_core(const AssocCore& C) {
       C.match_map[o] = ok ? (C.gate ? (int32_t)(sel[bests] & 0xffffffffull) : bests) : -1;
     }
   }
+  ASTAMP(6);
 }
+#ifdef SLIDE_STAMPS
+extern "C" void slide_debug_assoc_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_assoc_stamps), sizeof(g_assoc_stamps)); }
+#endif
 
 // grid = 3 (cylinders, cubes, ellipsoids of ONE key frame)
 __global__ __launch_bounds__(1024) void k_assoc_frame(const AssocFrameDev* __restrict__ cls3, const double* __restrict__ pose12) {
@@ -247,7 +285,7 @@ __global__ __launch_bounds__(1024) void k_assoc_frame(const AssocFrameDev* __res
   __syncthreads();
   AssocCore C;
   C.cx = F.cx; C.cy = F.cy; C.cz = F.cz; C.model = F.model; C.label = F.label; C.n = F.n; C.K = F.K;
-  C.gate = F.gate; C.Kp = F.Kp; C.cached = F.cached;
+  C.gate = F.gate; C.Kp = F.Kp; C.cached = F.cached; C.staged = F.staged;
   C.thresh = F.thresh; C.best_init = F.best_init; C.label_gate = F.label_gate; C.is_cyl = F.is_cyl;
   C.qpos = pose12 + 9;
   C.det_world = F.det_world;
@@ -264,11 +302,11 @@ __global__ __launch_bounds__(1024) void k_assoc_sweep(const float* __restrict__ 
                                                       const double* __restrict__ model_xyz, const int32_t* __restrict__ label, int n_map,
                                                       const double* __restrict__ query_pos, const double* __restrict__ obs_xyz,
                                                       const int32_t* __restrict__ obs_label, int n_obs, int K, int Kp, int cached,
-                                                      double thresh, int32_t* __restrict__ out_map_idx) {
+                                                      int staged, double thresh, int32_t* __restrict__ out_map_idx) {
   const int q = blockIdx.x;
   AssocCore C;
   C.cx = cx; C.cy = cy; C.cz = cz; C.model = model_xyz; C.label = label; C.n = n_map; C.K = K;
-  C.gate = 1; C.Kp = Kp; C.cached = cached;
+  C.gate = 1; C.Kp = Kp; C.cached = cached; C.staged = staged;
   C.thresh = thresh; C.best_init = 1000.0; C.label_gate = 1; C.is_cyl = 0;
   C.qpos = query_pos + 3 * (size_t)q;
   C.det_world = obs_xyz + 3 * (size_t)q * n_obs;
@@ -305,9 +343,10 @@ static void ensure_lds_attr() {
   g_attr_set = true;
 }
 
-// LDS plan of one class: sort buffer length, whether the distance words are cached, bytes.  false: K exceeds the sort buffer.
-bool assoc_plan(int n, int K, int gate, int* Kp, int* cached, size_t* bytes) {
-  *Kp = 0; *cached = 0; *bytes = 0;
+// LDS plan of one class: sort buffer length, whether the distance words are cached during the select, whether the K survivors'
+// models are staged for the matching (the two share one region), bytes.  false: K exceeds the sort buffer.
+bool assoc_plan(int n, int K, int gate, int model_stride, int* Kp, int* cached, int* staged, size_t* bytes) {
+  *Kp = 0; *cached = 0; *staged = 0; *bytes = 0;
   if (!gate || n <= 0) return true;
   const int Ksub = K < n ? K : n;
   if (Ksub > ASSOC_MAX_K) return false;
@@ -315,8 +354,10 @@ bool assoc_plan(int n, int K, int gate, int* Kp, int* cached, size_t* bytes) {
   while (p < Ksub) p <<= 1;
   *Kp = p;
   const size_t fixed = (size_t)p * 8 + 256 * 4;
-  *cached = fixed + (size_t)n * 4 <= (size_t)ASSOC_LDS_BUDGET ? 1 : 0;
-  *bytes = fixed + (*cached ? (size_t)n * 4 : 0);
+  const size_t dc = (size_t)n * 4, st = ((size_t)Ksub * (model_stride * 8 + 4) + 7) / 8 * 8;
+  *cached = fixed + dc <= (size_t)ASSOC_LDS_BUDGET ? 1 : 0;
+  *staged = fixed + st <= (size_t)ASSOC_LDS_BUDGET ? 1 : 0;
+  *bytes = fixed + std::max(*cached ? dc : 0, *staged ? st : 0);
   return true;
 }
 
@@ -329,11 +370,11 @@ int launch_assoc_sweep(const float* cx, const float* cy, const float* cz, const 
                        const double* query_pos, const double* obs_xyz, const int32_t* obs_label, int n_query, int n_obs,
                        int K, double thresh, int32_t* out_map_idx, hipStream_t s) {
   ensure_lds_attr();
-  int Kp, cached;
+  int Kp, cached, staged;
   size_t bytes;
-  if (!assoc_plan(n_map, K, 1, &Kp, &cached, &bytes)) return -1;
+  if (!assoc_plan(n_map, K, 1, 3, &Kp, &cached, &staged, &bytes)) return -1;
   hipLaunchKernelGGL(k_assoc_sweep, dim3(n_query), dim3(1024), bytes, s, cx, cy, cz, model_xyz, label, n_map, query_pos, obs_xyz,
-                     obs_label, n_obs, K, Kp, cached, thresh, out_map_idx);
+                     obs_label, n_obs, K, Kp, cached, staged, thresh, out_map_idx);
   return 0;
 }
 

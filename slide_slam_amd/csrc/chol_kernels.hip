@@ -836,6 +836,168 @@ __global__ __launch_bounds__(256) void k_chol_bwd_chain_batched(BwdBatchArgs A) 
 }
 
 
+// ---- forward substitution L x = r on the finished factor, ONE launch (the mirror image of bwd_chain_body) ----------------------------
+// The preconditioner of the joint solve (pcg_kernels.hip) applies S_a^-1 = L^-T L^-1 to vectors other than the right-hand side
+// that rode through the factorisation.  Ticket t owns block row c = t: x_c = L_cc^-1 (r_c - sum_{j < c} L(c, j) x_j), the x_j
+// polled from `xout` (pre-filled with the sentinel) as the lower tickets publish them; tiles L(c, j) prefetched three ahead.
+__device__ __forceinline__ void fwd_chain_body(const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
+                                               const double* __restrict__ Winv, const double* __restrict__ rin, double* xout, int* status, int c) {
+  __shared__ double Ms[NB][NB + 1];     // M = L_cc^-1 (lower triangle), Ms[row][col]
+  __shared__ double Lo[6][256];
+  __shared__ double Ws[4][256];
+  __shared__ double tmp[3][256];
+  __shared__ double xs[2][NB];
+  __shared__ double red[4][NB];
+  __shared__ double ys[NB];
+  const int tid = threadIdx.x;
+  const int row = tid & 63, cp = tid >> 6;             // tile work: row `row`, columns 16 cp .. 16 cp + 15
+  const int nj = c;                                    // tiles (c, j), j = 0 .. c-1
+  constexpr int RB = 3;
+  double tr[RB][16];
+  const double* tbase = S + (size_t)(16 * cp) * ld + (size_t)c * NB + row;     // + (j * NB + r) * ld
+#pragma unroll
+  for (int q = 0; q < RB; ++q) {
+    if (q < nj) {
+      const double* tp = tbase + (size_t)(q * NB) * ld;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tr[q][r] = tp[(size_t)r * ld];
+    }
+  }
+  const double r0 = rin[c * NB + row];
+  {
+    const double* Ldk = Ld + (size_t)c * NB * NB;
+    const double* Wk = Winv + (size_t)c * 1024;
+#pragma unroll
+    for (int b = 1; b < 4; ++b)
+#pragma unroll
+      for (int a = 0; a < b; ++a) Lo[b * (b - 1) / 2 + a][tid] = Ldk[(size_t)(16 * a + (tid >> 4)) * NB + 16 * b + (tid & 15)];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) Ws[b][tid] = Wk[(size_t)b * 256 + tid];
+  }
+  __syncthreads();
+  {
+    const int r = tid & 15, cc = tid >> 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) Ms[16 * b + r][16 * b + cc] = Ws[b][cc * 16 + r];
+    __syncthreads();
+#pragma unroll
+    for (int d = 1; d < 4; ++d) {
+#pragma unroll
+      for (int a = 0; a + d < 4; ++a) {
+        const int b = a + d;
+        double t = 0.0;
+#pragma unroll
+        for (int m = a; m < b; ++m)
+#pragma unroll
+          for (int n = 0; n < 16; ++n) t += Lo[b * (b - 1) / 2 + m][n * 16 + r] * Ms[16 * m + n][16 * a + cc];
+        tmp[a][cc * 16 + r] = t;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int a = 0; a + d < 4; ++a) {
+        const int b = a + d;
+        double v = 0.0;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) v += Ws[b][n * 16 + r] * tmp[a][cc * 16 + n];
+        Ms[16 * b + r][16 * a + cc] = -v;
+      }
+      __syncthreads();
+    }
+  }
+  double acc = 0.0;
+  for (int q0 = 0; q0 < nj; q0 += RB) {
+#pragma unroll
+    for (int qq = 0; qq < RB; ++qq) {
+      const int q = q0 + qq;
+      if (q < nj) {
+        if (tid < NB) {
+          double v;
+          int spins = 0;
+          for (;;) {
+            v = __hip_atomic_load(xout + (size_t)q * NB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned long long)__double_as_longlong(v) != BWD_SENT) break;
+            if (++spins > (1 << 21)) {          // exit condition every wave reaches
+              v = __builtin_nan("");
+              atomicOr(&status[1], 2);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          xs[q & 1][tid] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc += tr[qq][r] * xs[q & 1][16 * cp + r];
+        if (q + RB < nj) {
+          const double* tp = tbase + (size_t)((q + RB) * NB) * ld;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tr[qq][r] = tp[(size_t)r * ld];
+        }
+      }
+    }
+  }
+  red[cp][row] = acc;
+  __syncthreads();
+  if (cp == 0) ys[row] = r0 - ((red[0][row] + red[1][row]) + (red[2][row] + red[3][row]));
+  __syncthreads();
+  double part = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int col = 16 * cp + k;
+    if (col <= row) part += Ms[row][col] * ys[col];
+  }
+  red[cp][row] = part;
+  __syncthreads();
+  if (cp == 0) {
+    const double x = (red[0][row] + red[1][row]) + (red[2][row] + red[3][row]);
+    __hip_atomic_store(xout + (size_t)c * NB + row, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// Both triangular solves of S_a^-1 for up to CHOL_BATCH_MAX systems: fwd (ticket counter status[0][5]) or bwd (status[0][4]);
+// rin / xout: per system, T * NB doubles; xout pre-filled with the sentinel, the ticket counter cleared (k_chain_prepare).
+struct ChainBatchArgs {
+  int n;
+  const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX];
+  const double* Ld[CHOL_BATCH_MAX]; const double* Winv[CHOL_BATCH_MAX]; const double* in[CHOL_BATCH_MAX]; double* out[CHOL_BATCH_MAX];
+  int* status[CHOL_BATCH_MAX];
+  int Tmax;
+};
+template <bool FWD>
+__global__ __launch_bounds__(256) void k_chain_batched(ChainBatchArgs A) {
+  for (;;) {
+    const int t = bwd_ticket(&A.status[0][FWD ? 5 : 4]);
+    if (t >= A.n * A.Tmax) return;
+    const int r = t % A.n, b = t / A.n;
+    if (b >= A.T[r]) continue;
+    if (FWD) fwd_chain_body(A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.in[r], A.out[r], A.status[r], b);
+    else bwd_chain_body(A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.in[r], A.out[r], A.status[r], b);
+    return;
+  }
+}
+__global__ void k_chain_prepare(double* out, int n, int* ticket) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && ticket) *ticket = 0;
+  if (i < n) out[i] = __longlong_as_double((long long)BWD_SENT);
+}
+// x = L^-1 in (fwd) or x = L^-T in (bwd) for every system of the batch: out[i] is sentinel-filled and the chain launched
+void launch_chain_batch(const CholSystem* d, int n, const double* const* in, double* const* out, bool fwd, hipStream_t s) {
+  ChainBatchArgs A{};
+  A.n = n;
+  int Tmax = 0, total = 0;
+  for (int i = 0; i < n; ++i) {
+    A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.Ld[i] = d[i].Ld; A.Winv[i] = d[i].Winv; A.in[i] = in[i]; A.out[i] = out[i];
+    A.status[i] = d[i].status;
+    Tmax = d[i].T > Tmax ? d[i].T : Tmax;
+    total += d[i].T;
+    const int len = d[i].T * NB;
+    hipLaunchKernelGGL(k_chain_prepare, dim3((len + 255) / 256), dim3(256), 0, s, out[i], len, i == 0 ? d[0].status + (fwd ? 5 : 4) : nullptr);
+  }
+  A.Tmax = Tmax;
+  if (total <= 0) return;
+  if (fwd) hipLaunchKernelGGL(k_chain_batched<true>, dim3(total), dim3(256), 0, s, A);
+  else hipLaunchKernelGGL(k_chain_batched<false>, dim3(total), dim3(256), 0, s, A);
+}
+
 // ---- marginal covariance of one pose (getPoseCovariance graph.cpp:314-323) ---------------------------------------------------
 // Cov = E^T S^-1 E = Y^T Y with L Y = E (E = the six unit columns of the pose): a forward substitution with six right-hand
 // sides on the finished factor (panel tiles in S, diagonal blocks as their off-diagonal 16x16 sub-tiles in Ld plus the 16x16

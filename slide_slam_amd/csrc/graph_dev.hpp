@@ -80,6 +80,11 @@ struct GraphDev {
   double* yv;        // T*NB  forward-substituted RHS
   double* dp;        // T*NB  reduced solution (delta_p = -dp)
   int* chol_ctr;     // T + 2 : work counters of the Cholesky step kernels (self-clearing)
+  // ---- joint solve over several robots (pcg_kernels.hip) --------------------------------------
+  double* S0;        // copy of S (lower triangle + padding) taken before the factorisation overwrites it: the symmetric products
+  double* pcg;       // 7 vectors of T*NB doubles: r, u, w, p, s, x, y
+  double* lm_c;      // 9 L  cross-robot part of sum_b W_b^T u_b per shared landmark (zero for the others)
+  double* pcg_scal;  // 8    gamma_old, alpha_old, alpha, beta, first gamma, last gamma
   int* status;       // [0] not-SPD flag (landmark), [1] not-SPD flag (chol), [2] #relinearised
   // ---- parameters ------------------------------------------------------------------------
   int chart;

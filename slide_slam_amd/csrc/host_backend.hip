@@ -57,7 +57,7 @@ int HostBackend::associate(const SE3& poseEstimate, const slide_detections_t& de
   for (int c = 0; c < 3; ++c) {
     ClassMap& M = maps[c];
     size_t lb = 0;
-    if (!assoc_plan(M.n(), M.K, 1, &F[c].Kp, &F[c].cached, &lb)) {
+    if (!assoc_plan(M.n(), M.K, 1, M.stride, &F[c].Kp, &F[c].cached, &F[c].staged, &lb)) {
       g_last_error = "K-NN gate: K exceeds the on-chip sort buffer (16384 neighbours)";
       return SLIDE_ERR_CAPACITY;
     }

@@ -23,6 +23,7 @@ bool hip_ok(hipError_t e, const char* what) {
 int decode_status(const int* st) {
   if (st[0]) { g_last_error = "landmark block not positive definite"; return SLIDE_ERR_NOT_SPD; }
   if (st[1] & 1) { g_last_error = "reduced pose system not positive definite"; return SLIDE_ERR_NOT_SPD; }
+  if (st[1] & 4) { g_last_error = "joint solve: the conjugate-gradient iteration broke down (coupled pose system not positive definite)"; return SLIDE_ERR_NOT_SPD; }
   if (st[1] & 2) { g_last_error = "backward substitution: a workgroup waited too long for the blocks it depends on (scheduling stall, the update was rejected)"; return SLIDE_ERR_RUNTIME; }
   return SLIDE_OK;
 }
@@ -504,6 +505,7 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
   };
   const int n_slots = graphs[0]->G.n_slots;
   const bool whole = part < 0;
+  const bool joint = pcg_iters > 0 && n_slots > 0;       // PCG over the robots' coupled systems instead of the plain block solves
   if (whole || part == 0) {
     each(0);
     if (rc == SLIDE_OK) launch_sum_bcast(d_bufs, n, 54 * n_slots, master);
@@ -514,10 +516,30 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
       if (batch_p3) launch_phase3_batched(d_Gs, hG.data(), n, d_bufs, master);      // five launches for all robots (blockIdx.z = robot)
       else each(3);
     }
+    if (rc == SLIDE_OK && joint) rc = save_systems();
     if (rc == SLIDE_OK && e0) (void)hipEventRecord(e0, master);
     if (rc == SLIDE_OK) launch_chol_batch(sys.data(), n, d_ctr, master, e1);
-    if (rc == SLIDE_OK) each(4);
-    if (rc == SLIDE_OK) launch_sum_bcast(d_bufs, n, 9 * n_slots, master);
+    if (rc == SLIDE_OK && joint) rc = enqueue_pcg_head(d_bufs);
+  }
+  if (joint) {
+    // the PCG iterations: whole pass = all of them inline; cut pass = part 10 (after the t_l exchange), part 11 / 12 (after the
+    // exchange of the two dot products; 12 = the last iteration)
+    for (int it = 0; it < pcg_iters && rc == SLIDE_OK; ++it) {
+      const bool last = it == pcg_iters - 1;
+      if (whole || (part == 10 && it == 0)) {
+        if (!whole) launch_bcast(d_bufs, n, 9 * n_slots, master);
+        rc = enqueue_pcg_mid(d_bufs);
+      }
+      if (rc == SLIDE_OK && (whole || (part == 11 && it == 0 && !last) || (part == 12 && last))) {
+        if (!whole) launch_bcast(d_bufs, n, 2, master);
+        rc = enqueue_pcg_tail(d_bufs, last);
+      }
+    }
+  }
+  if (whole || part == 1 || part == 12) {
+    const bool here = whole || (part == 1 && !joint) || (part == 12 && joint);
+    if (rc == SLIDE_OK && here) each(4);
+    if (rc == SLIDE_OK && here) launch_sum_bcast(d_bufs, n, 9 * n_slots, master);
   }
   if (whole || part == 2) {
     if (rc == SLIDE_OK && !whole) launch_bcast(d_bufs, n, 9 * n_slots, master);
@@ -637,6 +659,49 @@ int CholBatch::end_pass() {
   return SLIDE_OK;
 }
 
+void CholBatch::set_pcg(int iters) {
+  std::lock_guard<std::mutex> pl(pass_mtx);
+  std::lock_guard<std::mutex> lk(mtx);
+  pcg_iters = iters < 0 ? 0 : iters;
+  pass_dirty = true;
+}
+// S -> S0 for every joined graph (the factorisation works in place; the joint solve multiplies with the original blocks)
+int CholBatch::save_systems() {
+  for (int i = 0; i < n; ++i) {
+    const GraphDev& G = hG[i];
+    const size_t bytes = (size_t)G.ld * G.T * NB * sizeof(double);
+    if (bytes) SL_HIP(hipMemcpyAsync(G.S0, G.S, bytes, hipMemcpyDeviceToDevice, master));
+  }
+  return SLIDE_OK;
+}
+int CholBatch::enqueue_pcg_head(double* const* d_bufs) {
+  launch_pcg_init(d_Gs, hG.data(), n, master);
+  launch_pcg_tl(d_Gs, hG.data(), n, d_bufs, PCG_VEC_U, master);
+  launch_sum_bcast(d_bufs, n, 9 * hG[0].n_slots, master);
+  return SLIDE_OK;
+}
+int CholBatch::enqueue_pcg_mid(double* const* d_bufs) {
+  launch_pcg_matvec_dots(d_Gs, hG.data(), n, d_bufs, master);
+  launch_sum_bcast(d_bufs, n, 2, master);
+  return SLIDE_OK;
+}
+int CholBatch::enqueue_pcg_tail(double* const* d_bufs, bool last) {
+  launch_pcg_update(d_Gs, hG.data(), n, d_bufs, master);
+  if (last) {
+    launch_pcg_finish(d_Gs, hG.data(), n, master);
+    return SLIDE_OK;
+  }
+  const double* in[CHOL_BATCH_HOST_MAX];
+  double* out[CHOL_BATCH_HOST_MAX];
+  for (int i = 0; i < n; ++i) { in[i] = hG[i].pcg + (size_t)PCG_VEC_R * hG[i].T * NB; out[i] = hG[i].pcg + (size_t)PCG_VEC_Y * hG[i].T * NB; }
+  launch_chain_batch(sys.data(), n, in, out, true, master);
+  for (int i = 0; i < n; ++i) { in[i] = out[i]; out[i] = hG[i].pcg + (size_t)PCG_VEC_U * hG[i].T * NB; }
+  launch_chain_batch(sys.data(), n, in, out, false, master);
+  launch_pcg_tl(d_Gs, hG.data(), n, d_bufs, PCG_VEC_U, master);
+  launch_sum_bcast(d_bufs, n, 9 * hG[0].n_slots, master);
+  return SLIDE_OK;
+}
+
 hipStream_t CholBatch::pass_stream() {
   std::lock_guard<std::mutex> pl(pass_mtx);
   if (!master) {
@@ -659,7 +724,8 @@ int CholBatch::pass_all(double* const* d_bufs) {
 // The pass in three stream-ordered parts for a job that spans GPUs (see enqueue_pass): parts 0 and 1 return without a host
 // synchronisation — the caller's collective goes onto stream() behind them — part 2 ends with the one synchronisation of the pass.
 int CholBatch::pass_part(double* const* d_bufs, int part) {
-  if (part < 0 || part > 2) return SLIDE_ERR_INVALID;
+  const int slot = part >= 0 && part <= 2 ? part : (part >= 10 && part <= 12 ? part - 7 : -1);
+  if (slot < 0) return SLIDE_ERR_INVALID;
   std::lock_guard<std::mutex> pl(pass_mtx);
   int rc;
   if (part == 0) {
@@ -669,8 +735,9 @@ int CholBatch::pass_part(double* const* d_bufs, int part) {
     g_last_error = "batched pass: part 0 has not run";
     return SLIDE_ERR_INVALID;
   }
-  if (!part_exec[part] && (rc = capture_pass(d_bufs, part, &part_exec[part])) != SLIDE_OK) return rc;
-  SL_HIP(hipGraphLaunch(part_exec[part], master));
+  if (part >= 10 && !(pcg_iters > 0 && hG[0].n_slots > 0)) return SLIDE_OK;      // no joint solve: nothing between parts 1 and 2
+  if (!part_exec[slot] && (rc = capture_pass(d_bufs, part, &part_exec[slot])) != SLIDE_OK) return rc;
+  SL_HIP(hipGraphLaunch(part_exec[slot], master));
   return part == 2 ? end_pass() : SLIDE_OK;
 }
 
@@ -854,6 +921,8 @@ int HostGraph::upload_new() {
   if (d_lm_g.ensure(std::max<size_t>(9 * Ln, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_lm_Hacc.ensure(std::max<size_t>(54 * Ln, 1), 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_lm_t.ensure(std::max<size_t>(9 * Ln, 1), 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_lm_c.ensure(std::max<size_t>(9 * Ln, 1), 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (Ln) SL_HIP(hipMemsetAsync(d_lm_c.d, 0, 9 * Ln * sizeof(double), s));      // (only the shared landmarks are ever written)
   if (d_pose_H.ensure(std::max<size_t>(36 * Pn, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_pose_g.ensure(std::max<size_t>(6 * Pn, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   std::vector<int> ptr, val;
@@ -891,6 +960,11 @@ int HostGraph::upload_new() {
     d_S.cap = 0;
     if (d_S.d) { SL_HIP(hipFree(d_S.d)); d_S.d = nullptr; }
     if (d_S.ensure(ld * (size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+    d_S0.cap = 0;
+    if (d_S0.d) { SL_HIP(hipFree(d_S0.d)); d_S0.d = nullptr; }
+    if (d_S0.ensure(ld * (size_t)Tcap * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_pcg.ensure((size_t)PCG_VEC_COUNT * Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_pcg_scal.ensure(8, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_Ld.ensure((size_t)Tcap * NB * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_Winv.ensure((size_t)Tcap * 1024, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_cctr.ensure((size_t)Tcap + 2, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
@@ -923,6 +997,7 @@ int HostGraph::upload_new() {
   G.lm_Hacc = d_lm_Hacc.d; G.lm_t = d_lm_t.d; G.n_slots = (int)h_sh_lid.size(); G.sh_lid = d_sh_lid.d; G.sh_owner = d_sh_owner.d;
   G.lm_Hinv = d_lm_Hinv.d; G.lm_g = d_lm_g.d; G.pose_H = d_pose_H.d; G.pose_g = d_pose_g.d;
   G.S = d_S.d; G.ld = (Tcap + 1) * NB; G.T = T; G.Ld = d_Ld.d; G.Winv = d_Winv.d; G.yv = d_yv.d; G.dp = d_dp.d; G.chol_ctr = d_cctr.d;
+  G.S0 = d_S0.d; G.pcg = d_pcg.d; G.lm_c = d_lm_c.d; G.pcg_scal = d_pcg_scal.d;
   G.status = d_status.d;
   G.chart = P.pose_chart;
   G.bearing_sigma = P.bearing_range_sigma; G.cyl_sigma = P.cylinder_sigma; G.numdiff_delta = P.numdiff_delta;
@@ -1029,6 +1104,7 @@ int HostGraph::set_shared(const int32_t* cls, const int64_t* idx, const int32_t*
   if (d_sh_owner.ensure(std::max(n_slots, 1), 0, stream) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_sh_lid.upload(h_sh_lid.data(), 0, n_slots, stream) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_sh_owner.upload(h_sh_owner.data(), 0, n_slots, stream) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (G.L) SL_HIP(hipMemsetAsync(d_lm_c.d, 0, 9 * (size_t)G.L * sizeof(double), stream));      // the shared set changed
   SL_HIP(hipStreamSynchronize(stream));
   G.n_slots = n_slots; G.sh_lid = d_sh_lid.d; G.sh_owner = d_sh_owner.d;
   return SLIDE_OK;
@@ -1041,8 +1117,24 @@ int HostGraph::set_shared(const int32_t* cls, const int64_t* idx, const int32_t*
 //  10: pack the owner's landmark values (15/slot)      11: unpack them (every rank adopts the owner's value)
 // Every robot solves its own reduced pose system with the GLOBAL landmark blocks (block-Jacobi over robots on
 // the Schur complement, exact gradient): the fixed point is the joint optimum.
+void HostGraph::set_pcg(int iters) {
+  pcg_iters = iters < 0 ? 0 : iters;
+  for (auto& pg : phase_graph)            // the captured phase 1 depends on it
+    if (pg.exec) { (void)hipGraphExecDestroy(pg.exec); pg.exec = nullptr; }
+}
+int HostGraph::sync_self() {
+  if (have_self && std::memcmp(&G_self, &G, sizeof(GraphDev)) == 0) return SLIDE_OK;
+  if (d_Gself.ensure(1, 0, stream) != SLIDE_OK) return SLIDE_ERR_HIP;
+  SL_HIP(hipMemcpyAsync(d_Gself.d, &G, sizeof(GraphDev), hipMemcpyHostToDevice, stream));
+  SL_HIP(hipStreamSynchronize(stream));       // (&G is host memory that may change right after)
+  G_self = G;
+  have_self = true;
+  return SLIDE_OK;
+}
+
 int HostGraph::enqueue_phase(int phase, double* d_buf) {
   hipStream_t s = stream;
+  const bool joint = pcg_iters > 0 && G.n_slots > 0 && !batch;      // un-batched joint solve: phases 31 / 32 / 33 follow phase 1
   if (phase == 0) {
     launch_relin(G, s);
     launch_linearize(G, s);
@@ -1056,12 +1148,37 @@ int HostGraph::enqueue_phase(int phase, double* d_buf) {
       launch_schur(G, s);
     }
     if (phase == 1) {
+      if (joint) SL_HIP(hipMemcpyAsync(G.S0, G.S, (size_t)G.ld * G.T * NB * sizeof(double), hipMemcpyDeviceToDevice, s));
       const int rc = factor_and_solve(s);
       if (rc != SLIDE_OK) return rc;
+      if (joint) {
+        launch_pcg_init(d_Gself.d, &G, 1, s);
+        launch_pcg_tl(d_Gself.d, &G, 1, &d_buf, PCG_VEC_U, s);
+        return SLIDE_OK;
+      }
     }
     if (phase != 3) {
       launch_backsub(G, 1, s);
       launch_shared_pack(G, 1, d_buf, s);
+    }
+  } else if (phase == 31) {          // after the exchange of t_l: w = S u, partial dots -> d_buf[0 .. 1]
+    launch_pcg_matvec_dots(d_Gself.d, &G, 1, &d_buf, s);
+  } else if (phase == 32 || phase == 33) {     // after the exchange of the dots: the updates; 32: next u, t_l -> d_buf; 33 (last): dp = x, t_l(dp) -> d_buf
+    launch_pcg_update(d_Gself.d, &G, 1, &d_buf, s);
+    if (phase == 33) {
+      launch_pcg_finish(d_Gself.d, &G, 1, s);
+      launch_backsub(G, 1, s);
+      launch_shared_pack(G, 1, d_buf, s);
+    } else {
+      const size_t nT = (size_t)G.T * NB;
+      const CholSystem cs{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status};
+      const double* in = G.pcg + PCG_VEC_R * nT;
+      double* out = G.pcg + PCG_VEC_Y * nT;
+      launch_chain_batch(&cs, 1, &in, &out, true, s);
+      in = out;
+      out = G.pcg + PCG_VEC_U * nT;
+      launch_chain_batch(&cs, 1, &in, &out, false, s);
+      launch_pcg_tl(d_Gself.d, &G, 1, &d_buf, PCG_VEC_U, s);
     }
   } else {
     launch_shared_unpack(G, 1, d_buf, s);
@@ -1112,6 +1229,7 @@ int HostGraph::dist_phase(int phase, double* d_buf) {
       rc = upload_new();
       if (rc != SLIDE_OK) return rc;
       G.relin_thr = 0.0;
+      if (pcg_iters > 0 && (rc = sync_self()) != SLIDE_OK) return rc;
       SL_HIP(hipMemsetAsync(d_status.d, 0, 8 * sizeof(int), s));     // (outside the captured sequence, as in run_update)
     }
     {
@@ -1125,6 +1243,10 @@ int HostGraph::dist_phase(int phase, double* d_buf) {
       SL_HIP(hipGetLastError());
       return decode_status(st);
     }
+  } else if (phase >= 31 && phase <= 33) {
+    if (!(pcg_iters > 0 && G.n_slots > 0) || batch || !have_self) { g_last_error = "dist_phase 31-33: the joint solve is not set up (set_pcg, phases 0 and 1 first)"; return SLIDE_ERR_INVALID; }
+    const int rc = enqueue_phase(phase, d_buf);
+    if (rc != SLIDE_OK) return rc;
   } else if (phase == 10) {
     // commit every variable (theta <- theta (+) delta, delta <- 0), then publish the owners' values
     G.relin_thr = 0.0;
@@ -1243,5 +1365,35 @@ void HostGraph::stats(int64_t* o) const {
   o[4] = (int64_t)G.T * NB;
 }
 int64_t HostGraph::rejected() const { return n_rejected; }
+// 2 x NonlinearFactorGraph::error at the CURRENT estimate: theta <- theta (+) delta, relinearise, sum r^T r
+int HostGraph::chi2(double* out4) {
+  int rc = merge_pending();
+  if (rc != SLIDE_OK) return rc;
+  rc = upload_new();
+  if (rc != SLIDE_OK) return rc;
+  for (int i = 0; i < 4; ++i) out4[i] = 0.0;
+  if (G.P == 0) return SLIDE_OK;
+  hipStream_t s = stream;
+  G.relin_thr = 0.0;
+  launch_relin(G, s);                 // theta <- theta (+) delta ...
+  SL_HIP(hipMemsetAsync(G.pose_delta, 0, 6 * (size_t)G.P * sizeof(double), s));      // ... and delta <- 0: the next update must not apply it again
+  if (G.L) SL_HIP(hipMemsetAsync(G.lm_delta, 0, 9 * (size_t)G.L * sizeof(double), s));
+  launch_linearize(G, s);
+  launch_estimate(G, s);
+  if (d_covY.ensure(8, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  launch_chi2(G, d_covY.d, s);
+  SL_HIP(hipMemcpyAsync(out4, d_covY.d, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+  SL_HIP(hipStreamSynchronize(s));
+  SL_HIP(hipGetLastError());
+  factor_valid = false;
+  return SLIDE_OK;
+}
+int HostGraph::pcg_stats(double* out8) {
+  for (int i = 0; i < 8; ++i) out8[i] = 0.0;
+  if (!d_pcg_scal.d) return SLIDE_OK;
+  SL_HIP(hipMemcpyAsync(out8, d_pcg_scal.d, 8 * sizeof(double), hipMemcpyDeviceToHost, stream));
+  SL_HIP(hipStreamSynchronize(stream));
+  return SLIDE_OK;
+}
 
 }  // namespace sl

@@ -138,7 +138,11 @@ class CholBatch {
   // joined to the batch's stream around the two device-side exchanges and the batched factor + solve, captured once and replayed
   // as ONE hipGraph per pass.  bufs[i]: exchange buffer of the graph in slot i.
   int pass_all(double* const* d_bufs);
-  int pass_part(double* const* d_bufs, int part);       // the same pass cut at its two exchanges (multi-GPU jobs); part 0, 1, 2
+  int pass_part(double* const* d_bufs, int part);       // the same pass cut at its exchanges (multi-GPU jobs): parts 0, 1, 2 and, with the joint solve, 10, 11, 12
+  // Joint solve: after the factorisations, `iters` PCG iterations on the global reduced system (pcg_kernels.hip); 0 = each robot's own
+  // block solve only (block-Jacobi over robots).  Changing it invalidates the captured launch sequences.
+  void set_pcg(int iters);
+  int pcg() const { return pcg_iters; }
   hipStream_t pass_stream();                             // the stream the passes run on (created on first use)
   int profile_pass(double* const* d_bufs, double* ms_steps, int* n_launches);
 
@@ -155,7 +159,12 @@ class CholBatch {
   std::vector<double*> bufs;
   std::vector<HostGraph*> graphs;
   hipGraphExec_t pass_exec = nullptr;
-  hipGraphExec_t part_exec[3] = {nullptr, nullptr, nullptr};
+  hipGraphExec_t part_exec[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // parts 0, 1, 2, 10, 11, 12
+  int pcg_iters = 0;
+  int enqueue_pcg_head(double* const* d_bufs);                   // r = b, u = M^-1 b, t_l(u) packed + local sum
+  int enqueue_pcg_mid(double* const* d_bufs);                    // w = S u, partial dots + local sum
+  int enqueue_pcg_tail(double* const* d_bufs, bool last);        // alpha, beta, updates; then u = M^-1 r, t_l(u) | dp = x
+  int save_systems();                                            // S -> S0 before the factorisation (joint solve only)
   std::vector<GraphDev> pass_G;
   std::vector<double*> pass_bufs;
   hipEvent_t ev_fork = nullptr;
@@ -206,8 +215,11 @@ class HostGraph {
   // one-robot-per-GPU mode: shared-landmark slots + the three phases of a distributed GN pass
   int set_shared(const int32_t* cls, const int64_t* idx, const int32_t* owner, int n_slots);
   int dist_phase(int phase, double* d_buf);
+  void set_pcg(int iters);      // un-batched passes: dist_phase 1 prepares the joint solve, 31 / 32 / 33 run it (0 = block solves only)
   void stats(int64_t* out5) const;
-  int64_t rejected() const;               // entries merge_pending refused since creation
+  int64_t rejected() const;
+  int chi2(double* out4);                 // sum of squared whitened residuals at the current estimate: total, priors, betweens, landmark factors
+  int pcg_stats(double* out8);            // scalars of the last joint solve: gamma_old, alpha_old, alpha, beta, first gamma, last gamma               // entries merge_pending refused since creation
 
   static uint64_t pose_key(int robot, uint64_t idx);
   static uint64_t lm_key(int cls, uint64_t idx);
@@ -262,6 +274,12 @@ class HostGraph {
   DevArr<int> d_sh_lid, d_sh_owner;
   std::vector<int> h_sh_lid, h_sh_owner;
   DevArr<double> d_S, d_Ld, d_Winv, d_yv, d_dp;
+  DevArr<double> d_S0, d_pcg, d_lm_c, d_pcg_scal;      // joint solve (pcg_kernels.hip)
+  DevArr<GraphDev> d_Gself;                             // this graph's view on the device, for the kernels that take an array of views
+  GraphDev G_self{};
+  bool have_self = false;
+  int pcg_iters = 0;
+  int sync_self();
   DevArr<int> d_cctr;
   DevArr<double> d_covY;
   bool factor_valid = false;            // S / Ld / Winv hold the factor of the system of the last solve

@@ -18,6 +18,7 @@ void launch_backsub(const GraphDev& G, int mode, hipStream_t s);       // mode: 
 void launch_shared_pack(const GraphDev& G, int what, double* buf, hipStream_t s);
 void launch_shared_unpack(const GraphDev& G, int what, const double* buf, hipStream_t s);
 void launch_estimate(const GraphDev& G, hipStream_t s);
+void launch_chi2(const GraphDev& G, double* out4, hipStream_t s);   // sum of squared whitened residuals at the last linearisation point
 void launch_pose_adj(const GraphDev& G, hipStream_t s);        // pose adjacency bitmap of the Schur assembly (topology only)
 void launch_scatter(const void* stage, unsigned desc_off, int nseg, hipStream_t s);
 void launch_gather(void* stage, unsigned desc_off, int nseg, hipStream_t s);
@@ -33,12 +34,24 @@ void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv,
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s);   // also clears status[4], the ticket counter of launch_chol_bwd_all
 struct CholSystem { double* S; int ld, T; double* Ld; double* Winv; double* yv; double* dp; int* status; };
 void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps = nullptr);            // up to 8 systems, one launch per block column
+// one of the two triangular solves with the finished factors of up to 8 systems on arbitrary vectors (T * NB doubles each): out = L^-1 in
+// (fwd) or L^-T in (bwd); the preconditioner of the joint solve (pcg_kernels.hip)
+void launch_chain_batch(const CholSystem* d, int n, const double* const* in, double* const* out, bool fwd, hipStream_t s);
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp, int* status, hipStream_t s);
 // marginal covariance of the pose whose first tangent row is row0 (Y: 6 * T * NB scratch doubles holding the six unit columns)
 void launch_pose_covariance(const double* S, int ld, int T, const double* Ld, const double* Winv, double* Y, int row0, double* cov36,
                             hipStream_t s);
 // stand-alone dense SPD solve on device buffers (used by the unit tests and the roofline bench leg)
 int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double* yv, double* dp, int* status, int* ctr, hipStream_t s);
+
+// pcg_kernels.hip — joint Gauss-Newton step of the robots of a GPU (and, through the caller's exchanges, of the job): PCG on the
+// global reduced pose system with the robots' own factors as preconditioner.  d: device array of the n graphs' views, h: host copy.
+enum { PCG_VEC_R = 0, PCG_VEC_U = 1, PCG_VEC_W = 2, PCG_VEC_P = 3, PCG_VEC_S = 4, PCG_VEC_X = 5, PCG_VEC_Y = 6, PCG_VEC_COUNT = 7 };
+void launch_pcg_init(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);
+void launch_pcg_tl(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, int vec, hipStream_t s);      // -> bufs[i][9 slot ..]
+void launch_pcg_matvec_dots(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s);     // bufs: summed t_l in, (gamma, delta) partials out
+void launch_pcg_update(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s);          // bufs: summed (gamma, delta) in
+void launch_pcg_finish(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);
 
 // assoc_kernels.hip
 struct AssocFrameDev {
@@ -49,7 +62,7 @@ struct AssocFrameDev {
   int n;
   int K;
   int gate;                  // 1: K-NN gate; 0: the submap is the whole map in the caller's order (stand-alone matchers)
-  int Kp, cached;            // LDS plan of the gate (assoc_plan)
+  int Kp, cached, staged;    // LDS plan of the gate (assoc_plan)
   double thresh;
   double best_init;          // sloam.cpp:90 / :128,136 / :176,180
   int label_gate;            // 0 none (cubes), 1 skip unless equal (ellipsoids), 2 distance = 1000 (cylinders)
@@ -67,7 +80,7 @@ struct AssocFrameDev {
 };
 // LDS plan of one class for the K-NN gate: sort buffer length Kp (power of two >= min(K, n)), whether the n distance words are cached
 // in LDS, dynamic LDS bytes.  false: min(K, n) exceeds ASSOC_MAX_K.  The cloud itself may be of any size.
-bool assoc_plan(int n, int K, int gate, int* Kp, int* cached, size_t* bytes);
+bool assoc_plan(int n, int K, int gate, int model_stride, int* Kp, int* cached, int* staged, size_t* bytes);
 void launch_assoc_frame(const AssocFrameDev* classes3, size_t lds_bytes /* max over the three classes */, const double* pose12, hipStream_t s);
 int launch_assoc_sweep(const float* cx, const float* cy, const float* cz, const double* model_xyz, const int32_t* label, int n_map,
                        const double* query_pos, const double* obs_xyz, const int32_t* obs_label, int n_query,

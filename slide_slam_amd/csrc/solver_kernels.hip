@@ -970,6 +970,30 @@ __global__ void k_estimate(GraphDev G) {
   }
 }
 
+// sum of squared whitened residuals of every factor at the last linearisation point (NonlinearFactorGraph::error x 2): one workgroup,
+// fixed summation order.  out[0] = total, out[1] = priors, out[2] = betweens (incl. ghost), out[3] = landmark factors.
+__global__ __launch_bounds__(256) void k_chi2(GraphDev G, double* __restrict__ out) {
+  __shared__ double sh[3][256];
+  const int tid = threadIdx.x;
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int i = tid; i < 6 * G.n_prior; i += 256) a += G.pr_r[i] * G.pr_r[i];
+  for (int i = tid; i < 6 * G.n_between; i += 256) b += G.bt_r[i] * G.bt_r[i];
+  for (int i = tid; i < 6 * G.n_ghost; i += 256) b += G.gh_r[i] * G.gh_r[i];
+  for (int f = tid; f < G.n_lf; f += 256) {
+    const int M = lf_rows(G.lf_type[f]);
+    const double* r = G.jbuf + G.lf_joff[f];
+    for (int k = 0; k < M; ++k) c += r[k] * r[k];
+  }
+  sh[0][tid] = a; sh[1][tid] = b; sh[2][tid] = c;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) { sh[0][tid] += sh[0][tid + st]; sh[1][tid] += sh[1][tid + st]; sh[2][tid] += sh[2][tid + st]; }
+    __syncthreads();
+  }
+  if (tid == 0) { out[1] = sh[0][0]; out[2] = sh[1][0]; out[3] = sh[2][0]; out[0] = sh[0][0] + sh[1][0] + sh[2][0]; }
+}
+void launch_chi2(const GraphDev& G, double* out4, hipStream_t s) { hipLaunchKernelGGL(k_chi2, dim3(1), dim3(256), 0, s, G, out4); }
+
 // ------------------------------------------------------------------------------------------------
 static inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 

@@ -211,11 +211,20 @@ class PassDriver:
     pass).  Without one (oracle shards on the CPU, or un-batched HIP shards): the same sequence spelled out with dist_phase calls
     and host-side sums — the CPU rehearsal of exactly this control flow."""
 
-    def __init__(self, shards, bufs, n_slots, batch=None, base=None, world=1, device=None):
+    def __init__(self, shards, bufs, n_slots, batch=None, base=None, world=1, device=None, pcg_iters=0):
         self.shards, self.bufs, self.n_slots, self.batch, self.base, self.world, self.device = shards, bufs, n_slots, batch, base, world, device
         self.ptrs = [b.data_ptr() for b in bufs] if device is not None else None
         self.passes = 0
         self.stream_ordered = True      # False (diagnostic): host-synchronous collectives
+        # joint solve: PCG iterations on the global reduced system after the factorisations (0: block-Jacobi over robots).  HIP
+        # shards only — the oracle's replica solves the joint graph directly, which is what the joint solve is checked against.
+        self.pcg_iters = pcg_iters if n_slots > 0 else 0
+        if pcg_iters:
+            if batch is not None:
+                batch.set_pcg(pcg_iters)
+            else:
+                for sh in shards:
+                    sh.graph.set_pcg(pcg_iters)
 
     def _exchange(self, count):
         """all-reduce(sum) of buffer 0's first `count` doubles across the processes, ordered behind the batch's stream."""
@@ -237,8 +246,11 @@ class PassDriver:
             import torch
             torch.cuda.synchronize()
 
+    def _all(self, count):
+        self._local_sum(count); self._exchange(count); self._local_bcast(count)
+
     def one_pass(self):
-        n54, n9 = 54 * self.n_slots, 9 * self.n_slots
+        n54, n9, K = 54 * self.n_slots, 9 * self.n_slots, self.pcg_iters
         if self.batch is not None:
             if self.world == 1:
                 self.batch.pass_all(self.ptrs)
@@ -246,18 +258,29 @@ class PassDriver:
                 self.batch.pass_part(self.ptrs, 0)
                 self._exchange(n54)
                 self.batch.pass_part(self.ptrs, 1)
+                for it in range(K):
+                    self._exchange(n9)
+                    self.batch.pass_part(self.ptrs, 10)
+                    self._exchange(2)
+                    self.batch.pass_part(self.ptrs, 12 if it == K - 1 else 11)
                 self._exchange(n9)
                 self.batch.pass_part(self.ptrs, 2)
         else:
             h = (lambda b: b.data_ptr()) if self.device is not None else (lambda b: b)
-            for sh, b in zip(self.shards, self.bufs):
-                sh.graph.dist_phase(0, h(b))
-            self._local_sum(n54); self._exchange(n54); self._local_bcast(n54)
-            for sh, b in zip(self.shards, self.bufs):
-                sh.graph.dist_phase(1, h(b))
-            self._local_sum(n9); self._exchange(n9); self._local_bcast(n9)
-            for sh, b in zip(self.shards, self.bufs):
-                sh.graph.dist_phase(2, h(b))
+
+            def each(ph):
+                for sh, b in zip(self.shards, self.bufs):
+                    sh.graph.dist_phase(ph, h(b))
+            each(0)
+            self._all(n54)
+            each(1)
+            for it in range(K):
+                self._all(n9)
+                each(31)
+                self._all(2)
+                each(33 if it == K - 1 else 32)
+            self._all(n9)
+            each(2)
         self.passes += 1
 
     def gauss_newton(self, iterations=1):

@@ -88,6 +88,17 @@ def c4_parity(out, preset="C4", passes=3):
         res["batched_vs_unbatched"].append(float(np.abs(a - b).max() / np.abs(b).max()))
         nrm = np.linalg.norm(o.reshape(R, -1), axis=1)
         res["batched_vs_oracle"].append(float((np.linalg.norm((a - o).reshape(R, -1), axis=1) / nrm).max()))
+    # the joint solve (PCG on the global reduced system) batched in the replayed graph vs un-batched through dist_phase 31 / 32 / 33
+    dA2 = PassDriver(A, bufA, infoA["n_slots"], batch=batch, device=dev, pcg_iters=4)
+    dB2 = PassDriver(B, bufB, infoB["n_slots"], device=dev, pcg_iters=4)
+    res["pcg_batched_vs_unbatched"] = []
+    for _ in range(2):
+        dA2.one_pass()
+        dB2.one_pass()
+        a, b = poses_of(A, P), poses_of(B, P)
+        res["pcg_batched_vs_unbatched"].append(float(np.abs(a - b).max() / np.abs(b).max()))
+        say("PCG pass: batched vs un-batched", res["pcg_batched_vs_unbatched"][-1], A[0].graph.pcg_stats())
+    res["pcg_chi2"] = [sum(x.graph.chi2()["total"] for x in A), sum(x.graph.chi2()["total"] for x in B)]
     res["finite"] = bool(np.isfinite(poses_of(A, P)).all())
     for a in A:
         a.graph.join_chol_batch(None)
@@ -167,8 +178,8 @@ def c5_stream(out, preset="C4", ticks=None, budget_ms=100.0):
     json.dump(res, open(out, "w"))
 
 
-def c3_converge(out, preset="C3", passes=400, every=20):
-    """Convergence of the sharded block-Jacobi passes to the joint replica's optimum (diagnostic)."""
+def c3_converge(out, preset="C3", passes=400, every=20, pcg=0, unbatched=0):
+    """Convergence of the sharded passes (pcg = 0: block-Jacobi; > 0: joint solve by PCG) to the joint replica's optimum."""
     import torch
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -181,38 +192,115 @@ def c3_converge(out, preset="C3", passes=400, every=20):
     data = make_dataset(cfg)
     data["relmeas"] = []
     R, P = cfg.robots, cfg.poses_per_robot
-    gb = s.SlideBackend(s.default_params(number_of_robots=R), R)
-    replay_multi(gb, data, own_node_factory=lambda: s.SlideBackend(s.default_params(), 1))
-    prevj = None
-    for it in range(30):
-        gb.graph.gauss_newton(1)
-        joint = np.array([[gb.graph.get_pose12(r, k)[1] for k in range(P)] for r in range(R)])
-        if prevj is not None:
-            say("joint GN", it, "step", float(np.abs(joint - prevj).max()))
-        prevj = joint
+    joint, chi2_joint, joint_counts = None, None, None
+    if R <= 2:          # (the 8-robot replica's streaming build takes minutes: n = 30016 solved per frame)
+        gb = s.SlideBackend(s.default_params(number_of_robots=R), R)
+        replay_multi(gb, data, own_node_factory=lambda: s.SlideBackend(s.default_params(), 1))
+        prevj = None
+        for it in range(30):
+            gb.graph.gauss_newton(1)
+            joint = np.array([[gb.graph.get_pose12(r, k)[1] for k in range(P)] for r in range(R)])
+            if prevj is not None:
+                say("joint GN", it, "step", float(np.abs(joint - prevj).max()))
+            prevj = joint
+        cj = gb.graph.chi2()
+        chi2_joint = cj["total"]
+        cnt = gb.counts()
+        joint_counts = [cnt["cyl"], cnt["cube"], cnt["point"]]
+        say("joint replica chi2", cj, gb.graph.stats(), cnt, "rejected", gb.graph.rejected_count())
+        del gb
     shards = [s.SlideBackend(s.default_params(), 1) for _ in range(R)]
     for sh, lg in zip(shards, data["logs"]):
         replay_single(sh, lg, collect=False)
-    batch = s.CholBatch(R)
-    for t, sh in enumerate(shards):
-        sh.graph.join_chol_batch(batch, t)
+    say("shards chi2 before", [sh.graph.chi2() for sh in shards], [sh.graph.stats() for sh in shards], [sh.counts() for sh in shards])
+    batch = None if unbatched else s.CholBatch(R)
+    if batch is not None:
+        for t, sh in enumerate(shards):
+            sh.graph.join_chol_batch(batch, t)
     bufs, info = setup_local_shards(shards, gpu_matcher, device=dev)
-    drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, device=dev)
-    nrm = np.linalg.norm(joint.reshape(R, -1), axis=1)
+    drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, device=dev, pcg_iters=pcg)
+    nrm = np.linalg.norm(joint.reshape(R, -1), axis=1) if joint is not None else None
     hist = []
+    t_pass = 0.0
     for p in range(passes):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
         drv.one_pass()
+        torch.cuda.synchronize(); t_pass += time.perf_counter() - t0
         if (p + 1) % every == 0 or p < 5:
             d = poses_of(shards, P)
-            e = float((np.linalg.norm((d - joint).reshape(R, -1), axis=1) / nrm).max())
+            e = float((np.linalg.norm((d - joint).reshape(R, -1), axis=1) / nrm).max()) if joint is not None else float("nan")
             hist.append((p + 1, e))
-            say("pass", p + 1, "rel err vs joint", e)
-    for sh in shards:
-        sh.graph.join_chol_batch(None)
-    json.dump(dict(hist=hist, n_slots=info["n_slots"]), open(out, "w"))
+            say("pass", p + 1, "rel err vs joint", e, "chi2 sum", sum(sh.graph.chi2()["total"] for sh in shards), "ms/pass so far", 1e3 * t_pass / (p + 1),
+                shards[0].graph.pcg_stats() if pcg else "")
+    cs = [sh.graph.chi2() for sh in shards]
+    say("shards chi2 after", cs, "sum", sum(c["total"] for c in cs))
+    # replica consistency: the copies of every shared landmark must hold the same value in both shards
+    from slide_slam_amd.distributed import associate_global, shared_slots
+    tables = [[sh.landmark_table(c) for c in range(3)] for sh in shards]
+    gid, n_global = associate_global(tables, (2.0, 2.0, 0.75), gpu_matcher)
+    sl = [shared_slots(gid, n_global, r) for r in range(R)]
+    worst, worst_tab = 0.0, 0.0
+    for k in range(len(sl[0][0])):
+        vals = [shards[r].graph.get_landmark(int(sl[r][0][k]), int(sl[r][1][k]))[1] for r in range(R) if sl[r][0][k] >= 0]
+        tabs = [tables[r][int(sl[r][0][k])][0][int(sl[r][1][k])] for r in range(R) if sl[r][0][k] >= 0]
+        for v in vals[1:]:
+            worst = max(worst, float(np.abs(v - vals[0]).max()))
+        for t in tabs[1:]:
+            worst_tab = max(worst_tab, float(np.abs(t - tabs[0]).max()))
+    say("shared landmark copies: max |difference| between the shards", worst, "(positions in the tables:", worst_tab, ") slots", len(sl[0][0]), info["n_slots"])
+    if batch is not None:
+        for sh in shards:
+            sh.graph.join_chol_batch(None)
+    json.dump(dict(hist=hist, n_slots=info["n_slots"], final=poses_of(shards, P).tolist(), chi2_shards=sum(c["total"] for c in cs),
+                   chi2_joint=(float(chi2_joint) if joint is not None else None), ms_per_pass=1e3 * t_pass / max(passes, 1),
+                   n_global=[int(v) for v in info["n_global"]], joint_counts=joint_counts), open(out, "w"))
+
+
+def c3_assoc_check(out, preset="C3"):
+    """Diagnostic: is the landmark association of the joint replica (frame by frame against a growing map) the same partition of
+    the detections as the merge of the two robots' final maps?"""
+    import torch
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)
+    import slide_slam_amd as s
+    from slide_slam_amd.distributed import associate_global, gpu_matcher
+    from slide_slam_amd.replay import replay_multi, replay_single
+    from slide_slam_amd.synth import SynthConfig, make_dataset
+    cfg = SynthConfig.preset(preset)
+    data = make_dataset(cfg)
+    data["relmeas"] = []
+    R, P = cfg.robots, cfg.poses_per_robot
+    gb = s.SlideBackend(s.default_params(number_of_robots=R), R)
+    jo = replay_multi(gb, data, own_node_factory=lambda: s.SlideBackend(s.default_params(), 1))
+    shards, outs = [], []
+    for lg in data["logs"]:
+        sh = s.SlideBackend(s.default_params(), 1)
+        outs.append(replay_single(sh, lg))
+        shards.append(sh)
+    tables = [[sh.landmark_table(c) for c in range(3)] for sh in shards]
+    gid, n_global = associate_global(tables, (2.0, 2.0, 0.75), gpu_matcher)
+    names = ("cyl_id", "cube_id", "ell_id")
+    res = {}
+    for c in range(3):
+        pairs = set()
+        for k in range(P):
+            for r in range(R):
+                jid = jo["ids"][k][r][c]
+                lid = outs[r][names[c]][k]
+                assert len(jid) == len(lid)
+                for a, b in zip(jid, lid):
+                    pairs.add((int(a), int(gid[r][c][int(b)])))
+        j2s, s2j = {}, {}
+        for a, b in pairs:
+            j2s.setdefault(a, set()).add(b); s2j.setdefault(b, set()).add(a)
+        res[names[c]] = dict(joint_ids=len(j2s), shard_ids=len(s2j), joint_split=sum(1 for v in j2s.values() if len(v) > 1),
+                             shard_split=sum(1 for v in s2j.values() if len(v) > 1))
+        say(names[c], res[names[c]])
+    json.dump(res, open(out, "w"))
 
 
 if __name__ == "__main__":
-    fn = {"c4_parity": c4_parity, "c3_joint": c3_joint, "c5_stream": c5_stream, "c3_converge": c3_converge}[sys.argv[1]]
+    fn = {"c4_parity": c4_parity, "c3_joint": c3_joint, "c5_stream": c5_stream, "c3_converge": c3_converge, "c3_assoc_check": c3_assoc_check}[sys.argv[1]]
     extra = [int(a) if a.lstrip("-").isdigit() else a for a in sys.argv[3:]]
     fn(sys.argv[2], *extra)
