@@ -393,6 +393,9 @@ CholBatch::~CholBatch() {
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (pass_exec) (void)hipGraphExecDestroy(pass_exec);
   if (d_Gs) (void)hipFree(d_Gs);
+  if (ev_aux0) (void)hipEventDestroy(ev_aux0);
+  for (hipEvent_t e : ev_aux1) if (e) (void)hipEventDestroy(e);
+  for (hipStream_t a : aux) if (a) (void)hipStreamDestroy(a);
   if (master) (void)hipStreamDestroy(master);
   if (d_ctr) (void)hipFree(d_ctr);
 }
@@ -428,9 +431,9 @@ int CholBatch::rendezvous(int slot, hipStream_t s, bool reduce, int count) {
     if (!reduce) {
       int Tmax = 0;
       for (const CholSystem& c : sys) Tmax = c.T > Tmax ? c.T : Tmax;
-      if (Tmax + 2 > ctr_cap) {
+      if (CHOL_BATCH_HOST_MAX * (Tmax + 2) > ctr_cap) {
         if (d_ctr) { (void)hipStreamSynchronize(master); (void)hipFree(d_ctr); d_ctr = nullptr; }
-        ctr_cap = 2 * (Tmax + 2);
+        ctr_cap = CHOL_BATCH_HOST_MAX * 2 * (Tmax + 2);
         if (hipMalloc(reinterpret_cast<void**>(&d_ctr), ctr_cap * sizeof(int)) != hipSuccess) rc = SLIDE_ERR_HIP;
         else if (hipMemsetAsync(d_ctr, 0, ctr_cap * sizeof(int), master) != hipSuccess) rc = SLIDE_ERR_HIP;
       }
@@ -472,9 +475,9 @@ int CholBatch::prepare_pass() {
     Tmax = G.T > Tmax ? G.T : Tmax;
     hG[i] = G;
   }
-  if (Tmax + 2 > ctr_cap) {
+  if (CHOL_BATCH_HOST_MAX * (Tmax + 2) > ctr_cap) {
     if (d_ctr) { SL_HIP(hipStreamSynchronize(master)); SL_HIP(hipFree(d_ctr)); d_ctr = nullptr; }
-    ctr_cap = 2 * (Tmax + 2);
+    ctr_cap = CHOL_BATCH_HOST_MAX * 2 * (Tmax + 2);
     SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_ctr), ctr_cap * sizeof(int)));
     SL_HIP(hipMemsetAsync(d_ctr, 0, ctr_cap * sizeof(int), master));
     SL_HIP(hipStreamSynchronize(master));
@@ -518,7 +521,7 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
     }
     if (rc == SLIDE_OK && joint) rc = save_systems();
     if (rc == SLIDE_OK && e0) (void)hipEventRecord(e0, master);
-    if (rc == SLIDE_OK) launch_chol_batch(sys.data(), n, d_ctr, master, e1);
+    if (rc == SLIDE_OK) rc = factor_all(e1);
     if (rc == SLIDE_OK && joint) rc = enqueue_pcg_head(d_bufs);
   }
   if (joint) {
@@ -656,6 +659,44 @@ int CholBatch::end_pass() {
     const int rc = decode_status(st[i]);
     if (rc != SLIDE_OK) return rc;
   }
+  return SLIDE_OK;
+}
+
+// All joined systems in ONE launch sequence (one step launch per block column for all of them), or — SLIDE_CHOL_GROUPS=2, four or
+// more systems — in TWO sequences of half the systems each on two streams: the systems are independent, so nothing synchronises the
+// two between the fork and the join, and the launch tails / serial chains of one sequence overlap with the trailing-update flood of
+// the other.  `after` (measurement): recorded behind everything (the join included).
+int CholBatch::factor_all(hipEvent_t after) {
+  static const int env_groups = getenv("SLIDE_CHOL_GROUPS") ? atoi(getenv("SLIDE_CHOL_GROUPS")) : 2;
+  int groups = env_groups < 1 ? 1 : env_groups;
+  if (groups > n / 2) groups = n / 2;              // at least two systems per sequence
+  if (groups < 2) {
+    launch_chol_batch(sys.data(), n, d_ctr, master, nullptr);
+    if (after) SL_HIP(hipEventRecord(after, master));
+    return SLIDE_OK;
+  }
+  if (!ev_aux0) SL_HIP(hipEventCreateWithFlags(&ev_aux0, hipEventDisableTiming));
+  SL_HIP(hipEventRecord(ev_aux0, master));
+  const int per = (n + groups - 1) / groups;
+  for (int g = 0; g < groups; ++g) {
+    const int lo = g * per, hi = std::min(n, lo + per);
+    if (lo >= hi) break;
+    hipStream_t st = master;
+    if (g > 0) {
+      if (!aux[g]) {
+        SL_HIP(hipStreamCreateWithFlags(&aux[g], hipStreamNonBlocking));
+        SL_HIP(hipEventCreateWithFlags(&ev_aux1[g], hipEventDisableTiming));
+      }
+      st = aux[g];
+      SL_HIP(hipStreamWaitEvent(st, ev_aux0, 0));
+    }
+    launch_chol_batch(sys.data() + lo, hi - lo, d_ctr + (size_t)g * (ctr_cap / CHOL_BATCH_HOST_MAX), st, nullptr);
+    if (g > 0) {
+      SL_HIP(hipEventRecord(ev_aux1[g], st));
+      SL_HIP(hipStreamWaitEvent(master, ev_aux1[g], 0));
+    }
+  }
+  if (after) SL_HIP(hipEventRecord(after, master));
   return SLIDE_OK;
 }
 

@@ -179,8 +179,11 @@ class CholBatch {
   std::vector<hipEvent_t> ev_in;
   hipEvent_t ev_out = nullptr;
   hipStream_t master = nullptr;
+  hipStream_t aux[8] = {};               // further streams of the grouped factorisation (the groups' launches overlap on the GPU)
+  hipEvent_t ev_aux0 = nullptr, ev_aux1[8] = {};
   int* d_ctr = nullptr;
   int ctr_cap = 0;
+  int factor_all(hipEvent_t after);      // the batched factor + solve of all joined systems, in one or two launch sequences
 };
 
 class HostGraph {
