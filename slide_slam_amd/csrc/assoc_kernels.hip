@@ -79,7 +79,8 @@ __device__ __forceinline__ unsigned dist_bits(const AssocCore& C, int i, float q
 __device__ inline int knn_select(const AssocCore& C, unsigned long long* sel, unsigned* hist, unsigned* dcache) {
   __shared__ unsigned long long s_prefix;
   __shared__ int s_krem, s_stop, s_cnt;
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+  __shared__ unsigned whist[16 * 256];          // per-wave digit histograms of the radix select
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6;
   const int n = C.n, Ksub = C.K < n ? C.K : n;
   const float qx = (float)C.qpos[0], qy = (float)C.qpos[1], qz = (float)C.qpos[2];
   const int n_up = (n + nthr - 1) / nthr * nthr;
@@ -96,30 +97,21 @@ __device__ inline int knn_select(const AssocCore& C, unsigned long long* sel, un
   if (Ksub < n) {
     for (int byte = 7; byte >= 0; --byte) {
       shift = 8 * byte;
-      for (int b = tid; b < 256; b += nthr) hist[b] = 0u;
+      // one histogram per wave (no contention between waves; lanes of a wave that hit the same bin are serialised by the LDS
+      // atomic unit, ~1 per clock — cheaper than any software aggregation), summed into hist[0 .. 255] afterwards
+      for (int b = tid; b < 256 * nw; b += nthr) whist[b] = 0u;
       __syncthreads();
       const unsigned long long prefix = s_prefix;
-      for (int i = tid; i < n_up; i += nthr) {
-        bool act = i < n;
-        unsigned digit = 0;
-        if (act) {
-          const unsigned long long key = key_at(i);
-          act = byte == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8));
-          digit = (unsigned)(key >> shift) & 255u;
-        }
-        // the top bytes of a float land in a handful of bins: lanes with the same digit add once (at most four rounds), the
-        // stragglers of a spread-out pass fall back to one atomic each
-        unsigned long long m = __ballot(act);
-#pragma unroll 1
-        for (int r = 0; r < 4 && m; ++r) {
-          const int leader = __ffsll((long long)m) - 1;
-          const unsigned d0 = (unsigned)__shfl((int)digit, leader);
-          const unsigned long long same = __ballot(act && digit == d0);
-          if (lane == leader) atomicAdd(&hist[d0], (unsigned)__popcll(same));
-          if (digit == d0) act = false;
-          m &= ~same;
-        }
-        if (act) atomicAdd(&hist[digit], 1u);
+      unsigned* mine = whist + 256 * (tid >> 6);
+      for (int i = tid; i < n; i += nthr) {
+        const unsigned long long key = key_at(i);
+        if (byte == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&mine[(unsigned)(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      for (int b = tid; b < 256; b += nthr) {
+        unsigned t = 0;
+        for (int w = 0; w < nw; ++w) t += whist[256 * w + b];
+        hist[b] = t;
       }
       __syncthreads();
       if (tid < 64) {
@@ -174,17 +166,41 @@ __device__ inline int knn_select(const AssocCore& C, unsigned long long* sel, un
   for (int i = Ksub + tid; i < C.Kp; i += nthr) sel[i] = ~0ull;
   __syncthreads();
   ASTAMP(3);
-  for (int k = 2; k <= C.Kp; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < C.Kp; i += nthr) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long a = sel[i], b = sel[ixj];
-          const bool asc = (i & k) == 0;
-          if ((a > b) == asc) { sel[i] = b; sel[ixj] = a; }
+  if (C.Kp <= nthr) {
+    // one key per thread: compare-exchange steps inside a wave (partner distance < 64) are two 32-bit shuffles, only the steps
+    // across waves go through LDS (10 of the 55 steps of a 1024-key sort)
+    unsigned long long v = tid < C.Kp ? sel[tid] : ~0ull;
+    for (int k = 2; k <= C.Kp; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        unsigned long long p;
+        if (j >= 64) {
+          if (tid < C.Kp) sel[tid] = v;
+          __syncthreads();
+          p = tid < C.Kp ? sel[tid ^ j] : ~0ull;
+          __syncthreads();
+        } else {
+          const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, j), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), j);
+          p = ((unsigned long long)hi << 32) | lo;
         }
+        const bool keep_min = ((tid & k) == 0) == ((tid & j) == 0);
+        v = keep_min ? (v < p ? v : p) : (v > p ? v : p);
       }
-      __syncthreads();
+    }
+    if (tid < C.Kp) sel[tid] = v;
+    __syncthreads();
+  } else {
+    for (int k = 2; k <= C.Kp; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < C.Kp; i += nthr) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const unsigned long long a = sel[i], b = sel[ixj];
+            const bool asc = (i & k) == 0;
+            if ((a > b) == asc) { sel[i] = b; sel[ixj] = a; }
+          }
+        }
+        __syncthreads();
+      }
     }
   }
   ASTAMP(4);
@@ -220,40 +236,78 @@ __device__ inline void assoc_core(const AssocCore& C) {
     __syncthreads();
   }
   ASTAMP(5);
-  // one wavefront per detection
+  // one wavefront per PAIR of detections (o, o + nwave): the candidates are read once for both.  Boxes: a lane scans its
+  // candidates in ascending submap index and keeps the one with the smallest distance d = sqrt(d2), the first on ties.  The
+  // correctly rounded f64 sqrt (a long instruction sequence) stays out of the loop: a later candidate replaces the lane's best iff
+  // its d is strictly smaller; that is decided on the squared distances when they differ by more than 2^-48 relative (the rounded
+  // roots are then distinct), and by the two roots themselves inside that band.  One sqrt per lane at the end feeds the
+  // lexicographic (d, index) reduction and the threshold tests, which therefore see exactly the reference's numbers.
   const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
-  for (int o = wave; o < C.n_det; o += nwave) {
-    double best = C.best_init;
-    int bests = INT_MAX;
-    const int ol = C.det_label[o];
-    const double* dw = C.det_world + (size_t)o * C.det_stride + C.det_off;
-    for (int s = lane; s < Ksub; s += 64) {
-      const int mi = C.gate ? (int)(sel[s] & 0xffffffffull) : s;
-      const double* mm = staged ? cand + (size_t)s * ms : C.model + (size_t)ms * mi;
-      const int ml = staged ? cand_lab[s] : C.label[mi];
-      double d;
-      bool consider = true;
-      if (C.is_cyl) {
-        d = cyl_distance(mm, ml, dw - C.det_off, ol);
-      } else {
-        if (C.label_gate == 1 && ml != ol) consider = false;
-        const double dx = dw[0] - mm[0], dy = dw[1] - mm[1], dz = dw[2] - mm[2];
-        d = sqrt(dx * dx + dy * dy + dz * dz);
+  for (int o0 = wave; o0 < C.n_det; o0 += 2 * nwave) {
+    const int o1 = o0 + nwave;
+    const bool two = o1 < C.n_det;
+    const double* dw0 = C.det_world + (size_t)o0 * C.det_stride + C.det_off;
+    const double* dw1 = C.det_world + (size_t)(two ? o1 : o0) * C.det_stride + C.det_off;
+    const int ol0 = C.det_label[o0], ol1 = C.det_label[two ? o1 : o0];
+    double best[2] = {C.best_init, C.best_init};
+    int bests[2] = {INT_MAX, INT_MAX};
+    if (C.is_cyl) {
+      for (int s = lane; s < Ksub; s += 64) {
+        const int mi = C.gate ? (int)(sel[s] & 0xffffffffull) : s;
+        const double* mm = staged ? cand + (size_t)s * ms : C.model + (size_t)ms * mi;
+        const int ml = staged ? cand_lab[s] : C.label[mi];
+        const double d0 = cyl_distance(mm, ml, dw0 - C.det_off, ol0);
+        if (d0 < C.best_init && d0 < best[0]) { best[0] = d0; bests[0] = s; }
+        if (two) {
+          const double d1 = cyl_distance(mm, ml, dw1 - C.det_off, ol1);
+          if (d1 < C.best_init && d1 < best[1]) { best[1] = d1; bests[1] = s; }
+        }
       }
-      // sequential rule: "if (d < bestDist)" scanning s upward -> lexicographic min over (d, s) of the
-      // candidates that beat the initial bestDist
-      if (consider && d < C.best_init && (d < best || (d == best && s < bests))) { best = d; bests = s; }
+    } else {
+      double q0[3], q1[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { q0[k] = dw0[k]; q1[k] = dw1[k]; }
+      double b2[2] = {-1.0, -1.0};          // squared distance of the lane's best (none yet: < 0)
+      constexpr double BAND = 1.0 - 0x1p-48;
+      for (int s = lane; s < Ksub; s += 64) {
+        const int mi = C.gate ? (int)(sel[s] & 0xffffffffull) : s;
+        const double* mm = staged ? cand + (size_t)s * ms : C.model + (size_t)ms * mi;
+        const int ml = staged ? cand_lab[s] : C.label[mi];
+        const double m0 = mm[0], m1 = mm[1], m2 = mm[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (h == 1 && !two) continue;
+          if (C.label_gate == 1 && ml != (h ? ol1 : ol0)) continue;
+          const double* q = h ? q1 : q0;
+          const double dx = q[0] - m0, dy = q[1] - m1, dz = q[2] - m2;
+          const double d2 = dx * dx + dy * dy + dz * dz;
+          bool take = b2[h] < 0.0 || d2 < b2[h] * BAND;
+          if (!take && d2 < b2[h]) take = sqrt(d2) < sqrt(b2[h]);       // inside the band: the rounded roots decide
+          if (take) { b2[h] = d2; bests[h] = s; }
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const double d = b2[h] >= 0.0 ? sqrt(b2[h]) : C.best_init;
+        if (d < C.best_init) best[h] = d; else bests[h] = INT_MAX;      // "if (d < bestDist)" against the initial bestDist
+      }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ob = __shfl_xor(best, off);
-      const int os = __shfl_xor(bests, off);
-      if (ob < best || (ob == best && os < bests)) { best = ob; bests = os; }
-    }
-    if (lane == 0) {
-      const bool ok = (bests != INT_MAX) && (best < C.thresh);
-      if (C.match_sub) C.match_sub[o] = ok ? bests : -1;
-      C.match_map[o] = ok ? (C.gate ? (int32_t)(sel[bests] & 0xffffffffull) : bests) : -1;
+    for (int h = 0; h < 2; ++h) {
+      double b = best[h];
+      int bs = bests[h];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(b, off);
+        const int os = __shfl_xor(bs, off);
+        if (ob < b || (ob == b && os < bs)) { b = ob; bs = os; }
+      }
+      const int o = h == 0 ? o0 : o1;
+      if (lane == 0 && (h == 0 || two)) {
+        const bool ok = (bs != INT_MAX) && (b < C.thresh);
+        if (C.match_sub) C.match_sub[o] = ok ? bs : -1;
+        C.match_map[o] = ok ? (C.gate ? (int32_t)(sel[bs] & 0xffffffffull) : bs) : -1;
+      }
     }
   }
   ASTAMP(6);

@@ -84,6 +84,9 @@ uint64_t HostGraph::lm_key(int cls, uint64_t idx) {
 HostGraph::HostGraph(const slide_params_t& p) : P(p) {}
 HostGraph::~HostGraph() {
   if (batch) batch->detach(this);         // the batch must not keep a pointer to a dead graph
+  // nothing of this graph may still be in flight when its streams, events and (member destructors, after this body) buffers go
+  if (stream) (void)hipStreamSynchronize(stream);
+  if (stream2) (void)hipStreamSynchronize(stream2);
   if (gexec) (void)hipGraphExecDestroy(gexec);
   for (auto& pg : phase_graph)
     if (pg.exec) (void)hipGraphExecDestroy(pg.exec);
@@ -385,6 +388,8 @@ void HostGraph::join_batch(CholBatch* b, int slot) {
   if (b) b->set_graph(slot, this);
 }
 CholBatch::~CholBatch() {
+  if (master) (void)hipStreamSynchronize(master);
+  for (hipStream_t a : aux) if (a) (void)hipStreamSynchronize(a);
   for (auto& e : part_exec) if (e) (void)hipGraphExecDestroy(e);
   for (HostGraph* g : graphs)
     if (g) { std::lock_guard<std::mutex> gl(g->mtx); if (g->batch == this) g->batch = nullptr; }

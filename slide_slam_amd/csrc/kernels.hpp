@@ -88,7 +88,7 @@ int launch_assoc_sweep(const float* cx, const float* cy, const float* cz, const 
 void launch_map_refresh(double* cyl_model, int n_cyl, const int* cyl_lid, double* cube_xyz, int n_cube, const int* cube_lid,
                         double* ell_xyz, int n_ell, const int* ell_lid, const double* lm_est, hipStream_t s);
 constexpr int ASSOC_MAX_K = 16384;                 // neighbours kept by the K-NN gate (LDS sort buffer); the cloud is unbounded
-constexpr int ASSOC_LDS_BUDGET = 144 * 1024;
+constexpr int ASSOC_LDS_BUDGET = 140 * 1024;      // dynamic part; the select keeps another 16 KB of per-wave histograms (static)
 
 // place_kernels.hip
 struct PlaceDev {

@@ -230,3 +230,21 @@ def test_merge_refuses_unknown_keys_loudly():
     there), not dropped silently.  Host logic up to the upload, which needs a device: without one the call fails earlier with
     SLIDE_ERR_HIP, so only the symbol / counter plumbing is checked here; the behaviour itself is tested under -m gpu."""
     assert "slide_graph_rejected_count" in s.api.EXPORTS
+
+
+def _build_adaptor_check(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "adaptor_check")
+    lib_dir = os.path.dirname(s.LIB_PATH)
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "adaptor_compile_check.cpp"),
+                        "-o", exe, "-L" + lib_dir, "-lslide_gpu", "-Wl,-rpath," + lib_dir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_cpp_adaptor_compiles_and_links(tmp_path):
+    """include/slide_sloam_adaptor.hpp: the S1 / S2 classes with the reference's method names (graph.h:70-121, graphWrapper.h:82-134)
+    compile warning-free as C++17 and link against libslide_gpu.so; executed on the GPU box by tests/test_host_entry_points_gpu.py."""
+    import subprocess
+    exe = _build_adaptor_check(tmp_path)
+    assert subprocess.run([exe]).returncode == 0          # no argument: link check only

@@ -46,3 +46,15 @@ def test_merge_refuses_unknown_keys_loudly_gpu(gpu):
     assert g.rejected_count() == 3
     st, lm = g.get_landmark(2, 0)
     assert st == 0 and abs(lm[0] - 9.0) > 1.0                          # the resident value was not overwritten
+
+
+@pytest.mark.gpu
+def test_cpp_adaptor_runs(gpu, tmp_path):
+    """The S1 / S2 adaptor classes of include/slide_sloam_adaptor.hpp driven the way graphWrapper.cpp / sloamNode.cpp drive the
+    reference's: priors, odometry, all three landmark factor kinds, a loop closure, solve, the read-back methods with the reference's
+    absent-key conventions (false + identity, zero point, std::out_of_range)."""
+    import subprocess
+    exe = test_abi._build_adaptor_check(tmp_path)
+    r = subprocess.run([exe, "run"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "adaptor ok=1 missing=1 threw=1" in r.stdout and "wrapper poses=1 counter=1" in r.stdout
