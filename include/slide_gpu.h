@@ -351,7 +351,8 @@ void slide_clipper_default_params(slide_clipper_params_t* p);
  * upper triangle filled (slide_clipper_affinity's output).  u0: n start weights; NULL draws them from a fixed-seed
  * generator (the reference uses a std::random_device-seeded mt19937, utils.cpp:22-29, i.e. is not reproducible).
  * nodes_out: caller buffer of n entries (selected associations, largest weight first); u_out (n) / score may be NULL.
- * The two symmetric products of every gradient evaluation run on the GPU; the O(n) control flow stays on the host. */
+ * The whole solve runs on the device: M as CSR (like the reference's sparse M / C, clipper.cpp:55-64), every product, reduction,
+ * projection, line-search and stopping decision in one persistent workgroup — no host round trip inside the iteration. */
 int slide_clipper_dense_clique(const double* M_upper, int n, const double* u0, const slide_clipper_params_t* p,
                                int32_t* nodes_out, int* n_nodes, double* u_out, double* score);
 /* semantic_clipper::match_triangles / compute_triangle_diff semantic_clipper.cpp:49-118.  Triangles: 3 x (x, y) doubles each

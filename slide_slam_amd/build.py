@@ -25,6 +25,7 @@ SOURCES = [
     ("pcg_kernels.hip", []),
     ("assoc_kernels.hip", ["-ffp-contract=off"]),
     ("place_kernels.hip", ["-ffp-contract=off"]),
+    ("clipper_kernels.hip", ["-ffp-contract=off"]),
     ("host_graph.hip", ["-ffp-contract=off"]),
     ("host_backend.hip", ["-ffp-contract=off"]),
     ("capi.hip", ["-ffp-contract=off"]),

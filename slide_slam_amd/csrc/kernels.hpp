@@ -105,7 +105,13 @@ void launch_place_argmax(const int32_t* inliers, long long n, long long* best_id
 void launch_tri_prepare(const double* tri, int n, double* sdist, double* sxy, hipStream_t s);
 void launch_tri_match(bool emit, const double* dm, const double* xm, int ntm, const double* dd, const double* xd, int ntd, double thr,
                       int* counts, const long long* offs, double* pts, double* diffs, hipStream_t s);
-void launch_clq_matvec(const double* Mup, int n, const double* v, double* Mu, double* Cu, hipStream_t s);
+// clipper_kernels.hip — CLIPPER dense clique on the device: CSR of the symmetric affinity matrix from its dense upper triangle (count,
+// host prefix sum, fill), then the whole projected-gradient solve in one persistent workgroup.  work6n: 6 n doubles (u comes back in the
+// first n), out4: {F, d, gradient evaluations, outer iterations}
+void launch_clq_csr_count(const double* Mup, int n, int* rowcnt, hipStream_t s);
+void launch_clq_csr_fill(const double* Mup, int n, const int* rowptr, int* col, double* val, hipStream_t s);
+void launch_clq_solve(const int* rowptr, const int* col, const double* val, int n, const double* u0, double* work6n, double tol_u, double tol_F,
+                      double beta, double eps, int maxin, int maxol, int maxls, int rescale, double* out4, hipStream_t s);
 void launch_clipper_affinity(const double* D1, const double* D2, int dim, const int32_t* A, int m, double sigma, double eps,
                              double mindist, double affinityeps, double* M, hipStream_t s);
 

@@ -180,25 +180,6 @@ __global__ __launch_bounds__(256) void k_tri_match(const double* __restrict__ dm
   if (!EMIT && lane == 0) counts[i] = cnt;
 }
 
-// ---- CLIPPER dense-clique solver: the two symmetric products of one projected-gradient evaluation ---------------------
-// Mup: n x n row-major, upper triangle filled (slide_clipper_affinity's output).  One wave per row i:
-//   Mu[i] = sum_j M_sym[i][j] v[j],   Cu[i] = sum_{j : M_sym[i][j] != 0} v[j]     (C = sparsity pattern of M, clipper.cpp:60-63)
-__global__ __launch_bounds__(256) void k_clq_matvec(const double* __restrict__ Mup, int n, const double* __restrict__ v,
-                                                    double* __restrict__ Mu, double* __restrict__ Cu) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (i >= n) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int j = lane; j < n; j += 64) {
-    const double a = j > i ? Mup[(size_t)i * n + j] : (j < i ? Mup[(size_t)j * n + i] : 0.0);
-    const double x = v[j];
-    s1 += a * x;
-    s2 += (a != 0.0) ? x : 0.0;
-  }
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
-  if (lane == 0) { Mu[i] = s1; Cu[i] = s2; }
-}
-
 void launch_tri_prepare(const double* tri, int n, double* sdist, double* sxy, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_tri_prepare, dim3((n + 255) / 256), dim3(256), 0, s, tri, n, sdist, sxy);
 }
@@ -207,9 +188,6 @@ void launch_tri_match(bool emit, const double* dm, const double* xm, int ntm, co
   if (ntm <= 0) return;
   if (emit) hipLaunchKernelGGL(k_tri_match<true>, dim3((ntm + 3) / 4), dim3(256), 0, s, dm, xm, ntm, dd, xd, ntd, thr, counts, offs, pts, diffs);
   else hipLaunchKernelGGL(k_tri_match<false>, dim3((ntm + 3) / 4), dim3(256), 0, s, dm, xm, ntm, dd, xd, ntd, thr, counts, offs, pts, diffs);
-}
-void launch_clq_matvec(const double* Mup, int n, const double* v, double* Mu, double* Cu, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_clq_matvec, dim3((n + 3) / 4), dim3(256), 0, s, Mup, n, v, Mu, Cu);
 }
 
 void launch_place_sweep(const PlaceDev& P, hipStream_t s) {

@@ -242,6 +242,27 @@ def test_dense_clique_matches_oracle(gpu):
 
 
 @pytest.mark.gpu
+def test_dense_clique_large_planted(gpu):
+    """m = 4000 putative associations (a 128 MB dense affinity matrix on the host, ~1 % of it non-zero): a planted set of 60 mutually
+    consistent associations among random pairwise-consistent noise — the device-resident solve (CSR + one persistent workgroup)
+    returns exactly the planted clique; score ~ its size (DSD_HEU: omega = round(F))."""
+    rng = np.random.default_rng(5)
+    m, k = 4000, 60
+    M = np.zeros((m, m))
+    iu = np.triu_indices(m, 1)
+    mask = rng.uniform(0, 1, len(iu[0])) < 0.01
+    M[iu[0][mask], iu[1][mask]] = rng.uniform(0.2, 0.9, int(mask.sum()))
+    planted = np.sort(rng.permutation(m)[:k])
+    for a in range(k):
+        for b in range(a + 1, k):
+            M[planted[a], planted[b]] = rng.uniform(0.9, 1.0)
+    nodes, u, score = gpu.clipper_dense_clique(M, rng.uniform(0, 1, m), gpu.clipper_params())
+    assert sorted(nodes.tolist()) == planted.tolist()
+    assert abs(score - k) < 0.1 * k
+    assert np.all(u >= 0) and abs(np.linalg.norm(u) - 1.0) < 1e-9
+
+
+@pytest.mark.gpu
 def test_semantic_clipper_pipeline(gpu):
     import ctypes as C
     found = 0
