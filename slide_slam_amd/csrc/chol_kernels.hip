@@ -974,26 +974,32 @@ __global__ __launch_bounds__(256) void k_chain_batched(ChainBatchArgs A) {
     return;
   }
 }
-__global__ void k_chain_prepare(double* out, int n, int* ticket) {
+struct ChainPrepArgs { int n; double* out[CHOL_BATCH_MAX]; int len[CHOL_BATCH_MAX]; int* ticket; };
+__global__ void k_chain_prepare(ChainPrepArgs A) {
+  const int r = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0 && ticket) *ticket = 0;
-  if (i < n) out[i] = __longlong_as_double((long long)BWD_SENT);
+  if (r == 0 && i == 0) *A.ticket = 0;
+  if (i < A.len[r]) A.out[r][i] = __longlong_as_double((long long)BWD_SENT);
 }
-// x = L^-1 in (fwd) or x = L^-T in (bwd) for every system of the batch: out[i] is sentinel-filled and the chain launched
+// x = L^-1 in (fwd) or x = L^-T in (bwd) for every system of the batch: out[i] is sentinel-filled (one launch for all) and the chain launched
 void launch_chain_batch(const CholSystem* d, int n, const double* const* in, double* const* out, bool fwd, hipStream_t s) {
   ChainBatchArgs A{};
+  ChainPrepArgs Pr{};
   A.n = n;
+  Pr.n = n;
   int Tmax = 0, total = 0;
   for (int i = 0; i < n; ++i) {
     A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.Ld[i] = d[i].Ld; A.Winv[i] = d[i].Winv; A.in[i] = in[i]; A.out[i] = out[i];
     A.status[i] = d[i].status;
     Tmax = d[i].T > Tmax ? d[i].T : Tmax;
     total += d[i].T;
-    const int len = d[i].T * NB;
-    hipLaunchKernelGGL(k_chain_prepare, dim3((len + 255) / 256), dim3(256), 0, s, out[i], len, i == 0 ? d[0].status + (fwd ? 5 : 4) : nullptr);
+    Pr.out[i] = out[i];
+    Pr.len[i] = d[i].T * NB;
   }
   A.Tmax = Tmax;
   if (total <= 0) return;
+  Pr.ticket = d[0].status + (fwd ? 5 : 4);
+  hipLaunchKernelGGL(k_chain_prepare, dim3((Tmax * NB + 255) / 256, n), dim3(256), 0, s, Pr);
   if (fwd) hipLaunchKernelGGL(k_chain_batched<true>, dim3(total), dim3(256), 0, s, A);
   else hipLaunchKernelGGL(k_chain_batched<false>, dim3(total), dim3(256), 0, s, A);
 }

@@ -104,33 +104,34 @@ __global__ void k_pcg_c(const GraphDev* __restrict__ Gs, PcgBufs B) {
 // out = S0 * in for the symmetric S0 held as its lower triangle (column-major, leading dimension ld): one workgroup per block row
 // i of 64: tiles (i, j <= i) as they lie, tiles (j > i, i) transposed.  Deterministic (no atomics): every block row is summed by
 // one workgroup in a fixed order.
-__global__ __launch_bounds__(256) void k_pcg_symv(const GraphDev* __restrict__ Gs, int vin, int vout) {
+__global__ __launch_bounds__(256) void k_pcg_symv(const GraphDev* __restrict__ Gs, int vin, int vout, int in_lds) {
   const GraphDev G = Gs[blockIdx.z];
   const int bi = blockIdx.x;
   if (bi >= G.T) return;
-  __shared__ double xj[NB];
+  extern __shared__ double xs_lds[];      // the whole input vector (T * 64 doubles) when it fits: no barrier inside the tile loops
   __shared__ double red[4][NB];
   __shared__ double redt[NB][5];
   const int tid = threadIdx.x, row = tid & 63, cp = tid >> 6;
   const double* x = pvec(G, vin);
   const double* S0 = G.S0;
-  const int ld = G.ld;
+  const int ld = G.ld, nT = G.T * NB;
+  if (in_lds) {
+    for (int i = tid; i < nT; i += 256) xs_lds[i] = x[i];
+    __syncthreads();
+  }
+  const double* xs = in_lds ? xs_lds : x;
   double acc = 0.0;
   // tiles (bi, j), j < bi: y[row] += sum_c tile[row][c] x_j[c]; thread (row, cp) takes columns 16 cp ..
   for (int j = 0; j < bi; ++j) {
-    __syncthreads();
-    if (tid < NB) xj[tid] = x[(size_t)j * NB + tid];
-    __syncthreads();
     const double* tp = S0 + (size_t)(j * NB + 16 * cp) * ld + (size_t)bi * NB + row;
+    const double* xj = xs + j * NB + 16 * cp;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc += tp[(size_t)r * ld] * xj[16 * cp + r];
+    for (int r = 0; r < 16; ++r) acc += tp[(size_t)r * ld] * xj[r];
   }
   // diagonal tile: lower triangle only
-  __syncthreads();
-  if (tid < NB) xj[tid] = x[(size_t)bi * NB + tid];
-  __syncthreads();
   {
     const double* tp = S0 + (size_t)(bi * NB) * ld + (size_t)bi * NB;
+    const double* xj = xs + bi * NB;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int c = 16 * cp + r;
@@ -143,12 +144,10 @@ __global__ __launch_bounds__(256) void k_pcg_symv(const GraphDev* __restrict__ G
   const int col = tid >> 2, part = tid & 3;
   double acct = 0.0;
   for (int j = bi + 1; j < G.T; ++j) {
-    __syncthreads();
-    if (tid < NB) xj[tid] = x[(size_t)j * NB + tid];
-    __syncthreads();
     const double* tp = S0 + (size_t)(bi * NB + col) * ld + (size_t)j * NB + 16 * part;
+    const double* xj = xs + j * NB + 16 * part;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acct += tp[r] * xj[16 * part + r];
+    for (int r = 0; r < 16; ++r) acct += tp[r] * xj[r];
   }
   redt[col][part] = acct;
   __syncthreads();
@@ -307,7 +306,8 @@ void launch_pcg_matvec_dots(const GraphDev* d, const GraphDev* h, int n, double*
   maxima(h, n, &nT, &P, &slots);
   const PcgBufs B = bufs_of(bufs, n);
   if (slots > 0) hipLaunchKernelGGL(k_pcg_c, dim3(nblk(9LL * slots, 128), 1, n), dim3(128), 0, s, d, B);
-  if (nT > 0) hipLaunchKernelGGL(k_pcg_symv, dim3(nT / NB, 1, n), dim3(256), 0, s, d, (int)PV_U, (int)PV_W);
+  const int in_lds = (size_t)nT * sizeof(double) <= 48 * 1024 ? 1 : 0;      // (beyond that the vector is read from L2)
+  if (nT > 0) hipLaunchKernelGGL(k_pcg_symv, dim3(nT / NB, 1, n), dim3(256), in_lds ? (size_t)nT * sizeof(double) : 0, s, d, (int)PV_U, (int)PV_W, in_lds);
   if (P > 0 && slots > 0) hipLaunchKernelGGL(k_pcg_cross, dim3(nblk(P, 4), 1, n), dim3(256), 0, s, d, (int)PV_W);
   hipLaunchKernelGGL(k_pcg_dots, dim3(1, 1, n), dim3(256), 0, s, d, B);
 }
