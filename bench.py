@@ -280,9 +280,11 @@ def main():
         drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, base=base, world=wdev, device=device, pcg_iters=args.pcg)
         if sync_coll:
             drv.stream_ordered = False
+        if os.environ.get("SLIDE_BENCH_FORCE_PARTS") == "1":      # rehearsal of the N > 1 control flow (cut pass + RCCL on the batch's stream) on one rank
+            drv.force_parts = True
         step = drv.one_pass
         js = f", joint solve: {drv.pcg_iters} PCG iterations on the global reduced system" if drv.pcg_iters else ", block-Jacobi over robots"
-        mode = ("one replayed hipGraph per pass, factorisations batched" if wdev == 1 else
+        mode = ("one replayed hipGraph per pass, factorisations batched" if (wdev == 1 and not drv.force_parts) else
                 f"replayed hipGraph parts, {backend} all-reduces of the shared-landmark blocks on the same stream between them") + js
     else:
         g = shards[0].graph

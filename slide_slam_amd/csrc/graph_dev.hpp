@@ -82,6 +82,7 @@ struct GraphDev {
   int* chol_ctr;     // T + 2 : work counters of the Cholesky step kernels (self-clearing)
   // ---- joint solve over several robots (pcg_kernels.hip) --------------------------------------
   double* S0;        // copy of S (lower triangle + padding) taken before the factorisation overwrites it: the symmetric products
+  int save_S0;       // 1: the Schur assembly writes every block to S0 as well (batched passes with the joint solve; else a device copy)
   double* pcg;       // 7 vectors of T*NB doubles: r, u, w, p, s, x, y
   double* lm_c;      // 9 L  cross-robot part of sum_b W_b^T u_b per shared landmark (zero for the others)
   double* pcg_scal;  // 8    gamma_old, alpha_old, alpha, beta, first gamma, last gamma

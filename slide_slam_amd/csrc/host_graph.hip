@@ -479,6 +479,7 @@ int CholBatch::prepare_pass() {
     sys[i] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status};
     Tmax = G.T > Tmax ? G.T : Tmax;
     hG[i] = G;
+    hG[i].save_S0 = (pcg_iters > 0 && G.n_slots > 0) ? 1 : 0;      // the batched Schur assembly writes S0 itself
   }
   if (CHOL_BATCH_HOST_MAX * (Tmax + 2) > ctr_cap) {
     if (d_ctr) { SL_HIP(hipStreamSynchronize(master)); SL_HIP(hipFree(d_ctr)); d_ctr = nullptr; }
@@ -524,7 +525,7 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
       if (batch_p3) launch_phase3_batched(d_Gs, hG.data(), n, d_bufs, master);      // five launches for all robots (blockIdx.z = robot)
       else each(3);
     }
-    if (rc == SLIDE_OK && joint) rc = save_systems();
+    if (rc == SLIDE_OK && joint && !batch_p3) rc = save_systems();      // (the batched assembly wrote S0 along with S)
     if (rc == SLIDE_OK && e0) (void)hipEventRecord(e0, master);
     if (rc == SLIDE_OK) rc = factor_all(e1);
     if (rc == SLIDE_OK && joint) rc = enqueue_pcg_head(d_bufs);
@@ -1043,7 +1044,7 @@ int HostGraph::upload_new() {
   G.lm_Hacc = d_lm_Hacc.d; G.lm_t = d_lm_t.d; G.n_slots = (int)h_sh_lid.size(); G.sh_lid = d_sh_lid.d; G.sh_owner = d_sh_owner.d;
   G.lm_Hinv = d_lm_Hinv.d; G.lm_g = d_lm_g.d; G.pose_H = d_pose_H.d; G.pose_g = d_pose_g.d;
   G.S = d_S.d; G.ld = (Tcap + 1) * NB; G.T = T; G.Ld = d_Ld.d; G.Winv = d_Winv.d; G.yv = d_yv.d; G.dp = d_dp.d; G.chol_ctr = d_cctr.d;
-  G.S0 = d_S0.d; G.pcg = d_pcg.d; G.lm_c = d_lm_c.d; G.pcg_scal = d_pcg_scal.d;
+  G.S0 = d_S0.d; G.save_S0 = 0; G.pcg = d_pcg.d; G.lm_c = d_lm_c.d; G.pcg_scal = d_pcg_scal.d;
   G.status = d_status.d;
   G.chart = P.pose_chart;
   G.bearing_sigma = P.bearing_range_sigma; G.cyl_sigma = P.cylinder_sigma; G.numdiff_delta = P.numdiff_delta;

@@ -654,12 +654,16 @@ __device__ __forceinline__ void k_schur_body(const GraphDev& G) {
   for (int pi0 = pj + 32 * (int)blockIdx.y; pi0 < G.P; pi0 += 32 * (int)gridDim.y) {
     const int nval = 6 * min(32, G.P - pi0);
     double* Sb = G.S + (size_t)(6 * pj) * G.ld + 6 * (size_t)pi0;
+    double* S0b = G.S0 + (size_t)(6 * pj) * G.ld + 6 * (size_t)pi0;      // second copy for the joint solve (save_S0)
     const int w = pi0 >> 5, sh = pi0 & 31;
     const unsigned m = sh ? ((adj[w] >> sh) | (adj[w + 1] << (32 - sh))) : adj[w];      // poses pi0 .. pi0 + 31
     if (m == 0u) {
       for (int e = tid; e < 6 * 192; e += 256) {
         const int c = e / 192, r = e % 192;
-        if (r < nval) Sb[(size_t)c * G.ld + r] = 0.0;
+        if (r < nval) {
+          Sb[(size_t)c * G.ld + r] = 0.0;
+          if (G.save_S0) S0b[(size_t)c * G.ld + r] = 0.0;
+        }
       }
       continue;
     }
@@ -767,7 +771,10 @@ __device__ __forceinline__ void k_schur_body(const GraphDev& G) {
   __syncthreads();
   for (int e = tid; e < 6 * 192; e += 256) {
     const int c = e / 192, r = e % 192;
-    if (r < nval) Sb[(size_t)c * G.ld + r] = schur_tile[c][r];
+    if (r < nval) {
+      Sb[(size_t)c * G.ld + r] = schur_tile[c][r];
+      if (G.save_S0) S0b[(size_t)c * G.ld + r] = schur_tile[c][r];
+    }
   }
   __syncthreads();      // the tile is reused by the next chunk
   }
@@ -843,7 +850,7 @@ __device__ __forceinline__ void k_pad_rhs_body(const GraphDev& G) {
   if (t < NT) {
     const int c = (int)t;
     G.S[(size_t)c * G.ld + NT] = (c < n) ? -G.pose_g[c] : 0.0;
-    return;
+    return;                               // (the right-hand-side row is not part of S0: the joint solve takes b from pose_g)
   }
   const long long u = t - NT;
   const int npad = NT - n;
@@ -851,6 +858,7 @@ __device__ __forceinline__ void k_pad_rhs_body(const GraphDev& G) {
   const int r = n + (int)(u / NT), c = (int)(u % NT);
   if (c > r) return;
   G.S[(size_t)c * G.ld + r] = (c == r) ? 1.0 : 0.0;
+  if (G.save_S0) G.S0[(size_t)c * G.ld + r] = (c == r) ? 1.0 : 0.0;
 }
 __global__ void k_pad_rhs(GraphDev G) { k_pad_rhs_body(G); }
 __global__ void k_pad_rhs_b(const GraphDev* __restrict__ Gs) {

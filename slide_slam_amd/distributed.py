@@ -216,6 +216,7 @@ class PassDriver:
         self.ptrs = [b.data_ptr() for b in bufs] if device is not None else None
         self.passes = 0
         self.stream_ordered = True      # False (diagnostic): host-synchronous collectives
+        self.force_parts = False        # True (rehearsal): the cut pass + collectives even when the job is this process alone
         # joint solve: PCG iterations on the global reduced system after the factorisations (0: block-Jacobi over robots).  HIP
         # shards only — the oracle's replica solves the joint graph directly, which is what the joint solve is checked against.
         self.pcg_iters = pcg_iters if n_slots > 0 else 0
@@ -228,7 +229,7 @@ class PassDriver:
 
     def _exchange(self, count):
         """all-reduce(sum) of buffer 0's first `count` doubles across the processes, ordered behind the batch's stream."""
-        if self.world > 1 and count:
+        if (self.world > 1 or (self.force_parts and self.base is not None)) and count:
             self.base.all_reduce_on(self.bufs[0], count, self.batch.stream() if (self.batch is not None and self.stream_ordered) else None)
 
     def _local_sum(self, count):
@@ -252,7 +253,7 @@ class PassDriver:
     def one_pass(self):
         n54, n9, K = 54 * self.n_slots, 9 * self.n_slots, self.pcg_iters
         if self.batch is not None:
-            if self.world == 1:
+            if self.world == 1 and not self.force_parts:
                 self.batch.pass_all(self.ptrs)
             else:
                 self.batch.pass_part(self.ptrs, 0)

@@ -300,7 +300,50 @@ def c3_assoc_check(out, preset="C3"):
     json.dump(res, open(out, "w"))
 
 
+def tiny_pcg(out, preset="C3tiny", passes=15, pcg=8):
+    """Sharded passes with the joint solve on the GPU against the ORACLE's joint replica (the reference's arrangement: one host graph
+    holding every robot, batch Gauss-Newton to convergence) at a size the oracle replays in seconds."""
+    import torch
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)
+    import slide_slam_amd as s
+    from slide_slam_amd.distributed import PassDriver, gpu_matcher, setup_local_shards
+    from slide_slam_amd.replay import replay_single
+    from slide_slam_amd.synth import SynthConfig, make_robot_log, make_world
+    from test_distributed import _joint_optimum
+    joint, counts = _joint_optimum(preset)
+    cfg = SynthConfig.preset(preset)
+    wm = make_world(cfg)
+    R, P = cfg.robots, cfg.poses_per_robot
+    res = {}
+    for mode in ("batched", "unbatched"):
+        shards = [s.SlideBackend(s.default_params(), 1) for _ in range(R)]
+        for r, sh in enumerate(shards):
+            replay_single(sh, make_robot_log(cfg, wm, r), collect=False)
+        batch = s.CholBatch(R) if mode == "batched" else None
+        if batch is not None:
+            for t, sh in enumerate(shards):
+                sh.graph.join_chol_batch(batch, t)
+        bufs, info = setup_local_shards(shards, gpu_matcher, device=dev)
+        drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, device=dev, pcg_iters=pcg)
+        drv.gauss_newton(passes)
+        d = poses_of(shards, P)
+        rel = np.linalg.norm((d - joint).reshape(R, -1), axis=1) / np.linalg.norm(joint.reshape(R, -1), axis=1)
+        res[mode] = dict(rel=float(rel.max()), n_slots=info["n_slots"], n_global=[int(v) for v in info["n_global"]],
+                         chi2=sum(sh.graph.chi2()["total"] for sh in shards), poses=d.tolist())
+        say(mode, "rel err vs the oracle's joint optimum", rel.max(), "slots", info["n_slots"])
+        if batch is not None:
+            for sh in shards:
+                sh.graph.join_chol_batch(None)
+    res["joint_counts"] = [counts["cyl"], counts["cube"], counts["point"]]
+    res["batched_vs_unbatched"] = float(np.abs(np.array(res["batched"]["poses"]) - np.array(res["unbatched"]["poses"])).max())
+    for m in ("batched", "unbatched"):
+        del res[m]["poses"]
+    json.dump(res, open(out, "w"))
+
+
 if __name__ == "__main__":
-    fn = {"c4_parity": c4_parity, "c3_joint": c3_joint, "c5_stream": c5_stream, "c3_converge": c3_converge, "c3_assoc_check": c3_assoc_check}[sys.argv[1]]
+    fn = {"c4_parity": c4_parity, "c3_joint": c3_joint, "c5_stream": c5_stream, "c3_converge": c3_converge, "c3_assoc_check": c3_assoc_check, "tiny_pcg": tiny_pcg}[sys.argv[1]]
     extra = [int(a) if a.lstrip("-").isdigit() else a for a in sys.argv[3:]]
     fn(sys.argv[2], *extra)

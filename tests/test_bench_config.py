@@ -41,6 +41,21 @@ def test_c4_eight_robots_batched_pass_parity(gpu, tmp_path):
     assert abs(z["pcg_chi2"][0] - z["pcg_chi2"][1]) <= 1e-8 * z["pcg_chi2"][1]
 
 
+@pytest.mark.parametrize("preset", ["C3tiny", "C4tiny"])
+def test_joint_solve_matches_the_oracles_joint_replica(gpu, tmp_path, preset):
+    """The sharded passes with the joint solve (PCG, batched in the replayed graph and un-batched through dist_phase 31 / 32 / 33)
+    against the ORACLE's joint replica — one CPU graph holding every robot, the reference's arrangement — on two robots and on FOUR
+    robots that share landmarks: 15 passes end within 1e-4 (the north-star bar) of its optimum; batched == un-batched."""
+    out = str(tmp_path / "tiny.json")
+    _scenario("tiny_pcg", out, preset)
+    z = json.load(open(out))
+    for mode in ("batched", "unbatched"):
+        assert z[mode]["n_slots"] > 0
+        assert sum(abs(a - b) for a, b in zip(z[mode]["n_global"], z["joint_counts"])) <= 1
+        assert z[mode]["rel"] < 1e-4, (mode, z[mode]["rel"])
+    assert z["batched_vs_unbatched"] < 1e-9
+
+
 def test_c3_full_size_sharded_joint_solve_reaches_the_replica_optimum(gpu, tmp_path):
     """configs[2] at size: 2 robots x 500 poses, 188 landmarks observed by both.  The sharded passes with the joint solve (24 PCG
     iterations on the global reduced system per pass) against the optimum of the joint graph a single host replica holds (the
