@@ -27,8 +27,10 @@ namespace sl {
 // experiment builds (python -m slide_slam_amd.build --stamps): phase time stamps of workgroup 0 (100 MHz wall clock)
 __device__ unsigned long long g_assoc_stamps[16];
 #define ASTAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) g_assoc_stamps[i] = wall_clock64(); } while (0)
+#define ASTAMPW(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_assoc_stamps[i] = wall_clock64(); } while (0)      // wave 0, no barrier
 #else
 #define ASTAMP(i)
+#define ASTAMPW(i)
 #endif
 
 __device__ inline double cyl_distance(const double* model, int mlabel, const double* tgt, int tlabel) {
@@ -251,6 +253,7 @@ __device__ inline void assoc_core(const AssocCore& C) {
     const int ol0 = C.det_label[o0], ol1 = C.det_label[two ? o1 : o0];
     double best[2] = {C.best_init, C.best_init};
     int bests[2] = {INT_MAX, INT_MAX};
+    ASTAMPW(8);
     if (C.is_cyl) {
       for (int s = lane; s < Ksub; s += 64) {
         const int mi = C.gate ? (int)(sel[s] & 0xffffffffull) : s;
@@ -267,6 +270,10 @@ __device__ inline void assoc_core(const AssocCore& C) {
       double q0[3], q1[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) { q0[k] = dw0[k]; q1[k] = dw1[k]; }
+#ifdef SLIDE_STAMPS
+      if (q0[0] + q1[0] == 1.2345e300) best[0] = 0.0;      // (forces the loads to complete before the stamp)
+#endif
+      ASTAMPW(9);
       double b2[2] = {-1.0, -1.0};          // squared distance of the lane's best (none yet: < 0)
       constexpr double BAND = 1.0 - 0x1p-48;
       for (int s = lane; s < Ksub; s += 64) {
@@ -286,6 +293,7 @@ __device__ inline void assoc_core(const AssocCore& C) {
           if (take) { b2[h] = d2; bests[h] = s; }
         }
       }
+      ASTAMPW(10);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const double d = b2[h] >= 0.0 ? sqrt(b2[h]) : C.best_init;
@@ -303,6 +311,7 @@ __device__ inline void assoc_core(const AssocCore& C) {
         if (ob < b || (ob == b && os < bs)) { b = ob; bs = os; }
       }
       const int o = h == 0 ? o0 : o1;
+      if (h == 1) ASTAMPW(11);
       if (lane == 0 && (h == 0 || two)) {
         const bool ok = (bs != INT_MAX) && (b < C.thresh);
         if (C.match_sub) C.match_sub[o] = ok ? bs : -1;

@@ -22,3 +22,6 @@ names = ["start", "distance words in LDS", "radix select done", "compaction + pa
 print("rc", rc, "launch ms", ms.value, "n_query", nq)
 for i in range(1, 7):
     print(f"  {names[i]:28s} +{(t[i] - t[i-1]) * 0.01:8.2f} us   (at {(t[i] - t[0]) * 0.01:8.2f} us)")
+w = np.array(st[8:12], dtype=np.float64)
+print("  matching, wave 0: detection data loaded +%.2f us, candidate loop +%.2f us, roots + reduction +%.2f us (first at %.2f us)" %
+      ((w[1] - w[0]) * 0.01, (w[2] - w[1]) * 0.01, (w[3] - w[2]) * 0.01, (w[0] - t[0]) * 0.01))
