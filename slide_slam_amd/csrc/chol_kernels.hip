@@ -13,6 +13,7 @@
 // D[row = (lane>>4) + 4*reg][col = lane&15].
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "graph_dev.hpp"
 #include "kernels.hpp"
@@ -41,9 +42,15 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {   // src: comp
 __device__ unsigned long long g_stamps[40];
 #define STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define STAMPW(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)   // no barrier
+// chained substitutions: wall-clock (100 MHz) stamps of two consecutive blocks in the middle of the chain
+__device__ unsigned long long g_chain_stamps[32];
+#define CSTAMP(i) do { if (threadIdx.x == 0 && (bidx == 30 || bidx == 31)) g_chain_stamps[(bidx - 30) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define CSTAMPP(i) do { if (threadIdx.x == 256 && (bidx == 30 || bidx == 31)) g_chain_stamps[(bidx - 30) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)   // the polling wave
 #else
 #define STAMP(i)
 #define STAMPW(i)
+#define CSTAMP(i)
+#define CSTAMPP(i)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -444,9 +451,10 @@ __device__ __forceinline__ void panel_load(const double* __restrict__ S, int ld,
 // themselves and this wave would only compete for the matrix pipe and the LDS.
 template <int NPAN, bool EARLY>
 __device__ __forceinline__ void panel_rows(double* __restrict__ S, int ld, int k, int it, int q, int gate, int lane, ALds& L, v4d (&Tq)[4],
-                                           const double (&tb)[16]) {
+                                           const double (&tb)[16], float* __restrict__ L32t) {
   const int lr = lane & 15, lk = lane >> 4;
   double* tcol = S + (size_t)(k * NB) * ld + (size_t)it * NB + 16 * q + lr;
+  float* pcol = L32t ? L32t + lk * NB + 16 * q + lr : nullptr;      // packed f32 copy of the tile (element (row, col) at col * 64 + row)
   v4d xt[4], t[4];
   // order: | T(0) x(0) T(1) t(1) | x(1) T(2) t(2) | x(2) T(3) t(3) | x(3): after the last phase only the four MFMAs with the
   // last inverse are left.  t(b) = A_b - sum_{c<b} X_c L(b,c)^T needs phase b-1, x(b) = t(b) L_bb^-T the inverse of phase b.
@@ -486,6 +494,10 @@ __device__ __forceinline__ void panel_rows(double* __restrict__ S, int ld, int k
     xt[b] = x;
 #pragma unroll
     for (int r = 0; r < 4; ++r) tcol[(size_t)(16 * b + lk + 4 * r) * ld] = x[r];
+    if (pcol) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pcol[(16 * b + 4 * r) * NB] = (float)x[r];
+    }
     if (b < 3) {
       PANEL_YIELD();
       if (NPAN > 0 && !EARLY) {
@@ -512,7 +524,7 @@ __device__ __forceinline__ void panel_rows(double* __restrict__ S, int ld, int k
 
 template <int NPAN>
 __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld, int k, int ia, int half, double* __restrict__ Ld,
-                                                 double* __restrict__ Winv, int* status, ALds& L) {
+                                                 double* __restrict__ Winv, int* status, ALds& L, float* __restrict__ L32t) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..7
   const int lr = lane & 15, lk = lane >> 4;
@@ -552,7 +564,7 @@ __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld,
     } else if (wave == 1) {
       v4d R1[2] = {R[0], R[1]};
       a_worker_wave<1, NPAN>(ia, Ld, Winv, L, lane, R1);
-      if (half < 0) panel_rows<NPAN, false>(S, ld, k, it, 0, 0, lane, L, Tq, tb);      // idle from here on otherwise
+      if (half < 0) panel_rows<NPAN, false>(S, ld, k, it, 0, 0, lane, L, Tq, tb, L32t);      // idle from here on otherwise
     } else if (wave == 2) {
       v4d R2[3] = {R[0], R[1], R[2]};
       a_worker_wave<2, NPAN>(ia, Ld, Winv, L, lane, R2);
@@ -574,17 +586,21 @@ __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld,
     double tb[16];
     if (rows) panel_load<NPAN>(S, ld, k, it, q, lr, lk, Tq, tb);
     __syncthreads();
-    if (rows) panel_rows<NPAN, true>(S, ld, k, it, q, wave - 4, lane, L, Tq, tb);
+    if (rows) panel_rows<NPAN, true>(S, ld, k, it, q, wave - 4, lane, L, Tq, tb, L32t);
     STAMPW(14);
     __syncthreads();
     STAMP(1);
     STAMP(2);
   }
 }
-__device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int k, int ia, int half, double* __restrict__ Ld,
-                                            double* __restrict__ Winv, int* status, ALds& L) {
-  if (k > 0) step_type_a_impl<1>(S, ld, k, ia, half, Ld, Winv, status, L);
-  else step_type_a_impl<0>(S, ld, k, ia, half, Ld, Winv, status, L);
+// L32 (or null): packed f32 copy of the factor's off-diagonal tiles, written along with the panel (the preconditioner of the joint solve
+// streams it, see bwd_chain_body): tile (i, k), k < i < T, at 4096 * (k (T-1) - k (k-1) / 2 + i - k - 1)
+__device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int k, int T, int ia, int half, double* __restrict__ Ld,
+                                            double* __restrict__ Winv, int* status, ALds& L, float* __restrict__ L32) {
+  const int it = k + 1 + ia;
+  float* L32t = (L32 && it < T) ? L32 + ((size_t)k * (T - 1) - (size_t)k * (k - 1) / 2 + (it - k - 1)) * (NB * NB) : nullptr;
+  if (k > 0) step_type_a_impl<1>(S, ld, k, ia, half, Ld, Winv, status, L, L32t);
+  else step_type_a_impl<0>(S, ld, k, ia, half, Ld, Winv, status, L, L32t);
 }
 
 // One launch per block column k.  Workgroups 0 .. T-k-1 are type A (column k with its pending panel k-1); every workgroup of
@@ -593,13 +609,13 @@ __device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int 
 // the one workgroup per CU the register-heavy kernel gets.  ctr[k+1] is cleared here for the next launch (ctr[0..1] start at 0).
 __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Ld,
                                                    double* __restrict__ Winv, int* status, int* __restrict__ ctr, int kb, int nP,
-                                                   int g0, int g1, int nX, int a_joins, int a_split) {
+                                                   int g0, int g1, int nX, int a_joins, int a_split, float* __restrict__ L32) {
   __shared__ ALds L;
   __shared__ int s_g;
   const int nA = (T - k) << a_split;      // a_split: two type-A workgroups per tile, 32 panel rows each (A-bound launches: the CUs are there)
   if (blockIdx.x == 0 && threadIdx.x == 0) ctr[k + 1] = 0;
   if ((int)blockIdx.x < nA) {
-    step_type_a(S, ld, k, (int)blockIdx.x >> a_split, a_split ? (int)(blockIdx.x & 1) : -1, Ld, Winv, status, L);
+    step_type_a(S, ld, k, T, (int)blockIdx.x >> a_split, a_split ? (int)(blockIdx.x & 1) : -1, Ld, Winv, status, L, L32);
     if (!a_joins) return;        // the queue workers are through before the chain is: an item taken now would only add a tail
   }
   const int nR = g1 - g0, nItems = nR + nX;
@@ -625,6 +641,7 @@ struct CholBatchArgs {
   int n;
   double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX];
   double* Ld[CHOL_BATCH_MAX]; double* Winv[CHOL_BATCH_MAX]; int* status[CHOL_BATCH_MAX];
+  float* L32[CHOL_BATCH_MAX];
   int nP[CHOL_BATCH_MAX], g0[CHOL_BATCH_MAX], g1[CHOL_BATCH_MAX], nX[CHOL_BATCH_MAX], a_split[CHOL_BATCH_MAX];
   int a_base[CHOL_BATCH_MAX + 1];      // prefix sums of the type-A workgroup counts
   int b_base[CHOL_BATCH_MAX + 1];      // prefix sums of the type-B item counts
@@ -638,8 +655,8 @@ __global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int 
     int r = 0;
     while (bid >= A.a_base[r + 1]) ++r;
     const int local = bid - A.a_base[r], sp = A.a_split[r];
-    step_type_a(A.S[r], A.ld[r], k, local >> sp, sp ? (local & 1) : -1, A.Ld[r] + (size_t)k * NB * NB, A.Winv[r] + (size_t)k * 1024,
-                A.status[r], L);
+    step_type_a(A.S[r], A.ld[r], k, A.T[r], local >> sp, sp ? (local & 1) : -1, A.Ld[r] + (size_t)k * NB * NB, A.Winv[r] + (size_t)k * 1024,
+                A.status[r], L, A.L32[r]);
     if (!a_joins) return;
   }
   const int nItems = A.b_base[A.n];
@@ -664,6 +681,7 @@ __global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int 
 
 #ifdef SLIDE_STAMPS
 extern "C" void slide_debug_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
+extern "C" void slide_debug_chain_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_stamps), sizeof(g_chain_stamps)); }
 #endif
 
 // A quiet-NaN payload no solution value can equal bit for bit: dp[] is filled with it before the backward substitution,
@@ -688,31 +706,64 @@ __global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, do
 // do not depend on x and are prefetched three ahead; the explicit 64x64 inverse of L_cc is assembled from the 16x16 inverses
 // and sub-tiles of the factorisation while the workgroup would otherwise wait.  Polling loads and publishing stores are
 // relaxed device-scope atomics (they bypass the non-coherent cache levels between XCDs); the data is its own flag.
-__device__ __forceinline__ void bwd_chain_body(const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
-                                               const double* __restrict__ Winv, const double* __restrict__ yv, double* dp, int* status, int bidx) {
-  __shared__ double Ms[NB][NB + 1];     // M = L_cc^-1 (lower triangle), Ms[row][col]
-  __shared__ double Lo[6][256];         // off-diagonal 16x16 blocks (b > a) of L_cc: Lo[b (b-1)/2 + a][col * 16 + row]
-  __shared__ double Ws[4][256];         // 16x16 inverses: Ws[b][col * 16 + row]
-  __shared__ double tmp[3][256];
-  __shared__ double xs[2][NB];
-  __shared__ double ys[NB];
+// F32 = false: tiles from S (f64) — the solve of the factorisation's own right-hand side.  F32 = true: tiles from L32, the packed f32
+// copy the type-A workgroups of the factorisation write next to every panel tile (step_type_a) — the preconditioner of the joint
+// solve (pcg_kernels.hip) streams half the bytes, in 16 KB runs; any SPD M~ = L~ L~^T is a valid preconditioner, the operator S0
+// and all vectors stay f64.  L32: tile (j, c), j > c, at 4096 * (c (T-1) - c (c-1) / 2 + j - c - 1), element (row, col) of it at
+// col * 64 + row.
+// Workgroups of the chained substitutions: four waves own the tiles, a fifth does nothing but poll for the next x_j.  Vector-memory
+// loads return in order, so a poll issued by a wave that has tile prefetches in flight is not seen before those have come back from
+// HBM (measured with tools/chain_stamps.py: 0.9 us mean per hop against 0.5 us for the bare publish -> poll round trip,
+// tools/hop_bench.hip); the polling wave has no other loads outstanding.
+constexpr int CHAIN_THREADS = 320;
+struct alignas(16) ChainLds {     // one per workgroup, shared by every instantiation of the chain bodies (16-byte aligned: ds_read_b128)
+  alignas(16) double xs[2][NB];
+  alignas(16) double ys[NB];
+  alignas(16) double red[4][NB];
+  alignas(16) double Lo[6][256];  // off-diagonal 16x16 blocks (b > a) of L_cc: Lo[b (b-1)/2 + a][col * 16 + row]
+  alignas(16) double Ws[4][256];  // 16x16 inverses: Ws[b][col * 16 + row]
+  alignas(16) double tmp[3][256];
+  alignas(16) double Ms[NB][NB + 1];   // M = L_cc^-1 (lower triangle), Ms[row][col]
+};
+template <bool F32>
+__device__ __forceinline__ void bwd_chain_body(ChainLds& W, const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
+                                               const double* __restrict__ Winv, const double* __restrict__ yv, double* dp, int* status, int bidx,
+                                               const float* __restrict__ L32) {
+  auto& Ms = W.Ms; auto& Lo = W.Lo; auto& Ws = W.Ws; auto& tmp = W.tmp; auto& xs = W.xs; auto& ys = W.ys;
   const int tid = threadIdx.x;
+  const bool worker = tid < 256;                       // waves 0..3: the tiles; wave 4 only polls (see CHAIN_THREADS)
+  CSTAMP(0);
   const int c = T - 1 - bidx;
   const int col = tid >> 2, part = tid & 3;            // tile work: column col, rows 16 part .. 16 part + 15
   const int nj = T - 1 - c;                            // tiles (j, c), j = T-1-q, q = 0 .. nj-1
-  constexpr int RB = 3;
-  double tr[RB][16];
+  constexpr int RB = F32 ? 6 : 3;
+  typedef typename std::conditional<F32, float, double>::type tile_t;
+  tile_t tr[RB][16];
   const double* tcol = S + (size_t)(c * NB + col) * ld + 16 * part;
+  // packed tiles of column c: (c+1, c) first; tile (T-1-q, c) is number nj-1-q of the run
+  const float* pcol = F32 ? L32 + ((size_t)c * (T - 1) - (size_t)c * (c - 1) / 2) * (NB * NB) + col * NB + 16 * part : nullptr;
+  auto tile_load = [&](tile_t (&dst)[16], int q) {
+    if (F32) {
+      const float4* tp = reinterpret_cast<const float4*>(pcol + (size_t)(nj - 1 - q) * (NB * NB));
 #pragma unroll
-  for (int q = 0; q < RB; ++q) {
-    if (q < nj) {
+      for (int r = 0; r < 4; ++r) {
+        const float4 v = tp[r];
+        dst[4 * r] = v.x; dst[4 * r + 1] = v.y; dst[4 * r + 2] = v.z; dst[4 * r + 3] = v.w;
+      }
+    } else {
       const double* tp = tcol + (size_t)(T - 1 - q) * NB;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tr[q][r] = tp[r];
+      for (int r = 0; r < 16; ++r) dst[r] = tp[r];
     }
+  };
+  double y0 = 0.0;
+  if (worker) {
+#pragma unroll
+    for (int q = 0; q < RB; ++q)
+      if (q < nj) tile_load(tr[q], q);
+    y0 = yv[c * NB + col];
   }
-  const double y0 = yv[c * NB + col];
-  {
+  if (worker) {
     const double* Ldk = Ld + (size_t)c * NB * NB;
     const double* Wk = Winv + (size_t)c * 1024;
 #pragma unroll
@@ -725,9 +776,11 @@ __device__ __forceinline__ void bwd_chain_body(const double* __restrict__ S, int
   __syncthreads();
   {
     // M_bb = W_b ; M_ba = -W_b sum_{m = a}^{b-1} L_bm M_ma  (b > a), by distance from the diagonal; thread = element (r, cc)
-    const int r = tid & 15, cc = tid >> 4;
+    const int r = tid & 15, cc = (tid >> 4) & 15;
+    if (worker) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) Ms[16 * b + r][16 * b + cc] = Ws[b][cc * 16 + r];
+      for (int b = 0; b < 4; ++b) Ms[16 * b + r][16 * b + cc] = Ws[b][cc * 16 + r];
+    }
     __syncthreads();
 #pragma unroll
     for (int d = 1; d < 4; ++d) {
@@ -739,7 +792,7 @@ __device__ __forceinline__ void bwd_chain_body(const double* __restrict__ S, int
         for (int m = a; m < b; ++m)
 #pragma unroll
           for (int n = 0; n < 16; ++n) t += Lo[b * (b - 1) / 2 + m][n * 16 + r] * Ms[16 * m + n][16 * a + cc];
-        tmp[a][cc * 16 + r] = t;
+        if (worker) tmp[a][cc * 16 + r] = t;
       }
       __syncthreads();
 #pragma unroll
@@ -748,26 +801,29 @@ __device__ __forceinline__ void bwd_chain_body(const double* __restrict__ S, int
         double v = 0.0;
 #pragma unroll
         for (int n = 0; n < 16; ++n) v += Ws[b][n * 16 + r] * tmp[a][cc * 16 + n];
-        Ms[16 * b + r][16 * a + cc] = -v;
+        if (worker) Ms[16 * b + r][16 * a + cc] = -v;
       }
       __syncthreads();
     }
   }
   double mreg[16];                       // own column of M^T: rows 16 part .. of column col (zero above the diagonal)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) mreg[r] = (16 * part + r >= col) ? Ms[16 * part + r][col] : 0.0;
+  for (int r = 0; r < 16; ++r) mreg[r] = (worker && 16 * part + r >= col) ? Ms[16 * part + r][col] : 0.0;
   double acc = 0.0;
+  CSTAMP(1);
   for (int q0 = 0; q0 < nj; q0 += RB) {
 #pragma unroll
     for (int qq = 0; qq < RB; ++qq) {
       const int q = q0 + qq;
       if (q < nj) {
         const int j = T - 1 - q;
-        if (tid < NB) {
+        if (q == nj - 1) CSTAMPP(2);
+        if (!worker) {                          // the polling wave has no other vector-memory traffic: its loads are not queued behind tile prefetches
+          const int lane = tid - 256;
           double v;
           int spins = 0;
           for (;;) {
-            v = __hip_atomic_load(dp + (size_t)j * NB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __hip_atomic_load(dp + (size_t)j * NB + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned long long)__double_as_longlong(v) != BWD_SENT) break;
             if (++spins > (1 << 21)) {          // exit condition every wave reaches: give up (seconds), flag the solve as failed
               v = __builtin_nan("");
@@ -776,29 +832,32 @@ __device__ __forceinline__ void bwd_chain_body(const double* __restrict__ S, int
             }
             __builtin_amdgcn_s_sleep(1);
           }
-          xs[q & 1][tid] = v;
+          xs[q & 1][lane] = v;
+          if (q == nj - 1) CSTAMPP(3);
+          if (q == nj - 2) CSTAMPP(7);
         }
         __syncthreads();
+        if (worker) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc += tr[qq][r] * xs[q & 1][16 * part + r];
-        if (q + RB < nj) {
-          const double* tp = tcol + (size_t)(T - 1 - (q + RB)) * NB;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) tr[qq][r] = tp[r];
+          for (int r = 0; r < 16; ++r) acc += (double)tr[qq][r] * xs[q & 1][16 * part + r];
+          if (q + RB < nj) tile_load(tr[qq], q + RB);
         }
       }
     }
   }
+  CSTAMP(4);
   acc += __shfl_xor(acc, 1);
   acc += __shfl_xor(acc, 2);
-  if (part == 0) ys[col] = y0 - acc;
+  if (worker && part == 0) ys[col] = y0 - acc;
   __syncthreads();
+  CSTAMP(5);
   double x = 0.0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) x += mreg[r] * ys[16 * part + r];
   x += __shfl_xor(x, 1);
   x += __shfl_xor(x, 2);
-  if (part == 0) __hip_atomic_store(dp + (size_t)c * NB + col, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (worker && part == 0) __hip_atomic_store(dp + (size_t)c * NB + col, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  CSTAMP(6);
 }
 __device__ __forceinline__ int bwd_ticket(int* ctr) {
   __shared__ int s_t;
@@ -808,11 +867,12 @@ __device__ __forceinline__ int bwd_ticket(int* ctr) {
   __syncthreads();
   return t;
 }
-__global__ __launch_bounds__(256) void k_chol_bwd_chain(const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
+__global__ __launch_bounds__(CHAIN_THREADS) void k_chol_bwd_chain(const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
                                                         const double* __restrict__ Winv, const double* __restrict__ yv, double* dp, int* status) {
+  __shared__ ChainLds W;
   const int t = bwd_ticket(&status[4]);
   if (t >= T) return;
-  bwd_chain_body(S, ld, T, Ld, Winv, yv, dp, status, t);
+  bwd_chain_body<false>(W, S, ld, T, Ld, Winv, yv, dp, status, t, nullptr);
 }
 struct BwdBatchArgs {
   int n;
@@ -824,13 +884,14 @@ struct BwdBatchArgs {
 };
 // ticket t -> system t % n, block t / n of it: the chains of all systems advance side by side; a ticket beyond a shorter system's
 // end is void and the workgroup draws again (there are exactly as many valid tickets as workgroups)
-__global__ __launch_bounds__(256) void k_chol_bwd_chain_batched(BwdBatchArgs A) {
+__global__ __launch_bounds__(CHAIN_THREADS) void k_chol_bwd_chain_batched(BwdBatchArgs A) {
+  __shared__ ChainLds W;
   for (;;) {
     const int t = bwd_ticket(&A.status[0][4]);
     if (t >= A.n * A.Tmax) return;
     const int r = t % A.n, b = t / A.n;
     if (b >= A.T[r]) continue;
-    bwd_chain_body(A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.yv[r], A.dp[r], A.status[r], b);
+    bwd_chain_body<false>(W, A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.yv[r], A.dp[r], A.status[r], b, nullptr);
     return;
   }
 }
@@ -840,31 +901,38 @@ __global__ __launch_bounds__(256) void k_chol_bwd_chain_batched(BwdBatchArgs A) 
 // The preconditioner of the joint solve (pcg_kernels.hip) applies S_a^-1 = L^-T L^-1 to vectors other than the right-hand side
 // that rode through the factorisation.  Ticket t owns block row c = t: x_c = L_cc^-1 (r_c - sum_{j < c} L(c, j) x_j), the x_j
 // polled from `xout` (pre-filled with the sentinel) as the lower tickets publish them; tiles L(c, j) prefetched three ahead.
-__device__ __forceinline__ void fwd_chain_body(const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
-                                               const double* __restrict__ Winv, const double* __restrict__ rin, double* xout, int* status, int c) {
-  __shared__ double Ms[NB][NB + 1];     // M = L_cc^-1 (lower triangle), Ms[row][col]
-  __shared__ double Lo[6][256];
-  __shared__ double Ws[4][256];
-  __shared__ double tmp[3][256];
-  __shared__ double xs[2][NB];
-  __shared__ double red[4][NB];
-  __shared__ double ys[NB];
+template <bool F32>      // tiles from the packed f32 copy (see bwd_chain_body) instead of S
+__device__ __forceinline__ void fwd_chain_body(ChainLds& W, const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
+                                               const double* __restrict__ Winv, const double* __restrict__ rin, double* xout, int* status, int c,
+                                               const float* __restrict__ L32) {
+  auto& Ms = W.Ms; auto& Lo = W.Lo; auto& Ws = W.Ws; auto& tmp = W.tmp; auto& xs = W.xs; auto& ys = W.ys; auto& red = W.red;
   const int tid = threadIdx.x;
-  const int row = tid & 63, cp = tid >> 6;             // tile work: row `row`, columns 16 cp .. 16 cp + 15
+  const bool worker = tid < 256;                       // waves 0..3: the tiles; wave 4 only polls
+  const int row = tid & 63, cp = (tid >> 6) & 3;       // tile work: row `row`, columns 16 cp .. 16 cp + 15
   const int nj = c;                                    // tiles (c, j), j = 0 .. c-1
-  constexpr int RB = 3;
-  double tr[RB][16];
+  constexpr int RB = F32 ? 6 : 3;
+  typedef typename std::conditional<F32, float, double>::type tile_t;
+  tile_t tr[RB][16];
   const double* tbase = S + (size_t)(16 * cp) * ld + (size_t)c * NB + row;     // + (j * NB + r) * ld
+  const float* pbase = F32 ? L32 + 16 * cp * NB + row : nullptr;               // + tile (c, j) + r * NB
+  auto tile_load = [&](tile_t (&dst)[16], int j) {
+    if (F32) {
+      const float* tp = pbase + ((size_t)j * (T - 1) - (size_t)j * (j - 1) / 2 + (c - j - 1)) * (NB * NB);
 #pragma unroll
-  for (int q = 0; q < RB; ++q) {
-    if (q < nj) {
-      const double* tp = tbase + (size_t)(q * NB) * ld;
+      for (int r = 0; r < 16; ++r) dst[r] = tp[r * NB];
+    } else {
+      const double* tp = tbase + (size_t)(j * NB) * ld;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tr[q][r] = tp[(size_t)r * ld];
+      for (int r = 0; r < 16; ++r) dst[r] = tp[(size_t)r * ld];
     }
+  };
+  if (worker) {
+#pragma unroll
+    for (int q = 0; q < RB; ++q)
+      if (q < nj) tile_load(tr[q], q);
   }
   const double r0 = rin[c * NB + row];
-  {
+  if (worker) {
     const double* Ldk = Ld + (size_t)c * NB * NB;
     const double* Wk = Winv + (size_t)c * 1024;
 #pragma unroll
@@ -876,9 +944,11 @@ __device__ __forceinline__ void fwd_chain_body(const double* __restrict__ S, int
   }
   __syncthreads();
   {
-    const int r = tid & 15, cc = tid >> 4;
+    const int r = tid & 15, cc = (tid >> 4) & 15;
+    if (worker) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) Ms[16 * b + r][16 * b + cc] = Ws[b][cc * 16 + r];
+      for (int b = 0; b < 4; ++b) Ms[16 * b + r][16 * b + cc] = Ws[b][cc * 16 + r];
+    }
     __syncthreads();
 #pragma unroll
     for (int d = 1; d < 4; ++d) {
@@ -890,7 +960,7 @@ __device__ __forceinline__ void fwd_chain_body(const double* __restrict__ S, int
         for (int m = a; m < b; ++m)
 #pragma unroll
           for (int n = 0; n < 16; ++n) t += Lo[b * (b - 1) / 2 + m][n * 16 + r] * Ms[16 * m + n][16 * a + cc];
-        tmp[a][cc * 16 + r] = t;
+        if (worker) tmp[a][cc * 16 + r] = t;
       }
       __syncthreads();
 #pragma unroll
@@ -899,7 +969,7 @@ __device__ __forceinline__ void fwd_chain_body(const double* __restrict__ S, int
         double v = 0.0;
 #pragma unroll
         for (int n = 0; n < 16; ++n) v += Ws[b][n * 16 + r] * tmp[a][cc * 16 + n];
-        Ms[16 * b + r][16 * a + cc] = -v;
+        if (worker) Ms[16 * b + r][16 * a + cc] = -v;
       }
       __syncthreads();
     }
@@ -910,11 +980,11 @@ __device__ __forceinline__ void fwd_chain_body(const double* __restrict__ S, int
     for (int qq = 0; qq < RB; ++qq) {
       const int q = q0 + qq;
       if (q < nj) {
-        if (tid < NB) {
+        if (!worker) {                          // the polling wave: no tile loads in front of its own (see bwd_chain_body)
           double v;
           int spins = 0;
           for (;;) {
-            v = __hip_atomic_load(xout + (size_t)q * NB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __hip_atomic_load(xout + (size_t)q * NB + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned long long)__double_as_longlong(v) != BWD_SENT) break;
             if (++spins > (1 << 21)) {          // exit condition every wave reaches
               v = __builtin_nan("");
@@ -923,22 +993,20 @@ __device__ __forceinline__ void fwd_chain_body(const double* __restrict__ S, int
             }
             __builtin_amdgcn_s_sleep(1);
           }
-          xs[q & 1][tid] = v;
+          xs[q & 1][row] = v;
         }
         __syncthreads();
+        if (worker) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc += tr[qq][r] * xs[q & 1][16 * cp + r];
-        if (q + RB < nj) {
-          const double* tp = tbase + (size_t)((q + RB) * NB) * ld;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) tr[qq][r] = tp[(size_t)r * ld];
+          for (int r = 0; r < 16; ++r) acc += (double)tr[qq][r] * xs[q & 1][16 * cp + r];
+          if (q + RB < nj) tile_load(tr[qq], q + RB);
         }
       }
     }
   }
-  red[cp][row] = acc;
+  if (worker) red[cp][row] = acc;
   __syncthreads();
-  if (cp == 0) ys[row] = r0 - ((red[0][row] + red[1][row]) + (red[2][row] + red[3][row]));
+  if (tid < NB) ys[row] = r0 - ((red[0][row] + red[1][row]) + (red[2][row] + red[3][row]));
   __syncthreads();
   double part = 0.0;
 #pragma unroll
@@ -946,9 +1014,9 @@ __device__ __forceinline__ void fwd_chain_body(const double* __restrict__ S, int
     const int col = 16 * cp + k;
     if (col <= row) part += Ms[row][col] * ys[col];
   }
-  red[cp][row] = part;
+  if (worker) red[cp][row] = part;
   __syncthreads();
-  if (cp == 0) {
+  if (tid < NB) {
     const double x = (red[0][row] + red[1][row]) + (red[2][row] + red[3][row]);
     __hip_atomic_store(xout + (size_t)c * NB + row, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -960,17 +1028,19 @@ struct ChainBatchArgs {
   const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX];
   const double* Ld[CHOL_BATCH_MAX]; const double* Winv[CHOL_BATCH_MAX]; const double* in[CHOL_BATCH_MAX]; double* out[CHOL_BATCH_MAX];
   int* status[CHOL_BATCH_MAX];
+  float* L32[CHOL_BATCH_MAX];          // packed f32 copy of the factor (written by the factorisation's own backward chain) or null
   int Tmax;
 };
 template <bool FWD>
-__global__ __launch_bounds__(256) void k_chain_batched(ChainBatchArgs A) {
+__global__ __launch_bounds__(CHAIN_THREADS) void k_chain_batched(ChainBatchArgs A) {
+  __shared__ ChainLds W;
   for (;;) {
     const int t = bwd_ticket(&A.status[0][FWD ? 5 : 4]);
     if (t >= A.n * A.Tmax) return;
     const int r = t % A.n, b = t / A.n;
     if (b >= A.T[r]) continue;
-    if (FWD) fwd_chain_body(A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.in[r], A.out[r], A.status[r], b);
-    else bwd_chain_body(A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.in[r], A.out[r], A.status[r], b);
+    if (FWD) fwd_chain_body<true>(W, A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.in[r], A.out[r], A.status[r], b, A.L32[r]);
+    else bwd_chain_body<true>(W, A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.in[r], A.out[r], A.status[r], b, A.L32[r]);
     return;
   }
 }
@@ -991,6 +1061,7 @@ void launch_chain_batch(const CholSystem* d, int n, const double* const* in, dou
   for (int i = 0; i < n; ++i) {
     A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.Ld[i] = d[i].Ld; A.Winv[i] = d[i].Winv; A.in[i] = in[i]; A.out[i] = out[i];
     A.status[i] = d[i].status;
+    A.L32[i] = d[i].L32;
     Tmax = d[i].T > Tmax ? d[i].T : Tmax;
     total += d[i].T;
     Pr.out[i] = out[i];
@@ -998,10 +1069,12 @@ void launch_chain_batch(const CholSystem* d, int n, const double* const* in, dou
   }
   A.Tmax = Tmax;
   if (total <= 0) return;
+  for (int i = 0; i < n; ++i)
+    if (!d[i].L32) { fprintf(stderr, "slide_slam_amd: launch_chain_batch without the packed f32 factor\n"); abort(); }
   Pr.ticket = d[0].status + (fwd ? 5 : 4);
   hipLaunchKernelGGL(k_chain_prepare, dim3((Tmax * NB + 255) / 256, n), dim3(256), 0, s, Pr);
-  if (fwd) hipLaunchKernelGGL(k_chain_batched<true>, dim3(total), dim3(256), 0, s, A);
-  else hipLaunchKernelGGL(k_chain_batched<false>, dim3(total), dim3(256), 0, s, A);
+  if (fwd) hipLaunchKernelGGL(k_chain_batched<true>, dim3(total), dim3(CHAIN_THREADS), 0, s, A);
+  else hipLaunchKernelGGL(k_chain_batched<false>, dim3(total), dim3(CHAIN_THREADS), 0, s, A);
 }
 
 // ---- marginal covariance of one pose (getPoseCovariance graph.cpp:314-323) ---------------------------------------------------
@@ -1117,7 +1190,7 @@ static StepPlan plan_step(int k, int T) {
   p.nB = p.g1 - p.g0 + p.nX;
   return p;
 }
-void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, hipStream_t s) {
+void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, float* L32, hipStream_t s) {
   const int n_cu = chol_n_cu();
   const StepPlan p = plan_step(k, T);
   const long long nA = p.nA, nB = p.nB;
@@ -1131,7 +1204,7 @@ void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv,
   static const int join_mul = getenv("SLIDE_CHOL_JOIN") ? atoi(getenv("SLIDE_CHOL_JOIN")) : 1;
   const int a_joins = nB > join_mul * free_cu ? 1 : 0;
   hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nAw + extra)), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status, ctr, p.kb, p.nP,
-                     p.g0, p.g1, p.nX, a_joins, a_split);
+                     p.g0, p.g1, p.nX, a_joins, a_split, L32);
 }
 // The factorisations + solves of several systems as one launch sequence (max T step launches, the extractions, one chained backward
 // substitution): d[i] describes system i; ctr is the work counter array of the batch (max T + 2 ints, zeroed once).
@@ -1149,6 +1222,7 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
     A.a_base[0] = A.b_base[0] = 0;
     for (int i = 0; i < n; ++i) {
       A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.Ld[i] = d[i].Ld; A.Winv[i] = d[i].Winv; A.status[i] = d[i].status;
+      A.L32[i] = d[i].L32;
       A.nP[i] = pl[i].nP; A.g0[i] = pl[i].g0; A.g1[i] = pl[i].g1; A.nX[i] = pl[i].nX; A.a_split[i] = a_split;
       A.a_base[i + 1] = A.a_base[i] + (int)(pl[i].nA << a_split);
       A.b_base[i + 1] = A.b_base[i] + (int)pl[i].nB;
@@ -1170,15 +1244,15 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
     B.base[i + 1] = B.base[i] + d[i].T;
   }
   B.Tmax = Tmax;
-  if (B.base[n] > 0) hipLaunchKernelGGL(k_chol_bwd_chain_batched, dim3(B.base[n]), dim3(256), 0, s, B);
+  if (B.base[n] > 0) hipLaunchKernelGGL(k_chol_bwd_chain_batched, dim3(B.base[n]), dim3(CHAIN_THREADS), 0, s, B);
 }
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp,
                          int* status, hipStream_t s) {
-  hipLaunchKernelGGL(k_chol_bwd_chain, dim3(T), dim3(256), 0, s, S, ld, T, Ld, Winv, yv, dp, status);
+  hipLaunchKernelGGL(k_chol_bwd_chain, dim3(T), dim3(CHAIN_THREADS), 0, s, S, ld, T, Ld, Winv, yv, dp, status);
 }
 
 int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double* yv, double* dp, int* status, int* ctr, hipStream_t s) {
-  for (int k = 0; k < T; ++k) launch_chol_step(S, ld, k, T, Ld + (size_t)k * NB * NB, Winv + (size_t)k * 1024, status, ctr, s);
+  for (int k = 0; k < T; ++k) launch_chol_step(S, ld, k, T, Ld + (size_t)k * NB * NB, Winv + (size_t)k * 1024, status, ctr, nullptr, s);
   launch_chol_extract_y(S, ld, T, yv, dp, status, s);
   launch_chol_bwd_all(S, ld, T, Ld, Winv, yv, dp, status, s);
   return 0;

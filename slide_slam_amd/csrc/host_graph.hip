@@ -408,7 +408,7 @@ int CholBatch::factor_solve(int slot, const GraphDev& G, hipStream_t s) {
   if (slot < 0 || slot >= n) return SLIDE_ERR_INVALID;
   {
     std::lock_guard<std::mutex> lk(mtx);
-    sys[slot] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status};
+    sys[slot] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, (pcg_iters > 0 && G.n_slots > 0) ? graphs[slot]->d_L32.d : nullptr};
   }
   return rendezvous(slot, s, false, 0);
 }
@@ -476,7 +476,7 @@ int CholBatch::prepare_pass() {
   hG.resize(n);
   for (int i = 0; i < n; ++i) {
     const GraphDev& G = graphs[i]->G;
-    sys[i] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status};
+    sys[i] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, (pcg_iters > 0 && G.n_slots > 0) ? graphs[i]->d_L32.d : nullptr};
     Tmax = G.T > Tmax ? G.T : Tmax;
     hG[i] = G;
     hG[i].save_S0 = (pcg_iters > 0 && G.n_slots > 0) ? 1 : 0;      // the batched Schur assembly writes S0 itself
@@ -791,7 +791,8 @@ int CholBatch::pass_part(double* const* d_bufs, int part) {
 int HostGraph::factor_and_solve(hipStream_t s) {
   if (batch) return batch->factor_solve(batch_slot, G, s);
   for (int k = 0; k < G.T; ++k)
-    launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, s);
+    launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr,
+                     (pcg_iters > 0 && G.n_slots > 0) ? d_L32.d : nullptr, s);
   launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, G.status, s);
   launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, s);
   return SLIDE_OK;
@@ -1010,6 +1011,7 @@ int HostGraph::upload_new() {
     d_S0.cap = 0;
     if (d_S0.d) { SL_HIP(hipFree(d_S0.d)); d_S0.d = nullptr; }
     if (d_S0.ensure(ld * (size_t)Tcap * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_L32.ensure((size_t)Tcap * (Tcap - 1) / 2 * NB * NB + 4, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_pcg.ensure((size_t)PCG_VEC_COUNT * Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_pcg_scal.ensure(8, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_Ld.ensure((size_t)Tcap * NB * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
@@ -1066,7 +1068,7 @@ int HostGraph::enqueue_iteration(bool lookahead) {
   STAGE(4, launch_schur(G, s));
   (void)lookahead;
   for (int k = 0; k < G.T; ++k)
-    STAGE(5, launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, s));
+    STAGE(5, launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, nullptr, s));
   STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, G.status, s));
   STAGE(8, launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, s));
   STAGE(9, launch_backsub(G, 0, s));
@@ -1218,7 +1220,7 @@ int HostGraph::enqueue_phase(int phase, double* d_buf) {
       launch_shared_pack(G, 1, d_buf, s);
     } else {
       const size_t nT = (size_t)G.T * NB;
-      const CholSystem cs{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status};
+      const CholSystem cs{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, d_L32.d};
       const double* in = G.pcg + PCG_VEC_R * nT;
       double* out = G.pcg + PCG_VEC_Y * nT;
       launch_chain_batch(&cs, 1, &in, &out, true, s);

@@ -278,6 +278,7 @@ class HostGraph {
   std::vector<int> h_sh_lid, h_sh_owner;
   DevArr<double> d_S, d_Ld, d_Winv, d_yv, d_dp;
   DevArr<double> d_S0, d_pcg, d_lm_c, d_pcg_scal;      // joint solve (pcg_kernels.hip)
+  DevArr<float> d_L32;                                 // packed f32 copy of the factor: the joint solve's preconditioner streams this
   DevArr<GraphDev> d_Gself;                             // this graph's view on the device, for the kernels that take an array of views
   GraphDev G_self{};
   bool have_self = false;
