@@ -141,7 +141,10 @@ __device__ __forceinline__ void b_quadrant(double* __restrict__ S, int ld, const
 // item g of launch k.  g < nR: item g0 + g of the rank-128 pass of pair base kb = tile row i of a 2x2 group, tiles (i, j0),
 // (i, j0 + 1).  Then the column items c = g - nR of an odd launch: tiles (k+1 + 2c, k+1), (k+2 + 2c, k+1) take panel k-1.
 // Eight waves: tile (wave >> 2), 32x32 quadrant (wave & 3).
-__device__ __forceinline__ BItem b_decode(int g, int nItems, int nR, int g0, int k, int kb, int T, int nP, long long nG, int wave) {
+// Profile (envelope) of the factor: the launches enumerate rows / columns up to a VIRTUAL size Tv <= T — real tile rows 0 .. Tv-1, the
+// right-hand-side row as virtual row Tv — and map virtual row Tv to the physical tile row T.  TvB = profile of panel kb-1 (the rank-128
+// pass), TvX = profile of panel k-1 (the column items); tiles beyond hold zeros and get zero contributions (launch_chol_step).
+__device__ __forceinline__ BItem b_decode(int g, int nItems, int nR, int g0, int k, int kb, int T, int TvB, int TvX, int nP, long long nG, int wave) {
   BItem it;
   it.ok = false; it.i = it.j = it.pcb = 0; it.ks = 32;
   if (g >= nItems) return it;
@@ -154,13 +157,15 @@ __device__ __forceinline__ BItem b_decode(int g, int nItems, int nR, int g0, int
     it.i = kb + 1 + 2 * bi + (int)(tt & 1);
     it.j = kb + 1 + 2 * bj + (wave >> 2);
     it.pcb = kb - 2;
-    it.ok = !(it.i > T || it.j > T - 1 || it.i < it.j);
+    it.ok = !(it.i > TvB || it.j > TvB - 1 || it.i < it.j);
+    if (it.i == TvB) it.i = T;
   } else {
     const int c = g - nR;
     it.j = k + 1;
     it.i = k + 1 + 2 * c + (wave >> 2);
     it.pcb = k - 1; it.ks = 16;
-    it.ok = !(it.i > T || it.j > T - 1);
+    it.ok = !(it.i > TvX || it.j > TvX - 1);
+    if (it.i == TvX) it.i = T;
   }
   return it;
 }
@@ -523,12 +528,11 @@ __device__ __forceinline__ void panel_rows(double* __restrict__ S, int ld, int k
 }
 
 template <int NPAN>
-__device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld, int k, int ia, int half, double* __restrict__ Ld,
+__device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld, int k, int ia, int it, int half, double* __restrict__ Ld,
                                                  double* __restrict__ Winv, int* status, ALds& L, float* __restrict__ L32t) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..7
   const int lr = lane & 15, lk = lane >> 4;
-  const int it = k + 1 + ia;
   STAMP(0);
   // ---- prologue: every global load of this workgroup is issued here, in one wave of traffic ----
   if (NPAN > 0) {
@@ -595,12 +599,12 @@ __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld,
 }
 // L32 (or null): packed f32 copy of the factor's off-diagonal tiles, written along with the panel (the preconditioner of the joint solve
 // streams it, see bwd_chain_body): tile (i, k), k < i < T, at 4096 * (k (T-1) - k (k-1) / 2 + i - k - 1)
-__device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int k, int T, int ia, int half, double* __restrict__ Ld,
+__device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int k, int T, int TvA, int ia, int half, double* __restrict__ Ld,
                                             double* __restrict__ Winv, int* status, ALds& L, float* __restrict__ L32) {
-  const int it = k + 1 + ia;
+  const int it = (k + 1 + ia == TvA) ? T : k + 1 + ia;      // rows k+1 .. TvA-1 of the profile, then the right-hand-side row
   float* L32t = (L32 && it < T) ? L32 + ((size_t)k * (T - 1) - (size_t)k * (k - 1) / 2 + (it - k - 1)) * (NB * NB) : nullptr;
-  if (k > 0) step_type_a_impl<1>(S, ld, k, ia, half, Ld, Winv, status, L, L32t);
-  else step_type_a_impl<0>(S, ld, k, ia, half, Ld, Winv, status, L, L32t);
+  if (k > 0) step_type_a_impl<1>(S, ld, k, ia, it, half, Ld, Winv, status, L, L32t);
+  else step_type_a_impl<0>(S, ld, k, ia, it, half, Ld, Winv, status, L, L32t);
 }
 
 // One launch per block column k.  Workgroups 0 .. T-k-1 are type A (column k with its pending panel k-1); every workgroup of
@@ -609,13 +613,14 @@ __device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int 
 // the one workgroup per CU the register-heavy kernel gets.  ctr[k+1] is cleared here for the next launch (ctr[0..1] start at 0).
 __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Ld,
                                                    double* __restrict__ Winv, int* status, int* __restrict__ ctr, int kb, int nP,
-                                                   int g0, int g1, int nX, int a_joins, int a_split, float* __restrict__ L32) {
+                                                   int g0, int g1, int nX, int a_joins, int a_split, float* __restrict__ L32,
+                                                   int TvA, int TvB, int TvX) {
   __shared__ ALds L;
   __shared__ int s_g;
-  const int nA = (T - k) << a_split;      // a_split: two type-A workgroups per tile, 32 panel rows each (A-bound launches: the CUs are there)
+  const int nA = (TvA - k) << a_split;      // a_split: two type-A workgroups per tile, 32 panel rows each (A-bound launches: the CUs are there)
   if (blockIdx.x == 0 && threadIdx.x == 0) ctr[k + 1] = 0;
   if ((int)blockIdx.x < nA) {
-    step_type_a(S, ld, k, T, (int)blockIdx.x >> a_split, a_split ? (int)(blockIdx.x & 1) : -1, Ld, Winv, status, L, L32);
+    step_type_a(S, ld, k, T, TvA, (int)blockIdx.x >> a_split, a_split ? (int)(blockIdx.x & 1) : -1, Ld, Winv, status, L, L32);
     if (!a_joins) return;        // the queue workers are through before the chain is: an item taken now would only add a tail
   }
   const int nR = g1 - g0, nItems = nR + nX;
@@ -628,7 +633,7 @@ __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ S, int l
     __syncthreads();
     const int g = __builtin_amdgcn_readfirstlane(s_g);
     if (g >= nItems) break;
-    const BItem it = b_decode(g, nItems, nR, g0, k, kb, T, nP, nG, wave);
+    const BItem it = b_decode(g, nItems, nR, g0, k, kb, T, TvB, TvX, nP, nG, wave);
     if (!it.ok) continue;
     if (it.ks == 32) b_quadrant<32>(S, ld, it, wave & 3);
     else b_quadrant<16>(S, ld, it, wave & 3);
@@ -642,6 +647,7 @@ struct CholBatchArgs {
   double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX];
   double* Ld[CHOL_BATCH_MAX]; double* Winv[CHOL_BATCH_MAX]; int* status[CHOL_BATCH_MAX];
   float* L32[CHOL_BATCH_MAX];
+  int TvA[CHOL_BATCH_MAX], TvB[CHOL_BATCH_MAX], TvX[CHOL_BATCH_MAX];      // virtual sizes of the step (profile), see b_decode
   int nP[CHOL_BATCH_MAX], g0[CHOL_BATCH_MAX], g1[CHOL_BATCH_MAX], nX[CHOL_BATCH_MAX], a_split[CHOL_BATCH_MAX];
   int a_base[CHOL_BATCH_MAX + 1];      // prefix sums of the type-A workgroup counts
   int b_base[CHOL_BATCH_MAX + 1];      // prefix sums of the type-B item counts
@@ -655,8 +661,8 @@ __global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int 
     int r = 0;
     while (bid >= A.a_base[r + 1]) ++r;
     const int local = bid - A.a_base[r], sp = A.a_split[r];
-    step_type_a(A.S[r], A.ld[r], k, A.T[r], local >> sp, sp ? (local & 1) : -1, A.Ld[r] + (size_t)k * NB * NB, A.Winv[r] + (size_t)k * 1024,
-                A.status[r], L, A.L32[r]);
+    step_type_a(A.S[r], A.ld[r], k, A.T[r], A.TvA[r], local >> sp, sp ? (local & 1) : -1, A.Ld[r] + (size_t)k * NB * NB,
+                A.Winv[r] + (size_t)k * 1024, A.status[r], L, A.L32[r]);
     if (!a_joins) return;
   }
   const int nItems = A.b_base[A.n];
@@ -672,7 +678,7 @@ __global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int 
     while (g >= A.b_base[r + 1]) ++r;
     const int gl = g - A.b_base[r], nR = A.g1[r] - A.g0[r];
     const long long nG = (long long)A.nP[r] * (A.nP[r] + 1) / 2;
-    const BItem it = b_decode(gl, nR + A.nX[r], nR, A.g0[r], k, kb, A.T[r], A.nP[r], nG, wave);
+    const BItem it = b_decode(gl, nR + A.nX[r], nR, A.g0[r], k, kb, A.T[r], A.TvB[r], A.TvX[r], A.nP[r], nG, wave);
     if (!it.ok) continue;
     if (it.ks == 32) b_quadrant<32>(A.S[r], A.ld[r], it, wave & 3);
     else b_quadrant<16>(A.S[r], A.ld[r], it, wave & 3);
@@ -728,19 +734,20 @@ struct alignas(16) ChainLds {     // one per workgroup, shared by every instanti
 template <bool F32>
 __device__ __forceinline__ void bwd_chain_body(ChainLds& W, const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
                                                const double* __restrict__ Winv, const double* __restrict__ yv, double* dp, int* status, int bidx,
-                                               const float* __restrict__ L32) {
+                                               const float* __restrict__ L32, const int* __restrict__ prof) {
   auto& Ms = W.Ms; auto& Lo = W.Lo; auto& Ws = W.Ws; auto& tmp = W.tmp; auto& xs = W.xs; auto& ys = W.ys;
   const int tid = threadIdx.x;
   const bool worker = tid < 256;                       // waves 0..3: the tiles; wave 4 only polls (see CHAIN_THREADS)
   CSTAMP(0);
   const int c = T - 1 - bidx;
   const int col = tid >> 2, part = tid & 3;            // tile work: column col, rows 16 part .. 16 part + 15
-  const int nj = T - 1 - c;                            // tiles (j, c), j = T-1-q, q = 0 .. nj-1
+  const int jtop = prof ? prof[c] : T - 1;             // last tile row of column c inside the factor's profile (dense: T - 1)
+  const int nj = jtop - c;                             // tiles (j, c), j = jtop-q, q = 0 .. nj-1
   constexpr int RB = F32 ? 6 : 3;
   typedef typename std::conditional<F32, float, double>::type tile_t;
   tile_t tr[RB][16];
   const double* tcol = S + (size_t)(c * NB + col) * ld + 16 * part;
-  // packed tiles of column c: (c+1, c) first; tile (T-1-q, c) is number nj-1-q of the run
+  // packed tiles of column c: (c+1, c) first; tile (jtop-q, c) is number nj-1-q of the run
   const float* pcol = F32 ? L32 + ((size_t)c * (T - 1) - (size_t)c * (c - 1) / 2) * (NB * NB) + col * NB + 16 * part : nullptr;
   auto tile_load = [&](tile_t (&dst)[16], int q) {
     if (F32) {
@@ -751,7 +758,7 @@ __device__ __forceinline__ void bwd_chain_body(ChainLds& W, const double* __rest
         dst[4 * r] = v.x; dst[4 * r + 1] = v.y; dst[4 * r + 2] = v.z; dst[4 * r + 3] = v.w;
       }
     } else {
-      const double* tp = tcol + (size_t)(T - 1 - q) * NB;
+      const double* tp = tcol + (size_t)(jtop - q) * NB;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dst[r] = tp[r];
     }
@@ -816,7 +823,7 @@ __device__ __forceinline__ void bwd_chain_body(ChainLds& W, const double* __rest
     for (int qq = 0; qq < RB; ++qq) {
       const int q = q0 + qq;
       if (q < nj) {
-        const int j = T - 1 - q;
+        const int j = jtop - q;
         if (q == nj - 1) CSTAMPP(2);
         if (!worker) {                          // the polling wave has no other vector-memory traffic: its loads are not queued behind tile prefetches
           const int lane = tid - 256;
@@ -868,17 +875,19 @@ __device__ __forceinline__ int bwd_ticket(int* ctr) {
   return t;
 }
 __global__ __launch_bounds__(CHAIN_THREADS) void k_chol_bwd_chain(const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
-                                                        const double* __restrict__ Winv, const double* __restrict__ yv, double* dp, int* status) {
+                                                        const double* __restrict__ Winv, const double* __restrict__ yv, double* dp, int* status,
+                                                        const int* __restrict__ prof) {
   __shared__ ChainLds W;
   const int t = bwd_ticket(&status[4]);
   if (t >= T) return;
-  bwd_chain_body<false>(W, S, ld, T, Ld, Winv, yv, dp, status, t, nullptr);
+  bwd_chain_body<false>(W, S, ld, T, Ld, Winv, yv, dp, status, t, nullptr, prof);
 }
 struct BwdBatchArgs {
   int n;
   const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX];
   const double* Ld[CHOL_BATCH_MAX]; const double* Winv[CHOL_BATCH_MAX]; const double* yv[CHOL_BATCH_MAX]; double* dp[CHOL_BATCH_MAX];
   int* status[CHOL_BATCH_MAX];
+  const int* prof[CHOL_BATCH_MAX];     // device: profile of the factor (see plan_step) or null
   int base[CHOL_BATCH_MAX + 1];        // prefix sums of T (grid size = base[n])
   int Tmax;
 };
@@ -891,7 +900,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chol_bwd_chain_batched(BwdBat
     if (t >= A.n * A.Tmax) return;
     const int r = t % A.n, b = t / A.n;
     if (b >= A.T[r]) continue;
-    bwd_chain_body<false>(W, A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.yv[r], A.dp[r], A.status[r], b, nullptr);
+    bwd_chain_body<false>(W, A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.yv[r], A.dp[r], A.status[r], b, nullptr, A.prof[r]);
     return;
   }
 }
@@ -904,12 +913,13 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chol_bwd_chain_batched(BwdBat
 template <bool F32>      // tiles from the packed f32 copy (see bwd_chain_body) instead of S
 __device__ __forceinline__ void fwd_chain_body(ChainLds& W, const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
                                                const double* __restrict__ Winv, const double* __restrict__ rin, double* xout, int* status, int c,
-                                               const float* __restrict__ L32) {
+                                               const float* __restrict__ L32, const int* __restrict__ first) {
   auto& Ms = W.Ms; auto& Lo = W.Lo; auto& Ws = W.Ws; auto& tmp = W.tmp; auto& xs = W.xs; auto& ys = W.ys; auto& red = W.red;
   const int tid = threadIdx.x;
   const bool worker = tid < 256;                       // waves 0..3: the tiles; wave 4 only polls
   const int row = tid & 63, cp = (tid >> 6) & 3;       // tile work: row `row`, columns 16 cp .. 16 cp + 15
-  const int nj = c;                                    // tiles (c, j), j = 0 .. c-1
+  const int j0 = first ? first[c] : 0;                 // first block column whose profile reaches block row c (dense: 0)
+  const int nj = c - j0;                               // tiles (c, j), j = j0 .. c-1
   constexpr int RB = F32 ? 6 : 3;
   typedef typename std::conditional<F32, float, double>::type tile_t;
   tile_t tr[RB][16];
@@ -929,7 +939,7 @@ __device__ __forceinline__ void fwd_chain_body(ChainLds& W, const double* __rest
   if (worker) {
 #pragma unroll
     for (int q = 0; q < RB; ++q)
-      if (q < nj) tile_load(tr[q], q);
+      if (q < nj) tile_load(tr[q], j0 + q);
   }
   const double r0 = rin[c * NB + row];
   if (worker) {
@@ -984,7 +994,7 @@ __device__ __forceinline__ void fwd_chain_body(ChainLds& W, const double* __rest
           double v;
           int spins = 0;
           for (;;) {
-            v = __hip_atomic_load(xout + (size_t)q * NB + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __hip_atomic_load(xout + (size_t)(j0 + q) * NB + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned long long)__double_as_longlong(v) != BWD_SENT) break;
             if (++spins > (1 << 21)) {          // exit condition every wave reaches
               v = __builtin_nan("");
@@ -999,7 +1009,7 @@ __device__ __forceinline__ void fwd_chain_body(ChainLds& W, const double* __rest
         if (worker) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc += (double)tr[qq][r] * xs[q & 1][16 * cp + r];
-          if (q + RB < nj) tile_load(tr[qq], q + RB);
+          if (q + RB < nj) tile_load(tr[qq], j0 + q + RB);
         }
       }
     }
@@ -1028,7 +1038,9 @@ struct ChainBatchArgs {
   const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX];
   const double* Ld[CHOL_BATCH_MAX]; const double* Winv[CHOL_BATCH_MAX]; const double* in[CHOL_BATCH_MAX]; double* out[CHOL_BATCH_MAX];
   int* status[CHOL_BATCH_MAX];
-  float* L32[CHOL_BATCH_MAX];          // packed f32 copy of the factor (written by the factorisation's own backward chain) or null
+  float* L32[CHOL_BATCH_MAX];          // packed f32 copy of the factor (written by the type-A workgroups of the factorisation)
+  const int* prof[CHOL_BATCH_MAX];     // device: profile of the factor and, per block row, the first block column reaching it; or null
+  const int* first[CHOL_BATCH_MAX];
   int Tmax;
 };
 template <bool FWD>
@@ -1039,8 +1051,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chain_batched(ChainBatchArgs 
     if (t >= A.n * A.Tmax) return;
     const int r = t % A.n, b = t / A.n;
     if (b >= A.T[r]) continue;
-    if (FWD) fwd_chain_body<true>(W, A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.in[r], A.out[r], A.status[r], b, A.L32[r]);
-    else bwd_chain_body<true>(W, A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.in[r], A.out[r], A.status[r], b, A.L32[r]);
+    if (FWD) fwd_chain_body<true>(W, A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.in[r], A.out[r], A.status[r], b, A.L32[r], A.first[r]);
+    else bwd_chain_body<true>(W, A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.in[r], A.out[r], A.status[r], b, A.L32[r], A.prof[r]);
     return;
   }
 }
@@ -1062,6 +1074,7 @@ void launch_chain_batch(const CholSystem* d, int n, const double* const* in, dou
     A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.Ld[i] = d[i].Ld; A.Winv[i] = d[i].Winv; A.in[i] = in[i]; A.out[i] = out[i];
     A.status[i] = d[i].status;
     A.L32[i] = d[i].L32;
+    A.prof[i] = d[i].prof; A.first[i] = d[i].first;
     Tmax = d[i].T > Tmax ? d[i].T : Tmax;
     total += d[i].T;
     Pr.out[i] = out[i];
@@ -1162,7 +1175,7 @@ void launch_pose_covariance(const double* S, int ld, int T, const double* Ld, co
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s) {
   hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv, dp, status);
 }
-struct StepPlan { int kb, nP, g0, g1, nX; long long nA, nB; };
+struct StepPlan { int kb, nP, g0, g1, nX, TvA, TvB, TvX; long long nA, nB; };
 static int chol_n_cu() {
   static int n_cu = 0;
   if (!n_cu) {
@@ -1173,26 +1186,36 @@ static int chol_n_cu() {
   }
   return n_cu;
 }
-static StepPlan plan_step(int k, int T) {
+// prof (host, T ints, or null = dense): prof[c] = last tile row of block column c inside the monotone profile of the factor (>= c).
+// Column k's tiles reach row prof[k]; the rank-128 pass of pair base kb (panels kb-2, kb-1) touches rows / columns <= prof[kb-1]; the
+// column items of an odd launch (panel k-1 onto column k+1) rows <= prof[k-1].  Everything else is structurally zero and skipped.
+static StepPlan plan_step(int k, int T, const int* prof) {
   static const double frac = getenv("SLIDE_CHOL_FRAC") ? atof(getenv("SLIDE_CHOL_FRAC")) : 0.5;   // diagnostic: share of a pass done by its first launch
   StepPlan p{};
-  p.nA = k < T ? T - k : 0;                                     // column-k tiles below the diagonal (+ RHS tile)
   p.kb = k & ~1;                                                // base of the pair
+  p.TvA = p.TvB = p.TvX = T;
+  if (prof && k < T) {
+    p.TvA = prof[k] + 1;
+    if (p.kb >= 1) p.TvB = prof[p.kb - 1] + 1;
+    if (k >= 1) p.TvX = prof[k - 1] + 1;
+  }
+  p.nA = k < T ? p.TvA - k : 0;                                 // column-k tiles below the diagonal (+ RHS tile)
   if (k >= 2 && k < T) {
-    p.nP = (T - p.kb + 1) / 2;                                  // 2x2 tile groups per side of the trailing matrix of the pair
+    p.nP = p.TvB > p.kb ? (p.TvB - p.kb + 1) / 2 : 0;           // 2x2 tile groups per side of the trailing matrix of the pair
     const long long nG = (long long)p.nP * (p.nP + 1) / 2;
     long long first = (long long)(frac * (double)nG + 0.5);
     if (first < p.nP) first = p.nP;                             // the group column with tile columns kb+1, kb+2 entirely
     if (first > nG) first = nG;
     if (k & 1) { p.g0 = (int)(2 * first); p.g1 = (int)(2 * nG); } else { p.g0 = 0; p.g1 = (int)(2 * first); }   // items = half groups
   }
-  p.nX = (k & 1) && k + 1 < T ? (T - k + 1) / 2 : 0;            // column items: tile rows k+1 .. T of column k+1, two per item
+  p.nX = (k & 1) && k + 1 < p.TvX ? (p.TvX - k + 1) / 2 : 0;    // column items: tile rows k+1 .. TvX of column k+1, two per item
   p.nB = p.g1 - p.g0 + p.nX;
   return p;
 }
-void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, float* L32, hipStream_t s) {
+void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, float* L32, const int* h_prof,
+                      hipStream_t s) {
   const int n_cu = chol_n_cu();
-  const StepPlan p = plan_step(k, T);
+  const StepPlan p = plan_step(k, T, h_prof);
   const long long nA = p.nA, nB = p.nB;
   static const int split_pct = getenv("SLIDE_CHOL_ASPLIT") ? atoi(getenv("SLIDE_CHOL_ASPLIT")) : 100;   // diagnostic: 0 = never
   // two workgroups per type-A tile once the launch is bound by the chain, not by the flood
@@ -1204,7 +1227,7 @@ void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv,
   static const int join_mul = getenv("SLIDE_CHOL_JOIN") ? atoi(getenv("SLIDE_CHOL_JOIN")) : 1;
   const int a_joins = nB > join_mul * free_cu ? 1 : 0;
   hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nAw + extra)), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status, ctr, p.kb, p.nP,
-                     p.g0, p.g1, p.nX, a_joins, a_split, L32);
+                     p.g0, p.g1, p.nX, a_joins, a_split, L32, p.TvA, p.TvB, p.TvX);
 }
 // The factorisations + solves of several systems as one launch sequence (max T step launches, the extractions, one chained backward
 // substitution): d[i] describes system i; ctr is the work counter array of the batch (max T + 2 ints, zeroed once).
@@ -1217,12 +1240,13 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
     A.n = n;
     long long nA2 = 0, nBt = 0;
     StepPlan pl[CHOL_BATCH_MAX];
-    for (int i = 0; i < n; ++i) { pl[i] = plan_step(k, d[i].T); nA2 += 2 * pl[i].nA; nBt += pl[i].nB; }
+    for (int i = 0; i < n; ++i) { pl[i] = plan_step(k, d[i].T, d[i].h_prof); nA2 += 2 * pl[i].nA; nBt += pl[i].nB; }
     const int a_split = (k > 0 && nA2 + nBt <= n_cu) ? 1 : 0;
     A.a_base[0] = A.b_base[0] = 0;
     for (int i = 0; i < n; ++i) {
       A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.Ld[i] = d[i].Ld; A.Winv[i] = d[i].Winv; A.status[i] = d[i].status;
       A.L32[i] = d[i].L32;
+      A.TvA[i] = pl[i].TvA; A.TvB[i] = pl[i].TvB; A.TvX[i] = pl[i].TvX;
       A.nP[i] = pl[i].nP; A.g0[i] = pl[i].g0; A.g1[i] = pl[i].g1; A.nX[i] = pl[i].nX; A.a_split[i] = a_split;
       A.a_base[i + 1] = A.a_base[i] + (int)(pl[i].nA << a_split);
       A.b_base[i + 1] = A.b_base[i] + (int)pl[i].nB;
@@ -1241,20 +1265,21 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
     launch_chol_extract_y(d[i].S, d[i].ld, d[i].T, d[i].yv, d[i].dp, d[i].status, s);
     B.S[i] = d[i].S; B.ld[i] = d[i].ld; B.T[i] = d[i].T; B.Ld[i] = d[i].Ld; B.Winv[i] = d[i].Winv; B.yv[i] = d[i].yv; B.dp[i] = d[i].dp;
     B.status[i] = d[i].status;
+    B.prof[i] = d[i].prof;
     B.base[i + 1] = B.base[i] + d[i].T;
   }
   B.Tmax = Tmax;
   if (B.base[n] > 0) hipLaunchKernelGGL(k_chol_bwd_chain_batched, dim3(B.base[n]), dim3(CHAIN_THREADS), 0, s, B);
 }
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp,
-                         int* status, hipStream_t s) {
-  hipLaunchKernelGGL(k_chol_bwd_chain, dim3(T), dim3(CHAIN_THREADS), 0, s, S, ld, T, Ld, Winv, yv, dp, status);
+                         int* status, const int* prof, hipStream_t s) {
+  hipLaunchKernelGGL(k_chol_bwd_chain, dim3(T), dim3(CHAIN_THREADS), 0, s, S, ld, T, Ld, Winv, yv, dp, status, prof);
 }
 
 int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double* yv, double* dp, int* status, int* ctr, hipStream_t s) {
-  for (int k = 0; k < T; ++k) launch_chol_step(S, ld, k, T, Ld + (size_t)k * NB * NB, Winv + (size_t)k * 1024, status, ctr, nullptr, s);
+  for (int k = 0; k < T; ++k) launch_chol_step(S, ld, k, T, Ld + (size_t)k * NB * NB, Winv + (size_t)k * 1024, status, ctr, nullptr, nullptr, s);
   launch_chol_extract_y(S, ld, T, yv, dp, status, s);
-  launch_chol_bwd_all(S, ld, T, Ld, Winv, yv, dp, status, s);
+  launch_chol_bwd_all(S, ld, T, Ld, Winv, yv, dp, status, nullptr, s);
   return 0;
 }
 

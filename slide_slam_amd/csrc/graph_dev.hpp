@@ -80,6 +80,12 @@ struct GraphDev {
   double* yv;        // T*NB  forward-substituted RHS
   double* dp;        // T*NB  reduced solution (delta_p = -dp)
   int* chol_ctr;     // T + 2 : work counters of the Cholesky step kernels (self-clearing)
+  // profile (envelope) of the reduced system at tile level, from the topology (HostGraph::upload_new): everything outside it is
+  // structurally zero in S AND in its Cholesky factor, is never written after the clear that follows a change of profile, and is
+  // skipped by the assembly, the factorisation, the substitutions and the products
+  const int* prof;   // T : prof[c] = last tile row of block column c inside the profile (monotone in c, >= c); null = dense
+  const int* first;  // T : first[r] = first block column whose profile reaches block row r
+  int prof_ver;      // bumped whenever the arrays change (launch plans captured in hipGraphs depend on their values)
   // ---- joint solve over several robots (pcg_kernels.hip) --------------------------------------
   double* S0;        // copy of S (lower triangle + padding) taken before the factorisation overwrites it: the symmetric products
   int save_S0;       // 1: the Schur assembly writes every block to S0 as well (batched passes with the joint solve; else a device copy)

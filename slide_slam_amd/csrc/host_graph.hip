@@ -408,7 +408,8 @@ int CholBatch::factor_solve(int slot, const GraphDev& G, hipStream_t s) {
   if (slot < 0 || slot >= n) return SLIDE_ERR_INVALID;
   {
     std::lock_guard<std::mutex> lk(mtx);
-    sys[slot] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, (pcg_iters > 0 && G.n_slots > 0) ? graphs[slot]->d_L32.d : nullptr};
+    sys[slot] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, (pcg_iters > 0 && G.n_slots > 0) ? graphs[slot]->d_L32.d : nullptr,
+                                graphs[slot]->h_prof.data(), G.prof, G.first};
   }
   return rendezvous(slot, s, false, 0);
 }
@@ -476,7 +477,8 @@ int CholBatch::prepare_pass() {
   hG.resize(n);
   for (int i = 0; i < n; ++i) {
     const GraphDev& G = graphs[i]->G;
-    sys[i] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, (pcg_iters > 0 && G.n_slots > 0) ? graphs[i]->d_L32.d : nullptr};
+    sys[i] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, (pcg_iters > 0 && G.n_slots > 0) ? graphs[i]->d_L32.d : nullptr,
+                             graphs[i]->h_prof.data(), G.prof, G.first};
     Tmax = G.T > Tmax ? G.T : Tmax;
     hG[i] = G;
     hG[i].save_S0 = (pcg_iters > 0 && G.n_slots > 0) ? 1 : 0;      // the batched Schur assembly writes S0 itself
@@ -792,9 +794,9 @@ int HostGraph::factor_and_solve(hipStream_t s) {
   if (batch) return batch->factor_solve(batch_slot, G, s);
   for (int k = 0; k < G.T; ++k)
     launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr,
-                     (pcg_iters > 0 && G.n_slots > 0) ? d_L32.d : nullptr, s);
+                     (pcg_iters > 0 && G.n_slots > 0) ? d_L32.d : nullptr, h_prof.data(), s);
   launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, G.status, s);
-  launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, s);
+  launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, G.prof, s);
   return SLIDE_OK;
 }
 
@@ -1020,6 +1022,48 @@ int HostGraph::upload_new() {
     if (d_yv.ensure((size_t)Tcap * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_dp.ensure((size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
   }
+  // Profile of the reduced pose system at tile level.  reach(p) = the last pose coupled to pose p (a landmark both observe, a
+  // relative-pose factor); block column c reaches the tile row of the farthest reach of its poses; the running maximum over c is
+  // closed under the fill of the factorisation (eliminating column c fills rows <= prof[c] of columns <= prof[c] only).
+  {
+    std::vector<int> lm_last(Ln, -1), reach(Pn);
+    for (size_t f = 0; f < nlf; ++f) lm_last[h_lf_lm[f]] = std::max(lm_last[h_lf_lm[f]], h_lf_pose[f]);
+    for (size_t p = 0; p < Pn; ++p) reach[p] = (int)p;
+    for (size_t f = 0; f < nlf; ++f) reach[h_lf_pose[f]] = std::max(reach[h_lf_pose[f]], lm_last[h_lf_lm[f]]);
+    for (size_t b = 0; b < nbt; ++b) {
+      const int lo = std::min(h_bt_i[b], h_bt_j[b]), hi = std::max(h_bt_i[b], h_bt_j[b]);
+      reach[lo] = std::max(reach[lo], hi);
+    }
+    static const bool dense = getenv("SLIDE_CHOL_DENSE") && getenv("SLIDE_CHOL_DENSE")[0] == '1';      // diagnostic: ignore the structure
+    std::vector<int> prof(T), first(T);
+    for (int c = 0; c < T; ++c) prof[c] = dense ? T - 1 : c;
+    for (size_t p = 0; p < Pn && !dense; ++p) {
+      const int rt = (6 * reach[p] + 5) / NB;
+      const int ta = (int)(6 * p) / NB, tb = (int)(6 * p + 5) / NB;
+      prof[ta] = std::max(prof[ta], rt);
+      prof[tb] = std::max(prof[tb], rt);
+    }
+    for (int c = 1; c < T; ++c) prof[c] = std::max(prof[c], prof[c - 1]);
+    for (int r = 0, c = 0; r < T; ++r) {
+      while (prof[c] < r) ++c;
+      first[r] = c;
+    }
+    if (prof != h_prof) {
+      // a tile that leaves the profile (or the right-hand-side row moving down as T grows) would keep stale values: clear S
+      bool superset = T == (int)h_prof.size();
+      for (int c = 0; superset && c < T; ++c) superset = prof[c] >= h_prof[c];
+      if (!superset && d_S.d) SL_HIP(hipMemsetAsync(d_S.d, 0, d_S.cap * sizeof(double), s));
+      h_prof = prof;
+      h_first = first;
+      if (d_prof.ensure(std::max<size_t>(T, 1), 0, s) != SLIDE_OK || d_first.ensure(std::max<size_t>(T, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+      if (T) {
+        SL_HIP(hipMemcpyAsync(d_prof.d, h_prof.data(), T * sizeof(int), hipMemcpyHostToDevice, s));
+        SL_HIP(hipMemcpyAsync(d_first.d, h_first.data(), T * sizeof(int), hipMemcpyHostToDevice, s));
+        SL_HIP(hipStreamSynchronize(s));      // (pageable host vectors: the copies must have left them before they can change again)
+      }
+      ++prof_ver;
+    }
+  }
   topo_dirty = false;
   uploaded_once = true;
   up_P = Pn; up_L = Ln; up_pr = npr; up_bt = nbt; up_lf = nlf; up_gh = ngh;
@@ -1046,6 +1090,7 @@ int HostGraph::upload_new() {
   G.lm_Hacc = d_lm_Hacc.d; G.lm_t = d_lm_t.d; G.n_slots = (int)h_sh_lid.size(); G.sh_lid = d_sh_lid.d; G.sh_owner = d_sh_owner.d;
   G.lm_Hinv = d_lm_Hinv.d; G.lm_g = d_lm_g.d; G.pose_H = d_pose_H.d; G.pose_g = d_pose_g.d;
   G.S = d_S.d; G.ld = (Tcap + 1) * NB; G.T = T; G.Ld = d_Ld.d; G.Winv = d_Winv.d; G.yv = d_yv.d; G.dp = d_dp.d; G.chol_ctr = d_cctr.d;
+  G.prof = d_prof.d; G.first = d_first.d; G.prof_ver = prof_ver;
   G.S0 = d_S0.d; G.save_S0 = 0; G.pcg = d_pcg.d; G.lm_c = d_lm_c.d; G.pcg_scal = d_pcg_scal.d;
   G.status = d_status.d;
   G.chart = P.pose_chart;
@@ -1068,9 +1113,9 @@ int HostGraph::enqueue_iteration(bool lookahead) {
   STAGE(4, launch_schur(G, s));
   (void)lookahead;
   for (int k = 0; k < G.T; ++k)
-    STAGE(5, launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, nullptr, s));
+    STAGE(5, launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, nullptr, h_prof.data(), s));
   STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, G.status, s));
-  STAGE(8, launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, s));
+  STAGE(8, launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, G.prof, s));
   STAGE(9, launch_backsub(G, 0, s));
   STAGE(10, launch_estimate(G, s));
 #undef STAGE
@@ -1220,7 +1265,7 @@ int HostGraph::enqueue_phase(int phase, double* d_buf) {
       launch_shared_pack(G, 1, d_buf, s);
     } else {
       const size_t nT = (size_t)G.T * NB;
-      const CholSystem cs{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, d_L32.d};
+      const CholSystem cs{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, d_L32.d, h_prof.data(), G.prof, G.first};
       const double* in = G.pcg + PCG_VEC_R * nT;
       double* out = G.pcg + PCG_VEC_Y * nT;
       launch_chain_batch(&cs, 1, &in, &out, true, s);

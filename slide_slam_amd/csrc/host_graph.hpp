@@ -278,6 +278,9 @@ class HostGraph {
   std::vector<int> h_sh_lid, h_sh_owner;
   DevArr<double> d_S, d_Ld, d_Winv, d_yv, d_dp;
   DevArr<double> d_S0, d_pcg, d_lm_c, d_pcg_scal;      // joint solve (pcg_kernels.hip)
+  DevArr<int> d_prof, d_first;                         // tile-level profile of the reduced system (graph_dev.hpp), host copies h_prof / h_first
+  std::vector<int> h_prof, h_first;
+  int prof_ver = 0;
   DevArr<float> d_L32;                                 // packed f32 copy of the factor: the joint solve's preconditioner streams this
   DevArr<GraphDev> d_Gself;                             // this graph's view on the device, for the kernels that take an array of views
   GraphDev G_self{};

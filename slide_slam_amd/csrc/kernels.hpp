@@ -30,15 +30,17 @@ void launch_ghost_exchange(const GraphDev& G, int what, double* buf, hipStream_t
 // chol_kernels.hip — blocked right-looking FP64 Cholesky of the (T*NB)^2 lower matrix S (column-major,
 // leading dimension ld = (T+1)*NB; the extra row tile carries the right-hand side), tile edge NB = 64.
 // ctr: T + 2 ints, zero before the first factorisation (each step clears the next step's work counter itself)
-void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, float* L32, hipStream_t s);   // L32: see CholSystem
+void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, float* L32, const int* h_prof, hipStream_t s);   // L32, h_prof: see CholSystem
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s);   // also clears status[4], the ticket counter of launch_chol_bwd_all
 struct CholSystem { double* S; int ld, T; double* Ld; double* Winv; double* yv; double* dp; int* status;
-                    float* L32; };   // L32: packed f32 copy of the factor for the joint solve's preconditioner (null: none), see bwd_chain_body
+                    float* L32;      // packed f32 copy of the factor for the joint solve's preconditioner (null: none), see bwd_chain_body
+                    const int* h_prof;           // host: profile of the factor, T ints (plan_step in chol_kernels.hip), or null = dense
+                    const int* prof; const int* first; };   // device: the same and, per block row, the first block column that reaches it
 void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps = nullptr);            // up to 8 systems, one launch per block column
 // one of the two triangular solves with the finished factors of up to 8 systems on arbitrary vectors (T * NB doubles each): out = L^-1 in
 // (fwd) or L^-T in (bwd); the preconditioner of the joint solve (pcg_kernels.hip)
 void launch_chain_batch(const CholSystem* d, int n, const double* const* in, double* const* out, bool fwd, hipStream_t s);
-void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp, int* status, hipStream_t s);
+void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp, int* status, const int* prof, hipStream_t s);
 // marginal covariance of the pose whose first tangent row is row0 (Y: 6 * T * NB scratch doubles holding the six unit columns)
 void launch_pose_covariance(const double* S, int ld, int T, const double* Ld, const double* Winv, double* Y, int row0, double* cov36,
                             hipStream_t s);

@@ -121,12 +121,39 @@ __global__ __launch_bounds__(256) void k_pcg_symv(const GraphDev* __restrict__ G
   }
   const double* xs = in_lds ? xs_lds : x;
   double acc = 0.0;
-  // tiles (bi, j), j < bi: y[row] += sum_c tile[row][c] x_j[c]; thread (row, cp) takes columns 16 cp ..
-  for (int j = 0; j < bi; ++j) {
-    const double* tp = S0 + (size_t)(j * NB + 16 * cp) * ld + (size_t)bi * NB + row;
-    const double* xj = xs + j * NB + 16 * cp;
+  // tiles (bi, j), j < bi: y[row] += sum_c tile[row][c] x_j[c]; thread (row, cp) takes columns 16 cp ..; the next tile's sixteen
+  // loads are issued before this tile's products (two register sets): the loop is a pure stream, latency is all there is to hide
+  {
+    double ta[16], tb[16];
+    const double* tp0 = S0 + (size_t)(16 * cp) * ld + (size_t)bi * NB + row;
+    const int jf = G.first ? G.first[bi] : 0;      // tiles left of the profile are structurally zero
+    if (jf < bi) {
+      const double* tp = tp0 + (size_t)(jf * NB) * ld;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc += tp[(size_t)r * ld] * xj[r];
+      for (int r = 0; r < 16; ++r) ta[r] = tp[(size_t)r * ld];
+    }
+    for (int j = jf; j < bi; j += 2) {
+      if (j + 1 < bi) {
+        const double* tp = tp0 + (size_t)((j + 1) * NB) * ld;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tb[r] = tp[(size_t)r * ld];
+      }
+      {
+        const double* xj = xs + j * NB + 16 * cp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc += ta[r] * xj[r];
+      }
+      if (j + 2 < bi) {
+        const double* tp = tp0 + (size_t)((j + 2) * NB) * ld;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ta[r] = tp[(size_t)r * ld];
+      }
+      if (j + 1 < bi) {
+        const double* xj = xs + (j + 1) * NB + 16 * cp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc += tb[r] * xj[r];
+      }
+    }
   }
   // diagonal tile: lower triangle only
   {
@@ -143,11 +170,34 @@ __global__ __launch_bounds__(256) void k_pcg_symv(const GraphDev* __restrict__ G
   // tiles (j, bi), j > bi, transposed: y[c] += sum_r tile[r][c] x_j[r]; thread (col = tid >> 2, part = tid & 3) takes rows 16 part ..
   const int col = tid >> 2, part = tid & 3;
   double acct = 0.0;
-  for (int j = bi + 1; j < G.T; ++j) {
-    const double* tp = S0 + (size_t)(bi * NB + col) * ld + (size_t)j * NB + 16 * part;
-    const double* xj = xs + j * NB + 16 * part;
+  {
+    double ta[16], tb[16];
+    const double* tp0 = S0 + (size_t)(bi * NB + col) * ld + 16 * part;
+    const int j0 = bi + 1, T = G.prof ? G.prof[bi] + 1 : G.T;      // tiles below the profile of column bi: zero
+    if (j0 < T) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acct += tp[r] * xj[r];
+      for (int r = 0; r < 16; ++r) ta[r] = tp0[(size_t)j0 * NB + r];
+    }
+    for (int j = j0; j < T; j += 2) {
+      if (j + 1 < T) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tb[r] = tp0[(size_t)(j + 1) * NB + r];
+      }
+      {
+        const double* xj = xs + j * NB + 16 * part;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acct += ta[r] * xj[r];
+      }
+      if (j + 2 < T) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ta[r] = tp0[(size_t)(j + 2) * NB + r];
+      }
+      if (j + 1 < T) {
+        const double* xj = xs + (j + 1) * NB + 16 * part;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acct += tb[r] * xj[r];
+      }
+    }
   }
   redt[col][part] = acct;
   __syncthreads();

@@ -650,8 +650,14 @@ __device__ __forceinline__ void k_schur_body(const GraphDev& G) {
   }
   __syncthreads();
   const int sub = tid & 7;
+  // rows below the profile of this column's tile are structurally zero and stay untouched (zero since the last change of profile)
+  int p_end = G.P;
+  if (G.prof) {
+    const int rows = (G.prof[(6 * pj + 5) / NB] + 1) * NB;      // (the profile is monotone: the later of the column's two tiles)
+    p_end = min(G.P, (rows + 5) / 6);
+  }
   // the chunks of the strip are dealt out to the gridDim.y workgroups of this pose column (each builds the two tables itself)
-  for (int pi0 = pj + 32 * (int)blockIdx.y; pi0 < G.P; pi0 += 32 * (int)gridDim.y) {
+  for (int pi0 = pj + 32 * (int)blockIdx.y; pi0 < p_end; pi0 += 32 * (int)gridDim.y) {
     const int nval = 6 * min(32, G.P - pi0);
     double* Sb = G.S + (size_t)(6 * pj) * G.ld + 6 * (size_t)pi0;
     double* S0b = G.S0 + (size_t)(6 * pj) * G.ld + 6 * (size_t)pi0;      // second copy for the joint solve (save_S0)
@@ -857,6 +863,7 @@ __device__ __forceinline__ void k_pad_rhs_body(const GraphDev& G) {
   if (u >= (long long)npad * NT) return;
   const int r = n + (int)(u / NT), c = (int)(u % NT);
   if (c > r) return;
+  if (G.first && c < G.first[G.T - 1] * NB) return;      // left of the profile: zero already
   G.S[(size_t)c * G.ld + r] = (c == r) ? 1.0 : 0.0;
   if (G.save_S0) G.S0[(size_t)c * G.ld + r] = (c == r) ? 1.0 : 0.0;
 }
