@@ -906,45 +906,31 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chol_bwd_chain_batched(BwdBat
 }
 
 
-// ---- forward substitution L x = r on the finished factor, ONE launch (the mirror image of bwd_chain_body) ----------------------------
-// The preconditioner of the joint solve (pcg_kernels.hip) applies S_a^-1 = L^-T L^-1 to vectors other than the right-hand side
-// that rode through the factorisation.  Ticket t owns block row c = t: x_c = L_cc^-1 (r_c - sum_{j < c} L(c, j) x_j), the x_j
-// polled from `xout` (pre-filled with the sentinel) as the lower tickets publish them; tiles L(c, j) prefetched three ahead.
-template <bool F32>      // tiles from the packed f32 copy (see bwd_chain_body) instead of S
-__device__ __forceinline__ void fwd_chain_body(ChainLds& W, const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
-                                               const double* __restrict__ Winv, const double* __restrict__ rin, double* xout, int* status, int c,
-                                               const float* __restrict__ L32, const int* __restrict__ first) {
-  auto& Ms = W.Ms; auto& Lo = W.Lo; auto& Ws = W.Ws; auto& tmp = W.tmp; auto& xs = W.xs; auto& ys = W.ys; auto& red = W.red;
-  const int tid = threadIdx.x;
-  const bool worker = tid < 256;                       // waves 0..3: the tiles; wave 4 only polls
-  const int row = tid & 63, cp = (tid >> 6) & 3;       // tile work: row `row`, columns 16 cp .. 16 cp + 15
-  const int j0 = first ? first[c] : 0;                 // first block column whose profile reaches block row c (dense: 0)
-  const int nj = c - j0;                               // tiles (c, j), j = j0 .. c-1
-  constexpr int RB = F32 ? 6 : 3;
-  typedef typename std::conditional<F32, float, double>::type tile_t;
-  tile_t tr[RB][16];
-  const double* tbase = S + (size_t)(16 * cp) * ld + (size_t)c * NB + row;     // + (j * NB + r) * ld
-  const float* pbase = F32 ? L32 + 16 * cp * NB + row : nullptr;               // + tile (c, j) + r * NB
-  auto tile_load = [&](tile_t (&dst)[16], int j) {
-    if (F32) {
-      const float* tp = pbase + ((size_t)j * (T - 1) - (size_t)j * (j - 1) / 2 + (c - j - 1)) * (NB * NB);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dst[r] = tp[r * NB];
-    } else {
-      const double* tp = tbase + (size_t)(j * NB) * ld;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dst[r] = tp[(size_t)r * ld];
-    }
-  };
-  if (worker) {
-#pragma unroll
-    for (int q = 0; q < RB; ++q)
-      if (q < nj) tile_load(tr[q], j0 + q);
-  }
-  const double r0 = rin[c * NB + row];
-  if (worker) {
-    const double* Ldk = Ld + (size_t)c * NB * NB;
-    const double* Wk = Winv + (size_t)c * 1024;
+// ---- tables for the chained substitutions of the joint solve ---------------------------------------------------------------------------
+// The preconditioner of the joint solve runs both substitutions eight times per factorisation.  Once per factorisation, one
+// workgroup per block c writes, in the thread order (i = tid >> 2, part = tid & 3: sixteen consecutive entries of row / column i):
+//   TAB_MF  M[i][16 part + k]                      M = L_cc^-1 (explicit, from the 16x16 inverses and sub-tiles of the factorisation)
+//   TAB_MB  M[16 part + r][i]
+//   TAB_PF  (M T(c, c-1))[i][16 part + k]          the sub-diagonal tile folded into the inverse: the block that arrives LAST in the
+//   TAB_PB  (T(c+1, c) M)[16 part + r][i]          forward (x_{c-1}) / backward (x_{c+1}) chain then costs ONE 64x64 product on the
+// critical path, x_c = z_c - P x_last, where z_c (everything else, times M) is finished while the chain is still one block away.
+// ctab: [4][T][4096] doubles per system.  Without the tables a block builds M in LDS (8 us of prologue) and pays two dependent
+// products per hop (tools/chain_stamps.py: 0.72 of 1.4 us per block).
+enum { TAB_MF = 0, TAB_MB = 1, TAB_PF = 2, TAB_PB = 3 };
+struct ChainTabArgs {
+  int n; int T[CHOL_BATCH_MAX]; const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX];
+  const double* Ld[CHOL_BATCH_MAX]; const double* Winv[CHOL_BATCH_MAX]; const int* prof[CHOL_BATCH_MAX]; double* ctab[CHOL_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void k_chain_tables(ChainTabArgs A) {
+  __shared__ ChainLds W;
+  __shared__ double Ts[NB][NB];       // the sub-diagonal tile as it lies in memory: Ts[column][row]
+  auto& Ms = W.Ms; auto& Lo = W.Lo; auto& Ws = W.Ws; auto& tmp = W.tmp;
+  const int sys = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+  const int T = A.T[sys];
+  if (c >= T) return;
+  {
+    const double* Ldk = A.Ld[sys] + (size_t)c * NB * NB;
+    const double* Wk = A.Winv[sys] + (size_t)c * 1024;
 #pragma unroll
     for (int b = 1; b < 4; ++b)
 #pragma unroll
@@ -952,13 +938,13 @@ __device__ __forceinline__ void fwd_chain_body(ChainLds& W, const double* __rest
 #pragma unroll
     for (int b = 0; b < 4; ++b) Ws[b][tid] = Wk[(size_t)b * 256 + tid];
   }
+  for (int e = tid; e < NB * (NB + 1); e += 256) (&Ms[0][0])[e] = 0.0;      // (zeros above the diagonal blocks)
   __syncthreads();
   {
-    const int r = tid & 15, cc = (tid >> 4) & 15;
-    if (worker) {
+    // M_bb = W_b ; M_ba = -W_b sum_{m = a}^{b-1} L_bm M_ma  (b > a), by distance from the diagonal (as in bwd_chain_body)
+    const int r = tid & 15, cc = tid >> 4;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) Ms[16 * b + r][16 * b + cc] = Ws[b][cc * 16 + r];
-    }
+    for (int b = 0; b < 4; ++b) Ms[16 * b + r][16 * b + cc] = Ws[b][cc * 16 + r];
     __syncthreads();
 #pragma unroll
     for (int d = 1; d < 4; ++d) {
@@ -970,7 +956,7 @@ __device__ __forceinline__ void fwd_chain_body(ChainLds& W, const double* __rest
         for (int m = a; m < b; ++m)
 #pragma unroll
           for (int n = 0; n < 16; ++n) t += Lo[b * (b - 1) / 2 + m][n * 16 + r] * Ms[16 * m + n][16 * a + cc];
-        if (worker) tmp[a][cc * 16 + r] = t;
+        tmp[a][cc * 16 + r] = t;
       }
       __syncthreads();
 #pragma unroll
@@ -979,80 +965,216 @@ __device__ __forceinline__ void fwd_chain_body(ChainLds& W, const double* __rest
         double v = 0.0;
 #pragma unroll
         for (int n = 0; n < 16; ++n) v += Ws[b][n * 16 + r] * tmp[a][cc * 16 + n];
-        if (worker) Ms[16 * b + r][16 * a + cc] = -v;
+        Ms[16 * b + r][16 * a + cc] = -v;
       }
       __syncthreads();
     }
   }
+  const int i = tid >> 2, part = tid & 3;
+  double* tab = A.ctab[sys] + (size_t)c * (NB * NB) + (size_t)tid * 16;
+  const size_t tstride = (size_t)T * (NB * NB);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tab[TAB_MF * tstride + k] = Ms[i][16 * part + k];      // (zero above the diagonal already)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tab[TAB_MB * tstride + r] = Ms[16 * part + r][i];
+  const int ld = A.ld[sys];
+  const int* prof = A.prof[sys];
+  // P_f = M T(c, c-1): rows of block c, columns of block c-1
+  {
+    double pf[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pf[k] = 0.0;
+    const bool have = c >= 1 && (prof ? prof[c - 1] >= c : true);
+    if (have) {
+      const double* tp = A.S[sys] + (size_t)((c - 1) * NB) * ld + (size_t)c * NB;
+      for (int e = tid; e < NB * NB; e += 256) Ts[e >> 6][e & 63] = tp[(size_t)(e >> 6) * ld + (e & 63)];
+    }
+    __syncthreads();
+    if (have) {
+      for (int m = 0; m <= i; ++m) {
+        const double a = Ms[i][m];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pf[k] += a * Ts[16 * part + k][m];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tab[TAB_PF * tstride + k] = pf[k];
+    __syncthreads();
+  }
+  // P_b = T(c+1, c) M: rows of block c+1, columns of block c
+  {
+    double pb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pb[r] = 0.0;
+    const bool have = c + 1 < T && (prof ? prof[c] >= c + 1 : true);
+    if (have) {
+      const double* tp = A.S[sys] + (size_t)(c * NB) * ld + (size_t)(c + 1) * NB;
+      for (int e = tid; e < NB * NB; e += 256) Ts[e >> 6][e & 63] = tp[(size_t)(e >> 6) * ld + (e & 63)];
+    }
+    __syncthreads();
+    if (have) {
+      for (int m = i; m < NB; ++m) {
+        const double a = Ms[m][i];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pb[r] += Ts[m][16 * part + r] * a;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tab[TAB_PB * tstride + r] = pb[r];
+  }
+}
+
+// One block of a chained substitution with the tables (see above; the f64 variant solves the factorisation's own right-hand side in a
+// joint-solve pass, the f32 variant is the preconditioner).  FWD: block row c, tiles (c, j), j0 <= j < c, x_j polled in ascending
+// order; the last, x_{c-1}, meets P_f.  BWD: block column c, tiles (j, c), c < j <= prof[c], polled in descending order; the last,
+// x_{c+1}, meets P_b.  Waves 0..3 own the tiles, wave 4 polls (CHAIN_THREADS).
+struct alignas(16) TabLds {
+  alignas(16) double xs[2][NB];
+  alignas(16) double ys[NB];
+  alignas(16) double red[4][NB];
+};
+template <bool FWD, bool F32>
+__device__ __forceinline__ void tab_chain_body(TabLds& W, const double* __restrict__ S, int ld, int T, const float* __restrict__ L32,
+                                               const double* __restrict__ ctab, const double* __restrict__ rin, double* xout, int* status, int c,
+                                               const int* __restrict__ prof, const int* __restrict__ first) {
+  auto& xs = W.xs; auto& ys = W.ys; auto& red = W.red;
+  const int tid = threadIdx.x;
+  const bool worker = tid < 256;
+  const int i = (tid >> 2) & 63, part = tid & 3;       // table products: row / column i, entries 16 part ..
+  const int row = tid & 63, cp = (tid >> 6) & 3;       // forward tile products: row `row`, columns 16 cp ..
+  const int jlo = FWD ? (first ? first[c] : 0) : c + 1;
+  const int jhi = FWD ? c - 1 : (prof ? prof[c] : T - 1);      // tiles jlo .. jhi beside the diagonal
+  const int nj = jhi - jlo + 1;
+  const bool has_p = nj >= 1;                          // the neighbour tile: folded into P
+  const int nloop = has_p ? nj - 1 : 0;                // the others, in the order their x arrive: FWD j = jlo + q, BWD j = jhi - q
+  constexpr int RB = F32 ? 6 : 3;
+  typedef typename std::conditional<F32, float, double>::type tile_t;
+  tile_t tr[RB][16];
+  auto tile_load = [&](tile_t (&dst)[16], int q) {
+    const int j = FWD ? jlo + q : jhi - q;
+    if (FWD) {
+      if (F32) {
+        const float* tp = L32 + ((size_t)j * (T - 1) - (size_t)j * (j - 1) / 2 + (c - j - 1)) * (NB * NB) + 16 * cp * NB + row;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r] = tp[r * NB];
+      } else {
+        const double* tp = S + (size_t)(j * NB + 16 * cp) * ld + (size_t)c * NB + row;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r] = tp[(size_t)r * ld];
+      }
+    } else {
+      if (F32) {
+        const float4* tp = reinterpret_cast<const float4*>(L32 + ((size_t)c * (T - 1) - (size_t)c * (c - 1) / 2 + (j - c - 1)) * (NB * NB) + i * NB + 16 * part);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float4 v = tp[r];
+          dst[4 * r] = v.x; dst[4 * r + 1] = v.y; dst[4 * r + 2] = v.z; dst[4 * r + 3] = v.w;
+        }
+      } else {
+        const double* tp = S + (size_t)(c * NB + i) * ld + (size_t)j * NB + 16 * part;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r] = tp[r];
+      }
+    }
+  };
+  double mt[16], pt[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) mt[k] = pt[k] = 0.0;
+  double r0 = 0.0;
+  if (worker) {
+#pragma unroll
+    for (int q = 0; q < RB; ++q)
+      if (q < nloop) tile_load(tr[q], q);
+    const size_t tstride = (size_t)T * (NB * NB);
+    const double* tab = ctab + (size_t)c * (NB * NB) + (size_t)tid * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mt[k] = tab[(FWD ? TAB_MF : TAB_MB) * tstride + k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pt[k] = has_p ? tab[(FWD ? TAB_PF : TAB_PB) * tstride + k] : 0.0;
+    r0 = rin[c * NB + (FWD ? row : i)];
+  }
+  auto poll = [&](int j, int slot) {                   // the polling wave: block x_j -> xs[slot]
+    const int lane = tid - 256;
+    double v;
+    int spins = 0;
+    for (;;) {
+      v = __hip_atomic_load(xout + (size_t)j * NB + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned long long)__double_as_longlong(v) != BWD_SENT) break;
+      if (++spins > (1 << 21)) {                       // exit condition every wave reaches: give up (seconds), flag the solve as failed
+        v = __builtin_nan("");
+        atomicOr(&status[1], 2);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    xs[slot][lane] = v;
+  };
   double acc = 0.0;
-  for (int q0 = 0; q0 < nj; q0 += RB) {
+  for (int q0 = 0; q0 < nloop; q0 += RB) {
 #pragma unroll
     for (int qq = 0; qq < RB; ++qq) {
       const int q = q0 + qq;
-      if (q < nj) {
-        if (!worker) {                          // the polling wave: no tile loads in front of its own (see bwd_chain_body)
-          double v;
-          int spins = 0;
-          for (;;) {
-            v = __hip_atomic_load(xout + (size_t)(j0 + q) * NB + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned long long)__double_as_longlong(v) != BWD_SENT) break;
-            if (++spins > (1 << 21)) {          // exit condition every wave reaches
-              v = __builtin_nan("");
-              atomicOr(&status[1], 2);
-              break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-          }
-          xs[q & 1][row] = v;
-        }
+      if (q < nloop) {
+        if (!worker) poll(FWD ? jlo + q : jhi - q, q & 1);
         __syncthreads();
         if (worker) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc += (double)tr[qq][r] * xs[q & 1][16 * cp + r];
-          if (q + RB < nj) tile_load(tr[qq], j0 + q + RB);
+          for (int r = 0; r < 16; ++r) acc += (double)tr[qq][r] * xs[q & 1][16 * (FWD ? cp : part) + r];
+          if (q + RB < nloop) tile_load(tr[qq], q + RB);
         }
       }
     }
   }
-  if (worker) red[cp][row] = acc;
+  // right-hand side of the block without its neighbour's term, in ys
+  if (FWD) {
+    if (worker) red[cp][row] = acc;
+    __syncthreads();
+    if (tid < NB) ys[row] = r0 - ((red[0][row] + red[1][row]) + (red[2][row] + red[3][row]));
+  } else {
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (worker && part == 0) ys[i] = r0 - acc;
+  }
   __syncthreads();
-  if (tid < NB) ys[row] = r0 - ((red[0][row] + red[1][row]) + (red[2][row] + red[3][row]));
-  __syncthreads();
-  double part = 0.0;
+  if (!worker && has_p) poll(FWD ? c - 1 : c + 1, nloop & 1);      // (while the others finish z)
+  double z = 0.0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int col = 16 * cp + k;
-    if (col <= row) part += Ms[row][col] * ys[col];
+  for (int k = 0; k < 16; ++k) z += mt[k] * ys[16 * part + k];
+  z += __shfl_xor(z, 1);
+  z += __shfl_xor(z, 2);
+  if (has_p) {
+    __syncthreads();
+    double pv = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pv += pt[k] * xs[nloop & 1][16 * part + k];
+    pv += __shfl_xor(pv, 1);
+    pv += __shfl_xor(pv, 2);
+    z -= pv;
   }
-  if (worker) red[cp][row] = part;
-  __syncthreads();
-  if (tid < NB) {
-    const double x = (red[0][row] + red[1][row]) + (red[2][row] + red[3][row]);
-    __hip_atomic_store(xout + (size_t)c * NB + row, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (worker && part == 0) __hip_atomic_store(xout + (size_t)c * NB + i, z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Both triangular solves of S_a^-1 for up to CHOL_BATCH_MAX systems: fwd (ticket counter status[0][5]) or bwd (status[0][4]);
-// rin / xout: per system, T * NB doubles; xout pre-filled with the sentinel, the ticket counter cleared (k_chain_prepare).
+// Both triangular solves for up to CHOL_BATCH_MAX systems with the tables: fwd (ticket counter status[0][5]) or bwd (status[0][4]);
+// in / out: per system, T * NB doubles; out pre-filled with the sentinel, the ticket counter cleared (k_chain_prepare).
 struct ChainBatchArgs {
   int n;
   const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX];
-  const double* Ld[CHOL_BATCH_MAX]; const double* Winv[CHOL_BATCH_MAX]; const double* in[CHOL_BATCH_MAX]; double* out[CHOL_BATCH_MAX];
+  const double* ctab[CHOL_BATCH_MAX]; const double* in[CHOL_BATCH_MAX]; double* out[CHOL_BATCH_MAX];
   int* status[CHOL_BATCH_MAX];
-  float* L32[CHOL_BATCH_MAX];          // packed f32 copy of the factor (written by the type-A workgroups of the factorisation)
+  const float* L32[CHOL_BATCH_MAX];    // packed f32 copy of the factor (written by the type-A workgroups of the factorisation)
   const int* prof[CHOL_BATCH_MAX];     // device: profile of the factor and, per block row, the first block column reaching it; or null
   const int* first[CHOL_BATCH_MAX];
   int Tmax;
 };
-template <bool FWD>
+template <bool FWD, bool F32>
 __global__ __launch_bounds__(CHAIN_THREADS) void k_chain_batched(ChainBatchArgs A) {
-  __shared__ ChainLds W;
+  __shared__ TabLds W;
   for (;;) {
     const int t = bwd_ticket(&A.status[0][FWD ? 5 : 4]);
     if (t >= A.n * A.Tmax) return;
     const int r = t % A.n, b = t / A.n;
     if (b >= A.T[r]) continue;
-    if (FWD) fwd_chain_body<true>(W, A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.in[r], A.out[r], A.status[r], b, A.L32[r], A.first[r]);
-    else bwd_chain_body<true>(W, A.S[r], A.ld[r], A.T[r], A.Ld[r], A.Winv[r], A.in[r], A.out[r], A.status[r], b, A.L32[r], A.prof[r]);
+    tab_chain_body<FWD, F32>(W, A.S[r], A.ld[r], A.T[r], A.L32[r], A.ctab[r], A.in[r], A.out[r], A.status[r], FWD ? b : A.T[r] - 1 - b,
+                             A.prof[r], A.first[r]);
     return;
   }
 }
@@ -1063,15 +1185,33 @@ __global__ void k_chain_prepare(ChainPrepArgs A) {
   if (r == 0 && i == 0) *A.ticket = 0;
   if (i < A.len[r]) A.out[r][i] = __longlong_as_double((long long)BWD_SENT);
 }
-// x = L^-1 in (fwd) or x = L^-T in (bwd) for every system of the batch: out[i] is sentinel-filled (one launch for all) and the chain launched
-void launch_chain_batch(const CholSystem* d, int n, const double* const* in, double* const* out, bool fwd, hipStream_t s) {
+// the tables of every system of the batch: once per factorisation in a joint-solve pass (systems with L32 and ctab)
+static bool chain_has_tables(const CholSystem* d, int n) {
+  for (int i = 0; i < n; ++i)
+    if (!d[i].L32 || !d[i].ctab) return false;
+  return n > 0;
+}
+void launch_chain_tables(const CholSystem* d, int n, hipStream_t s) {
+  if (!chain_has_tables(d, n)) return;
+  ChainTabArgs A{};
+  A.n = n;
+  int Tmax = 0;
+  for (int i = 0; i < n; ++i) {
+    A.T[i] = d[i].T; A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.Ld[i] = d[i].Ld; A.Winv[i] = d[i].Winv; A.prof[i] = d[i].prof; A.ctab[i] = d[i].ctab;
+    Tmax = d[i].T > Tmax ? d[i].T : Tmax;
+  }
+  if (Tmax > 0) hipLaunchKernelGGL(k_chain_tables, dim3(Tmax, n), dim3(256), 0, s, A);
+}
+// x = L^-1 in (fwd) or x = L^-T in (bwd) for every system of the batch (tables required): out[i] is sentinel-filled (one launch for
+// all) and the chain launched; f32: tiles from the packed f32 copy (the preconditioner), else from S
+void launch_chain_batch(const CholSystem* d, int n, const double* const* in, double* const* out, bool fwd, bool f32, hipStream_t s) {
   ChainBatchArgs A{};
   ChainPrepArgs Pr{};
   A.n = n;
   Pr.n = n;
   int Tmax = 0, total = 0;
   for (int i = 0; i < n; ++i) {
-    A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.Ld[i] = d[i].Ld; A.Winv[i] = d[i].Winv; A.in[i] = in[i]; A.out[i] = out[i];
+    A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.ctab[i] = d[i].ctab; A.in[i] = in[i]; A.out[i] = out[i];
     A.status[i] = d[i].status;
     A.L32[i] = d[i].L32;
     A.prof[i] = d[i].prof; A.first[i] = d[i].first;
@@ -1082,12 +1222,16 @@ void launch_chain_batch(const CholSystem* d, int n, const double* const* in, dou
   }
   A.Tmax = Tmax;
   if (total <= 0) return;
-  for (int i = 0; i < n; ++i)
-    if (!d[i].L32) { fprintf(stderr, "slide_slam_amd: launch_chain_batch without the packed f32 factor\n"); abort(); }
+  if (!chain_has_tables(d, n)) { fprintf(stderr, "slide_slam_amd: launch_chain_batch without the tables / the packed f32 factor\n"); abort(); }
   Pr.ticket = d[0].status + (fwd ? 5 : 4);
   hipLaunchKernelGGL(k_chain_prepare, dim3((Tmax * NB + 255) / 256, n), dim3(256), 0, s, Pr);
-  if (fwd) hipLaunchKernelGGL(k_chain_batched<true>, dim3(total), dim3(CHAIN_THREADS), 0, s, A);
-  else hipLaunchKernelGGL(k_chain_batched<false>, dim3(total), dim3(CHAIN_THREADS), 0, s, A);
+  if (fwd) {
+    if (f32) hipLaunchKernelGGL((k_chain_batched<true, true>), dim3(total), dim3(CHAIN_THREADS), 0, s, A);
+    else hipLaunchKernelGGL((k_chain_batched<true, false>), dim3(total), dim3(CHAIN_THREADS), 0, s, A);
+  } else {
+    if (f32) hipLaunchKernelGGL((k_chain_batched<false, true>), dim3(total), dim3(CHAIN_THREADS), 0, s, A);
+    else hipLaunchKernelGGL((k_chain_batched<false, false>), dim3(total), dim3(CHAIN_THREADS), 0, s, A);
+  }
 }
 
 // ---- marginal covariance of one pose (getPoseCovariance graph.cpp:314-323) ---------------------------------------------------
@@ -1172,6 +1316,8 @@ void launch_pose_covariance(const double* S, int ld, int T, const double* Ld, co
 // Schedule (see step_type_b): launch 0 factors column 0, launch 1 column 1 with panel 0 (and brings column 2 up to panel 0);
 // from then on every launch k takes the one pending panel k-1 in its column, even launches start the rank-128 pass of panels
 // k-2, k-1 over the trailing matrix, odd launches finish the pass their predecessor started and bring column k+1 up to panel k-1.
+void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp,
+                         int* status, const int* prof, hipStream_t s);
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s) {
   hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv, dp, status);
 }
@@ -1258,18 +1404,38 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
     hipLaunchKernelGGL(k_chol_step_batched, dim3((unsigned)(nAw + extra)), dim3(512), 0, s, A, k, k & ~1, ctr, a_joins);
   }
   if (after_steps) (void)hipEventRecord(after_steps, s);
+  launch_chain_tables(d, n, s);
   BwdBatchArgs B{};
   B.n = n;
   B.base[0] = 0;
+  const double* yin[CHOL_BATCH_MAX];
+  double* xout[CHOL_BATCH_MAX];
   for (int i = 0; i < n; ++i) {
     launch_chol_extract_y(d[i].S, d[i].ld, d[i].T, d[i].yv, d[i].dp, d[i].status, s);
+    yin[i] = d[i].yv; xout[i] = d[i].dp;
     B.S[i] = d[i].S; B.ld[i] = d[i].ld; B.T[i] = d[i].T; B.Ld[i] = d[i].Ld; B.Winv[i] = d[i].Winv; B.yv[i] = d[i].yv; B.dp[i] = d[i].dp;
     B.status[i] = d[i].status;
     B.prof[i] = d[i].prof;
     B.base[i + 1] = B.base[i] + d[i].T;
   }
   B.Tmax = Tmax;
-  if (B.base[n] > 0) hipLaunchKernelGGL(k_chol_bwd_chain_batched, dim3(B.base[n]), dim3(CHAIN_THREADS), 0, s, B);
+  if (B.base[n] <= 0) return;
+  if (chain_has_tables(d, n)) {                 // joint-solve pass: the tables are there for the preconditioner anyway
+    launch_chain_batch(d, n, yin, xout, false, false, s);
+    return;
+  }
+  hipLaunchKernelGGL(k_chol_bwd_chain_batched, dim3(B.base[n]), dim3(CHAIN_THREADS), 0, s, B);
+}
+// the solve of the factorisation's own right-hand side for one system (after launch_chol_extract_y): yv -> dp
+void launch_chol_solve_bwd(const CholSystem& cs, hipStream_t s) {
+  if (chain_has_tables(&cs, 1)) {
+    launch_chain_tables(&cs, 1, s);
+    const double* yin = cs.yv;
+    double* xout = cs.dp;
+    launch_chain_batch(&cs, 1, &yin, &xout, false, false, s);
+    return;
+  }
+  launch_chol_bwd_all(cs.S, cs.ld, cs.T, cs.Ld, cs.Winv, cs.yv, cs.dp, cs.status, cs.prof, s);
 }
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp,
                          int* status, const int* prof, hipStream_t s) {

@@ -409,7 +409,7 @@ int CholBatch::factor_solve(int slot, const GraphDev& G, hipStream_t s) {
   {
     std::lock_guard<std::mutex> lk(mtx);
     sys[slot] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, (pcg_iters > 0 && G.n_slots > 0) ? graphs[slot]->d_L32.d : nullptr,
-                                graphs[slot]->h_prof.data(), G.prof, G.first};
+                                graphs[slot]->h_prof.data(), G.prof, G.first, graphs[slot]->d_ctab.d};
   }
   return rendezvous(slot, s, false, 0);
 }
@@ -478,7 +478,7 @@ int CholBatch::prepare_pass() {
   for (int i = 0; i < n; ++i) {
     const GraphDev& G = graphs[i]->G;
     sys[i] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, (pcg_iters > 0 && G.n_slots > 0) ? graphs[i]->d_L32.d : nullptr,
-                             graphs[i]->h_prof.data(), G.prof, G.first};
+                             graphs[i]->h_prof.data(), G.prof, G.first, graphs[i]->d_ctab.d};
     Tmax = G.T > Tmax ? G.T : Tmax;
     hG[i] = G;
     hG[i].save_S0 = (pcg_iters > 0 && G.n_slots > 0) ? 1 : 0;      // the batched Schur assembly writes S0 itself
@@ -743,9 +743,9 @@ int CholBatch::enqueue_pcg_tail(double* const* d_bufs, bool last) {
   const double* in[CHOL_BATCH_HOST_MAX];
   double* out[CHOL_BATCH_HOST_MAX];
   for (int i = 0; i < n; ++i) { in[i] = hG[i].pcg + (size_t)PCG_VEC_R * hG[i].T * NB; out[i] = hG[i].pcg + (size_t)PCG_VEC_Y * hG[i].T * NB; }
-  launch_chain_batch(sys.data(), n, in, out, true, master);
+  launch_chain_batch(sys.data(), n, in, out, true, true, master);
   for (int i = 0; i < n; ++i) { in[i] = out[i]; out[i] = hG[i].pcg + (size_t)PCG_VEC_U * hG[i].T * NB; }
-  launch_chain_batch(sys.data(), n, in, out, false, master);
+  launch_chain_batch(sys.data(), n, in, out, false, true, master);
   launch_pcg_tl(d_Gs, hG.data(), n, d_bufs, PCG_VEC_U, master);
   launch_sum_bcast(d_bufs, n, 9 * hG[0].n_slots, master);
   return SLIDE_OK;
@@ -796,7 +796,8 @@ int HostGraph::factor_and_solve(hipStream_t s) {
     launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr,
                      (pcg_iters > 0 && G.n_slots > 0) ? d_L32.d : nullptr, h_prof.data(), s);
   launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, G.status, s);
-  launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, G.prof, s);
+  launch_chol_solve_bwd(CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, (pcg_iters > 0 && G.n_slots > 0) ? d_L32.d : nullptr,
+                                   h_prof.data(), G.prof, G.first, d_ctab.d}, s);
   return SLIDE_OK;
 }
 
@@ -1014,6 +1015,7 @@ int HostGraph::upload_new() {
     if (d_S0.d) { SL_HIP(hipFree(d_S0.d)); d_S0.d = nullptr; }
     if (d_S0.ensure(ld * (size_t)Tcap * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_L32.ensure((size_t)Tcap * (Tcap - 1) / 2 * NB * NB + 4, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_ctab.ensure((size_t)4 * Tcap * NB * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_pcg.ensure((size_t)PCG_VEC_COUNT * Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_pcg_scal.ensure(8, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_Ld.ensure((size_t)Tcap * NB * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
@@ -1115,7 +1117,7 @@ int HostGraph::enqueue_iteration(bool lookahead) {
   for (int k = 0; k < G.T; ++k)
     STAGE(5, launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, nullptr, h_prof.data(), s));
   STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, G.status, s));
-  STAGE(8, launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, G.prof, s));
+  STAGE(8, launch_chol_solve_bwd(CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, nullptr, h_prof.data(), G.prof, G.first, d_ctab.d}, s));
   STAGE(9, launch_backsub(G, 0, s));
   STAGE(10, launch_estimate(G, s));
 #undef STAGE
@@ -1265,13 +1267,13 @@ int HostGraph::enqueue_phase(int phase, double* d_buf) {
       launch_shared_pack(G, 1, d_buf, s);
     } else {
       const size_t nT = (size_t)G.T * NB;
-      const CholSystem cs{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, d_L32.d, h_prof.data(), G.prof, G.first};
+      const CholSystem cs{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, d_L32.d, h_prof.data(), G.prof, G.first, d_ctab.d};
       const double* in = G.pcg + PCG_VEC_R * nT;
       double* out = G.pcg + PCG_VEC_Y * nT;
-      launch_chain_batch(&cs, 1, &in, &out, true, s);
+      launch_chain_batch(&cs, 1, &in, &out, true, true, s);
       in = out;
       out = G.pcg + PCG_VEC_U * nT;
-      launch_chain_batch(&cs, 1, &in, &out, false, s);
+      launch_chain_batch(&cs, 1, &in, &out, false, true, s);
       launch_pcg_tl(d_Gself.d, &G, 1, &d_buf, PCG_VEC_U, s);
     }
   } else {

@@ -281,6 +281,7 @@ class HostGraph {
   DevArr<int> d_prof, d_first;                         // tile-level profile of the reduced system (graph_dev.hpp), host copies h_prof / h_first
   std::vector<int> h_prof, h_first;
   int prof_ver = 0;
+  DevArr<double> d_ctab;                               // explicit inverses of the diagonal blocks (k_chain_tables)
   DevArr<float> d_L32;                                 // packed f32 copy of the factor: the joint solve's preconditioner streams this
   DevArr<GraphDev> d_Gself;                             // this graph's view on the device, for the kernels that take an array of views
   GraphDev G_self{};

@@ -35,16 +35,19 @@ void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* d
 struct CholSystem { double* S; int ld, T; double* Ld; double* Winv; double* yv; double* dp; int* status;
                     float* L32;      // packed f32 copy of the factor for the joint solve's preconditioner (null: none), see bwd_chain_body
                     const int* h_prof;           // host: profile of the factor, T ints (plan_step in chol_kernels.hip), or null = dense
-                    const int* prof; const int* first; };   // device: the same and, per block row, the first block column that reaches it
+                    const int* prof; const int* first;      // device: the same and, per block row, the first block column that reaches it
+                    double* ctab; };             // 4 * T * 4096 doubles: tables of the chained substitutions in a joint-solve pass (k_chain_tables), or null
 void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps = nullptr);            // up to 8 systems, one launch per block column
 // one of the two triangular solves with the finished factors of up to 8 systems on arbitrary vectors (T * NB doubles each): out = L^-1 in
 // (fwd) or L^-T in (bwd); the preconditioner of the joint solve (pcg_kernels.hip)
-void launch_chain_batch(const CholSystem* d, int n, const double* const* in, double* const* out, bool fwd, hipStream_t s);
+void launch_chain_batch(const CholSystem* d, int n, const double* const* in, double* const* out, bool fwd, bool f32, hipStream_t s);   // needs the tables (launch_chain_tables) of this factorisation
+void launch_chain_tables(const CholSystem* d, int n, hipStream_t s);
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp, int* status, const int* prof, hipStream_t s);
 // marginal covariance of the pose whose first tangent row is row0 (Y: 6 * T * NB scratch doubles holding the six unit columns)
 void launch_pose_covariance(const double* S, int ld, int T, const double* Ld, const double* Winv, double* Y, int row0, double* cov36,
                             hipStream_t s);
 // stand-alone dense SPD solve on device buffers (used by the unit tests and the roofline bench leg)
+void launch_chol_solve_bwd(const CholSystem& cs, hipStream_t s);   // yv -> dp after launch_chol_extract_y: one-workgroup substitution for narrow profiles, else the chained kernel
 int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double* yv, double* dp, int* status, int* ctr, hipStream_t s);
 
 // pcg_kernels.hip — joint Gauss-Newton step of the robots of a GPU (and, through the caller's exchanges, of the job): PCG on the
