@@ -182,6 +182,13 @@ int slide_graph_set_pcg(slide_graph_t* g, int iterations);
  * last iteration, gamma of the FIRST iteration, gamma of the last; 0, 0} with gamma = r^T M^-1 r (M = the robots' own factors), summed
  * over all robots: gamma_last / gamma_first is the squared reduction of the preconditioned residual. */
 int slide_graph_get_pcg_stats(slide_graph_t* g, double out8[8]);
+/* Tile-level profile (envelope) of the reduced pose system the solver works in (64 x 64 tiles; the reference's sparse elimination,
+ * ISAM2 graph.cpp:260-272, exploits the same structure): returns T, the number of block columns, and writes prof[c] = the last tile row
+ * of block column c that can be non-zero in the factor (c <= prof[c] < T, monotone) for c < min(T, cap).  Pending additions are
+ * merged first.  slide_graph_set_dense_profile(g, 1) makes the solver ignore the structure (every tile of the lower triangle: the
+ * GEMM-shaped extreme, a measurement aid); results are the same either way. */
+int slide_graph_get_tile_profile(slide_graph_t* g, int* prof, int cap);
+int slide_graph_set_dense_profile(slide_graph_t* g, int on);
 /* Measurement aid: the same pass issued without the graph, HIP events around the batched step kernels; *ms_steps = their device time
  * (launch gaps included), *n_launches = their number. */
 int slide_chol_batch_profile(slide_chol_batch_t* b, double* const* d_bufs, double* ms_steps, int* n_launches);

@@ -1036,7 +1036,7 @@ int HostGraph::upload_new() {
       const int lo = std::min(h_bt_i[b], h_bt_j[b]), hi = std::max(h_bt_i[b], h_bt_j[b]);
       reach[lo] = std::max(reach[lo], hi);
     }
-    static const bool dense = getenv("SLIDE_CHOL_DENSE") && getenv("SLIDE_CHOL_DENSE")[0] == '1';      // diagnostic: ignore the structure
+    const bool dense = force_dense;      // measurement aid (slide_graph_set_dense_profile / SLIDE_CHOL_DENSE=1): ignore the structure
     std::vector<int> prof(T), first(T);
     for (int c = 0; c < T; ++c) prof[c] = dense ? T - 1 : c;
     for (size_t p = 0; p < Pn && !dense; ++p) {
@@ -1483,6 +1483,19 @@ int HostGraph::chi2(double* out4) {
   SL_HIP(hipGetLastError());
   factor_valid = false;
   return SLIDE_OK;
+}
+int HostGraph::get_tile_profile(int* out, int cap) {
+  int rc = merge_pending();
+  if (rc == SLIDE_OK) rc = upload_new();
+  if (rc != SLIDE_OK) return rc < 0 ? rc : -rc;
+  const int T = (int)h_prof.size();
+  for (int c = 0; c < T && c < cap; ++c) out[c] = h_prof[c];
+  return T;
+}
+void HostGraph::set_dense_profile(bool on) {
+  if (force_dense == on) return;
+  force_dense = on;
+  topo_dirty = true;
 }
 int HostGraph::pcg_stats(double* out8) {
   for (int i = 0; i < 8; ++i) out8[i] = 0.0;

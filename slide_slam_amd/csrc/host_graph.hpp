@@ -222,6 +222,8 @@ class HostGraph {
   void stats(int64_t* out5) const;
   int64_t rejected() const;
   int chi2(double* out4);                 // sum of squared whitened residuals at the current estimate: total, priors, betweens, landmark factors
+  int get_tile_profile(int* out, int cap);     // T (>= 0) or a negative error; out[c] = prof[c] for c < min(T, cap)
+  void set_dense_profile(bool on);        // ignore the structure of the reduced system (measurement aid)
   int pcg_stats(double* out8);            // scalars of the last joint solve: gamma_old, alpha_old, alpha, beta, first gamma, last gamma               // entries merge_pending refused since creation
 
   static uint64_t pose_key(int robot, uint64_t idx);
@@ -281,6 +283,7 @@ class HostGraph {
   DevArr<int> d_prof, d_first;                         // tile-level profile of the reduced system (graph_dev.hpp), host copies h_prof / h_first
   std::vector<int> h_prof, h_first;
   int prof_ver = 0;
+  bool force_dense = getenv("SLIDE_CHOL_DENSE") && getenv("SLIDE_CHOL_DENSE")[0] == '1';
   DevArr<double> d_ctab;                               // explicit inverses of the diagonal blocks (k_chain_tables)
   DevArr<float> d_L32;                                 // packed f32 copy of the factor: the joint solve's preconditioner streams this
   DevArr<GraphDev> d_Gself;                             // this graph's view on the device, for the kernels that take an array of views
