@@ -40,12 +40,17 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak, public spec (MI355X_MI
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
+DENSE_PROFILE = False          # --dense-profile: every graph of the run ignores the structure of its reduced system (profiling aid)
+
+
 def build_shard(s, log, frames=None, ingest_only=False):
     """Stream one robot's frame log through the per-frame path (association + add + iSAM2-equivalent update).
     ingest_only (profiling aid): add every frame without solving (association against the un-refined map at the ground-truth
     poses, as the cpu_baseline leg does), then one solve — every k_chol_step launch of the run is then full-size."""
     from slide_slam_amd.replay import replay_single
     gb = s.SlideBackend(s.default_params(), 1)
+    if DENSE_PROFILE:
+        gb.graph.set_dense_profile(True)
     if not ingest_only:
         out = replay_single(gb, log, n_frames=frames, collect=False)
         return gb, out
@@ -207,6 +212,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the un-batched re-run and the convergence probe")
     ap.add_argument("--ingest-only", action="store_true", help="build the graph without per-frame solves (profiling aid)")
+    ap.add_argument("--dense-profile", action="store_true",
+                    help="the whole run on the dense profile (every tile of the lower triangle): the configuration of roofline.dense_profile, "
+                         "for rocprofv3 runs")
     ap.add_argument("--robots-per-gpu", type=int, default=0,
                     help="robot shards per GPU; 0 = the preset's robots / N when that divides (the SAME 8-robot graph at every N: "
                          "strong scaling), else 1; 1 = one robot per GPU at every N (weak scaling)")
@@ -214,6 +222,8 @@ def main():
     ap.add_argument("--pcg", type=int, default=8,
                     help="PCG iterations of the joint solve per pass (0 = every robot's own block solve only: block-Jacobi over robots)")
     args = ap.parse_args()
+    global DENSE_PROFILE
+    DENSE_PROFILE = args.dense_profile
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -326,9 +336,9 @@ def main():
             batched_prof = dict(ms_steps=pr[len(pr) // 2][0], launches=pr[0][1], robots=R, flops=sum(chol_flops(T, pf) for pf in profs),
                                 tiles=int(sum(int(pf[k]) - k + 1 for pf in profs for k in range(len(pf)))), tiles_dense=R * T * (T + 1) // 2)
             # the same graphs with the structure ignored (every tile of the lower triangle): the GEMM-shaped extreme of the same kernels
-            for gb in shards:
+            for gb in ([] if DENSE_PROFILE else shards):
                 gb.graph.set_dense_profile(True)
-            for _ in range(3):
+            for _ in range(0 if DENSE_PROFILE else 3):
                 step()
             barrier()
             td = time.perf_counter()
@@ -339,7 +349,7 @@ def main():
             td = (time.perf_counter() - td) / nd
             prd = sorted(batch.profile(ptrs) for _ in range(5))
             dense_leg = dict(ms_steps=prd[len(prd) // 2][0], launches=prd[0][1], ms_per_step=td * 1e3, flops=R * chol_flops(T))
-            for gb in shards:
+            for gb in ([] if DENSE_PROFILE else shards):
                 gb.graph.set_dense_profile(False)
             step()
         if n_probe:
@@ -414,7 +424,7 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
     for _ in range(nprof):
         g.gauss_newton(1)
     prof_all = g.get_profile()
-    g.set_dense_profile(False)
+    g.set_dense_profile(DENSE_PROFILE)
     g.set_profiling(False)
     devs = [f"cuda:{torch.cuda.current_device()} {torch.cuda.get_device_name()}"]
     if dist is not None and world > 1:

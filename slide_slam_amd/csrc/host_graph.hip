@@ -1001,7 +1001,9 @@ int HostGraph::upload_new() {
   if (ub.flush(s) != SLIDE_OK) return SLIDE_ERR_HIP;   // (the host temporaries were copied into the pinned staging buffer)
   // dense reduced system
   const int T = (int)((6 * Pn + NB - 1) / NB);
+  bool fresh_S = false;
   if (T > Tcap) {
+    fresh_S = true;
     int nc = Tcap ? Tcap : 4;
     while (nc < T) nc = nc + nc / 2 + 1;
     Tcap = nc;
@@ -1051,10 +1053,18 @@ int HostGraph::upload_new() {
       first[r] = c;
     }
     if (prof != h_prof) {
-      // a tile that leaves the profile (or the right-hand-side row moving down as T grows) would keep stale values: clear S
-      bool superset = T == (int)h_prof.size();
-      for (int c = 0; superset && c < T; ++c) superset = prof[c] >= h_prof[c];
-      if (!superset && d_S.d) SL_HIP(hipMemsetAsync(d_S.d, 0, d_S.cap * sizeof(double), s));
+      // S outside the profile must hold zeros.  A freshly allocated S does; when T grows, the old right-hand-side row (one row of
+      // the old last tile row + 1) becomes a matrix row and is cleared; when a tile LEAVES the profile (never on a growing graph) the
+      // used part of S is cleared as a whole.
+      const int Told = (int)h_prof.size();
+      bool shrink = T < Told;
+      for (int c = 0; !shrink && c < std::min(T, Told); ++c) shrink = prof[c] < h_prof[c];
+      const size_t ld = (size_t)(Tcap + 1) * NB;
+      if (!fresh_S && d_S.d) {
+        if (shrink) SL_HIP(hipMemsetAsync(d_S.d, 0, ld * (size_t)std::max(T, Told) * NB * sizeof(double), s));
+        else if (T > Told && Told > 0)
+          SL_HIP(hipMemset2DAsync(d_S.d + (size_t)Told * NB, ld * sizeof(double), 0, sizeof(double), (size_t)Told * NB, s));
+      }
       h_prof = prof;
       h_first = first;
       if (d_prof.ensure(std::max<size_t>(T, 1), 0, s) != SLIDE_OK || d_first.ensure(std::max<size_t>(T, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;

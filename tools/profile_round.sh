@@ -7,17 +7,19 @@ R=${1:-r02}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT profiles
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-BENCH="python3 bench.py --steps 10 --warmup 3 --no-cpu --no-parity"
+BENCH="python3 bench.py --steps 10 --warmup 3 --no-cpu --no-parity ${BENCH_ARGS}"      # BENCH_ARGS=--dense-profile: the dense-profile configuration
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || exit 1
 echo "trace done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f -- $BENCH > $OUT/pmc_f.log 2>&1 || exit 1
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w -- $BENCH > $OUT/pmc_w.log 2>&1 || exit 1
 echo "write done"
+if [ -z "$SKIP_ASSOC" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/atrace -- python3 tools/assoc_sweep_prof.py > $OUT/atrace.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/apmc_f -- python3 tools/assoc_sweep_prof.py > $OUT/apmc_f.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/apmc_w -- python3 tools/assoc_sweep_prof.py > $OUT/apmc_w.log 2>&1 || exit 1
 echo "assoc done"
+fi
 python3 tools/profile_summary.py $OUT $R
 python3 tools/trace_batched.py $OUT/trace 59 > profiles/${R}_bench_chol_step_batched_by_k.txt 2>&1
 # the raw traces are hundreds of MB: keep the summaries only (profiles/ is what is committed; a copy goes back through gpurun_out/)
