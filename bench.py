@@ -40,6 +40,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak, public spec (MI355X_MI
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
+DENSE_LEG = True               # roofline.dense_profile: the same kernels on the same graphs with the structure ignored
 DENSE_PROFILE = False          # --dense-profile: every graph of the run ignores the structure of its reduced system (profiling aid)
 
 
@@ -180,7 +181,7 @@ def _pmc_traffic(kernel, **match):
     """HBM-side bytes per launch of `kernel` from the committed PMC summaries (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     passes, gfx950 corrections applied; a PMC pass cannot run inside the timed bench): newest round first."""
     pdir = os.path.join(ROOT, "profiles")
-    for rnd in ("r02", "r01"):
+    for rnd in ("r02_dense", "r02", "r01"):
         for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
             if not (name.startswith(rnd + "_pmc_traffic") and name.endswith(".json")):
                 continue
@@ -212,6 +213,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the un-batched re-run and the convergence probe")
     ap.add_argument("--ingest-only", action="store_true", help="build the graph without per-frame solves (profiling aid)")
+    ap.add_argument("--no-dense-leg", action="store_true", help="skip the dense-profile legs of the roofline (rocprofv3 runs of the default)")
     ap.add_argument("--dense-profile", action="store_true",
                     help="the whole run on the dense profile (every tile of the lower triangle): the configuration of roofline.dense_profile, "
                          "for rocprofv3 runs")
@@ -222,8 +224,9 @@ def main():
     ap.add_argument("--pcg", type=int, default=8,
                     help="PCG iterations of the joint solve per pass (0 = every robot's own block solve only: block-Jacobi over robots)")
     args = ap.parse_args()
-    global DENSE_PROFILE
+    global DENSE_PROFILE, DENSE_LEG
     DENSE_PROFILE = args.dense_profile
+    DENSE_LEG = not (args.no_dense_leg or args.dense_profile)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -336,22 +339,23 @@ def main():
             batched_prof = dict(ms_steps=pr[len(pr) // 2][0], launches=pr[0][1], robots=R, flops=sum(chol_flops(T, pf) for pf in profs),
                                 tiles=int(sum(int(pf[k]) - k + 1 for pf in profs for k in range(len(pf)))), tiles_dense=R * T * (T + 1) // 2)
             # the same graphs with the structure ignored (every tile of the lower triangle): the GEMM-shaped extreme of the same kernels
-            for gb in ([] if DENSE_PROFILE else shards):
-                gb.graph.set_dense_profile(True)
-            for _ in range(0 if DENSE_PROFILE else 3):
+            if DENSE_LEG:
+                for gb in shards:
+                    gb.graph.set_dense_profile(True)
+                for _ in range(3):
+                    step()
+                barrier()
+                td = time.perf_counter()
+                nd = max(5, min(args.steps, 20))
+                for _ in range(nd):
+                    step()
+                barrier()
+                td = (time.perf_counter() - td) / nd
+                prd = sorted(batch.profile(ptrs) for _ in range(5))
+                dense_leg = dict(ms_steps=prd[len(prd) // 2][0], launches=prd[0][1], ms_per_step=td * 1e3, flops=R * chol_flops(T))
+                for gb in shards:
+                    gb.graph.set_dense_profile(False)
                 step()
-            barrier()
-            td = time.perf_counter()
-            nd = max(5, min(args.steps, 20))
-            for _ in range(nd):
-                step()
-            barrier()
-            td = (time.perf_counter() - td) / nd
-            prd = sorted(batch.profile(ptrs) for _ in range(5))
-            dense_leg = dict(ms_steps=prd[len(prd) // 2][0], launches=prd[0][1], ms_per_step=td * 1e3, flops=R * chol_flops(T))
-            for gb in ([] if DENSE_PROFILE else shards):
-                gb.graph.set_dense_profile(False)
-            step()
         if n_probe:
             # cost (sum of squared whitened residuals over all factors of the job) after every probe pass, and how many passes it
             # took to come within 0.1 % of the cost the run ended at; pose change relative to the final state for orientation
@@ -419,12 +423,14 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
         g.gauss_newton(1)
     prof = g.get_profile()
     tprof = g.tile_profile()
-    g.set_dense_profile(True)          # and robot 0 alone with the structure ignored
-    g.gauss_newton(1)
-    for _ in range(nprof):
+    prof_all = prof
+    if DENSE_LEG:
+        g.set_dense_profile(True)          # and robot 0 alone with the structure ignored
         g.gauss_newton(1)
-    prof_all = g.get_profile()
-    g.set_dense_profile(DENSE_PROFILE)
+        for _ in range(nprof):
+            g.gauss_newton(1)
+        prof_all = g.get_profile()
+        g.set_dense_profile(False)
     g.set_profiling(False)
     devs = [f"cuda:{torch.cuda.current_device()} {torch.cuda.get_device_name()}"]
     if dist is not None and world > 1:
@@ -464,7 +470,7 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
         upd_ms = bt["ms_steps"] / max(upd_launches_per_iter, 1)
         flops_per_launch = bt["flops"] / max(upd_launches_per_iter, 1)
         ach = flops_per_launch / (upd_ms * 1e-3) / 1e12
-        traffic = None
+        traffic = _pmc_traffic("k_chol_step_batched", robots=bt["robots"], robots_per_launch=per, profile="dense" if DENSE_PROFILE else "structure") if n == 3776 else None
     kernel_ms = {k: v["ms"] / nprof for k, v in prof.items()}
     dominant = max(kernel_ms, key=kernel_ms.get)
     n_slots = info.get("n_slots", 0) if info else 0
@@ -503,7 +509,7 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
                      "dense_profile": (None if not (bt and dense_leg) else (lambda dm, dfl: {
                          "achieved": dfl / (dm * 1e-3) / 1e12, "frac": dfl / (dm * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                          "flops_per_launch": dfl, "avg_launch_ms": dm, "ms_per_step": dense_leg["ms_per_step"],
-                         "traffic": _pmc_traffic("k_chol_step_batched", robots=bt["robots"], robots_per_launch=per) if n == 3776 else None})(
+                         "traffic": _pmc_traffic("k_chol_step_batched", robots=bt["robots"], robots_per_launch=per, profile="dense") if n == 3776 else None})(
                              dense_leg["ms_steps"] / max(dense_leg["launches"] * groups, 1), dense_leg["flops"] / max(dense_leg["launches"] * groups, 1))),
                      "flops_per_launch": flops_per_launch, "avg_launch_ms": upd_ms,
                      "launches_per_iter": upd_launches_per_iter, "dominant_by_time": dominant,

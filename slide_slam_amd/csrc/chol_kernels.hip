@@ -1036,10 +1036,12 @@ struct alignas(16) TabLds {
 template <bool FWD, bool F32>
 __device__ __forceinline__ void tab_chain_body(TabLds& W, const double* __restrict__ S, int ld, int T, const float* __restrict__ L32,
                                                const double* __restrict__ ctab, const double* __restrict__ rin, double* xout, int* status, int c,
-                                               const int* __restrict__ prof, const int* __restrict__ first) {
+                                               const int* __restrict__ prof, const int* __restrict__ first, double* __restrict__ next_out) {
   auto& xs = W.xs; auto& ys = W.ys; auto& red = W.red;
   const int tid = threadIdx.x;
   const bool worker = tid < 256;
+  // the substitution that follows this one (the backward chain after the forward one) finds its output pre-filled with the sentinel
+  if (next_out && !worker) next_out[(size_t)c * NB + (tid - 256)] = __longlong_as_double((long long)BWD_SENT);
   const int i = (tid >> 2) & 63, part = tid & 3;       // table products: row / column i, entries 16 part ..
   const int row = tid & 63, cp = (tid >> 6) & 3;       // forward tile products: row `row`, columns 16 cp ..
   const int jlo = FWD ? (first ? first[c] : 0) : c + 1;
@@ -1163,6 +1165,8 @@ struct ChainBatchArgs {
   const float* L32[CHOL_BATCH_MAX];    // packed f32 copy of the factor (written by the type-A workgroups of the factorisation)
   const int* prof[CHOL_BATCH_MAX];     // device: profile of the factor and, per block row, the first block column reaching it; or null
   const int* first[CHOL_BATCH_MAX];
+  double* next_out[CHOL_BATCH_MAX];    // output of the chain launched after this one: sentinel-filled here, its ticket counter cleared (or null)
+  int* next_ticket;
   int Tmax;
 };
 template <bool FWD, bool F32>
@@ -1172,9 +1176,10 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chain_batched(ChainBatchArgs 
     const int t = bwd_ticket(&A.status[0][FWD ? 5 : 4]);
     if (t >= A.n * A.Tmax) return;
     const int r = t % A.n, b = t / A.n;
+    if (t == 0 && A.next_ticket && threadIdx.x == 0) *A.next_ticket = 0;
     if (b >= A.T[r]) continue;
     tab_chain_body<FWD, F32>(W, A.S[r], A.ld[r], A.T[r], A.L32[r], A.ctab[r], A.in[r], A.out[r], A.status[r], FWD ? b : A.T[r] - 1 - b,
-                             A.prof[r], A.first[r]);
+                             A.prof[r], A.first[r], A.next_out[r]);
     return;
   }
 }
@@ -1202,9 +1207,12 @@ void launch_chain_tables(const CholSystem* d, int n, hipStream_t s) {
   }
   if (Tmax > 0) hipLaunchKernelGGL(k_chain_tables, dim3(Tmax, n), dim3(256), 0, s, A);
 }
-// x = L^-1 in (fwd) or x = L^-T in (bwd) for every system of the batch (tables required): out[i] is sentinel-filled (one launch for
-// all) and the chain launched; f32: tiles from the packed f32 copy (the preconditioner), else from S
-void launch_chain_batch(const CholSystem* d, int n, const double* const* in, double* const* out, bool fwd, bool f32, hipStream_t s) {
+// x = L^-1 in (fwd) or x = L^-T in (bwd) for every system of the batch (tables required); f32: tiles from the packed f32 copy (the
+// preconditioner), else from S.  out[i] must be sentinel-filled and the ticket counter clear: `prepared` = the caller's kernels did
+// that (k_chol_extract_y, k_pcg_update, the chain before — next_out), else one extra launch does.  next_out (or null): the outputs of
+// the chain that will be launched after this one, prepared here.
+void launch_chain_batch(const CholSystem* d, int n, const double* const* in, double* const* out, bool fwd, bool f32, bool prepared,
+                        double* const* next_out, hipStream_t s) {
   ChainBatchArgs A{};
   ChainPrepArgs Pr{};
   A.n = n;
@@ -1219,12 +1227,14 @@ void launch_chain_batch(const CholSystem* d, int n, const double* const* in, dou
     total += d[i].T;
     Pr.out[i] = out[i];
     Pr.len[i] = d[i].T * NB;
+    A.next_out[i] = next_out ? next_out[i] : nullptr;
   }
+  A.next_ticket = next_out ? d[0].status + (fwd ? 4 : 5) : nullptr;
   A.Tmax = Tmax;
   if (total <= 0) return;
   if (!chain_has_tables(d, n)) { fprintf(stderr, "slide_slam_amd: launch_chain_batch without the tables / the packed f32 factor\n"); abort(); }
   Pr.ticket = d[0].status + (fwd ? 5 : 4);
-  hipLaunchKernelGGL(k_chain_prepare, dim3((Tmax * NB + 255) / 256, n), dim3(256), 0, s, Pr);
+  if (!prepared) hipLaunchKernelGGL(k_chain_prepare, dim3((Tmax * NB + 255) / 256, n), dim3(256), 0, s, Pr);
   if (fwd) {
     if (f32) hipLaunchKernelGGL((k_chain_batched<true, true>), dim3(total), dim3(CHAIN_THREADS), 0, s, A);
     else hipLaunchKernelGGL((k_chain_batched<true, false>), dim3(total), dim3(CHAIN_THREADS), 0, s, A);
@@ -1421,7 +1431,7 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
   B.Tmax = Tmax;
   if (B.base[n] <= 0) return;
   if (chain_has_tables(d, n)) {                 // joint-solve pass: the tables are there for the preconditioner anyway
-    launch_chain_batch(d, n, yin, xout, false, false, s);
+    launch_chain_batch(d, n, yin, xout, false, false, true, nullptr, s);      // (k_chol_extract_y prepared dp)
     return;
   }
   hipLaunchKernelGGL(k_chol_bwd_chain_batched, dim3(B.base[n]), dim3(CHAIN_THREADS), 0, s, B);
@@ -1432,7 +1442,7 @@ void launch_chol_solve_bwd(const CholSystem& cs, hipStream_t s) {
     launch_chain_tables(&cs, 1, s);
     const double* yin = cs.yv;
     double* xout = cs.dp;
-    launch_chain_batch(&cs, 1, &yin, &xout, false, false, s);
+    launch_chain_batch(&cs, 1, &yin, &xout, false, false, true, nullptr, s);
     return;
   }
   launch_chol_bwd_all(cs.S, cs.ld, cs.T, cs.Ld, cs.Winv, cs.yv, cs.dp, cs.status, cs.prof, s);

@@ -383,6 +383,7 @@ void HostGraph::join_batch(CholBatch* b, int slot) {
     old = batch;
     batch = b;
     batch_slot = slot;
+    topo_dirty = true;      // (the joint-solve buffers depend on the batch's setting: upload_new looks again)
   }
   if (old && old != b) old->detach(this);
   if (b) b->set_graph(slot, this);
@@ -390,6 +391,7 @@ void HostGraph::join_batch(CholBatch* b, int slot) {
 CholBatch::~CholBatch() {
   if (master) (void)hipStreamSynchronize(master);
   for (hipStream_t a : aux) if (a) (void)hipStreamSynchronize(a);
+  if (side) (void)hipStreamSynchronize(side);
   for (auto& e : part_exec) if (e) (void)hipGraphExecDestroy(e);
   for (HostGraph* g : graphs)
     if (g) { std::lock_guard<std::mutex> gl(g->mtx); if (g->batch == this) g->batch = nullptr; }
@@ -399,6 +401,9 @@ CholBatch::~CholBatch() {
   if (pass_exec) (void)hipGraphExecDestroy(pass_exec);
   if (d_Gs) (void)hipFree(d_Gs);
   if (ev_aux0) (void)hipEventDestroy(ev_aux0);
+  if (ev_side0) (void)hipEventDestroy(ev_side0);
+  if (ev_side1) (void)hipEventDestroy(ev_side1);
+  if (side) (void)hipStreamDestroy(side);
   for (hipEvent_t e : ev_aux1) if (e) (void)hipEventDestroy(e);
   for (hipStream_t a : aux) if (a) (void)hipStreamDestroy(a);
   if (master) (void)hipStreamDestroy(master);
@@ -530,7 +535,7 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
     if (rc == SLIDE_OK && joint && !batch_p3) rc = save_systems();      // (the batched assembly wrote S0 along with S)
     if (rc == SLIDE_OK && e0) (void)hipEventRecord(e0, master);
     if (rc == SLIDE_OK) rc = factor_all(e1);
-    if (rc == SLIDE_OK && joint) rc = enqueue_pcg_head(d_bufs);
+    if (rc == SLIDE_OK && joint) rc = enqueue_pcg_head(d_bufs, whole);
   }
   if (joint) {
     // the PCG iterations: whole pass = all of them inline; cut pass = part 10 (after the t_l exchange), part 11 / 12 (after the
@@ -539,11 +544,11 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
       const bool last = it == pcg_iters - 1;
       if (whole || (part == 10 && it == 0)) {
         if (!whole) launch_bcast(d_bufs, n, 9 * n_slots, master);
-        rc = enqueue_pcg_mid(d_bufs);
+        rc = enqueue_pcg_mid(d_bufs, whole);
       }
       if (rc == SLIDE_OK && (whole || (part == 11 && it == 0 && !last) || (part == 12 && last))) {
         if (!whole) launch_bcast(d_bufs, n, 2, master);
-        rc = enqueue_pcg_tail(d_bufs, last);
+        rc = enqueue_pcg_tail(d_bufs, last, whole);
       }
     }
   }
@@ -710,9 +715,15 @@ int CholBatch::factor_all(hipEvent_t after) {
 
 void CholBatch::set_pcg(int iters) {
   std::lock_guard<std::mutex> pl(pass_mtx);
-  std::lock_guard<std::mutex> lk(mtx);
-  pcg_iters = iters < 0 ? 0 : iters;
-  pass_dirty = true;
+  std::vector<HostGraph*> gs;
+  {
+    std::lock_guard<std::mutex> lk(mtx);
+    pcg_iters = iters < 0 ? 0 : iters;
+    pass_dirty = true;
+    gs.assign(graphs.begin(), graphs.end());
+  }
+  for (HostGraph* g : gs)              // the joined graphs (re)build their device view: the joint-solve buffers are allocated on demand
+    if (g) { std::lock_guard<std::mutex> gl(g->mtx); g->topo_dirty = true; }
 }
 // S -> S0 for every joined graph (the factorisation works in place; the joint solve multiplies with the original blocks)
 int CholBatch::save_systems() {
@@ -723,18 +734,33 @@ int CholBatch::save_systems() {
   }
   return SLIDE_OK;
 }
-int CholBatch::enqueue_pcg_head(double* const* d_bufs) {
+// w = S0 u on a side stream, beside t_l and its exchange (whole-pass graphs: a cut pass has the exchange outside its graphs)
+int CholBatch::fork_symv() {
+  if (!side) {
+    SL_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    SL_HIP(hipEventCreateWithFlags(&ev_side0, hipEventDisableTiming));
+    SL_HIP(hipEventCreateWithFlags(&ev_side1, hipEventDisableTiming));
+  }
+  SL_HIP(hipEventRecord(ev_side0, master));
+  SL_HIP(hipStreamWaitEvent(side, ev_side0, 0));
+  launch_pcg_symv(d_Gs, hG.data(), n, side);
+  SL_HIP(hipEventRecord(ev_side1, side));
+  return SLIDE_OK;
+}
+int CholBatch::enqueue_pcg_head(double* const* d_bufs, bool fork) {
   launch_pcg_init(d_Gs, hG.data(), n, master);
+  if (fork) { const int rc = fork_symv(); if (rc != SLIDE_OK) return rc; }
   launch_pcg_tl(d_Gs, hG.data(), n, d_bufs, PCG_VEC_U, master);
   launch_sum_bcast(d_bufs, n, 9 * hG[0].n_slots, master);
   return SLIDE_OK;
 }
-int CholBatch::enqueue_pcg_mid(double* const* d_bufs) {
-  launch_pcg_matvec_dots(d_Gs, hG.data(), n, d_bufs, master);
+int CholBatch::enqueue_pcg_mid(double* const* d_bufs, bool forked) {
+  if (forked) SL_HIP(hipStreamWaitEvent(master, ev_side1, 0));
+  launch_pcg_matvec_dots(d_Gs, hG.data(), n, d_bufs, !forked, master);
   launch_sum_bcast(d_bufs, n, 2, master);
   return SLIDE_OK;
 }
-int CholBatch::enqueue_pcg_tail(double* const* d_bufs, bool last) {
+int CholBatch::enqueue_pcg_tail(double* const* d_bufs, bool last, bool fork) {
   launch_pcg_update(d_Gs, hG.data(), n, d_bufs, master);
   if (last) {
     launch_pcg_finish(d_Gs, hG.data(), n, master);
@@ -742,10 +768,15 @@ int CholBatch::enqueue_pcg_tail(double* const* d_bufs, bool last) {
   }
   const double* in[CHOL_BATCH_HOST_MAX];
   double* out[CHOL_BATCH_HOST_MAX];
-  for (int i = 0; i < n; ++i) { in[i] = hG[i].pcg + (size_t)PCG_VEC_R * hG[i].T * NB; out[i] = hG[i].pcg + (size_t)PCG_VEC_Y * hG[i].T * NB; }
-  launch_chain_batch(sys.data(), n, in, out, true, true, master);
-  for (int i = 0; i < n; ++i) { in[i] = out[i]; out[i] = hG[i].pcg + (size_t)PCG_VEC_U * hG[i].T * NB; }
-  launch_chain_batch(sys.data(), n, in, out, false, true, master);
+  double* nxt[CHOL_BATCH_HOST_MAX];
+  for (int i = 0; i < n; ++i) {
+    in[i] = hG[i].pcg + (size_t)PCG_VEC_R * hG[i].T * NB; out[i] = hG[i].pcg + (size_t)PCG_VEC_Y * hG[i].T * NB;
+    nxt[i] = hG[i].pcg + (size_t)PCG_VEC_U * hG[i].T * NB;
+  }
+  launch_chain_batch(sys.data(), n, in, out, true, true, true, nxt, master);       // (y prepared by k_pcg_update; prepares u for the backward chain)
+  for (int i = 0; i < n; ++i) { in[i] = out[i]; out[i] = nxt[i]; }
+  launch_chain_batch(sys.data(), n, in, out, false, true, true, nullptr, master);
+  if (fork) { const int rc = fork_symv(); if (rc != SLIDE_OK) return rc; }
   launch_pcg_tl(d_Gs, hG.data(), n, d_bufs, PCG_VEC_U, master);
   launch_sum_bcast(d_bufs, n, 9 * hG[0].n_slots, master);
   return SLIDE_OK;
@@ -1010,14 +1041,7 @@ int HostGraph::upload_new() {
     const size_t ld = (size_t)(Tcap + 1) * NB;
     // S is rewritten by every Schur pass, so nothing is carried over; zero once so the never-written
     // strict upper tiles and the idle rows of the RHS tile hold finite values.
-    d_S.cap = 0;
-    if (d_S.d) { SL_HIP(hipFree(d_S.d)); d_S.d = nullptr; }
-    if (d_S.ensure(ld * (size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
-    d_S0.cap = 0;
-    if (d_S0.d) { SL_HIP(hipFree(d_S0.d)); d_S0.d = nullptr; }
-    if (d_S0.ensure(ld * (size_t)Tcap * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
-    if (d_L32.ensure((size_t)Tcap * (Tcap - 1) / 2 * NB * NB + 4, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
-    if (d_ctab.ensure((size_t)4 * Tcap * NB * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_S.ensure_exact(ld * (size_t)Tcap * NB, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_pcg.ensure((size_t)PCG_VEC_COUNT * Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_pcg_scal.ensure(8, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_Ld.ensure((size_t)Tcap * NB * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
@@ -1025,6 +1049,18 @@ int HostGraph::upload_new() {
     if (d_cctr.ensure((size_t)Tcap + 2, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_yv.ensure((size_t)Tcap * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_dp.ensure((size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+  }
+  // Buffers of the joint solve (the saved system, the f32 factor copy, the chain tables): only for graphs that take part in one —
+  // a streaming replica never pays for them (three more allocations of S's size at every growth step were 100 ms spikes there)
+  {
+    const bool want_joint = pcg_iters > 0 || (batch && batch->pcg() > 0);
+    if (want_joint && joint_Tcap != Tcap) {
+      const size_t ld = (size_t)(Tcap + 1) * NB;
+      if (d_S0.ensure_exact(ld * (size_t)Tcap * NB, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+      if (d_L32.ensure_exact((size_t)Tcap * (Tcap - 1) / 2 * NB * NB + 4, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+      if (d_ctab.ensure_exact((size_t)4 * Tcap * NB * NB, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+      joint_Tcap = Tcap;
+    }
   }
   // Profile of the reduced pose system at tile level.  reach(p) = the last pose coupled to pose p (a landmark both observe, a
   // relative-pose factor); block column c reaches the tile row of the farthest reach of its poses; the running maximum over c is
@@ -1225,6 +1261,7 @@ int HostGraph::set_shared(const int32_t* cls, const int64_t* idx, const int32_t*
 // the Schur complement, exact gradient): the fixed point is the joint optimum.
 void HostGraph::set_pcg(int iters) {
   pcg_iters = iters < 0 ? 0 : iters;
+  topo_dirty = true;                      // (the joint-solve buffers are allocated by upload_new on demand)
   for (auto& pg : phase_graph)            // the captured phase 1 depends on it
     if (pg.exec) { (void)hipGraphExecDestroy(pg.exec); pg.exec = nullptr; }
 }
@@ -1268,7 +1305,7 @@ int HostGraph::enqueue_phase(int phase, double* d_buf) {
       launch_shared_pack(G, 1, d_buf, s);
     }
   } else if (phase == 31) {          // after the exchange of t_l: w = S u, partial dots -> d_buf[0 .. 1]
-    launch_pcg_matvec_dots(d_Gself.d, &G, 1, &d_buf, s);
+    launch_pcg_matvec_dots(d_Gself.d, &G, 1, &d_buf, true, s);
   } else if (phase == 32 || phase == 33) {     // after the exchange of the dots: the updates; 32: next u, t_l -> d_buf; 33 (last): dp = x, t_l(dp) -> d_buf
     launch_pcg_update(d_Gself.d, &G, 1, &d_buf, s);
     if (phase == 33) {
@@ -1280,10 +1317,11 @@ int HostGraph::enqueue_phase(int phase, double* d_buf) {
       const CholSystem cs{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, d_L32.d, h_prof.data(), G.prof, G.first, d_ctab.d};
       const double* in = G.pcg + PCG_VEC_R * nT;
       double* out = G.pcg + PCG_VEC_Y * nT;
-      launch_chain_batch(&cs, 1, &in, &out, true, true, s);
+      double* nxt = G.pcg + PCG_VEC_U * nT;
+      launch_chain_batch(&cs, 1, &in, &out, true, true, true, &nxt, s);
       in = out;
-      out = G.pcg + PCG_VEC_U * nT;
-      launch_chain_batch(&cs, 1, &in, &out, false, true, s);
+      out = nxt;
+      launch_chain_batch(&cs, 1, &in, &out, false, true, true, nullptr, s);
       launch_pcg_tl(d_Gself.d, &G, 1, &d_buf, PCG_VEC_U, s);
     }
   } else {

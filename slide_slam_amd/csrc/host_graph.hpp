@@ -81,6 +81,20 @@ struct DevArr {
     cap = nc;
     return SLIDE_OK;
   }
+  // exactly n elements (the big per-system buffers: the caller's own growth policy, no rounding up on top of it); contents dropped
+  int ensure_exact(size_t n, hipStream_t s, bool zero_new = false) {
+    if (d) {
+      SL_HIP(hipStreamSynchronize(s));
+      SL_HIP(hipFree(d));
+      d = nullptr;
+      cap = 0;
+    }
+    if (n == 0) return SLIDE_OK;
+    SL_HIP(hipMalloc(&d, n * sizeof(T)));
+    cap = n;
+    if (zero_new) SL_HIP(hipMemsetAsync(d, 0, n * sizeof(T), s));
+    return SLIDE_OK;
+  }
   int upload(const T* h, size_t off, size_t count, hipStream_t s) {
     if (count == 0) return SLIDE_OK;
     if (UploadBatch::current && sizeof(T) % 4 == 0) return UploadBatch::current->add(d + off, h, count * sizeof(T));
@@ -161,9 +175,10 @@ class CholBatch {
   hipGraphExec_t pass_exec = nullptr;
   hipGraphExec_t part_exec[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // parts 0, 1, 2, 10, 11, 12
   int pcg_iters = 0;
-  int enqueue_pcg_head(double* const* d_bufs);                   // r = b, u = M^-1 b, t_l(u) packed + local sum
-  int enqueue_pcg_mid(double* const* d_bufs);                    // w = S u, partial dots + local sum
-  int enqueue_pcg_tail(double* const* d_bufs, bool last);        // alpha, beta, updates; then u = M^-1 r, t_l(u) | dp = x
+  int fork_symv();                                               // w = S0 u on `side`, joined by enqueue_pcg_mid
+  int enqueue_pcg_head(double* const* d_bufs, bool fork);                   // r = b, u = M^-1 b, t_l(u) packed + local sum
+  int enqueue_pcg_mid(double* const* d_bufs, bool forked);                    // w = S u, partial dots + local sum
+  int enqueue_pcg_tail(double* const* d_bufs, bool last, bool fork);        // alpha, beta, updates; then u = M^-1 r, t_l(u) | dp = x
   int save_systems();                                            // S -> S0 before the factorisation (joint solve only)
   std::vector<GraphDev> pass_G;
   std::vector<double*> pass_bufs;
@@ -181,6 +196,8 @@ class CholBatch {
   hipStream_t master = nullptr;
   hipStream_t aux[8] = {};               // further streams of the grouped factorisation (the groups' launches overlap on the GPU)
   hipEvent_t ev_aux0 = nullptr, ev_aux1[8] = {};
+  hipStream_t side = nullptr;            // the products of the joint solve beside the t_l exchange (whole-pass graphs)
+  hipEvent_t ev_side0 = nullptr, ev_side1 = nullptr;
   int* d_ctr = nullptr;
   int ctr_cap = 0;
   int factor_all(hipEvent_t after);      // the batched factor + solve of all joined systems, in one or two launch sequences
@@ -283,6 +300,7 @@ class HostGraph {
   DevArr<int> d_prof, d_first;                         // tile-level profile of the reduced system (graph_dev.hpp), host copies h_prof / h_first
   std::vector<int> h_prof, h_first;
   int prof_ver = 0;
+  int joint_Tcap = 0;                                   // Tcap the joint-solve buffers (S0, L32, ctab) are allocated for; 0 = not allocated
   bool force_dense = getenv("SLIDE_CHOL_DENSE") && getenv("SLIDE_CHOL_DENSE")[0] == '1';
   DevArr<double> d_ctab;                               // explicit inverses of the diagonal blocks (k_chain_tables)
   DevArr<float> d_L32;                                 // packed f32 copy of the factor: the joint solve's preconditioner streams this

@@ -40,7 +40,8 @@ struct CholSystem { double* S; int ld, T; double* Ld; double* Winv; double* yv; 
 void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps = nullptr);            // up to 8 systems, one launch per block column
 // one of the two triangular solves with the finished factors of up to 8 systems on arbitrary vectors (T * NB doubles each): out = L^-1 in
 // (fwd) or L^-T in (bwd); the preconditioner of the joint solve (pcg_kernels.hip)
-void launch_chain_batch(const CholSystem* d, int n, const double* const* in, double* const* out, bool fwd, bool f32, hipStream_t s);   // needs the tables (launch_chain_tables) of this factorisation
+void launch_chain_batch(const CholSystem* d, int n, const double* const* in, double* const* out, bool fwd, bool f32, bool prepared,
+                        double* const* next_out, hipStream_t s);   // needs the tables (launch_chain_tables) of this factorisation
 void launch_chain_tables(const CholSystem* d, int n, hipStream_t s);
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp, int* status, const int* prof, hipStream_t s);
 // marginal covariance of the pose whose first tangent row is row0 (Y: 6 * T * NB scratch doubles holding the six unit columns)
@@ -55,7 +56,8 @@ int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double
 enum { PCG_VEC_R = 0, PCG_VEC_U = 1, PCG_VEC_W = 2, PCG_VEC_P = 3, PCG_VEC_S = 4, PCG_VEC_X = 5, PCG_VEC_Y = 6, PCG_VEC_COUNT = 7 };
 void launch_pcg_init(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);
 void launch_pcg_tl(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, int vec, hipStream_t s);      // -> bufs[i][9 slot ..]
-void launch_pcg_matvec_dots(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s);     // bufs: summed t_l in, (gamma, delta) partials out
+void launch_pcg_symv(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);                                // w = S0 u (own blocks)
+void launch_pcg_matvec_dots(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, bool with_symv, hipStream_t s);     // bufs: summed t_l in, (gamma, delta) partials out; with_symv = false: launch_pcg_symv ran already
 void launch_pcg_update(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s);          // bufs: summed (gamma, delta) in
 void launch_pcg_finish(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);
 

@@ -303,11 +303,14 @@ __global__ void k_pcg_scalars(const GraphDev* __restrict__ Gs, PcgBufs B) {
   sc[5] = gamma;
 }
 
-// p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s
+// p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s.  Also prepares the forward substitution that follows (u = M^-1 r):
+// its output y pre-filled with the sentinel of the chained kernels (chol_kernels.hip BWD_SENT), its ticket counter (status[5]) cleared.
 __global__ __launch_bounds__(256) void k_pcg_update(const GraphDev* __restrict__ Gs) {
   const GraphDev G = Gs[blockIdx.z];
   const int i = blockIdx.x * 256 + threadIdx.x, nT = G.T * NB;
+  if (i == 0) G.status[5] = 0;
   if (i >= nT) return;
+  pvec(G, PV_Y)[i] = __longlong_as_double(0x7FF8DEADBEEF0BADll);
   const double alpha = G.pcg_scal[2], beta = G.pcg_scal[3];
   const double p = pvec(G, PV_U)[i] + beta * pvec(G, PV_P)[i];
   const double s = pvec(G, PV_W)[i] + beta * pvec(G, PV_S)[i];
@@ -351,13 +354,19 @@ void launch_pcg_tl(const GraphDev* d, const GraphDev* h, int n, double* const* b
   if (slots > 0) hipLaunchKernelGGL(k_pcg_tl, dim3(nblk(slots, 4), 1, n), dim3(256), 0, s, d, bufs_of(bufs, n), vec);
 }
 // after the exchange of t_l: w = S u (own block + cross-robot fill), then the two partial dot products into bufs[i][0..1]
-void launch_pcg_matvec_dots(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s) {
+// w = S0 u, every robot's own block: needs u only, not the exchanged t_l — a whole-pass graph runs it beside the exchange
+void launch_pcg_symv(const GraphDev* d, const GraphDev* h, int n, hipStream_t s) {
+  int nT, P, slots;
+  maxima(h, n, &nT, &P, &slots);
+  const int in_lds = (size_t)nT * sizeof(double) <= 48 * 1024 ? 1 : 0;      // (beyond that the vector is read from L2)
+  if (nT > 0) hipLaunchKernelGGL(k_pcg_symv, dim3(nT / NB, 1, n), dim3(256), in_lds ? (size_t)nT * sizeof(double) : 0, s, d, (int)PV_U, (int)PV_W, in_lds);
+}
+void launch_pcg_matvec_dots(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, bool with_symv, hipStream_t s) {
   int nT, P, slots;
   maxima(h, n, &nT, &P, &slots);
   const PcgBufs B = bufs_of(bufs, n);
   if (slots > 0) hipLaunchKernelGGL(k_pcg_c, dim3(nblk(9LL * slots, 128), 1, n), dim3(128), 0, s, d, B);
-  const int in_lds = (size_t)nT * sizeof(double) <= 48 * 1024 ? 1 : 0;      // (beyond that the vector is read from L2)
-  if (nT > 0) hipLaunchKernelGGL(k_pcg_symv, dim3(nT / NB, 1, n), dim3(256), in_lds ? (size_t)nT * sizeof(double) : 0, s, d, (int)PV_U, (int)PV_W, in_lds);
+  if (with_symv) launch_pcg_symv(d, h, n, s);
   if (P > 0 && slots > 0) hipLaunchKernelGGL(k_pcg_cross, dim3(nblk(P, 4), 1, n), dim3(256), 0, s, d, (int)PV_W);
   hipLaunchKernelGGL(k_pcg_dots, dim3(1, 1, n), dim3(256), 0, s, d, B);
 }

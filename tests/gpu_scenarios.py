@@ -174,6 +174,7 @@ def c5_stream(out, preset="C4", ticks=None, budget_ms=100.0):
                last_tick_ms=[float(v) for v in lat[-1]], over_budget=int((lat > budget_ms).sum()),
                n_pose=[st["n_pose"] for st in stats], chol_dim=[st["chol_dim"] for st in stats],
                rejected=[int(nd.graph.rejected_count()) for nd in nodes],
+               worst=[(int(i // R), int(i % R), float(lat.flat[i])) for i in np.argsort(lat, axis=None)[::-1][:6]],      # (tick, robot, ms)
                finite=bool(all(np.isfinite(p).all() for p in prev)))
     json.dump(res, open(out, "w"))
 

@@ -48,6 +48,7 @@ for tag, fs, ws, stats in (("bench", "pmc_f", "pmc_w", st), ("assoc", "apmc_f", 
                   "hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0}
             if short in stats:
                 js["rocprof_calls"], js["rocprof_avg_ns"] = stats[short]
+            js["profile"] = "dense" if "--dense-profile" in os.environ.get("BENCH_ARGS", "") else "structure"      # which tiles the solver touched
             if short == "k_chol_step_batched":
                 js["robots"], js["robots_per_launch"] = 8, 4
             json.dump(js, open(os.path.join(prof, f"{rnd}_pmc_traffic_{short}.json"), "w"), indent=1)
