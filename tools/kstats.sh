@@ -4,7 +4,7 @@ set -o pipefail
 OUT=gpurun_out/kstats
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu --no-parity ${BENCH_ARGS} > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu --no-parity --no-dense-leg ${BENCH_ARGS} > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
 python3 - <<'PY'
 import csv, glob
 f = glob.glob('gpurun_out/kstats/trace/**/*kernel_stats.csv', recursive=True)[0]
