@@ -1096,28 +1096,18 @@ __device__ __forceinline__ void tab_chain_body(TabLds& W, const double* __restri
     r0 = rin[c * NB + (FWD ? row : i)];
   }
   auto poll = [&](int j, int slot) {                   // the polling wave: block x_j -> xs[slot]
-    // FOUR loads in flight, re-issued as they come back: the value is seen a quarter of a round trip after it lands instead of
-    // (on average) half a round trip (the wave has nothing else outstanding, so the loads return in the order of issue)
     const int lane = tid - 256;
-    const double* p = xout + (size_t)j * NB + lane;
-    auto ld = [&]() { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    auto ok = [](double x) { return (unsigned long long)__double_as_longlong(x) != BWD_SENT; };
-    double v0 = ld(), v1 = ld(), v2 = ld(), v3 = ld(), v;
+    double v;
     int spins = 0;
     for (;;) {
-      if (ok(v0)) { v = v0; break; }
-      v0 = ld();
-      if (ok(v1)) { v = v1; break; }
-      v1 = ld();
-      if (ok(v2)) { v = v2; break; }
-      v2 = ld();
-      if (ok(v3)) { v = v3; break; }
-      v3 = ld();
-      if (++spins > (1 << 19)) {                       // exit condition every wave reaches: give up (seconds), flag the solve as failed
+      v = __hip_atomic_load(xout + (size_t)j * NB + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned long long)__double_as_longlong(v) != BWD_SENT) break;
+      if (++spins > (1 << 21)) {                       // exit condition every wave reaches: give up (seconds), flag the solve as failed
         v = __builtin_nan("");
         atomicOr(&status[1], 2);
         break;
       }
+      __builtin_amdgcn_s_sleep(1);
     }
     xs[slot][lane] = v;
   };
