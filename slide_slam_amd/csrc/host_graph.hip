@@ -400,6 +400,7 @@ CholBatch::~CholBatch() {
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (pass_exec) (void)hipGraphExecDestroy(pass_exec);
   if (d_Gs) (void)hipFree(d_Gs);
+  if (d_status_all) (void)hipFree(d_status_all);
   if (ev_aux0) (void)hipEventDestroy(ev_aux0);
   if (ev_side0) (void)hipEventDestroy(ev_side0);
   if (ev_side1) (void)hipEventDestroy(ev_side1);
@@ -496,6 +497,7 @@ int CholBatch::prepare_pass() {
     SL_HIP(hipStreamSynchronize(master));
   }
   if (!d_Gs) SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_Gs), CHOL_BATCH_HOST_MAX * sizeof(GraphDev)));
+  if (!d_status_all) SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_status_all), CHOL_BATCH_HOST_MAX * 8 * sizeof(int)));
   SL_HIP(hipMemcpy(d_Gs, hG.data(), n * sizeof(GraphDev), hipMemcpyHostToDevice));
   return SLIDE_OK;
 }
@@ -523,6 +525,7 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
   const bool whole = part < 0;
   const bool joint = pcg_iters > 0 && n_slots > 0;       // PCG over the robots' coupled systems instead of the plain block solves
   if (whole || part == 0) {
+    launch_status_clear(d_Gs, n, master);      // (a kernel node: a captured hipMemsetAsync did not clear on replay, DESIGN §4 finding 6)
     each(0);
     if (rc == SLIDE_OK) launch_sum_bcast(d_bufs, n, 54 * n_slots, master);
   }
@@ -560,6 +563,7 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
   if (whole || part == 2) {
     if (rc == SLIDE_OK && !whole) launch_bcast(d_bufs, n, 9 * n_slots, master);
     if (rc == SLIDE_OK) each(2);
+    if (rc == SLIDE_OK) launch_status_gather(d_Gs, n, d_status_all, master);
   }
   return rc;
 }
@@ -601,7 +605,6 @@ int CholBatch::profile_pass(double* const* d_bufs, double* ms_steps, int* n_laun
     if (rc != SLIDE_OK) return rc;
     g->G.relin_thr = 0.0;
     SL_HIP(hipStreamSynchronize(g->stream));
-    SL_HIP(hipMemsetAsync(g->G.status, 0, 8 * sizeof(int), master));
   }
   int rc = prepare_pass();
   if (rc != SLIDE_OK) return rc;
@@ -648,7 +651,6 @@ int CholBatch::begin_pass(double* const* d_bufs, bool* same) {
     g->G.relin_thr = 0.0;
     if (g->G.n_slots != graphs[0]->G.n_slots) { g_last_error = "batched pass: the graphs disagree on the shared slots"; return SLIDE_ERR_INVALID; }
     SL_HIP(hipStreamSynchronize(g->stream));                       // (uploads of a changed graph; idle otherwise)
-    SL_HIP(hipMemsetAsync(g->G.status, 0, 8 * sizeof(int), master));
     *same = *same && std::memcmp(&pass_G[i], &g->G, sizeof(GraphDev)) == 0 && pass_bufs[i] == d_bufs[i];
   }
   if (!*same) {
@@ -665,7 +667,7 @@ int CholBatch::begin_pass(double* const* d_bufs, bool* same) {
 }
 int CholBatch::end_pass() {
   int st[CHOL_BATCH_HOST_MAX][8];
-  for (int i = 0; i < n; ++i) SL_HIP(hipMemcpyAsync(st[i], graphs[i]->G.status, 8 * sizeof(int), hipMemcpyDeviceToHost, master));
+  SL_HIP(hipMemcpyAsync(st, d_status_all, (size_t)n * 8 * sizeof(int), hipMemcpyDeviceToHost, master));      // (gathered by the pass's last node)
   SL_HIP(hipStreamSynchronize(master));
   SL_HIP(hipGetLastError());
   for (int i = 0; i < n; ++i) {

@@ -54,6 +54,8 @@ int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double
 // pcg_kernels.hip — joint Gauss-Newton step of the robots of a GPU (and, through the caller's exchanges, of the job): PCG on the
 // global reduced pose system with the robots' own factors as preconditioner.  d: device array of the n graphs' views, h: host copy.
 enum { PCG_VEC_R = 0, PCG_VEC_U = 1, PCG_VEC_W = 2, PCG_VEC_P = 3, PCG_VEC_S = 4, PCG_VEC_X = 5, PCG_VEC_Y = 6, PCG_VEC_COUNT = 7 };
+void launch_status_clear(const GraphDev* d, int n, hipStream_t s);             // status[0..7] = 0 for every graph of the batch
+void launch_status_gather(const GraphDev* d, int n, int* out, hipStream_t s);  // out[8 i ..] = graph i's status words
 void launch_pcg_init(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);
 void launch_pcg_tl(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, int vec, hipStream_t s);      // -> bufs[i][9 slot ..]
 void launch_pcg_symv(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);                                // w = S0 u (own blocks)

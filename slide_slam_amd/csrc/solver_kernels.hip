@@ -819,6 +819,21 @@ void launch_sum_bcast(double* const* bufs, int n, int count, hipStream_t s) {
   hipLaunchKernelGGL(k_sum_bcast, dim3((count + 255) / 256), dim3(256), 0, s, A, count);
 }
 
+// status words of the joined graphs: cleared by the first node of a batched pass, gathered into one array by its last (one device ->
+// host copy per pass instead of one per robot)
+__global__ void k_status_clear(const GraphDev* __restrict__ Gs) {
+  if (threadIdx.x < 8) Gs[blockIdx.x].status[threadIdx.x] = 0;
+}
+__global__ void k_status_gather(const GraphDev* __restrict__ Gs, int* __restrict__ out) {
+  if (threadIdx.x < 8) out[8 * blockIdx.x + threadIdx.x] = Gs[blockIdx.x].status[threadIdx.x];
+}
+void launch_status_clear(const GraphDev* d, int n, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_status_clear, dim3(n), dim3(64), 0, s, d);
+}
+void launch_status_gather(const GraphDev* d, int n, int* out, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_status_gather, dim3(n), dim3(64), 0, s, d, out);
+}
+
 // buf[0] -> buf[1 .. n-1]: hands the result of a cross-GPU all-reduce (done on buf[0]) to the other robots of this GPU
 __global__ __launch_bounds__(256) void k_bcast(SumBcastArgs A, int count) {
   const int i = blockIdx.x * 256 + threadIdx.x;
