@@ -86,11 +86,12 @@ struct GraphDev {
   const int* prof;   // T : prof[c] = last tile row of block column c inside the profile (monotone in c, >= c); null = dense
   const int* first;  // T : first[r] = first block column whose profile reaches block row r
   int prof_ver;      // bumped whenever the arrays change (launch plans captured in hipGraphs depend on their values)
+  int schur_split;   // workgroups per pose column of the Schur assembly: 1 on a narrow profile (the strip is one or two chunks), else 2
   // ---- joint solve over several robots (pcg_kernels.hip) --------------------------------------
   double* S0;        // copy of S (lower triangle + padding) taken before the factorisation overwrites it: the symmetric products
   int save_S0;       // 1: the Schur assembly writes every block to S0 as well (batched passes with the joint solve; else a device copy)
   double* pcg;       // 7 vectors of T*NB doubles: r, u, w, p, s, x, y
-  double* lm_c;      // 9 L  cross-robot part of sum_b W_b^T u_b per shared landmark (zero for the others)
+  const int* lm_slot; // L   shared slot of a landmark or -1: the cross-robot part of the products reads the exchanged sums through it
   double* pcg_scal;  // 8    gamma_old, alpha_old, alpha, beta, first gamma, last gamma
   int* status;       // [0] not-SPD flag (landmark), [1] not-SPD flag (chol), [2] #relinearised
   // ---- parameters ------------------------------------------------------------------------

@@ -1005,8 +1005,6 @@ int HostGraph::upload_new() {
   if (d_lm_g.ensure(std::max<size_t>(9 * Ln, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_lm_Hacc.ensure(std::max<size_t>(54 * Ln, 1), 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_lm_t.ensure(std::max<size_t>(9 * Ln, 1), 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
-  if (d_lm_c.ensure(std::max<size_t>(9 * Ln, 1), 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
-  if (Ln) SL_HIP(hipMemsetAsync(d_lm_c.d, 0, 9 * Ln * sizeof(double), s));      // (only the shared landmarks are ever written)
   if (d_pose_H.ensure(std::max<size_t>(36 * Pn, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_pose_g.ensure(std::max<size_t>(6 * Pn, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   std::vector<int> ptr, val;
@@ -1141,11 +1139,27 @@ int HostGraph::upload_new() {
   G.lm_Hinv = d_lm_Hinv.d; G.lm_g = d_lm_g.d; G.pose_H = d_pose_H.d; G.pose_g = d_pose_g.d;
   G.S = d_S.d; G.ld = (Tcap + 1) * NB; G.T = T; G.Ld = d_Ld.d; G.Winv = d_Winv.d; G.yv = d_yv.d; G.dp = d_dp.d; G.chol_ctr = d_cctr.d;
   G.prof = d_prof.d; G.first = d_first.d; G.prof_ver = prof_ver;
-  G.S0 = d_S0.d; G.save_S0 = 0; G.pcg = d_pcg.d; G.lm_c = d_lm_c.d; G.pcg_scal = d_pcg_scal.d;
+  {
+    int band = 0;
+    for (int c = 0; c < (int)h_prof.size(); ++c) band = std::max(band, h_prof[c] - c);
+    G.schur_split = band <= 8 ? 1 : 2;
+  }
+  G.S0 = d_S0.d; G.save_S0 = 0; G.pcg = d_pcg.d; G.pcg_scal = d_pcg_scal.d;
   G.status = d_status.d;
   G.chart = P.pose_chart;
   G.bearing_sigma = P.bearing_range_sigma; G.cyl_sigma = P.cylinder_sigma; G.numdiff_delta = P.numdiff_delta;
   launch_pose_adj(G, s);             // the topology changed: rebuild the pose adjacency of the Schur assembly
+  return sync_lm_slot();
+}
+int HostGraph::sync_lm_slot() {
+  const size_t Ln = h_lm_type.size();
+  std::vector<int> slot(std::max<size_t>(Ln, 1), -1);
+  for (size_t i = 0; i < h_sh_lid.size(); ++i)
+    if (h_sh_lid[i] >= 0 && (size_t)h_sh_lid[i] < Ln) slot[h_sh_lid[i]] = (int)i;
+  if (d_lm_slot.ensure(slot.size(), 0, stream) != SLIDE_OK) return SLIDE_ERR_HIP;
+  SL_HIP(hipMemcpyAsync(d_lm_slot.d, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+  SL_HIP(hipStreamSynchronize(stream));      // (a pageable temporary)
+  G.lm_slot = d_lm_slot.d;
   return SLIDE_OK;
 }
 
@@ -1248,10 +1262,9 @@ int HostGraph::set_shared(const int32_t* cls, const int64_t* idx, const int32_t*
   if (d_sh_owner.ensure(std::max(n_slots, 1), 0, stream) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_sh_lid.upload(h_sh_lid.data(), 0, n_slots, stream) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_sh_owner.upload(h_sh_owner.data(), 0, n_slots, stream) != SLIDE_OK) return SLIDE_ERR_HIP;
-  if (G.L) SL_HIP(hipMemsetAsync(d_lm_c.d, 0, 9 * (size_t)G.L * sizeof(double), stream));      // the shared set changed
   SL_HIP(hipStreamSynchronize(stream));
   G.n_slots = n_slots; G.sh_lid = d_sh_lid.d; G.sh_owner = d_sh_owner.d;
-  return SLIDE_OK;
+  return sync_lm_slot();
 }
 
 // Distributed Gauss-Newton pass = phase 0, all-reduce(buf: 54/slot), phase 1, all-reduce(buf: 9/slot), phase 2.

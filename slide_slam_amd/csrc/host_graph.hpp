@@ -297,7 +297,9 @@ class HostGraph {
   DevArr<int> d_sh_lid, d_sh_owner;
   std::vector<int> h_sh_lid, h_sh_owner;
   DevArr<double> d_S, d_Ld, d_Winv, d_yv, d_dp;
-  DevArr<double> d_S0, d_pcg, d_lm_c, d_pcg_scal;      // joint solve (pcg_kernels.hip)
+  DevArr<double> d_S0, d_pcg, d_pcg_scal;              // joint solve (pcg_kernels.hip)
+  DevArr<int> d_lm_slot;                               // landmark -> shared slot or -1
+  int sync_lm_slot();                                  // rebuilds it from h_sh_lid (upload_new, set_shared)
   DevArr<int> d_prof, d_first;                         // tile-level profile of the reduced system (graph_dev.hpp), host copies h_prof / h_first
   std::vector<int> h_prof, h_first;
   int prof_ver = 0;

@@ -90,17 +90,6 @@ __global__ __launch_bounds__(256) void k_pcg_tl(const GraphDev* __restrict__ Gs,
   }
 }
 
-// after the exchange: c_l = (sum over all robots of t_l) - own t_l, for the shared landmarks this robot observes
-__global__ void k_pcg_c(const GraphDev* __restrict__ Gs, PcgBufs B) {
-  const GraphDev G = Gs[blockIdx.z];
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int sidx = t / 9, k = t - 9 * sidx;
-  if (sidx >= G.n_slots) return;
-  const int l = G.sh_lid[sidx];
-  if (l < 0) return;
-  G.lm_c[9 * (size_t)l + k] = B.p[blockIdx.z][t] - G.lm_t[9 * (size_t)l + k];
-}
-
 // out = S0 * in for the symmetric S0 held as its lower triangle (column-major, leading dimension ld): one workgroup per block row
 // i of 64: tiles (i, j <= i) as they lie, tiles (j > i, i) transposed.  Deterministic (no atomics): every block row is summed by
 // one workgroup in a fixed order.
@@ -208,9 +197,9 @@ __global__ __launch_bounds__(256) void k_pcg_symv(const GraphDev* __restrict__ G
   }
 }
 
-// w_p -= sum_{f at pose p} F_f c_lm(f): the cross-robot Schur fill through the shared landmarks (c = 0 for the others).
-// One wave per pose, lanes over its landmark factors.
-__global__ __launch_bounds__(256) void k_pcg_cross(const GraphDev* __restrict__ Gs, int vout) {
+// w_p -= sum_{f at pose p} F_f c_lm(f): the cross-robot Schur fill through the shared landmarks, c_l = (sum over all robots of t_l,
+// from the exchange buffer) - own t_l; a landmark without a slot contributes nothing.  One wave per pose, lanes over its landmark factors.
+__global__ __launch_bounds__(256) void k_pcg_cross(const GraphDev* __restrict__ Gs, PcgBufs B, int vout) {
   const GraphDev G = Gs[blockIdx.z];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int p = blockIdx.x * 4 + wave;
@@ -220,17 +209,15 @@ __global__ __launch_bounds__(256) void k_pcg_cross(const GraphDev* __restrict__ 
   for (int a = 0; a < 6; ++a) y[a] = 0.0;
   for (int q = G.pose_ptr[p] + lane; q < G.pose_ptr[p + 1]; q += 64) {
     const int l = G.pose_lms[q];
+    const int sl = G.lm_slot[l];
+    if (sl < 0) continue;
     const long long ed = G.pose_ed[q];
     const int D = (int)(ed & 15);
-    const double* c = G.lm_c + 9 * (size_t)l;
+    const double* tsum = B.p[blockIdx.z] + 9 * (size_t)sl;
+    const double* town = G.lm_t + 9 * (size_t)l;
     double cc[9];
-    bool any = false;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      cc[k] = k < D ? c[k] : 0.0;
-      any = any || cc[k] != 0.0;
-    }
-    if (!any) continue;
+    for (int k = 0; k < 9; ++k) cc[k] = k < D ? tsum[k] - town[k] : 0.0;
     const double* F = G.ebuf + (ed >> 4) + 6 * D;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
@@ -365,9 +352,8 @@ void launch_pcg_matvec_dots(const GraphDev* d, const GraphDev* h, int n, double*
   int nT, P, slots;
   maxima(h, n, &nT, &P, &slots);
   const PcgBufs B = bufs_of(bufs, n);
-  if (slots > 0) hipLaunchKernelGGL(k_pcg_c, dim3(nblk(9LL * slots, 128), 1, n), dim3(128), 0, s, d, B);
   if (with_symv) launch_pcg_symv(d, h, n, s);
-  if (P > 0 && slots > 0) hipLaunchKernelGGL(k_pcg_cross, dim3(nblk(P, 4), 1, n), dim3(256), 0, s, d, (int)PV_W);
+  if (P > 0 && slots > 0) hipLaunchKernelGGL(k_pcg_cross, dim3(nblk(P, 4), 1, n), dim3(256), 0, s, d, B, (int)PV_W);
   hipLaunchKernelGGL(k_pcg_dots, dim3(1, 1, n), dim3(256), 0, s, d, B);
 }
 // after the exchange of (gamma, delta): alpha, beta, the four vector updates

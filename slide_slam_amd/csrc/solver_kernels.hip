@@ -1051,7 +1051,8 @@ void launch_pose(const GraphDev& G, hipStream_t s) {
 }
 void launch_schur(const GraphDev& G, hipStream_t s) {
   if (G.P == 0) return;
-  static const int split = getenv("SLIDE_SCHUR_SPLIT") ? atoi(getenv("SLIDE_SCHUR_SPLIT")) : 2;     // diagnostic
+  static const int env_split = getenv("SLIDE_SCHUR_SPLIT") ? atoi(getenv("SLIDE_SCHUR_SPLIT")) : 0;     // diagnostic
+  const int split = env_split > 0 ? env_split : (G.schur_split > 0 ? G.schur_split : 2);
   hipLaunchKernelGGL(k_schur, dim3(G.P, split > 0 ? split : 1), dim3(256), (size_t)((G.L + 7) / 8 * 8) * sizeof(short) + (size_t)((G.P + 31) / 32 + 1) * sizeof(unsigned), s, G);
   const long long NT = (long long)G.T * NB;
   const long long tot = NT + (NT - 6LL * G.P) * NT;
@@ -1093,7 +1094,10 @@ void launch_phase3_batched(const GraphDev* d, const GraphDev* h, int n, double* 
   if (L > 0) hipLaunchKernelGGL(k_landmark_b<2>, dim3(blocks_for(L, 4), 1, n), dim3(256), 0, s, d);
   if (P > 0) {
     hipLaunchKernelGGL(k_pose_b, dim3(blocks_for(P, 4), 1, n), dim3(256), 0, s, d);
-    static const int split = getenv("SLIDE_SCHUR_SPLIT") ? atoi(getenv("SLIDE_SCHUR_SPLIT")) : 2;
+    static const int env_split = getenv("SLIDE_SCHUR_SPLIT") ? atoi(getenv("SLIDE_SCHUR_SPLIT")) : 0;
+    int split = 1;
+    for (int i = 0; i < n; ++i) split = std::max(split, h[i].schur_split > 0 ? h[i].schur_split : 2);
+    if (env_split > 0) split = env_split;
     hipLaunchKernelGGL(k_schur_b, dim3(P, split > 0 ? split : 1, n), dim3(256),
                        (size_t)((L + 7) / 8 * 8) * sizeof(short) + (size_t)((P + 31) / 32 + 1) * sizeof(unsigned), s, d);
     hipLaunchKernelGGL(k_pad_rhs_b, dim3(blocks_for(pad, 256), 1, n), dim3(256), 0, s, d);
