@@ -753,17 +753,19 @@ int CholBatch::enqueue_pcg_head(double* const* d_bufs, bool fork) {
   launch_pcg_init(d_Gs, hG.data(), n, master);
   if (fork) { const int rc = fork_symv(); if (rc != SLIDE_OK) return rc; }
   launch_pcg_tl(d_Gs, hG.data(), n, d_bufs, PCG_VEC_U, master);
-  launch_sum_bcast(d_bufs, n, 9 * hG[0].n_slots, master);
+  if (!fork) launch_sum_bcast(d_bufs, n, 9 * hG[0].n_slots, master);      // (a whole-pass graph: the consumers sum the robots' buffers themselves)
   return SLIDE_OK;
 }
-int CholBatch::enqueue_pcg_mid(double* const* d_bufs, bool forked) {
-  if (forked) SL_HIP(hipStreamWaitEvent(master, ev_side1, 0));
-  launch_pcg_matvec_dots(d_Gs, hG.data(), n, d_bufs, !forked, master);
-  launch_sum_bcast(d_bufs, n, 2, master);
+// whole = a whole-pass graph (every robot of the job on this GPU): the products ran on the side stream, and the kernels that consume
+// the exchanged t_l / dot products sum the n robots' buffers themselves (k_sum_bcast's order) instead of a sum node before them
+int CholBatch::enqueue_pcg_mid(double* const* d_bufs, bool whole) {
+  if (whole) SL_HIP(hipStreamWaitEvent(master, ev_side1, 0));
+  launch_pcg_matvec_dots(d_Gs, hG.data(), n, d_bufs, !whole, whole ? n : 1, master);
+  if (!whole) launch_sum_bcast(d_bufs, n, 2, master);
   return SLIDE_OK;
 }
 int CholBatch::enqueue_pcg_tail(double* const* d_bufs, bool last, bool fork) {
-  launch_pcg_update(d_Gs, hG.data(), n, d_bufs, master);
+  launch_pcg_update(d_Gs, hG.data(), n, d_bufs, fork ? n : 1, master);
   if (last) {
     launch_pcg_finish(d_Gs, hG.data(), n, master);
     return SLIDE_OK;
@@ -780,7 +782,7 @@ int CholBatch::enqueue_pcg_tail(double* const* d_bufs, bool last, bool fork) {
   launch_chain_batch(sys.data(), n, in, out, false, true, true, nullptr, master);
   if (fork) { const int rc = fork_symv(); if (rc != SLIDE_OK) return rc; }
   launch_pcg_tl(d_Gs, hG.data(), n, d_bufs, PCG_VEC_U, master);
-  launch_sum_bcast(d_bufs, n, 9 * hG[0].n_slots, master);
+  if (!fork) launch_sum_bcast(d_bufs, n, 9 * hG[0].n_slots, master);
   return SLIDE_OK;
 }
 
@@ -1320,9 +1322,9 @@ int HostGraph::enqueue_phase(int phase, double* d_buf) {
       launch_shared_pack(G, 1, d_buf, s);
     }
   } else if (phase == 31) {          // after the exchange of t_l: w = S u, partial dots -> d_buf[0 .. 1]
-    launch_pcg_matvec_dots(d_Gself.d, &G, 1, &d_buf, true, s);
+    launch_pcg_matvec_dots(d_Gself.d, &G, 1, &d_buf, true, 1, s);
   } else if (phase == 32 || phase == 33) {     // after the exchange of the dots: the updates; 32: next u, t_l -> d_buf; 33 (last): dp = x, t_l(dp) -> d_buf
-    launch_pcg_update(d_Gself.d, &G, 1, &d_buf, s);
+    launch_pcg_update(d_Gself.d, &G, 1, &d_buf, 1, s);
     if (phase == 33) {
       launch_pcg_finish(d_Gself.d, &G, 1, s);
       launch_backsub(G, 1, s);

@@ -59,8 +59,8 @@ void launch_status_gather(const GraphDev* d, int n, int* out, hipStream_t s);  /
 void launch_pcg_init(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);
 void launch_pcg_tl(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, int vec, hipStream_t s);      // -> bufs[i][9 slot ..]
 void launch_pcg_symv(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);                                // w = S0 u (own blocks)
-void launch_pcg_matvec_dots(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, bool with_symv, hipStream_t s);     // bufs: summed t_l in, (gamma, delta) partials out; with_symv = false: launch_pcg_symv ran already
-void launch_pcg_update(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s);          // bufs: summed (gamma, delta) in
+void launch_pcg_matvec_dots(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, bool with_symv, int nsum, hipStream_t s);     // bufs: summed t_l in, (gamma, delta) partials out; with_symv = false: launch_pcg_symv ran already
+void launch_pcg_update(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, int nsum, hipStream_t s);          // bufs: summed (gamma, delta) in
 void launch_pcg_finish(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);
 
 // assoc_kernels.hip

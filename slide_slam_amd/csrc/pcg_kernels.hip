@@ -199,7 +199,9 @@ __global__ __launch_bounds__(256) void k_pcg_symv(const GraphDev* __restrict__ G
 
 // w_p -= sum_{f at pose p} F_f c_lm(f): the cross-robot Schur fill through the shared landmarks, c_l = (sum over all robots of t_l,
 // from the exchange buffer) - own t_l; a landmark without a slot contributes nothing.  One wave per pose, lanes over its landmark factors.
-__global__ __launch_bounds__(256) void k_pcg_cross(const GraphDev* __restrict__ Gs, PcgBufs B, int vout) {
+// nsum > 1 (whole-pass graphs of one GPU): the exchange buffers of the nsum robots still hold their own t_l — the sum is taken
+// here, in the order k_sum_bcast takes it (same arithmetic); nsum = 1: the buffer holds the all-reduced sum already.
+__global__ __launch_bounds__(256) void k_pcg_cross(const GraphDev* __restrict__ Gs, PcgBufs B, int vout, int nsum) {
   const GraphDev G = Gs[blockIdx.z];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int p = blockIdx.x * 4 + wave;
@@ -213,11 +215,23 @@ __global__ __launch_bounds__(256) void k_pcg_cross(const GraphDev* __restrict__ 
     if (sl < 0) continue;
     const long long ed = G.pose_ed[q];
     const int D = (int)(ed & 15);
-    const double* tsum = B.p[blockIdx.z] + 9 * (size_t)sl;
     const double* town = G.lm_t + 9 * (size_t)l;
     double cc[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) cc[k] = k < D ? tsum[k] - town[k] : 0.0;
+    for (int k = 0; k < 9; ++k) cc[k] = 0.0;
+    if (nsum > 1) {
+      for (int r = 0; r < nsum; ++r) {
+        const double* tr = B.p[r] + 9 * (size_t)sl;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) cc[k] += k < D ? tr[k] : 0.0;
+      }
+    } else {
+      const double* tsum = B.p[blockIdx.z] + 9 * (size_t)sl;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cc[k] = k < D ? tsum[k] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cc[k] = k < D ? cc[k] - town[k] : 0.0;
     const double* F = G.ebuf + (ed >> 4) + 6 * D;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
@@ -267,10 +281,14 @@ __global__ __launch_bounds__(256) void k_pcg_dots(const GraphDev* __restrict__ G
 }
 
 // alpha, beta of this iteration from the all-reduced (gamma, delta) in the exchange buffer; every robot computes the same numbers
-__global__ void k_pcg_scalars(const GraphDev* __restrict__ Gs, PcgBufs B) {
+__global__ void k_pcg_scalars(const GraphDev* __restrict__ Gs, PcgBufs B, int nsum) {
   const GraphDev G = Gs[blockIdx.x];
   if (threadIdx.x != 0) return;
-  const double gamma = B.p[blockIdx.x][0], delta = B.p[blockIdx.x][1];
+  double gamma = B.p[blockIdx.x][0], delta = B.p[blockIdx.x][1];
+  if (nsum > 1) {              // the partial dot products of the nsum robots of this GPU, summed in k_sum_bcast's order
+    gamma = 0.0; delta = 0.0;
+    for (int r = 0; r < nsum; ++r) { gamma += B.p[r][0]; delta += B.p[r][1]; }
+  }
   double* sc = G.pcg_scal;
   const double gamma_old = sc[0], alpha_old = sc[1];
   double beta = 0.0, alpha;
@@ -348,19 +366,19 @@ void launch_pcg_symv(const GraphDev* d, const GraphDev* h, int n, hipStream_t s)
   const int in_lds = (size_t)nT * sizeof(double) <= 48 * 1024 ? 1 : 0;      // (beyond that the vector is read from L2)
   if (nT > 0) hipLaunchKernelGGL(k_pcg_symv, dim3(nT / NB, 1, n), dim3(256), in_lds ? (size_t)nT * sizeof(double) : 0, s, d, (int)PV_U, (int)PV_W, in_lds);
 }
-void launch_pcg_matvec_dots(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, bool with_symv, hipStream_t s) {
+void launch_pcg_matvec_dots(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, bool with_symv, int nsum, hipStream_t s) {
   int nT, P, slots;
   maxima(h, n, &nT, &P, &slots);
   const PcgBufs B = bufs_of(bufs, n);
   if (with_symv) launch_pcg_symv(d, h, n, s);
-  if (P > 0 && slots > 0) hipLaunchKernelGGL(k_pcg_cross, dim3(nblk(P, 4), 1, n), dim3(256), 0, s, d, B, (int)PV_W);
+  if (P > 0 && slots > 0) hipLaunchKernelGGL(k_pcg_cross, dim3(nblk(P, 4), 1, n), dim3(256), 0, s, d, B, (int)PV_W, nsum);
   hipLaunchKernelGGL(k_pcg_dots, dim3(1, 1, n), dim3(256), 0, s, d, B);
 }
 // after the exchange of (gamma, delta): alpha, beta, the four vector updates
-void launch_pcg_update(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s) {
+void launch_pcg_update(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, int nsum, hipStream_t s) {
   int nT, P, slots;
   maxima(h, n, &nT, &P, &slots);
-  hipLaunchKernelGGL(k_pcg_scalars, dim3(n), dim3(64), 0, s, d, bufs_of(bufs, n));
+  hipLaunchKernelGGL(k_pcg_scalars, dim3(n), dim3(64), 0, s, d, bufs_of(bufs, n), nsum);
   if (nT > 0) hipLaunchKernelGGL(k_pcg_update, dim3(nblk(nT, 256), 1, n), dim3(256), 0, s, d);
 }
 void launch_pcg_finish(const GraphDev* d, const GraphDev* h, int n, hipStream_t s) {
