@@ -753,14 +753,15 @@ int CholBatch::enqueue_pcg_head(double* const* d_bufs, bool fork) {
   launch_pcg_init(d_Gs, hG.data(), n, master);
   if (fork) { const int rc = fork_symv(); if (rc != SLIDE_OK) return rc; }
   launch_pcg_tl(d_Gs, hG.data(), n, d_bufs, PCG_VEC_U, master);
-  if (!fork) launch_sum_bcast(d_bufs, n, 9 * hG[0].n_slots, master);      // (a whole-pass graph: the consumers sum the robots' buffers themselves)
+  launch_sum_bcast(d_bufs, n, 9 * hG[0].n_slots, master);
   return SLIDE_OK;
 }
-// whole = a whole-pass graph (every robot of the job on this GPU): the products ran on the side stream, and the kernels that consume
-// the exchanged t_l / dot products sum the n robots' buffers themselves (k_sum_bcast's order) instead of a sum node before them
+// whole = a whole-pass graph (every robot of the job on this GPU): the products ran on the side stream, and k_pcg_scalars sums the
+// n robots' partial dot products itself (k_sum_bcast's order) instead of a sum node before it.  (The same for t_l inside
+// k_pcg_cross was slower than the sum node: 35 against 25 + 5 us — scattered reads of eight buffers.)
 int CholBatch::enqueue_pcg_mid(double* const* d_bufs, bool whole) {
   if (whole) SL_HIP(hipStreamWaitEvent(master, ev_side1, 0));
-  launch_pcg_matvec_dots(d_Gs, hG.data(), n, d_bufs, !whole, whole ? n : 1, master);
+  launch_pcg_matvec_dots(d_Gs, hG.data(), n, d_bufs, !whole, 1, master);
   if (!whole) launch_sum_bcast(d_bufs, n, 2, master);
   return SLIDE_OK;
 }
@@ -782,7 +783,7 @@ int CholBatch::enqueue_pcg_tail(double* const* d_bufs, bool last, bool fork) {
   launch_chain_batch(sys.data(), n, in, out, false, true, true, nullptr, master);
   if (fork) { const int rc = fork_symv(); if (rc != SLIDE_OK) return rc; }
   launch_pcg_tl(d_Gs, hG.data(), n, d_bufs, PCG_VEC_U, master);
-  if (!fork) launch_sum_bcast(d_bufs, n, 9 * hG[0].n_slots, master);
+  launch_sum_bcast(d_bufs, n, 9 * hG[0].n_slots, master);
   return SLIDE_OK;
 }
 

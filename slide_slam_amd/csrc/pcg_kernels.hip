@@ -220,10 +220,19 @@ __global__ __launch_bounds__(256) void k_pcg_cross(const GraphDev* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 9; ++k) cc[k] = 0.0;
     if (nsum > 1) {
-      for (int r = 0; r < nsum; ++r) {
-        const double* tr = B.p[r] + 9 * (size_t)sl;
+      // all loads of one component first (independent), then its sum in buffer order
 #pragma unroll
-        for (int k = 0; k < 9; ++k) cc[k] += k < D ? tr[k] : 0.0;
+      for (int k = 0; k < 9; ++k) {
+        if (k < D) {
+          double t[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) t[r] = r < nsum ? B.p[r][9 * (size_t)sl + k] : 0.0;
+          double acc = 0.0;
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if (r < nsum) acc += t[r];
+          cc[k] = acc;
+        }
       }
     } else {
       const double* tsum = B.p[blockIdx.z] + 9 * (size_t)sl;
