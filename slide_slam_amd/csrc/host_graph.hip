@@ -1155,6 +1155,10 @@ int HostGraph::upload_new() {
   return sync_lm_slot();
 }
 int HostGraph::sync_lm_slot() {
+  if (h_sh_lid.empty()) {            // no shared slots (single-robot graphs, replicas): nothing reads the table
+    G.lm_slot = nullptr;
+    return SLIDE_OK;
+  }
   const size_t Ln = h_lm_type.size();
   std::vector<int> slot(std::max<size_t>(Ln, 1), -1);
   for (size_t i = 0; i < h_sh_lid.size(); ++i)
