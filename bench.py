@@ -463,14 +463,14 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
         # join), so launches overlap in time: achieved = ALL algorithmic flops of the batched factor + solve / the HIP-event window
         # around it (fork .. join, the extractions and the chained backward substitutions included); flops_per_launch and
         # avg_launch_ms are that window shared out over the groups x 59 launches
-        groups = max(1, min(int(os.environ.get("SLIDE_CHOL_GROUPS", "2")), bt["robots"] // 2))
-        per = bt["robots"] // groups
+        groups = max(1, bt["launches"] // max(T, 1))       # launch sequences the library used (one per system on a narrow profile, else two)
+        per = max(1, bt["robots"] // groups)
         roof_kernel = (f"k_chol_step_batched (v_mfma_f64_16x16x4_f64, {per} factorisations per launch, {groups} overlapping launch sequences)")
-        upd_launches_per_iter = bt["launches"] * groups
+        upd_launches_per_iter = bt["launches"]
         upd_ms = bt["ms_steps"] / max(upd_launches_per_iter, 1)
         flops_per_launch = bt["flops"] / max(upd_launches_per_iter, 1)
         ach = flops_per_launch / (upd_ms * 1e-3) / 1e12
-        traffic = _pmc_traffic("k_chol_step_batched", robots=bt["robots"], robots_per_launch=per, profile="dense" if DENSE_PROFILE else "structure") if n == 3776 else None
+        traffic = _pmc_traffic("k_chol_step_batched", robots=bt["robots"], profile="dense" if DENSE_PROFILE else "structure") if n == 3776 else None
     kernel_ms = {k: v["ms"] / nprof for k, v in prof.items()}
     dominant = max(kernel_ms, key=kernel_ms.get)
     n_slots = info.get("n_slots", 0) if info else 0
@@ -509,8 +509,9 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
                      "dense_profile": (None if not (bt and dense_leg) else (lambda dm, dfl: {
                          "achieved": dfl / (dm * 1e-3) / 1e12, "frac": dfl / (dm * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                          "flops_per_launch": dfl, "avg_launch_ms": dm, "ms_per_step": dense_leg["ms_per_step"],
-                         "traffic": _pmc_traffic("k_chol_step_batched", robots=bt["robots"], robots_per_launch=per, profile="dense") if n == 3776 else None})(
-                             dense_leg["ms_steps"] / max(dense_leg["launches"] * groups, 1), dense_leg["flops"] / max(dense_leg["launches"] * groups, 1))),
+                         "traffic": _pmc_traffic("k_chol_step_batched", robots=bt["robots"], profile="dense") if n == 3776 else None,
+                         "launch_sequences": max(1, dense_leg["launches"] // max(T, 1))})(
+                             dense_leg["ms_steps"] / max(dense_leg["launches"], 1), dense_leg["flops"] / max(dense_leg["launches"], 1))),
                      "flops_per_launch": flops_per_launch, "avg_launch_ms": upd_ms,
                      "launches_per_iter": upd_launches_per_iter, "dominant_by_time": dominant,
                      "scope": ("HIP events on the batch's stream around the batched factor + solve (fork .. join of the launch sequences) of "

@@ -619,7 +619,7 @@ int CholBatch::profile_pass(double* const* d_bufs, double* ms_steps, int* n_laun
     if (ms_steps) *ms_steps = ms;
     int Tmax = 0;
     for (const CholSystem& c : sys) Tmax = c.T > Tmax ? c.T : Tmax;
-    if (n_launches) *n_launches = Tmax;
+    if (n_launches) *n_launches = Tmax * last_groups;      // step launches of the pass: Tmax per launch sequence
   } else if (rc == SLIDE_OK) rc = SLIDE_ERR_HIP;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
@@ -682,9 +682,16 @@ int CholBatch::end_pass() {
 // two between the fork and the join, and the launch tails / serial chains of one sequence overlap with the trailing-update flood of
 // the other.  `after` (measurement): recorded behind everything (the join included).
 int CholBatch::factor_all(hipEvent_t after) {
-  static const int env_groups = getenv("SLIDE_CHOL_GROUPS") ? atoi(getenv("SLIDE_CHOL_GROUPS")) : 2;
-  int groups = env_groups < 1 ? 1 : env_groups;
-  if (groups > n / 2) groups = n / 2;              // at least two systems per sequence
+  static const int env_groups = getenv("SLIDE_CHOL_GROUPS") ? atoi(getenv("SLIDE_CHOL_GROUPS")) : 0;
+  // wide profiles: two sequences (the floods share the CUs; four measured slower); narrow profiles (every launch is a handful of
+  // chain-bound workgroups): four sequences of two systems — more launches in flight hide each other's gaps and prologues (eight
+  // robots: 3.67 ms per pass with two sequences, 3.50 with four, 4.29 with eight: the cross-stream joins then cost more than they hide)
+  bool narrow = true;
+  for (int i = 0; i < n; ++i) narrow = narrow && hG[i].schur_split == 1;
+  int groups = env_groups > 0 ? env_groups : (narrow ? 4 : 2);
+  if (groups > (env_groups > 0 ? n : n / 2)) groups = env_groups > 0 ? n : n / 2;      // (at least two systems per sequence by default)
+  if (groups > 8) groups = 8;
+  last_groups = groups < 1 ? 1 : groups;
   if (groups < 2) {
     launch_chol_batch(sys.data(), n, d_ctr, master, nullptr);
     if (after) SL_HIP(hipEventRecord(after, master));

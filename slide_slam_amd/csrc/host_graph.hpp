@@ -199,6 +199,7 @@ class CholBatch {
   hipStream_t side = nullptr;            // the products of the joint solve beside the t_l exchange (whole-pass graphs)
   hipEvent_t ev_side0 = nullptr, ev_side1 = nullptr;
   int* d_ctr = nullptr;
+  int last_groups = 1;                   // launch sequences factor_all used last
   int* d_status_all = nullptr;           // the joined graphs' status words, gathered by the last node of a pass
   int ctr_cap = 0;
   int factor_all(hipEvent_t after);      // the batched factor + solve of all joined systems, in one or two launch sequences

@@ -50,7 +50,7 @@ for tag, fs, ws, stats in (("bench", "pmc_f", "pmc_w", st), ("assoc", "apmc_f", 
                 js["rocprof_calls"], js["rocprof_avg_ns"] = stats[short]
             js["profile"] = "dense" if "--dense-profile" in os.environ.get("BENCH_ARGS", "") else "structure"      # which tiles the solver touched
             if short == "k_chol_step_batched":
-                js["robots"], js["robots_per_launch"] = 8, 4
+                js["robots"] = 8      # systems per launch: two launch sequences of four on a wide (dense) profile, one sequence per system on a narrow one
             json.dump(js, open(os.path.join(prof, f"{rnd}_pmc_traffic_{short}.json"), "w"), indent=1)
 open(os.path.join(prof, f"{rnd}_pmc_hbm_traffic.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:25]))
