@@ -526,7 +526,8 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
   const bool joint = pcg_iters > 0 && n_slots > 0;       // PCG over the robots' coupled systems instead of the plain block solves
   if (whole || part == 0) {
     launch_status_clear(d_Gs, n, master);      // (a kernel node: a captured hipMemsetAsync did not clear on replay, DESIGN §4 finding 6)
-    each(0);
+    if (batch_p3) launch_phase0_batched(d_Gs, hG.data(), n, d_bufs, master);      // (all robots in one launch sequence: no fork / join)
+    else each(0);
     if (rc == SLIDE_OK) launch_sum_bcast(d_bufs, n, 54 * n_slots, master);
   }
   if (whole || part == 1) {
@@ -557,12 +558,18 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
   }
   if (whole || part == 1 || part == 12) {
     const bool here = whole || (part == 1 && !joint) || (part == 12 && joint);
-    if (rc == SLIDE_OK && here) each(4);
+    if (rc == SLIDE_OK && here) {
+      if (batch_p3) launch_phase4_batched(d_Gs, hG.data(), n, d_bufs, master);
+      else each(4);
+    }
     if (rc == SLIDE_OK && here) launch_sum_bcast(d_bufs, n, 9 * n_slots, master);
   }
   if (whole || part == 2) {
     if (rc == SLIDE_OK && !whole) launch_bcast(d_bufs, n, 9 * n_slots, master);
-    if (rc == SLIDE_OK) each(2);
+    if (rc == SLIDE_OK) {
+      if (batch_p3) launch_phase2_batched(d_Gs, hG.data(), n, d_bufs, master);
+      else each(2);
+    }
     if (rc == SLIDE_OK) launch_status_gather(d_Gs, n, d_status_all, master);
   }
   return rc;

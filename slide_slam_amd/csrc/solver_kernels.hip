@@ -34,7 +34,7 @@ __device__ inline void lm_retract(int type, const double* in, const double* d, i
 
 // [GTSAM ISAM2 relinearisation] theta <- theta (+) delta where |delta|_inf >= threshold.
 // Every private array below is indexed by fully unrolled loops only, so the kernel needs no scratch.
-__global__ void k_relin(GraphDev G) {
+__device__ __forceinline__ void k_relin_body(const GraphDev& G) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < G.P) {
     double d[6];
@@ -87,11 +87,13 @@ __global__ void k_relin(GraphDev G) {
     }
   }
 }
+__global__ void k_relin(GraphDev G) { k_relin_body(G); }
+__global__ void k_relin_b(const GraphDev* __restrict__ Gs) { k_relin_body(Gs[blockIdx.z]); }
 
 // ------------------------------------------------------------------------------------------------
 // prior / between factors   [GTSAM PriorFactor / BetweenFactor<Pose3>]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_lin_pose_factors(GraphDev G) {
+__device__ __forceinline__ void k_lin_pose_factors_body(const GraphDev& G) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < G.n_prior) {
     // r = -Local(x, prior), J = I
@@ -139,6 +141,8 @@ __global__ __launch_bounds__(128) void k_lin_pose_factors(GraphDev G) {
     }
   }
 }
+__global__ __launch_bounds__(128) void k_lin_pose_factors(GraphDev G) { k_lin_pose_factors_body(G); }
+__global__ __launch_bounds__(128) void k_lin_pose_factors_b(const GraphDev* __restrict__ Gs) { k_lin_pose_factors_body(Gs[blockIdx.z]); }
 
 // ------------------------------------------------------------------------------------------------
 // landmark factors
@@ -164,7 +168,7 @@ __device__ inline void cyl_err(const SE3& X, const double* q, const double* z, d
 // evaluations of the error function per factor — one per lane (lane = 2 column + sign; lanes 30/31 evaluate the
 // unperturbed error), paired by a lane swap.  Every lane runs the same code on its own perturbation (a zero tangent
 // retracts to the value itself, exactly), so a thread no longer walks through thirty evaluations one after the other.
-__global__ __launch_bounds__(256) void k_lin_lf(GraphDev G) {
+__device__ __forceinline__ void k_lin_lf_body(const GraphDev& G) {
   const int f = (blockIdx.x * 256 + threadIdx.x) >> 5, j = threadIdx.x & 31;
   if (f >= G.n_lf) return;
   const int type = G.lf_type[f];
@@ -262,6 +266,8 @@ __global__ __launch_bounds__(256) void k_lin_lf(GraphDev G) {
     }
   }
 }
+__global__ __launch_bounds__(256) void k_lin_lf(GraphDev G) { k_lin_lf_body(G); }
+__global__ __launch_bounds__(256) void k_lin_lf_b(const GraphDev* __restrict__ Gs) { k_lin_lf_body(Gs[blockIdx.z]); }
 
 // ------------------------------------------------------------------------------------------------
 // landmark reduce: H_ll = sum Jl^T Jl, g_l = sum Jl^T r, H_ll^-1, and per factor
@@ -894,7 +900,7 @@ __global__ void k_pad_rhs_b(const GraphDev* __restrict__ Gs) {
 // One wave per landmark (lanes over its factors, butterfly sum of the <= 9 numbers), four landmarks per workgroup; the
 // pose part is a plain copy by the first blocks' threads.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_backsub(GraphDev G) {
+__device__ __forceinline__ void k_backsub_body(const GraphDev& G) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (MODE != 2) {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -950,11 +956,15 @@ __global__ __launch_bounds__(256) void k_backsub(GraphDev G) {
     }
   }
 }
+template <int MODE>
+__global__ __launch_bounds__(256) void k_backsub(GraphDev G) { k_backsub_body<MODE>(G); }
+template <int MODE>
+__global__ __launch_bounds__(256) void k_backsub_b(const GraphDev* __restrict__ Gs) { k_backsub_body<MODE>(Gs[blockIdx.z]); }
 
 // ---- cross-robot exchange of shared landmarks (one robot per GPU) --------------------------
 // what 0: normal-equation partial sums (54 per slot: packed lower H_ll, g_l), what 1: t_l (9), what 2: the
 // landmark VALUE from its owner rank (15; other ranks contribute zeros so that an all-reduce(sum) broadcasts it).
-__global__ void k_shared_pack(GraphDev G, int what, double* __restrict__ buf) {       // one thread per (slot, element)
+__device__ __forceinline__ void k_shared_pack_body(const GraphDev& G, int what, double* __restrict__ buf) {       // one thread per (slot, element)
   const int w = what == 0 ? 54 : (what == 1 ? 9 : 15);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int sidx = t / w, k = t - sidx * w;
@@ -964,6 +974,7 @@ __global__ void k_shared_pack(GraphDev G, int what, double* __restrict__ buf) { 
   const double* src = what == 0 ? G.lm_Hacc + 54 * (size_t)(l < 0 ? 0 : l) : (what == 1 ? G.lm_t + 9 * (size_t)(l < 0 ? 0 : l) : G.lm_val + 15 * (size_t)(l < 0 ? 0 : l));
   buf[t] = live ? src[k] : 0.0;
 }
+__global__ void k_shared_pack(GraphDev G, int what, double* __restrict__ buf) { k_shared_pack_body(G, what, buf); }
 __global__ void k_shared_unpack(GraphDev G, int what, const double* __restrict__ buf) {
   const int w = what == 0 ? 54 : (what == 1 ? 9 : 15);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -990,7 +1001,7 @@ __global__ void k_ghost_exchange(GraphDev G, int what, double* __restrict__ buf)
   }
 }
 
-__global__ void k_estimate(GraphDev G) {
+__device__ __forceinline__ void k_estimate_body(const GraphDev& G) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < G.P) {
     pose_retract12(G.pose_val + 12 * (size_t)t, G.pose_delta + 6 * (size_t)t, G.chart, G.pose_est + 12 * (size_t)t);
@@ -999,6 +1010,8 @@ __global__ void k_estimate(GraphDev G) {
     lm_retract(G.lm_type[l], G.lm_val + 15 * (size_t)l, G.lm_delta + 9 * (size_t)l, G.chart, G.lm_est + 15 * (size_t)l);
   }
 }
+__global__ void k_estimate(GraphDev G) { k_estimate_body(G); }
+__global__ void k_estimate_b(const GraphDev* __restrict__ Gs) { k_estimate_body(Gs[blockIdx.z]); }
 
 // sum of squared whitened residuals of every factor at the last linearisation point (NonlinearFactorGraph::error x 2): one workgroup,
 // fixed summation order.  out[0] = total, out[1] = priors, out[2] = betweens (incl. ghost), out[3] = landmark factors.
@@ -1101,6 +1114,47 @@ void launch_phase3_batched(const GraphDev* d, const GraphDev* h, int n, double* 
     hipLaunchKernelGGL(k_schur_b, dim3(P, split > 0 ? split : 1, n), dim3(256),
                        (size_t)((L + 7) / 8 * 8) * sizeof(short) + (size_t)((P + 31) / 32 + 1) * sizeof(unsigned), s, d);
     hipLaunchKernelGGL(k_pad_rhs_b, dim3(blocks_for(pad, 256), 1, n), dim3(256), 0, s, d);
+  }
+}
+__global__ void k_shared_pack_b(const GraphDev* __restrict__ Gs, int what, BufPtrs B) { k_shared_pack_body(Gs[blockIdx.z], what, B.p[blockIdx.z]); }
+// The per-robot phases of a batched pass in ONE launch sequence for all robots (blockIdx.z = robot, grids sized for the largest graph):
+// forking every robot's phase onto its own stream and joining again cost three cross-stream joins of ~15 us per pass.
+// phase 0: relinearise, linearise, per-landmark partial sums, pack H_ll / g_l of the shared slots
+void launch_phase0_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s) {
+  int L = 0, P = 0, slots = 0, npf = 0;
+  long long nlf = 0;
+  for (int i = 0; i < n; ++i) {
+    L = std::max(L, h[i].L); P = std::max(P, h[i].P); slots = std::max(slots, h[i].n_slots);
+    npf = std::max(npf, h[i].n_prior + h[i].n_between + h[i].n_ghost);
+    nlf = std::max<long long>(nlf, h[i].n_lf);
+  }
+  BufPtrs B{};
+  for (int i = 0; i < n; ++i) B.p[i] = bufs[i];
+  if (P + L > 0) hipLaunchKernelGGL(k_relin_b, dim3(blocks_for(P + L, 256), 1, n), dim3(256), 0, s, d);
+  if (npf > 0) hipLaunchKernelGGL(k_lin_pose_factors_b, dim3(blocks_for(npf, 128), 1, n), dim3(128), 0, s, d);
+  if (nlf > 0) hipLaunchKernelGGL(k_lin_lf_b, dim3(blocks_for(32LL * nlf, 256), 1, n), dim3(256), 0, s, d);
+  if (L > 0) hipLaunchKernelGGL(k_landmark_b<1>, dim3(blocks_for(L, 4), 1, n), dim3(256), 0, s, d);
+  if (slots > 0) hipLaunchKernelGGL(k_shared_pack_b, dim3(blocks_for(54LL * slots, 128), 1, n), dim3(128), 0, s, d, 0, B);
+}
+// phase 4: t_l = sum E^T delta_p per landmark, packed for the exchange
+void launch_phase4_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s) {
+  int L = 0, P = 0, slots = 0;
+  for (int i = 0; i < n; ++i) { L = std::max(L, h[i].L); P = std::max(P, h[i].P); slots = std::max(slots, h[i].n_slots); }
+  BufPtrs B{};
+  for (int i = 0; i < n; ++i) B.p[i] = bufs[i];
+  if (P + L > 0) hipLaunchKernelGGL(k_backsub_b<1>, dim3(std::max(blocks_for(L, 4), blocks_for(6 * P, 256)), 1, n), dim3(256), 0, s, d);
+  if (slots > 0) hipLaunchKernelGGL(k_shared_pack_b, dim3(blocks_for(9LL * slots, 128), 1, n), dim3(128), 0, s, d, 1, B);
+}
+// phase 2: the exchanged t_l back, landmark back-substitution, estimate = theta (+) delta
+void launch_phase2_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s) {
+  int L = 0, P = 0, slots = 0;
+  for (int i = 0; i < n; ++i) { L = std::max(L, h[i].L); P = std::max(P, h[i].P); slots = std::max(slots, h[i].n_slots); }
+  BufPtrs B{};
+  for (int i = 0; i < n; ++i) B.p[i] = bufs[i];
+  if (slots > 0) hipLaunchKernelGGL(k_shared_unpack_b, dim3(blocks_for(9LL * slots, 128), 1, n), dim3(128), 0, s, d, 1, B);
+  if (P + L > 0) {
+    hipLaunchKernelGGL(k_backsub_b<2>, dim3(std::max(blocks_for(L, 4), blocks_for(6 * P, 256)), 1, n), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_estimate_b, dim3(blocks_for(P + L, 256), 1, n), dim3(256), 0, s, d);
   }
 }
 void launch_shared_pack(const GraphDev& G, int what, double* buf, hipStream_t s) {
