@@ -523,6 +523,7 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
   };
   const int n_slots = graphs[0]->G.n_slots;
   const bool whole = part < 0;
+  static const bool pcg_fork = !(getenv("SLIDE_PCG_FORK") && getenv("SLIDE_PCG_FORK")[0] == '0');      // diagnostic: the products on the pass's own stream
   const bool joint = pcg_iters > 0 && n_slots > 0;       // PCG over the robots' coupled systems instead of the plain block solves
   if (whole || part == 0) {
     launch_status_clear(d_Gs, n, master);      // (a kernel node: a captured hipMemsetAsync did not clear on replay, DESIGN §4 finding 6)
@@ -539,7 +540,7 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
     if (rc == SLIDE_OK && joint && !batch_p3) rc = save_systems();      // (the batched assembly wrote S0 along with S)
     if (rc == SLIDE_OK && e0) (void)hipEventRecord(e0, master);
     if (rc == SLIDE_OK) rc = factor_all(e1);
-    if (rc == SLIDE_OK && joint) rc = enqueue_pcg_head(d_bufs, whole);
+    if (rc == SLIDE_OK && joint) rc = enqueue_pcg_head(d_bufs, whole && pcg_fork);
   }
   if (joint) {
     // the PCG iterations: whole pass = all of them inline; cut pass = part 10 (after the t_l exchange), part 11 / 12 (after the
@@ -548,11 +549,11 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
       const bool last = it == pcg_iters - 1;
       if (whole || (part == 10 && it == 0)) {
         if (!whole) launch_bcast(d_bufs, n, 9 * n_slots, master);
-        rc = enqueue_pcg_mid(d_bufs, whole);
+        rc = enqueue_pcg_mid(d_bufs, whole && pcg_fork, whole);
       }
       if (rc == SLIDE_OK && (whole || (part == 11 && it == 0 && !last) || (part == 12 && last))) {
         if (!whole) launch_bcast(d_bufs, n, 2, master);
-        rc = enqueue_pcg_tail(d_bufs, last, whole);
+        rc = enqueue_pcg_tail(d_bufs, last, whole && pcg_fork, whole);
       }
     }
   }
@@ -773,14 +774,14 @@ int CholBatch::enqueue_pcg_head(double* const* d_bufs, bool fork) {
 // whole = a whole-pass graph (every robot of the job on this GPU): the products ran on the side stream, and k_pcg_scalars sums the
 // n robots' partial dot products itself (k_sum_bcast's order) instead of a sum node before it.  (The same for t_l inside
 // k_pcg_cross was slower than the sum node: 35 against 25 + 5 us — scattered reads of eight buffers.)
-int CholBatch::enqueue_pcg_mid(double* const* d_bufs, bool whole) {
-  if (whole) SL_HIP(hipStreamWaitEvent(master, ev_side1, 0));
-  launch_pcg_matvec_dots(d_Gs, hG.data(), n, d_bufs, !whole, 1, master);
+int CholBatch::enqueue_pcg_mid(double* const* d_bufs, bool forked, bool whole) {
+  if (forked) SL_HIP(hipStreamWaitEvent(master, ev_side1, 0));
+  launch_pcg_matvec_dots(d_Gs, hG.data(), n, d_bufs, !forked, 1, master);
   if (!whole) launch_sum_bcast(d_bufs, n, 2, master);
   return SLIDE_OK;
 }
-int CholBatch::enqueue_pcg_tail(double* const* d_bufs, bool last, bool fork) {
-  launch_pcg_update(d_Gs, hG.data(), n, d_bufs, fork ? n : 1, master);
+int CholBatch::enqueue_pcg_tail(double* const* d_bufs, bool last, bool fork, bool whole) {
+  launch_pcg_update(d_Gs, hG.data(), n, d_bufs, whole ? n : 1, master);
   if (last) {
     launch_pcg_finish(d_Gs, hG.data(), n, master);
     return SLIDE_OK;

@@ -177,8 +177,8 @@ class CholBatch {
   int pcg_iters = 0;
   int fork_symv();                                               // w = S0 u on `side`, joined by enqueue_pcg_mid
   int enqueue_pcg_head(double* const* d_bufs, bool fork);                   // r = b, u = M^-1 b, t_l(u) packed + local sum
-  int enqueue_pcg_mid(double* const* d_bufs, bool forked);                    // w = S u, partial dots + local sum
-  int enqueue_pcg_tail(double* const* d_bufs, bool last, bool fork);        // alpha, beta, updates; then u = M^-1 r, t_l(u) | dp = x
+  int enqueue_pcg_mid(double* const* d_bufs, bool forked, bool whole);                    // w = S u, partial dots + local sum
+  int enqueue_pcg_tail(double* const* d_bufs, bool last, bool fork, bool whole);        // alpha, beta, updates; then u = M^-1 r, t_l(u) | dp = x
   int save_systems();                                            // S -> S0 before the factorisation (joint solve only)
   std::vector<GraphDev> pass_G;
   std::vector<double*> pass_bufs;
