@@ -391,7 +391,6 @@ void HostGraph::join_batch(CholBatch* b, int slot) {
 CholBatch::~CholBatch() {
   if (master) (void)hipStreamSynchronize(master);
   for (hipStream_t a : aux) if (a) (void)hipStreamSynchronize(a);
-  if (side) (void)hipStreamSynchronize(side);
   for (auto& e : part_exec) if (e) (void)hipGraphExecDestroy(e);
   for (HostGraph* g : graphs)
     if (g) { std::lock_guard<std::mutex> gl(g->mtx); if (g->batch == this) g->batch = nullptr; }
@@ -402,9 +401,7 @@ CholBatch::~CholBatch() {
   if (d_Gs) (void)hipFree(d_Gs);
   if (d_status_all) (void)hipFree(d_status_all);
   if (ev_aux0) (void)hipEventDestroy(ev_aux0);
-  if (ev_side0) (void)hipEventDestroy(ev_side0);
-  if (ev_side1) (void)hipEventDestroy(ev_side1);
-  if (side) (void)hipStreamDestroy(side);
+
   for (hipEvent_t e : ev_aux1) if (e) (void)hipEventDestroy(e);
   for (hipStream_t a : aux) if (a) (void)hipStreamDestroy(a);
   if (master) (void)hipStreamDestroy(master);
@@ -523,7 +520,6 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
   };
   const int n_slots = graphs[0]->G.n_slots;
   const bool whole = part < 0;
-  static const bool pcg_fork = !(getenv("SLIDE_PCG_FORK") && getenv("SLIDE_PCG_FORK")[0] == '0');      // diagnostic: the products on the pass's own stream
   const bool joint = pcg_iters > 0 && n_slots > 0;       // PCG over the robots' coupled systems instead of the plain block solves
   if (whole || part == 0) {
     launch_status_clear(d_Gs, n, master);      // (a kernel node: a captured hipMemsetAsync did not clear on replay, DESIGN §4 finding 6)
@@ -540,7 +536,7 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
     if (rc == SLIDE_OK && joint && !batch_p3) rc = save_systems();      // (the batched assembly wrote S0 along with S)
     if (rc == SLIDE_OK && e0) (void)hipEventRecord(e0, master);
     if (rc == SLIDE_OK) rc = factor_all(e1);
-    if (rc == SLIDE_OK && joint) rc = enqueue_pcg_head(d_bufs, whole && pcg_fork);
+    if (rc == SLIDE_OK && joint) rc = enqueue_pcg_head(d_bufs);
   }
   if (joint) {
     // the PCG iterations: whole pass = all of them inline; cut pass = part 10 (after the t_l exchange), part 11 / 12 (after the
@@ -549,11 +545,11 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
       const bool last = it == pcg_iters - 1;
       if (whole || (part == 10 && it == 0)) {
         if (!whole) launch_bcast(d_bufs, n, 9 * n_slots, master);
-        rc = enqueue_pcg_mid(d_bufs, whole && pcg_fork, whole);
+        rc = enqueue_pcg_mid(d_bufs, whole);
       }
       if (rc == SLIDE_OK && (whole || (part == 11 && it == 0 && !last) || (part == 12 && last))) {
         if (!whole) launch_bcast(d_bufs, n, 2, master);
-        rc = enqueue_pcg_tail(d_bufs, last, whole && pcg_fork, whole);
+        rc = enqueue_pcg_tail(d_bufs, last, whole);
       }
     }
   }
@@ -751,36 +747,22 @@ int CholBatch::save_systems() {
   }
   return SLIDE_OK;
 }
-// w = S0 u on a side stream, beside t_l and its exchange (whole-pass graphs: a cut pass has the exchange outside its graphs)
-int CholBatch::fork_symv() {
-  if (!side) {
-    SL_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    SL_HIP(hipEventCreateWithFlags(&ev_side0, hipEventDisableTiming));
-    SL_HIP(hipEventCreateWithFlags(&ev_side1, hipEventDisableTiming));
-  }
-  SL_HIP(hipEventRecord(ev_side0, master));
-  SL_HIP(hipStreamWaitEvent(side, ev_side0, 0));
-  launch_pcg_symv(d_Gs, hG.data(), n, side);
-  SL_HIP(hipEventRecord(ev_side1, side));
-  return SLIDE_OK;
-}
-int CholBatch::enqueue_pcg_head(double* const* d_bufs, bool fork) {
+int CholBatch::enqueue_pcg_head(double* const* d_bufs) {
   launch_pcg_init(d_Gs, hG.data(), n, master);
-  if (fork) { const int rc = fork_symv(); if (rc != SLIDE_OK) return rc; }
   launch_pcg_tl(d_Gs, hG.data(), n, d_bufs, PCG_VEC_U, master);
   launch_sum_bcast(d_bufs, n, 9 * hG[0].n_slots, master);
   return SLIDE_OK;
 }
-// whole = a whole-pass graph (every robot of the job on this GPU): the products ran on the side stream, and k_pcg_scalars sums the
-// n robots' partial dot products itself (k_sum_bcast's order) instead of a sum node before it.  (The same for t_l inside
-// k_pcg_cross was slower than the sum node: 35 against 25 + 5 us — scattered reads of eight buffers.)
-int CholBatch::enqueue_pcg_mid(double* const* d_bufs, bool forked, bool whole) {
-  if (forked) SL_HIP(hipStreamWaitEvent(master, ev_side1, 0));
-  launch_pcg_matvec_dots(d_Gs, hG.data(), n, d_bufs, !forked, 1, master);
+// whole = a whole-pass graph (every robot of the job on this GPU): k_pcg_scalars sums the n robots' partial dot products itself
+// (k_sum_bcast's order) instead of a sum node before it.  (The same for t_l inside k_pcg_cross was slower than the sum node: 35
+// against 25 + 5 us — scattered reads of eight buffers.  Running the products w = S0 u on a side stream beside t_l and its exchange
+// was slower too: the cross-stream join costs ~12 us, more than the 22 us product hides.)
+int CholBatch::enqueue_pcg_mid(double* const* d_bufs, bool whole) {
+  launch_pcg_matvec_dots(d_Gs, hG.data(), n, d_bufs, true, 1, master);
   if (!whole) launch_sum_bcast(d_bufs, n, 2, master);
   return SLIDE_OK;
 }
-int CholBatch::enqueue_pcg_tail(double* const* d_bufs, bool last, bool fork, bool whole) {
+int CholBatch::enqueue_pcg_tail(double* const* d_bufs, bool last, bool whole) {
   launch_pcg_update(d_Gs, hG.data(), n, d_bufs, whole ? n : 1, master);
   if (last) {
     launch_pcg_finish(d_Gs, hG.data(), n, master);
@@ -796,7 +778,6 @@ int CholBatch::enqueue_pcg_tail(double* const* d_bufs, bool last, bool fork, boo
   launch_chain_batch(sys.data(), n, in, out, true, true, true, nxt, master);       // (y prepared by k_pcg_update; prepares u for the backward chain)
   for (int i = 0; i < n; ++i) { in[i] = out[i]; out[i] = nxt[i]; }
   launch_chain_batch(sys.data(), n, in, out, false, true, true, nullptr, master);
-  if (fork) { const int rc = fork_symv(); if (rc != SLIDE_OK) return rc; }
   launch_pcg_tl(d_Gs, hG.data(), n, d_bufs, PCG_VEC_U, master);
   launch_sum_bcast(d_bufs, n, 9 * hG[0].n_slots, master);
   return SLIDE_OK;

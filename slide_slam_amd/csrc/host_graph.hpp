@@ -175,10 +175,9 @@ class CholBatch {
   hipGraphExec_t pass_exec = nullptr;
   hipGraphExec_t part_exec[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // parts 0, 1, 2, 10, 11, 12
   int pcg_iters = 0;
-  int fork_symv();                                               // w = S0 u on `side`, joined by enqueue_pcg_mid
-  int enqueue_pcg_head(double* const* d_bufs, bool fork);                   // r = b, u = M^-1 b, t_l(u) packed + local sum
-  int enqueue_pcg_mid(double* const* d_bufs, bool forked, bool whole);                    // w = S u, partial dots + local sum
-  int enqueue_pcg_tail(double* const* d_bufs, bool last, bool fork, bool whole);        // alpha, beta, updates; then u = M^-1 r, t_l(u) | dp = x
+  int enqueue_pcg_head(double* const* d_bufs);                   // r = b, u = M^-1 b, t_l(u) packed + local sum
+  int enqueue_pcg_mid(double* const* d_bufs, bool whole);                    // w = S u, partial dots + local sum
+  int enqueue_pcg_tail(double* const* d_bufs, bool last, bool whole);        // alpha, beta, updates; then u = M^-1 r, t_l(u) | dp = x
   int save_systems();                                            // S -> S0 before the factorisation (joint solve only)
   std::vector<GraphDev> pass_G;
   std::vector<double*> pass_bufs;
@@ -196,8 +195,6 @@ class CholBatch {
   hipStream_t master = nullptr;
   hipStream_t aux[8] = {};               // further streams of the grouped factorisation (the groups' launches overlap on the GPU)
   hipEvent_t ev_aux0 = nullptr, ev_aux1[8] = {};
-  hipStream_t side = nullptr;            // the products of the joint solve beside the t_l exchange (whole-pass graphs)
-  hipEvent_t ev_side0 = nullptr, ev_side1 = nullptr;
   int* d_ctr = nullptr;
   int last_groups = 1;                   // launch sequences factor_all used last
   int* d_status_all = nullptr;           // the joined graphs' status words, gathered by the last node of a pass
