@@ -758,7 +758,7 @@ int CholBatch::enqueue_pcg_head(double* const* d_bufs) {
 // against 25 + 5 us — scattered reads of eight buffers.  Running the products w = S0 u on a side stream beside t_l and its exchange
 // was slower too: the cross-stream join costs ~12 us, more than the 22 us product hides.)
 int CholBatch::enqueue_pcg_mid(double* const* d_bufs, bool whole) {
-  launch_pcg_matvec_dots(d_Gs, hG.data(), n, d_bufs, true, 1, master);
+  launch_pcg_matvec_dots(d_Gs, hG.data(), n, d_bufs, 1, master);
   if (!whole) launch_sum_bcast(d_bufs, n, 2, master);
   return SLIDE_OK;
 }
@@ -1323,7 +1323,7 @@ int HostGraph::enqueue_phase(int phase, double* d_buf) {
       launch_shared_pack(G, 1, d_buf, s);
     }
   } else if (phase == 31) {          // after the exchange of t_l: w = S u, partial dots -> d_buf[0 .. 1]
-    launch_pcg_matvec_dots(d_Gself.d, &G, 1, &d_buf, true, 1, s);
+    launch_pcg_matvec_dots(d_Gself.d, &G, 1, &d_buf, 1, s);
   } else if (phase == 32 || phase == 33) {     // after the exchange of the dots: the updates; 32: next u, t_l -> d_buf; 33 (last): dp = x, t_l(dp) -> d_buf
     launch_pcg_update(d_Gself.d, &G, 1, &d_buf, 1, s);
     if (phase == 33) {

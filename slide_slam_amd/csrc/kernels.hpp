@@ -60,9 +60,8 @@ enum { PCG_VEC_R = 0, PCG_VEC_U = 1, PCG_VEC_W = 2, PCG_VEC_P = 3, PCG_VEC_S = 4
 void launch_status_clear(const GraphDev* d, int n, hipStream_t s);             // status[0..7] = 0 for every graph of the batch
 void launch_status_gather(const GraphDev* d, int n, int* out, hipStream_t s);  // out[8 i ..] = graph i's status words
 void launch_pcg_init(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);
-void launch_pcg_tl(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, int vec, hipStream_t s);      // -> bufs[i][9 slot ..]
-void launch_pcg_symv(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);                                // w = S0 u (own blocks)
-void launch_pcg_matvec_dots(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, bool with_symv, int nsum, hipStream_t s);     // bufs: summed t_l in, (gamma, delta) partials out; with_symv = false: launch_pcg_symv ran already
+void launch_pcg_tl(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, int vec, hipStream_t s);      // t_l -> bufs[i][9 slot ..], and w = S0 v in the same launch
+void launch_pcg_matvec_dots(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, int nsum, hipStream_t s);     // bufs: summed t_l in, (gamma, delta) partials out (w = S0 u ran in launch_pcg_tl)
 void launch_pcg_update(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, int nsum, hipStream_t s);          // bufs: summed (gamma, delta) in
 void launch_pcg_finish(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);
 

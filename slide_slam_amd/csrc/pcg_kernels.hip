@@ -43,10 +43,9 @@ struct PcgBufs { double* p[8]; };
 
 // t_l = sum_f E_f^T v_pose(f) for the landmarks of the shared slots, written to lm_t and packed (9 per slot) into the robot's
 // exchange buffer; slots this robot does not observe contribute zeros.  One wave per slot.
-__global__ __launch_bounds__(256) void k_pcg_tl(const GraphDev* __restrict__ Gs, PcgBufs B, int vec) {
-  const GraphDev G = Gs[blockIdx.z];
+__device__ __forceinline__ void pcg_tl_body(const GraphDev& G, const PcgBufs& B, int blk, int vec) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int sidx = blockIdx.x * 4 + wave;
+  const int sidx = blk * 4 + wave;
   if (sidx >= G.n_slots) return;
   double* out = B.p[blockIdx.z] + 9 * (size_t)sidx;
   const int l = G.sh_lid[sidx];
@@ -93,9 +92,7 @@ __global__ __launch_bounds__(256) void k_pcg_tl(const GraphDev* __restrict__ Gs,
 // out = S0 * in for the symmetric S0 held as its lower triangle (column-major, leading dimension ld): one workgroup per block row
 // i of 64: tiles (i, j <= i) as they lie, tiles (j > i, i) transposed.  Deterministic (no atomics): every block row is summed by
 // one workgroup in a fixed order.
-__global__ __launch_bounds__(256) void k_pcg_symv(const GraphDev* __restrict__ Gs, int vin, int vout, int in_lds) {
-  const GraphDev G = Gs[blockIdx.z];
-  const int bi = blockIdx.x;
+__device__ __forceinline__ void pcg_symv_body(const GraphDev& G, int bi, int vin, int vout, int in_lds) {
   if (bi >= G.T) return;
   extern __shared__ double xs_lds[];      // the whole input vector (T * 64 doubles) when it fits: no barrier inside the tile loops
   __shared__ double red[4][NB];
@@ -195,6 +192,14 @@ __global__ __launch_bounds__(256) void k_pcg_symv(const GraphDev* __restrict__ G
     const double b = (redt[tid][0] + redt[tid][1]) + (redt[tid][2] + redt[tid][3]);
     pvec(G, vout)[(size_t)bi * NB + tid] = a + b;
   }
+}
+
+// t_l(v) and w = S0 v in ONE launch: both need v only (the products do not wait for the exchange of t_l), so the first n_row_blocks
+// workgroups of a robot take the block rows of the product, the others four shared slots each
+__global__ __launch_bounds__(256) void k_pcg_tl_symv(const GraphDev* __restrict__ Gs, PcgBufs B, int vec, int vout, int n_row_blocks, int in_lds) {
+  const GraphDev G = Gs[blockIdx.z];
+  if ((int)blockIdx.x < n_row_blocks) pcg_symv_body(G, blockIdx.x, vec, vout, in_lds);
+  else pcg_tl_body(G, B, (int)blockIdx.x - n_row_blocks, vec);
 }
 
 // w_p -= sum_{f at pose p} F_f c_lm(f): the cross-robot Schur fill through the shared landmarks, c_l = (sum over all robots of t_l,
@@ -362,24 +367,23 @@ void launch_pcg_init(const GraphDev* d, const GraphDev* h, int n, hipStream_t s)
   if (nT > 0) hipLaunchKernelGGL(k_pcg_init, dim3(nblk(nT, 256), 1, n), dim3(256), 0, s, d);
 }
 // t_l of vector `vec` (PV_U during the iterations) packed into every robot's exchange buffer (9 doubles per slot)
+// t_l(v) -> bufs[i][9 slot ..] and, in the same launch, w = S0 v (launch_pcg_matvec_dots continues with the cross-robot part of w)
 void launch_pcg_tl(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, int vec, hipStream_t s) {
   int nT, P, slots;
   maxima(h, n, &nT, &P, &slots);
-  if (slots > 0) hipLaunchKernelGGL(k_pcg_tl, dim3(nblk(slots, 4), 1, n), dim3(256), 0, s, d, bufs_of(bufs, n), vec);
+  const int in_lds = (size_t)nT * sizeof(double) <= 48 * 1024 ? 1 : 0;      // (beyond that the vector is read from L2)
+  const unsigned nrb = nT / NB, nsl = slots > 0 ? nblk(slots, 4) : 0;
+  if (nrb + nsl > 0)
+    hipLaunchKernelGGL(k_pcg_tl_symv, dim3(nrb + nsl, 1, n), dim3(256), in_lds ? (size_t)nT * sizeof(double) : 0, s, d, bufs_of(bufs, n), vec, (int)PV_W,
+                       (int)nrb, in_lds);
 }
 // after the exchange of t_l: w = S u (own block + cross-robot fill), then the two partial dot products into bufs[i][0..1]
-// w = S0 u, every robot's own block: needs u only, not the exchanged t_l — a whole-pass graph runs it beside the exchange
-void launch_pcg_symv(const GraphDev* d, const GraphDev* h, int n, hipStream_t s) {
-  int nT, P, slots;
-  maxima(h, n, &nT, &P, &slots);
-  const int in_lds = (size_t)nT * sizeof(double) <= 48 * 1024 ? 1 : 0;      // (beyond that the vector is read from L2)
-  if (nT > 0) hipLaunchKernelGGL(k_pcg_symv, dim3(nT / NB, 1, n), dim3(256), in_lds ? (size_t)nT * sizeof(double) : 0, s, d, (int)PV_U, (int)PV_W, in_lds);
-}
-void launch_pcg_matvec_dots(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, bool with_symv, int nsum, hipStream_t s) {
+// after the exchange of t_l (the product w = S0 u ran with t_l, launch_pcg_tl): the cross-robot part of w, then the two partial dot
+// products into bufs[i][0..1]
+void launch_pcg_matvec_dots(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, int nsum, hipStream_t s) {
   int nT, P, slots;
   maxima(h, n, &nT, &P, &slots);
   const PcgBufs B = bufs_of(bufs, n);
-  if (with_symv) launch_pcg_symv(d, h, n, s);
   if (P > 0 && slots > 0) hipLaunchKernelGGL(k_pcg_cross, dim3(nblk(P, 4), 1, n), dim3(256), 0, s, d, B, (int)PV_W, nsum);
   hipLaunchKernelGGL(k_pcg_dots, dim3(1, 1, n), dim3(256), 0, s, d, B);
 }
