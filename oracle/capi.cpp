@@ -208,6 +208,26 @@ int orc_backend_landmark_table(void* h, int cls, double* xyz, int* label, int ca
 void orc_graph_set_relin_threshold(void* h, double thr) { ((Graph*)h)->P.relin_threshold = thr; }
 
 // ---- association primitives ------------------------------------------------------------------
+// Self-check of the profile-restricted Cholesky (graph.hpp chol_profile): solves A x = b for a row-major SPD matrix (lower triangle
+// used) once with the dense loops and once inside the profile; x_dense / x_prof: n doubles each.  Returns 0, or 1 + failing pivot.
+int orc_chol_solve_both(const double* A, int n, const double* b, double* x_dense, double* x_prof, int* rows_in_profile) {
+  std::vector<double> L1(A, A + (size_t)n * n), L2(A, A + (size_t)n * n);
+  int rc = chol_lower(L1.data(), n, n, 1, nullptr);
+  if (rc != 0) return rc;
+  std::memcpy(x_dense, b, sizeof(double) * n);
+  chol_solve_lower(L1.data(), n, n, x_dense, nullptr);
+  const CholProfile prof = chol_profile(L2.data(), n, n);
+  rc = chol_lower(L2.data(), n, n, 1, &prof);
+  if (rc != 0) return rc;
+  std::memcpy(x_prof, b, sizeof(double) * n);
+  chol_solve_lower(L2.data(), n, n, x_prof, &prof);
+  if (rows_in_profile) {
+    long long t = 0;
+    for (size_t bl = 0; bl < prof.rend.size(); ++bl) t += prof.rend[bl] - (long long)bl * 64;
+    *rows_in_profile = (int)std::min<long long>(t, 2147483647LL);
+  }
+  return 0;
+}
 int orc_knn_f32(const float* cloud_xyz, int n, const double* query, int K, int* out_idx) {
   std::vector<float> c(cloud_xyz, cloud_xyz + 3 * (size_t)n);
   std::vector<int> o;

@@ -35,8 +35,11 @@ def lib(native: bool = False):
     if _LIB is not None and not native:
         return _LIB
     path = os.path.join(_HERE, "_build", "liboracle_native.so" if native else "liboracle.so")
-    if not os.path.exists(path):
-        path = build(native)
+    try:
+        path = build(native)          # make: a no-op when the library is newer than its sources, so a stale build cannot be loaded
+    except (subprocess.CalledProcessError, OSError):
+        if not os.path.exists(path):
+            raise
     L = C.CDLL(path)
     L.orc_graph_create.restype = C.c_void_p
     L.orc_backend_create.restype = C.c_void_p

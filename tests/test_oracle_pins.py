@@ -361,3 +361,45 @@ def test_oracle_triangle_matching_and_tf():
     # a reflected point set: the reference's "negate column 1" fix still returns a proper rotation
     po.lib().orc_estimate_tf2d(_p(np.ascontiguousarray(b * [1, -1])), _p(np.ascontiguousarray(a)), C.c_int(len(a)), _p(tf.reshape(-1)))
     assert abs(np.linalg.det(tf[:2, :2]) - 1.0) < 1e-12
+
+
+def test_oracle_profile_cholesky_equals_the_dense_loops():
+    """The oracle's blocked Cholesky and substitutions work inside the row profile of the assembled matrix (graph.hpp chol_profile,
+    what keeps the CPU baseline from being a dense n^3 / 3 on a pose chain).  The entries skipped are exact zeros, so the solution must
+    equal the dense loops' bit for bit — on a band, on a band with a far coupling (fill up to it), and on a dense matrix."""
+    import ctypes as C
+    L = po.lib()
+    rng = np.random.default_rng(7)
+    n = 300
+    for case in ("band", "band+loop", "dense"):
+        G = np.zeros((n, n))
+        if case == "dense":
+            G = rng.normal(size=(n, n))
+        else:
+            for i in range(n):
+                j0 = max(0, i - 20)
+                G[i, j0:i + 1] = rng.normal(size=i + 1 - j0)
+            if case == "band+loop":
+                G[250:256, 10:16] = rng.normal(size=(6, 6))
+        A = np.tril(G @ G.T + n * np.eye(n)) if case == "dense" else None
+        if A is None:
+            # a banded SPD matrix: B B^T of a banded lower factor keeps the band; the far block is added symmetrically and dominated by the diagonal
+            B = np.tril(G)
+            A = B @ B.T + n * np.eye(n)
+            mask = np.abs(np.subtract.outer(np.arange(n), np.arange(n))) <= 20
+            if case == "band+loop":
+                mask[250:256, 10:16] = True
+                mask[10:16, 250:256] = True
+            A = np.tril(A * mask)
+        A = np.ascontiguousarray(A)
+        b = rng.normal(size=n)
+        xd, xp = np.zeros(n), np.zeros(n)
+        rows = C.c_int(0)
+        rc = L.orc_chol_solve_both(A.ctypes.data_as(C.c_void_p), C.c_int(n), b.ctypes.data_as(C.c_void_p), xd.ctypes.data_as(C.c_void_p),
+                                   xp.ctypes.data_as(C.c_void_p), C.byref(rows))
+        assert rc == 0, case
+        assert np.array_equal(xd, xp), case
+        full = A + np.tril(A, -1).T
+        assert np.abs(full @ xd - b).max() < 1e-9 * np.abs(b).max() * np.linalg.cond(full)
+        if case == "band":
+            assert rows.value < n * n // 4        # the profile is a band
