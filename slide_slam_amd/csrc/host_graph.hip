@@ -681,10 +681,10 @@ int CholBatch::end_pass() {
   return SLIDE_OK;
 }
 
-// All joined systems in ONE launch sequence (one step launch per block column for all of them), or — SLIDE_CHOL_GROUPS=2, four or
-// more systems — in TWO sequences of half the systems each on two streams: the systems are independent, so nothing synchronises the
-// two between the fork and the join, and the launch tails / serial chains of one sequence overlap with the trailing-update flood of
-// the other.  `after` (measurement): recorded behind everything (the join included).
+// The batched factor + solve of all joined systems in several launch sequences on as many streams (two on wide profiles, four on
+// narrow ones; SLIDE_CHOL_GROUPS overrides): the systems are independent, so nothing synchronises the sequences between the fork and
+// the join, and the launch tails / serial chains of one sequence overlap with the work of the others.  `after` (measurement): recorded
+// behind everything (the join included).
 int CholBatch::factor_all(hipEvent_t after) {
   static const int env_groups = getenv("SLIDE_CHOL_GROUPS") ? atoi(getenv("SLIDE_CHOL_GROUPS")) : 0;
   // wide profiles: two sequences (the floods share the CUs; four measured slower); narrow profiles (every launch is a handful of

@@ -199,7 +199,7 @@ class CholBatch {
   int last_groups = 1;                   // launch sequences factor_all used last
   int* d_status_all = nullptr;           // the joined graphs' status words, gathered by the last node of a pass
   int ctr_cap = 0;
-  int factor_all(hipEvent_t after);      // the batched factor + solve of all joined systems, in one or two launch sequences
+  int factor_all(hipEvent_t after);      // the batched factor + solve of all joined systems, in one to four overlapping launch sequences
 };
 
 class HostGraph {
