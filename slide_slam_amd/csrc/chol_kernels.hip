@@ -692,7 +692,7 @@ extern "C" void slide_debug_chain_stamps(unsigned long long* out) { (void)hipMem
 
 // A quiet-NaN payload no solution value can equal bit for bit: dp[] is filled with it before the backward substitution,
 // whose workgroups poll the entries of the blocks they depend on ("flag in data": one round trip per link of the chain).
-constexpr unsigned long long BWD_SENT = 0x7FF8DEADBEEF0BADull;
+constexpr unsigned long long BWD_SENT = CHAIN_SENTINEL;      // (kernels.hpp: k_pcg_update pre-fills the forward chain's output with it)
 
 __global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, double* __restrict__ yv, double* __restrict__ dp, int* status) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -35,6 +35,9 @@ void launch_ghost_exchange(const GraphDev& G, int what, double* buf, hipStream_t
 // ctr: T + 2 ints, zero before the first factorisation (each step clears the next step's work counter itself)
 void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, float* L32, const int* h_prof, hipStream_t s);   // L32, h_prof: see CholSystem
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s);   // also clears status[4], the ticket counter of launch_chol_bwd_all
+// A quiet-NaN payload no solution value can equal bit for bit: the outputs of the chained substitutions are pre-filled with it and the
+// workgroups poll the blocks they depend on ("flag in data").
+constexpr unsigned long long CHAIN_SENTINEL = 0x7FF8DEADBEEF0BADull;
 struct CholSystem { double* S; int ld, T; double* Ld; double* Winv; double* yv; double* dp; int* status;
                     float* L32;      // packed f32 copy of the factor for the joint solve's preconditioner (null: none), see bwd_chain_body
                     const int* h_prof;           // host: profile of the factor, T ints (plan_step in chol_kernels.hip), or null = dense

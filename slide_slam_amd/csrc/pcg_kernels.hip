@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void k_pcg_update(const GraphDev* __restrict__
   const int i = blockIdx.x * 256 + threadIdx.x, nT = G.T * NB;
   if (i == 0) G.status[5] = 0;
   if (i >= nT) return;
-  pvec(G, PV_Y)[i] = __longlong_as_double(0x7FF8DEADBEEF0BADll);
+  pvec(G, PV_Y)[i] = __longlong_as_double((long long)CHAIN_SENTINEL);
   const double alpha = G.pcg_scal[2], beta = G.pcg_scal[3];
   const double p = pvec(G, PV_U)[i] + beta * pvec(G, PV_P)[i];
   const double s = pvec(G, PV_W)[i] + beta * pvec(G, PV_S)[i];
