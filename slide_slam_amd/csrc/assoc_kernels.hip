@@ -77,8 +77,10 @@ __device__ __forceinline__ unsigned dist_bits(const AssocCore& C, int i, float q
   return __float_as_uint(r);       // r >= 0: the bit pattern orders like the value
 }
 
-// The K smallest (distance bits << 32 | index) keys of the cloud, ascending, into sel[0 .. Ksub).  Returns Ksub.
-__device__ inline int knn_select(const AssocCore& C, unsigned long long* sel, unsigned* hist, unsigned* dcache) {
+// The K smallest (distance bits << 32 | index) keys of the cloud into sel[0 .. Ksub): ascending when `sorted` (the reference's
+// nearest-first submap), else in the order the compaction happened to place them (the matching breaks ties by the keys themselves, so
+// it needs the SET only: the bitonic sort is a quarter of a frame's time).  Returns Ksub.
+__device__ inline int knn_select(const AssocCore& C, unsigned long long* sel, unsigned* hist, unsigned* dcache, bool sorted) {
   __shared__ unsigned long long s_prefix;
   __shared__ int s_krem, s_stop, s_cnt;
   __shared__ unsigned whist[16 * 256];          // per-wave digit histograms of the radix select
@@ -168,6 +170,10 @@ __device__ inline int knn_select(const AssocCore& C, unsigned long long* sel, un
   for (int i = Ksub + tid; i < C.Kp; i += nthr) sel[i] = ~0ull;
   __syncthreads();
   ASTAMP(3);
+  if (!sorted) {
+    ASTAMP(4);
+    return Ksub;
+  }
   if (C.Kp <= nthr) {
     // one key per thread: compare-exchange steps inside a wave (partner distance < 64) are two 32-bit shuffles, only the steps
     // across waves go through LDS (10 of the 55 steps of a 1024-key sort)
@@ -216,8 +222,11 @@ __device__ inline void assoc_core(const AssocCore& C) {
   unsigned* hist = reinterpret_cast<unsigned*>(assoc_lds + (C.gate ? C.Kp : 0));
   unsigned* dcache = hist + 256;
   int Ksub = C.n;
+  // the submap ORDER (nearest first, ties by map index) matters to the caller only when it asks for the list or for positions in it;
+  // the matching itself needs it for ties alone: "the first of equally distant candidates" = the one with the smallest key
+  const bool need_sort = C.submap != nullptr || C.match_sub != nullptr;
   if (C.gate) {
-    Ksub = C.n > 0 ? knn_select(C, sel, hist, dcache) : 0;
+    Ksub = C.n > 0 ? knn_select(C, sel, hist, dcache, need_sort) : 0;
     if (C.submap)
       for (int s = tid; s < Ksub; s += nthr) C.submap[s] = (int32_t)(sel[s] & 0xffffffffull);
   }
@@ -253,17 +262,19 @@ __device__ inline void assoc_core(const AssocCore& C) {
     const int ol0 = C.det_label[o0], ol1 = C.det_label[two ? o1 : o0];
     double best[2] = {C.best_init, C.best_init};
     int bests[2] = {INT_MAX, INT_MAX};
+    unsigned long long bkey[2] = {~0ull, ~0ull};       // order of the candidates: the select's key (gate) or the index itself
     ASTAMPW(8);
     if (C.is_cyl) {
       for (int s = lane; s < Ksub; s += 64) {
-        const int mi = C.gate ? (int)(sel[s] & 0xffffffffull) : s;
+        const unsigned long long key = C.gate ? sel[s] : (unsigned long long)s;
+        const int mi = C.gate ? (int)(key & 0xffffffffull) : s;
         const double* mm = staged ? cand + (size_t)s * ms : C.model + (size_t)ms * mi;
         const int ml = staged ? cand_lab[s] : C.label[mi];
         const double d0 = cyl_distance(mm, ml, dw0 - C.det_off, ol0);
-        if (d0 < C.best_init && d0 < best[0]) { best[0] = d0; bests[0] = s; }
+        if (d0 < C.best_init && (d0 < best[0] || (d0 == best[0] && key < bkey[0]))) { best[0] = d0; bests[0] = s; bkey[0] = key; }
         if (two) {
           const double d1 = cyl_distance(mm, ml, dw1 - C.det_off, ol1);
-          if (d1 < C.best_init && d1 < best[1]) { best[1] = d1; bests[1] = s; }
+          if (d1 < C.best_init && (d1 < best[1] || (d1 == best[1] && key < bkey[1]))) { best[1] = d1; bests[1] = s; bkey[1] = key; }
         }
       }
     } else {
@@ -277,7 +288,8 @@ __device__ inline void assoc_core(const AssocCore& C) {
       double b2[2] = {-1.0, -1.0};          // squared distance of the lane's best (none yet: < 0)
       constexpr double BAND = 1.0 - 0x1p-48;
       for (int s = lane; s < Ksub; s += 64) {
-        const int mi = C.gate ? (int)(sel[s] & 0xffffffffull) : s;
+        const unsigned long long key = C.gate ? sel[s] : (unsigned long long)s;
+        const int mi = C.gate ? (int)(key & 0xffffffffull) : s;
         const double* mm = staged ? cand + (size_t)s * ms : C.model + (size_t)ms * mi;
         const int ml = staged ? cand_lab[s] : C.label[mi];
         const double m0 = mm[0], m1 = mm[1], m2 = mm[2];
@@ -289,33 +301,39 @@ __device__ inline void assoc_core(const AssocCore& C) {
           const double dx = q[0] - m0, dy = q[1] - m1, dz = q[2] - m2;
           const double d2 = dx * dx + dy * dy + dz * dz;
           bool take = b2[h] < 0.0 || d2 < b2[h] * BAND;
-          if (!take && d2 < b2[h]) take = sqrt(d2) < sqrt(b2[h]);       // inside the band: the rounded roots decide
-          if (take) { b2[h] = d2; bests[h] = s; }
+          if (!take && d2 * BAND <= b2[h]) {       // inside the band (either side): the rounded roots decide, equal roots the order
+            const double rd = sqrt(d2), rb = sqrt(b2[h]);
+            take = rd < rb || (rd == rb && key < bkey[h]);
+          }
+          if (take) { b2[h] = d2; bests[h] = s; bkey[h] = key; }
         }
       }
       ASTAMPW(10);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const double d = b2[h] >= 0.0 ? sqrt(b2[h]) : C.best_init;
-        if (d < C.best_init) best[h] = d; else bests[h] = INT_MAX;      // "if (d < bestDist)" against the initial bestDist
+        if (d < C.best_init) best[h] = d; else { bests[h] = INT_MAX; bkey[h] = ~0ull; }      // "if (d < bestDist)" against the initial bestDist
       }
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       double b = best[h];
       int bs = bests[h];
+      unsigned long long bk = bkey[h];
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
         const double ob = __shfl_xor(b, off);
         const int os = __shfl_xor(bs, off);
-        if (ob < b || (ob == b && os < bs)) { b = ob; bs = os; }
+        const unsigned klo = (unsigned)__shfl_xor((int)(unsigned)bk, off), khi = (unsigned)__shfl_xor((int)(unsigned)(bk >> 32), off);
+        const unsigned long long ok_ = ((unsigned long long)khi << 32) | klo;
+        if (ob < b || (ob == b && ok_ < bk)) { b = ob; bs = os; bk = ok_; }
       }
       const int o = h == 0 ? o0 : o1;
       if (h == 1) ASTAMPW(11);
       if (lane == 0 && (h == 0 || two)) {
         const bool ok = (bs != INT_MAX) && (b < C.thresh);
-        if (C.match_sub) C.match_sub[o] = ok ? bs : -1;
-        C.match_map[o] = ok ? (C.gate ? (int32_t)(sel[bs] & 0xffffffffull) : bs) : -1;
+        if (C.match_sub) C.match_sub[o] = ok ? bs : -1;      // (position in the sorted submap: the list was sorted when this is asked for)
+        C.match_map[o] = ok ? (int32_t)(bk & 0xffffffffull) : -1;
       }
     }
   }
