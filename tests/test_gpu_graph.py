@@ -179,6 +179,9 @@ def test_profile_aware_solve_equals_dense_and_follows_loop_closures(gpu):
     chain the profile is a narrow band; (b) ignoring the structure (slide_graph_set_dense_profile) gives bit-identical poses —
     everything skipped is an exact zero; (c) a loop closure between far-apart key frames (addLoopClosureFactor graph.cpp:232-245)
     widens the profile to the closing pose's tile row and the solve still matches the oracle's dense arithmetic."""
+    import os
+    if os.environ.get("SLIDE_CHOL_DENSE") == "1":
+        pytest.skip("the structure is switched off for this run (SLIDE_CHOL_DENSE=1): nothing to compare")
     from slide_slam_amd.synth import make_robot_log, make_world
     cfg = SynthConfig.preset("small")
     log = make_robot_log(cfg, make_world(cfg), 0)
