@@ -182,6 +182,14 @@ int orc_graph_set_shared(void* h, const int* cls, const int64_t* idx, const int*
   return ((Graph*)h)->set_shared(cls, idx, owner, n);
 }
 int orc_graph_dist_phase(void* h, int phase, double* buf) { return ((Graph*)h)->dist_phase(phase, buf); }
+// joint solve of the sharded pass: PCG iterations (upper bound) and relative tolerance on sqrt(r^T M^-1 r); stats: iterations that
+// did work in the last solve, first and last gamma, state (0 running, 1 converged, 2 breakdown)
+void orc_graph_set_pcg(void* h, int iters, double tol) { ((Graph*)h)->pcg_iters = iters < 0 ? 0 : iters; ((Graph*)h)->pcg_tol = tol; }
+void orc_graph_pcg_stats(void* h, double* out4) {
+  const Graph* g = (Graph*)h;
+  out4[0] = g->D.pcg_its; out4[1] = g->D.gamma0; out4[2] = g->D.gamma_last; out4[3] = g->D.pcg_done;
+}
+int orc_graph_set_separator(void* h, const int* off, int n) { return ((Graph*)h)->set_separator(off, n); }
 void orc_graph_keep_factor(void* h, int on) { ((Graph*)h)->keep_factor = on != 0; }
 int orc_graph_pose_covariance(void* h, int robot, uint64_t idx, double* cov36) {
   return ((Graph*)h)->pose_covariance(Graph::pose_key(robot, idx), cov36);

@@ -597,8 +597,38 @@ class Graph {
     std::vector<int> pidx, lidx, pose_vars, lm_vars;
     std::vector<DLm> acc;
     std::vector<double> Hinv_all, dp;
-    std::vector<std::vector<double>> Eall;
+    std::vector<std::vector<double>> Eall, Fall;
+    // joint solve (phases 31 / 32 / 33): the robot's block before factoring (S0), its factor, the PCG vectors and scalars
+    std::vector<double> S0, Lf, g, r, u, w, p, s, x;
+    CholProfile prof;
+    double gamma_old = 0.0, alpha_old = 0.0, gamma0 = 0.0, gamma_last = 0.0;
+    int pcg_done = 0, pcg_its = 0;
   } D;
+  // PCG on the global reduced pose system after the factorisation of the robot's own block: the restatement of
+  // slide_slam_amd/csrc/pcg_kernels.hip in plain f64 loops (Chronopoulos-Gear recurrences; the preconditioner is the robot's own
+  // Cholesky factor; the reference solves the joint graph of all robots directly, graph.cpp:260-272 on a full replica).
+  // pcg_iters = 0: every robot's own block solve only.  pcg_tol: the solve counts as converged once gamma = r^T M^-1 r has fallen
+  // to pcg_tol^2 times its first value — later iterations are no-ops.
+  int pcg_iters = 0;
+  double pcg_tol = 0.0;
+  // EXACT joint step ("arrow" solve, phases 40 / 41 / 42): the shared landmarks are NOT eliminated into the robots' pose systems —
+  // they stay as the separator of the joint graph.  Robot a eliminates its private landmarks and its poses from
+  //     [A_a B_a; B_a^T C_a]   (A_a: its reduced pose block, B_a: pose x shared-landmark blocks J_p^T J_l, C_a: its own J_l^T J_l)
+  // and contributes C_a - B_a^T A_a^-1 B_a (and the matching right-hand side) to the separator system of all shared landmarks;
+  // the sum over the robots is the Schur complement of the JOINT graph onto the shared landmarks, so solving it and substituting
+  // back gives exactly the Gauss-Newton step of the full replica the reference solves (graph.cpp:260-272 on a graph holding every
+  // robot, sloamNode.cpp:912-1002).  sep_off[slot] = offset of the slot's tangent coordinates in the separator (global, every rank
+  // the same; sep_off[nslots] = its dimension m).
+  std::vector<int> sep_off;
+  struct ArrowState {
+    std::vector<double> L, W, yp;     // factor of A_a (row-major lower, n x n), W = L^-1 B_a (n x ma, row-major), y_p = L^-1 b_p
+    std::vector<int> lcol, first_row; // local separator column -> global separator coordinate; first non-zero row of the column
+    CholProfile prof;
+    int n = 0, ma = 0;
+  } AR;
+  int set_separator(const int* off, int n) { sep_off.assign(off, off + n); return 0; }
+  void pcg_pack_tl(const std::vector<double>& v, double* buf);
+  void pcg_scalars_update(const double* buf);
   // graph.cpp:314-323  isam->marginalCovariance(X(idx)): the (pose, pose) block of the inverse information matrix at the
   // current linearisation = the pose's block of S^-1 (S = landmark-eliminated pose system) = Y^T Y with L Y = E_pose.
   bool keep_factor = false;
@@ -891,6 +921,58 @@ inline int Graph::set_shared(const int* cls, const int64_t* idx, const int* owne
   return 0;
 }
 
+// t_l(v) = sum_f E_f^T v_pose(f) of every landmark (kept in acc[l].t), the shared slots' packed 9 per slot into buf (zeros for the
+// slots this robot does not observe)
+inline void Graph::pcg_pack_tl(const std::vector<double>& v, double* buf) {
+  const int nl = (int)D.lm_vars.size(), nslots = (int)sh_var.size();
+  for (int l = 0; l < nl; ++l) {
+    DLm& A = D.acc[l];
+    const int d = var_dim(vars[D.lm_vars[l]].type);
+    for (int k = 0; k < 9; ++k) A.t[k] = 0.0;
+    for (size_t a = 0; a < A.fac.size(); ++a) {
+      const int pa = D.pidx[factors[A.fac[a]].v0];
+      const double* Ea = &D.Eall[l][a * 6 * d];
+      for (int k = 0; k < d; ++k) {
+        double s2 = 0.0;
+        for (int r = 0; r < 6; ++r) s2 += Ea[r * d + k] * v[6 * pa + r];
+        A.t[k] += s2;
+      }
+    }
+  }
+  for (int sidx = 0; sidx < nslots; ++sidx) {
+    double* o = buf + 9 * (size_t)sidx;
+    for (int k = 0; k < 9; ++k) o[k] = (sh_var[sidx] >= 0) ? D.acc[D.lidx[sh_var[sidx]]].t[k] : 0.0;
+  }
+}
+// alpha, beta from the all-reduced (gamma, delta) — Chronopoulos-Gear: beta = gamma / gamma_old, alpha = gamma / (delta - beta gamma /
+// alpha_old) — then p = u + beta p, s = w + beta s, x += alpha p, r -= alpha s.  Converged (gamma <= tol^2 gamma_0, or gamma == 0):
+// alpha = beta = 0, the iteration is a no-op.
+inline void Graph::pcg_scalars_update(const double* buf) {
+  const double gamma = buf[0], delta = buf[1];
+  double beta = 0.0, alpha;
+  if (D.gamma_old > 0.0) {
+    beta = gamma / D.gamma_old;
+    alpha = gamma / (delta - beta * gamma / D.alpha_old);
+  } else {
+    alpha = gamma / delta;
+    D.gamma0 = gamma;
+  }
+  if (!(gamma > 0.0) || gamma <= pcg_tol * pcg_tol * D.gamma0 || D.pcg_done) { alpha = 0.0; beta = 0.0; D.pcg_done = 1; }
+  else if (!(alpha > 0.0) || !(alpha < 1e300)) { alpha = 0.0; beta = 0.0; D.pcg_done = 2; }       // breakdown: not positive definite
+  else ++D.pcg_its;
+  if (gamma > 0.0) D.gamma_old = gamma;
+  if (alpha > 0.0) D.alpha_old = alpha;
+  D.gamma_last = gamma;
+  const int n = (int)D.u.size();
+  for (int i = 0; i < n; ++i) {
+    const double p = D.u[i] + beta * D.p[i];
+    const double s2 = D.w[i] + beta * D.s[i];
+    D.p[i] = p; D.s[i] = s2;
+    D.x[i] += alpha * p;
+    D.r[i] -= alpha * s2;
+  }
+}
+
 // phases and buffer layouts identical to slide_graph_dist_phase (include/slide_gpu.h)
 inline int Graph::dist_phase(int phase, double* buf) {
   const int nslots = (int)sh_var.size();
@@ -1004,6 +1086,7 @@ inline int Graph::dist_phase(int phase, double* buf) {
     }
     D.Hinv_all.assign((size_t)nl * 81, 0.0);
     D.Eall.assign(nl, {});
+    D.Fall.assign(nl, {});
     for (int l = 0; l < nl; ++l) {
       DLm& A = D.acc[l];
       const int d = var_dim(vars[D.lm_vars[l]].type);
@@ -1013,7 +1096,8 @@ inline int Graph::dist_phase(int phase, double* buf) {
       const int nf = (int)A.fac.size();
       std::vector<double>& E = D.Eall[l];
       E.assign((size_t)nf * 6 * d, 0.0);
-      std::vector<double> Fm((size_t)nf * 6 * d);
+      std::vector<double>& Fm = D.Fall[l];
+      Fm.assign((size_t)nf * 6 * d, 0.0);
       for (int a = 0; a < nf; ++a) {
         const LinFactor& L = D.lin[A.fac[a]];
         double* Ea = &E[(size_t)a * 6 * d];
@@ -1052,11 +1136,26 @@ inline int Graph::dist_phase(int phase, double* buf) {
         }
       }
     }
+    const bool joint = pcg_iters > 0 && nslots > 0;
     const CholProfile prof = chol_profile(S.data(), n, n);
+    if (joint) D.S0 = S;
     if (chol_lower(S.data(), n, n, P.num_threads, &prof) != 0) return -1;
     D.dp.assign(n, 0.0);
     for (int i = 0; i < n; ++i) D.dp[i] = -g[i];
     chol_solve_lower(S.data(), n, n, D.dp.data(), &prof);
+    if (joint) {
+      // PCG head (k_pcg_init): r = b, u = M^-1 b (the block solve just done), x = p = s = 0; t_l(u) goes into the exchange
+      D.prof = prof;
+      D.Lf.swap(S);
+      D.r.assign(n, 0.0);
+      for (int i = 0; i < n; ++i) D.r[i] = -g[i];
+      D.u = D.dp;
+      D.x.assign(n, 0.0); D.p.assign(n, 0.0); D.s.assign(n, 0.0); D.w.assign(n, 0.0);
+      D.gamma_old = D.alpha_old = D.gamma0 = D.gamma_last = 0.0;
+      D.pcg_done = 0; D.pcg_its = 0;
+      pcg_pack_tl(D.u, buf);
+      return 0;
+    }
     for (int p = 0; p < np; ++p)
       for (int k = 0; k < 6; ++k) vars[D.pose_vars[p]].delta[k] = D.dp[6 * p + k];
     for (int l = 0; l < nl; ++l) {
@@ -1076,6 +1175,293 @@ inline int Graph::dist_phase(int phase, double* buf) {
     for (int sidx = 0; sidx < nslots; ++sidx) {
       double* o = buf + 9 * (size_t)sidx;
       for (int k = 0; k < 9; ++k) o[k] = (sh_var[sidx] >= 0) ? D.acc[D.lidx[sh_var[sidx]]].t[k] : 0.0;
+    }
+    return 0;
+  }
+  if (phase == 31) {
+    // buf: the all-reduced t_l(u) of the shared slots.  w = S0 u - sum over own factors on shared landmarks F_f (t_sum - t_own)
+    // (k_pcg_tl_symv + k_pcg_cross), then the partial dot products (r, u), (w, u) -> buf[0 .. 1] (k_pcg_dots)
+    if (!(pcg_iters > 0 && nslots > 0) || D.S0.empty()) return -3;
+    const int n = (int)D.u.size();
+    for (int i = 0; i < n; ++i) D.w[i] = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const double* Si = &D.S0[(size_t)i * n];
+      double s2 = 0.0;
+      const double ui = D.u[i];
+      for (int k = D.prof.fnz[i]; k < i; ++k) { s2 += Si[k] * D.u[k]; D.w[k] += Si[k] * ui; }
+      D.w[i] += s2 + Si[i] * ui;
+    }
+    for (int sidx = 0; sidx < nslots; ++sidx) {
+      if (sh_var[sidx] < 0) continue;
+      const int l = D.lidx[sh_var[sidx]];
+      DLm& A = D.acc[l];
+      const int d = var_dim(vars[sh_var[sidx]].type);
+      double c[9];
+      for (int k = 0; k < d; ++k) c[k] = buf[9 * (size_t)sidx + k] - A.t[k];
+      for (size_t a = 0; a < A.fac.size(); ++a) {
+        const int pa = D.pidx[factors[A.fac[a]].v0];
+        const double* Fa = &D.Fall[l][a * 6 * d];
+        for (int r = 0; r < 6; ++r) {
+          double s2 = 0.0;
+          for (int k = 0; k < d; ++k) s2 += Fa[r * d + k] * c[k];
+          D.w[6 * pa + r] -= s2;
+        }
+      }
+    }
+    double gamma = 0.0, delta = 0.0;
+    for (int i = 0; i < n; ++i) { gamma += D.r[i] * D.u[i]; delta += D.w[i] * D.u[i]; }
+    buf[0] = gamma; buf[1] = delta;
+    return 0;
+  }
+  if (phase == 32 || phase == 33) {
+    // buf[0 .. 1]: the all-reduced (gamma, delta).  k_pcg_scalars + k_pcg_update; 32: u = M^-1 r, t_l(u) -> buf; 33 (last): the
+    // joint step replaces the block solve, dp = x, t_l(dp) -> buf (what phase 1 ends with when there is no joint solve)
+    if (!(pcg_iters > 0 && nslots > 0) || D.S0.empty()) return -3;
+    pcg_scalars_update(buf);
+    const int n = (int)D.u.size();
+    if (phase == 32) {
+      D.u = D.r;
+      chol_solve_lower(D.Lf.data(), n, n, D.u.data(), &D.prof);
+      pcg_pack_tl(D.u, buf);
+      return 0;
+    }
+    D.dp = D.x;
+    for (size_t p = 0; p < D.pose_vars.size(); ++p)
+      for (int k = 0; k < 6; ++k) vars[D.pose_vars[p]].delta[k] = D.dp[6 * p + k];
+    pcg_pack_tl(D.dp, buf);
+    return 0;
+  }
+  if (phase == 40) {
+    // after phase 0 (linearisation, per-landmark sums of the own factors).  buf: [m x m row-major | m] = this robot's contribution
+    // to the separator system (lower triangle) and its right-hand side, everything else zero; the caller sums over the robots.
+    if ((int)sep_off.size() != nslots + 1) return -3;
+    const int m = sep_off[nslots];
+    std::memset(buf, 0, sizeof(double) * ((size_t)m * m + 2 * (size_t)m));
+    const int np = (int)D.pose_vars.size(), nl = (int)D.lm_vars.size(), n = 6 * np;
+    std::vector<int> lm_sep(nl, -1);            // landmark -> global separator offset, or -1 (private)
+    for (int sidx = 0; sidx < nslots; ++sidx)
+      if (sh_var[sidx] >= 0) lm_sep[D.lidx[sh_var[sidx]]] = sep_off[sidx];
+    std::vector<double> S((size_t)n * n, 0.0), g(n, 0.0);
+    auto add_block = [&](int pi, int pj, const double* Ja, const double* Jb, int mm) {
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) {
+          double s2 = 0.0;
+          for (int r = 0; r < mm; ++r) s2 += Ja[r * 6 + a] * Jb[r * 6 + b];
+          S[(size_t)(6 * pi + a) * n + 6 * pj + b] += s2;
+        }
+    };
+    for (size_t i = 0; i < factors.size(); ++i) {
+      const Factor& f = factors[i];
+      const LinFactor& L = D.lin[i];
+      const int p0 = D.pidx[f.v0];
+      add_block(p0, p0, L.J0, L.J0, L.m);
+      for (int a = 0; a < 6; ++a) {
+        double s2 = 0.0;
+        for (int r = 0; r < L.m; ++r) s2 += L.J0[r * 6 + a] * L.r[r];
+        g[6 * p0 + a] += s2;
+      }
+      if (f.type == F_BETWEEN) {
+        const int p1 = D.pidx[f.v1];
+        add_block(p1, p1, L.J1, L.J1, L.m);
+        if (p1 >= p0) add_block(p1, p0, L.J1, L.J0, L.m); else add_block(p0, p1, L.J0, L.J1, L.m);
+        for (int a = 0; a < 6; ++a) {
+          double s2 = 0.0;
+          for (int r = 0; r < L.m; ++r) s2 += L.J1[r * 6 + a] * L.r[r];
+          g[6 * p1 + a] += s2;
+        }
+      }
+    }
+    // local separator columns in slot order
+    AR = ArrowState();
+    AR.n = n;
+    std::vector<int> lm_lcol(nl, -1);
+    for (int sidx = 0; sidx < nslots; ++sidx) {
+      if (sh_var[sidx] < 0) continue;
+      const int l = D.lidx[sh_var[sidx]], d = var_dim(vars[sh_var[sidx]].type);
+      lm_lcol[l] = (int)AR.lcol.size();
+      for (int k = 0; k < d; ++k) AR.lcol.push_back(sep_off[sidx] + k);
+    }
+    const int ma = AR.ma = (int)AR.lcol.size();
+    std::vector<double> B((size_t)n * ma, 0.0);       // B[row * ma + col]
+    D.Hinv_all.assign((size_t)nl * 81, 0.0);
+    D.Eall.assign(nl, {});
+    D.Fall.assign(nl, {});
+    for (int l = 0; l < nl; ++l) {
+      DLm& A = D.acc[l];
+      const int d = var_dim(vars[D.lm_vars[l]].type);
+      if (A.fac.empty()) continue;
+      const int nf = (int)A.fac.size();
+      std::vector<double>& E = D.Eall[l];
+      E.assign((size_t)nf * 6 * d, 0.0);
+      for (int a = 0; a < nf; ++a) {
+        const LinFactor& L = D.lin[A.fac[a]];
+        double* Ea = &E[(size_t)a * 6 * d];
+        for (int r = 0; r < 6; ++r)
+          for (int c = 0; c < d; ++c) {
+            double s2 = 0.0;
+            for (int k = 0; k < L.m; ++k) s2 += L.J0[k * 6 + r] * L.J1[k * d + c];
+            Ea[r * d + c] = s2;
+          }
+      }
+      if (lm_sep[l] >= 0) {
+        // separator landmark: its pose coupling goes into B_a, its own block and gradient into the separator contribution
+        const int c0 = lm_lcol[l], o = lm_sep[l];
+        for (int a = 0; a < nf; ++a) {
+          const int pa = D.pidx[factors[A.fac[a]].v0];
+          const double* Ea = &E[(size_t)a * 6 * d];
+          for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < d; ++c) B[(size_t)(6 * pa + r) * ma + c0 + c] += Ea[r * d + c];
+        }
+        for (int a = 0; a < d; ++a) {
+          for (int c = 0; c <= a; ++c) buf[(size_t)(o + a) * m + o + c] += A.H[a * d + c];
+          buf[(size_t)m * m + o + a] -= A.g[a];
+        }
+        continue;
+      }
+      double* Hinv = &D.Hinv_all[(size_t)l * 81];
+      if (!spd_inverse(A.H, d, Hinv)) return -2;
+      std::vector<double>& Fm = D.Fall[l];
+      Fm.assign((size_t)nf * 6 * d, 0.0);
+      for (int a = 0; a < nf; ++a) {
+        const double* Ea = &E[(size_t)a * 6 * d];
+        double* Fa = &Fm[(size_t)a * 6 * d];
+        for (int r = 0; r < 6; ++r)
+          for (int c = 0; c < d; ++c) {
+            double s2 = 0.0;
+            for (int k = 0; k < d; ++k) s2 += Ea[r * d + k] * Hinv[k * d + c];
+            Fa[r * d + c] = s2;
+          }
+      }
+      for (int a = 0; a < nf; ++a) {
+        const int pa = D.pidx[factors[A.fac[a]].v0];
+        const double* Fa = &Fm[(size_t)a * 6 * d];
+        for (int r = 0; r < 6; ++r) {
+          double s2 = 0.0;
+          for (int k = 0; k < d; ++k) s2 += Fa[r * d + k] * A.g[k];
+          g[6 * pa + r] -= s2;
+        }
+        for (int b = 0; b < nf; ++b) {
+          const int pb = D.pidx[factors[A.fac[b]].v0];
+          if (pb > pa) continue;
+          const double* Eb = &E[(size_t)b * 6 * d];
+          for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) {
+              double s2 = 0.0;
+              for (int k = 0; k < d; ++k) s2 += Fa[r * d + k] * Eb[c * d + k];
+              S[(size_t)(6 * pa + r) * n + 6 * pb + c] -= s2;
+            }
+        }
+      }
+    }
+    AR.prof = chol_profile(S.data(), n, n);
+    if (chol_lower(S.data(), n, n, P.num_threads, &AR.prof) != 0) return -1;
+    AR.L.swap(S);
+    const double* Lf = AR.L.data();
+    // y_p = L^-1 b_p,  W = L^-1 B_a  (forward substitutions inside the row profile; a column starts at its first non-zero row)
+    AR.yp.assign(n, 0.0);
+    for (int i = 0; i < n; ++i) {
+      const double* Li = Lf + (size_t)i * n;
+      double s2 = -g[i];
+      for (int k = AR.prof.fnz[i]; k < i; ++k) s2 -= Li[k] * AR.yp[k];
+      AR.yp[i] = s2 / Li[i];
+    }
+    AR.first_row.assign(ma, n);
+    for (int i = n - 1; i >= 0; --i)
+      for (int c = 0; c < ma; ++c)
+        if (B[(size_t)i * ma + c] != 0.0) AR.first_row[c] = i;
+    AR.W.swap(B);
+    double* W = AR.W.data();
+    for (int i = 0; i < n; ++i) {
+      const double* Li = Lf + (size_t)i * n;
+      double* Wi = W + (size_t)i * ma;
+      for (int k = AR.prof.fnz[i]; k < i; ++k) {
+        const double lik = Li[k];
+        if (lik == 0.0) continue;
+        const double* Wk = W + (size_t)k * ma;
+        for (int c = 0; c < ma; ++c) Wi[c] -= lik * Wk[c];
+      }
+      const double inv = 1.0 / Li[i];
+      for (int c = 0; c < ma; ++c) Wi[c] *= inv;
+    }
+    // contribution: C_a - W^T W (lower triangle, global coordinates), right-hand side -g_l - W^T y_p
+    const int nthreads = P.num_threads;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(nthreads)
+    for (int a = 0; a < ma; ++a) {
+      const int ga = AR.lcol[a];
+      std::vector<double> col(n);
+      for (int i = 0; i < n; ++i) col[i] = W[(size_t)i * ma + a];
+      for (int b = 0; b <= a; ++b) {
+        const int gb = AR.lcol[b];
+        double s2 = 0.0;
+        for (int i = std::max(AR.first_row[a], AR.first_row[b]); i < n; ++i) s2 += col[i] * W[(size_t)i * ma + b];
+        buf[(size_t)ga * m + gb] -= s2;         // (slots in increasing order: ga >= gb)
+      }
+      double s2 = 0.0;
+      for (int i = AR.first_row[a]; i < n; ++i) s2 += col[i] * AR.yp[i];
+      buf[(size_t)m * m + ga] -= s2;
+    }
+    return 0;
+  }
+  if (phase == 41 || phase == 42) {
+    // buf: [summed separator system | summed right-hand side | solution].  41: factor and solve it (the solution is left behind the
+    // right-hand side for the other robots of the process, which run 42), then back-substitute: poses, private landmarks, retract.
+    if ((int)sep_off.size() != nslots + 1) return -3;
+    const int m = sep_off[nslots], n = AR.n, ma = AR.ma;
+    double* xs = buf + (size_t)m * m + m;
+    if (phase == 41) {
+      std::vector<double> Cs(buf, buf + (size_t)m * m);
+      if (m > 0 && chol_lower(Cs.data(), m, m, P.num_threads) != 0) return -4;
+      for (int i = 0; i < m; ++i) xs[i] = buf[(size_t)m * m + i];
+      if (m > 0) chol_solve_lower(Cs.data(), m, m, xs);
+    }
+    // L^T dp = y_p - W x_s
+    D.dp.assign(n, 0.0);
+    const double* W = AR.W.data();
+    for (int i = 0; i < n; ++i) {
+      double s2 = AR.yp[i];
+      const double* Wi = W + (size_t)i * ma;
+      for (int c = 0; c < ma; ++c) s2 -= Wi[c] * xs[AR.lcol[c]];
+      D.dp[i] = s2;
+    }
+    const double* Lf = AR.L.data();
+    for (int i = n - 1; i >= 0; --i) {
+      const double s2 = D.dp[i] / Lf[(size_t)i * n + i];
+      D.dp[i] = s2;
+      for (int k = AR.prof.fnz[i]; k < i; ++k) D.dp[k] -= Lf[(size_t)i * n + k] * s2;
+    }
+    for (size_t p = 0; p < D.pose_vars.size(); ++p)
+      for (int k = 0; k < 6; ++k) vars[D.pose_vars[p]].delta[k] = D.dp[6 * p + k];
+    std::vector<int> lm_sep(D.lm_vars.size(), -1);
+    for (int sidx = 0; sidx < nslots; ++sidx)
+      if (sh_var[sidx] >= 0) lm_sep[D.lidx[sh_var[sidx]]] = sep_off[sidx];
+    for (size_t l = 0; l < D.lm_vars.size(); ++l) {
+      DLm& A = D.acc[l];
+      Var& v = vars[D.lm_vars[l]];
+      const int d = var_dim(v.type);
+      if (lm_sep[l] >= 0) { for (int k = 0; k < d; ++k) v.delta[k] = xs[lm_sep[l] + k]; continue; }
+      if (A.fac.empty()) { for (int k = 0; k < d; ++k) v.delta[k] = 0.0; continue; }
+      double rhs[9];
+      for (int k = 0; k < d; ++k) rhs[k] = A.g[k];
+      for (size_t a = 0; a < A.fac.size(); ++a) {
+        const int pa = D.pidx[factors[A.fac[a]].v0];
+        const double* Ea = &D.Eall[l][a * 6 * d];
+        for (int k = 0; k < d; ++k) {
+          double s2 = 0.0;
+          for (int r = 0; r < 6; ++r) s2 += Ea[r * d + k] * D.dp[6 * pa + r];
+          rhs[k] += s2;
+        }
+      }
+      const double* Hinv = &D.Hinv_all[l * 81];
+      for (int k = 0; k < d; ++k) {
+        double s2 = 0.0;
+        for (int c = 0; c < d; ++c) s2 += Hinv[k * d + c] * rhs[c];
+        v.delta[k] = -s2;
+      }
+    }
+    estimate.resize(vars.size());
+    for (size_t i = 0; i < vars.size(); ++i) {
+      var_retract(vars[i], vars[i].delta, P.pose_chart, estimate[i]);
+      std::memcpy(estimate[i].delta, vars[i].delta, sizeof(vars[i].delta));
     }
     return 0;
   }

@@ -169,6 +169,22 @@ class OracleGraph:
             raise RuntimeError(f"oracle dist_phase {phase} failed: {rc}")
         return rc
 
+    def set_pcg(self, iterations, tol=0.0):
+        """Joint solve of the sharded pass (dist_phase 31 / 32 / 33): upper bound on the PCG iterations and the relative tolerance
+        on sqrt(r^T M^-1 r) below which the iterations become no-ops (0: every iteration counts)."""
+        self.L.orc_graph_set_pcg(self.h, C.c_int(int(iterations)), C.c_double(float(tol)))
+
+    def pcg_stats(self):
+        out = np.zeros(4)
+        self.L.orc_graph_pcg_stats(self.h, _p(out))
+        return dict(iterations=int(out[0]), gamma_first=out[1], gamma_last=out[2], state=int(out[3]))
+
+    def set_separator(self, offsets):
+        """Exact joint step (dist_phase 40 / 41 / 42): offsets[slot] = offset of the shared slot's tangent coordinates in the separator
+        system of all shared landmarks (len n_slots + 1, the same on every rank)."""
+        off = _i(offsets)
+        self.L.orc_graph_set_separator(self.h, _p(off), C.c_int(len(off)))
+
     def keep_factor(self, on=True):
         self.L.orc_graph_keep_factor(self.h, C.c_int(int(on)))
 

@@ -101,6 +101,22 @@ def shared_slots(gid, n_global, rank):
     return np.array(cls_out, np.int32), np.array(idx_out, np.int64), np.array(own_out, np.int32)
 
 
+SLOT_DIM = {0: 7, 1: 9, 2: 3}        # tangent dimension per class: cylinder [ray, root, radius], cube [pose, scale], point
+
+
+def separator_offsets(gid, n_global):
+    """Offsets of the shared slots' tangent coordinates in the separator system of the exact joint step (len n_slots + 1, the same
+    on every rank; slot order = shared_slots' order: by class, then by global id)."""
+    off = [0]
+    for cls in range(3):
+        count = np.zeros(n_global[cls], np.int32)
+        for g in gid:
+            count[g[cls]] += 1
+        for _ in np.nonzero(count >= 2)[0]:
+            off.append(off[-1] + SLOT_DIM[cls])
+    return np.array(off, np.int32)
+
+
 class DistributedGraph:
     def __init__(self, shard, comm, rank, world):
         self.shard, self.comm, self.rank, self.world = shard, comm, rank, world
@@ -177,10 +193,13 @@ def setup_local_shards(shards, matcher, base=None, rank=0, world=1, thresh=(2.0,
     else:
         alloc = lambda n: np.zeros(n)
         handle = lambda b: b
+    sep_off = separator_offsets(gid, n_global)
     for t, sh in enumerate(shards):
         cls, idx, own = shared_slots(gid, n_global, rank * R + t)
         n_slots = len(cls)
         sh.graph.set_shared(cls, idx, own)
+        if hasattr(sh.graph, "set_separator"):
+            sh.graph.set_separator(sep_off)
         bufs.append(alloc(max(n_slots, 1) * 54))
     # value broadcast: every replica of a shared landmark adopts its owner's value (phase 10, all-reduce(sum) of 15 / slot, phase 11)
     for t, sh in enumerate(shards):
@@ -199,7 +218,7 @@ def setup_local_shards(shards, matcher, base=None, rank=0, world=1, thresh=(2.0,
             torch.cuda.synchronize()
     for t, sh in enumerate(shards):
         sh.graph.dist_phase(11, handle(bufs[t]))
-    return bufs, dict(n_slots=n_slots, n_global=n_global)
+    return bufs, dict(n_slots=n_slots, n_global=n_global, sep_dim=int(sep_off[-1]), sep_off=sep_off)
 
 
 class PassDriver:
@@ -211,21 +230,34 @@ class PassDriver:
     pass).  Without one (oracle shards on the CPU, or un-batched HIP shards): the same sequence spelled out with dist_phase calls
     and host-side sums — the CPU rehearsal of exactly this control flow."""
 
-    def __init__(self, shards, bufs, n_slots, batch=None, base=None, world=1, device=None, pcg_iters=0):
+    def __init__(self, shards, bufs, n_slots, batch=None, base=None, world=1, device=None, pcg_iters=0, pcg_tol=0.0, arrow=False, sep_dim=0):
         self.shards, self.bufs, self.n_slots, self.batch, self.base, self.world, self.device = shards, bufs, n_slots, batch, base, world, device
         self.ptrs = [b.data_ptr() for b in bufs] if device is not None else None
         self.passes = 0
         self.stream_ordered = True      # False (diagnostic): host-synchronous collectives
         self.force_parts = False        # True (rehearsal): the cut pass + collectives even when the job is this process alone
-        # joint solve: PCG iterations on the global reduced system after the factorisations (0: block-Jacobi over robots).  HIP
-        # shards only — the oracle's replica solves the joint graph directly, which is what the joint solve is checked against.
+        # joint solve: PCG on the global reduced system after the factorisations (0: block-Jacobi over robots).  pcg_iters is the
+        # upper bound per pass; with pcg_tol > 0 the solve ends as soon as sqrt(r^T M^-1 r) has fallen to pcg_tol times its first
+        # value (every rank sees the same all-reduced scalars, so every rank takes the same decision).
         self.pcg_iters = pcg_iters if n_slots > 0 else 0
-        if pcg_iters:
-            if batch is not None:
-                batch.set_pcg(pcg_iters)
-            else:
-                for sh in shards:
-                    sh.graph.set_pcg(pcg_iters)
+        self.pcg_tol = float(pcg_tol)
+        self.pcg_history = []           # iterations that did work, per pass
+        # EXACT joint step ("arrow"): the shared landmarks stay as the separator of the joint graph; every robot eliminates its
+        # private landmarks and poses, ONE all-reduce(sum) of the separator system (sep_dim^2 + sep_dim doubles), every rank solves it
+        # and substitutes back — the Gauss-Newton step of the reference's full replica, no inner iteration.
+        self.arrow = bool(arrow) and n_slots > 0
+        self.sep_dim = int(sep_dim)
+        self.sbufs = None
+        if self.arrow:
+            self.pcg_iters = 0
+            if device is None:
+                m = self.sep_dim
+                self.sbufs = [np.zeros(m * m + 2 * m) for _ in shards]
+        if batch is not None:           # (always pushed, zero included: a batch or graph may still hold an earlier driver's setting)
+            batch.set_pcg(self.pcg_iters, self.pcg_tol)
+        else:
+            for sh in shards:
+                sh.graph.set_pcg(self.pcg_iters, self.pcg_tol)
 
     def _exchange(self, count):
         """all-reduce(sum) of buffer 0's first `count` doubles across the processes, ordered behind the batch's stream."""
@@ -273,13 +305,38 @@ class PassDriver:
                 for sh, b in zip(self.shards, self.bufs):
                     sh.graph.dist_phase(ph, h(b))
             each(0)
+            if self.arrow:
+                m = self.sep_dim
+                for sh, b in zip(self.shards, self.sbufs):
+                    sh.graph.dist_phase(40, b)
+                tot = self.sbufs[0]
+                for b in self.sbufs[1:]:
+                    tot[:m * m + m] += b[:m * m + m]
+                if self.world > 1:
+                    self.base.all_reduce(tot, m * m + m)
+                self.shards[0].graph.dist_phase(41, tot)         # (factors and solves the separator, leaves the solution in the buffer)
+                for sh in self.shards[1:]:
+                    sh.graph.dist_phase(42, tot)
+                self.passes += 1
+                return
             self._all(n54)
             each(1)
+            gamma0, done = None, 0
             for it in range(K):
                 self._all(n9)
                 each(31)
                 self._all(2)
-                each(33 if it == K - 1 else 32)
+                gamma = float(self.bufs[0][0])
+                if gamma0 is None:
+                    gamma0 = gamma
+                conv = (not gamma > 0.0) or (self.pcg_tol > 0.0 and gamma <= self.pcg_tol ** 2 * gamma0)
+                done += 0 if conv else 1
+                last = conv or it == K - 1
+                each(33 if last else 32)
+                if last:
+                    break
+            if K:
+                self.pcg_history.append(done)
             self._all(n9)
             each(2)
         self.passes += 1
