@@ -178,6 +178,28 @@ void* slide_chol_batch_stream(slide_chol_batch_t* b);
  * with every all-reduce on the first max(1, ..) doubles of the exchange buffer. */
 int slide_chol_batch_set_pcg(slide_chol_batch_t* b, int iterations);
 int slide_graph_set_pcg(slide_graph_t* g, int iterations);
+/* Residual-based end of that iteration: `iterations` stays the upper bound per pass; with tol > 0 the solve counts as converged once
+ * gamma = r^T M^-1 r has fallen to tol^2 times its value in the first iteration (never later than at eps^2) — the remaining iterations
+ * of the pass are no-ops (alpha = beta = 0), so captured launch sequences keep their shape and every rank takes the same decision from
+ * the same all-reduced scalars.  Call before slide_*_set_pcg or repeat that call. */
+int slide_chol_batch_set_pcg_tolerance(slide_chol_batch_t* b, double tol);
+int slide_graph_set_pcg_tolerance(slide_graph_t* g, double tol);
+/* EXACT joint Gauss-Newton step over the robots ("arrow" solve) — what the reference's replica computes with ONE solve() on a graph
+ * holding every robot (graph.cpp:260-272 on the replica of sloamNode.cpp:912-1002), without an inner iteration.  The landmarks of the
+ * shared slots are not eliminated into the robots' pose systems: they stay as the SEPARATOR of the joint graph.  Every robot eliminates
+ * its private landmarks, factors its banded pose system with the separator's coupling rows riding below the band (the step kernels),
+ * and forms its Schur complement onto the separator with one FP64-MFMA product; the sum over the robots — ONE all-reduce(sum) of the
+ * separator buffer per pass for a job that spans GPUs — is the Schur complement of the JOINT graph onto the shared landmarks; every rank
+ * factors it (dense, the same step kernels), substitutes back through its bands and retracts.
+ *   slide_graph_set_separator: off[i] = offset of shared slot i's tangent coordinates (cylinder 7, cube 9, point 3, in slot order) in
+ *     the separator system, n = n_slots + 1 entries, identical on every rank; after slide_graph_set_shared.
+ *   slide_chol_batch_set_exact_joint(b, 1, sep_buf, len): passes of the batch take the exact joint step (batched passes only; the PCG
+ *     setting is ignored).  sep_buf: device buffer of slide_chol_batch_sep_buffer_len(m) doubles, m = off[n_slots] — the caller's when
+ *     it all-reduces it between the parts, or NULL (allocated by the batch).
+ * A cut pass then reads   part 0 | all-reduce(sum) of sep_buf[0 .. len) on slide_chol_batch_stream() | part 2. */
+int slide_graph_set_separator(slide_graph_t* g, const int32_t* off, int n);
+int slide_chol_batch_set_exact_joint(slide_chol_batch_t* b, int on, double* sep_buf, long long len);
+long long slide_chol_batch_sep_buffer_len(int m);
 /* Scalars of the last joint solve this graph took part in: out8 = {gamma of the last but one iteration, alpha of it, alpha, beta of the
  * last iteration, gamma of the FIRST iteration, gamma of the last; 0, 0} with gamma = r^T M^-1 r (M = the robots' own factors), summed
  * over all robots: gamma_last / gamma_first is the squared reduction of the preconditioned residual. */

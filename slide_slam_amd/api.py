@@ -28,7 +28,7 @@ EXPORTS = [
     "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
     "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
-    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
+    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_chol_batch_set_pcg_tolerance", "slide_graph_set_pcg_tolerance", "slide_graph_set_separator", "slide_chol_batch_set_exact_joint", "slide_chol_batch_sep_buffer_len", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
     "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
     "slide_dense_spd_solve", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device", "slide_assoc_sweep_batch",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
@@ -250,9 +250,16 @@ class SlideGraph:
         """Share the dense factor + solve of phase 1 with the other graphs of `batch` (CholBatch; None leaves it)."""
         _check(self.L.slide_graph_join_chol_batch(self.h, C.c_void_p(batch.h if batch is not None else None), C.c_int(slot)))
 
-    def set_pcg(self, iterations):
-        """Un-batched passes: PCG iterations of the joint solve (dist_phase 31 / 32 / 33 between phases 1 and 2); 0 = block solves only."""
+    def set_pcg(self, iterations, tol=0.0):
+        """Un-batched passes: PCG iterations of the joint solve (dist_phase 31 / 32 / 33 between phases 1 and 2); 0 = block solves only.
+        tol > 0: iterations past a relative reduction of sqrt(r^T M^-1 r) by tol are no-ops."""
+        _check(self.L.slide_graph_set_pcg_tolerance(self.h, C.c_double(float(tol))))
         _check(self.L.slide_graph_set_pcg(self.h, C.c_int(iterations)))
+
+    def set_separator(self, offsets):
+        """Exact joint step: offsets of the shared slots' tangent coordinates in the separator system (n_slots + 1 ints)."""
+        off = np.ascontiguousarray(offsets, dtype=np.int32)
+        _check(self.L.slide_graph_set_separator(self.h, _p(off), C.c_int(len(off))))
 
     def chi2(self):
         """Sum of squared whitened residuals at the current estimate: dict(total, prior, between, landmark)."""
@@ -317,9 +324,22 @@ class CholBatch:
         arr = (C.c_void_p * len(buf_ptrs))(*[int(p) for p in buf_ptrs])
         return _check(self.L.slide_chol_batch_pass(C.c_void_p(self.h), arr))
 
-    def set_pcg(self, iterations):
-        """PCG iterations of the joint solve after the factorisations (0 = every robot's own block solve only)."""
+    def set_pcg(self, iterations, tol=0.0):
+        """PCG iterations of the joint solve after the factorisations (0 = every robot's own block solve only); tol > 0: iterations
+        past a relative reduction of sqrt(r^T M^-1 r) by tol are no-ops."""
+        _check(self.L.slide_chol_batch_set_pcg_tolerance(C.c_void_p(self.h), C.c_double(float(tol))))
         _check(self.L.slide_chol_batch_set_pcg(C.c_void_p(self.h), C.c_int(iterations)))
+
+    def set_exact_joint(self, on=True, sep_ptr=0, sep_len=0):
+        """Passes take the EXACT joint Gauss-Newton step (shared landmarks as the separator of the joint graph, slide_gpu.h);
+        sep_ptr / sep_len: the caller's device buffer for the separator system (sep_buffer_len(m) doubles) or 0."""
+        _check(self.L.slide_chol_batch_set_exact_joint(C.c_void_p(self.h), C.c_int(int(on)), C.c_void_p(int(sep_ptr) or None), C.c_longlong(int(sep_len))))
+
+    @staticmethod
+    def sep_buffer_len(m):
+        L = lib()
+        L.slide_chol_batch_sep_buffer_len.restype = C.c_longlong
+        return int(L.slide_chol_batch_sep_buffer_len(C.c_int(int(m))))
 
     def pass_part(self, buf_ptrs, part):
         """Part 0 / 1 / 2 of the pass cut at its two exchanges (jobs that span GPUs): the caller's all-reduce of buffer 0 goes onto

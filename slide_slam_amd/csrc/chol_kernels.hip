@@ -144,7 +144,12 @@ __device__ __forceinline__ void b_quadrant(double* __restrict__ S, int ld, const
 // Profile (envelope) of the factor: the launches enumerate rows / columns up to a VIRTUAL size Tv <= T — real tile rows 0 .. Tv-1, the
 // right-hand-side row as virtual row Tv — and map virtual row Tv to the physical tile row T.  TvB = profile of panel kb-1 (the rank-128
 // pass), TvX = profile of panel k-1 (the column items); tiles beyond hold zeros and get zero contributions (launch_chol_step).
-__device__ __forceinline__ BItem b_decode(int g, int nItems, int nR, int g0, int k, int kb, int T, int TvB, int TvX, int nP, long long nG, int wave) {
+// Border (nbr > 0, the exact joint step of several robots, host_graph.hip "arrow"): nbr further row tiles ride below the profile like
+// the right-hand side does — virtual rows Tv .. Tv + nbr - 1 are the physical tile rows T .. T + nbr - 1 (the coupling of the band's
+// columns to the separator variables, W^T = B^T L^-T after the steps), virtual row Tv + nbr the right-hand side at physical row T + nbr.
+// The steps never touch border COLUMNS: the border x border block is one product at the end (k_border_syrk).
+__device__ __forceinline__ BItem b_decode(int g, int nItems, int nR, int g0, int k, int kb, int T, int TvB, int TvX, int nP, long long nG, int wave,
+                                          int nbr) {
   BItem it;
   it.ok = false; it.i = it.j = it.pcb = 0; it.ks = 32;
   if (g >= nItems) return it;
@@ -157,15 +162,15 @@ __device__ __forceinline__ BItem b_decode(int g, int nItems, int nR, int g0, int
     it.i = kb + 1 + 2 * bi + (int)(tt & 1);
     it.j = kb + 1 + 2 * bj + (wave >> 2);
     it.pcb = kb - 2;
-    it.ok = !(it.i > TvB || it.j > TvB - 1 || it.i < it.j);
-    if (it.i == TvB) it.i = T;
+    it.ok = !(it.i > TvB + nbr || it.j > TvB - 1 || it.i < it.j);
+    if (it.i >= TvB) it.i = T + (it.i - TvB);
   } else {
     const int c = g - nR;
     it.j = k + 1;
     it.i = k + 1 + 2 * c + (wave >> 2);
     it.pcb = k - 1; it.ks = 16;
-    it.ok = !(it.i > TvX || it.j > TvX - 1);
-    if (it.i == TvX) it.i = T;
+    it.ok = !(it.i > TvX + nbr || it.j > TvX - 1);
+    if (it.i >= TvX) it.i = T + (it.i - TvX);
   }
   return it;
 }
@@ -601,7 +606,7 @@ __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld,
 // streams it, see bwd_chain_body): tile (i, k), k < i < T, at 4096 * (k (T-1) - k (k-1) / 2 + i - k - 1)
 __device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int k, int T, int TvA, int ia, int half, double* __restrict__ Ld,
                                             double* __restrict__ Winv, int* status, ALds& L, float* __restrict__ L32) {
-  const int it = (k + 1 + ia == TvA) ? T : k + 1 + ia;      // rows k+1 .. TvA-1 of the profile, then the right-hand-side row
+  const int it = (k + 1 + ia >= TvA) ? T + (k + 1 + ia - TvA) : k + 1 + ia;      // rows k+1 .. TvA-1 of the profile, then the border rows and the right-hand-side row
   float* L32t = (L32 && it < T) ? L32 + ((size_t)k * (T - 1) - (size_t)k * (k - 1) / 2 + (it - k - 1)) * (NB * NB) : nullptr;
   if (k > 0) step_type_a_impl<1>(S, ld, k, ia, it, half, Ld, Winv, status, L, L32t);
   else step_type_a_impl<0>(S, ld, k, ia, it, half, Ld, Winv, status, L, L32t);
@@ -614,10 +619,10 @@ __device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int 
 __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Ld,
                                                    double* __restrict__ Winv, int* status, int* __restrict__ ctr, int kb, int nP,
                                                    int g0, int g1, int nX, int a_joins, int a_split, float* __restrict__ L32,
-                                                   int TvA, int TvB, int TvX) {
+                                                   int TvA, int TvB, int TvX, int nbr) {
   __shared__ ALds L;
   __shared__ int s_g;
-  const int nA = (TvA - k) << a_split;      // a_split: two type-A workgroups per tile, 32 panel rows each (A-bound launches: the CUs are there)
+  const int nA = (TvA - k + nbr) << a_split;      // a_split: two type-A workgroups per tile, 32 panel rows each (A-bound launches: the CUs are there)
   if (blockIdx.x == 0 && threadIdx.x == 0) ctr[k + 1] = 0;
   if ((int)blockIdx.x < nA) {
     step_type_a(S, ld, k, T, TvA, (int)blockIdx.x >> a_split, a_split ? (int)(blockIdx.x & 1) : -1, Ld, Winv, status, L, L32);
@@ -633,7 +638,7 @@ __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ S, int l
     __syncthreads();
     const int g = __builtin_amdgcn_readfirstlane(s_g);
     if (g >= nItems) break;
-    const BItem it = b_decode(g, nItems, nR, g0, k, kb, T, TvB, TvX, nP, nG, wave);
+    const BItem it = b_decode(g, nItems, nR, g0, k, kb, T, TvB, TvX, nP, nG, wave, nbr);
     if (!it.ok) continue;
     if (it.ks == 32) b_quadrant<32>(S, ld, it, wave & 3);
     else b_quadrant<16>(S, ld, it, wave & 3);
@@ -649,6 +654,7 @@ struct CholBatchArgs {
   float* L32[CHOL_BATCH_MAX];
   int TvA[CHOL_BATCH_MAX], TvB[CHOL_BATCH_MAX], TvX[CHOL_BATCH_MAX];      // virtual sizes of the step (profile), see b_decode
   int nP[CHOL_BATCH_MAX], g0[CHOL_BATCH_MAX], g1[CHOL_BATCH_MAX], nX[CHOL_BATCH_MAX], a_split[CHOL_BATCH_MAX];
+  int nbr[CHOL_BATCH_MAX];             // border row tiles below the profile (b_decode)
   int a_base[CHOL_BATCH_MAX + 1];      // prefix sums of the type-A workgroup counts
   int b_base[CHOL_BATCH_MAX + 1];      // prefix sums of the type-B item counts
 };
@@ -678,7 +684,7 @@ __global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int 
     while (g >= A.b_base[r + 1]) ++r;
     const int gl = g - A.b_base[r], nR = A.g1[r] - A.g0[r];
     const long long nG = (long long)A.nP[r] * (A.nP[r] + 1) / 2;
-    const BItem it = b_decode(gl, nR + A.nX[r], nR, A.g0[r], k, kb, A.T[r], A.TvB[r], A.TvX[r], A.nP[r], nG, wave);
+    const BItem it = b_decode(gl, nR + A.nX[r], nR, A.g0[r], k, kb, A.T[r], A.TvB[r], A.TvX[r], A.nP[r], nG, wave, A.nbr[r]);
     if (!it.ok) continue;
     if (it.ks == 32) b_quadrant<32>(A.S[r], A.ld[r], it, wave & 3);
     else b_quadrant<16>(A.S[r], A.ld[r], it, wave & 3);
@@ -694,11 +700,11 @@ extern "C" void slide_debug_chain_stamps(unsigned long long* out) { (void)hipMem
 // whose workgroups poll the entries of the blocks they depend on ("flag in data": one round trip per link of the chain).
 constexpr unsigned long long BWD_SENT = CHAIN_SENTINEL;      // (kernels.hpp: k_pcg_update pre-fills the forward chain's output with it)
 
-__global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, double* __restrict__ yv, double* __restrict__ dp, int* status) {
+__global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, int Tr, double* __restrict__ yv, double* __restrict__ dp, int* status) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0) status[4] = 0;            // ticket counter of the chained backward substitution that follows
   if (c < T * NB) {
-    yv[c] = S[(size_t)c * ld + (size_t)T * NB];
+    yv[c] = S[(size_t)c * ld + (size_t)Tr * NB];      // (Tr: tile row of the right-hand side, T + border rows)
     dp[c] = __longlong_as_double((long long)BWD_SENT);
   }
 }
@@ -1322,14 +1328,127 @@ void launch_pose_covariance(const double* S, int ld, int T, const double* Ld, co
   hipLaunchKernelGGL(k_cov_gram, dim3(1), dim3(256), 0, s, Y, nT, row0 / NB * NB, cov36);
 }
 
+// ---- the border of a bordered system (exact joint step of several robots) --------------------------------------------------------------
+// After the steps over the band's T block columns the nbr border row tiles hold W^T = B^T L^-T (B: coupling of the poses to the
+// separator variables) and the right-hand-side row y^T = (L^-1 b)^T.  The Schur complement of the band onto the separator,
+//     bord(i, j) -= sum_c W^T(i, c) W^T(j, c)^T          i >= j border tile rows, i = nbr: the right-hand-side row (b_s - W^T y),
+// is ONE product over the T column blocks — a real GEMM (K = 64 T), every output tile independent: one workgroup per 64x64 tile, four
+// waves with a 32x32 quadrant each (the quadrant of b_quadrant: four 16x16 accumulators, operands as 16-byte loads three k-steps
+// ahead), C read and written once.  bfirst[i]: first column block in which border tile row i can be non-zero (a landmark first seen
+// late in the trajectory has an all-zero W^T row up to there): the sum starts at max(bfirst[i], bfirst[j]).
+struct SyrkArgs {
+  int n;
+  const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX]; int nbr[CHOL_BATCH_MAX];
+  double* bord[CHOL_BATCH_MAX]; int ldb[CHOL_BATCH_MAX]; const int* bfirst[CHOL_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
+  const int r = blockIdx.z, ib = blockIdx.x, jb = blockIdx.y;
+  const int nbr = A.nbr[r];
+  if (ib > nbr || jb >= nbr || ib < jb) return;
+  const int T = A.T[r], ld = A.ld[r], ldb = A.ldb[r];
+  int c0 = 0;
+  if (A.bfirst[r]) c0 = max(A.bfirst[r][ib], A.bfirst[r][jb]);
+  if (c0 >= T) return;
+  const double* S = A.S[r];
+  const int wq = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  const int ch = (wq >> 1) & 1, rh = wq & 1;      // column half, row half of the tile
+  const double* pjh = S + (size_t)(c0 * NB + lk) * ld + (size_t)(T + jb) * NB + 32 * ch + 2 * lr;
+  const double* pih = S + (size_t)(c0 * NB + lk) * ld + (size_t)(T + ib) * NB + 32 * rh + 2 * lr;
+  double* cbh = A.bord[r] + (size_t)(jb * NB + 32 * ch + 2 * lk) * ldb + (size_t)ib * NB + 32 * rh + 2 * lr;
+  v4d acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const v2d c2 = *(const v2d*)(cbh + (size_t)(8 * q + a) * ldb);
+      acc[a][0][q] = c2[0]; acc[a][1][q] = c2[1];
+    }
+  const int KS = (T - c0) * 16;                   // k-steps of four columns (a multiple of 16)
+  constexpr int RD = 4;
+  v2d pa[RD], pb[RD];
+#pragma unroll
+  for (int pre = 0; pre < RD - 1; ++pre) {
+    const size_t off = (size_t)(4 * pre) * ld;
+    pa[pre] = *(const v2d*)(pjh + off);
+    pb[pre] = *(const v2d*)(pih + off);
+  }
+  for (int ks0 = 0; ks0 < KS; ks0 += RD) {
+#pragma unroll
+    for (int u = 0; u < RD; ++u) {
+      const int ks = ks0 + u;
+      if (ks + RD - 1 < KS) {
+        const size_t off = (size_t)(4 * (ks + RD - 1)) * ld;
+        pa[(u + RD - 1) % RD] = *(const v2d*)(pjh + off);
+        pb[(u + RD - 1) % RD] = *(const v2d*)(pih + off);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const double na = -pa[u][a];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = mfma_f64(na, pb[u][b], acc[a][b]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v2d c2;
+      c2[0] = acc[a][0][q]; c2[1] = acc[a][1][q];
+      *(v2d*)(cbh + (size_t)(8 * q + a) * ldb) = c2;
+    }
+}
+void launch_border_syrk(const CholSystem* d, int n, hipStream_t s) {
+  SyrkArgs A{};
+  A.n = n;
+  int nb = 0;
+  for (int i = 0; i < n; ++i) {
+    A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.nbr[i] = d[i].nbr; A.bord[i] = d[i].bord; A.ldb[i] = d[i].ldb; A.bfirst[i] = d[i].bfirst;
+    nb = d[i].nbr > nb ? d[i].nbr : nb;
+  }
+  if (nb > 0) hipLaunchKernelGGL(k_border_syrk, dim3(nb + 1, nb, n), dim3(256), 0, s, A);
+}
+// y -= W x_loc before the backward substitution of the band (x_loc: the separator's solution in the system's own border order, zeros
+// in the padding): one wave per column of the band, lanes over the border rows (contiguous down a column of S)
+struct BorderApplyArgs {
+  int n;
+  const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX]; int nbr[CHOL_BATCH_MAX];
+  double* yv[CHOL_BATCH_MAX]; const double* x[CHOL_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void k_border_apply(BorderApplyArgs A) {
+  const int r = blockIdx.z;
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (col >= A.T[r] * NB) return;
+  const int nrow = A.nbr[r] * NB;
+  const double* w = A.S[r] + (size_t)col * A.ld[r] + (size_t)A.T[r] * NB;
+  const double* x = A.x[r];
+  double acc = 0.0;
+  for (int q = lane; q < nrow; q += 64) acc += w[q] * x[q];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  if (lane == 0) A.yv[r][col] -= acc;
+}
+void launch_border_apply(const CholSystem* d, int n, const double* const* xloc, hipStream_t s) {
+  BorderApplyArgs A{};
+  A.n = n;
+  int Tmax = 0;
+  for (int i = 0; i < n; ++i) {
+    A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.nbr[i] = d[i].nbr; A.yv[i] = d[i].yv; A.x[i] = xloc[i];
+    Tmax = d[i].T > Tmax ? d[i].T : Tmax;
+  }
+  if (Tmax > 0) hipLaunchKernelGGL(k_border_apply, dim3(Tmax * NB / 4, 1, n), dim3(256), 0, s, A);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Schedule (see step_type_b): launch 0 factors column 0, launch 1 column 1 with panel 0 (and brings column 2 up to panel 0);
 // from then on every launch k takes the one pending panel k-1 in its column, even launches start the rank-128 pass of panels
 // k-2, k-1 over the trailing matrix, odd launches finish the pass their predecessor started and bring column k+1 up to panel k-1.
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp,
                          int* status, const int* prof, hipStream_t s);
-void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s) {
-  hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, yv, dp, status);
+void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s, int nbr) {
+  hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, T + nbr, yv, dp, status);
 }
 struct StepPlan { int kb, nP, g0, g1, nX, TvA, TvB, TvX; long long nA, nB; };
 static int chol_n_cu() {
@@ -1345,7 +1464,7 @@ static int chol_n_cu() {
 // prof (host, T ints, or null = dense): prof[c] = last tile row of block column c inside the monotone profile of the factor (>= c).
 // Column k's tiles reach row prof[k]; the rank-128 pass of pair base kb (panels kb-2, kb-1) touches rows / columns <= prof[kb-1]; the
 // column items of an odd launch (panel k-1 onto column k+1) rows <= prof[k-1].  Everything else is structurally zero and skipped.
-static StepPlan plan_step(int k, int T, const int* prof) {
+static StepPlan plan_step(int k, int T, const int* prof, int nbr = 0) {
   static const double frac = getenv("SLIDE_CHOL_FRAC") ? atof(getenv("SLIDE_CHOL_FRAC")) : 0.5;   // diagnostic: share of a pass done by its first launch
   StepPlan p{};
   p.kb = k & ~1;                                                // base of the pair
@@ -1355,23 +1474,31 @@ static StepPlan plan_step(int k, int T, const int* prof) {
     if (p.kb >= 1) p.TvB = prof[p.kb - 1] + 1;
     if (k >= 1) p.TvX = prof[k - 1] + 1;
   }
-  p.nA = k < T ? p.TvA - k : 0;                                 // column-k tiles below the diagonal (+ RHS tile)
+  p.nA = k < T ? p.TvA - k + nbr : 0;                           // column-k tiles below the diagonal (+ border tiles + RHS tile)
   if (k >= 2 && k < T) {
-    p.nP = p.TvB > p.kb ? (p.TvB - p.kb + 1) / 2 : 0;           // 2x2 tile groups per side of the trailing matrix of the pair
-    const long long nG = (long long)p.nP * (p.nP + 1) / 2;
+    p.nP = p.TvB + nbr > p.kb ? (p.TvB + nbr - p.kb + 1) / 2 : 0;     // 2x2 tile groups per side of the trailing matrix of the pair
+    long long nG = (long long)p.nP * (p.nP + 1) / 2;
+    if (nbr > 0) {
+      // the border has rows only: the group columns right of the profile's last column hold no item — the enumeration (column-major
+      // over the groups, b_decode) is cut behind the last group column with a real tile column
+      const int ncol = p.TvB - 1 >= p.kb + 1 ? (p.TvB - 2 - p.kb) / 2 + 1 : 0;
+      long long nv = 0;
+      for (int bj = 0; bj < ncol && bj < p.nP; ++bj) nv += p.nP - bj;
+      nG = nv;
+    }
     long long first = (long long)(frac * (double)nG + 0.5);
     if (first < p.nP) first = p.nP;                             // the group column with tile columns kb+1, kb+2 entirely
     if (first > nG) first = nG;
     if (k & 1) { p.g0 = (int)(2 * first); p.g1 = (int)(2 * nG); } else { p.g0 = 0; p.g1 = (int)(2 * first); }   // items = half groups
   }
-  p.nX = (k & 1) && k + 1 < p.TvX ? (p.TvX - k + 1) / 2 : 0;    // column items: tile rows k+1 .. TvX of column k+1, two per item
+  p.nX = (k & 1) && k + 1 < p.TvX ? (p.TvX + nbr - k + 1) / 2 : 0;    // column items: tile rows k+1 .. TvX (+ border) of column k+1, two per item
   p.nB = p.g1 - p.g0 + p.nX;
   return p;
 }
 void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, float* L32, const int* h_prof,
-                      hipStream_t s) {
+                      hipStream_t s, int nbr) {
   const int n_cu = chol_n_cu();
-  const StepPlan p = plan_step(k, T, h_prof);
+  const StepPlan p = plan_step(k, T, h_prof, nbr);
   const long long nA = p.nA, nB = p.nB;
   static const int split_pct = getenv("SLIDE_CHOL_ASPLIT") ? atoi(getenv("SLIDE_CHOL_ASPLIT")) : 100;   // diagnostic: 0 = never
   // two workgroups per type-A tile once the launch is bound by the chain, not by the flood
@@ -1383,11 +1510,11 @@ void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv,
   static const int join_mul = getenv("SLIDE_CHOL_JOIN") ? atoi(getenv("SLIDE_CHOL_JOIN")) : 1;
   const int a_joins = nB > join_mul * free_cu ? 1 : 0;
   hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nAw + extra)), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status, ctr, p.kb, p.nP,
-                     p.g0, p.g1, p.nX, a_joins, a_split, L32, p.TvA, p.TvB, p.TvX);
+                     p.g0, p.g1, p.nX, a_joins, a_split, L32, p.TvA, p.TvB, p.TvX, nbr);
 }
 // The factorisations + solves of several systems as one launch sequence (max T step launches, the extractions, one chained backward
 // substitution): d[i] describes system i; ctr is the work counter array of the batch (max T + 2 ints, zeroed once).
-void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps) {
+void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps, bool solve) {
   const int n_cu = chol_n_cu();
   int Tmax = 0;
   for (int i = 0; i < n; ++i) Tmax = d[i].T > Tmax ? d[i].T : Tmax;
@@ -1396,7 +1523,7 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
     A.n = n;
     long long nA2 = 0, nBt = 0;
     StepPlan pl[CHOL_BATCH_MAX];
-    for (int i = 0; i < n; ++i) { pl[i] = plan_step(k, d[i].T, d[i].h_prof); nA2 += 2 * pl[i].nA; nBt += pl[i].nB; }
+    for (int i = 0; i < n; ++i) { pl[i] = plan_step(k, d[i].T, d[i].h_prof, d[i].nbr); nA2 += 2 * pl[i].nA; nBt += pl[i].nB; }
     const int a_split = (k > 0 && nA2 + nBt <= n_cu) ? 1 : 0;
     A.a_base[0] = A.b_base[0] = 0;
     for (int i = 0; i < n; ++i) {
@@ -1404,6 +1531,7 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
       A.L32[i] = d[i].L32;
       A.TvA[i] = pl[i].TvA; A.TvB[i] = pl[i].TvB; A.TvX[i] = pl[i].TvX;
       A.nP[i] = pl[i].nP; A.g0[i] = pl[i].g0; A.g1[i] = pl[i].g1; A.nX[i] = pl[i].nX; A.a_split[i] = a_split;
+      A.nbr[i] = d[i].nbr;
       A.a_base[i + 1] = A.a_base[i] + (int)(pl[i].nA << a_split);
       A.b_base[i + 1] = A.b_base[i] + (int)pl[i].nB;
     }
@@ -1414,26 +1542,38 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
     hipLaunchKernelGGL(k_chol_step_batched, dim3((unsigned)(nAw + extra)), dim3(512), 0, s, A, k, k & ~1, ctr, a_joins);
   }
   if (after_steps) (void)hipEventRecord(after_steps, s);
+  if (!solve) {       // the caller continues with the border (k_border_syrk, the separator system) and runs launch_chol_bwd_batch itself
+    for (int i = 0; i < n; ++i) launch_chol_extract_y(d[i].S, d[i].ld, d[i].T, d[i].yv, d[i].dp, d[i].status, s, d[i].nbr);
+    return;
+  }
   launch_chain_tables(d, n, s);
-  BwdBatchArgs B{};
-  B.n = n;
-  B.base[0] = 0;
   const double* yin[CHOL_BATCH_MAX];
   double* xout[CHOL_BATCH_MAX];
   for (int i = 0; i < n; ++i) {
-    launch_chol_extract_y(d[i].S, d[i].ld, d[i].T, d[i].yv, d[i].dp, d[i].status, s);
+    launch_chol_extract_y(d[i].S, d[i].ld, d[i].T, d[i].yv, d[i].dp, d[i].status, s, d[i].nbr);
     yin[i] = d[i].yv; xout[i] = d[i].dp;
-    B.S[i] = d[i].S; B.ld[i] = d[i].ld; B.T[i] = d[i].T; B.Ld[i] = d[i].Ld; B.Winv[i] = d[i].Winv; B.yv[i] = d[i].yv; B.dp[i] = d[i].dp;
-    B.status[i] = d[i].status;
-    B.prof[i] = d[i].prof;
-    B.base[i + 1] = B.base[i] + d[i].T;
   }
-  B.Tmax = Tmax;
-  if (B.base[n] <= 0) return;
   if (chain_has_tables(d, n)) {                 // joint-solve pass: the tables are there for the preconditioner anyway
     launch_chain_batch(d, n, yin, xout, false, false, true, nullptr, s);      // (k_chol_extract_y prepared dp)
     return;
   }
+  launch_chol_bwd_batch(d, n, s);
+}
+// the chained backward substitutions yv -> dp of up to 8 factored systems in one launch (after launch_chol_extract_y)
+void launch_chol_bwd_batch(const CholSystem* d, int n, hipStream_t s) {
+  BwdBatchArgs B{};
+  B.n = n;
+  B.base[0] = 0;
+  int Tmax = 0;
+  for (int i = 0; i < n; ++i) {
+    B.S[i] = d[i].S; B.ld[i] = d[i].ld; B.T[i] = d[i].T; B.Ld[i] = d[i].Ld; B.Winv[i] = d[i].Winv; B.yv[i] = d[i].yv; B.dp[i] = d[i].dp;
+    B.status[i] = d[i].status;
+    B.prof[i] = d[i].prof;
+    B.base[i + 1] = B.base[i] + d[i].T;
+    Tmax = d[i].T > Tmax ? d[i].T : Tmax;
+  }
+  B.Tmax = Tmax;
+  if (B.base[n] <= 0) return;
   hipLaunchKernelGGL(k_chol_bwd_chain_batched, dim3(B.base[n]), dim3(CHAIN_THREADS), 0, s, B);
 }
 // the solve of the factorisation's own right-hand side for one system (after launch_chol_extract_y): yv -> dp

@@ -92,7 +92,15 @@ struct GraphDev {
   int save_S0;       // 1: the Schur assembly writes every block to S0 as well (batched passes with the joint solve; else a device copy)
   double* pcg;       // 7 vectors of T*NB doubles: r, u, w, p, s, x, y
   const int* lm_slot; // L   shared slot of a landmark or -1: the cross-robot part of the products reads the exchanged sums through it
-  double* pcg_scal;  // 8    gamma_old, alpha_old, alpha, beta, first gamma, last gamma
+  double* pcg_scal;  // 8    gamma_old, alpha_old, alpha, beta, first gamma, last gamma, iterations that did work
+  double pcg_tol2;   // the joint solve counts as converged once gamma = r^T M^-1 r <= pcg_tol2 * (first gamma): later iterations are no-ops
+  // ---- exact joint step over several robots ("arrow": the shared landmarks are the separator of the joint graph) ---------------
+  int arrow;         // 1: landmarks with a shared slot are NOT eliminated into the pose system (H_ll^-1 = 0: F = u = 0); their coupling
+                     //    rows E^T ride below the band as nbr border row tiles of S, their own blocks start the border x border block
+  int nbr;           // border row tiles: physical tile rows T .. T + nbr - 1 of S; the right-hand-side row is tile row T + nbr
+  const int* lm_bord; // L   offset of a shared landmark's tangent coordinates in this robot's border, or -1
+  double* bord;      // ((nbr + 1) * NB) x (nbr * NB), column-major, ldb: border x border block (lower) + right-hand-side row at nbr * NB
+  int ldb;
   int* status;       // [0] not-SPD flag (landmark), [1] not-SPD flag (chol), [2] #relinearised
   // ---- parameters ------------------------------------------------------------------------
   int chart;

@@ -364,6 +364,16 @@ int HostGraph::merge_pending() {
 }
 
 constexpr int CHOL_BATCH_HOST_MAX = 8;
+// the Cholesky view of a graph's reduced system (joint: with the f32 factor copy of the PCG preconditioner)
+static CholSystem chol_system_of(HostGraph* g, const GraphDev& G, bool joint, float* L32, const int* h_prof, double* ctab, const int* bfirst) {
+  (void)g;
+  CholSystem c{};
+  c.S = G.S; c.ld = G.ld; c.T = G.T; c.Ld = G.Ld; c.Winv = G.Winv; c.yv = G.yv; c.dp = G.dp; c.status = G.status;
+  c.L32 = joint ? L32 : nullptr;
+  c.h_prof = h_prof; c.prof = G.prof; c.first = G.first; c.ctab = ctab;
+  c.nbr = G.arrow ? G.nbr : 0; c.bord = G.bord; c.ldb = G.ldb; c.bfirst = bfirst;
+  return c;
+}
 CholBatch::CholBatch(int n_) : n(n_ < 1 ? 1 : (n_ > 8 ? 8 : n_)), sys(n), ev_in(n, nullptr), bufs(n, nullptr), graphs(n, nullptr) {}
 void CholBatch::set_graph(int slot, HostGraph* g) {
   std::lock_guard<std::mutex> lk(mtx);
@@ -398,6 +408,7 @@ CholBatch::~CholBatch() {
   if (ev_out) (void)hipEventDestroy(ev_out);
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (pass_exec) (void)hipGraphExecDestroy(pass_exec);
+  free_separator();
   if (d_Gs) (void)hipFree(d_Gs);
   if (d_status_all) (void)hipFree(d_status_all);
   if (ev_aux0) (void)hipEventDestroy(ev_aux0);
@@ -411,8 +422,8 @@ int CholBatch::factor_solve(int slot, const GraphDev& G, hipStream_t s) {
   if (slot < 0 || slot >= n) return SLIDE_ERR_INVALID;
   {
     std::lock_guard<std::mutex> lk(mtx);
-    sys[slot] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, (pcg_iters > 0 && G.n_slots > 0) ? graphs[slot]->d_L32.d : nullptr,
-                                graphs[slot]->h_prof.data(), G.prof, G.first, graphs[slot]->d_ctab.d};
+    sys[slot] = chol_system_of(graphs[slot], G, pcg_iters > 0 && G.n_slots > 0, graphs[slot]->d_L32.d, graphs[slot]->h_prof.data(), graphs[slot]->d_ctab.d,
+                               graphs[slot]->d_bfirst.d);
   }
   return rendezvous(slot, s, false, 0);
 }
@@ -480,8 +491,7 @@ int CholBatch::prepare_pass() {
   hG.resize(n);
   for (int i = 0; i < n; ++i) {
     const GraphDev& G = graphs[i]->G;
-    sys[i] = CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, (pcg_iters > 0 && G.n_slots > 0) ? graphs[i]->d_L32.d : nullptr,
-                             graphs[i]->h_prof.data(), G.prof, G.first, graphs[i]->d_ctab.d};
+    sys[i] = chol_system_of(graphs[i], G, pcg_iters > 0 && G.n_slots > 0, graphs[i]->d_L32.d, graphs[i]->h_prof.data(), graphs[i]->d_ctab.d, graphs[i]->d_bfirst.d);
     Tmax = G.T > Tmax ? G.T : Tmax;
     hG[i] = G;
     hG[i].save_S0 = (pcg_iters > 0 && G.n_slots > 0) ? 1 : 0;      // the batched Schur assembly writes S0 itself
@@ -496,6 +506,103 @@ int CholBatch::prepare_pass() {
   if (!d_Gs) SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_Gs), CHOL_BATCH_HOST_MAX * sizeof(GraphDev)));
   if (!d_status_all) SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_status_all), CHOL_BATCH_HOST_MAX * 8 * sizeof(int)));
   SL_HIP(hipMemcpy(d_Gs, hG.data(), n * sizeof(GraphDev), hipMemcpyHostToDevice));
+  if (arrow && hG[0].n_slots > 0) return prepare_separator();
+  return SLIDE_OK;
+}
+// ---- exact joint step: the separator system of all shared landmarks -------------------------------------------------------------------
+void CholBatch::free_separator() {
+  if (sep_owned && sepS) (void)hipFree(sepS);
+  sepS = nullptr; sep_owned = false; sep_len = 0;
+  for (double** p : {&sep_Ld, &sep_Winv, &sep_yv, &sep_dp}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  for (int** p : {&sep_status, &sep_ctr, &d_sep_off}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  sep_cap = 0;
+}
+int CholBatch::set_arrow(bool on, double* sep_buf, long long len) {
+  std::lock_guard<std::mutex> pl(pass_mtx);
+  std::vector<HostGraph*> gs;
+  {
+    std::lock_guard<std::mutex> lk(mtx);
+    if (master) (void)hipStreamSynchronize(master);
+    if (sep_owned && sepS) (void)hipFree(sepS);
+    sepS = sep_buf; sep_owned = false; sep_len = sep_buf ? len : 0;
+    arrow = on;
+    pass_dirty = true;
+    gs.assign(graphs.begin(), graphs.end());
+  }
+  for (HostGraph* g : gs)
+    if (g) { std::lock_guard<std::mutex> gl(g->mtx); g->topo_dirty = true; }
+  return SLIDE_OK;
+}
+// the separator's buffers for the joined graphs' current slots (called with the graphs up to date)
+int CholBatch::prepare_separator() {
+  for (int i = 0; i < n; ++i) {
+    HostGraph* g = graphs[i];
+    if (!g->arrow_on() || g->h_sep_off != graphs[0]->h_sep_off) {
+      g_last_error = "exact joint step: every graph of the batch needs the shared slots and the same separator offsets (slide_graph_set_shared, slide_graph_set_separator)";
+      return SLIDE_ERR_INVALID;
+    }
+  }
+  const std::vector<int>& off = graphs[0]->h_sep_off;
+  sep_m = off.back();
+  sep_Ts = (sep_m + NB - 1) / NB;
+  const long long need = sep_buffer_len(sep_m);
+  if (sepS && !sep_owned && sep_len < need) { g_last_error = "exact joint step: the separator buffer is too small (slide_chol_batch_sep_buffer_len)"; return SLIDE_ERR_INVALID; }
+  if (!sepS || (sep_owned && sep_len < need)) {
+    if (sep_owned && sepS) { SL_HIP(hipStreamSynchronize(master)); SL_HIP(hipFree(sepS)); sepS = nullptr; }
+    SL_HIP(hipMalloc(reinterpret_cast<void**>(&sepS), std::max<long long>(need, 1) * sizeof(double)));
+    sep_owned = true; sep_len = need;
+  }
+  if (sep_Ts > sep_cap) {
+    SL_HIP(hipStreamSynchronize(master));
+    for (double** p : {&sep_Ld, &sep_Winv, &sep_yv, &sep_dp}) if (*p) { SL_HIP(hipFree(*p)); *p = nullptr; }
+    for (int** p : {&sep_status, &sep_ctr}) if (*p) { SL_HIP(hipFree(*p)); *p = nullptr; }
+    sep_cap = sep_Ts;
+    SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_Ld), (size_t)sep_cap * NB * NB * sizeof(double)));
+    SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_Winv), (size_t)sep_cap * 1024 * sizeof(double)));
+    SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_yv), (size_t)sep_cap * NB * sizeof(double)));
+    SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_dp), (size_t)sep_cap * NB * sizeof(double)));
+    SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_status), 8 * sizeof(int)));
+    SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_ctr), ((size_t)sep_cap + 2) * sizeof(int)));
+    SL_HIP(hipMemset(sep_ctr, 0, ((size_t)sep_cap + 2) * sizeof(int)));
+    SL_HIP(hipMemset(sep_status, 0, 8 * sizeof(int)));
+  }
+  // zero once: the strict upper triangle and the idle rows of the right-hand-side tile are never written by the gather
+  SL_HIP(hipMemset(sepS, 0, (size_t)need * sizeof(double)));
+  if (d_sep_off) { SL_HIP(hipFree(d_sep_off)); d_sep_off = nullptr; }
+  SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_off), off.size() * sizeof(int)));
+  SL_HIP(hipMemcpy(d_sep_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+  return SLIDE_OK;
+}
+// One exact joint Gauss-Newton pass of all joined graphs.  part -1: the whole pass; 0: up to this GPU's partial sum of the separator
+// system (the caller all-reduces the separator buffer across the GPUs on the pass's stream); 2: the rest.
+int CholBatch::enqueue_arrow(double* const* d_bufs, int part) {
+  const bool whole = part < 0;
+  const int* maps[CHOL_BATCH_HOST_MAX];
+  double* xloc[CHOL_BATCH_HOST_MAX];
+  for (int i = 0; i < n; ++i) { maps[i] = graphs[i]->d_sep_map.d; xloc[i] = graphs[i]->d_xloc.d; }
+  const int ld_s = (sep_Ts + 1) * NB;
+  if (whole || part == 0) {
+    launch_status_clear(d_Gs, n, master);
+    launch_ints_clear(sep_status, 8, master);
+    launch_phase0_batched(d_Gs, hG.data(), n, d_bufs, master);      // relinearise, linearise, the robots' own per-landmark sums
+    launch_phase3_arrow_batched(d_Gs, hG.data(), n, master);         // private landmarks eliminated, reduced pose systems, borders
+    const int rc = factor_all(nullptr);                              // the bands' steps: W^T and y in the border rows
+    if (rc != SLIDE_OK) return rc;
+    launch_border_syrk(sys.data(), n, master);                       // border blocks: C_a - W^T W, b_s - W^T y
+    launch_sep_gather(hG.data(), n, maps, sep_m, sepS, sep_Ts, master);
+  }
+  if (whole || part == 2) {
+    for (int k = 0; k < sep_Ts; ++k)
+      launch_chol_step(sepS, ld_s, k, sep_Ts, sep_Ld + (size_t)k * NB * NB, sep_Winv + (size_t)k * 1024, sep_status, sep_ctr, nullptr, nullptr, master);
+    launch_chol_extract_y(sepS, ld_s, sep_Ts, sep_yv, sep_dp, sep_status, master);
+    launch_chol_bwd_all(sepS, ld_s, sep_Ts, sep_Ld, sep_Winv, sep_yv, sep_dp, sep_status, nullptr, master);
+    launch_sep_xloc(n, maps, sep_m, sep_dp, xloc, master);
+    launch_border_apply(sys.data(), n, xloc, master);                // y -= W x_s
+    launch_chol_bwd_batch(sys.data(), n, master);                    // L^T dp = y
+    launch_arrow_finish_batched(d_Gs, hG.data(), n, sep_dp, d_sep_off, master);
+    launch_status_or(hG[0].status, sep_status, 8, master);           // (the separator's not-SPD / chain flags are reported with graph 0's)
+    launch_status_gather(d_Gs, n, d_status_all, master);
+  }
   return SLIDE_OK;
 }
 // the launches of one pass of all joined graphs (captured by capture_pass, or issued directly by profile_pass with events e0 / e1
@@ -519,6 +626,7 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
     }
   };
   const int n_slots = graphs[0]->G.n_slots;
+  if (arrow && n_slots > 0) return enqueue_arrow(d_bufs, part);
   const bool whole = part < 0;
   const bool joint = pcg_iters > 0 && n_slots > 0;       // PCG over the robots' coupled systems instead of the plain block solves
   if (whole || part == 0) {
@@ -696,8 +804,9 @@ int CholBatch::factor_all(hipEvent_t after) {
   if (groups > (env_groups > 0 ? n : n / 2)) groups = env_groups > 0 ? n : n / 2;      // (at least two systems per sequence by default)
   if (groups > 8) groups = 8;
   last_groups = groups < 1 ? 1 : groups;
+  const bool solve = !(arrow && hG[0].n_slots > 0);      // exact joint step: the backward substitutions wait for the separator's solution
   if (groups < 2) {
-    launch_chol_batch(sys.data(), n, d_ctr, master, nullptr);
+    launch_chol_batch(sys.data(), n, d_ctr, master, nullptr, solve);
     if (after) SL_HIP(hipEventRecord(after, master));
     return SLIDE_OK;
   }
@@ -716,7 +825,7 @@ int CholBatch::factor_all(hipEvent_t after) {
       st = aux[g];
       SL_HIP(hipStreamWaitEvent(st, ev_aux0, 0));
     }
-    launch_chol_batch(sys.data() + lo, hi - lo, d_ctr + (size_t)g * (ctr_cap / CHOL_BATCH_HOST_MAX), st, nullptr);
+    launch_chol_batch(sys.data() + lo, hi - lo, d_ctr + (size_t)g * (ctr_cap / CHOL_BATCH_HOST_MAX), st, nullptr, solve);
     if (g > 0) {
       SL_HIP(hipEventRecord(ev_aux1[g], st));
       SL_HIP(hipStreamWaitEvent(master, ev_aux1[g], 0));
@@ -726,12 +835,13 @@ int CholBatch::factor_all(hipEvent_t after) {
   return SLIDE_OK;
 }
 
-void CholBatch::set_pcg(int iters) {
+void CholBatch::set_pcg(int iters, double tol) {
   std::lock_guard<std::mutex> pl(pass_mtx);
   std::vector<HostGraph*> gs;
   {
     std::lock_guard<std::mutex> lk(mtx);
     pcg_iters = iters < 0 ? 0 : iters;
+    pcg_tol = tol > 0.0 ? tol : 0.0;
     pass_dirty = true;
     gs.assign(graphs.begin(), graphs.end());
   }
@@ -816,6 +926,7 @@ int CholBatch::pass_part(double* const* d_bufs, int part) {
     g_last_error = "batched pass: part 0 has not run";
     return SLIDE_ERR_INVALID;
   }
+  if (arrow && hG[0].n_slots > 0 && part != 0 && part != 2) return SLIDE_OK;      // exact joint step: one exchange, between parts 0 and 2
   if (part >= 10 && !(pcg_iters > 0 && hG[0].n_slots > 0)) return SLIDE_OK;      // no joint solve: nothing between parts 1 and 2
   if (!part_exec[slot] && (rc = capture_pass(d_bufs, part, &part_exec[slot])) != SLIDE_OK) return rc;
   SL_HIP(hipGraphLaunch(part_exec[slot], master));
@@ -1029,15 +1140,62 @@ int HostGraph::upload_new() {
   }
   if (up_csr(d_pose_bt_ptr, d_pose_bt, pose_bt, ptr, val, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (ub.flush(s) != SLIDE_OK) return SLIDE_ERR_HIP;   // (the host temporaries were copied into the pinned staging buffer)
+  // exact joint step: this robot's border = its shared landmarks in slot order (the order of the separator system, so local and
+  // global coordinates are both increasing)
+  const bool arrow_now = arrow_on();
+  int nbr_new = 0;
+  if (arrow_now) {
+    const int ns = (int)h_sh_lid.size(), m = h_sep_off.back();
+    h_lm_bord.assign(std::max<size_t>(Ln, 1), -1);
+    h_sep_map.assign(std::max(m, 1), -1);
+    int o = 0;
+    for (int i = 0; i < ns; ++i) {
+      const int lid = h_sh_lid[i];
+      if (lid < 0 || (size_t)lid >= Ln) continue;
+      const int dim = h_sep_off[i + 1] - h_sep_off[i];
+      if (dim != lm_dim(h_lm_type[lid])) { g_last_error = "separator offsets do not match the landmark classes of the shared slots"; return SLIDE_ERR_INVALID; }
+      h_lm_bord[lid] = o;
+      for (int k = 0; k < dim; ++k) h_sep_map[h_sep_off[i] + k] = o + k;
+      o += dim;
+    }
+    nbr_new = (o + NB - 1) / NB;
+    h_bfirst.assign(nbr_new + 1, 0);
+    for (int t = 0; t < nbr_new; ++t) h_bfirst[t] = 1 << 30;
+    for (size_t l = 0; l < Ln; ++l) {
+      if (h_lm_bord[l] < 0) continue;
+      int fp = 1 << 30;
+      for (int f : lm_fids[l]) fp = std::min(fp, h_lf_pose[f]);
+      if (fp == (1 << 30)) continue;
+      const int cb = 6 * fp / NB, d = lm_dim(h_lm_type[l]);
+      for (int t = h_lm_bord[l] / NB; t <= (h_lm_bord[l] + d - 1) / NB; ++t) h_bfirst[t] = std::min(h_bfirst[t], cb);
+    }
+    for (int t = 0; t < nbr_new; ++t) if (h_bfirst[t] == (1 << 30)) h_bfirst[t] = 0;
+    if (d_lm_bord.ensure(h_lm_bord.size(), 0, s) != SLIDE_OK || d_sep_map.ensure(h_sep_map.size(), 0, s) != SLIDE_OK ||
+        d_bfirst.ensure(h_bfirst.size(), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    SL_HIP(hipMemcpyAsync(d_lm_bord.d, h_lm_bord.data(), h_lm_bord.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    SL_HIP(hipMemcpyAsync(d_sep_map.d, h_sep_map.data(), h_sep_map.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    SL_HIP(hipMemcpyAsync(d_bfirst.d, h_bfirst.data(), h_bfirst.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    SL_HIP(hipStreamSynchronize(s));      // (host vectors that may change right after)
+    if (nbr_new > 0) {
+      if (d_bord.ensure((size_t)(nbr_new + 1) * NB * nbr_new * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+      if (d_xloc.ensure((size_t)nbr_new * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+      SL_HIP(hipMemsetAsync(d_xloc.d, 0, (size_t)nbr_new * NB * sizeof(double), s));
+    }
+  }
+  nbr = nbr_new;
   // dense reduced system
   const int T = (int)((6 * Pn + NB - 1) / NB);
   bool fresh_S = false;
-  if (T > Tcap) {
+  if (T > Tcap || nbr_new != nbr_alloc || (arrow_now && T != arrow_T)) {
     fresh_S = true;
-    int nc = Tcap ? Tcap : 4;
-    while (nc < T) nc = nc + nc / 2 + 1;
-    Tcap = nc;
-    const size_t ld = (size_t)(Tcap + 1) * NB;
+    if (T > Tcap) {
+      int nc = Tcap ? Tcap : 4;
+      while (nc < T) nc = nc + nc / 2 + 1;
+      Tcap = nc;
+    }
+    nbr_alloc = nbr_new;
+    arrow_T = T;
+    const size_t ld = (size_t)(Tcap + nbr_alloc + 1) * NB;      // band rows, border rows (exact joint step), the right-hand-side tile row
     // S is rewritten by every Schur pass, so nothing is carried over; zero once so the never-written
     // strict upper tiles and the idle rows of the RHS tile hold finite values.
     if (d_S.ensure_exact(ld * (size_t)Tcap * NB, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
@@ -1048,13 +1206,14 @@ int HostGraph::upload_new() {
     if (d_cctr.ensure((size_t)Tcap + 2, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_yv.ensure((size_t)Tcap * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_dp.ensure((size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+    joint_Tcap = 0;      // (the joint-solve buffers follow S's leading dimension)
   }
   // Buffers of the joint solve (the saved system, the f32 factor copy, the chain tables): only for graphs that take part in one —
   // a streaming replica never pays for them (three more allocations of S's size at every growth step were 100 ms spikes there)
   {
     const bool want_joint = pcg_iters > 0 || (batch && batch->pcg() > 0);
     if (want_joint && joint_Tcap != Tcap) {
-      const size_t ld = (size_t)(Tcap + 1) * NB;
+      const size_t ld = (size_t)(Tcap + nbr_alloc + 1) * NB;
       if (d_S0.ensure_exact(ld * (size_t)Tcap * NB, s) != SLIDE_OK) return SLIDE_ERR_HIP;
       if (d_L32.ensure_exact((size_t)Tcap * (Tcap - 1) / 2 * NB * NB + 4, s) != SLIDE_OK) return SLIDE_ERR_HIP;
       if (d_ctab.ensure_exact((size_t)4 * Tcap * NB * NB, s) != SLIDE_OK) return SLIDE_ERR_HIP;
@@ -1094,10 +1253,10 @@ int HostGraph::upload_new() {
       const int Told = (int)h_prof.size();
       bool shrink = T < Told;
       for (int c = 0; !shrink && c < std::min(T, Told); ++c) shrink = prof[c] < h_prof[c];
-      const size_t ld = (size_t)(Tcap + 1) * NB;
+      const size_t ld = (size_t)(Tcap + nbr_alloc + 1) * NB;
       if (!fresh_S && d_S.d) {
         if (shrink) SL_HIP(hipMemsetAsync(d_S.d, 0, ld * (size_t)std::max(T, Told) * NB * sizeof(double), s));
-        else if (T > Told && Told > 0)
+        else if (T > Told && Told > 0)      // (a graph with a border is re-allocated whenever T changes: fresh_S)
           SL_HIP(hipMemset2DAsync(d_S.d + (size_t)Told * NB, ld * sizeof(double), 0, sizeof(double), (size_t)Told * NB, s));
       }
       h_prof = prof;
@@ -1136,7 +1295,7 @@ int HostGraph::upload_new() {
   G.pose_adj = d_pose_adj.d;
   G.lm_Hacc = d_lm_Hacc.d; G.lm_t = d_lm_t.d; G.n_slots = (int)h_sh_lid.size(); G.sh_lid = d_sh_lid.d; G.sh_owner = d_sh_owner.d;
   G.lm_Hinv = d_lm_Hinv.d; G.lm_g = d_lm_g.d; G.pose_H = d_pose_H.d; G.pose_g = d_pose_g.d;
-  G.S = d_S.d; G.ld = (Tcap + 1) * NB; G.T = T; G.Ld = d_Ld.d; G.Winv = d_Winv.d; G.yv = d_yv.d; G.dp = d_dp.d; G.chol_ctr = d_cctr.d;
+  G.S = d_S.d; G.ld = (Tcap + nbr_alloc + 1) * NB; G.T = T; G.Ld = d_Ld.d; G.Winv = d_Winv.d; G.yv = d_yv.d; G.dp = d_dp.d; G.chol_ctr = d_cctr.d;
   G.prof = d_prof.d; G.first = d_first.d; G.prof_ver = prof_ver;
   {
     int band = 0;
@@ -1144,6 +1303,9 @@ int HostGraph::upload_new() {
     G.schur_split = band <= 8 ? 1 : 2;
   }
   G.S0 = d_S0.d; G.save_S0 = 0; G.pcg = d_pcg.d; G.pcg_scal = d_pcg_scal.d;
+  G.pcg_tol2 = (batch ? batch->pcg_tolerance() : pcg_tol) * (batch ? batch->pcg_tolerance() : pcg_tol);
+  G.arrow = arrow_now ? 1 : 0; G.nbr = nbr; G.lm_bord = arrow_now ? d_lm_bord.d : nullptr; G.bord = arrow_now ? d_bord.d : nullptr;
+  G.ldb = (nbr + 1) * NB;
   G.status = d_status.d;
   G.chart = P.pose_chart;
   G.bearing_sigma = P.bearing_range_sigma; G.cyl_sigma = P.cylinder_sigma; G.numdiff_delta = P.numdiff_delta;
@@ -1277,8 +1439,20 @@ int HostGraph::set_shared(const int32_t* cls, const int64_t* idx, const int32_t*
 //  10: pack the owner's landmark values (15/slot)      11: unpack them (every rank adopts the owner's value)
 // Every robot solves its own reduced pose system with the GLOBAL landmark blocks (block-Jacobi over robots on
 // the Schur complement, exact gradient): the fixed point is the joint optimum.
-void HostGraph::set_pcg(int iters) {
+bool HostGraph::arrow_on() const {
+  return batch && batch->is_arrow() && !h_sh_lid.empty() && h_sep_off.size() == h_sh_lid.size() + 1;
+}
+int HostGraph::set_separator(const int32_t* off, int n) {
+  if (n < 0 || (n > 0 && !off)) return SLIDE_ERR_INVALID;
+  for (int i = 1; i < n; ++i)
+    if (off[i] < off[i - 1]) { g_last_error = "set_separator: offsets must be non-decreasing"; return SLIDE_ERR_INVALID; }
+  h_sep_off.assign(off, off + n);
+  topo_dirty = true;
+  return SLIDE_OK;
+}
+void HostGraph::set_pcg(int iters, double tol) {
   pcg_iters = iters < 0 ? 0 : iters;
+  pcg_tol = tol > 0.0 ? tol : 0.0;
   topo_dirty = true;                      // (the joint-solve buffers are allocated by upload_new on demand)
   for (auto& pg : phase_graph)            // the captured phase 1 depends on it
     if (pg.exec) { (void)hipGraphExecDestroy(pg.exec); pg.exec = nullptr; }

@@ -155,8 +155,15 @@ class CholBatch {
   int pass_part(double* const* d_bufs, int part);       // the same pass cut at its exchanges (multi-GPU jobs): parts 0, 1, 2 and, with the joint solve, 10, 11, 12
   // Joint solve: after the factorisations, `iters` PCG iterations on the global reduced system (pcg_kernels.hip); 0 = each robot's own
   // block solve only (block-Jacobi over robots).  Changing it invalidates the captured launch sequences.
-  void set_pcg(int iters);
+  void set_pcg(int iters, double tol = 0.0);
   int pcg() const { return pcg_iters; }
+  double pcg_tolerance() const { return pcg_tol; }
+  // Exact joint step ("arrow"): the shared landmarks stay as the separator of the joint graph (graph_dev.hpp).  sep_buf: device buffer
+  // of sep_buffer_len(m) doubles that holds the separator system — the caller's (the cross-GPU all-reduce of a job that spans GPUs runs
+  // on it) or null: allocated here.  Changing it invalidates the captured launch sequences.
+  int set_arrow(bool on, double* sep_buf, long long sep_len);
+  bool is_arrow() const { return arrow; }
+  static long long sep_buffer_len(int m) { const long long Ts = (m + NB - 1) / NB; return (Ts + 1) * NB * Ts * NB; }
   hipStream_t pass_stream();                             // the stream the passes run on (created on first use)
   int profile_pass(double* const* d_bufs, double* ms_steps, int* n_launches);
 
@@ -173,8 +180,19 @@ class CholBatch {
   std::vector<double*> bufs;
   std::vector<HostGraph*> graphs;
   hipGraphExec_t pass_exec = nullptr;
-  hipGraphExec_t part_exec[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // parts 0, 1, 2, 10, 11, 12
+  hipGraphExec_t part_exec[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // parts 0, 1, 2, 10, 11, 12 (exact joint step: 0 and 2 only)
   int pcg_iters = 0;
+  double pcg_tol = 0.0;
+  bool arrow = false;
+  // separator system of the exact joint step: m coordinates, Ts tile columns; factored by the un-batched step kernels on the pass's stream
+  double* sepS = nullptr; bool sep_owned = false; long long sep_len = 0;
+  int sep_m = 0, sep_Ts = 0;
+  double *sep_Ld = nullptr, *sep_Winv = nullptr, *sep_yv = nullptr, *sep_dp = nullptr;
+  int *sep_status = nullptr, *sep_ctr = nullptr, *d_sep_off = nullptr;
+  int sep_cap = 0;
+  int prepare_separator();
+  int enqueue_arrow(double* const* d_bufs, int part);
+  void free_separator();
   int enqueue_pcg_head(double* const* d_bufs);                   // r = b, u = M^-1 b, t_l(u) packed + local sum
   int enqueue_pcg_mid(double* const* d_bufs, bool whole);                    // w = S u, partial dots + local sum
   int enqueue_pcg_tail(double* const* d_bufs, bool last, bool whole);        // alpha, beta, updates; then u = M^-1 r, t_l(u) | dp = x
@@ -234,7 +252,12 @@ class HostGraph {
   // one-robot-per-GPU mode: shared-landmark slots + the three phases of a distributed GN pass
   int set_shared(const int32_t* cls, const int64_t* idx, const int32_t* owner, int n_slots);
   int dist_phase(int phase, double* d_buf);
-  void set_pcg(int iters);      // un-batched passes: dist_phase 1 prepares the joint solve, 31 / 32 / 33 run it (0 = block solves only)
+  int pcg() const { return pcg_iters; }
+  double pcg_tolerance() const { return pcg_tol; }
+  void set_pcg(int iters, double tol = 0.0);      // un-batched passes: dist_phase 1 prepares the joint solve, 31 / 32 / 33 run it (0 = block solves only)
+  // exact joint step (batched passes only): offsets of the shared slots' tangent coordinates in the separator system, n_slots + 1 ints,
+  // the same on every rank (slide_graph_set_separator)
+  int set_separator(const int32_t* off, int n);
   void stats(int64_t* out5) const;
   int64_t rejected() const;
   int chi2(double* out4);                 // sum of squared whitened residuals at the current estimate: total, priors, betweens, landmark factors
@@ -309,6 +332,14 @@ class HostGraph {
   GraphDev G_self{};
   bool have_self = false;
   int pcg_iters = 0;
+  double pcg_tol = 0.0;
+  // exact joint step: this robot's border = its shared landmarks in slot order
+  std::vector<int> h_sep_off;                          // global offsets (n_slots + 1) or empty
+  std::vector<int> h_lm_bord, h_sep_map, h_bfirst;     // landmark -> border offset; global separator coordinate -> border coordinate; first column block per border tile row
+  DevArr<int> d_lm_bord, d_sep_map, d_bfirst;
+  DevArr<double> d_bord, d_xloc;
+  int nbr = 0, nbr_alloc = -1, arrow_T = -1;
+  bool arrow_on() const;                               // the batch runs exact joint passes and this graph has shared slots + separator offsets
   int sync_self();
   DevArr<int> d_cctr;
   DevArr<double> d_covY;

@@ -29,12 +29,20 @@ void launch_phase4_batched(const GraphDev* d, const GraphDev* h, int n, double* 
 void launch_phase2_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s);
 void launch_phase3_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s);   // blockIdx.z = robot               // local all-reduce(sum) of up to 8 buffers             // device arrays -> one staging buffer (DownloadBatch)   // staged upload -> destinations (UploadBatch)
 void launch_ghost_exchange(const GraphDev& G, int what, double* buf, hipStream_t s);   // what: 0 pack owned poses, 1 adopt
+// exact joint step ("arrow", graph_dev.hpp): border rows + border block of every robot; the separator system of all shared landmarks
+// gathered from the robots' border blocks (maps[i]: m ints, global separator coordinate -> robot i's border coordinate or -1); its
+// solution handed back
+void launch_border_assemble_batched(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);
+void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, int m, double* out, int Ts, hipStream_t s);
+void launch_sep_xloc(int n, const int* const* maps, int m, const double* xs, double* const* xloc, hipStream_t s);
+void launch_arrow_finish_batched(const GraphDev* d, const GraphDev* h, int n, const double* xs, const int* sep_off, hipStream_t s);
+void launch_phase3_arrow_batched(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);   // phase 3 without the exchanged sums: the robots' own H_ll
 
 // chol_kernels.hip — blocked right-looking FP64 Cholesky of the (T*NB)^2 lower matrix S (column-major,
 // leading dimension ld = (T+1)*NB; the extra row tile carries the right-hand side), tile edge NB = 64.
 // ctr: T + 2 ints, zero before the first factorisation (each step clears the next step's work counter itself)
-void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, float* L32, const int* h_prof, hipStream_t s);   // L32, h_prof: see CholSystem
-void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s);   // also clears status[4], the ticket counter of launch_chol_bwd_all
+void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, float* L32, const int* h_prof, hipStream_t s, int nbr = 0);   // L32, h_prof: see CholSystem
+void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s, int nbr = 0);   // also clears status[4], the ticket counter of launch_chol_bwd_all
 // A quiet-NaN payload no solution value can equal bit for bit: the outputs of the chained substitutions are pre-filled with it and the
 // workgroups poll the blocks they depend on ("flag in data").
 constexpr unsigned long long CHAIN_SENTINEL = 0x7FF8DEADBEEF0BADull;
@@ -42,8 +50,15 @@ struct CholSystem { double* S; int ld, T; double* Ld; double* Winv; double* yv; 
                     float* L32;      // packed f32 copy of the factor for the joint solve's preconditioner (null: none), see bwd_chain_body
                     const int* h_prof;           // host: profile of the factor, T ints (plan_step in chol_kernels.hip), or null = dense
                     const int* prof; const int* first;      // device: the same and, per block row, the first block column that reaches it
-                    double* ctab; };             // 4 * T * 4096 doubles: tables of the chained substitutions in a joint-solve pass (k_chain_tables), or null
-void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps = nullptr);            // up to 8 systems, one launch per block column
+                    double* ctab;                // 4 * T * 4096 doubles: tables of the chained substitutions in a joint-solve pass (k_chain_tables), or null
+                    int nbr;                     // border row tiles between the band and the right-hand-side row (exact joint step: the separator's coupling rows), see b_decode
+                    double* bord; int ldb;       // border x border block of the system ((nbr + 1) * NB rows, nbr * NB columns, column-major) — k_border_syrk
+                    const int* bfirst; };        // device, nbr + 1 ints: first block column of the band in which border tile row i can be non-zero
+void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps = nullptr, bool solve = true);            // up to 8 systems, one launch per block column; solve = false: steps + extraction of y only
+void launch_chol_bwd_batch(const CholSystem* d, int n, hipStream_t s);       // yv -> dp of up to 8 factored systems (chained backward substitution)
+// Exact joint step (the border of the systems = the separator's coupling rows, W^T after the steps):
+void launch_border_syrk(const CholSystem* d, int n, hipStream_t s);          // bord(i, j) -= sum_c W^T(i, c) W^T(j, c)^T, i >= j, right-hand-side row included
+void launch_border_apply(const CholSystem* d, int n, const double* const* xloc, hipStream_t s);   // yv -= W x_loc (x_loc: nbr * NB doubles per system)
 // one of the two triangular solves with the finished factors of up to 8 systems on arbitrary vectors (T * NB doubles each): out = L^-1 in
 // (fwd) or L^-T in (bwd); the preconditioner of the joint solve (pcg_kernels.hip)
 void launch_chain_batch(const CholSystem* d, int n, const double* const* in, double* const* out, bool fwd, bool f32, bool prepared,
@@ -62,6 +77,8 @@ int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double
 enum { PCG_VEC_R = 0, PCG_VEC_U = 1, PCG_VEC_W = 2, PCG_VEC_P = 3, PCG_VEC_S = 4, PCG_VEC_X = 5, PCG_VEC_Y = 6, PCG_VEC_COUNT = 7 };
 void launch_status_clear(const GraphDev* d, int n, hipStream_t s);             // status[0..7] = 0 for every graph of the batch
 void launch_status_gather(const GraphDev* d, int n, int* out, hipStream_t s);  // out[8 i ..] = graph i's status words
+void launch_ints_clear(int* p, int n, hipStream_t s);                          // p[0 .. n-1] = 0 (a kernel node: see launch_status_clear)
+void launch_status_or(int* dst, const int* src, int n, hipStream_t s);         // dst[i] |= src[i]
 void launch_pcg_init(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);
 void launch_pcg_tl(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, int vec, hipStream_t s);      // t_l -> bufs[i][9 slot ..], and w = S0 v in the same launch
 void launch_pcg_matvec_dots(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, int nsum, hipStream_t s);     // bufs: summed t_l in, (gamma, delta) partials out (w = S0 u ran in launch_pcg_tl)

@@ -313,8 +313,12 @@ __global__ void k_pcg_scalars(const GraphDev* __restrict__ Gs, PcgBufs B, int ns
     alpha = gamma / delta;
     sc[4] = gamma;
   }
-  if (!(gamma > 0.0)) { alpha = 0.0; beta = 0.0; }          // r = 0 already (or NaN upstream): a no-op step, x stays
+  // converged: gamma has fallen to tol^2 (at least eps^2) of its first value — r is at rounding level, the recurrence's denominator
+  // would only cancel; the step and every later one are no-ops (alpha = beta = 0 leaves x and r)
+  const double t2 = G.pcg_tol2 > 4.930380657631324e-32 ? G.pcg_tol2 : 4.930380657631324e-32;
+  if (!(gamma > 0.0) || (gamma_old > 0.0 && gamma <= t2 * sc[4])) { alpha = 0.0; beta = 0.0; }          // r = 0 already (or NaN upstream): a no-op step, x stays
   else if (!(alpha > 0.0) || !(alpha < 1e300)) { alpha = 0.0; beta = 0.0; atomicOr(&G.status[1], 4); }     // breakdown: not positive definite
+  else sc[6] += 1.0;
   sc[0] = gamma > 0.0 ? gamma : gamma_old;
   sc[1] = alpha > 0.0 ? alpha : alpha_old;
   sc[2] = alpha;

@@ -336,6 +336,9 @@ __device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
 #pragma unroll
     for (int a = 0; a < D; ++a) gout[a] = g[a];
   }
+  // exact joint step: a separator landmark is not eliminated here — H_ll^-1 = 0 makes F and u vanish (nothing of it enters the pose
+  // system), E = Jp^T Jl is still written: it is the landmark's coupling row in the border (k_border_fill)
+  const bool sep = MODE == 2 && G.arrow && G.lm_slot && G.lm_slot[l] >= 0;
   if (nf == 0 && MODE == 0) {
     if (lane == 0) {
 #pragma unroll
@@ -362,7 +365,7 @@ __device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
       Cm[i][j] = t / dj;
     }
   }
-  if (!ok && lane == 0) atomicOr(&G.status[0], 1);
+  if (!ok && !sep && lane == 0) atomicOr(&G.status[0], 1);
   double Ci[D][D];
 #pragma unroll
   for (int c = 0; c < D; ++c) {
@@ -383,6 +386,7 @@ __device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
       double s = 0.0;
 #pragma unroll
       for (int k = a; k < D; ++k) s += Ci[k][a] * Ci[k][c];
+      if (sep) s = 0.0;
       Hi[a][c] = s;
       Hi[c][a] = s;
     }
@@ -833,6 +837,10 @@ __global__ void k_status_clear(const GraphDev* __restrict__ Gs) {
 __global__ void k_status_gather(const GraphDev* __restrict__ Gs, int* __restrict__ out) {
   if (threadIdx.x < 8) out[8 * blockIdx.x + threadIdx.x] = Gs[blockIdx.x].status[threadIdx.x];
 }
+__global__ void k_ints_clear(int* p, int n) { if ((int)threadIdx.x < n) p[threadIdx.x] = 0; }
+__global__ void k_status_or(int* dst, const int* src, int n) { if ((int)threadIdx.x < n && threadIdx.x != 4 && threadIdx.x != 5) dst[threadIdx.x] |= src[threadIdx.x]; }   // (words 4 / 5 are ticket counters)
+void launch_ints_clear(int* p, int n, hipStream_t s) { hipLaunchKernelGGL(k_ints_clear, dim3(1), dim3(64), 0, s, p, n); }
+void launch_status_or(int* dst, const int* src, int n, hipStream_t s) { hipLaunchKernelGGL(k_status_or, dim3(1), dim3(64), 0, s, dst, src, n); }
 void launch_status_clear(const GraphDev* d, int n, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_status_clear, dim3(n), dim3(64), 0, s, d);
 }
@@ -876,7 +884,7 @@ __device__ __forceinline__ void k_pad_rhs_body(const GraphDev& G) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < NT) {
     const int c = (int)t;
-    G.S[(size_t)c * G.ld + NT] = (c < n) ? -G.pose_g[c] : 0.0;
+    G.S[(size_t)c * G.ld + NT + (size_t)G.nbr * NB] = (c < n) ? -G.pose_g[c] : 0.0;      // (the right-hand-side row lies below the border rows)
     return;                               // (the right-hand-side row is not part of S0: the joint solve takes b from pose_g)
   }
   const long long u = t - NT;
@@ -987,6 +995,96 @@ __global__ void k_shared_unpack(GraphDev G, int what, const double* __restrict__
   if (k < nv) dst[k] = buf[t];
 }
 
+// ---- exact joint step: the border of a robot's system and the separator system of all shared landmarks ------------------------
+// k_border_clear: zero the border rows of S (tile rows T .. T + nbr - 1, every band column) and the border x border block.
+// k_border_fill: one wave per shared slot this robot observes: its factors' E = Jp^T Jl (6 x D, k_landmark) are added into the
+// border rows at the observing pose's columns (sequentially over the landmark's factor list: two factors of one pose add up, no
+// atomics), the robot's OWN H_ll block (packed lower in lm_Hacc, k_landmark<1>) goes onto the diagonal of the border block and
+// -g_l into its right-hand-side row.
+__global__ __launch_bounds__(256) void k_border_clear_b(const GraphDev* __restrict__ Gs) {
+  const GraphDev G = Gs[blockIdx.z];
+  if (!G.arrow || G.nbr <= 0) return;
+  const long long nrow = (long long)G.nbr * NB, ncol = (long long)G.T * NB;
+  const long long nb = (long long)(G.nbr + 1) * NB * G.nbr * NB;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < nrow * ncol + nb; t += (long long)gridDim.x * 256) {
+    if (t < nrow * ncol) G.S[(size_t)(t / nrow) * G.ld + (size_t)G.T * NB + (size_t)(t % nrow)] = 0.0;
+    else G.bord[t - nrow * ncol] = 0.0;
+  }
+}
+__global__ __launch_bounds__(256) void k_border_fill_b(const GraphDev* __restrict__ Gs) {
+  const GraphDev G = Gs[blockIdx.z];
+  if (!G.arrow || G.nbr <= 0) return;
+  const int sidx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (sidx >= G.n_slots) return;
+  const int l = G.sh_lid[sidx];
+  if (l < 0) return;
+  const int o = G.lm_bord[l];
+  if (o < 0) return;
+  const int D = lm_dim(G.lm_type[l]);
+  const int a = lane / D, k = lane - a * D;
+  if (lane < 6 * D) {
+    for (int q = G.lm_ptr[l]; q < G.lm_ptr[l + 1]; ++q) {
+      const int f = G.lm_fids[q];
+      const double e = G.ebuf[G.lf_eoff[f] + a * D + k];
+      double* dst = G.S + (size_t)(6 * G.lf_pose[f] + a) * G.ld + (size_t)G.T * NB + o + k;
+      *dst += e;
+    }
+  }
+  const double* acc = G.lm_Hacc + 54 * (size_t)l;
+  if (lane < D * (D + 1) / 2) {
+    int r = 0;
+    while ((r + 1) * (r + 2) / 2 <= lane) ++r;
+    const int c = lane - r * (r + 1) / 2;
+    G.bord[(size_t)(o + c) * G.ldb + o + r] = acc[lane];
+  }
+  if (lane < D) G.bord[(size_t)(o + lane) * G.ldb + (size_t)G.nbr * NB] = -acc[45 + lane];
+}
+// separator system of all shared landmarks = sum over the robots of their border blocks after k_border_syrk, gathered through the
+// robots' global -> local coordinate maps into the layout the Cholesky kernels factor (column-major lower, ld = (Ts + 1) * NB, the
+// right-hand side as first row of tile row Ts); the padding up to Ts * NB gets a unit diagonal.  Fixed summation order.
+struct SepGatherArgs {
+  int n, m, Ts, ld;
+  double* out;
+  const double* bord[8]; int ldb[8]; int nbr[8]; const int* map[8];
+};
+__global__ __launch_bounds__(256) void k_sep_gather(SepGatherArgs A) {
+  const int gr = blockIdx.x * 256 + threadIdx.x, gc = blockIdx.y;
+  const int NT = A.Ts * NB;
+  if (gr > NT || gc >= NT) return;
+  const bool rhs = gr == NT;
+  if (!rhs && gr < gc) return;
+  double s = 0.0;
+  if (gc >= A.m || (!rhs && gr >= A.m)) {
+    s = (gr == gc) ? 1.0 : 0.0;
+  } else {
+    for (int r = 0; r < A.n; ++r) {
+      const int lc = A.map[r][gc];
+      if (lc < 0) continue;
+      const int lr = rhs ? A.nbr[r] * NB : A.map[r][gr];
+      if (lr < 0) continue;
+      s += A.bord[r][(size_t)lc * A.ldb[r] + lr];
+    }
+  }
+  A.out[(size_t)gc * A.ld + gr] = s;
+}
+// the separator's solution back to the robots: x_loc (border order, for k_border_apply) and, after the landmark back-substitution,
+// the shared landmarks' own deltas
+struct SepScatterArgs { int n, m; const double* xs; double* xloc[8]; const int* map[8]; };
+__global__ __launch_bounds__(256) void k_sep_xloc(SepScatterArgs A) {
+  const int g = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (g >= A.m || r >= A.n) return;
+  const int lc = A.map[r][g];
+  if (lc >= 0) A.xloc[r][lc] = A.xs[g];
+}
+__global__ __launch_bounds__(256) void k_sep_lm_delta_b(const GraphDev* __restrict__ Gs, SepScatterArgs A, const int* __restrict__ sep_off) {
+  const GraphDev G = Gs[blockIdx.z];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int sidx = t / 9, k = t - 9 * sidx;
+  if (sidx >= G.n_slots) return;
+  const int l = G.sh_lid[sidx];
+  if (l < 0) return;
+  if (k < lm_dim(G.lm_type[l])) G.lm_delta[9 * (size_t)l + k] = A.xs[sep_off[sidx] + k];
+}
 // calculateEstimate(): theta (+) delta
 // what 0: buf[12 s ..] = estimate of the local pose owning ghost slot s (zeros when another rank owns it)
 // what 1: ghost_val <- buf (after the all-reduce every slot holds its owner's pose)
@@ -1116,6 +1214,26 @@ void launch_phase3_batched(const GraphDev* d, const GraphDev* h, int n, double* 
     hipLaunchKernelGGL(k_pad_rhs_b, dim3(blocks_for(pad, 256), 1, n), dim3(256), 0, s, d);
   }
 }
+// the same for an exact joint pass: no exchanged sums to unpack (a separator landmark keeps the robot's own H_ll / g_l), then the border
+void launch_phase3_arrow_batched(const GraphDev* d, const GraphDev* h, int n, hipStream_t s) {
+  int L = 0, P = 0;
+  long long pad = 0;
+  for (int i = 0; i < n; ++i) {
+    L = std::max(L, h[i].L); P = std::max(P, h[i].P);
+    const long long NT = (long long)h[i].T * NB;
+    pad = std::max(pad, NT + (NT - 6LL * h[i].P) * NT);
+  }
+  if (L > 0) hipLaunchKernelGGL(k_landmark_b<2>, dim3(blocks_for(L, 4), 1, n), dim3(256), 0, s, d);
+  if (P > 0) {
+    hipLaunchKernelGGL(k_pose_b, dim3(blocks_for(P, 4), 1, n), dim3(256), 0, s, d);
+    int split = 1;
+    for (int i = 0; i < n; ++i) split = std::max(split, h[i].schur_split > 0 ? h[i].schur_split : 2);
+    hipLaunchKernelGGL(k_schur_b, dim3(P, split > 0 ? split : 1, n), dim3(256),
+                       (size_t)((L + 7) / 8 * 8) * sizeof(short) + (size_t)((P + 31) / 32 + 1) * sizeof(unsigned), s, d);
+    hipLaunchKernelGGL(k_pad_rhs_b, dim3(blocks_for(pad, 256), 1, n), dim3(256), 0, s, d);
+  }
+  launch_border_assemble_batched(d, h, n, s);
+}
 __global__ void k_shared_pack_b(const GraphDev* __restrict__ Gs, int what, BufPtrs B) { k_shared_pack_body(Gs[blockIdx.z], what, B.p[blockIdx.z]); }
 // The per-robot phases of a batched pass in ONE launch sequence for all robots (blockIdx.z = robot, grids sized for the largest graph):
 // forking every robot's phase onto its own stream and joining again cost three cross-stream joins of ~15 us per pass.
@@ -1169,6 +1287,42 @@ void launch_ghost_exchange(const GraphDev& G, int what, double* buf, hipStream_t
 void launch_estimate(const GraphDev& G, hipStream_t s) {
   if (G.P + G.L == 0) return;
   hipLaunchKernelGGL(k_estimate, dim3(blocks_for(G.P + G.L, 256)), dim3(256), 0, s, G);
+}
+
+void launch_border_assemble_batched(const GraphDev* d, const GraphDev* h, int n, hipStream_t s) {
+  int slots = 0;
+  long long work = 0;
+  for (int i = 0; i < n; ++i) {
+    slots = std::max(slots, h[i].n_slots);
+    work = std::max(work, (long long)h[i].nbr * NB * h[i].T * NB + (long long)(h[i].nbr + 1) * NB * h[i].nbr * NB);
+  }
+  if (work <= 0 || slots <= 0) return;
+  hipLaunchKernelGGL(k_border_clear_b, dim3((unsigned)std::min<long long>((work + 255) / 256, 4096), 1, n), dim3(256), 0, s, d);
+  hipLaunchKernelGGL(k_border_fill_b, dim3((slots + 3) / 4, 1, n), dim3(256), 0, s, d);
+}
+void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, int m, double* out, int Ts, hipStream_t s) {
+  SepGatherArgs A{};
+  A.n = n; A.m = m; A.Ts = Ts; A.ld = (Ts + 1) * NB; A.out = out;
+  for (int i = 0; i < n; ++i) { A.bord[i] = h[i].bord; A.ldb[i] = h[i].ldb; A.nbr[i] = h[i].nbr; A.map[i] = maps[i]; }
+  if (Ts > 0) hipLaunchKernelGGL(k_sep_gather, dim3((Ts * NB + 1 + 255) / 256, Ts * NB), dim3(256), 0, s, A);
+}
+void launch_sep_xloc(int n, const int* const* maps, int m, const double* xs, double* const* xloc, hipStream_t s) {
+  SepScatterArgs A{};
+  A.n = n; A.m = m; A.xs = xs;
+  for (int i = 0; i < n; ++i) { A.xloc[i] = xloc[i]; A.map[i] = maps[i]; }
+  if (m > 0) hipLaunchKernelGGL(k_sep_xloc, dim3((m + 255) / 256, n), dim3(256), 0, s, A);
+}
+// the last steps of an exact joint pass for all robots of the GPU: pose_delta = dp and the private landmarks' deltas (k_backsub<0>; a
+// separator landmark gets 0 there: H_ll^-1 = 0), the separator landmarks' deltas from the separator's solution, estimate
+void launch_arrow_finish_batched(const GraphDev* d, const GraphDev* h, int n, const double* xs, const int* sep_off, hipStream_t s) {
+  int L = 0, P = 0, slots = 0;
+  for (int i = 0; i < n; ++i) { L = std::max(L, h[i].L); P = std::max(P, h[i].P); slots = std::max(slots, h[i].n_slots); }
+  if (P + L == 0) return;
+  hipLaunchKernelGGL(k_backsub_b<0>, dim3(std::max(blocks_for(L, 4), blocks_for(6 * P, 256)), 1, n), dim3(256), 0, s, d);
+  SepScatterArgs A{};
+  A.n = n; A.xs = xs;
+  if (slots > 0) hipLaunchKernelGGL(k_sep_lm_delta_b, dim3(blocks_for(9LL * slots, 256), 1, n), dim3(256), 0, s, d, A, sep_off);
+  hipLaunchKernelGGL(k_estimate_b, dim3(blocks_for(P + L, 256), 1, n), dim3(256), 0, s, d);
 }
 
 }  // namespace sl

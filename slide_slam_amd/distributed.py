@@ -248,11 +248,20 @@ class PassDriver:
         self.arrow = bool(arrow) and n_slots > 0
         self.sep_dim = int(sep_dim)
         self.sbufs = None
+        self.sep = None
         if self.arrow:
             self.pcg_iters = 0
             if device is None:
                 m = self.sep_dim
                 self.sbufs = [np.zeros(m * m + 2 * m) for _ in shards]
+            else:
+                if batch is None:
+                    raise ValueError("the exact joint step of HIP shards runs as a batched pass: join the shards to a CholBatch")
+                import torch
+                self.sep_len = batch.sep_buffer_len(self.sep_dim)
+                self.sep = torch.zeros(max(self.sep_len, 1), dtype=torch.float64, device=device)      # the separator system: all-reduced between the parts
+        if batch is not None:
+            batch.set_exact_joint(self.arrow, self.sep.data_ptr() if self.sep is not None else 0, self.sep_len if self.sep is not None else 0)
         if batch is not None:           # (always pushed, zero included: a batch or graph may still hold an earlier driver's setting)
             batch.set_pcg(self.pcg_iters, self.pcg_tol)
         else:
@@ -287,6 +296,11 @@ class PassDriver:
         if self.batch is not None:
             if self.world == 1 and not self.force_parts:
                 self.batch.pass_all(self.ptrs)
+            elif self.arrow:
+                self.batch.pass_part(self.ptrs, 0)
+                if self.world > 1 or self.base is not None:
+                    self.base.all_reduce_on(self.sep, self.sep_len, self.batch.stream() if self.stream_ordered else None)
+                self.batch.pass_part(self.ptrs, 2)
             else:
                 self.batch.pass_part(self.ptrs, 0)
                 self._exchange(n54)

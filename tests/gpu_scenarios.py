@@ -344,7 +344,74 @@ def tiny_pcg(out, preset="C3tiny", passes=15, pcg=8):
     json.dump(res, open(out, "w"))
 
 
+def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1):
+    """The EXACT joint step (shared landmarks as the separator of the joint graph) of the HIP shards in one CholBatch — the whole pass
+    one replayed hipGraph — against oracle shards taking the same step pass by pass, and (small presets) against the optimum of the
+    oracle's joint replica, the reference's arrangement.  mode: replay = streaming build per robot (per-frame solves), ingest = all
+    frames at their ground-truth poses, one solve (bench.py's workload build)."""
+    import torch
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)
+    import slide_slam_amd as s
+    from oracle import pyoracle as po
+    from dist_worker import oracle_matcher
+    from slide_slam_amd.distributed import PassDriver, gpu_matcher, setup_local_shards
+    from slide_slam_amd.replay import replay_single
+    from slide_slam_amd.synth import SynthConfig, make_robot_log, make_world
+    cfg = SynthConfig.preset(preset)
+    wm = make_world(cfg)
+    R, P = cfg.robots, cfg.poses_per_robot
+    logs = [make_robot_log(cfg, wm, r) for r in range(R)]
+    joint, counts = None, None
+    if with_joint:
+        from test_distributed import _joint_optimum
+        joint, counts = _joint_optimum(preset)
+    A = [s.SlideBackend(s.default_params(), 1) for _ in range(R)]
+    L = po.lib(native=True)
+    O = [po.OracleBackend(po.OrcParams.default(num_threads=min(os.cpu_count() or 1, 16)), 1, L=L) for _ in range(R)]
+    for a, o, lg in zip(A, O, logs):
+        if mode == "ingest":
+            ingest(a, lg, s.FRAME_FOREIGN)
+            ingest(o, lg, 2)
+        else:
+            replay_single(a, lg, collect=False)
+            replay_single(o, lg, robot=0, collect=False)
+    say("shards built")
+    batch = s.CholBatch(R)
+    for t, a in enumerate(A):
+        a.graph.join_chol_batch(batch, t)
+    bufA, infoA = setup_local_shards(A, gpu_matcher, device=dev)
+    bufO, infoO = setup_local_shards(O, oracle_matcher)
+    dA = PassDriver(A, bufA, infoA["n_slots"], batch=batch, device=dev, arrow=True, sep_dim=infoA["sep_dim"])
+    dO = PassDriver(O, bufO, infoO["n_slots"], arrow=True, sep_dim=infoO["sep_dim"])
+    say("associated:", infoA["n_slots"], infoO["n_slots"], "slots, separator", infoA["sep_dim"], infoO["sep_dim"])
+    res = dict(n_slots=[infoA["n_slots"], infoO["n_slots"]], sep_dim=[infoA["sep_dim"], infoO["sep_dim"]],
+               n_global=[list(map(int, infoA["n_global"])), list(map(int, infoO["n_global"]))], gpu_vs_oracle=[], step=[], vs_joint=[], ms=[])
+    prev = None
+    for p in range(passes):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        dA.one_pass()
+        torch.cuda.synchronize(); res["ms"].append((time.perf_counter() - t0) * 1e3)
+        dO.one_pass()
+        a, o = poses_of(A, P), poses_of(O, P)
+        nrm = np.linalg.norm(o.reshape(R, -1), axis=1)
+        res["gpu_vs_oracle"].append(float((np.linalg.norm((a - o).reshape(R, -1), axis=1) / nrm).max()))
+        res["step"].append(float(np.abs(a - prev).max()) if prev is not None else None)
+        if joint is not None:
+            res["vs_joint"].append(float((np.linalg.norm((a - joint).reshape(R, -1), axis=1) / np.linalg.norm(joint.reshape(R, -1), axis=1)).max()))
+        prev = a
+        say("pass", p + 1, "GPU vs oracle", res["gpu_vs_oracle"][-1], "step", res["step"][-1], "vs joint", res["vs_joint"][-1:] , "ms", res["ms"][-1])
+    res["finite"] = bool(np.isfinite(prev).all())
+    res["chi2"] = sum(x.graph.chi2()["total"] for x in A)
+    if counts is not None:
+        res["joint_counts"] = [counts["cyl"], counts["cube"], counts["point"]]
+    for a in A:
+        a.graph.join_chol_batch(None)
+    json.dump(res, open(out, "w"))
+
+
 if __name__ == "__main__":
-    fn = {"c4_parity": c4_parity, "c3_joint": c3_joint, "c5_stream": c5_stream, "c3_converge": c3_converge, "c3_assoc_check": c3_assoc_check, "tiny_pcg": tiny_pcg}[sys.argv[1]]
+    fn = {"arrow_parity": arrow_parity, "c4_parity": c4_parity, "c3_joint": c3_joint, "c5_stream": c5_stream, "c3_converge": c3_converge, "c3_assoc_check": c3_assoc_check, "tiny_pcg": tiny_pcg}[sys.argv[1]]
     extra = [int(a) if a.lstrip("-").isdigit() else a for a in sys.argv[3:]]
     fn(sys.argv[2], *extra)
