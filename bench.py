@@ -221,8 +221,12 @@ def main():
                     help="robot shards per GPU; 0 = the preset's robots / N when that divides (the SAME 8-robot graph at every N: "
                          "strong scaling), else 1; 1 = one robot per GPU at every N (weak scaling)")
     ap.add_argument("--probe", type=int, default=20, help="passes recorded one by one for the convergence figure")
-    ap.add_argument("--pcg", type=int, default=8,
-                    help="PCG iterations of the joint solve per pass (0 = every robot's own block solve only: block-Jacobi over robots)")
+    ap.add_argument("--joint", choices=("exact", "pcg", "jacobi"), default="exact",
+                    help="joint Gauss-Newton step over the robots: exact = shared landmarks as the separator of the joint graph (one "
+                         "all-reduce per pass, no inner iteration: the step of the reference's full replica); pcg = --pcg conjugate-gradient "
+                         "iterations on the global reduced pose system per pass (inexact); jacobi = every robot's own block solve only")
+    ap.add_argument("--pcg", type=int, default=8, help="--joint pcg: PCG iterations per pass")
+    ap.add_argument("--pcg-tol", type=float, default=0.0, help="--joint pcg: relative tolerance on sqrt(r^T M^-1 r) (0: every iteration counts)")
     args = ap.parse_args()
     global DENSE_PROFILE, DENSE_LEG
     DENSE_PROFILE = args.dense_profile
@@ -292,13 +296,15 @@ def main():
         for t, gb in enumerate(shards):
             gb.graph.join_chol_batch(batch, t)
         bufs, info = setup_local_shards(shards, gpu_matcher, base=base, rank=rank, world=wdev, device=device)
-        drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, base=base, world=wdev, device=device, pcg_iters=args.pcg)
+        drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, base=base, world=wdev, device=device,
+                         pcg_iters=args.pcg if args.joint == "pcg" else 0, pcg_tol=args.pcg_tol, arrow=args.joint == "exact", sep_dim=info["sep_dim"])
         if sync_coll:
             drv.stream_ordered = False
         if os.environ.get("SLIDE_BENCH_FORCE_PARTS") == "1":      # rehearsal of the N > 1 control flow (cut pass + RCCL on the batch's stream) on one rank
             drv.force_parts = True
         step = drv.one_pass
-        js = f", joint solve: {drv.pcg_iters} PCG iterations on the global reduced system" if drv.pcg_iters else ", block-Jacobi over robots"
+        js = (f", exact joint step: shared landmarks as separator ({info['sep_dim']} coordinates)" if drv.arrow else
+              f", joint solve: {drv.pcg_iters} PCG iterations on the global reduced system" if drv.pcg_iters else ", block-Jacobi over robots")
         mode = ("one replayed hipGraph per pass, factorisations batched" if (wdev == 1 and not drv.force_parts) else
                 f"replayed hipGraph parts, {backend} all-reduces of the shared-landmark blocks on the same stream between them") + js
     else:
@@ -332,7 +338,13 @@ def main():
 
     if multi:
         ptrs = [b.data_ptr() for b in bufs]
-        if wdev == 1:
+        if wdev == 1 and drv.arrow:
+            runs = [batch.profile_exact_joint(ptrs) for _ in range(5)]
+            stages = {k: float(np.median([r[0][k] for r in runs])) for k in runs[0][0]}
+            info["exact_joint_stages_ms"] = stages
+            info["separator_block_columns"] = runs[0][1]
+            print("exact joint pass, stage times (ms):", stages, file=sys.stderr, flush=True)
+        if wdev == 1 and not drv.arrow:
             # device time of the batched step kernels (HIP events on the batch's stream, un-captured passes) for the roofline
             pr = sorted(batch.profile(ptrs) for _ in range(5))
             profs = [gb.graph.tile_profile() for gb in shards]
@@ -374,7 +386,7 @@ def main():
                     "note": ("joint Gauss-Newton step by PCG on the global reduced pose system" if drv.pcg_iters else
                              "block-Jacobi over robots (no joint solve): does not converge once robots share many landmarks") +
                             f"; final = after all {n_passes} passes of this run; chi2 = 2 x NonlinearFactorGraph::error over all robots"}
-        if not args.no_parity:
+        if not args.no_parity and not drv.arrow:
             # ---- parity of what was timed: identically built shards, the same number of passes through the UN-batched path ----
             for gb in shards:
                 gb.graph.join_chol_batch(None)

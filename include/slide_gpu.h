@@ -194,8 +194,9 @@ int slide_graph_set_pcg_tolerance(slide_graph_t* g, double tol);
  *   slide_graph_set_separator: off[i] = offset of shared slot i's tangent coordinates (cylinder 7, cube 9, point 3, in slot order) in
  *     the separator system, n = n_slots + 1 entries, identical on every rank; after slide_graph_set_shared.
  *   slide_chol_batch_set_exact_joint(b, 1, sep_buf, len): passes of the batch take the exact joint step (batched passes only; the PCG
- *     setting is ignored).  sep_buf: device buffer of slide_chol_batch_sep_buffer_len(m) doubles, m = off[n_slots] — the caller's when
- *     it all-reduces it between the parts, or NULL (allocated by the batch).
+ *     setting is ignored).  sep_buf: the caller's device buffer of slide_chol_batch_sep_buffer_len(m) doubles, m = off[n_slots], in which
+ *     part 0 of a cut pass leaves this GPU's partial sum of the separator system (packed: the lower tile columns only) and from which
+ *     part 2 takes the all-reduced sum; NULL when the job is this process alone (whole passes only).
  * A cut pass then reads   part 0 | all-reduce(sum) of sep_buf[0 .. len) on slide_chol_batch_stream() | part 2. */
 int slide_graph_set_separator(slide_graph_t* g, const int32_t* off, int n);
 int slide_chol_batch_set_exact_joint(slide_chol_batch_t* b, int on, double* sep_buf, long long len);
@@ -214,6 +215,10 @@ int slide_graph_set_dense_profile(slide_graph_t* g, int on);
 /* Measurement aid: the same pass issued without the graph, HIP events around the batched step kernels; *ms_steps = their device time
  * (launch gaps included), *n_launches = their number. */
 int slide_chol_batch_profile(slide_chol_batch_t* b, double* const* d_bufs, double* ms_steps, int* n_launches);
+/* The same for an exact joint pass, stage by stage (HIP events on the pass's stream): out6 = ms of {assembly (relinearisation ..
+ * borders), the bands' factorisations, the border products (k_border_syrk), the separator gather, the separator's factorisation +
+ * solve, the back-substitutions}; *n_sep_steps = block columns of the separator system. */
+int slide_chol_batch_profile_exact_joint(slide_chol_batch_t* b, double* const* d_bufs, double out6[6], int* n_sep_steps);
 /* Sharded mode, inter-robot relative-pose factors (addRelativeMeasFactor graph.cpp:247-258 between poses of two ranks).
  * Ghost slots enumerate, identically on every rank, the poses such factors touch; slot i is this rank's pose
  * (own_robot[i], own_idx[i]) or belongs to another rank (own_robot[i] < 0).  A factor is added on BOTH ranks, each with its

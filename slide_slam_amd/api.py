@@ -28,7 +28,7 @@ EXPORTS = [
     "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
     "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
-    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_chol_batch_set_pcg_tolerance", "slide_graph_set_pcg_tolerance", "slide_graph_set_separator", "slide_chol_batch_set_exact_joint", "slide_chol_batch_sep_buffer_len", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
+    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_chol_batch_set_pcg_tolerance", "slide_graph_set_pcg_tolerance", "slide_graph_set_separator", "slide_chol_batch_set_exact_joint", "slide_chol_batch_sep_buffer_len", "slide_chol_batch_profile_exact_joint", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
     "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
     "slide_dense_spd_solve", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device", "slide_assoc_sweep_batch",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
@@ -357,6 +357,15 @@ class CholBatch:
         ms, nl = C.c_double(0), C.c_int(0)
         _check(self.L.slide_chol_batch_profile(C.c_void_p(self.h), arr, C.byref(ms), C.byref(nl)))
         return ms.value, nl.value
+
+    def profile_exact_joint(self, buf_ptrs):
+        """Stage times (ms) of one un-captured exact joint pass + block columns of the separator system."""
+        arr = (C.c_void_p * len(buf_ptrs))(*[int(p) for p in buf_ptrs])
+        out = np.zeros(6)
+        ns = C.c_int(0)
+        _check(self.L.slide_chol_batch_profile_exact_joint(C.c_void_p(self.h), arr, _p(out), C.byref(ns)))
+        names = ("assembly", "band_factorisations", "border_products", "separator_gather", "separator_solve", "back_substitution")
+        return dict(zip(names, [float(v) for v in out])), ns.value
 
     def close(self):
         if self.h:

@@ -511,8 +511,8 @@ int CholBatch::prepare_pass() {
 }
 // ---- exact joint step: the separator system of all shared landmarks -------------------------------------------------------------------
 void CholBatch::free_separator() {
-  if (sep_owned && sepS) (void)hipFree(sepS);
-  sepS = nullptr; sep_owned = false; sep_len = 0;
+  if (sepS) (void)hipFree(sepS);
+  sepS = nullptr; sep_len = 0;
   for (double** p : {&sep_Ld, &sep_Winv, &sep_yv, &sep_dp}) if (*p) { (void)hipFree(*p); *p = nullptr; }
   for (int** p : {&sep_status, &sep_ctr, &d_sep_off}) if (*p) { (void)hipFree(*p); *p = nullptr; }
   sep_cap = 0;
@@ -523,8 +523,7 @@ int CholBatch::set_arrow(bool on, double* sep_buf, long long len) {
   {
     std::lock_guard<std::mutex> lk(mtx);
     if (master) (void)hipStreamSynchronize(master);
-    if (sep_owned && sepS) (void)hipFree(sepS);
-    sepS = sep_buf; sep_owned = false; sep_len = sep_buf ? len : 0;
+    sep_x = sep_buf; sep_x_len = sep_buf ? len : 0;
     arrow = on;
     pass_dirty = true;
     gs.assign(graphs.begin(), graphs.end());
@@ -545,12 +544,12 @@ int CholBatch::prepare_separator() {
   const std::vector<int>& off = graphs[0]->h_sep_off;
   sep_m = off.back();
   sep_Ts = (sep_m + NB - 1) / NB;
-  const long long need = sep_buffer_len(sep_m);
-  if (sepS && !sep_owned && sep_len < need) { g_last_error = "exact joint step: the separator buffer is too small (slide_chol_batch_sep_buffer_len)"; return SLIDE_ERR_INVALID; }
-  if (!sepS || (sep_owned && sep_len < need)) {
-    if (sep_owned && sepS) { SL_HIP(hipStreamSynchronize(master)); SL_HIP(hipFree(sepS)); sepS = nullptr; }
+  const long long need = (long long)(sep_Ts + 1) * NB * sep_Ts * NB;
+  if (sep_x && sep_x_len < sep_buffer_len(sep_m)) { g_last_error = "exact joint step: the separator exchange buffer is too small (slide_chol_batch_sep_buffer_len)"; return SLIDE_ERR_INVALID; }
+  if (!sepS || sep_len < need) {
+    if (sepS) { SL_HIP(hipStreamSynchronize(master)); SL_HIP(hipFree(sepS)); sepS = nullptr; }
     SL_HIP(hipMalloc(reinterpret_cast<void**>(&sepS), std::max<long long>(need, 1) * sizeof(double)));
-    sep_owned = true; sep_len = need;
+    sep_len = need;
   }
   if (sep_Ts > sep_cap) {
     SL_HIP(hipStreamSynchronize(master));
@@ -568,6 +567,7 @@ int CholBatch::prepare_separator() {
   }
   // zero once: the strict upper triangle and the idle rows of the right-hand-side tile are never written by the gather
   SL_HIP(hipMemset(sepS, 0, (size_t)need * sizeof(double)));
+  if (sep_x) SL_HIP(hipMemset(sep_x, 0, (size_t)sep_buffer_len(sep_m) * sizeof(double)));
   if (d_sep_off) { SL_HIP(hipFree(d_sep_off)); d_sep_off = nullptr; }
   SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_off), off.size() * sizeof(int)));
   SL_HIP(hipMemcpy(d_sep_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -575,8 +575,9 @@ int CholBatch::prepare_separator() {
 }
 // One exact joint Gauss-Newton pass of all joined graphs.  part -1: the whole pass; 0: up to this GPU's partial sum of the separator
 // system (the caller all-reduces the separator buffer across the GPUs on the pass's stream); 2: the rest.
-int CholBatch::enqueue_arrow(double* const* d_bufs, int part) {
+int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hipEvent_t e1) {
   const bool whole = part < 0;
+  auto mark = [&](int i) { if (prof_ev[0]) (void)hipEventRecord(prof_ev[i], master); };
   const int* maps[CHOL_BATCH_HOST_MAX];
   double* xloc[CHOL_BATCH_HOST_MAX];
   for (int i = 0; i < n; ++i) { maps[i] = graphs[i]->d_sep_map.d; xloc[i] = graphs[i]->d_xloc.d; }
@@ -586,24 +587,63 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part) {
     launch_ints_clear(sep_status, 8, master);
     launch_phase0_batched(d_Gs, hG.data(), n, d_bufs, master);      // relinearise, linearise, the robots' own per-landmark sums
     launch_phase3_arrow_batched(d_Gs, hG.data(), n, master);         // private landmarks eliminated, reduced pose systems, borders
-    const int rc = factor_all(nullptr);                              // the bands' steps: W^T and y in the border rows
+    if (e0) (void)hipEventRecord(e0, master);
+    mark(0);
+    const int rc = factor_all(e1);                                   // the bands' steps: W^T and y in the border rows
     if (rc != SLIDE_OK) return rc;
+    mark(1);
     launch_border_syrk(sys.data(), n, master);                       // border blocks: C_a - W^T W, b_s - W^T y
-    launch_sep_gather(hG.data(), n, maps, sep_m, sepS, sep_Ts, master);
+    mark(2);
+    // a cut pass leaves this GPU's partial sum in the caller's exchange buffer (packed), a whole pass writes the system itself
+    if (whole) launch_sep_gather(hG.data(), n, maps, sep_m, sepS, sep_Ts, false, master);
+    else launch_sep_gather(hG.data(), n, maps, sep_m, sep_x, sep_Ts, true, master);
+    mark(3);
   }
   if (whole || part == 2) {
+    if (!whole) launch_sep_unpack(sep_x, sepS, sep_Ts, master);
     for (int k = 0; k < sep_Ts; ++k)
       launch_chol_step(sepS, ld_s, k, sep_Ts, sep_Ld + (size_t)k * NB * NB, sep_Winv + (size_t)k * 1024, sep_status, sep_ctr, nullptr, nullptr, master);
     launch_chol_extract_y(sepS, ld_s, sep_Ts, sep_yv, sep_dp, sep_status, master);
     launch_chol_bwd_all(sepS, ld_s, sep_Ts, sep_Ld, sep_Winv, sep_yv, sep_dp, sep_status, nullptr, master);
+    mark(4);
     launch_sep_xloc(n, maps, sep_m, sep_dp, xloc, master);
     launch_border_apply(sys.data(), n, xloc, master);                // y -= W x_s
     launch_chol_bwd_batch(sys.data(), n, master);                    // L^T dp = y
     launch_arrow_finish_batched(d_Gs, hG.data(), n, sep_dp, d_sep_off, master);
     launch_status_or(hG[0].status, sep_status, 8, master);           // (the separator's not-SPD / chain flags are reported with graph 0's)
     launch_status_gather(d_Gs, n, d_status_all, master);
+    mark(5);
   }
   return SLIDE_OK;
+}
+// One exact joint pass issued directly (no graph) with HIP events on the pass's stream between its stages: out6 = ms of {assembly
+// (linearisation .. borders), the bands' factorisations, the border products, the separator gather, the separator's factorisation +
+// solve, the back-substitutions}, *n_sep_steps = block columns of the separator system
+int CholBatch::profile_arrow(double* const* d_bufs, double* out6, int* n_sep_steps) {
+  std::lock_guard<std::mutex> pl(pass_mtx);
+  bool same = false;
+  int rc = begin_pass(d_bufs, &same);
+  if (rc != SLIDE_OK) return rc;
+  if (!(arrow && hG[0].n_slots > 0)) { g_last_error = "profile_arrow: the batch does not run exact joint passes"; return SLIDE_ERR_INVALID; }
+  hipEvent_t start = nullptr;
+  SL_HIP(hipEventCreate(&start));
+  for (auto& e : prof_ev) SL_HIP(hipEventCreate(&e));
+  (void)hipEventRecord(start, master);
+  rc = enqueue_arrow(d_bufs, -1, nullptr, nullptr);
+  const hipError_t es = hipStreamSynchronize(master);
+  if (rc == SLIDE_OK && es == hipSuccess) {
+    hipEvent_t prev = start;
+    for (int i = 0; i < 6; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, prev, prof_ev[i]) != hipSuccess) rc = SLIDE_ERR_HIP;
+      out6[i] = ms;
+      prev = prof_ev[i];
+    }
+    if (n_sep_steps) *n_sep_steps = sep_Ts;
+  } else if (rc == SLIDE_OK) rc = SLIDE_ERR_HIP;
+  (void)hipEventDestroy(start);
+  for (auto& e : prof_ev) { (void)hipEventDestroy(e); e = nullptr; }
+  return rc == SLIDE_OK ? end_pass() : rc;
 }
 // the launches of one pass of all joined graphs (captured by capture_pass, or issued directly by profile_pass with events e0 / e1
 // around the batched step kernels)
@@ -626,7 +666,7 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
     }
   };
   const int n_slots = graphs[0]->G.n_slots;
-  if (arrow && n_slots > 0) return enqueue_arrow(d_bufs, part);
+  if (arrow && n_slots > 0) return enqueue_arrow(d_bufs, part, e0, e1);
   const bool whole = part < 0;
   const bool joint = pcg_iters > 0 && n_slots > 0;       // PCG over the robots' coupled systems instead of the plain block solves
   if (whole || part == 0) {
@@ -927,6 +967,7 @@ int CholBatch::pass_part(double* const* d_bufs, int part) {
     return SLIDE_ERR_INVALID;
   }
   if (arrow && hG[0].n_slots > 0 && part != 0 && part != 2) return SLIDE_OK;      // exact joint step: one exchange, between parts 0 and 2
+  if (arrow && hG[0].n_slots > 0 && !sep_x) { g_last_error = "exact joint step: a cut pass needs the caller's separator exchange buffer (slide_chol_batch_set_exact_joint)"; return SLIDE_ERR_INVALID; }
   if (part >= 10 && !(pcg_iters > 0 && hG[0].n_slots > 0)) return SLIDE_OK;      // no joint solve: nothing between parts 1 and 2
   if (!part_exec[slot] && (rc = capture_pass(d_bufs, part, &part_exec[slot])) != SLIDE_OK) return rc;
   SL_HIP(hipGraphLaunch(part_exec[slot], master));

@@ -158,14 +158,16 @@ class CholBatch {
   void set_pcg(int iters, double tol = 0.0);
   int pcg() const { return pcg_iters; }
   double pcg_tolerance() const { return pcg_tol; }
-  // Exact joint step ("arrow"): the shared landmarks stay as the separator of the joint graph (graph_dev.hpp).  sep_buf: device buffer
-  // of sep_buffer_len(m) doubles that holds the separator system — the caller's (the cross-GPU all-reduce of a job that spans GPUs runs
-  // on it) or null: allocated here.  Changing it invalidates the captured launch sequences.
+  // Exact joint step ("arrow"): the shared landmarks stay as the separator of the joint graph (graph_dev.hpp).  sep_buf: the caller's
+  // device buffer of sep_buffer_len(m) doubles in which part 0 of a cut pass leaves this GPU's partial sum of the separator system
+  // (packed: lower tile columns only) for the cross-GPU all-reduce, and from which part 2 takes the sum; null: no exchange (the job is
+  // this process alone).  Changing it invalidates the captured launch sequences.
   int set_arrow(bool on, double* sep_buf, long long sep_len);
   bool is_arrow() const { return arrow; }
-  static long long sep_buffer_len(int m) { const long long Ts = (m + NB - 1) / NB; return (Ts + 1) * NB * Ts * NB; }
+  static long long sep_buffer_len(int m) { const long long Ts = (m + NB - 1) / NB; return (long long)NB * NB * Ts * (Ts + 3) / 2; }      // packed exchange layout
   hipStream_t pass_stream();                             // the stream the passes run on (created on first use)
   int profile_pass(double* const* d_bufs, double* ms_steps, int* n_launches);
+  int profile_arrow(double* const* d_bufs, double* out6, int* n_sep_steps);
 
  private:
   int n;
@@ -185,13 +187,15 @@ class CholBatch {
   double pcg_tol = 0.0;
   bool arrow = false;
   // separator system of the exact joint step: m coordinates, Ts tile columns; factored by the un-batched step kernels on the pass's stream
-  double* sepS = nullptr; bool sep_owned = false; long long sep_len = 0;
+  double* sepS = nullptr; long long sep_len = 0;          // the system in the factorisation's layout (owned)
+  double* sep_x = nullptr; long long sep_x_len = 0;       // the caller's exchange buffer (packed layout), or null: no exchange
   int sep_m = 0, sep_Ts = 0;
   double *sep_Ld = nullptr, *sep_Winv = nullptr, *sep_yv = nullptr, *sep_dp = nullptr;
   int *sep_status = nullptr, *sep_ctr = nullptr, *d_sep_off = nullptr;
   int sep_cap = 0;
   int prepare_separator();
-  int enqueue_arrow(double* const* d_bufs, int part);
+  int enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hipEvent_t e1);
+  hipEvent_t prof_ev[6] = {};
   void free_separator();
   int enqueue_pcg_head(double* const* d_bufs);                   // r = b, u = M^-1 b, t_l(u) packed + local sum
   int enqueue_pcg_mid(double* const* d_bufs, bool whole);                    // w = S u, partial dots + local sum

@@ -33,7 +33,8 @@ void launch_ghost_exchange(const GraphDev& G, int what, double* buf, hipStream_t
 // gathered from the robots' border blocks (maps[i]: m ints, global separator coordinate -> robot i's border coordinate or -1); its
 // solution handed back
 void launch_border_assemble_batched(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);
-void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, int m, double* out, int Ts, hipStream_t s);
+void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, int m, double* out, int Ts, bool packed, hipStream_t s);   // packed: the exchange layout (lower tile columns only)
+void launch_sep_unpack(const double* in, double* out, int Ts, hipStream_t s);
 void launch_sep_xloc(int n, const int* const* maps, int m, const double* xs, double* const* xloc, hipStream_t s);
 void launch_arrow_finish_batched(const GraphDev* d, const GraphDev* h, int n, const double* xs, const int* sep_off, hipStream_t s);
 void launch_phase3_arrow_batched(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);   // phase 3 without the exchanged sums: the robots' own H_ll

@@ -1042,8 +1042,15 @@ __global__ __launch_bounds__(256) void k_border_fill_b(const GraphDev* __restric
 // separator system of all shared landmarks = sum over the robots of their border blocks after k_border_syrk, gathered through the
 // robots' global -> local coordinate maps into the layout the Cholesky kernels factor (column-major lower, ld = (Ts + 1) * NB, the
 // right-hand side as first row of tile row Ts); the padding up to Ts * NB gets a unit diagonal.  Fixed summation order.
+// packed: the exchange buffer of a job that spans GPUs — tile column j holds its tile rows j .. Ts only (column-major inside, height
+// (Ts + 1 - j) * NB), 4096 * Ts (Ts + 3) / 2 doubles instead of the full rectangle; k_sep_unpack copies it into the factorisation's layout
+__device__ __forceinline__ size_t sep_packed_addr(int row, int col, int Ts) {
+  const int tj = col / NB, cc = col - tj * NB;
+  const size_t off = (size_t)(NB * NB) * ((size_t)tj * (Ts + 1) - (size_t)tj * (tj - 1) / 2);
+  return off + (size_t)cc * ((size_t)(Ts + 1 - tj) * NB) + (size_t)(row - tj * NB);
+}
 struct SepGatherArgs {
-  int n, m, Ts, ld;
+  int n, m, Ts, ld, packed;
   double* out;
   const double* bord[8]; int ldb[8]; int nbr[8]; const int* map[8];
 };
@@ -1065,7 +1072,14 @@ __global__ __launch_bounds__(256) void k_sep_gather(SepGatherArgs A) {
       s += A.bord[r][(size_t)lc * A.ldb[r] + lr];
     }
   }
-  A.out[(size_t)gc * A.ld + gr] = s;
+  if (A.packed) A.out[sep_packed_addr(gr, gc, A.Ts)] = s;
+  else A.out[(size_t)gc * A.ld + gr] = s;
+}
+__global__ __launch_bounds__(256) void k_sep_unpack(const double* __restrict__ in, double* __restrict__ out, int Ts) {
+  const int gr = blockIdx.x * 256 + threadIdx.x, gc = blockIdx.y;
+  const int NT = Ts * NB;
+  if (gr > NT || gc >= NT || gr < gc / NB * NB) return;
+  out[(size_t)gc * (size_t)(Ts + 1) * NB + gr] = in[sep_packed_addr(gr, gc, Ts)];
 }
 // the separator's solution back to the robots: x_loc (border order, for k_border_apply) and, after the landmark back-substitution,
 // the shared landmarks' own deltas
@@ -1300,9 +1314,12 @@ void launch_border_assemble_batched(const GraphDev* d, const GraphDev* h, int n,
   hipLaunchKernelGGL(k_border_clear_b, dim3((unsigned)std::min<long long>((work + 255) / 256, 4096), 1, n), dim3(256), 0, s, d);
   hipLaunchKernelGGL(k_border_fill_b, dim3((slots + 3) / 4, 1, n), dim3(256), 0, s, d);
 }
-void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, int m, double* out, int Ts, hipStream_t s) {
+void launch_sep_unpack(const double* in, double* out, int Ts, hipStream_t s) {
+  if (Ts > 0) hipLaunchKernelGGL(k_sep_unpack, dim3((Ts * NB + 1 + 255) / 256, Ts * NB), dim3(256), 0, s, in, out, Ts);
+}
+void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, int m, double* out, int Ts, bool packed, hipStream_t s) {
   SepGatherArgs A{};
-  A.n = n; A.m = m; A.Ts = Ts; A.ld = (Ts + 1) * NB; A.out = out;
+  A.n = n; A.m = m; A.Ts = Ts; A.ld = (Ts + 1) * NB; A.out = out; A.packed = packed ? 1 : 0;
   for (int i = 0; i < n; ++i) { A.bord[i] = h[i].bord; A.ldb[i] = h[i].ldb; A.nbr[i] = h[i].nbr; A.map[i] = maps[i]; }
   if (Ts > 0) hipLaunchKernelGGL(k_sep_gather, dim3((Ts * NB + 1 + 255) / 256, Ts * NB), dim3(256), 0, s, A);
 }

@@ -254,19 +254,25 @@ class PassDriver:
             if device is None:
                 m = self.sep_dim
                 self.sbufs = [np.zeros(m * m + 2 * m) for _ in shards]
-            else:
-                if batch is None:
-                    raise ValueError("the exact joint step of HIP shards runs as a batched pass: join the shards to a CholBatch")
-                import torch
-                self.sep_len = batch.sep_buffer_len(self.sep_dim)
-                self.sep = torch.zeros(max(self.sep_len, 1), dtype=torch.float64, device=device)      # the separator system: all-reduced between the parts
+            elif batch is None:
+                raise ValueError("the exact joint step of HIP shards runs as a batched pass: join the shards to a CholBatch")
         if batch is not None:
-            batch.set_exact_joint(self.arrow, self.sep.data_ptr() if self.sep is not None else 0, self.sep_len if self.sep is not None else 0)
+            batch.set_exact_joint(self.arrow, 0, 0)      # (the exchange buffer of a cut pass is installed on first use: _sep_exchange_buffer)
         if batch is not None:           # (always pushed, zero included: a batch or graph may still hold an earlier driver's setting)
             batch.set_pcg(self.pcg_iters, self.pcg_tol)
         else:
             for sh in shards:
                 sh.graph.set_pcg(self.pcg_iters, self.pcg_tol)
+
+    def _sep_exchange_buffer(self):
+        """The separator system's exchange buffer of a cut pass (packed lower tile columns): this GPU's partial sum after part 0,
+        all-reduced across the GPUs on the batch's stream, read back by part 2."""
+        if self.sep is None:
+            import torch
+            self.sep_len = self.batch.sep_buffer_len(self.sep_dim)
+            self.sep = torch.zeros(max(self.sep_len, 1), dtype=torch.float64, device=self.device)
+            self.batch.set_exact_joint(True, self.sep.data_ptr(), self.sep_len)
+        return self.sep
 
     def _exchange(self, count):
         """all-reduce(sum) of buffer 0's first `count` doubles across the processes, ordered behind the batch's stream."""
@@ -297,9 +303,10 @@ class PassDriver:
             if self.world == 1 and not self.force_parts:
                 self.batch.pass_all(self.ptrs)
             elif self.arrow:
+                sep = self._sep_exchange_buffer()
                 self.batch.pass_part(self.ptrs, 0)
                 if self.world > 1 or self.base is not None:
-                    self.base.all_reduce_on(self.sep, self.sep_len, self.batch.stream() if self.stream_ordered else None)
+                    self.base.all_reduce_on(sep, self.sep_len, self.batch.stream() if self.stream_ordered else None)
                 self.batch.pass_part(self.ptrs, 2)
             else:
                 self.batch.pass_part(self.ptrs, 0)

@@ -179,8 +179,9 @@ def c5_stream(out, preset="C4", ticks=None, budget_ms=100.0):
     json.dump(res, open(out, "w"))
 
 
-def c3_converge(out, preset="C3", passes=400, every=20, pcg=0, unbatched=0):
-    """Convergence of the sharded passes (pcg = 0: block-Jacobi; > 0: joint solve by PCG) to the joint replica's optimum."""
+def c3_converge(out, preset="C3", passes=400, every=20, pcg=0, unbatched=0, arrow=0):
+    """Convergence of the sharded passes (pcg = 0: block-Jacobi; > 0: joint solve by PCG; arrow = 1: the exact joint step) to the
+    joint replica's optimum."""
     import torch
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -219,7 +220,7 @@ def c3_converge(out, preset="C3", passes=400, every=20, pcg=0, unbatched=0):
         for t, sh in enumerate(shards):
             sh.graph.join_chol_batch(batch, t)
     bufs, info = setup_local_shards(shards, gpu_matcher, device=dev)
-    drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, device=dev, pcg_iters=pcg)
+    drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, device=dev, pcg_iters=pcg, arrow=bool(arrow), sep_dim=info["sep_dim"])
     nrm = np.linalg.norm(joint.reshape(R, -1), axis=1) if joint is not None else None
     hist = []
     t_pass = 0.0
@@ -401,7 +402,8 @@ def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1):
         if joint is not None:
             res["vs_joint"].append(float((np.linalg.norm((a - joint).reshape(R, -1), axis=1) / np.linalg.norm(joint.reshape(R, -1), axis=1)).max()))
         prev = a
-        say("pass", p + 1, "GPU vs oracle", res["gpu_vs_oracle"][-1], "step", res["step"][-1], "vs joint", res["vs_joint"][-1:] , "ms", res["ms"][-1])
+        res.setdefault("chi2_pass", []).append(sum(x.graph.chi2()["total"] for x in A))
+        say("pass", p + 1, "GPU vs oracle", res["gpu_vs_oracle"][-1], "step", res["step"][-1], "vs joint", res["vs_joint"][-1:], "ms", res["ms"][-1], "chi2", res["chi2_pass"][-1])
     res["finite"] = bool(np.isfinite(prev).all())
     res["chi2"] = sum(x.graph.chi2()["total"] for x in A)
     if counts is not None:

@@ -75,6 +75,65 @@ def test_c3_full_size_sharded_joint_solve_reaches_the_replica_optimum(gpu, tmp_p
     assert z["hist"][-1][1] < 5e-3, z["hist"]                                  # poses: relative to the replica's
 
 
+@pytest.mark.parametrize("preset,tol", [("C3tiny", 5e-6), ("C4tiny", 1e-4)])
+def test_exact_joint_step_matches_oracle_shards_and_the_joint_replica(gpu, tmp_path, preset, tol):
+    """The exact joint step (shared landmarks as the separator of the joint graph: bordered band factorisations, FP64-MFMA border
+    products, separator solve — the whole pass one replayed hipGraph) against (a) oracle shards taking the same step, PASS BY PASS, and
+    (b) the optimum of the oracle's joint replica (one CPU graph holding every robot: the reference's arrangement, whose Gauss-Newton
+    step this is): six passes end there.  C4tiny: the merge of the four final maps differs from the replica's frame-by-frame
+    association by one landmark, which bounds (b) at ~5e-5."""
+    out = str(tmp_path / "arrow.json")
+    _scenario("arrow_parity", out, preset, 6, "replay", 1)
+    z = json.load(open(out))
+    assert z["finite"] and z["n_slots"][0] == z["n_slots"][1] > 0 and z["sep_dim"][0] == z["sep_dim"][1] and z["n_global"][0] == z["n_global"][1]
+    assert max(z["gpu_vs_oracle"]) < 1e-7, z["gpu_vs_oracle"]
+    assert z["vs_joint"][-1] < tol, z["vs_joint"]
+    assert sum(abs(a - b) for a, b in zip(z["n_global"][0], z["joint_counts"])) <= 1
+
+
+def test_c4_exact_joint_step_matches_oracle_shards_at_size(gpu, tmp_path):
+    """configs[3] at size through the path bench.py times (eight robots in one CholBatch, 59 block columns + 16 border row tiles each,
+    a 3809-coordinate separator system): the GPU pass against eight ORACLE shards taking the same exact joint step, pass by pass —
+    measured 1e-8 .. 4e-8 relative on poses (the bar is 1e-4) — and the Gauss-Newton iteration converges: the fourth step is three
+    orders below the second (it then sits in a 2-cycle of ~3e-4 m on 200 m trajectories, the noise of the numerical Jacobians)."""
+    out = str(tmp_path / "arrow_c4.json")
+    _scenario("arrow_parity", out, "C4", 4, "ingest", 0)
+    z = json.load(open(out))
+    assert z["finite"] and z["n_slots"][0] == z["n_slots"][1] > 500 and z["sep_dim"][0] == z["sep_dim"][1] > 1500
+    assert max(z["gpu_vs_oracle"]) < 1e-6, z["gpu_vs_oracle"]
+    assert z["step"][3] < 5e-3 * z["step"][1], z["step"]
+    assert abs(z["chi2_pass"][3] - z["chi2_pass"][2]) < 1e-4 * z["chi2_pass"][3], z["chi2_pass"]
+
+
+def test_c3_full_size_exact_joint_step_reaches_the_replica_optimum_1e4_on_poses(gpu, tmp_path):
+    """configs[2] at size, the bar VERDICT r2 asked to restore: 2 robots x 500 poses, 188 shared landmarks; the sharded passes with the
+    exact joint step end within 1e-4 RELATIVE ON POSES of the optimum of the joint graph a single host replica holds (streaming build +
+    30 Gauss-Newton iterations, on the GPU: the oracle would need hours for the 1000-pose streaming replay) — within SIX passes — and at
+    its cost."""
+    out = str(tmp_path / "c3a.json")
+    _scenario("c3_converge", out, "C3", 6, 1, 0, 0, 1)
+    z = json.load(open(out))
+    assert z["n_slots"] == 188 and z["n_global"] == z["joint_counts"]
+    assert z["hist"][-1][1] < 1e-4, z["hist"]
+    assert min(e for _, e in z["hist"][:5]) < 1e-4, z["hist"]          # (already there after five)
+    assert abs(z["chi2_shards"] - z["chi2_joint"]) <= 1e-5 * z["chi2_joint"], (z["chi2_shards"], z["chi2_joint"])
+
+
+def test_exact_joint_step_two_ranks_equal_one_process(gpu, tmp_path):
+    """configs[2] and configs[3] as TWO ranks on the one visible GPU (1 resp. 4 robots per rank; the pass cut at its ONE exchange, the
+    all-reduce of the packed separator system through gloo staged on the host standing in for RCCL) == one process holding all robots."""
+    from test_distributed import _run_workers
+    # C4: the eight robots' contributions to the separator system are summed as (0 + 1 + 2 + 3) + (4 + 5 + 6 + 7) instead of in one
+    # chain; the reduced systems carry the 1e-6 prior sigma (condition ~1e12), so the different rounding shows at ~1e-7 relative
+    for preset, per_rank, tol in (("C3", 1, 1e-9), ("C4", 4, 1e-6)):
+        out = str(tmp_path / f"{preset}_one.json")
+        _scenario("c3_converge", out, preset, 3, 3, 0, 0, 1)
+        one = np.array(json.load(open(out))["final"])
+        z = _run_workers("gpu", preset, 3, str(tmp_path / f"{preset}_two.npz"), world=2, extra=(f"driver={per_rank}", "arrow"))
+        assert z["poses"].shape == one.shape
+        assert np.abs(z["poses"] - one).max() < tol * np.abs(one).max(), preset
+
+
 def test_c3_full_size_two_ranks_equal_one_process(gpu, tmp_path):
     """The same job as two ranks (one robot each, two processes on the one visible GPU, the pass cut at its exchanges, gloo staged
     through the host standing in for RCCL) gives what one process with both robots gives: same slots, poses to 1e-9."""

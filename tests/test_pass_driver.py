@@ -88,3 +88,55 @@ def test_pass_driver_two_processes_two_shards_each_gloo(tmp_path):
     assert int(z["n_slots"]) == info["n_slots"] and list(z["n_global"]) == list(info["n_global"])
     assert z["poses"].shape == one.shape
     assert np.abs(z["poses"] - one).max() < 1e-9
+
+
+@pytest.mark.parametrize("preset,tol", [("C3tiny", 5e-6), ("C4tiny", 1e-4)])
+def test_exact_joint_step_reaches_the_joint_replica_optimum_in_a_few_passes(preset, tol):
+    """The exact joint step (shared landmarks as the separator of the joint graph; oracle dist_phase 40 / 41 / 42) takes the
+    Gauss-Newton step of the full replica, so the sharded passes converge like the replica's own batch Gauss-Newton: FIVE passes end
+    at its optimum (block-Jacobi needs 60, PCG with 8 iterations per pass 15).  C4tiny: the merge of the four robots' final maps
+    differs from the replica's frame-by-frame association by one landmark, which bounds the agreement at ~5e-5 (see the block-Jacobi
+    test above)."""
+    joint, counts = _joint_optimum(preset)
+    cfg, shards, _ = oracle_shards(preset)
+    bufs, info = setup_local_shards(shards, oracle_matcher)
+    assert info["n_slots"] > 0 and info["sep_dim"] >= 3 * info["n_slots"]
+    drv = PassDriver(shards, bufs, info["n_slots"], arrow=True, sep_dim=info["sep_dim"])
+    P, R = cfg.poses_per_robot, cfg.robots
+    steps, prev = [], poses_of(shards, P)
+    for _ in range(5):
+        drv.one_pass()
+        cur = poses_of(shards, P)
+        steps.append(float(np.abs(cur - prev).max()))
+        prev = cur
+    rel = np.linalg.norm((prev - joint).reshape(R, -1), axis=1) / np.linalg.norm(joint.reshape(R, -1), axis=1)
+    assert rel.max() < tol, rel
+    assert steps[-1] < 2e-4 and steps[-1] < 1e-3 * steps[0], steps          # the fifth step is down at the noise of the numerical Jacobians (a 2-cycle of ~5e-5)
+    inv = [counts["cyl"], counts["cube"], counts["point"]]
+    assert sum(abs(a - b) for a, b in zip(info["n_global"], inv)) <= 1
+
+
+def test_exact_joint_step_two_processes_two_shards_each_gloo(tmp_path):
+    """2 processes x 2 shards over gloo (one all-reduce of the separator system per pass) == four shards in one process."""
+    cfg, shards, _ = oracle_shards("C4tiny")
+    bufs, info = setup_local_shards(shards, oracle_matcher)
+    PassDriver(shards, bufs, info["n_slots"], arrow=True, sep_dim=info["sep_dim"]).gauss_newton(5)
+    one = poses_of(shards, cfg.poses_per_robot)
+    z = _run_workers("oracle", "C4tiny", 5, str(tmp_path / "a22.npz"), world=2, extra=("driver=2", "arrow"))
+    assert int(z["n_slots"]) == info["n_slots"]
+    assert np.abs(z["poses"] - one).max() < 1e-9
+
+
+def test_pcg_tolerance_ends_the_joint_solve():
+    """PCG phases of the oracle shards (31 / 32 / 33) with a relative tolerance: the iteration stops when sqrt(r^T M^-1 r) has fallen
+    by the tolerance, well before the upper bound, and the passes reach the joint replica's optimum."""
+    joint, counts = _joint_optimum("C3tiny")
+    cfg, shards, _ = oracle_shards("C3tiny")
+    bufs, info = setup_local_shards(shards, oracle_matcher)
+    drv = PassDriver(shards, bufs, info["n_slots"], pcg_iters=200, pcg_tol=1e-9)
+    drv.gauss_newton(6)
+    assert all(0 < k < 100 for k in drv.pcg_history), drv.pcg_history
+    st = shards[0].graph.pcg_stats()
+    assert st["state"] == 1 and st["gamma_last"] <= 1e-18 * st["gamma_first"] * 1.0001
+    z = dict(poses=poses_of(shards, cfg.poses_per_robot), n_slots=info["n_slots"], n_global=np.array(info["n_global"]))
+    _check(z, joint, counts, 5e-6)
