@@ -14,10 +14,16 @@ same HIP stream between them — one host synchronisation per pass.  value = rob
 `--robots-per-gpu 1` is the weak-scaling variant (one robot per GPU at every N).  Inputs are resident in HBM before the timed
 region.  Synthetic, seeded data (slide_slam_amd/synth.py).
 
-After the timed region the bench (a) re-runs the same number of passes on identically built shards through the UN-batched path
-(one dist_phase call per robot and phase, host-side sums) and reports the largest relative pose difference (`parity`; exit code 1
-when it is not finite or above 1e-6), (b) reports how many passes the block-Jacobi iteration needed to come within 1e-4 of its
-fixed point (`convergence`), (c) times the association sweep (`roofline.assoc`, HBM) and the CPU restatement beside it.
+A pass takes the EXACT joint Gauss-Newton step of all robots (default, --joint exact): the shared landmarks stay as the separator of
+the joint graph, every robot factors its banded pose system with the separator's coupling rows as a border, one FP64-MFMA product per
+robot forms its Schur complement onto the separator, the summed separator system (ONE all-reduce per pass at N > 1) is factored and
+substituted back — the step the reference's full replica takes with one solve(), no inner iteration.
+
+Around the timed region the bench (a) records the first passes one by one and reports how many passes / ms the job needs to come
+within 1e-4 (relative, on poses) of where it ends (`convergence`; exit code 1 when it does not), (b) times the stages of the pass with
+HIP events on the pass's stream (`roofline`: the border product against the FP64-MFMA peak, the factorisations' serial chains),
+(c) times the association sweep (`roofline.assoc`, HBM) and (d) in the cpu_baseline leg runs the SAME exact joint passes on oracle
+shards on this box's host cores — timed as the CPU figure, compared pose by pose with identically built GPU shards (`parity`).
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--robots-per-gpu R] [--no-cpu] [--frames F] [--ingest-only] [--no-parity]
 Multi-GPU: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
@@ -149,6 +155,65 @@ def cpu_baselines(logs, frames, budget_s=10.0):
     return out
 
 
+def cpu_exact_joint_leg(s, logs, frames, passes=3):
+    """cpu_baseline leg of the exact joint step: the job's robots as oracle shards (CPU restatement, C++ -O3 -march=native, NOT GTSAM)
+    on this box's host cores, built like bench.py --ingest-only builds the GPU shards (every frame at its ground-truth pose, association
+    against the un-refined map, one solve), merged across robots, then `passes` exact joint Gauss-Newton passes — linearise, eliminate
+    private landmarks and poses per robot (OpenMP over all cores inside a shard, one shard after the other), sum, factor and solve the
+    separator system, substitute back: the SAME algorithm and work as a GPU pass — timed.  By-product (the oracle as checker): identically
+    built GPU shards take the same passes and every pass's poses are compared."""
+    import torch
+    from oracle import pyoracle as po
+    from slide_slam_amd.distributed import PassDriver, gpu_matcher, setup_local_shards
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import oracle_matcher
+    from slide_slam_amd.synth import frame_detections
+    L = po.lib(native=True)
+    ncpu = min(os.cpu_count() or 1, 16)
+    R = len(logs)
+    P = len(logs[0]["rel7"]) if frames is None else frames
+    O, A = [], []
+    for lg in logs:
+        o = po.OracleBackend(po.OrcParams.default(num_threads=ncpu), 1, L=L)
+        a = s.SlideBackend(s.default_params(), 1)
+        for k in range(P):
+            o.process_frame(0, lg["rel7"][k], lg["gt7"][k], frame_detections(lg, k), 2)
+            a.process_frame(0, lg["rel7"][k], lg["gt7"][k], frame_detections(lg, k), s.FRAME_FOREIGN)
+        assert o.ingest_solve() == 0 and a.ingest_solve() == 0
+        O.append(o); A.append(a)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    batch = s.CholBatch(R)
+    for t, a in enumerate(A):
+        a.graph.join_chol_batch(batch, t)
+    bufA, infoA = setup_local_shards(A, gpu_matcher, device=dev)
+    bufO, infoO = setup_local_shards(O, oracle_matcher)
+    dA = PassDriver(A, bufA, infoA["n_slots"], batch=batch, device=dev, arrow=True, sep_dim=infoA["sep_dim"])
+    dO = PassDriver(O, bufO, infoO["n_slots"], arrow=True, sep_dim=infoO["sep_dim"])
+    poses = lambda sh: np.array([[x.graph.get_pose12(0, k)[1] for k in range(P)] for x in sh])      # noqa: E731
+    t_cpu, rel = [], []
+    for _ in range(passes):
+        dA.one_pass()
+        t0 = time.perf_counter()
+        dO.one_pass()
+        t_cpu.append(time.perf_counter() - t0)
+        a, o = poses(A), poses(O)
+        rel.append(float((np.linalg.norm((a - o).reshape(R, -1), axis=1) / np.linalg.norm(o.reshape(R, -1), axis=1)).max()))
+    for a in A:
+        a.graph.join_chol_batch(None)
+    tp = float(np.median(t_cpu))
+    st = O[0].graph.stats()
+    cb = dict(value=R / tp, unit="pose-graph updates/s", cores=ncpu, kind="port", ms_per_iter=tp * 1e3,
+              sample=f"{passes} exact joint Gauss-Newton passes of the {R} robot sub-graphs ({st['n_pose']} poses / {st['n_lm']} landmarks / "
+                     f"{st['n_factors']} factors in robot 0's; separator {infoO['sep_dim']} coordinates over {infoO['n_slots']} shared slots), "
+                     f"{sum(t_cpu):.1f} s, median; OpenMP with {ncpu} threads inside a shard, shards one after the other",
+              note="CPU restatement (oracle/), not GTSAM: the reference cannot be built here (DESIGN 2); same algorithm and work as a GPU pass")
+    ok = bool(infoA["n_slots"] == infoO["n_slots"] and infoA["sep_dim"] == infoO["sep_dim"] and all(np.isfinite(rel)) and max(rel) < 1e-6)
+    par = dict(gpu_vs_oracle_max_rel=max(rel), per_pass=rel, passes_compared=passes, slots_equal=infoA["n_slots"] == infoO["n_slots"], ok=ok,
+               what="poses of every robot after each exact joint pass: GPU shards (one CholBatch, replayed hipGraph) vs oracle shards taking "
+                    "the same passes, identically built (ingest-only) — relative, per robot, the worst; tolerance 1e-6 (north-star bar 1e-4)")
+    return cb, par
+
+
 def assoc_roofline(s, n_map=10000, K=1000, n_obs=20, n_query=8192, repeats=5):
     """Association sweep (getSubmap K-NN gate + matchEllipsoidModels) at the headline sizes, batched over query frames against one
     resident map: algorithmic bytes per frame = 12 N_map + 28 K_eff + 36 N_obs over the device time per frame
@@ -203,6 +268,32 @@ def chol_flops(T, prof=None):
     return sum(v * v * 64.0 + v * 64.0 * 64.0 + 64.0 ** 3 / 3.0 for v in nk)
 
 
+def band_flops(T, prof, nbr):
+    """FLOPs of the steps over the T block columns of a BORDERED band (exact joint step): per column k with v rows of the band below it
+    inside the profile and w = 64 nbr + 1 border rows (the separator's coupling rows and the right-hand side): trailing update of the band
+    and of the border rows (v^2 + 2 v w) * 64, triangular solves (v + w) * 64^2, diagonal block 64^3 / 3.  The border x border block is
+    not touched by the steps (border_flops)."""
+    w = 64 * nbr + 1
+    tot = 0.0
+    for k in range(T):
+        v = (int(prof[k]) - k) * 64
+        tot += (v * v + 2.0 * v * w) * 64.0 + (v + w) * 64.0 * 64.0 + 64.0 ** 3 / 3.0
+    return tot
+
+
+def border_flops(T, first):
+    """FLOPs of the border product bord(i, j) -= sum_c W^T(i, c) W^T(j, c)^T over the tiles i >= j (i = nbr: the right-hand-side row):
+    2 * 64^3 per tile and column block c >= max(first[i], first[j]) — (performed, the same with no column skipped)."""
+    nbr = len(first)
+    fi = list(first) + [0]
+    done = dense = 0.0
+    for j in range(nbr):
+        for i in range(j, nbr + 1):
+            done += 2.0 * 64 ** 3 * max(0, T - max(fi[i], fi[j]))
+            dense += 2.0 * 64 ** 3 * T
+    return done, dense
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,7 +311,7 @@ def main():
     ap.add_argument("--robots-per-gpu", type=int, default=0,
                     help="robot shards per GPU; 0 = the preset's robots / N when that divides (the SAME 8-robot graph at every N: "
                          "strong scaling), else 1; 1 = one robot per GPU at every N (weak scaling)")
-    ap.add_argument("--probe", type=int, default=20, help="passes recorded one by one for the convergence figure")
+    ap.add_argument("--probe", type=int, default=10, help="passes recorded one by one for the convergence figure")
     ap.add_argument("--joint", choices=("exact", "pcg", "jacobi"), default="exact",
                     help="joint Gauss-Newton step over the robots: exact = shared landmarks as the separator of the joint graph (one "
                          "all-reduce per pass, no inner iteration: the step of the reference's full replica); pcg = --pcg conjugate-gradient "
@@ -298,6 +389,9 @@ def main():
         bufs, info = setup_local_shards(shards, gpu_matcher, base=base, rank=rank, world=wdev, device=device)
         drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, base=base, world=wdev, device=device,
                          pcg_iters=args.pcg if args.joint == "pcg" else 0, pcg_tol=args.pcg_tol, arrow=args.joint == "exact", sep_dim=info["sep_dim"])
+        info["totals"] = {k: int(sum(gb.graph.stats()[k] for gb in shards)) for k in ("n_pose", "n_lm", "n_factors")}
+        info["totals"]["shared_slots"] = int(info["n_slots"])
+        info["sep_exchange_bytes"] = int(8 * s.CholBatch.sep_buffer_len(info["sep_dim"])) if info.get("sep_dim") else 0
         if sync_coll:
             drv.stream_ordered = False
         if os.environ.get("SLIDE_BENCH_FORCE_PARTS") == "1":      # rehearsal of the N > 1 control flow (cut pass + RCCL on the batch's stream) on one rank
@@ -338,20 +432,25 @@ def main():
 
     if multi:
         ptrs = [b.data_ptr() for b in bufs]
-        if wdev == 1 and drv.arrow:
-            runs = [batch.profile_exact_joint(ptrs) for _ in range(5)]
-            stages = {k: float(np.median([r[0][k] for r in runs])) for k in runs[0][0]}
-            info["exact_joint_stages_ms"] = stages
-            info["separator_block_columns"] = runs[0][1]
-            print("exact joint pass, stage times (ms):", stages, file=sys.stderr, flush=True)
-        if wdev == 1 and not drv.arrow:
+        if drv.arrow:
+            info["border"] = [dict(first=[int(v) for v in gb.graph.border_profile()], T=int(gb.graph.stats()["chol_dim"] // 64),
+                                   prof=[int(v) for v in gb.graph.tile_profile()]) for gb in shards]
+            if wdev == 1 and not drv.force_parts:
+                runs = [batch.profile_exact_joint(ptrs) for _ in range(7)]
+                info["exact_joint_stages_ms"] = {k: float(np.median([r[0][k] for r in runs])) for k in runs[0][0]}
+                info["separator_block_columns"] = runs[0][1]
+            else:
+                cuts = [drv.timed_cut_pass() for _ in range(7)]
+                info["cut_pass_ms"] = {k: float(np.median([c[k] for c in cuts])) for k in cuts[0]}
+            info["stream_ordered_collectives"] = bool(drv.stream_ordered)
+        if wdev == 1 and not drv.force_parts:
             # device time of the batched step kernels (HIP events on the batch's stream, un-captured passes) for the roofline
             pr = sorted(batch.profile(ptrs) for _ in range(5))
             profs = [gb.graph.tile_profile() for gb in shards]
             batched_prof = dict(ms_steps=pr[len(pr) // 2][0], launches=pr[0][1], robots=R, flops=sum(chol_flops(T, pf) for pf in profs),
                                 tiles=int(sum(int(pf[k]) - k + 1 for pf in profs for k in range(len(pf)))), tiles_dense=R * T * (T + 1) // 2)
             # the same graphs with the structure ignored (every tile of the lower triangle): the GEMM-shaped extreme of the same kernels
-            if DENSE_LEG:
+            if DENSE_LEG and not drv.arrow:
                 for gb in shards:
                     gb.graph.set_dense_profile(True)
                 for _ in range(3):
@@ -369,23 +468,31 @@ def main():
                     gb.graph.set_dense_profile(False)
                 step()
         if n_probe:
-            # cost (sum of squared whitened residuals over all factors of the job) after every probe pass, and how many passes it
-            # took to come within 0.1 % of the cost the run ended at; pose change relative to the final state for orientation
+            # cost (sum of squared whitened residuals over all factors of the job) after every probe pass and the poses' distance to
+            # where the run ends (relative, per robot, the worst): passes / ms until that distance stays below the north-star 1e-4
             chi = list(probe_chi2)
             fin = final_chi2
+            ref = np.linalg.norm(final.reshape(R, -1), axis=1)
+            errs = [float((np.linalg.norm((p - final).reshape(R, -1), axis=1) / ref).max()) for p in probe]
             if use_dist and world > 1:
                 tt = torch.tensor(chi + [fin], dtype=torch.float64, device="cuda")
                 dist.all_reduce(tt)
                 chi, fin = [float(v) for v in tt[:-1]], float(tt[-1])
+                te = torch.tensor(errs, dtype=torch.float64, device="cuda")
+                dist.all_reduce(te, op=dist.ReduceOp.MAX)
+                errs = [float(v) for v in te]
             hit = [i + 1 for i, c in enumerate(chi) if c <= fin * 1.001]
-            ref = np.linalg.norm(final.reshape(R, -1), axis=1)
-            errs = [float((np.linalg.norm((p - final).reshape(R, -1), axis=1) / ref).max()) for p in probe]
-            conv = {"passes_to_0.1pct_of_final_cost": hit[0] if hit else None, "probe_passes": n_probe, "final_chi2": fin,
-                    "chi2_after": {str(k): chi[k - 1] for k in (1, 2, 3, 5, 10, 20, 40) if k <= n_probe},
-                    "pose_rel_change_to_final_after": {str(k): errs[k - 1] for k in (1, 2, 5, 10, 20, 40) if k <= n_probe},
-                    "note": ("joint Gauss-Newton step by PCG on the global reduced pose system" if drv.pcg_iters else
+            below = [k + 1 for k in range(len(errs)) if all(e <= 1e-4 for e in errs[k:])]
+            p4 = below[0] if below else None
+            conv = {"passes_to_1e-4_pose": p4, "ms_to_1e-4": (p4 * dt / args.steps * 1e3 if p4 else None),
+                    "passes_to_0.1pct_of_final_cost": hit[0] if hit else None, "probe_passes": n_probe, "final_chi2": fin,
+                    "chi2_after": {str(k): chi[k - 1] for k in (1, 2, 3, 4, 5, 10, 20, 40) if k <= n_probe},
+                    "pose_rel_distance_to_final_after": {str(k): errs[k - 1] for k in (1, 2, 3, 4, 5, 10, 20, 40) if k <= n_probe},
+                    "note": ("exact joint Gauss-Newton step (shared landmarks as the separator of the joint graph)" if drv.arrow else
+                             "inexact joint step: PCG on the global reduced pose system" if drv.pcg_iters else
                              "block-Jacobi over robots (no joint solve): does not converge once robots share many landmarks") +
-                            f"; final = after all {n_passes} passes of this run; chi2 = 2 x NonlinearFactorGraph::error over all robots"}
+                            f"; final = after all {n_passes} passes of this run; start = the robots' own streaming builds merged (cross-robot "
+                            "association), nothing joint solved yet; chi2 = 2 x NonlinearFactorGraph::error over all robots"}
         if not args.no_parity and not drv.arrow:
             # ---- parity of what was timed: identically built shards, the same number of passes through the UN-batched path ----
             for gb in shards:
@@ -416,7 +523,8 @@ def main():
     report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build, info, mode, batched_prof, parity, conv, finite, dist, T, dense_leg)
     if use_dist:
         dist.destroy_process_group()
-    if rank == 0 and ((parity is not None and not parity["ok"]) or not finite):
+    if rank == 0 and ((parity is not None and not parity["ok"]) or not finite or
+                      (multi and conv is not None and args.joint == "exact" and conv["passes_to_1e-4_pose"] is None)):
         raise SystemExit(1)
 
 
@@ -486,6 +594,43 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
     kernel_ms = {k: v["ms"] / nprof for k, v in prof.items()}
     dominant = max(kernel_ms, key=kernel_ms.get)
     n_slots = info.get("n_slots", 0) if info else 0
+    exact = None
+    stages = info.get("exact_joint_stages_ms") if info else None
+    if stages and bt:
+        # ---- the exact joint pass, stage by stage (HIP events on the pass's stream, un-captured passes after the timed region) ----
+        bd = info["border"]
+        groups = max(1, bt["launches"] // max(T, 1))
+        fl_band = sum(band_flops(b["T"], b["prof"], len(b["first"])) for b in bd)
+        fl_done, fl_dense = (sum(v) for v in zip(*[border_flops(b["T"], b["first"]) for b in bd]))
+        Ts = info["separator_block_columns"]
+        fl_sep = chol_flops(Ts)
+        ms_band, ms_syrk, ms_sep = stages["band_factorisations"], stages["border_products"], stages["separator_solve"]
+        tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0      # noqa: E731
+        exact = {
+            "stages_ms": stages, "stages_sum_ms": float(sum(stages.values())),
+            "band_factorisations": {
+                "kernel": f"k_chol_step_batched ({max(1, bt['robots'] // groups)} bordered systems per launch, {groups} overlapping launch sequences of {T} launches)",
+                "bound": "latency", "flops": fl_band, "window_ms": ms_band, "launches": bt["launches"],
+                "flops_per_launch": fl_band / max(bt["launches"], 1), "avg_launch_ms": ms_band * groups / max(bt["launches"], 1),
+                "achieved": tf(fl_band / groups, ms_band), "aggregate": tf(fl_band, ms_band), "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS,
+                "frac": tf(fl_band / groups, ms_band) / FP64_MFMA_PEAK_TFLOPS,
+                "note": "every launch is the serial chain of one 64-column diagonal block (sixteen dependent 4x4 pivot steps) beside the "
+                        "panel tiles of the band and of the border: bound by that chain's latency, not by the matrix pipe; avg_launch_ms = "
+                        "the window over the launches of one sequence (dispatch gaps included), rocprofv3's per-launch average is in "
+                        "profiles/r03_*kernel_stats.csv"},
+            "border_product": {
+                "kernel": "k_border_syrk (v_mfma_f64_16x16x4_f64; one launch per pass: every robot's Schur complement onto the separator, K = 64 T)",
+                "bound": "mfma", "flops_per_launch": fl_done, "flops_dense_equivalent": fl_dense, "avg_launch_ms": ms_syrk,
+                "achieved": tf(fl_done, ms_syrk), "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS, "frac": tf(fl_done, ms_syrk) / FP64_MFMA_PEAK_TFLOPS,
+                "traffic": _pmc_traffic("k_border_syrk")},
+            "separator": {
+                "kernel": f"k_chol_step (dense {Ts}-block-column separator system of {info.get('sep_dim')} coordinates, one launch per block column) + chained substitution",
+                "bound": "mfma", "flops": fl_sep, "window_ms": ms_sep, "launches": Ts, "flops_per_launch": fl_sep / max(Ts, 1),
+                "avg_launch_ms": ms_sep / max(Ts, 1), "achieved": tf(fl_sep, ms_sep), "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS,
+                "frac": tf(fl_sep, ms_sep) / FP64_MFMA_PEAK_TFLOPS},
+        }
+        dom = max(("band_factorisations", "border_product", "separator"), key=lambda k: {"band_factorisations": ms_band, "border_product": ms_syrk, "separator": ms_sep}[k])
+        exact["dominant_by_time"] = dom
     res = {
         "metric": "pose-graph updates/sec + ms/Gauss-Newton iter, 8-robot 10k-landmark graph",
         "value": robots * args.steps / dt,
@@ -501,13 +646,22 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
         "data": "synthetic (seeded, slide_slam_amd/synth.py)",
         "config": {"workload": f"{cfg.name} (BASELINE configs[3]): {robots} robot sub-graphs, {R} per GPU ({mode}) "
                                f"({st['n_pose']} poses, {st['n_lm']} landmarks, {st['n_factors']} factors in robot 0's); "
-                               "a step = one Gauss-Newton pass of all of them, value = robot pose-graph updates/s",
+                               "a step = one Gauss-Newton pass of all of them, value = robot pose-graph updates/s; "
+                               f"graph totals of this rank's {R} robots: {info.get('totals')}; synthetic noise: odometry sigma per metre "
+                               f"{tuple(cfg.sigma_odom)} [rot, trans], detection position {cfg.sigma_det_pos} m, cube yaw {cfg.sigma_cube_yaw} rad, "
+                               f"scale {cfg.sigma_scale} (SURVEY 8d specifies 20x / 10x more: with it the cross-robot association finds 15 % of the "
+                               "shared landmarks, DESIGN 5); inter-robot relative-pose factors: " + str(info.get("relmeas", "none")),
                    "robots": robots, "robots_per_gpu": R, "reduced_system_dim": n, "chol_tile": 64,
                    "world_size": (dist.get_world_size() if dist is not None else 1), "backend": (backend if dist is not None else None),
                    "devices": devs,
-                   "collective": None if not n_slots else
-                   ((f"{backend} " if wdev > 1 else "device-side local sum, no inter-GPU ") +
-                    f"all-reduce x2 per pass over {n_slots} shared-landmark slots ({n_slots * 63 * 8} B per pass)")},
+                   "collective": None if not n_slots else (
+                       ((f"{backend} " if wdev > 1 else "device-side gather, no inter-GPU ") +
+                        f"all-reduce x1 per pass: the packed separator system of the {n_slots} shared-landmark slots "
+                        f"({info.get('sep_dim')} coordinates, {info.get('sep_exchange_bytes')} B)" +
+                        (f"; {'stream-ordered on the pass stream' if info.get('stream_ordered_collectives') else 'host-synchronous'}" if wdev > 1 else ""))
+                       if info.get("sep_dim") and args.joint == "exact" else
+                       ((f"{backend} " if wdev > 1 else "device-side local sum, no inter-GPU ") +
+                        f"all-reduce x2 per pass over {n_slots} shared-landmark slots ({n_slots * 63 * 8} B per pass)"))},
         "roofline": {"bound": "mfma", "kernel": roof_kernel, "achieved": ach,
                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                      "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r0x_pmc_traffic*.json)",
@@ -536,6 +690,18 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
                           "what": "robot 0's streaming build alone on the GPU: associate + add + iSAM2-equivalent update per frame, PCIe included"},
         "finite": finite,
     }
+    if exact:
+        d = exact[exact["dominant_by_time"]]
+        res["roofline"] = {"bound": d["bound"], "kernel": d["kernel"], "achieved": d["achieved"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": d["frac"], "traffic": _pmc_traffic("k_chol_step_batched", robots=bt["robots"], profile="exact_joint") if n == 3776 else None,
+                           "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r0x_pmc_traffic*.json)",
+                           "flops_per_launch": d["flops_per_launch"], "avg_launch_ms": d["avg_launch_ms"], "launches_per_iter": d.get("launches", 1),
+                           "dominant_by_time": exact["dominant_by_time"], "exact_joint_pass": exact, "one_robot_alone": single,
+                           "scope": "stage times: HIP events on the pass's stream between the stages of un-captured exact joint passes after the "
+                                    "timed region (medians of 7); the dominant stage by time is reported at the top, the others under "
+                                    "exact_joint_pass (border_product = the pass's FP64-MFMA GEMM)"}
+    if info.get("cut_pass_ms"):
+        res["cut_pass_ms"] = info["cut_pass_ms"]
     if parity is not None:
         res["parity"] = parity
     if conv is not None:
@@ -549,12 +715,21 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
             from slide_slam_amd.synth import make_robot_log, make_world
             wm = make_world(cfg)
             all_logs = [make_robot_log(cfg, wm, r) for r in range(min(cfg.robots, os.cpu_count() or 1, 8))]
-            v = cpu_baselines(all_logs, args.frames)
-            res["cpu_baseline"] = v["robots_as_threads"]
-            res["cpu_baseline_variants"] = {k: v[k] for k in ("single_thread", "omp")}
+            if args.joint == "exact" and robots > 1 and world == 1:
+                cb, par = cpu_exact_joint_leg(s, all_logs, args.frames)
+                res["cpu_baseline"] = cb
+                res["parity"] = par
+            v = cpu_baselines(all_logs, args.frames, budget_s=5.0 if "cpu_baseline" in res else 10.0)
+            if "cpu_baseline" not in res:
+                res["cpu_baseline"] = v["robots_as_threads"]
+                res["cpu_baseline_variants"] = {k: v[k] for k in ("single_thread", "omp")}
+            else:
+                res["cpu_baseline_variants"] = v
         except Exception as e:  # noqa: BLE001  (the GPU number stands on its own)
-            res["cpu_baseline"] = {"error": repr(e)}
-    print(json.dumps(res))
+            res.setdefault("cpu_baseline", {"error": repr(e)})
+    print(json.dumps(res), flush=True)
+    if isinstance(res.get("parity"), dict) and res["parity"].get("ok") is False:
+        raise SystemExit(1)
 
 
 if __name__ == "__main__":

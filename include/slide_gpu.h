@@ -212,6 +212,10 @@ int slide_graph_get_pcg_stats(slide_graph_t* g, double out8[8]);
  * GEMM-shaped extreme, a measurement aid); results are the same either way. */
 int slide_graph_get_tile_profile(slide_graph_t* g, int* prof, int cap);
 int slide_graph_set_dense_profile(slide_graph_t* g, int on);
+/* Exact joint step: the border of this graph's reduced system — returns the number of border row tiles (64 separator coordinates each;
+ * 0 when the graph's batch does not run exact joint passes) and writes first[i] = the first block column of the band in which border
+ * tile row i can be non-zero (the border product skips the columns before it) for i < min(n, cap). */
+int slide_graph_get_border_profile(slide_graph_t* g, int* first, int cap);
 /* Measurement aid: the same pass issued without the graph, HIP events around the batched step kernels; *ms_steps = their device time
  * (launch gaps included), *n_launches = their number. */
 int slide_chol_batch_profile(slide_chol_batch_t* b, double* const* d_bufs, double* ms_steps, int* n_launches);

@@ -1773,6 +1773,14 @@ int HostGraph::get_tile_profile(int* out, int cap) {
   for (int c = 0; c < T && c < cap; ++c) out[c] = h_prof[c];
   return T;
 }
+int HostGraph::get_border_profile(int* out, int cap) {
+  int rc = merge_pending();
+  if (rc == SLIDE_OK) rc = upload_new();
+  if (rc != SLIDE_OK) return rc < 0 ? rc : -rc;
+  if (!arrow_on()) return 0;
+  for (int i = 0; i < nbr && i < cap; ++i) out[i] = h_bfirst[i];
+  return nbr;
+}
 void HostGraph::set_dense_profile(bool on) {
   if (force_dense == on) return;
   force_dense = on;

@@ -265,7 +265,8 @@ class HostGraph {
   void stats(int64_t* out5) const;
   int64_t rejected() const;
   int chi2(double* out4);                 // sum of squared whitened residuals at the current estimate: total, priors, betweens, landmark factors
-  int get_tile_profile(int* out, int cap);     // T (>= 0) or a negative error; out[c] = prof[c] for c < min(T, cap)
+  int get_tile_profile(int* out, int cap);
+  int get_border_profile(int* out, int cap);   // nbr (>= 0) or a negative error; out[i] = first block column of border tile row i, i < min(nbr, cap)     // T (>= 0) or a negative error; out[c] = prof[c] for c < min(T, cap)
   void set_dense_profile(bool on);        // ignore the structure of the reduced system (measurement aid)
   int pcg_stats(double* out8);            // scalars of the last joint solve: gamma_old, alpha_old, alpha, beta, first gamma, last gamma               // entries merge_pending refused since creation
 

@@ -234,7 +234,12 @@ class PassDriver:
         self.shards, self.bufs, self.n_slots, self.batch, self.base, self.world, self.device = shards, bufs, n_slots, batch, base, world, device
         self.ptrs = [b.data_ptr() for b in bufs] if device is not None else None
         self.passes = 0
-        self.stream_ordered = True      # False (diagnostic): host-synchronous collectives
+        # Collectives of a cut pass: stream-ordered = issued under torch's ExternalStream of the batch's HIP stream (no host
+        # synchronisation until the end of the pass).  That path has run with ONE RCCL rank only (no multi-GPU node was available), so a
+        # job that spans processes defaults to host-synchronous collectives — one synchronisation per exchange, i.e. one per pass of the
+        # exact joint step — unless SLIDE_STREAM_ORDERED=1 asks for the stream-ordered ones (bench.py reports which ran).
+        import os
+        self.stream_ordered = world == 1 or os.environ.get("SLIDE_STREAM_ORDERED") == "1"
         self.force_parts = False        # True (rehearsal): the cut pass + collectives even when the job is this process alone
         # joint solve: PCG on the global reduced system after the factorisations (0: block-Jacobi over robots).  pcg_iters is the
         # upper bound per pass; with pcg_tol > 0 the solve ends as soon as sqrt(r^T M^-1 r) has fallen to pcg_tol times its first
@@ -365,6 +370,27 @@ class PassDriver:
     def gauss_newton(self, iterations=1):
         for _ in range(iterations):
             self.one_pass()
+
+    def timed_cut_pass(self):
+        """One exact joint pass cut at its exchange with a device synchronisation after every part: {part0_ms, exchange_ms, part2_ms,
+        exchange_bytes} — separates the collective's latency from the kernels' (diagnostic, N > 1 or force_parts)."""
+        import time
+        import torch
+        if not (self.arrow and self.batch is not None):
+            raise ValueError("timed_cut_pass: exact joint passes of a CholBatch only")
+        sep = self._sep_exchange_buffer()
+        out = {}
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        self.batch.pass_part(self.ptrs, 0)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        if self.world > 1 or self.base is not None:
+            self.base.all_reduce_on(sep, self.sep_len, None)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        self.batch.pass_part(self.ptrs, 2)
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        self.passes += 1
+        out.update(part0_ms=(t1 - t0) * 1e3, exchange_ms=(t2 - t1) * 1e3, part2_ms=(t3 - t2) * 1e3, exchange_bytes=8 * self.sep_len)
+        return out
 
 
 class TorchComm:
