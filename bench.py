@@ -155,7 +155,7 @@ def cpu_baselines(logs, frames, budget_s=10.0):
     return out
 
 
-def cpu_exact_joint_leg(s, logs, frames, passes=3):
+def cpu_exact_joint_leg(s, logs, frames, passes=3, relmeas=None):
     """cpu_baseline leg of the exact joint step: the job's robots as oracle shards (CPU restatement, C++ -O3 -march=native, NOT GTSAM)
     on this box's host cores, built like bench.py --ingest-only builds the GPU shards (every frame at its ground-truth pose, association
     against the un-refined map, one solve), merged across robots, then `passes` exact joint Gauss-Newton passes — linearise, eliminate
@@ -189,6 +189,9 @@ def cpu_exact_joint_leg(s, logs, frames, passes=3):
     bufO, infoO = setup_local_shards(O, oracle_matcher)
     dA = PassDriver(A, bufA, infoA["n_slots"], batch=batch, device=dev, arrow=True, sep_dim=infoA["sep_dim"])
     dO = PassDriver(O, bufO, infoO["n_slots"], arrow=True, sep_dim=infoO["sep_dim"])
+    if relmeas:
+        dA.setup_ghosts(relmeas)
+        dO.setup_ghosts(relmeas)
     poses = lambda sh: np.array([[x.graph.get_pose12(0, k)[1] for k in range(P)] for x in sh])      # noqa: E731
     t_cpu, rel = [], []
     for _ in range(passes):
@@ -316,6 +319,8 @@ def main():
                     help="joint Gauss-Newton step over the robots: exact = shared landmarks as the separator of the joint graph (one "
                          "all-reduce per pass, no inner iteration: the step of the reference's full replica); pcg = --pcg conjugate-gradient "
                          "iterations on the global reduced pose system per pass (inexact); jacobi = every robot's own block solve only")
+    ap.add_argument("--no-relmeas", action="store_true",
+                    help="leave out the inter-robot relative-pose factors (SURVEY 8d: one per robot pair within 60 m every 50 frames)")
     ap.add_argument("--pcg", type=int, default=8, help="--joint pcg: PCG iterations per pass")
     ap.add_argument("--pcg-tol", type=float, default=0.0, help="--joint pcg: relative tolerance on sqrt(r^T M^-1 r) (0: every iteration counts)")
     args = ap.parse_args()
@@ -389,9 +394,21 @@ def main():
         bufs, info = setup_local_shards(shards, gpu_matcher, base=base, rank=rank, world=wdev, device=device)
         drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, base=base, world=wdev, device=device,
                          pcg_iters=args.pcg if args.joint == "pcg" else 0, pcg_tol=args.pcg_tol, arrow=args.joint == "exact", sep_dim=info["sep_dim"])
+        info["relmeas"] = "none"
+        if not args.no_relmeas and robots == cfg.robots and args.frames is None:
+            from slide_slam_amd.synth import make_relmeas
+            all_logs = logs if world == 1 else [make_robot_log(cfg, world_map, r) for r in range(cfg.robots)]
+            rel = make_relmeas(cfg, all_logs)
+            ng = drv.setup_ghosts(rel, rank=rank)
+            info["n_relmeas"] = len(rel)
+            info["relmeas"] = (f"{len(rel)} (addRelativeMeasFactor, graph.cpp:247-258; one per robot pair within 60 m at the same key frame, every "
+                               f"{cfg.relmeas_every} frames), " +
+                               ("each carried exactly as six further separator coordinates (its linearised residual)" if args.joint == "exact" else
+                                "cross block left out of the step (gradient exact)") +
+                               f"; {ng} ghost pose slots (linearisation points) refreshed at the start of every pass")
         info["totals"] = {k: int(sum(gb.graph.stats()[k] for gb in shards)) for k in ("n_pose", "n_lm", "n_factors")}
         info["totals"]["shared_slots"] = int(info["n_slots"])
-        info["sep_exchange_bytes"] = int(8 * s.CholBatch.sep_buffer_len(info["sep_dim"])) if info.get("sep_dim") else 0
+        info["sep_exchange_bytes"] = int(8 * s.CholBatch.sep_buffer_len(info["sep_dim"], info.get("n_relmeas", 0))) if info.get("sep_dim") else 0
         if sync_coll:
             drv.stream_ordered = False
         if os.environ.get("SLIDE_BENCH_FORCE_PARTS") == "1":      # rehearsal of the N > 1 control flow (cut pass + RCCL on the batch's stream) on one rank
@@ -716,7 +733,9 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
             wm = make_world(cfg)
             all_logs = [make_robot_log(cfg, wm, r) for r in range(min(cfg.robots, os.cpu_count() or 1, 8))]
             if args.joint == "exact" and robots > 1 and world == 1:
-                cb, par = cpu_exact_joint_leg(s, all_logs, args.frames)
+                from slide_slam_amd.synth import make_relmeas
+                cb, par = cpu_exact_joint_leg(s, all_logs, args.frames,
+                                              relmeas=None if (args.no_relmeas or args.frames is not None) else make_relmeas(cfg, all_logs))
                 res["cpu_baseline"] = cb
                 res["parity"] = par
             v = cpu_baselines(all_logs, args.frames, budget_s=5.0 if "cpu_baseline" in res else 10.0)

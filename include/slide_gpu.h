@@ -197,10 +197,20 @@ int slide_graph_set_pcg_tolerance(slide_graph_t* g, double tol);
  *     setting is ignored).  sep_buf: the caller's device buffer of slide_chol_batch_sep_buffer_len(m) doubles, m = off[n_slots], in which
  *     part 0 of a cut pass leaves this GPU's partial sum of the separator system (packed: the lower tile columns only) and from which
  *     part 2 takes the all-reduced sum; NULL when the job is this process alone (whole passes only).
- * A cut pass then reads   part 0 | all-reduce(sum) of sep_buf[0 .. len) on slide_chol_batch_stream() | part 2. */
+ * A cut pass then reads   part 0 | all-reduce(sum) of sep_buf[0 .. len) on slide_chol_batch_stream() | part 2.
+ * With inter-robot relative-pose factors (slide_graph_set_ghosts) every pass, cut or whole, PCG or exact, opens with the refresh of the
+ * ghost poses; a cut pass reads   part 20 | all-reduce(sum) of d_bufs[0][0 .. 12 n_ghost_slots) | part 0 | ...  (the exchange buffers
+ * must hold 12 doubles per ghost slot).  The cross block of such a factor is left out of the step (gradient exact). */
 int slide_graph_set_separator(slide_graph_t* g, const int32_t* off, int n);
 int slide_chol_batch_set_exact_joint(slide_chol_batch_t* b, int on, double* sep_buf, long long len);
-long long slide_chol_batch_sep_buffer_len(int m);
+long long slide_chol_batch_sep_buffer_len(int m, int n_relmeas);
+/* Inter-robot relative-pose factors in an exact joint pass: the factor between pose a of robot A and pose b of robot B is the rank-6
+ * term U U^T, U = [J_a^T; J_b^T], of the joint normal equations; it is carried as six further separator coordinates "lambda" (the
+ * factor's linearised residual) of the bordered system [H_rest U; U^T -I] [delta; lambda] = [b; -r]: every robot couples to them through
+ * its OWN Jacobian only, and the step is exactly the joint replica's.  ids[i] = index, in the job's list of n_total measurements
+ * (identical on every rank), of this graph's i-th ghost factor (slide_graph_add_relative_meas_ghost order); the ghost poses are still
+ * refreshed at the start of every pass: they are where the factor is linearised. */
+int slide_graph_set_ghost_ids(slide_graph_t* g, const int32_t* ids, int n, int n_total);
 /* Scalars of the last joint solve this graph took part in: out8 = {gamma of the last but one iteration, alpha of it, alpha, beta of the
  * last iteration, gamma of the FIRST iteration, gamma of the last; 0, 0} with gamma = r^T M^-1 r (M = the robots' own factors), summed
  * over all robots: gamma_last / gamma_first is the squared reduction of the preconditioned residual. */

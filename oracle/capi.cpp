@@ -190,6 +190,7 @@ void orc_graph_pcg_stats(void* h, double* out4) {
   out4[0] = g->D.pcg_its; out4[1] = g->D.gamma0; out4[2] = g->D.gamma_last; out4[3] = g->D.pcg_done;
 }
 int orc_graph_set_separator(void* h, const int* off, int n) { return ((Graph*)h)->set_separator(off, n); }
+int orc_graph_set_ghost_ids(void* h, const int* ids, int n, int n_total) { return ((Graph*)h)->set_ghost_ids(ids, n, n_total); }
 void orc_graph_keep_factor(void* h, int on) { ((Graph*)h)->keep_factor = on != 0; }
 int orc_graph_pose_covariance(void* h, int robot, uint64_t idx, double* cov36) {
   return ((Graph*)h)->pose_covariance(Graph::pose_key(robot, idx), cov36);

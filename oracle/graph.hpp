@@ -627,6 +627,17 @@ class Graph {
     int n = 0, ma = 0;
   } AR;
   int set_separator(const int* off, int n) { sep_off.assign(off, off + n); return 0; }
+  // Inter-robot relative-pose factors inside the exact joint step: the factor between pose a of robot A and pose b of robot B is the
+  // rank-6 term U U^T, U = [J_a^T; J_b^T], of the joint normal equations.  It enters as the bordered (quasi-definite) system
+  //     [H_rest  U; U^T  -I] [delta; lambda] = [b; -r]        lambda = J_a delta_a + J_b delta_b + r, the factor's linearised residual
+  // i.e. six more separator coordinates per factor ("lambda"), coupled to each robot's band by its OWN Jacobian only: neither robot
+  // needs the other's pose in its system, and the step is still exactly the joint replica's.  ghost_gid[i] = the factor's index in the
+  // job's list of relative-pose measurements (same on every rank) for ghost factor i (in the order of `factors`), lam_total = 6 x the
+  // length of that list; the ghost factor with the FIRST key (z[12] != 0) contributes the -I block and the right-hand side -r.
+  // Separator coordinates: [landmark slots (sep_off) | lambda].
+  std::vector<int> ghost_gid;
+  int lam_total = 0;
+  int set_ghost_ids(const int* ids, int n, int n_total) { ghost_gid.assign(ids, ids + n); lam_total = 6 * n_total; return 0; }
   void pcg_pack_tl(const std::vector<double>& v, double* buf);
   void pcg_scalars_update(const double* buf);
   // graph.cpp:314-323  isam->marginalCovariance(X(idx)): the (pose, pose) block of the inverse information matrix at the
@@ -1235,9 +1246,22 @@ inline int Graph::dist_phase(int phase, double* buf) {
     // after phase 0 (linearisation, per-landmark sums of the own factors).  buf: [m x m row-major | m] = this robot's contribution
     // to the separator system (lower triangle) and its right-hand side, everything else zero; the caller sums over the robots.
     if ((int)sep_off.size() != nslots + 1) return -3;
-    const int m = sep_off[nslots];
+    const int ms = sep_off[nslots], m = ms + lam_total;
     std::memset(buf, 0, sizeof(double) * ((size_t)m * m + 2 * (size_t)m));
     const int np = (int)D.pose_vars.size(), nl = (int)D.lm_vars.size(), n = 6 * np;
+    // ghost factors (in the order of `factors`) -> their lambda coordinates
+    std::vector<int> fac_lam(factors.size(), -1);
+    {
+      size_t q = 0;
+      for (size_t i = 0; i < factors.size(); ++i)
+        if (factors[i].type == F_GHOST) {
+          if (lam_total > 0) {
+            if (q >= ghost_gid.size()) return -5;
+            fac_lam[i] = ms + 6 * ghost_gid[q];
+          }
+          ++q;
+        }
+    }
     std::vector<int> lm_sep(nl, -1);            // landmark -> global separator offset, or -1 (private)
     for (int sidx = 0; sidx < nslots; ++sidx)
       if (sh_var[sidx] >= 0) lm_sep[D.lidx[sh_var[sidx]]] = sep_off[sidx];
@@ -1254,6 +1278,7 @@ inline int Graph::dist_phase(int phase, double* buf) {
       const Factor& f = factors[i];
       const LinFactor& L = D.lin[i];
       const int p0 = D.pidx[f.v0];
+      if (fac_lam[i] >= 0) continue;        // a relative-pose factor: enters through its lambda coordinates, not through H_pp / g_p
       add_block(p0, p0, L.J0, L.J0, L.m);
       for (int a = 0; a < 6; ++a) {
         double s2 = 0.0;
@@ -1281,8 +1306,28 @@ inline int Graph::dist_phase(int phase, double* buf) {
       lm_lcol[l] = (int)AR.lcol.size();
       for (int k = 0; k < d; ++k) AR.lcol.push_back(sep_off[sidx] + k);
     }
+    std::vector<int> fac_lcol(factors.size(), -1);
+    for (size_t i = 0; i < factors.size(); ++i)
+      if (fac_lam[i] >= 0) {
+        fac_lcol[i] = (int)AR.lcol.size();
+        for (int k = 0; k < 6; ++k) AR.lcol.push_back(fac_lam[i] + k);
+      }
     const int ma = AR.ma = (int)AR.lcol.size();
     std::vector<double> B((size_t)n * ma, 0.0);       // B[row * ma + col]
+    for (size_t i = 0; i < factors.size(); ++i) {
+      if (fac_lam[i] < 0) continue;
+      // lambda rows: U^T = the factor's whitened Jacobian w.r.t. the own pose; the first-key side owns -I and -r
+      const LinFactor& L = D.lin[i];
+      const int p0 = D.pidx[factors[i].v0];
+      for (int k = 0; k < 6; ++k)
+        for (int a = 0; a < 6; ++a) B[(size_t)(6 * p0 + a) * ma + fac_lcol[i] + k] += L.J0[k * 6 + a];
+      if (factors[i].z[12] != 0.0)
+        for (int k = 0; k < 6; ++k) {
+          const int gk = fac_lam[i] + k;
+          buf[(size_t)gk * m + gk] -= 1.0;
+          buf[(size_t)m * m + gk] -= L.r[k];
+        }
+    }
     D.Hinv_all.assign((size_t)nl * 81, 0.0);
     D.Eall.assign(nl, {});
     D.Fall.assign(nl, {});
@@ -1394,7 +1439,7 @@ inline int Graph::dist_phase(int phase, double* buf) {
         const int gb = AR.lcol[b];
         double s2 = 0.0;
         for (int i = std::max(AR.first_row[a], AR.first_row[b]); i < n; ++i) s2 += col[i] * W[(size_t)i * ma + b];
-        buf[(size_t)ga * m + gb] -= s2;         // (slots in increasing order: ga >= gb)
+        buf[(size_t)std::max(ga, gb) * m + std::min(ga, gb)] -= s2;         // (lower triangle)
       }
       double s2 = 0.0;
       for (int i = AR.first_row[a]; i < n; ++i) s2 += col[i] * AR.yp[i];
@@ -1406,13 +1451,53 @@ inline int Graph::dist_phase(int phase, double* buf) {
     // buf: [summed separator system | summed right-hand side | solution].  41: factor and solve it (the solution is left behind the
     // right-hand side for the other robots of the process, which run 42), then back-substitute: poses, private landmarks, retract.
     if ((int)sep_off.size() != nslots + 1) return -3;
-    const int m = sep_off[nslots], n = AR.n, ma = AR.ma;
+    const int ms = sep_off[nslots], m = ms + lam_total, n = AR.n, ma = AR.ma;
     double* xs = buf + (size_t)m * m + m;
     if (phase == 41) {
-      std::vector<double> Cs(buf, buf + (size_t)m * m);
-      if (m > 0 && chol_lower(Cs.data(), m, m, P.num_threads) != 0) return -4;
+      // K = [K11 K21^T; K21 K22], K11 (landmarks) positive, K22 (lambda) negative definite: K11 = L11 L11^T, L21 = K21 L11^-T,
+      // M = -(K22 - L21 L21^T) = Lm Lm^T positive definite; forward z1 = L11^-1 r1, lambda = -M^-1 (r2 - L21 z1),
+      // x1 = L11^-T (z1 - L21^T lambda)
+      std::vector<double> Ks(buf, buf + (size_t)m * m);
       for (int i = 0; i < m; ++i) xs[i] = buf[(size_t)m * m + i];
-      if (m > 0) chol_solve_lower(Cs.data(), m, m, xs);
+      std::vector<double> K11((size_t)ms * ms);
+      for (int i = 0; i < ms; ++i) std::memcpy(&K11[(size_t)i * ms], &Ks[(size_t)i * m], sizeof(double) * ms);
+      if (ms > 0 && chol_lower(K11.data(), ms, ms, P.num_threads) != 0) return -4;
+      for (int i = 0; i < ms; ++i) {          // z1
+        double s2 = xs[i];
+        for (int k = 0; k < i; ++k) s2 -= K11[(size_t)i * ms + k] * xs[k];
+        xs[i] = s2 / K11[(size_t)i * ms + i];
+      }
+      const int ml = lam_total;
+      std::vector<double> L21((size_t)ml * ms), M((size_t)ml * ml, 0.0);
+      for (int r = 0; r < ml; ++r) {
+        double* Lr = &L21[(size_t)r * ms];
+        for (int j = 0; j < ms; ++j) {
+          double s2 = Ks[(size_t)(ms + r) * m + j];
+          for (int k = 0; k < j; ++k) s2 -= Lr[k] * K11[(size_t)j * ms + k];
+          Lr[j] = s2 / K11[(size_t)j * ms + j];
+        }
+      }
+      for (int r = 0; r < ml; ++r) {
+        for (int c = 0; c <= r; ++c) {
+          double s2 = Ks[(size_t)(ms + r) * m + ms + c];
+          for (int k = 0; k < ms; ++k) s2 -= L21[(size_t)r * ms + k] * L21[(size_t)c * ms + k];
+          M[(size_t)r * ml + c] = -s2;
+        }
+        double s2 = xs[ms + r];
+        for (int k = 0; k < ms; ++k) s2 -= L21[(size_t)r * ms + k] * xs[k];
+        xs[ms + r] = -s2;
+      }
+      if (ml > 0) {
+        if (chol_lower(M.data(), ml, ml, P.num_threads) != 0) return -6;
+        chol_solve_lower(M.data(), ml, ml, xs + ms);
+      }
+      for (int i = 0; i < ms; ++i)
+        for (int r = 0; r < ml; ++r) xs[i] -= L21[(size_t)r * ms + i] * xs[ms + r];
+      for (int i = ms - 1; i >= 0; --i) {
+        const double s2 = xs[i] / K11[(size_t)i * ms + i];
+        xs[i] = s2;
+        for (int k = 0; k < i; ++k) xs[k] -= K11[(size_t)i * ms + k] * s2;
+      }
     }
     // L^T dp = y_p - W x_s
     D.dp.assign(n, 0.0);

@@ -185,6 +185,12 @@ class OracleGraph:
         off = _i(offsets)
         self.L.orc_graph_set_separator(self.h, _p(off), C.c_int(len(off)))
 
+    def set_ghost_ids(self, ids, n_total):
+        """Exact joint step: ids[i] = index, in the job's list of n_total relative-pose measurements, of this graph's i-th ghost factor
+        (the factor then enters through six separator coordinates of its own instead of being frozen at the ghost pose)."""
+        a = _i(ids)
+        self.L.orc_graph_set_ghost_ids(self.h, _p(a), C.c_int(len(a)), C.c_int(int(n_total)))
+
     def keep_factor(self, on=True):
         self.L.orc_graph_keep_factor(self.h, C.c_int(int(on)))
 

@@ -101,6 +101,9 @@ struct GraphDev {
   const int* lm_bord; // L   offset of a shared landmark's tangent coordinates in this robot's border, or -1
   double* bord;      // ((nbr + 1) * NB) x (nbr * NB), column-major, ldb: border x border block (lower) + right-hand-side row at nbr * NB
   int ldb;
+  const int* gh_bord; // n_ghost  border offset of a ghost (inter-robot relative-pose) factor's six "lambda" coordinates, or null: the
+                      // factor then enters H_pp / g_p with the other pose frozen (block-Jacobi); non-null (exact joint step): it
+                      // enters through the border only — rows J (its Jacobian w.r.t. the own pose), the first-key side adds -I and -r
   int* status;       // [0] not-SPD flag (landmark), [1] not-SPD flag (chol), [2] #relinearised
   // ---- parameters ------------------------------------------------------------------------
   int chart;

@@ -513,9 +513,9 @@ int CholBatch::prepare_pass() {
 void CholBatch::free_separator() {
   if (sepS) (void)hipFree(sepS);
   sepS = nullptr; sep_len = 0;
-  for (double** p : {&sep_Ld, &sep_Winv, &sep_yv, &sep_dp}) if (*p) { (void)hipFree(*p); *p = nullptr; }
-  for (int** p : {&sep_status, &sep_ctr, &d_sep_off}) if (*p) { (void)hipFree(*p); *p = nullptr; }
-  sep_cap = 0;
+  for (double** p : {&sep_Ld, &sep_Winv, &sep_yv, &sep_dp, &sep_bord, &lamS, &lam_Ld, &lam_Winv, &lam_yv, &lam_dp}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  for (int** p : {&sep_status, &sep_ctr, &d_sep_off, &lam_status, &lam_ctr}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  sep_cap = 0; lam_cap = -1;
 }
 int CholBatch::set_arrow(bool on, double* sep_buf, long long len) {
   std::lock_guard<std::mutex> pl(pass_mtx);
@@ -544,8 +544,33 @@ int CholBatch::prepare_separator() {
   const std::vector<int>& off = graphs[0]->h_sep_off;
   sep_m = off.back();
   sep_Ts = (sep_m + NB - 1) / NB;
-  const long long need = (long long)(sep_Ts + 1) * NB * sep_Ts * NB;
-  if (sep_x && sep_x_len < sep_buffer_len(sep_m)) { g_last_error = "exact joint step: the separator exchange buffer is too small (slide_chol_batch_sep_buffer_len)"; return SLIDE_ERR_INVALID; }
+  sep_lam = graphs[0]->lam_total;
+  for (int i = 1; i < n; ++i)
+    if (graphs[i]->lam_total != sep_lam) { g_last_error = "exact joint step: the graphs disagree on the number of relative-pose measurements"; return SLIDE_ERR_INVALID; }
+  sep_nl = (sep_lam + NB - 1) / NB;
+  const long long need = (long long)(sep_Ts + sep_nl + 1) * NB * sep_Ts * NB;
+  if (sep_nl != lam_cap) {
+    SL_HIP(hipStreamSynchronize(master));
+    for (double** p : {&sep_bord, &lamS, &lam_Ld, &lam_Winv, &lam_yv, &lam_dp}) if (*p) { SL_HIP(hipFree(*p)); *p = nullptr; }
+    for (int** p : {&lam_status, &lam_ctr}) if (*p) { SL_HIP(hipFree(*p)); *p = nullptr; }
+    lam_cap = sep_nl;
+    if (sep_nl > 0) {
+      const size_t nb = (size_t)(sep_nl + 1) * NB * sep_nl * NB;
+      SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_bord), nb * sizeof(double)));
+      SL_HIP(hipMalloc(reinterpret_cast<void**>(&lamS), nb * sizeof(double)));
+      SL_HIP(hipMemset(sep_bord, 0, nb * sizeof(double)));
+      SL_HIP(hipMemset(lamS, 0, nb * sizeof(double)));
+      SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_Ld), (size_t)sep_nl * NB * NB * sizeof(double)));
+      SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_Winv), (size_t)sep_nl * 1024 * sizeof(double)));
+      SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_yv), (size_t)sep_nl * NB * sizeof(double)));
+      SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_dp), (size_t)sep_nl * NB * sizeof(double)));
+      SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_status), 8 * sizeof(int)));
+      SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_ctr), ((size_t)sep_nl + 2) * sizeof(int)));
+      SL_HIP(hipMemset(lam_ctr, 0, ((size_t)sep_nl + 2) * sizeof(int)));
+      SL_HIP(hipMemset(lam_status, 0, 8 * sizeof(int)));
+    }
+  }
+  if (sep_x && sep_x_len < sep_buffer_len(sep_m, sep_lam)) { g_last_error = "exact joint step: the separator exchange buffer is too small (slide_chol_batch_sep_buffer_len)"; return SLIDE_ERR_INVALID; }
   if (!sepS || sep_len < need) {
     if (sepS) { SL_HIP(hipStreamSynchronize(master)); SL_HIP(hipFree(sepS)); sepS = nullptr; }
     SL_HIP(hipMalloc(reinterpret_cast<void**>(&sepS), std::max<long long>(need, 1) * sizeof(double)));
@@ -567,7 +592,7 @@ int CholBatch::prepare_separator() {
   }
   // zero once: the strict upper triangle and the idle rows of the right-hand-side tile are never written by the gather
   SL_HIP(hipMemset(sepS, 0, (size_t)need * sizeof(double)));
-  if (sep_x) SL_HIP(hipMemset(sep_x, 0, (size_t)sep_buffer_len(sep_m) * sizeof(double)));
+  if (sep_x) SL_HIP(hipMemset(sep_x, 0, (size_t)sep_buffer_len(sep_m, sep_lam) * sizeof(double)));
   if (d_sep_off) { SL_HIP(hipFree(d_sep_off)); d_sep_off = nullptr; }
   SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_off), off.size() * sizeof(int)));
   SL_HIP(hipMemcpy(d_sep_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -575,16 +600,40 @@ int CholBatch::prepare_separator() {
 }
 // One exact joint Gauss-Newton pass of all joined graphs.  part -1: the whole pass; 0: up to this GPU's partial sum of the separator
 // system (the caller all-reduces the separator buffer across the GPUs on the pass's stream); 2: the rest.
+// Ghost poses of the inter-robot relative-pose factors (slide_graph_set_ghosts): refreshed at the start of every pass — every robot
+// packs the current estimates of the ghost slots it owns into its exchange buffer (12 doubles per slot, zeros elsewhere), the buffers
+// are summed (part 20 of a cut pass ends here: the caller all-reduces d_bufs[0][0 .. 12 n_gslots)), every robot adopts the sums.
+int CholBatch::enqueue_ghost_refresh(double* const* d_bufs, int part) {
+  const int ng = hG[0].n_gslots;
+  for (int i = 1; i < n; ++i)
+    if (hG[i].n_gslots != ng) { g_last_error = "batched pass: the graphs disagree on the ghost slots"; return SLIDE_ERR_INVALID; }
+  if (ng <= 0) return SLIDE_OK;
+  const bool whole = part < 0;
+  if (whole || part == 20) {
+    for (int i = 0; i < n; ++i) launch_ghost_exchange(hG[i], 0, d_bufs[i], master);
+    launch_sum_bcast(d_bufs, n, 12 * ng, master);
+  }
+  if (whole || part == 0) {
+    if (!whole) launch_bcast(d_bufs, n, 12 * ng, master);
+    for (int i = 0; i < n; ++i) launch_ghost_exchange(hG[i], 1, d_bufs[i], master);
+  }
+  return SLIDE_OK;
+}
 int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hipEvent_t e1) {
   const bool whole = part < 0;
+  if (part == 20) return enqueue_ghost_refresh(d_bufs, part);
   auto mark = [&](int i) { if (prof_ev[0]) (void)hipEventRecord(prof_ev[i], master); };
   const int* maps[CHOL_BATCH_HOST_MAX];
   double* xloc[CHOL_BATCH_HOST_MAX];
   for (int i = 0; i < n; ++i) { maps[i] = graphs[i]->d_sep_map.d; xloc[i] = graphs[i]->d_xloc.d; }
-  const int ld_s = (sep_Ts + 1) * NB;
+  const int ld_s = (sep_Ts + sep_nl + 1) * NB;
+  const SepLayout Y = sep_layout();
   if (whole || part == 0) {
     launch_status_clear(d_Gs, n, master);
     launch_ints_clear(sep_status, 8, master);
+    if (sep_nl > 0) launch_ints_clear(lam_status, 8, master);
+    const int rg = enqueue_ghost_refresh(d_bufs, part);
+    if (rg != SLIDE_OK) return rg;
     launch_phase0_batched(d_Gs, hG.data(), n, d_bufs, master);      // relinearise, linearise, the robots' own per-landmark sums
     launch_phase3_arrow_batched(d_Gs, hG.data(), n, master);         // private landmarks eliminated, reduced pose systems, borders
     if (e0) (void)hipEventRecord(e0, master);
@@ -595,22 +644,38 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     launch_border_syrk(sys.data(), n, master);                       // border blocks: C_a - W^T W, b_s - W^T y
     mark(2);
     // a cut pass leaves this GPU's partial sum in the caller's exchange buffer (packed), a whole pass writes the system itself
-    if (whole) launch_sep_gather(hG.data(), n, maps, sep_m, sepS, sep_Ts, false, master);
-    else launch_sep_gather(hG.data(), n, maps, sep_m, sep_x, sep_Ts, true, master);
+    launch_sep_gather(hG.data(), n, maps, Y, !whole, master);
     mark(3);
   }
   if (whole || part == 2) {
-    if (!whole) launch_sep_unpack(sep_x, sepS, sep_Ts, master);
+    if (!whole) launch_sep_unpack(Y, master);
+    // landmark part of the separator: the dense step kernels, the lambda coordinates' coupling rows riding as ITS border
     for (int k = 0; k < sep_Ts; ++k)
-      launch_chol_step(sepS, ld_s, k, sep_Ts, sep_Ld + (size_t)k * NB * NB, sep_Winv + (size_t)k * 1024, sep_status, sep_ctr, nullptr, nullptr, master);
-    launch_chol_extract_y(sepS, ld_s, sep_Ts, sep_yv, sep_dp, sep_status, master);
+      launch_chol_step(sepS, ld_s, k, sep_Ts, sep_Ld + (size_t)k * NB * NB, sep_Winv + (size_t)k * 1024, sep_status, sep_ctr, nullptr, nullptr, master, sep_nl);
+    launch_chol_extract_y(sepS, ld_s, sep_Ts, sep_yv, sep_dp, sep_status, master, sep_nl);
+    if (sep_nl > 0) {
+      // the inter-robot relative-pose factors: K22 - L21 L21^T is negative definite; factor its negative, lambda = -M^-1 (r2 - L21 z1),
+      // then z1 -= L21^T lambda before the landmark part's backward substitution
+      CholSystem ss{};
+      ss.S = sepS; ss.ld = ld_s; ss.T = sep_Ts; ss.yv = sep_yv; ss.nbr = sep_nl; ss.bord = sep_bord; ss.ldb = (sep_nl + 1) * NB; ss.bfirst = nullptr;
+      launch_border_syrk(&ss, 1, master);
+      launch_lam_prepare(sep_bord, sep_nl, sep_lam, lamS, master);
+      const int ld_l = (sep_nl + 1) * NB;
+      for (int k = 0; k < sep_nl; ++k)
+        launch_chol_step(lamS, ld_l, k, sep_nl, lam_Ld + (size_t)k * NB * NB, lam_Winv + (size_t)k * 1024, lam_status, lam_ctr, nullptr, nullptr, master);
+      launch_chol_extract_y(lamS, ld_l, sep_nl, lam_yv, lam_dp, lam_status, master);
+      launch_chol_bwd_all(lamS, ld_l, sep_nl, lam_Ld, lam_Winv, lam_yv, lam_dp, lam_status, nullptr, master);
+      const double* xl = lam_dp;
+      launch_border_apply(&ss, 1, &xl, master);
+    }
     launch_chol_bwd_all(sepS, ld_s, sep_Ts, sep_Ld, sep_Winv, sep_yv, sep_dp, sep_status, nullptr, master);
     mark(4);
-    launch_sep_xloc(n, maps, sep_m, sep_dp, xloc, master);
+    launch_sep_xloc(n, maps, sep_m, sep_lam, sep_dp, lam_dp, xloc, master);
     launch_border_apply(sys.data(), n, xloc, master);                // y -= W x_s
     launch_chol_bwd_batch(sys.data(), n, master);                    // L^T dp = y
     launch_arrow_finish_batched(d_Gs, hG.data(), n, sep_dp, d_sep_off, master);
     launch_status_or(hG[0].status, sep_status, 8, master);           // (the separator's not-SPD / chain flags are reported with graph 0's)
+    if (sep_nl > 0) launch_status_or(hG[0].status, lam_status, 8, master);
     launch_status_gather(d_Gs, n, d_status_all, master);
     mark(5);
   }
@@ -669,8 +734,10 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
   if (arrow && n_slots > 0) return enqueue_arrow(d_bufs, part, e0, e1);
   const bool whole = part < 0;
   const bool joint = pcg_iters > 0 && n_slots > 0;       // PCG over the robots' coupled systems instead of the plain block solves
+  if (part == 20) return enqueue_ghost_refresh(d_bufs, part);
   if (whole || part == 0) {
     launch_status_clear(d_Gs, n, master);      // (a kernel node: a captured hipMemsetAsync did not clear on replay, DESIGN §4 finding 6)
+    if ((rc = enqueue_ghost_refresh(d_bufs, part)) != SLIDE_OK) return rc;
     if (batch_p3) launch_phase0_batched(d_Gs, hG.data(), n, d_bufs, master);      // (all robots in one launch sequence: no fork / join)
     else each(0);
     if (rc == SLIDE_OK) launch_sum_bcast(d_bufs, n, 54 * n_slots, master);
@@ -955,18 +1022,22 @@ int CholBatch::pass_all(double* const* d_bufs) {
 // The pass in three stream-ordered parts for a job that spans GPUs (see enqueue_pass): parts 0 and 1 return without a host
 // synchronisation — the caller's collective goes onto stream() behind them — part 2 ends with the one synchronisation of the pass.
 int CholBatch::pass_part(double* const* d_bufs, int part) {
-  const int slot = part >= 0 && part <= 2 ? part : (part >= 10 && part <= 12 ? part - 7 : -1);
+  const int slot = part >= 0 && part <= 2 ? part : (part >= 10 && part <= 12 ? part - 7 : (part == 20 ? 6 : -1));
   if (slot < 0) return SLIDE_ERR_INVALID;
   std::lock_guard<std::mutex> pl(pass_mtx);
   int rc;
-  if (part == 0) {
+  if (part == 20) {           // (the ghost refresh opens a pass: it brings the graphs up to date like part 0 does; part 0 then finds them unchanged)
+    bool same = false;
+    if ((rc = begin_pass(d_bufs, &same)) != SLIDE_OK) return rc;
+    if (hG[0].n_gslots <= 0) return SLIDE_OK;
+  } else if (part == 0) {
     bool same = false;
     if ((rc = begin_pass(d_bufs, &same)) != SLIDE_OK) return rc;
   } else if ((int)pass_G.size() != n || !master) {
     g_last_error = "batched pass: part 0 has not run";
     return SLIDE_ERR_INVALID;
   }
-  if (arrow && hG[0].n_slots > 0 && part != 0 && part != 2) return SLIDE_OK;      // exact joint step: one exchange, between parts 0 and 2
+  if (arrow && hG[0].n_slots > 0 && part != 0 && part != 2 && part != 20) return SLIDE_OK;      // exact joint step: one exchange, between parts 0 and 2
   if (arrow && hG[0].n_slots > 0 && !sep_x) { g_last_error = "exact joint step: a cut pass needs the caller's separator exchange buffer (slide_chol_batch_set_exact_joint)"; return SLIDE_ERR_INVALID; }
   if (part >= 10 && !(pcg_iters > 0 && hG[0].n_slots > 0)) return SLIDE_OK;      // no joint solve: nothing between parts 1 and 2
   if (!part_exec[slot] && (rc = capture_pass(d_bufs, part, &part_exec[slot])) != SLIDE_OK) return rc;
@@ -1187,8 +1258,10 @@ int HostGraph::upload_new() {
   int nbr_new = 0;
   if (arrow_now) {
     const int ns = (int)h_sh_lid.size(), m = h_sep_off.back();
+    const bool lam_on = lam_total > 0 && h_gh_gid.size() == h_gh_pose.size();
+    if (lam_total > 0 && !lam_on) { g_last_error = "exact joint step: slide_graph_set_ghost_ids must name every ghost factor of the graph"; return SLIDE_ERR_INVALID; }
     h_lm_bord.assign(std::max<size_t>(Ln, 1), -1);
-    h_sep_map.assign(std::max(m, 1), -1);
+    h_sep_map.assign(std::max(m + lam_total, 1), -1);
     int o = 0;
     for (int i = 0; i < ns; ++i) {
       const int lid = h_sh_lid[i];
@@ -1199,9 +1272,27 @@ int HostGraph::upload_new() {
       for (int k = 0; k < dim; ++k) h_sep_map[h_sep_off[i] + k] = o + k;
       o += dim;
     }
+    // then the lambda coordinates of this robot's inter-robot relative-pose factors
+    const int o_lm = o;
+    h_gh_bord.assign(std::max<size_t>(h_gh_pose.size(), 1), -1);
+    if (lam_on)
+      for (size_t q = 0; q < h_gh_pose.size(); ++q) {
+        h_gh_bord[q] = o;
+        for (int k = 0; k < 6; ++k) {
+          if (h_sep_map[m + 6 * h_gh_gid[q] + k] >= 0) { g_last_error = "exact joint step: two ghost factors of one graph name the same measurement"; return SLIDE_ERR_INVALID; }
+          h_sep_map[m + 6 * h_gh_gid[q] + k] = o + k;
+        }
+        o += 6;
+      }
     nbr_new = (o + NB - 1) / NB;
     h_bfirst.assign(nbr_new + 1, 0);
     for (int t = 0; t < nbr_new; ++t) h_bfirst[t] = 1 << 30;
+    if (lam_on)
+      for (size_t q = 0; q < h_gh_pose.size(); ++q) {
+        const int cb = 6 * h_gh_pose[q] / NB;
+        for (int t = h_gh_bord[q] / NB; t <= (h_gh_bord[q] + 5) / NB; ++t) h_bfirst[t] = std::min(h_bfirst[t], cb);
+      }
+    (void)o_lm;
     for (size_t l = 0; l < Ln; ++l) {
       if (h_lm_bord[l] < 0) continue;
       int fp = 1 << 30;
@@ -1212,7 +1303,8 @@ int HostGraph::upload_new() {
     }
     for (int t = 0; t < nbr_new; ++t) if (h_bfirst[t] == (1 << 30)) h_bfirst[t] = 0;
     if (d_lm_bord.ensure(h_lm_bord.size(), 0, s) != SLIDE_OK || d_sep_map.ensure(h_sep_map.size(), 0, s) != SLIDE_OK ||
-        d_bfirst.ensure(h_bfirst.size(), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+        d_bfirst.ensure(h_bfirst.size(), 0, s) != SLIDE_OK || d_gh_bord.ensure(h_gh_bord.size(), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    SL_HIP(hipMemcpyAsync(d_gh_bord.d, h_gh_bord.data(), h_gh_bord.size() * sizeof(int), hipMemcpyHostToDevice, s));
     SL_HIP(hipMemcpyAsync(d_lm_bord.d, h_lm_bord.data(), h_lm_bord.size() * sizeof(int), hipMemcpyHostToDevice, s));
     SL_HIP(hipMemcpyAsync(d_sep_map.d, h_sep_map.data(), h_sep_map.size() * sizeof(int), hipMemcpyHostToDevice, s));
     SL_HIP(hipMemcpyAsync(d_bfirst.d, h_bfirst.data(), h_bfirst.size() * sizeof(int), hipMemcpyHostToDevice, s));
@@ -1347,6 +1439,7 @@ int HostGraph::upload_new() {
   G.pcg_tol2 = (batch ? batch->pcg_tolerance() : pcg_tol) * (batch ? batch->pcg_tolerance() : pcg_tol);
   G.arrow = arrow_now ? 1 : 0; G.nbr = nbr; G.lm_bord = arrow_now ? d_lm_bord.d : nullptr; G.bord = arrow_now ? d_bord.d : nullptr;
   G.ldb = (nbr + 1) * NB;
+  G.gh_bord = (arrow_now && lam_total > 0) ? d_gh_bord.d : nullptr;
   G.status = d_status.d;
   G.chart = P.pose_chart;
   G.bearing_sigma = P.bearing_range_sigma; G.cyl_sigma = P.cylinder_sigma; G.numdiff_delta = P.numdiff_delta;
@@ -1482,6 +1575,15 @@ int HostGraph::set_shared(const int32_t* cls, const int64_t* idx, const int32_t*
 // the Schur complement, exact gradient): the fixed point is the joint optimum.
 bool HostGraph::arrow_on() const {
   return batch && batch->is_arrow() && !h_sh_lid.empty() && h_sep_off.size() == h_sh_lid.size() + 1;
+}
+int HostGraph::set_ghost_ids(const int32_t* ids, int n, int n_total) {
+  if (n < 0 || n_total < 0 || (n > 0 && !ids)) return SLIDE_ERR_INVALID;
+  for (int i = 0; i < n; ++i)
+    if (ids[i] < 0 || ids[i] >= n_total) { g_last_error = "set_ghost_ids: index outside the job's list of relative-pose measurements"; return SLIDE_ERR_INVALID; }
+  h_gh_gid.assign(ids, ids + n);
+  lam_total = 6 * n_total;
+  topo_dirty = true;
+  return SLIDE_OK;
 }
 int HostGraph::set_separator(const int32_t* off, int n) {
   if (n < 0 || (n > 0 && !off)) return SLIDE_ERR_INVALID;

@@ -164,7 +164,8 @@ class CholBatch {
   // this process alone).  Changing it invalidates the captured launch sequences.
   int set_arrow(bool on, double* sep_buf, long long sep_len);
   bool is_arrow() const { return arrow; }
-  static long long sep_buffer_len(int m) { const long long Ts = (m + NB - 1) / NB; return (long long)NB * NB * Ts * (Ts + 3) / 2; }      // packed exchange layout
+  // packed exchange layout of the separator system: ms landmark coordinates + lam lambda coordinates (6 per inter-robot relative-pose factor)
+  static long long sep_buffer_len(int ms, int lam = 0) { const long long Tt = (ms + NB - 1) / NB + (lam + NB - 1) / NB; return (long long)NB * NB * Tt * (Tt + 3) / 2; }
   hipStream_t pass_stream();                             // the stream the passes run on (created on first use)
   int profile_pass(double* const* d_bufs, double* ms_steps, int* n_launches);
   int profile_arrow(double* const* d_bufs, double* out6, int* n_sep_steps);
@@ -182,7 +183,8 @@ class CholBatch {
   std::vector<double*> bufs;
   std::vector<HostGraph*> graphs;
   hipGraphExec_t pass_exec = nullptr;
-  hipGraphExec_t part_exec[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // parts 0, 1, 2, 10, 11, 12 (exact joint step: 0 and 2 only)
+  hipGraphExec_t part_exec[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // parts 0, 1, 2, 10, 11, 12 (exact joint step: 0 and 2 only), 20 (ghost refresh)
+  int enqueue_ghost_refresh(double* const* d_bufs, int part);
   int pcg_iters = 0;
   double pcg_tol = 0.0;
   bool arrow = false;
@@ -193,6 +195,11 @@ class CholBatch {
   double *sep_Ld = nullptr, *sep_Winv = nullptr, *sep_yv = nullptr, *sep_dp = nullptr;
   int *sep_status = nullptr, *sep_ctr = nullptr, *d_sep_off = nullptr;
   int sep_cap = 0;
+  // lambda coordinates of the inter-robot relative-pose factors: border rows of the separator system, their own small system
+  int sep_lam = 0, sep_nl = 0, lam_cap = -1;
+  double *sep_bord = nullptr, *lamS = nullptr, *lam_Ld = nullptr, *lam_Winv = nullptr, *lam_yv = nullptr, *lam_dp = nullptr;
+  int *lam_status = nullptr, *lam_ctr = nullptr;
+  SepLayout sep_layout() const { return SepLayout{sepS, sep_bord, sep_x, sep_Ts, sep_nl, sep_m, sep_lam}; }
   int prepare_separator();
   int enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hipEvent_t e1);
   hipEvent_t prof_ev[6] = {};
@@ -262,6 +269,9 @@ class HostGraph {
   // exact joint step (batched passes only): offsets of the shared slots' tangent coordinates in the separator system, n_slots + 1 ints,
   // the same on every rank (slide_graph_set_separator)
   int set_separator(const int32_t* off, int n);
+  // exact joint step: ids[i] = index of this graph's i-th ghost factor in the job's list of n_total inter-robot relative-pose
+  // measurements: the factor enters through six separator coordinates of its own ("lambda", graph_dev.hpp gh_bord)
+  int set_ghost_ids(const int32_t* ids, int n, int n_total);
   void stats(int64_t* out5) const;
   int64_t rejected() const;
   int chi2(double* out4);                 // sum of squared whitened residuals at the current estimate: total, priors, betweens, landmark factors
@@ -341,7 +351,9 @@ class HostGraph {
   // exact joint step: this robot's border = its shared landmarks in slot order
   std::vector<int> h_sep_off;                          // global offsets (n_slots + 1) or empty
   std::vector<int> h_lm_bord, h_sep_map, h_bfirst;     // landmark -> border offset; global separator coordinate -> border coordinate; first column block per border tile row
-  DevArr<int> d_lm_bord, d_sep_map, d_bfirst;
+  std::vector<int> h_gh_gid, h_gh_bord;                // ghost factor -> index in the job's relative-pose list; -> border offset of its lambda coordinates
+  int lam_total = 0;
+  DevArr<int> d_lm_bord, d_sep_map, d_bfirst, d_gh_bord;
   DevArr<double> d_bord, d_xloc;
   int nbr = 0, nbr_alloc = -1, arrow_T = -1;
   bool arrow_on() const;                               // the batch runs exact joint passes and this graph has shared slots + separator offsets

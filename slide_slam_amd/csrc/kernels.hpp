@@ -33,9 +33,14 @@ void launch_ghost_exchange(const GraphDev& G, int what, double* buf, hipStream_t
 // gathered from the robots' border blocks (maps[i]: m ints, global separator coordinate -> robot i's border coordinate or -1); its
 // solution handed back
 void launch_border_assemble_batched(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);
-void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, int m, double* out, int Ts, bool packed, hipStream_t s);   // packed: the exchange layout (lower tile columns only)
-void launch_sep_unpack(const double* in, double* out, int Ts, hipStream_t s);
-void launch_sep_xloc(int n, const int* const* maps, int m, const double* xs, double* const* xloc, hipStream_t s);
+// Separator system: Ts tile columns of landmark coordinates (ms real) in sys (ld = (Ts + nl + 1) * NB: band, nl border row tiles = the
+// coupling rows of the lam "lambda" coordinates of the inter-robot relative-pose factors, right-hand-side tile row), the lambda x lambda
+// block + its right-hand-side row in bord (ldb = (nl + 1) * NB); packed: the exchange buffer (lower tile columns of the whole)
+struct SepLayout { double* sys; double* bord; double* packed; int Ts, nl, ms, lam; };
+void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, const SepLayout& Y, bool packed, hipStream_t s);
+void launch_sep_unpack(const SepLayout& Y, hipStream_t s);
+void launch_lam_prepare(const double* bord, int nl, int lam, double* out, hipStream_t s);      // M = -(K22 - L21 L21^T), rhs = -(r2 - L21 z1)
+void launch_sep_xloc(int n, const int* const* maps, int ms, int lam, const double* xs, const double* xl, double* const* xloc, hipStream_t s);
 void launch_arrow_finish_batched(const GraphDev* d, const GraphDev* h, int n, const double* xs, const int* sep_off, hipStream_t s);
 void launch_phase3_arrow_batched(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);   // phase 3 without the exchanged sums: the robots' own H_ll
 

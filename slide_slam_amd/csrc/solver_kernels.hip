@@ -491,7 +491,7 @@ __device__ __forceinline__ void k_pose_body(const GraphDev& G) {
       }
     } else if (e < nun) {
       const int q = e - G.n_prior;
-      if (G.gh_pose[q] != p) continue;
+      if (G.gh_pose[q] != p || (G.arrow && G.gh_bord)) continue;      // (exact joint step: the factor enters through its lambda rows)
       const double* J = G.gh_J + 36 * (size_t)q;
       const double* r = G.gh_r + 6 * (size_t)q;
 #pragma unroll
@@ -1039,6 +1039,23 @@ __global__ __launch_bounds__(256) void k_border_fill_b(const GraphDev* __restric
   }
   if (lane < D) G.bord[(size_t)(o + lane) * G.ldb + (size_t)G.nbr * NB] = -acc[45 + lane];
 }
+// lambda rows of the inter-robot relative-pose factors: 36 threads per ghost factor write J (6 x 6, whitened, w.r.t. the own pose) into
+// the border rows at the pose's columns; the first-key side also writes -I onto the border block's diagonal and -r into its RHS row
+__global__ __launch_bounds__(256) void k_border_fill_lam_b(const GraphDev* __restrict__ Gs) {
+  const GraphDev G = Gs[blockIdx.z];
+  if (!G.arrow || !G.gh_bord || G.nbr <= 0) return;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int q = t / 36, e = t - 36 * q;
+  if (q >= G.n_ghost) return;
+  const int o = G.gh_bord[q];
+  if (o < 0) return;
+  const int k = e / 6, a = e - 6 * k;
+  G.S[(size_t)(6 * G.gh_pose[q] + a) * G.ld + (size_t)G.T * NB + o + k] = G.gh_J[36 * (size_t)q + 6 * k + a];
+  if (G.gh_first[q] && a == 0) {
+    G.bord[(size_t)(o + k) * G.ldb + o + k] = -1.0;
+    G.bord[(size_t)(o + k) * G.ldb + (size_t)G.nbr * NB] = -G.gh_r[6 * (size_t)q + k];
+  }
+}
 // separator system of all shared landmarks = sum over the robots of their border blocks after k_border_syrk, gathered through the
 // robots' global -> local coordinate maps into the layout the Cholesky kernels factor (column-major lower, ld = (Ts + 1) * NB, the
 // right-hand side as first row of tile row Ts); the padding up to Ts * NB gets a unit diagonal.  Fixed summation order.
@@ -1049,46 +1066,74 @@ __device__ __forceinline__ size_t sep_packed_addr(int row, int col, int Ts) {
   const size_t off = (size_t)(NB * NB) * ((size_t)tj * (Ts + 1) - (size_t)tj * (tj - 1) / 2);
   return off + (size_t)cc * ((size_t)(Ts + 1 - tj) * NB) + (size_t)(row - tj * NB);
 }
+// Layout of the separator system the kernels below write: Ts tile columns of landmark coordinates (ms real ones, unit diagonal on the
+// padding) in `sys` (column-major, ld = (Ts + nl + 1) * NB: band rows, then nl border row tiles = the lambda coordinates' coupling rows,
+// then the right-hand side as first row of tile row Ts + nl), and the lambda x lambda block with its right-hand-side row in `bord`
+// (ldb = (nl + 1) * NB).  Virtual index of a separator coordinate: landmark g -> g, lambda b -> Ts * NB + b, right-hand side -> Tt * NB,
+// Tt = Ts + nl.  The packed exchange layout is sep_packed_addr over the virtual indices with Tt tile columns.
+__device__ __forceinline__ double* sep_slot(const SepLayout& Y, int vr, int vc, bool packed) {
+  const int Tt = Y.Ts + Y.nl;
+  if (packed) return Y.packed + sep_packed_addr(vr, vc, Tt);
+  if (vc < Y.Ts * NB) return Y.sys + (size_t)vc * ((size_t)(Tt + 1) * NB) + vr;
+  return Y.bord + (size_t)(vc - Y.Ts * NB) * ((size_t)(Y.nl + 1) * NB) + (vr - Y.Ts * NB);
+}
 struct SepGatherArgs {
-  int n, m, Ts, ld, packed;
-  double* out;
-  const double* bord[8]; int ldb[8]; int nbr[8]; const int* map[8];
+  int n, packed;
+  SepLayout Y;
+  const double* bord[8]; int ldb[8]; int nbr[8]; const int* map[8];      // map: ms + lam ints, separator coordinate -> robot's border coordinate or -1
 };
 __global__ __launch_bounds__(256) void k_sep_gather(SepGatherArgs A) {
-  const int gr = blockIdx.x * 256 + threadIdx.x, gc = blockIdx.y;
-  const int NT = A.Ts * NB;
-  if (gr > NT || gc >= NT) return;
-  const bool rhs = gr == NT;
-  if (!rhs && gr < gc) return;
+  const SepLayout& Y = A.Y;
+  const int vr = blockIdx.x * 256 + threadIdx.x, vc = blockIdx.y;
+  const int NL = Y.Ts * NB, NT = (Y.Ts + Y.nl) * NB;
+  if (vr > NT || vc >= NT) return;
+  const bool rhs = vr == NT;
+  if (!rhs && vr < vc) return;
+  // separator coordinate of a virtual index, or -1 on the padding
+  const int gc = vc < NL ? (vc < Y.ms ? vc : -1) : (vc - NL < Y.lam ? Y.ms + vc - NL : -1);
+  const int gr = rhs ? 0 : (vr < NL ? (vr < Y.ms ? vr : -1) : (vr - NL < Y.lam ? Y.ms + vr - NL : -1));
   double s = 0.0;
-  if (gc >= A.m || (!rhs && gr >= A.m)) {
-    s = (gr == gc) ? 1.0 : 0.0;
+  if (gc < 0 || gr < 0) {
+    s = (vr == vc && vc < NL) ? 1.0 : 0.0;      // unit diagonal on the landmark padding (the lambda padding is set by k_lam_prepare)
   } else {
     for (int r = 0; r < A.n; ++r) {
       const int lc = A.map[r][gc];
       if (lc < 0) continue;
       const int lr = rhs ? A.nbr[r] * NB : A.map[r][gr];
       if (lr < 0) continue;
-      s += A.bord[r][(size_t)lc * A.ldb[r] + lr];
+      s += A.bord[r][(size_t)min(lr, lc) * A.ldb[r] + max(lr, lc)];      // (lower triangle of the robot's block)
     }
   }
-  if (A.packed) A.out[sep_packed_addr(gr, gc, A.Ts)] = s;
-  else A.out[(size_t)gc * A.ld + gr] = s;
+  *sep_slot(Y, vr, vc, A.packed != 0) = s;
 }
-__global__ __launch_bounds__(256) void k_sep_unpack(const double* __restrict__ in, double* __restrict__ out, int Ts) {
-  const int gr = blockIdx.x * 256 + threadIdx.x, gc = blockIdx.y;
-  const int NT = Ts * NB;
-  if (gr > NT || gc >= NT || gr < gc / NB * NB) return;
-  out[(size_t)gc * (size_t)(Ts + 1) * NB + gr] = in[sep_packed_addr(gr, gc, Ts)];
+__global__ __launch_bounds__(256) void k_sep_unpack(SepLayout Y) {
+  const int vr = blockIdx.x * 256 + threadIdx.x, vc = blockIdx.y;
+  const int NT = (Y.Ts + Y.nl) * NB;
+  if (vr > NT || vc >= NT || vr < vc / NB * NB) return;
+  *sep_slot(Y, vr, vc, false) = *sep_slot(Y, vr, vc, true);
+}
+// the lambda coordinates' own system after the landmark part is eliminated: bord holds K22 - L21 L21^T (negative definite) and
+// r2 - L21 z1; M = -(that) is positive definite and M lambda = -(r2 - L21 z1).  out: Tl = nl tile columns, ld = (nl + 1) * NB, unit
+// diagonal on the padding.
+__global__ __launch_bounds__(256) void k_lam_prepare(const double* __restrict__ bord, int nl, int lam, double* __restrict__ out) {
+  const int r = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+  const int NT = nl * NB, ld = (nl + 1) * NB;
+  if (r > NT || c >= NT) return;
+  const bool rhs = r == NT;
+  if (!rhs && r < c) return;
+  double v;
+  if (c < lam && (rhs || r < lam)) v = -bord[(size_t)c * ld + r];
+  else v = (r == c) ? 1.0 : 0.0;
+  out[(size_t)c * ld + r] = v;
 }
 // the separator's solution back to the robots: x_loc (border order, for k_border_apply) and, after the landmark back-substitution,
 // the shared landmarks' own deltas
-struct SepScatterArgs { int n, m; const double* xs; double* xloc[8]; const int* map[8]; };
+struct SepScatterArgs { int n, m, ms; const double* xs; const double* xl; double* xloc[8]; const int* map[8]; };
 __global__ __launch_bounds__(256) void k_sep_xloc(SepScatterArgs A) {
   const int g = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
   if (g >= A.m || r >= A.n) return;
   const int lc = A.map[r][g];
-  if (lc >= 0) A.xloc[r][lc] = A.xs[g];
+  if (lc >= 0) A.xloc[r][lc] = g < A.ms ? A.xs[g] : A.xl[g - A.ms];
 }
 __global__ __launch_bounds__(256) void k_sep_lm_delta_b(const GraphDev* __restrict__ Gs, SepScatterArgs A, const int* __restrict__ sep_off) {
   const GraphDev G = Gs[blockIdx.z];
@@ -1313,21 +1358,29 @@ void launch_border_assemble_batched(const GraphDev* d, const GraphDev* h, int n,
   if (work <= 0 || slots <= 0) return;
   hipLaunchKernelGGL(k_border_clear_b, dim3((unsigned)std::min<long long>((work + 255) / 256, 4096), 1, n), dim3(256), 0, s, d);
   hipLaunchKernelGGL(k_border_fill_b, dim3((slots + 3) / 4, 1, n), dim3(256), 0, s, d);
+  int ngh = 0;
+  for (int i = 0; i < n; ++i) ngh = std::max(ngh, h[i].gh_bord ? h[i].n_ghost : 0);
+  if (ngh > 0) hipLaunchKernelGGL(k_border_fill_lam_b, dim3((36 * ngh + 255) / 256, 1, n), dim3(256), 0, s, d);
 }
-void launch_sep_unpack(const double* in, double* out, int Ts, hipStream_t s) {
-  if (Ts > 0) hipLaunchKernelGGL(k_sep_unpack, dim3((Ts * NB + 1 + 255) / 256, Ts * NB), dim3(256), 0, s, in, out, Ts);
+void launch_sep_unpack(const SepLayout& Y, hipStream_t s) {
+  const int NT = (Y.Ts + Y.nl) * NB;
+  if (NT > 0) hipLaunchKernelGGL(k_sep_unpack, dim3((NT + 1 + 255) / 256, NT), dim3(256), 0, s, Y);
 }
-void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, int m, double* out, int Ts, bool packed, hipStream_t s) {
+void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, const SepLayout& Y, bool packed, hipStream_t s) {
   SepGatherArgs A{};
-  A.n = n; A.m = m; A.Ts = Ts; A.ld = (Ts + 1) * NB; A.out = out; A.packed = packed ? 1 : 0;
+  A.n = n; A.Y = Y; A.packed = packed ? 1 : 0;
   for (int i = 0; i < n; ++i) { A.bord[i] = h[i].bord; A.ldb[i] = h[i].ldb; A.nbr[i] = h[i].nbr; A.map[i] = maps[i]; }
-  if (Ts > 0) hipLaunchKernelGGL(k_sep_gather, dim3((Ts * NB + 1 + 255) / 256, Ts * NB), dim3(256), 0, s, A);
+  const int NT = (Y.Ts + Y.nl) * NB;
+  if (NT > 0) hipLaunchKernelGGL(k_sep_gather, dim3((NT + 1 + 255) / 256, NT), dim3(256), 0, s, A);
 }
-void launch_sep_xloc(int n, const int* const* maps, int m, const double* xs, double* const* xloc, hipStream_t s) {
+void launch_lam_prepare(const double* bord, int nl, int lam, double* out, hipStream_t s) {
+  if (nl > 0) hipLaunchKernelGGL(k_lam_prepare, dim3((nl * NB + 1 + 255) / 256, nl * NB), dim3(256), 0, s, bord, nl, lam, out);
+}
+void launch_sep_xloc(int n, const int* const* maps, int ms, int lam, const double* xs, const double* xl, double* const* xloc, hipStream_t s) {
   SepScatterArgs A{};
-  A.n = n; A.m = m; A.xs = xs;
+  A.n = n; A.m = ms + lam; A.ms = ms; A.xs = xs; A.xl = xl;
   for (int i = 0; i < n; ++i) { A.xloc[i] = xloc[i]; A.map[i] = maps[i]; }
-  if (m > 0) hipLaunchKernelGGL(k_sep_xloc, dim3((m + 255) / 256, n), dim3(256), 0, s, A);
+  if (A.m > 0) hipLaunchKernelGGL(k_sep_xloc, dim3((A.m + 255) / 256, n), dim3(256), 0, s, A);
 }
 // the last steps of an exact joint pass for all robots of the GPU: pose_delta = dp and the private landmarks' deltas (k_backsub<0>; a
 // separator landmark gets 0 there: H_ll^-1 = 0), the separator landmarks' deltas from the separator's solution, estimate

@@ -269,12 +269,66 @@ class PassDriver:
             for sh in shards:
                 sh.graph.set_pcg(self.pcg_iters, self.pcg_tol)
 
+    def setup_ghosts(self, relmeas, rank=0):
+        """Inter-robot relative-pose measurements of the job, [(pose index k, robot a, robot b, rel7 a->b)], identical on every rank
+        (addRelativeMeasFactor, graph.cpp:247-258).  Both robots hold the factor, each with its own pose as the variable and the other
+        pose as a GHOST — its current estimate, refreshed at the start of every pass (12 doubles per ghost slot, one small all-reduce),
+        at which the factor is linearised.  Exact joint step: the factor's six linearised residuals join the separator ("lambda"
+        coordinates), each robot couples to them through its own Jacobian, and the step is exactly the joint replica's.  PCG / block-Jacobi
+        passes: the cross block J_a^T J_b is left out of the step (gradient exact).  Virtual robot of local shard t = rank * R + t."""
+        R = len(self.shards)
+        keys = sorted({(a, k) for (k, a, b, _) in relmeas} | {(b, k) for (k, a, b, _) in relmeas})
+        slot = {key: i for i, key in enumerate(keys)}
+        self.n_gslots = len(keys)
+        self.n_relmeas = len(relmeas)
+        for t, sh in enumerate(self.shards):
+            v = rank * R + t
+            sh.graph.set_ghosts(np.array([0 if r == v else -1 for (r, _) in keys], np.int32), np.array([k for (_, k) in keys], np.int64))
+            ids = []
+            for i, (k, a, b, rel) in enumerate(relmeas):
+                if a == v:
+                    sh.graph.add_relative_meas_ghost(rel, k, 0, slot[(b, k)], True)
+                    ids.append(i)
+                if b == v:
+                    sh.graph.add_relative_meas_ghost(rel, k, 0, slot[(a, k)], False)
+                    ids.append(i)
+            if self.arrow:
+                # exact joint step: the factor enters through six separator coordinates of its own (its linearised residual), coupled to
+                # each robot's band by that robot's own Jacobian — the step stays exactly the joint replica's
+                sh.graph.set_ghost_ids(np.array(ids, np.int32), len(relmeas))
+        n12 = 12 * self.n_gslots
+        if self.arrow:
+            self.lam_dim = 6 * len(relmeas)
+            if self.device is None:
+                m = self.sep_dim + self.lam_dim
+                self.sbufs = [np.zeros(m * m + 2 * m) for _ in self.shards]
+        if self.device is None:
+            self.gbufs = [np.zeros(max(n12, 1)) for _ in self.shards]
+        else:
+            # (the batched pass runs the ghost exchange through the shards' exchange buffers: they must hold 12 doubles per ghost slot)
+            if any(b.numel() < n12 for b in self.bufs):
+                raise ValueError("setup_ghosts: the exchange buffers are smaller than 12 doubles per ghost slot")
+        return self.n_gslots
+
+    def _ghost_refresh_host(self):
+        """CPU shards: dist_phase 20 (pack the owned ghost poses' estimates), sum, dist_phase 21 (adopt)."""
+        n12 = 12 * self.n_gslots
+        for sh, b in zip(self.shards, self.gbufs):
+            sh.graph.dist_phase(20, b)
+        tot = self.gbufs[0]
+        for b in self.gbufs[1:]:
+            tot[:n12] += b[:n12]
+        if self.world > 1:
+            self.base.all_reduce(tot, n12)
+        for sh in self.shards:
+            sh.graph.dist_phase(21, tot)
+
     def _sep_exchange_buffer(self):
         """The separator system's exchange buffer of a cut pass (packed lower tile columns): this GPU's partial sum after part 0,
         all-reduced across the GPUs on the batch's stream, read back by part 2."""
         if self.sep is None:
             import torch
-            self.sep_len = self.batch.sep_buffer_len(self.sep_dim)
+            self.sep_len = self.batch.sep_buffer_len(self.sep_dim, getattr(self, "n_relmeas", 0))
             self.sep = torch.zeros(max(self.sep_len, 1), dtype=torch.float64, device=self.device)
             self.batch.set_exact_joint(True, self.sep.data_ptr(), self.sep_len)
         return self.sep
@@ -309,11 +363,17 @@ class PassDriver:
                 self.batch.pass_all(self.ptrs)
             elif self.arrow:
                 sep = self._sep_exchange_buffer()
+                if getattr(self, "n_gslots", 0):
+                    self.batch.pass_part(self.ptrs, 20)
+                    self._exchange(12 * self.n_gslots)
                 self.batch.pass_part(self.ptrs, 0)
                 if self.world > 1 or self.base is not None:
                     self.base.all_reduce_on(sep, self.sep_len, self.batch.stream() if self.stream_ordered else None)
                 self.batch.pass_part(self.ptrs, 2)
             else:
+                if getattr(self, "n_gslots", 0):
+                    self.batch.pass_part(self.ptrs, 20)
+                    self._exchange(12 * self.n_gslots)
                 self.batch.pass_part(self.ptrs, 0)
                 self._exchange(n54)
                 self.batch.pass_part(self.ptrs, 1)
@@ -326,13 +386,15 @@ class PassDriver:
                 self.batch.pass_part(self.ptrs, 2)
         else:
             h = (lambda b: b.data_ptr()) if self.device is not None else (lambda b: b)
+            if getattr(self, "n_gslots", 0) and self.device is None:
+                self._ghost_refresh_host()
 
             def each(ph):
                 for sh, b in zip(self.shards, self.bufs):
                     sh.graph.dist_phase(ph, h(b))
             each(0)
             if self.arrow:
-                m = self.sep_dim
+                m = self.sep_dim + getattr(self, "lam_dim", 0)
                 for sh, b in zip(self.shards, self.sbufs):
                     sh.graph.dist_phase(40, b)
                 tot = self.sbufs[0]

@@ -345,7 +345,7 @@ def tiny_pcg(out, preset="C3tiny", passes=15, pcg=8):
     json.dump(res, open(out, "w"))
 
 
-def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1):
+def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1, relmeas=0):
     """The EXACT joint step (shared landmarks as the separator of the joint graph) of the HIP shards in one CholBatch — the whole pass
     one replayed hipGraph — against oracle shards taking the same step pass by pass, and (small presets) against the optimum of the
     oracle's joint replica, the reference's arrangement.  mode: replay = streaming build per robot (per-frame solves), ingest = all
@@ -359,7 +359,7 @@ def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1):
     from dist_worker import oracle_matcher
     from slide_slam_amd.distributed import PassDriver, gpu_matcher, setup_local_shards
     from slide_slam_amd.replay import replay_single
-    from slide_slam_amd.synth import SynthConfig, make_robot_log, make_world
+    from slide_slam_amd.synth import SynthConfig, make_relmeas, make_robot_log, make_world
     cfg = SynthConfig.preset(preset)
     wm = make_world(cfg)
     R, P = cfg.robots, cfg.poses_per_robot
@@ -367,7 +367,7 @@ def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1):
     joint, counts = None, None
     if with_joint:
         from test_distributed import _joint_optimum
-        joint, counts = _joint_optimum(preset)
+        joint, counts = _joint_optimum(preset, relmeas=bool(relmeas))
     A = [s.SlideBackend(s.default_params(), 1) for _ in range(R)]
     L = po.lib(native=True)
     O = [po.OracleBackend(po.OrcParams.default(num_threads=min(os.cpu_count() or 1, 16)), 1, L=L) for _ in range(R)]
@@ -387,7 +387,14 @@ def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1):
     dA = PassDriver(A, bufA, infoA["n_slots"], batch=batch, device=dev, arrow=True, sep_dim=infoA["sep_dim"])
     dO = PassDriver(O, bufO, infoO["n_slots"], arrow=True, sep_dim=infoO["sep_dim"])
     say("associated:", infoA["n_slots"], infoO["n_slots"], "slots, separator", infoA["sep_dim"], infoO["sep_dim"])
-    res = dict(n_slots=[infoA["n_slots"], infoO["n_slots"]], sep_dim=[infoA["sep_dim"], infoO["sep_dim"]],
+    n_g = 0
+    if relmeas:
+        # inter-robot relative-pose factors (graph.cpp:247-258): ghost poses refreshed at the start of every pass, on both sides
+        rel = make_relmeas(cfg, logs)
+        n_g = dA.setup_ghosts(rel)
+        assert dO.setup_ghosts(rel) == n_g
+        say("relative-pose measurements:", len(rel), "ghost slots:", n_g)
+    res = dict(n_gslots=n_g, n_slots=[infoA["n_slots"], infoO["n_slots"]], sep_dim=[infoA["sep_dim"], infoO["sep_dim"]],
                n_global=[list(map(int, infoA["n_global"])), list(map(int, infoO["n_global"]))], gpu_vs_oracle=[], step=[], vs_joint=[], ms=[])
     prev = None
     for p in range(passes):

@@ -91,15 +91,29 @@ def test_exact_joint_step_matches_oracle_shards_and_the_joint_replica(gpu, tmp_p
     assert sum(abs(a - b) for a, b in zip(z["n_global"][0], z["joint_counts"])) <= 1
 
 
+def test_exact_joint_step_with_relative_pose_factors(gpu, tmp_path):
+    """Inter-robot relative-pose factors (addRelativeMeasFactor, graph.cpp:247-258) in the batched exact joint pass: every factor's six
+    linearised residuals are further separator coordinates (lambda rows in the robots' borders, a nested border of the separator
+    system, the negative-definite lambda block factored as its negative), ghost poses — the linearisation points — refreshed by the
+    first nodes of the replayed pass.  GPU == oracle shards pass by pass, and THREE passes end within 2e-6 of the optimum of the
+    oracle's joint replica that holds the measurements as ordinary Between factors (C3rel: one every 8 frames)."""
+    out = str(tmp_path / "arrow_rel.json")
+    _scenario("arrow_parity", out, "C3rel", 6, "replay", 1, 1)
+    z = json.load(open(out))
+    assert z["finite"] and z["n_gslots"] > 0 and z["n_slots"][0] == z["n_slots"][1] > 0
+    assert max(z["gpu_vs_oracle"]) < 1e-7, z["gpu_vs_oracle"]
+    assert z["vs_joint"][0] < 2e-4 and max(z["vs_joint"][2:]) < 5e-6, z["vs_joint"]
+
+
 def test_c4_exact_joint_step_matches_oracle_shards_at_size(gpu, tmp_path):
     """configs[3] at size through the path bench.py times (eight robots in one CholBatch, 59 block columns + 16 border row tiles each,
-    a 3809-coordinate separator system): the GPU pass against eight ORACLE shards taking the same exact joint step, pass by pass —
+    a 3809-coordinate separator system, the inter-robot relative-pose factors of SURVEY 8d as ghosts): the GPU pass against eight ORACLE shards taking the same exact joint step, pass by pass —
     measured 1e-8 .. 4e-8 relative on poses (the bar is 1e-4) — and the Gauss-Newton iteration converges: the fourth step is three
     orders below the second (it then sits in a 2-cycle of ~3e-4 m on 200 m trajectories, the noise of the numerical Jacobians)."""
     out = str(tmp_path / "arrow_c4.json")
-    _scenario("arrow_parity", out, "C4", 4, "ingest", 0)
+    _scenario("arrow_parity", out, "C4", 4, "ingest", 0, 1)
     z = json.load(open(out))
-    assert z["finite"] and z["n_slots"][0] == z["n_slots"][1] > 500 and z["sep_dim"][0] == z["sep_dim"][1] > 1500
+    assert z["finite"] and z["n_slots"][0] == z["n_slots"][1] > 500 and z["sep_dim"][0] == z["sep_dim"][1] > 1500 and z["n_gslots"] > 0
     assert max(z["gpu_vs_oracle"]) < 1e-6, z["gpu_vs_oracle"]
     assert z["step"][3] < 5e-3 * z["step"][1], z["step"]
     assert abs(z["chi2_pass"][3] - z["chi2_pass"][2]) < 1e-4 * z["chi2_pass"][3], z["chi2_pass"]

@@ -29,6 +29,11 @@ def main():
     bufs, info = setup_local_shards(shards, oracle_matcher)
     print("slots", info["n_slots"], "separator dim", info["sep_dim"], flush=True)
     drv = PassDriver(shards, bufs, info["n_slots"], arrow=True, sep_dim=info["sep_dim"])
+    if len(sys.argv) > 3 and sys.argv[3] == "relmeas":
+        from slide_slam_amd.synth import make_relmeas
+        logs = [make_robot_log(cfg, wm, r) for r in range(R)]
+        rel = make_relmeas(cfg, logs)
+        print("relmeas", [(k, a, b, [round(float(v), 2) for v in r7[:3]]) for (k, a, b, r7) in rel], "ghost slots", drv.setup_ghosts(rel), flush=True)
     prev = None
     for p in range(passes):
         t0 = time.time()
