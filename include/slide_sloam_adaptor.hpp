@@ -16,6 +16,7 @@
 #define SLIDE_SLOAM_ADAPTOR_HPP_
 
 #include <array>
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <stdexcept>
@@ -53,8 +54,23 @@ void to7(const T& p, double o[7]) {
 }
 template <class V>
 void to3(const V& p, double o[3]) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+// point of the world frame in the frame of pose7 (R^T (p - t)): graphWrapper.cpp:165-173 computes curr_pose^-1 * ellipsoid_world
+inline void to_body(const double T[7], const double p[3], double o[3]) {
+  const double x = T[3], y = T[4], z = T[5], w = T[6];
+  const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                       2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                       2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+  const double d[3] = {p[0] - T[0], p[1] - T[1], p[2] - T[2]};
+  for (int c = 0; c < 3; ++c) o[c] = R[c] * d[0] + R[3 + c] * d[1] + R[6 + c] * d[2];
+}
 inline void check(int rc, const char* what) { if (rc < 0) throw Error(rc, what); }
 }  // namespace detail
+
+// Customisation point for the read-back methods that hand poses to the CALLER's types (getCurrPose, updateFactorGraphMap, ...):
+// slide_assign_pose(dst, pose7) is found by argument-dependent lookup; the overload for slide::Pose7 is below, a maintainer adds
+//     inline void slide_assign_pose(Sophus::SE3d& d, const double p[7]) { d = Sophus::SE3d(Eigen::Quaterniond(p[6], p[3], p[4], p[5]), {p[0], p[1], p[2]}); }
+// next to the type.
+inline void slide_assign_pose(Pose7& dst, const double p[7]) { for (int i = 0; i < 7; ++i) dst.v[i] = p[i]; }
 
 // gtsam_cylinder::CylinderMeasurement / gtsam_cube::CubeMeasurement as the reference's call sites fill them
 // (cylinderFactor.h:22-40, cubeFactor.h:25-44): plain aggregates here.
@@ -200,7 +216,130 @@ class SemanticFactorGraphWrapper : public SemanticFactorGraph {
   }
   slide_backend_t* backend() const { return b_; }
 
+  // ---- the reference's own S2 signatures (graphWrapper.h:82-122) over the S1 entry points --------------------------------------
+  // For a caller that keeps the reference's map managers and association (RunSloam, *MapManager::updateMap) on the host and hands
+  // the match vectors over, exactly as sloamNode.cpp:889 / :993 do.  The types are template parameters that only have to provide
+  // what graphWrapper.cpp:99-237 uses: map.getMatchesMap().at(int) -> int, map.getRawMap()[i].model, cylinder.model.{root, ray,
+  // radius}, cube.model.{pose, scale}, ellipsoid.model.{pose, scale, semantic_label}.  These methods keep the reference's counters
+  // (graphWrapper.h:128-134) themselves; do not mix them with the whole-frame addSLOAMObservation above on one object.
+  std::vector<size_t> pose_counter_robot_ = std::vector<size_t>(SLIDE_MAX_ROBOTS, 0);                    // graphWrapper.h:128 (public there too)
+
+  template <class CylMap, class CubeMap, class EllMap, class Cyl, class Cube, class Ell, class SE3>
+  bool addSLOAMObservation(const CylMap& semanticMap, const CubeMap& cubeSemanticMap, const EllMap& ellipsoidSemanticMap,
+                           const std::vector<int>& cyl_matches, const std::vector<Cyl>& cylinders, const std::vector<int>& cube_matches,
+                           const std::vector<Cube>& cubes, const std::vector<int>& ellipsoid_matches, const std::vector<Ell>& ellipsoids,
+                           const SE3& relativeMotion, const SE3& poseEstimate, const int& robotID, bool opt = true) {   // graphWrapper.cpp:99-237
+    if (robotID < 0 || robotID >= SLIDE_MAX_ROBOTS) throw Error(SLIDE_ERR_INVALID, "addSLOAMObservation: robotID");
+    Pose7 curr; detail::to7(poseEstimate, curr.v);
+    const size_t pose_counter = pose_counter_robot_[robotID];
+    if (pose_counter == 0) setPriors(poseEstimate, robotID);                                             // :114-119
+    else addKeyPoseAndBetween(pose_counter - 1, pose_counter, relativeMotion, poseEstimate, robotID);    // :121
+    const auto matchesMap = semanticMap.getMatchesMap();
+    const auto cubeMatchesMap = cubeSemanticMap.getMatchesMap();
+    for (size_t i = 0; i < cyl_matches.size(); ++i) {                                                    // :127-140
+      CylinderMeasurement m;
+      detail::to3(cylinders[i].model.root, m.root); detail::to3(cylinders[i].model.ray, m.ray); m.radius = cylinders[i].model.radius;
+      if (cyl_matches[i] == -1) { addCylinderFactor(pose_counter, cyl_counter_, curr, m, false, robotID); ++cyl_counter_; }
+      else addCylinderFactor(pose_counter, (size_t)matchesMap.at(cyl_matches[i]), curr, m, true, robotID);
+    }
+    for (size_t i = 0; i < cube_matches.size(); ++i) {                                                   // :143-156
+      CubeMeasurement m;
+      detail::to7(cubes[i].model.pose, m.pose.v); detail::to3(cubes[i].model.scale, m.scale);
+      if (cube_matches[i] == -1) { addCubeFactor(pose_counter, cube_counter_, curr, m, false, robotID); ++cube_counter_; }
+      else addCubeFactor(pose_counter, (size_t)cubeMatchesMap.at(cube_matches[i]), curr, m, true, robotID);
+    }
+    const auto ellipMatchesMap = ellipsoidSemanticMap.getMatchesMap();
+    for (size_t i = 0; i < ellipsoid_matches.size(); ++i) {                                              // :159-203: body-frame bearing + range
+      double w[3], b[3];
+      detail::to3(ellipsoids[i].model.pose.translation(), w);
+      detail::to_body(curr.v, w, b);
+      const double range = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+      const double bearing[3] = {b[0] / range, b[1] / range, b[2] / range};
+      if (ellipsoid_matches[i] == -1) {
+        addPointLandmarkKey(point_landmark_counter_, w);
+        addRangeBearingFactor(pose_counter, point_landmark_counter_, bearing, range, robotID);
+        point_landmark_labels_.push_back(ellipsoids[i].model.semantic_label);
+        ++point_landmark_counter_;
+      } else {
+        addRangeBearingFactor(pose_counter, (size_t)ellipMatchesMap.at(ellipsoid_matches[i]), bearing, range, robotID);
+      }
+    }
+    pose_counter_robot_[robotID] = pose_counter + 1;                                                     // :206-207
+    if (opt) { solve(); return true; }                                                                   // :212-230
+    return false;
+  }
+  // updateFactorGraphMap graphWrapper.cpp:259-275 (+ updateCylinder / updateCube / updateEllipsoid :239-256): every optimised landmark
+  // back into the caller's map models; an ellipsoid's pose becomes identity rotation + the optimised point (:252-255)
+  template <class CylMap, class CubeMap, class EllMap>
+  void updateFactorGraphMap(CylMap& semanticMap, CubeMap& cubeSemanticMap, EllMap& ellipsoidSemanticMap) {
+    auto& map = semanticMap.getRawMap();
+    auto& cube_map = cubeSemanticMap.getRawMap();
+    auto& ellipsoid_map = ellipsoidSemanticMap.getRawMap();
+    for (size_t i = 0; i < cyl_counter_; ++i) {
+      const CylinderMeasurement m = getCylinder((int)i);
+      for (int k = 0; k < 3; ++k) { map[i].model.root[k] = m.root[k]; map[i].model.ray[k] = m.ray[k]; }
+      map[i].model.radius = m.radius;
+    }
+    for (size_t i = 0; i < cube_counter_; ++i) {
+      const std::array<double, 15> c = getCube((int)i);
+      double p7[7];
+      rt_to7(c.data(), c.data() + 9, p7);
+      slide_assign_pose(cube_map[i].model.pose, p7);
+      for (int k = 0; k < 3; ++k) cube_map[i].model.scale[k] = c[12 + k];
+    }
+    for (size_t i = 0; i < point_landmark_counter_; ++i) {
+      const std::array<double, 3> x = getCentroidLandmark((int)i);
+      const double p7[7] = {x[0], x[1], x[2], 0, 0, 0, 1};
+      slide_assign_pose(ellipsoid_map[i].model.pose, p7);
+    }
+  }
+  // getCurrPose graphWrapper.cpp:277-297 with the reference's argument list; cov (optional, boost::optional<MatrixXd&> there) = the
+  // 6x6 marginal covariance of that pose, row-major [rot, trans]
+  template <class SE3>
+  void getCurrPose(SE3& curr_pose, const int& robotID, std::array<double, 36>* cov) {
+    const size_t n = robotID >= 0 && robotID < SLIDE_MAX_ROBOTS ? pose_counter_robot_[robotID] : 0;
+    Pose7 p;
+    if (n > 0) (void)getPose(n - 1, robotID, p);                  // (absent: identity, as the reference after its ROS_ERROR)
+    slide_assign_pose(curr_pose, p.v);
+    if (cov && n > 0) *cov = getPoseCovariance((int)(n - 1), robotID);
+  }
+  // getAllCentroidLandmarks / ...AndLabels graphWrapper.cpp:340-400: a landmark whose optimised point is exactly (0, 0, 0) counts as
+  // missing (:345-347)
+  template <class SE3>
+  void getAllCentroidLandmarks(std::vector<SE3>& optimized_landmark_pos, std::vector<size_t>& landmark_inds) {
+    for (size_t i = 0; i < point_landmark_counter_; ++i) {
+      const std::array<double, 3> x = getCentroidLandmark((int)i);
+      if (x[0] == 0.0 && x[1] == 0.0 && x[2] == 0.0) continue;
+      const double p7[7] = {x[0], x[1], x[2], 0, 0, 0, 1};
+      SE3 pose; slide_assign_pose(pose, p7);
+      optimized_landmark_pos.push_back(pose);
+      landmark_inds.push_back(i);
+    }
+  }
+  template <class SE3>
+  void getAllCentroidLandmarksAndLabels(std::vector<SE3>& optimized_landmark_pos, std::vector<int>& landmark_labels) {
+    for (size_t i = 0; i < point_landmark_counter_; ++i) {
+      const std::array<double, 3> x = getCentroidLandmark((int)i);
+      if (x[0] == 0.0 && x[1] == 0.0 && x[2] == 0.0) continue;
+      const double p7[7] = {x[0], x[1], x[2], 0, 0, 0, 1};
+      SE3 pose; slide_assign_pose(pose, p7);
+      optimized_landmark_pos.push_back(pose);
+      landmark_labels.push_back(i < point_landmark_labels_.size() ? point_landmark_labels_[i] : -1);     // (:392-398)
+    }
+  }
+
  private:
+  size_t cyl_counter_ = 0, cube_counter_ = 0, point_landmark_counter_ = 0;                                // graphWrapper.h:131-133
+  std::vector<int> point_landmark_labels_;
+  static void rt_to7(const double R[9], const double t[3], double o[7]) {                                  // row-major R -> unit quaternion
+    const double tr = R[0] + R[4] + R[8];
+    double w, x, y, z;
+    if (tr > 0) { const double s = std::sqrt(tr + 1.0) * 2; w = 0.25 * s; x = (R[7] - R[5]) / s; y = (R[2] - R[6]) / s; z = (R[3] - R[1]) / s; }
+    else if (R[0] > R[4] && R[0] > R[8]) { const double s = std::sqrt(1.0 + R[0] - R[4] - R[8]) * 2; w = (R[7] - R[5]) / s; x = 0.25 * s; y = (R[1] + R[3]) / s; z = (R[2] + R[6]) / s; }
+    else if (R[4] > R[8]) { const double s = std::sqrt(1.0 + R[4] - R[0] - R[8]) * 2; w = (R[2] - R[6]) / s; x = (R[1] + R[3]) / s; y = 0.25 * s; z = (R[5] + R[7]) / s; }
+    else { const double s = std::sqrt(1.0 + R[8] - R[0] - R[4]) * 2; w = (R[3] - R[1]) / s; x = (R[2] + R[6]) / s; y = (R[5] + R[7]) / s; z = 0.25 * s; }
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = x; o[4] = y; o[5] = z; o[6] = w;
+  }
   static slide_backend_t* make(const slide_params_t* p) {
     slide_backend_t* b = slide_backend_create(p);
     if (!b) throw Error(SLIDE_ERR_HIP, "slide_backend_create");

@@ -148,8 +148,10 @@ __device__ __forceinline__ void b_quadrant(double* __restrict__ S, int ld, const
 // the right-hand side does — virtual rows Tv .. Tv + nbr - 1 are the physical tile rows T .. T + nbr - 1 (the coupling of the band's
 // columns to the separator variables, W^T = B^T L^-T after the steps), virtual row Tv + nbr the right-hand side at physical row T + nbr.
 // The steps never touch border COLUMNS: the border x border block is one product at the end (k_border_syrk).
+// nbB / nbX: the border rows that are active in the pass / for the column items — the rows whose coupling starts at a later block column
+// are still all-zero and form a suffix of the border (plan_step); the right-hand side is virtual row Tv + (active rows).
 __device__ __forceinline__ BItem b_decode(int g, int nItems, int nR, int g0, int k, int kb, int T, int TvB, int TvX, int nP, long long nG, int wave,
-                                          int nbr) {
+                                          int nbr, int nbB, int nbX) {
   BItem it;
   it.ok = false; it.i = it.j = it.pcb = 0; it.ks = 32;
   if (g >= nItems) return it;
@@ -162,15 +164,15 @@ __device__ __forceinline__ BItem b_decode(int g, int nItems, int nR, int g0, int
     it.i = kb + 1 + 2 * bi + (int)(tt & 1);
     it.j = kb + 1 + 2 * bj + (wave >> 2);
     it.pcb = kb - 2;
-    it.ok = !(it.i > TvB + nbr || it.j > TvB - 1 || it.i < it.j);
-    if (it.i >= TvB) it.i = T + (it.i - TvB);
+    it.ok = !(it.i > TvB + nbB || it.j > TvB - 1 || it.i < it.j);
+    if (it.i >= TvB) it.i = (it.i - TvB < nbB) ? T + (it.i - TvB) : T + nbr;
   } else {
     const int c = g - nR;
     it.j = k + 1;
     it.i = k + 1 + 2 * c + (wave >> 2);
     it.pcb = k - 1; it.ks = 16;
-    it.ok = !(it.i > TvX + nbr || it.j > TvX - 1);
-    if (it.i >= TvX) it.i = T + (it.i - TvX);
+    it.ok = !(it.i > TvX + nbX || it.j > TvX - 1);
+    if (it.i >= TvX) it.i = (it.i - TvX < nbX) ? T + (it.i - TvX) : T + nbr;
   }
   return it;
 }
@@ -605,8 +607,9 @@ __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld,
 // L32 (or null): packed f32 copy of the factor's off-diagonal tiles, written along with the panel (the preconditioner of the joint solve
 // streams it, see bwd_chain_body): tile (i, k), k < i < T, at 4096 * (k (T-1) - k (k-1) / 2 + i - k - 1)
 __device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int k, int T, int TvA, int ia, int half, double* __restrict__ Ld,
-                                            double* __restrict__ Winv, int* status, ALds& L, float* __restrict__ L32) {
-  const int it = (k + 1 + ia >= TvA) ? T + (k + 1 + ia - TvA) : k + 1 + ia;      // rows k+1 .. TvA-1 of the profile, then the border rows and the right-hand-side row
+                                            double* __restrict__ Winv, int* status, ALds& L, float* __restrict__ L32, int nbr, int nbA) {
+  const int vi = k + 1 + ia - TvA;      // rows k+1 .. TvA-1 of the profile, then the nbA active border rows, then the right-hand-side row
+  const int it = vi < 0 ? k + 1 + ia : (vi < nbA ? T + vi : T + nbr);
   float* L32t = (L32 && it < T) ? L32 + ((size_t)k * (T - 1) - (size_t)k * (k - 1) / 2 + (it - k - 1)) * (NB * NB) : nullptr;
   if (k > 0) step_type_a_impl<1>(S, ld, k, ia, it, half, Ld, Winv, status, L, L32t);
   else step_type_a_impl<0>(S, ld, k, ia, it, half, Ld, Winv, status, L, L32t);
@@ -619,13 +622,13 @@ __device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int 
 __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Ld,
                                                    double* __restrict__ Winv, int* status, int* __restrict__ ctr, int kb, int nP,
                                                    int g0, int g1, int nX, int a_joins, int a_split, float* __restrict__ L32,
-                                                   int TvA, int TvB, int TvX, int nbr) {
+                                                   int TvA, int TvB, int TvX, int nbr, int nbA, int nbB, int nbX) {
   __shared__ ALds L;
   __shared__ int s_g;
-  const int nA = (TvA - k + nbr) << a_split;      // a_split: two type-A workgroups per tile, 32 panel rows each (A-bound launches: the CUs are there)
+  const int nA = (TvA - k + nbA) << a_split;      // a_split: two type-A workgroups per tile, 32 panel rows each (A-bound launches: the CUs are there)
   if (blockIdx.x == 0 && threadIdx.x == 0) ctr[k + 1] = 0;
   if ((int)blockIdx.x < nA) {
-    step_type_a(S, ld, k, T, TvA, (int)blockIdx.x >> a_split, a_split ? (int)(blockIdx.x & 1) : -1, Ld, Winv, status, L, L32);
+    step_type_a(S, ld, k, T, TvA, (int)blockIdx.x >> a_split, a_split ? (int)(blockIdx.x & 1) : -1, Ld, Winv, status, L, L32, nbr, nbA);
     if (!a_joins) return;        // the queue workers are through before the chain is: an item taken now would only add a tail
   }
   const int nR = g1 - g0, nItems = nR + nX;
@@ -638,7 +641,7 @@ __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ S, int l
     __syncthreads();
     const int g = __builtin_amdgcn_readfirstlane(s_g);
     if (g >= nItems) break;
-    const BItem it = b_decode(g, nItems, nR, g0, k, kb, T, TvB, TvX, nP, nG, wave, nbr);
+    const BItem it = b_decode(g, nItems, nR, g0, k, kb, T, TvB, TvX, nP, nG, wave, nbr, nbB, nbX);
     if (!it.ok) continue;
     if (it.ks == 32) b_quadrant<32>(S, ld, it, wave & 3);
     else b_quadrant<16>(S, ld, it, wave & 3);
@@ -655,6 +658,7 @@ struct CholBatchArgs {
   int TvA[CHOL_BATCH_MAX], TvB[CHOL_BATCH_MAX], TvX[CHOL_BATCH_MAX];      // virtual sizes of the step (profile), see b_decode
   int nP[CHOL_BATCH_MAX], g0[CHOL_BATCH_MAX], g1[CHOL_BATCH_MAX], nX[CHOL_BATCH_MAX], a_split[CHOL_BATCH_MAX];
   int nbr[CHOL_BATCH_MAX];             // border row tiles below the profile (b_decode)
+  int nbA[CHOL_BATCH_MAX], nbB[CHOL_BATCH_MAX], nbX[CHOL_BATCH_MAX];      // ... of which active for column k / the pair's pass / the column items
   int a_base[CHOL_BATCH_MAX + 1];      // prefix sums of the type-A workgroup counts
   int b_base[CHOL_BATCH_MAX + 1];      // prefix sums of the type-B item counts
 };
@@ -668,7 +672,7 @@ __global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int 
     while (bid >= A.a_base[r + 1]) ++r;
     const int local = bid - A.a_base[r], sp = A.a_split[r];
     step_type_a(A.S[r], A.ld[r], k, A.T[r], A.TvA[r], local >> sp, sp ? (local & 1) : -1, A.Ld[r] + (size_t)k * NB * NB,
-                A.Winv[r] + (size_t)k * 1024, A.status[r], L, A.L32[r]);
+                A.Winv[r] + (size_t)k * 1024, A.status[r], L, A.L32[r], A.nbr[r], A.nbA[r]);
     if (!a_joins) return;
   }
   const int nItems = A.b_base[A.n];
@@ -684,7 +688,7 @@ __global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int 
     while (g >= A.b_base[r + 1]) ++r;
     const int gl = g - A.b_base[r], nR = A.g1[r] - A.g0[r];
     const long long nG = (long long)A.nP[r] * (A.nP[r] + 1) / 2;
-    const BItem it = b_decode(gl, nR + A.nX[r], nR, A.g0[r], k, kb, A.T[r], A.TvB[r], A.TvX[r], A.nP[r], nG, wave, A.nbr[r]);
+    const BItem it = b_decode(gl, nR + A.nX[r], nR, A.g0[r], k, kb, A.T[r], A.TvB[r], A.TvX[r], A.nP[r], nG, wave, A.nbr[r], A.nbB[r], A.nbX[r]);
     if (!it.ok) continue;
     if (it.ks == 32) b_quadrant<32>(A.S[r], A.ld[r], it, wave & 3);
     else b_quadrant<16>(A.S[r], A.ld[r], it, wave & 3);
@@ -1336,34 +1340,50 @@ void launch_pose_covariance(const double* S, int ld, int T, const double* Ld, co
 // waves with a 32x32 quadrant each (the quadrant of b_quadrant: four 16x16 accumulators, operands as 16-byte loads three k-steps
 // ahead), C read and written once.  bfirst[i]: first column block in which border tile row i can be non-zero (a landmark first seen
 // late in the trajectory has an all-zero W^T row up to there): the sum starts at max(bfirst[i], bfirst[j]).
+// Split K (ks > 1, one system with a handful of border tiles — the separator's own lambda border): blockIdx.z is the chunk of the column
+// blocks; chunk 0 works on the tile itself, chunk q > 0 leaves its partial product in scratch tile (tile, q - 1) and k_border_syrk_reduce
+// adds the partials in chunk order (deterministic, no atomics).
 struct SyrkArgs {
   int n;
   const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX]; int nbr[CHOL_BATCH_MAX];
   double* bord[CHOL_BATCH_MAX]; int ldb[CHOL_BATCH_MAX]; const int* bfirst[CHOL_BATCH_MAX];
+  int ks; double* scratch;
 };
 __global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
-  const int r = blockIdx.z, ib = blockIdx.x, jb = blockIdx.y;
+  const int r = A.ks > 1 ? 0 : blockIdx.z, q = A.ks > 1 ? blockIdx.z : 0, ib = blockIdx.x, jb = blockIdx.y;
   const int nbr = A.nbr[r];
   if (ib > nbr || jb >= nbr || ib < jb) return;
-  const int T = A.T[r], ld = A.ld[r], ldb = A.ldb[r];
-  int c0 = 0;
+  const int T = A.T[r], ld = A.ld[r];
+  int ldb = A.ldb[r];
+  int c0 = 0, c1 = T;                             // column blocks [c0, c1) of the band
   if (A.bfirst[r]) c0 = max(A.bfirst[r][ib], A.bfirst[r][jb]);
-  if (c0 >= T) return;
+  if (A.ks > 1) {
+    const int len = (T - c0 + A.ks - 1) / A.ks;
+    c0 += q * len;
+    c1 = min(T, c0 + len);
+  }
+  if (c0 >= c1) return;
   const double* S = A.S[r];
   const int wq = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
   const int ch = (wq >> 1) & 1, rh = wq & 1;      // column half, row half of the tile
   const double* pjh = S + (size_t)(c0 * NB + lk) * ld + (size_t)(T + jb) * NB + 32 * ch + 2 * lr;
   const double* pih = S + (size_t)(c0 * NB + lk) * ld + (size_t)(T + ib) * NB + 32 * rh + 2 * lr;
   double* cbh = A.bord[r] + (size_t)(jb * NB + 32 * ch + 2 * lk) * ldb + (size_t)ib * NB + 32 * rh + 2 * lr;
+  if (q > 0) {       // partial of a later chunk: a 64 x 64 scratch tile (leading dimension NB)
+    ldb = NB;
+    cbh = A.scratch + ((size_t)(jb * (nbr + 1) + ib) * (A.ks - 1) + (q - 1)) * (NB * NB) + (size_t)(32 * ch + 2 * lk) * NB + 32 * rh + 2 * lr;
+  }
   v4d acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const v2d c2 = *(const v2d*)(cbh + (size_t)(8 * q + a) * ldb);
-      acc[a][0][q] = c2[0]; acc[a][1][q] = c2[1];
+    for (int e = 0; e < 4; ++e) {
+      v2d c2;
+      c2[0] = 0.0; c2[1] = 0.0;
+      if (q == 0) c2 = *(const v2d*)(cbh + (size_t)(8 * e + a) * ldb);
+      acc[a][0][e] = c2[0]; acc[a][1][e] = c2[1];
     }
-  const int KS = (T - c0) * 16;                   // k-steps of four columns (a multiple of 16)
+  const int KS = (c1 - c0) * 16;                  // k-steps of four columns (a multiple of 16)
   constexpr int RD = 4;
   v2d pa[RD], pb[RD];
 #pragma unroll
@@ -1394,13 +1414,30 @@ __global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int e = 0; e < 4; ++e) {
       v2d c2;
-      c2[0] = acc[a][0][q]; c2[1] = acc[a][1][q];
-      *(v2d*)(cbh + (size_t)(8 * q + a) * ldb) = c2;
+      c2[0] = acc[a][0][e]; c2[1] = acc[a][1][e];
+      *(v2d*)(cbh + (size_t)(8 * e + a) * ldb) = c2;
     }
 }
-void launch_border_syrk(const CholSystem* d, int n, hipStream_t s) {
+__global__ __launch_bounds__(256) void k_border_syrk_reduce(double* __restrict__ bord, int ldb, int nbr, int ks, const double* __restrict__ scratch,
+                                                            const int* __restrict__ bfirst, int T) {
+  const int ib = blockIdx.x, jb = blockIdx.y;
+  if (ib > nbr || jb >= nbr || ib < jb) return;
+  int c0 = 0;
+  if (bfirst) c0 = max(bfirst[ib], bfirst[jb]);
+  const int len = (T - c0 + ks - 1) / ks;
+  for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    const int col = e / NB, row = e - col * NB;
+    double v = bord[(size_t)(jb * NB + col) * ldb + (size_t)ib * NB + row];
+    for (int q = 1; q < ks; ++q)
+      if (c0 + q * len < T) v += scratch[((size_t)(jb * (nbr + 1) + ib) * (ks - 1) + (q - 1)) * (NB * NB) + (size_t)col * NB + row];
+    bord[(size_t)(jb * NB + col) * ldb + (size_t)ib * NB + row] = v;
+  }
+}
+// scratch (or null): (nbr + 1) * nbr * (ks - 1) tiles of NB * NB doubles — with it, ONE system's product is split over ks chunks of its
+// column blocks (a system with a handful of border tiles would otherwise occupy a handful of CUs for the whole K)
+void launch_border_syrk(const CholSystem* d, int n, hipStream_t s, double* scratch, int ks) {
   SyrkArgs A{};
   A.n = n;
   int nb = 0;
@@ -1408,7 +1445,15 @@ void launch_border_syrk(const CholSystem* d, int n, hipStream_t s) {
     A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.nbr[i] = d[i].nbr; A.bord[i] = d[i].bord; A.ldb[i] = d[i].ldb; A.bfirst[i] = d[i].bfirst;
     nb = d[i].nbr > nb ? d[i].nbr : nb;
   }
-  if (nb > 0) hipLaunchKernelGGL(k_border_syrk, dim3(nb + 1, nb, n), dim3(256), 0, s, A);
+  if (nb <= 0) return;
+  if (scratch && n == 1 && ks > 1) {
+    A.ks = ks; A.scratch = scratch;
+    hipLaunchKernelGGL(k_border_syrk, dim3(nb + 1, nb, ks), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_border_syrk_reduce, dim3(nb + 1, nb), dim3(256), 0, s, d[0].bord, d[0].ldb, d[0].nbr, ks, scratch, d[0].bfirst, d[0].T);
+    return;
+  }
+  A.ks = 1; A.scratch = nullptr;
+  hipLaunchKernelGGL(k_border_syrk, dim3(nb + 1, nb, n), dim3(256), 0, s, A);
 }
 // y -= W x_loc before the backward substitution of the band (x_loc: the separator's solution in the system's own border order, zeros
 // in the padding): one wave per column of the band, lanes over the border rows (contiguous down a column of S)
@@ -1450,7 +1495,7 @@ void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s, int nbr) {
   hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, T + nbr, yv, dp, status);
 }
-struct StepPlan { int kb, nP, g0, g1, nX, TvA, TvB, TvX; long long nA, nB; };
+struct StepPlan { int kb, nP, g0, g1, nX, TvA, TvB, TvX, nbA, nbB, nbX; long long nA, nB; };
 static int chol_n_cu() {
   static int n_cu = 0;
   if (!n_cu) {
@@ -1464,7 +1509,9 @@ static int chol_n_cu() {
 // prof (host, T ints, or null = dense): prof[c] = last tile row of block column c inside the monotone profile of the factor (>= c).
 // Column k's tiles reach row prof[k]; the rank-128 pass of pair base kb (panels kb-2, kb-1) touches rows / columns <= prof[kb-1]; the
 // column items of an odd launch (panel k-1 onto column k+1) rows <= prof[k-1].  Everything else is structurally zero and skipped.
-static StepPlan plan_step(int k, int T, const int* prof, int nbr = 0) {
+// bfirst (host, nbr ints, non-decreasing, or null): first block column in which border tile row i is non-zero; a row whose first column lies
+// beyond the panels a launch handles is all-zero there and skipped
+static StepPlan plan_step(int k, int T, const int* prof, int nbr = 0, const int* bfirst = nullptr) {
   static const double frac = getenv("SLIDE_CHOL_FRAC") ? atof(getenv("SLIDE_CHOL_FRAC")) : 0.5;   // diagnostic: share of a pass done by its first launch
   StepPlan p{};
   p.kb = k & ~1;                                                // base of the pair
@@ -1474,9 +1521,11 @@ static StepPlan plan_step(int k, int T, const int* prof, int nbr = 0) {
     if (p.kb >= 1) p.TvB = prof[p.kb - 1] + 1;
     if (k >= 1) p.TvX = prof[k - 1] + 1;
   }
-  p.nA = k < T ? p.TvA - k + nbr : 0;                           // column-k tiles below the diagonal (+ border tiles + RHS tile)
+  auto active = [&](int upto) { int c = 0; while (c < nbr && (!bfirst || bfirst[c] <= upto)) ++c; return c; };
+  p.nbA = active(k); p.nbB = active(p.kb - 1); p.nbX = active(k - 1);
+  p.nA = k < T ? p.TvA - k + p.nbA : 0;                         // column-k tiles below the diagonal (+ active border tiles + RHS tile)
   if (k >= 2 && k < T) {
-    p.nP = p.TvB + nbr > p.kb ? (p.TvB + nbr - p.kb + 1) / 2 : 0;     // 2x2 tile groups per side of the trailing matrix of the pair
+    p.nP = p.TvB + p.nbB > p.kb ? (p.TvB + p.nbB - p.kb + 1) / 2 : 0;     // 2x2 tile groups per side of the trailing matrix of the pair
     long long nG = (long long)p.nP * (p.nP + 1) / 2;
     if (nbr > 0) {
       // the border has rows only: the group columns right of the profile's last column hold no item — the enumeration (column-major
@@ -1491,14 +1540,14 @@ static StepPlan plan_step(int k, int T, const int* prof, int nbr = 0) {
     if (first > nG) first = nG;
     if (k & 1) { p.g0 = (int)(2 * first); p.g1 = (int)(2 * nG); } else { p.g0 = 0; p.g1 = (int)(2 * first); }   // items = half groups
   }
-  p.nX = (k & 1) && k + 1 < p.TvX ? (p.TvX + nbr - k + 1) / 2 : 0;    // column items: tile rows k+1 .. TvX (+ border) of column k+1, two per item
+  p.nX = (k & 1) && k + 1 < p.TvX ? (p.TvX + p.nbX - k + 1) / 2 : 0;    // column items: tile rows k+1 .. TvX (+ active border) of column k+1, two per item
   p.nB = p.g1 - p.g0 + p.nX;
   return p;
 }
 void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, float* L32, const int* h_prof,
                       hipStream_t s, int nbr) {
   const int n_cu = chol_n_cu();
-  const StepPlan p = plan_step(k, T, h_prof, nbr);
+  const StepPlan p = plan_step(k, T, h_prof, nbr, nullptr);
   const long long nA = p.nA, nB = p.nB;
   static const int split_pct = getenv("SLIDE_CHOL_ASPLIT") ? atoi(getenv("SLIDE_CHOL_ASPLIT")) : 100;   // diagnostic: 0 = never
   // two workgroups per type-A tile once the launch is bound by the chain, not by the flood
@@ -1510,7 +1559,7 @@ void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv,
   static const int join_mul = getenv("SLIDE_CHOL_JOIN") ? atoi(getenv("SLIDE_CHOL_JOIN")) : 1;
   const int a_joins = nB > join_mul * free_cu ? 1 : 0;
   hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nAw + extra)), dim3(512), 0, s, S, ld, k, T, Ld, Winv, status, ctr, p.kb, p.nP,
-                     p.g0, p.g1, p.nX, a_joins, a_split, L32, p.TvA, p.TvB, p.TvX, nbr);
+                     p.g0, p.g1, p.nX, a_joins, a_split, L32, p.TvA, p.TvB, p.TvX, nbr, p.nbA, p.nbB, p.nbX);
 }
 // The factorisations + solves of several systems as one launch sequence (max T step launches, the extractions, one chained backward
 // substitution): d[i] describes system i; ctr is the work counter array of the batch (max T + 2 ints, zeroed once).
@@ -1523,7 +1572,7 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
     A.n = n;
     long long nA2 = 0, nBt = 0;
     StepPlan pl[CHOL_BATCH_MAX];
-    for (int i = 0; i < n; ++i) { pl[i] = plan_step(k, d[i].T, d[i].h_prof, d[i].nbr); nA2 += 2 * pl[i].nA; nBt += pl[i].nB; }
+    for (int i = 0; i < n; ++i) { pl[i] = plan_step(k, d[i].T, d[i].h_prof, d[i].nbr, d[i].h_bfirst); nA2 += 2 * pl[i].nA; nBt += pl[i].nB; }
     const int a_split = (k > 0 && nA2 + nBt <= n_cu) ? 1 : 0;
     A.a_base[0] = A.b_base[0] = 0;
     for (int i = 0; i < n; ++i) {
@@ -1531,7 +1580,7 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
       A.L32[i] = d[i].L32;
       A.TvA[i] = pl[i].TvA; A.TvB[i] = pl[i].TvB; A.TvX[i] = pl[i].TvX;
       A.nP[i] = pl[i].nP; A.g0[i] = pl[i].g0; A.g1[i] = pl[i].g1; A.nX[i] = pl[i].nX; A.a_split[i] = a_split;
-      A.nbr[i] = d[i].nbr;
+      A.nbr[i] = d[i].nbr; A.nbA[i] = pl[i].nbA; A.nbB[i] = pl[i].nbB; A.nbX[i] = pl[i].nbX;
       A.a_base[i + 1] = A.a_base[i] + (int)(pl[i].nA << a_split);
       A.b_base[i + 1] = A.b_base[i] + (int)pl[i].nB;
     }

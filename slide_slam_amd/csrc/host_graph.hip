@@ -365,13 +365,13 @@ int HostGraph::merge_pending() {
 
 constexpr int CHOL_BATCH_HOST_MAX = 8;
 // the Cholesky view of a graph's reduced system (joint: with the f32 factor copy of the PCG preconditioner)
-static CholSystem chol_system_of(HostGraph* g, const GraphDev& G, bool joint, float* L32, const int* h_prof, double* ctab, const int* bfirst) {
-  (void)g;
+static CholSystem chol_system_of(const GraphDev& G, bool joint, float* L32, const int* h_prof, double* ctab, const int* bfirst, const int* h_bfirst) {
   CholSystem c{};
   c.S = G.S; c.ld = G.ld; c.T = G.T; c.Ld = G.Ld; c.Winv = G.Winv; c.yv = G.yv; c.dp = G.dp; c.status = G.status;
   c.L32 = joint ? L32 : nullptr;
   c.h_prof = h_prof; c.prof = G.prof; c.first = G.first; c.ctab = ctab;
   c.nbr = G.arrow ? G.nbr : 0; c.bord = G.bord; c.ldb = G.ldb; c.bfirst = bfirst;
+  c.h_bfirst = (G.arrow && G.nbr > 0) ? h_bfirst : nullptr;
   return c;
 }
 CholBatch::CholBatch(int n_) : n(n_ < 1 ? 1 : (n_ > 8 ? 8 : n_)), sys(n), ev_in(n, nullptr), bufs(n, nullptr), graphs(n, nullptr) {}
@@ -422,8 +422,8 @@ int CholBatch::factor_solve(int slot, const GraphDev& G, hipStream_t s) {
   if (slot < 0 || slot >= n) return SLIDE_ERR_INVALID;
   {
     std::lock_guard<std::mutex> lk(mtx);
-    sys[slot] = chol_system_of(graphs[slot], G, pcg_iters > 0 && G.n_slots > 0, graphs[slot]->d_L32.d, graphs[slot]->h_prof.data(), graphs[slot]->d_ctab.d,
-                               graphs[slot]->d_bfirst.d);
+    sys[slot] = chol_system_of(G, pcg_iters > 0 && G.n_slots > 0, graphs[slot]->d_L32.d, graphs[slot]->h_prof.data(), graphs[slot]->d_ctab.d,
+                               graphs[slot]->d_bfirst.d, graphs[slot]->h_bfirst.data());
   }
   return rendezvous(slot, s, false, 0);
 }
@@ -491,7 +491,8 @@ int CholBatch::prepare_pass() {
   hG.resize(n);
   for (int i = 0; i < n; ++i) {
     const GraphDev& G = graphs[i]->G;
-    sys[i] = chol_system_of(graphs[i], G, pcg_iters > 0 && G.n_slots > 0, graphs[i]->d_L32.d, graphs[i]->h_prof.data(), graphs[i]->d_ctab.d, graphs[i]->d_bfirst.d);
+    sys[i] = chol_system_of(G, pcg_iters > 0 && G.n_slots > 0, graphs[i]->d_L32.d, graphs[i]->h_prof.data(), graphs[i]->d_ctab.d, graphs[i]->d_bfirst.d,
+                            graphs[i]->h_bfirst.data());
     Tmax = G.T > Tmax ? G.T : Tmax;
     hG[i] = G;
     hG[i].save_S0 = (pcg_iters > 0 && G.n_slots > 0) ? 1 : 0;      // the batched Schur assembly writes S0 itself
@@ -513,7 +514,7 @@ int CholBatch::prepare_pass() {
 void CholBatch::free_separator() {
   if (sepS) (void)hipFree(sepS);
   sepS = nullptr; sep_len = 0;
-  for (double** p : {&sep_Ld, &sep_Winv, &sep_yv, &sep_dp, &sep_bord, &lamS, &lam_Ld, &lam_Winv, &lam_yv, &lam_dp}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  for (double** p : {&sep_Ld, &sep_Winv, &sep_yv, &sep_dp, &sep_bord, &lamS, &lam_Ld, &lam_Winv, &lam_yv, &lam_dp, &lam_scratch}) if (*p) { (void)hipFree(*p); *p = nullptr; }
   for (int** p : {&sep_status, &sep_ctr, &d_sep_off, &lam_status, &lam_ctr}) if (*p) { (void)hipFree(*p); *p = nullptr; }
   sep_cap = 0; lam_cap = -1;
 }
@@ -551,12 +552,13 @@ int CholBatch::prepare_separator() {
   const long long need = (long long)(sep_Ts + sep_nl + 1) * NB * sep_Ts * NB;
   if (sep_nl != lam_cap) {
     SL_HIP(hipStreamSynchronize(master));
-    for (double** p : {&sep_bord, &lamS, &lam_Ld, &lam_Winv, &lam_yv, &lam_dp}) if (*p) { SL_HIP(hipFree(*p)); *p = nullptr; }
+    for (double** p : {&sep_bord, &lamS, &lam_Ld, &lam_Winv, &lam_yv, &lam_dp, &lam_scratch}) if (*p) { SL_HIP(hipFree(*p)); *p = nullptr; }
     for (int** p : {&lam_status, &lam_ctr}) if (*p) { SL_HIP(hipFree(*p)); *p = nullptr; }
     lam_cap = sep_nl;
     if (sep_nl > 0) {
       const size_t nb = (size_t)(sep_nl + 1) * NB * sep_nl * NB;
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_bord), nb * sizeof(double)));
+      if ((sep_nl + 1) * sep_nl <= 32) SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_scratch), (size_t)(sep_nl + 1) * sep_nl * 15 * NB * NB * sizeof(double)));
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&lamS), nb * sizeof(double)));
       SL_HIP(hipMemset(sep_bord, 0, nb * sizeof(double)));
       SL_HIP(hipMemset(lamS, 0, nb * sizeof(double)));
@@ -658,7 +660,8 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
       // then z1 -= L21^T lambda before the landmark part's backward substitution
       CholSystem ss{};
       ss.S = sepS; ss.ld = ld_s; ss.T = sep_Ts; ss.yv = sep_yv; ss.nbr = sep_nl; ss.bord = sep_bord; ss.ldb = (sep_nl + 1) * NB; ss.bfirst = nullptr;
-      launch_border_syrk(&ss, 1, master);
+      const int ks = (sep_nl + 1) * sep_nl <= 32 ? std::max(1, std::min(16, sep_Ts / 2)) : 1;      // few border tiles: split the column blocks
+      launch_border_syrk(&ss, 1, master, lam_scratch, ks);
       launch_lam_prepare(sep_bord, sep_nl, sep_lam, lamS, master);
       const int ld_l = (sep_nl + 1) * NB;
       for (int k = 0; k < sep_nl; ++k)
@@ -1252,8 +1255,7 @@ int HostGraph::upload_new() {
   }
   if (up_csr(d_pose_bt_ptr, d_pose_bt, pose_bt, ptr, val, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (ub.flush(s) != SLIDE_OK) return SLIDE_ERR_HIP;   // (the host temporaries were copied into the pinned staging buffer)
-  // exact joint step: this robot's border = its shared landmarks in slot order (the order of the separator system, so local and
-  // global coordinates are both increasing)
+  // exact joint step: this robot's border = its shared landmarks and the lambda coordinates of its relative-pose factors
   const bool arrow_now = arrow_on();
   int nbr_new = 0;
   if (arrow_now) {
@@ -1262,46 +1264,45 @@ int HostGraph::upload_new() {
     if (lam_total > 0 && !lam_on) { g_last_error = "exact joint step: slide_graph_set_ghost_ids must name every ghost factor of the graph"; return SLIDE_ERR_INVALID; }
     h_lm_bord.assign(std::max<size_t>(Ln, 1), -1);
     h_sep_map.assign(std::max(m + lam_total, 1), -1);
-    int o = 0;
+    h_gh_bord.assign(std::max<size_t>(h_gh_pose.size(), 1), -1);
+    // border items: this robot's shared landmarks and the lambda coordinates of its relative-pose factors, ordered by the first block
+    // column of the band in which their coupling row is non-zero (the first observing key frame) — the rows that are still all-zero at a
+    // block column are then a SUFFIX of the border, which the steps and the border product skip (the maps below carry the permutation)
+    struct Item { int cb, kind, id, dim, goff; };
+    std::vector<Item> items;
     for (int i = 0; i < ns; ++i) {
       const int lid = h_sh_lid[i];
       if (lid < 0 || (size_t)lid >= Ln) continue;
       const int dim = h_sep_off[i + 1] - h_sep_off[i];
       if (dim != lm_dim(h_lm_type[lid])) { g_last_error = "separator offsets do not match the landmark classes of the shared slots"; return SLIDE_ERR_INVALID; }
-      h_lm_bord[lid] = o;
-      for (int k = 0; k < dim; ++k) h_sep_map[h_sep_off[i] + k] = o + k;
-      o += dim;
+      int fp = 1 << 30;
+      for (int f : lm_fids[lid]) fp = std::min(fp, h_lf_pose[f]);
+      items.push_back(Item{fp == (1 << 30) ? 0 : 6 * fp / NB, 0, lid, dim, h_sep_off[i]});
     }
-    // then the lambda coordinates of this robot's inter-robot relative-pose factors
-    const int o_lm = o;
-    h_gh_bord.assign(std::max<size_t>(h_gh_pose.size(), 1), -1);
     if (lam_on)
       for (size_t q = 0; q < h_gh_pose.size(); ++q) {
-        h_gh_bord[q] = o;
-        for (int k = 0; k < 6; ++k) {
-          if (h_sep_map[m + 6 * h_gh_gid[q] + k] >= 0) { g_last_error = "exact joint step: two ghost factors of one graph name the same measurement"; return SLIDE_ERR_INVALID; }
-          h_sep_map[m + 6 * h_gh_gid[q] + k] = o + k;
-        }
-        o += 6;
+        for (int k = 0; k < 6; ++k)
+          if (h_sep_map[m + 6 * h_gh_gid[q] + k] == -2) { g_last_error = "exact joint step: two ghost factors of one graph name the same measurement"; return SLIDE_ERR_INVALID; }
+        for (int k = 0; k < 6; ++k) h_sep_map[m + 6 * h_gh_gid[q] + k] = -2;
+        items.push_back(Item{6 * h_gh_pose[q] / NB, 1, (int)q, 6, m + 6 * h_gh_gid[q]});
       }
+    std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.cb < y.cb; });
+    int o = 0;
+    for (const Item& it : items) {
+      if (it.kind == 0) h_lm_bord[it.id] = o; else h_gh_bord[it.id] = o;
+      for (int k = 0; k < it.dim; ++k) h_sep_map[it.goff + k] = o + k;
+      o += it.dim;
+    }
     nbr_new = (o + NB - 1) / NB;
     h_bfirst.assign(nbr_new + 1, 0);
     for (int t = 0; t < nbr_new; ++t) h_bfirst[t] = 1 << 30;
-    if (lam_on)
-      for (size_t q = 0; q < h_gh_pose.size(); ++q) {
-        const int cb = 6 * h_gh_pose[q] / NB;
-        for (int t = h_gh_bord[q] / NB; t <= (h_gh_bord[q] + 5) / NB; ++t) h_bfirst[t] = std::min(h_bfirst[t], cb);
-      }
-    (void)o_lm;
-    for (size_t l = 0; l < Ln; ++l) {
-      if (h_lm_bord[l] < 0) continue;
-      int fp = 1 << 30;
-      for (int f : lm_fids[l]) fp = std::min(fp, h_lf_pose[f]);
-      if (fp == (1 << 30)) continue;
-      const int cb = 6 * fp / NB, d = lm_dim(h_lm_type[l]);
-      for (int t = h_lm_bord[l] / NB; t <= (h_lm_bord[l] + d - 1) / NB; ++t) h_bfirst[t] = std::min(h_bfirst[t], cb);
+    o = 0;
+    for (const Item& it : items) {
+      for (int t = o / NB; t <= (o + it.dim - 1) / NB; ++t) h_bfirst[t] = std::min(h_bfirst[t], it.cb);
+      o += it.dim;
     }
     for (int t = 0; t < nbr_new; ++t) if (h_bfirst[t] == (1 << 30)) h_bfirst[t] = 0;
+    for (int t = 1; t < nbr_new; ++t) h_bfirst[t] = std::max(h_bfirst[t], h_bfirst[t - 1]);      // (non-decreasing by construction; kept so by force)
     if (d_lm_bord.ensure(h_lm_bord.size(), 0, s) != SLIDE_OK || d_sep_map.ensure(h_sep_map.size(), 0, s) != SLIDE_OK ||
         d_bfirst.ensure(h_bfirst.size(), 0, s) != SLIDE_OK || d_gh_bord.ensure(h_gh_bord.size(), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     SL_HIP(hipMemcpyAsync(d_gh_bord.d, h_gh_bord.data(), h_gh_bord.size() * sizeof(int), hipMemcpyHostToDevice, s));

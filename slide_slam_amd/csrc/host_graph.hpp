@@ -197,6 +197,7 @@ class CholBatch {
   int sep_cap = 0;
   // lambda coordinates of the inter-robot relative-pose factors: border rows of the separator system, their own small system
   int sep_lam = 0, sep_nl = 0, lam_cap = -1;
+  double *lam_scratch = nullptr;      // partial products of the separator's own border product (split K)
   double *sep_bord = nullptr, *lamS = nullptr, *lam_Ld = nullptr, *lam_Winv = nullptr, *lam_yv = nullptr, *lam_dp = nullptr;
   int *lam_status = nullptr, *lam_ctr = nullptr;
   SepLayout sep_layout() const { return SepLayout{sepS, sep_bord, sep_x, sep_Ts, sep_nl, sep_m, sep_lam}; }

@@ -59,11 +59,12 @@ struct CholSystem { double* S; int ld, T; double* Ld; double* Winv; double* yv; 
                     double* ctab;                // 4 * T * 4096 doubles: tables of the chained substitutions in a joint-solve pass (k_chain_tables), or null
                     int nbr;                     // border row tiles between the band and the right-hand-side row (exact joint step: the separator's coupling rows), see b_decode
                     double* bord; int ldb;       // border x border block of the system ((nbr + 1) * NB rows, nbr * NB columns, column-major) — k_border_syrk
-                    const int* bfirst; };        // device, nbr + 1 ints: first block column of the band in which border tile row i can be non-zero
+                    const int* bfirst;           // device, nbr + 1 ints: first block column of the band in which border tile row i can be non-zero (non-decreasing)
+                    const int* h_bfirst; };      // host copy (plan_step: the border rows still all-zero at a block column are skipped) or null: every row always
 void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps = nullptr, bool solve = true);            // up to 8 systems, one launch per block column; solve = false: steps + extraction of y only
 void launch_chol_bwd_batch(const CholSystem* d, int n, hipStream_t s);       // yv -> dp of up to 8 factored systems (chained backward substitution)
 // Exact joint step (the border of the systems = the separator's coupling rows, W^T after the steps):
-void launch_border_syrk(const CholSystem* d, int n, hipStream_t s);          // bord(i, j) -= sum_c W^T(i, c) W^T(j, c)^T, i >= j, right-hand-side row included
+void launch_border_syrk(const CholSystem* d, int n, hipStream_t s, double* scratch = nullptr, int ks = 1);          // bord(i, j) -= sum_c W^T(i, c) W^T(j, c)^T, i >= j, right-hand-side row included; scratch + ks: split K (one system)
 void launch_border_apply(const CholSystem* d, int n, const double* const* xloc, hipStream_t s);   // yv -= W x_loc (x_loc: nbr * NB doubles per system)
 // one of the two triangular solves with the finished factors of up to 8 systems on arbitrary vectors (T * NB doubles each): out = L^-1 in
 // (fwd) or L^-T in (bwd); the preconditioner of the joint solve (pcg_kernels.hip)

@@ -1,27 +1,29 @@
-"""One robot per GPU: cross-robot landmark association and the distributed Gauss-Newton pass.
+"""Robots sharded over GPUs: cross-robot landmark association and the distributed Gauss-Newton pass.
 
-The reference keeps a FULL replica of every robot's graph in every `sloam_node` and gossips packets over ROS
-topics (databaseManager.cpp:219-279; ingestion sloamNode.cpp:912-1002).  Here robot r's poses, factors and maps
-live on GPU r only; landmarks observed by several robots are replicated, and each Gauss-Newton pass exchanges
-just their normal-equation blocks:
+The reference keeps a FULL replica of every robot's graph in every `sloam_node` and gossips packets over ROS topics
+(databaseManager.cpp:219-279; ingestion sloamNode.cpp:912-1002): its solve() optimises the JOINT graph.  Here robot r's poses, factors
+and maps live on one GPU only (8 / N robots per GPU, one process per GPU, all robots of a process in one CholBatch driven by ONE host
+thread: `PassDriver`); landmarks observed by several robots are replicated and kept identical.
 
-    phase 0 (local)   relinearise, linearise, per-landmark partial sums  H_ll^(r), g_l^(r)
-    all-reduce(sum)   54 doubles per shared landmark                         [RCCL over xGMI]
-    phase 1 (local)   invert the GLOBAL H_ll, Schur-reduce, factor and solve the robot's own pose system,
-                      t_l^(r) = sum_f E_f^T delta_p
-    all-reduce(sum)   9 doubles per shared landmark
-    phase 2 (local)   landmark back-substitution with the global t_l, retract
+A pass = one joint Gauss-Newton iteration.  Three variants, selected on the PassDriver:
 
-i.e. block-Jacobi over robots on the reduced pose system with the exact gradient; its fixed point is the joint
-optimum the reference's replica converges to.
+  exact joint step (arrow=True, the default of bench.py)
+      The shared landmarks are NOT eliminated into the robots' pose systems: they are the separator of the joint graph.  Every robot
+      eliminates its private landmarks and its poses (banded Cholesky with the separator's coupling rows as a border), forms its Schur
+      complement onto the separator with one FP64-MFMA product; ONE all-reduce(sum) of the packed separator system per pass; every rank
+      factors it and substitutes back.  This is exactly the step the reference's replica takes with one solve().  Inter-robot
+      relative-pose factors (addRelativeMeasFactor, graph.cpp:247-258) ride along exactly as six further separator coordinates each
+      (setup_ghosts).
+  PCG (pcg_iters > 0)
+      phase 0 | AR 54/slot | phase 1 (global H_ll, Schur, factor own block) | { AR 9/slot | matvec | AR 2 | update } x iterations |
+      AR 9/slot | phase 2: preconditioned conjugate gradients on the global reduced pose system with the robots' own factors as
+      preconditioner; inexact (C3 needs ~200 iterations per pass for 1e-8), kept for comparison; pcg_tol ends it on the residual.
+  block-Jacobi (neither)
+      every robot solves its own block with the global landmark blocks; stalls once robots share many landmarks.
 
-Inter-robot relative-pose factors (addRelativeMeasFactor, graph.cpp:247-258) couple poses of two ranks: each of the two
-ranks holds the factor with its own pose as the variable and the other pose as a *ghost* — a constant refreshed at the
-start of every pass (phase 20: pack the owned ghost poses' estimates, all-reduce(sum) of 12 doubles per ghost slot,
-phase 21: adopt).  Same block-Jacobi argument: the cross block J_a^T J_b is dropped from the step, the gradient is exact.
-
-`shard` is any object with ``landmark_table(cls)``, ``graph.set_shared``, ``graph.dist_phase`` — the product's
-``SlideBackend`` on a GPU, or (tests only) the oracle wrapper; `comm` moves the exchange buffer.
+`shard` is any object with ``landmark_table(cls)``, ``graph.set_shared``, ``graph.dist_phase`` — the product's ``SlideBackend`` on a
+GPU, or (tests only) the oracle wrapper, which restates every variant on the CPU; `comm` moves the exchange buffer.
+`DistributedGraph` / `ThreadGroup` are the round-1 drivers (one thread per robot), kept with their tests.
 """
 from __future__ import annotations
 
