@@ -86,7 +86,12 @@ def main_driver(R):
     backend, preset, iters, out_path = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     import torch
     import torch.distributed as dist
-    dist.init_process_group(backend="gloo")
+    nccl = os.environ.get("SLIDE_TEST_NCCL") == "1"      # one GPU per rank, RCCL (a node with >= world GPUs); else gloo, every rank on GPU 0
+    if nccl:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     from slide_slam_amd.distributed import PassDriver, TorchComm, setup_local_shards
     from slide_slam_amd.replay import replay_single
@@ -101,10 +106,12 @@ def main_driver(R):
         base, device, batch, matcher = TorchComm(device=None), None, None, oracle_matcher
     else:
         import slide_slam_amd as s
-        torch.cuda.set_device(0)
-        device = torch.device("cuda", 0)
+        dev_index = torch.cuda.current_device() if nccl else 0
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
+        torch.zeros(1, device=device)
         shards = [s.SlideBackend(s.default_params(), 1) for _ in range(R)]
-        base, matcher = TorchComm(device=device, stage_through_host=True), gpu_matcher
+        base, matcher = TorchComm(device=device, stage_through_host=not nccl), gpu_matcher
         batch = s.CholBatch(R)
     for sh, lg in zip(shards, logs):
         replay_single(sh, lg, robot=0, collect=False)

@@ -148,6 +148,28 @@ def test_exact_joint_step_two_ranks_equal_one_process(gpu, tmp_path):
         assert np.abs(z["poses"] - one).max() < tol * np.abs(one).max(), preset
 
 
+def test_exact_joint_step_two_ranks_rccl(gpu, tmp_path):
+    """the multi-GPU path with MORE THAN ONE RCCL rank — configs[2] as two ranks on two GPUs (one robot each), the pass cut
+    at its exchange, the all-reduce of the packed separator system over RCCL, host-synchronous AND stream-ordered on the pass's stream —
+    against one process holding both robots.  Needs a node with two visible GPUs (skipped on the one-GPU box)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    from test_distributed import _run_workers
+    out = str(tmp_path / "c3_one.json")
+    _scenario("c3_converge", out, "C3", 3, 3, 0, 0, 1)
+    one = np.array(json.load(open(out))["final"])
+    for ordered in ("0", "1"):
+        os.environ["SLIDE_TEST_NCCL"] = "1"
+        os.environ["SLIDE_STREAM_ORDERED"] = ordered
+        try:
+            z = _run_workers("gpu", "C3", 3, str(tmp_path / f"c3_rccl{ordered}.npz"), world=2, extra=("driver=1", "arrow"))
+        finally:
+            os.environ.pop("SLIDE_TEST_NCCL", None)
+            os.environ.pop("SLIDE_STREAM_ORDERED", None)
+        assert np.abs(z["poses"] - one).max() < 1e-9 * np.abs(one).max(), ordered
+
+
 def test_c3_full_size_two_ranks_equal_one_process(gpu, tmp_path):
     """The same job as two ranks (one robot each, two processes on the one visible GPU, the pass cut at its exchanges, gloo staged
     through the host standing in for RCCL) gives what one process with both robots gives: same slots, poses to 1e-9."""

@@ -37,7 +37,7 @@ for tag, fs, ws, stats in (("bench", "pmc_f", "pmc_w", st), ("assoc", "apmc_f", 
         lines.append(f"{tag:6s} {k[:48]:48s} dispatches {max(nf, nw):6d}  FETCH_SIZE {sf / max(nf, 1):12.1f} KiB/dispatch (x2 on gfx950)  "
                      f"WRITE_SIZE {sw / max(nw, 1):12.1f} KiB/dispatch")
         short = k.split("::")[-1]
-        if short in ("k_chol_step_batched", "k_assoc_sweep", "k_pcg_symv", "k_pcg_tl_symv", "k_schur_b"):
+        if short in ("k_chol_step_batched", "k_assoc_sweep", "k_pcg_symv", "k_pcg_tl_symv", "k_schur_b", "k_border_syrk", "k_chol_step", "k_sep_gather"):
             # full-size dispatches only: the streaming build also launches these kernels on growing systems
             fetch_kib, write_kib = sf / max(nf, 1), sw / max(nw, 1)
             js = {"kernel": short, "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_round.sh {rnd}); "
@@ -48,7 +48,8 @@ for tag, fs, ws, stats in (("bench", "pmc_f", "pmc_w", st), ("assoc", "apmc_f", 
                   "hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0}
             if short in stats:
                 js["rocprof_calls"], js["rocprof_avg_ns"] = stats[short]
-            js["profile"] = "dense" if "--dense-profile" in os.environ.get("BENCH_ARGS", "") else "structure"      # which tiles the solver touched
+            js["profile"] = ("dense" if "--dense-profile" in os.environ.get("BENCH_ARGS", "") else
+                             "structure" if "--joint" in os.environ.get("BENCH_ARGS", "") else "exact_joint")      # which tiles the solver touched / which pass
             if short == "k_chol_step_batched":
                 js["robots"] = 8      # systems per launch: two launch sequences of four on a wide (dense) profile, one sequence per system on a narrow one
             json.dump(js, open(os.path.join(prof, f"{rnd}_pmc_traffic_{short}.json"), "w"), indent=1)
