@@ -61,6 +61,8 @@ class SynthConfig:
         if name == "C3":       # configs[2]: 2 robots, 30 % shared landmarks
             return SynthConfig(name="C3", robots=2, poses_per_robot=500, landmarks=1700, grid=(1, 2), cell=102.0,
                                overlap=18.0, **MULTI_ROBOT_NOISE)
+        if name == "C3spec":   # C3 with the noise SURVEY 8d writes down (the yaml's noise-model sigmas used as noise): 20 x / 10 x the above
+            return SynthConfig(name="C3spec", robots=2, poses_per_robot=500, landmarks=1700, grid=(1, 2), cell=102.0, overlap=18.0)
         if name == "C3tiny":
             return SynthConfig(name="C3tiny", robots=2, poses_per_robot=40, landmarks=110, grid=(1, 2), cell=34.0,
                                overlap=8.0)
