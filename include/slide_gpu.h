@@ -221,6 +221,15 @@ int slide_graph_get_pcg_stats(slide_graph_t* g, double out8[8]);
  * merged first.  slide_graph_set_dense_profile(g, 1) makes the solver ignore the structure (every tile of the lower triangle: the
  * GEMM-shaped extreme, a measurement aid); results are the same either way. */
 int slide_graph_get_tile_profile(slide_graph_t* g, int* prof, int cap);
+/* Incremental re-factorisation of slide_graph_solve (ISAM2::update re-eliminates only the part of the Bayes tree the new factors and the
+ * relinearised variables touch, graph.cpp:260-272; here: the block columns of the banded reduced system from the first dirty one on —
+ * the columns before it keep the factor of the last solve, the re-assembled trailing tiles catch up with their panels in one product,
+ * the step kernels run on the trailing sub-matrix).  out4 = {updates that re-factored a suffix only, updates that re-factored
+ * everything, first re-factored block column of the last update, block columns}.  slide_graph_set_incremental(g, 0) (or
+ * SLIDE_NO_INCREMENTAL=1 for the whole process) re-factors everything at every update: the same result up to the summation order of
+ * the kept columns' panels. */
+int slide_graph_get_incremental_stats(slide_graph_t* g, int64_t out4[4]);
+int slide_graph_set_incremental(slide_graph_t* g, int on);
 int slide_graph_set_dense_profile(slide_graph_t* g, int on);
 /* Exact joint step: the border of this graph's reduced system — returns the number of border row tiles (64 separator coordinates each;
  * 0 when the graph's batch does not run exact joint passes) and writes first[i] = the first block column of the band in which border

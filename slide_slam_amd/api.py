@@ -28,7 +28,7 @@ EXPORTS = [
     "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
     "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
-    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_chol_batch_set_pcg_tolerance", "slide_graph_set_pcg_tolerance", "slide_graph_set_separator", "slide_chol_batch_set_exact_joint", "slide_chol_batch_sep_buffer_len", "slide_chol_batch_profile_exact_joint", "slide_graph_get_border_profile", "slide_graph_set_ghost_ids", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
+    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_chol_batch_set_pcg_tolerance", "slide_graph_set_pcg_tolerance", "slide_graph_set_separator", "slide_chol_batch_set_exact_joint", "slide_chol_batch_sep_buffer_len", "slide_chol_batch_profile_exact_joint", "slide_graph_get_border_profile", "slide_graph_get_incremental_stats", "slide_graph_set_incremental", "slide_graph_set_ghost_ids", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
     "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
     "slide_dense_spd_solve", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device", "slide_assoc_sweep_batch",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
@@ -282,6 +282,16 @@ class SlideGraph:
         if T < 0:
             _check(T)
         return out[:T]
+
+    def set_incremental(self, on=True):
+        """False: every update re-factors all block columns (the reference behaviour of round 2; same result to rounding)."""
+        _check(self.L.slide_graph_set_incremental(self.h, C.c_int(int(on))))
+
+    def incremental_stats(self):
+        """Updates that re-factored a suffix of the block columns only / everything, first re-factored column of the last, block columns."""
+        out = np.zeros(4, np.int64)
+        _check(self.L.slide_graph_get_incremental_stats(self.h, _p(out)))
+        return dict(incremental=int(out[0]), full=int(out[1]), last_first_column=int(out[2]), block_columns=int(out[3]))
 
     def border_profile(self):
         """Exact joint step: first[i] = first block column of the band in which border tile row i can be non-zero (len = border row tiles)."""

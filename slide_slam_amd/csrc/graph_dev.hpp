@@ -104,7 +104,12 @@ struct GraphDev {
   const int* gh_bord; // n_ghost  border offset of a ghost (inter-robot relative-pose) factor's six "lambda" coordinates, or null: the
                       // factor then enters H_pp / g_p with the other pose frozen (block-Jacobi); non-null (exact joint step): it
                       // enters through the border only — rows J (its Jacobian w.r.t. the own pose), the first-key side adds -I and -r
-  int* status;       // [0] not-SPD flag (landmark), [1] not-SPD flag (chol), [2] #relinearised
+  // ---- incremental re-factorisation of the streaming path (HostGraph::run_update) --------------------------------------------------
+  const int* lm_first; // L   the first (lowest-index) pose observing a landmark: k_relin reports, in status[6], P - (the lowest pose whose
+                       //     rows of the reduced system a relinearisation changes) — 0: nothing was relinearised
+  int col0;            // columns of S below it hold the factor of the last solve and are left alone by the assembly (k_schur, k_pad_rhs);
+                       // their right-hand-side entries are the forward-substituted ones of that solve (yv).  0: assemble everything.
+  int* status;       // [0] not-SPD flag (landmark), [1] not-SPD flag (chol), [2] #relinearised, [6] see lm_first
   // ---- parameters ------------------------------------------------------------------------
   int chart;
   double relin_thr;

@@ -294,6 +294,7 @@ int HostGraph::merge_pending() {
     } else {
       if (key2lm.count(v.key)) { refuse("value inserted twice:", v.key); continue; }
       key2lm[v.key] = (int)h_lm_type.size();
+      h_lm_first.push_back(1 << 30);
       h_lm_type.push_back(v.type);
       h_lm_val.insert(h_lm_val.end(), v.val, v.val + 15);
       lm_fids.emplace_back();
@@ -303,6 +304,7 @@ int HostGraph::merge_pending() {
   for (const PendFac& f : pend_facs) {
     auto a = key2pose.find(f.k0);
     if (a == key2pose.end()) { refuse("factor on a pose that is not in the graph:", f.k0); continue; }
+    dirty_min_pose = std::min(dirty_min_pose, a->second);
     if (f.type == 0) {
       h_pr_pose.push_back(a->second);
       h_pr_z.insert(h_pr_z.end(), f.z, f.z + 12);
@@ -317,6 +319,7 @@ int HostGraph::merge_pending() {
       auto b = key2pose.find(f.k1);
       if (b == key2pose.end()) { refuse("factor on a pose that is not in the graph:", f.k1); continue; }
       const int bi = (int)h_bt_i.size();
+      dirty_min_pose = std::min(dirty_min_pose, b->second);
       h_bt_i.push_back(a->second);
       h_bt_j.push_back(b->second);
       h_bt_z.insert(h_bt_z.end(), f.z, f.z + 12);
@@ -327,6 +330,9 @@ int HostGraph::merge_pending() {
       auto b = key2lm.find(f.k1);
       if (b == key2lm.end()) { refuse("factor on a landmark that is not in the graph:", f.k1); continue; }
       const int fid = (int)h_lf_type.size();
+      // a new factor changes the landmark's H_ll, which enters the Schur terms of EVERY pose observing it
+      dirty_min_pose = std::min(dirty_min_pose, h_lm_first[b->second]);
+      h_lm_first[b->second] = std::min(h_lm_first[b->second], a->second);
       h_lf_type.push_back(f.type);
       h_lf_pose.push_back(a->second);
       h_lf_lm.push_back(b->second);
@@ -393,6 +399,7 @@ void HostGraph::join_batch(CholBatch* b, int slot) {
     old = batch;
     batch = b;
     batch_slot = slot;
+    factor_valid = false;   // (batched passes factor into the same S: a factor left by one is not the streaming path's)
     topo_dirty = true;      // (the joint-solve buffers depend on the batch's setting: upload_new looks again)
   }
   if (old && old != b) old->detach(this);
@@ -1254,6 +1261,8 @@ int HostGraph::upload_new() {
     return SLIDE_ERR_CAPACITY;
   }
   if (up_csr(d_pose_bt_ptr, d_pose_bt, pose_bt, ptr, val, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_lm_first.ensure(std::max<size_t>(Ln, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_lm_first.upload(h_lm_first.data(), 0, Ln, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (ub.flush(s) != SLIDE_OK) return SLIDE_ERR_HIP;   // (the host temporaries were copied into the pinned staging buffer)
   // exact joint step: this robot's border = its shared landmarks and the lambda coordinates of its relative-pose factors
   const bool arrow_now = arrow_on();
@@ -1329,6 +1338,7 @@ int HostGraph::upload_new() {
     }
     nbr_alloc = nbr_new;
     arrow_T = T;
+    ++S_gen;                 // (a resident factor does not survive the re-allocation)
     const size_t ld = (size_t)(Tcap + nbr_alloc + 1) * NB;      // band rows, border rows (exact joint step), the right-hand-side tile row
     // S is rewritten by every Schur pass, so nothing is carried over; zero once so the never-written
     // strict upper tiles and the idle rows of the RHS tile hold finite values.
@@ -1389,16 +1399,18 @@ int HostGraph::upload_new() {
       for (int c = 0; !shrink && c < std::min(T, Told); ++c) shrink = prof[c] < h_prof[c];
       const size_t ld = (size_t)(Tcap + nbr_alloc + 1) * NB;
       if (!fresh_S && d_S.d) {
+        if (shrink) ++S_gen;
         if (shrink) SL_HIP(hipMemsetAsync(d_S.d, 0, ld * (size_t)std::max(T, Told) * NB * sizeof(double), s));
         else if (T > Told && Told > 0)      // (a graph with a border is re-allocated whenever T changes: fresh_S)
           SL_HIP(hipMemset2DAsync(d_S.d + (size_t)Told * NB, ld * sizeof(double), 0, sizeof(double), (size_t)Told * NB, s));
       }
       h_prof = prof;
       h_first = first;
-      if (d_prof.ensure(std::max<size_t>(T, 1), 0, s) != SLIDE_OK || d_first.ensure(std::max<size_t>(T, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+      h_first.push_back(0);      // (one more entry: the right-hand-side row reaches every column — the catch-up product of an incremental update)
+      if (d_prof.ensure(std::max<size_t>(T, 1), 0, s) != SLIDE_OK || d_first.ensure(std::max<size_t>(T + 1, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
       if (T) {
         SL_HIP(hipMemcpyAsync(d_prof.d, h_prof.data(), T * sizeof(int), hipMemcpyHostToDevice, s));
-        SL_HIP(hipMemcpyAsync(d_first.d, h_first.data(), T * sizeof(int), hipMemcpyHostToDevice, s));
+        SL_HIP(hipMemcpyAsync(d_first.d, h_first.data(), (T + 1) * sizeof(int), hipMemcpyHostToDevice, s));
         SL_HIP(hipStreamSynchronize(s));      // (pageable host vectors: the copies must have left them before they can change again)
       }
       ++prof_ver;
@@ -1442,6 +1454,7 @@ int HostGraph::upload_new() {
   G.ldb = (nbr + 1) * NB;
   G.gh_bord = (arrow_now && lam_total > 0) ? d_gh_bord.d : nullptr;
   G.status = d_status.d;
+  G.lm_first = d_lm_first.d; G.col0 = 0;
   G.chart = P.pose_chart;
   G.bearing_sigma = P.bearing_range_sigma; G.cyl_sigma = P.cylinder_sigma; G.numdiff_delta = P.numdiff_delta;
   launch_pose_adj(G, s);             // the topology changed: rebuild the pose adjacency of the Schur assembly
@@ -1463,21 +1476,39 @@ int HostGraph::sync_lm_slot() {
   return SLIDE_OK;
 }
 
-int HostGraph::enqueue_iteration(bool lookahead) {
+int HostGraph::enqueue_iteration(bool lookahead, bool skip_relin, int c_d) {
   hipStream_t s = stream;
   static const char* kNames[] = {"relin", "linearize", "landmark_reduce", "pose_reduce", "schur_assemble", "chol_step",
-                                 "chol_unused", "chol_extract_y", "chol_bwd", "backsub", "estimate"};
+                                 "chol_catchup", "chol_extract_y", "chol_bwd", "backsub", "estimate"};
   int id[11];
   for (int i = 0; i < 11; ++i) id[i] = prof.id_of(kNames[i]);
 #define STAGE(i, call) do { prof.begin(id[i], s); call; prof.end(s); } while (0)
-  STAGE(0, launch_relin(G, s));
+  if (!skip_relin) STAGE(0, launch_relin(G, s));
   STAGE(1, launch_linearize(G, s));
   STAGE(2, launch_landmark(G, 0, s));
   STAGE(3, launch_pose(G, s));
   STAGE(4, launch_schur(G, s));
   (void)lookahead;
-  for (int k = 0; k < G.T; ++k)
-    STAGE(5, launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, nullptr, h_prof.data(), s));
+  if (c_d > 0 && c_d < G.T) {
+    // Incremental re-factorisation: block columns < c_d keep the factor of the last solve (the assembly left them alone, G.col0).  The
+    // re-assembled trailing tiles (i, j >= c_d) and the right-hand-side row first catch up with those columns' panels,
+    //     S(i, j) -= sum_{k < c_d} L(i, k) L(j, k)^T        (k_border_syrk on the view: "border rows" = tile rows c_d .. T, K = the columns < c_d,
+    //                                                        first[] skips what lies outside the profile),
+    // then the steps run on the trailing sub-matrix as a system of its own (same kernels, shifted base pointers and profile).
+    CholSystem cu{};
+    cu.S = G.S; cu.ld = G.ld; cu.T = c_d; cu.nbr = G.T - c_d; cu.ldb = G.ld;
+    cu.bord = G.S + (size_t)c_d * NB * G.ld + (size_t)c_d * NB; cu.bfirst = G.first + c_d;
+    STAGE(6, launch_border_syrk(&cu, 1, s));
+    std::vector<int> pv(G.T - c_d);
+    for (int c = c_d; c < G.T; ++c) pv[c - c_d] = h_prof[c] - c_d;
+    double* Sv = G.S + (size_t)c_d * NB * G.ld + (size_t)c_d * NB;
+    for (int k = 0; k < G.T - c_d; ++k)
+      STAGE(5, launch_chol_step(Sv, G.ld, k, G.T - c_d, G.Ld + (size_t)(c_d + k) * NB * NB, G.Winv + (size_t)(c_d + k) * 1024, G.status, G.chol_ctr, nullptr,
+                                pv.data(), s));
+  } else if (c_d < G.T) {
+    for (int k = 0; k < G.T; ++k)
+      STAGE(5, launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, nullptr, h_prof.data(), s));
+  }
   STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, G.status, s));
   STAGE(8, launch_chol_solve_bwd(CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, nullptr, h_prof.data(), G.prof, G.first, d_ctab.d}, s));
   STAGE(9, launch_backsub(G, 0, s));
@@ -1518,12 +1549,38 @@ int HostGraph::run_update(double relin_thr, int iterations) {
       else G_cap = G;
     }
   }
-  for (int it = 0; it < iterations; ++it) {
-    if (use_graph) SL_HIP(hipGraphLaunch(gexec, s));
-    else {
-      const int rc = enqueue_iteration(false);
-      if (rc != SLIDE_OK) return rc;
+  // Incremental re-factorisation (the streaming path: one update after a few new factors).  iSAM2 re-eliminates only the part of the
+  // Bayes tree the new factors and the relinearised variables touch (ISAM2::update, graph.cpp:260-272); on the banded reduced system of
+  // a pose chain that is "the block columns from the first dirty one on".  The lowest dirty pose = min(host: poses of the factors
+  // merged since the last solve and every pose observing one of their landmarks; device: the same for the variables k_relin moves,
+  // status[6]) — known only after k_relin, hence one extra (32-byte) read-back before the rest of the update is enqueued.
+  static const bool env_inc = !(getenv("SLIDE_NO_INCREMENTAL") && getenv("SLIDE_NO_INCREMENTAL")[0] == '1');
+  const bool try_inc = env_inc && inc_enabled && iterations == 1 && !use_graph && !batch && !force_dense && factor_valid && fact_gen == S_gen && relin_thr > 0.0 && G.T > 2;
+  if (try_inc) {
+    launch_relin(G, s);
+    int s0[8];
+    SL_HIP(hipMemcpyAsync(s0, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    int pmin = dirty_min_pose;
+    if (s0[6] > 0) pmin = std::min(pmin, G.P - s0[6]);
+    int c_d = pmin >= G.P ? G.T : (6 * std::max(pmin, 0)) / NB;      // (nothing dirty: no step at all, the substitutions are simply repeated)
+    c_d = std::min(c_d, G.T);
+    G.col0 = c_d * NB;
+    const int rc = enqueue_iteration(false, true, c_d);
+    G.col0 = 0;
+    if (rc != SLIDE_OK) return rc;
+    if (c_d > 0) ++n_inc; else ++n_full;
+    last_cd = c_d;
+  } else {
+    for (int it = 0; it < iterations; ++it) {
+      if (use_graph) SL_HIP(hipGraphLaunch(gexec, s));
+      else {
+        const int rc = enqueue_iteration(false);
+        if (rc != SLIDE_OK) return rc;
+      }
     }
+    ++n_full;
+    last_cd = 0;
   }
   int st[8];
   SL_HIP(hipMemcpyAsync(st, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1537,6 +1594,8 @@ int HostGraph::run_update(double relin_thr, int iterations) {
     if (rc != SLIDE_OK) return rc;
   }
   factor_valid = true;
+  fact_gen = S_gen;
+  dirty_min_pose = 1 << 30;
   return SLIDE_OK;
 }
 
@@ -1702,6 +1761,7 @@ int HostGraph::launch_phase(int phase, double* d_buf) {
 
 int HostGraph::dist_phase(int phase, double* d_buf) {
   hipStream_t s = stream;
+  factor_valid = false;      // (the phases move linearisation points and factor into S on their own schedule)
   if (phase >= 0 && phase <= 2) {
     if (phase == 0) {
       int rc = merge_pending();

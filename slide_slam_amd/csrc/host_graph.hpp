@@ -276,6 +276,8 @@ class HostGraph {
   void stats(int64_t* out5) const;
   int64_t rejected() const;
   int chi2(double* out4);                 // sum of squared whitened residuals at the current estimate: total, priors, betweens, landmark factors
+  void set_incremental(bool on) { inc_enabled = on; }
+  void incremental_stats(int64_t* out4) const { out4[0] = n_inc; out4[1] = n_full; out4[2] = last_cd; out4[3] = G.T; }
   int get_tile_profile(int* out, int cap);
   int get_border_profile(int* out, int cap);   // nbr (>= 0) or a negative error; out[i] = first block column of border tile row i, i < min(nbr, cap)     // T (>= 0) or a negative error; out[c] = prof[c] for c < min(T, cap)
   void set_dense_profile(bool on);        // ignore the structure of the reduced system (measurement aid)
@@ -297,7 +299,15 @@ class HostGraph {
   int64_t n_rejected = 0;                 // factors / variables refused by merge_pending since creation (slide_graph_stats)
   int upload_new();
   int run_update(double relin_thr, int iterations);
-  int enqueue_iteration(bool lookahead);      // one GN / iSAM2-equivalent pass on `stream` (+ stream2)
+  int enqueue_iteration(bool lookahead, bool skip_relin = false, int c_d = 0);      // one GN / iSAM2-equivalent pass on `stream`; c_d > 0: block columns below it keep their factor
+  // Incremental re-factorisation (iSAM2's "re-eliminate only the affected top of the tree", graph.cpp:260-272): the lowest pose whose
+  // rows of the reduced system the factors merged since the last solve change; the generation of S the resident factor belongs to
+  int dirty_min_pose = 1 << 30;
+  std::vector<int> h_lm_first;          // per landmark: lowest pose index observing it
+  DevArr<int> d_lm_first;
+  unsigned long long S_gen = 0, fact_gen = ~0ull;
+  int64_t n_inc = 0, n_full = 0, last_cd = 0;
+  bool inc_enabled = true;
 
   std::vector<PendVar> pend_vars;
   std::vector<PendFac> pend_facs;

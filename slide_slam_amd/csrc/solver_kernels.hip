@@ -32,6 +32,22 @@ __device__ inline void lm_retract(int type, const double* in, const double* d, i
   }
 }
 
+// The lowest pose whose blocks of the reduced system change when variable (pose p | landmark l) moves its linearisation point: the
+// pose itself, its relative-pose partners, every pose that observes one of its landmarks (a landmark's H_ll enters the Schur terms of
+// all its observers) — reported as the maximum of P - pose in status[6] (incremental re-factorisation, HostGraph::run_update).
+__device__ __forceinline__ void mark_dirty_pose(const GraphDev& G, int p) {
+  if (!G.lm_first) return;
+  int cand = p;
+  for (int q = G.pose_bt_ptr[p]; q < G.pose_bt_ptr[p + 1]; ++q) {
+    const int ent = G.pose_bt[q], b = ent >> 1;
+    cand = min(cand, (ent & 1) ? G.bt_i[b] : G.bt_j[b]);
+  }
+  for (int q = G.pose_ptr[p]; q < G.pose_ptr[p + 1]; ++q) cand = min(cand, G.lm_first[G.pose_lms[q]]);
+  atomicMax(&G.status[6], G.P - cand);
+}
+__device__ __forceinline__ void mark_dirty_lm(const GraphDev& G, int l) {
+  if (G.lm_first) atomicMax(&G.status[6], G.P - min(G.lm_first[l], G.P - 1));
+}
 // [GTSAM ISAM2 relinearisation] theta <- theta (+) delta where |delta|_inf >= threshold.
 // Every private array below is indexed by fully unrolled loops only, so the kernel needs no scratch.
 __device__ __forceinline__ void k_relin_body(const GraphDev& G) {
@@ -48,6 +64,7 @@ __device__ __forceinline__ void k_relin_body(const GraphDev& G) {
 #pragma unroll
       for (int k = 0; k < 12; ++k) v[k] = o[k];
       atomicAdd(&G.status[2], 1);
+      mark_dirty_pose(G, t);
     }
   } else if (t < G.P + G.L) {
     const int l = t - G.P;
@@ -59,6 +76,7 @@ __device__ __forceinline__ void k_relin_body(const GraphDev& G) {
       if (fmax(fmax(fabs(d0), fabs(d1)), fabs(d2)) >= G.relin_thr) {
         v[0] += d0; v[1] += d1; v[2] += d2;
         atomicAdd(&G.status[2], 1);
+        mark_dirty_lm(G, l);
       }
     } else if (type == VT_CUBE) {
       double d[9];
@@ -72,6 +90,7 @@ __device__ __forceinline__ void k_relin_body(const GraphDev& G) {
         for (int k = 0; k < 12; ++k) v[k] = o[k];
         v[12] += d[6]; v[13] += d[7]; v[14] += d[8];
         atomicAdd(&G.status[2], 1);
+        mark_dirty_lm(G, l);
       }
     } else {
       double d[7];
@@ -83,6 +102,7 @@ __device__ __forceinline__ void k_relin_body(const GraphDev& G) {
         v[0] += d[3]; v[1] += d[4]; v[2] += d[5];
         v[6] += d[6];
         atomicAdd(&G.status[2], 1);
+        mark_dirty_lm(G, l);
       }
     }
   }
@@ -643,6 +663,7 @@ __device__ __forceinline__ void k_schur_body(const GraphDev& G) {
   __shared__ int pj_lm[SCHUR_PJ_CAP];
   const int pj = blockIdx.x;
   if (pj >= G.P) return;            // (a batched launch covers the largest graph)
+  if (6 * pj + 5 < G.col0) return;  // incremental re-factorisation: this pose's columns hold the factor of the last solve
   const int tid = threadIdx.x;
   // dynamic LDS: landmark -> first entry of pose j's list (shorts), then the bitmap of the poses >= j that share a landmark or a
   // relative-pose factor with pose j — only those blocks of the strip are non-zero, all others are written as zeros unseen
@@ -676,7 +697,7 @@ __device__ __forceinline__ void k_schur_body(const GraphDev& G) {
     if (m == 0u) {
       for (int e = tid; e < 6 * 192; e += 256) {
         const int c = e / 192, r = e % 192;
-        if (r < nval) {
+        if (r < nval && 6 * pj + c >= G.col0) {
           Sb[(size_t)c * G.ld + r] = 0.0;
           if (G.save_S0) S0b[(size_t)c * G.ld + r] = 0.0;
         }
@@ -787,7 +808,7 @@ __device__ __forceinline__ void k_schur_body(const GraphDev& G) {
   __syncthreads();
   for (int e = tid; e < 6 * 192; e += 256) {
     const int c = e / 192, r = e % 192;
-    if (r < nval) {
+    if (r < nval && 6 * pj + c >= G.col0) {      // (a pose straddling the first dirty tile column: only its columns inside it)
       Sb[(size_t)c * G.ld + r] = schur_tile[c][r];
       if (G.save_S0) S0b[(size_t)c * G.ld + r] = schur_tile[c][r];
     }
@@ -884,14 +905,15 @@ __device__ __forceinline__ void k_pad_rhs_body(const GraphDev& G) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < NT) {
     const int c = (int)t;
-    G.S[(size_t)c * G.ld + NT + (size_t)G.nbr * NB] = (c < n) ? -G.pose_g[c] : 0.0;      // (the right-hand-side row lies below the border rows)
+    // (the right-hand-side row lies below the border rows; columns left of col0 keep the forward-substituted entries of the last solve)
+    G.S[(size_t)c * G.ld + NT + (size_t)G.nbr * NB] = c < G.col0 ? G.yv[c] : ((c < n) ? -G.pose_g[c] : 0.0);
     return;                               // (the right-hand-side row is not part of S0: the joint solve takes b from pose_g)
   }
   const long long u = t - NT;
   const int npad = NT - n;
   if (u >= (long long)npad * NT) return;
   const int r = n + (int)(u / NT), c = (int)(u % NT);
-  if (c > r) return;
+  if (c > r || c < G.col0) return;
   if (G.first && c < G.first[G.T - 1] * NB) return;      // left of the profile: zero already
   G.S[(size_t)c * G.ld + r] = (c == r) ? 1.0 : 0.0;
   if (G.save_S0) G.S0[(size_t)c * G.ld + r] = (c == r) ? 1.0 : 0.0;
