@@ -18,3 +18,4 @@ det = frame_detections(log, 624)
 st = g.stats(); print(st)
 for _ in range(3): g.gauss_newton(1)
 print({k: round(v["ms"]/3,4) for k,v in g.get_profile().items()})
+print("incremental:", g.incremental_stats())
