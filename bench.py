@@ -187,8 +187,8 @@ def cpu_exact_joint_leg(s, logs, frames, passes=3, relmeas=None):
         a.graph.join_chol_batch(batch, t)
     bufA, infoA = setup_local_shards(A, gpu_matcher, device=dev)
     bufO, infoO = setup_local_shards(O, oracle_matcher)
-    dA = PassDriver(A, bufA, infoA["n_slots"], batch=batch, device=dev, arrow=True, sep_dim=infoA["sep_dim"])
-    dO = PassDriver(O, bufO, infoO["n_slots"], arrow=True, sep_dim=infoO["sep_dim"])
+    dA = PassDriver(A, bufA, infoA["n_slots"], batch=batch, device=dev, arrow=True, sep_dim=infoA["sep_dim"], sep_prof=infoA.get("sep_prof"))
+    dO = PassDriver(O, bufO, infoO["n_slots"], arrow=True, sep_dim=infoO["sep_dim"], sep_prof=infoO.get("sep_prof"))
     if relmeas:
         dA.setup_ghosts(relmeas)
         dO.setup_ghosts(relmeas)
@@ -393,7 +393,7 @@ def main():
             gb.graph.join_chol_batch(batch, t)
         bufs, info = setup_local_shards(shards, gpu_matcher, base=base, rank=rank, world=wdev, device=device)
         drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, base=base, world=wdev, device=device,
-                         pcg_iters=args.pcg if args.joint == "pcg" else 0, pcg_tol=args.pcg_tol, arrow=args.joint == "exact", sep_dim=info["sep_dim"])
+                         pcg_iters=args.pcg if args.joint == "pcg" else 0, pcg_tol=args.pcg_tol, arrow=args.joint == "exact", sep_dim=info["sep_dim"], sep_prof=info.get("sep_prof"))
         info["relmeas"] = "none"
         if not args.no_relmeas and robots == cfg.robots and args.frames is None:
             from slide_slam_amd.synth import make_relmeas

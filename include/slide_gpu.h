@@ -191,8 +191,9 @@ int slide_graph_set_pcg_tolerance(slide_graph_t* g, double tol);
  * and forms its Schur complement onto the separator with one FP64-MFMA product; the sum over the robots — ONE all-reduce(sum) of the
  * separator buffer per pass for a job that spans GPUs — is the Schur complement of the JOINT graph onto the shared landmarks; every rank
  * factors it (dense, the same step kernels), substitutes back through its bands and retracts.
- *   slide_graph_set_separator: off[i] = offset of shared slot i's tangent coordinates (cylinder 7, cube 9, point 3, in slot order) in
- *     the separator system, n = n_slots + 1 entries, identical on every rank; after slide_graph_set_shared.
+ *   slide_graph_set_separator: off[i] = offset of shared slot i's tangent coordinates (cylinder 7, cube 9, point 3) in the separator
+ *     system — any non-overlapping layout —, off[n_slots] = its dimension; n = n_slots + 1 entries, identical on every rank; after
+ *     slide_graph_set_shared.
  *   slide_chol_batch_set_exact_joint(b, 1, sep_buf, len): passes of the batch take the exact joint step (batched passes only; the PCG
  *     setting is ignored).  sep_buf: the caller's device buffer of slide_chol_batch_sep_buffer_len(m) doubles, m = off[n_slots], in which
  *     part 0 of a cut pass leaves this GPU's partial sum of the separator system (packed: the lower tile columns only) and from which
@@ -203,6 +204,11 @@ int slide_graph_set_pcg_tolerance(slide_graph_t* g, double tol);
  * must hold 12 doubles per ghost slot).  The cross block of such a factor is left out of the step (gradient exact). */
 int slide_graph_set_separator(slide_graph_t* g, const int32_t* off, int n);
 int slide_chol_batch_set_exact_joint(slide_chol_batch_t* b, int on, double* sep_buf, long long len);
+/* Tile-level profile of the separator system (64-coordinate tiles, landmark part): prof[c] = last tile row of tile column c that can be
+ * non-zero, monotone, c <= prof[c] < n.  Two shared landmarks couple there only if some robot observes both, so with the slots'
+ * coordinates laid out along the robots' adjacency (slide_graph_set_separator takes any layout) the system is block-banded; the caller
+ * knows every robot's observer set (the cross-robot association), the batch only its own robots'.  Not set: dense. */
+int slide_chol_batch_set_separator_profile(slide_chol_batch_t* b, const int32_t* prof, int n);
 long long slide_chol_batch_sep_buffer_len(int m, int n_relmeas);
 /* Inter-robot relative-pose factors in an exact joint pass: the factor between pose a of robot A and pose b of robot B is the rank-6
  * term U U^T, U = [J_a^T; J_b^T], of the joint normal equations; it is carried as six further separator coordinates "lambda" (the

@@ -618,7 +618,7 @@ class Graph {
   // the sum over the robots is the Schur complement of the JOINT graph onto the shared landmarks, so solving it and substituting
   // back gives exactly the Gauss-Newton step of the full replica the reference solves (graph.cpp:260-272 on a graph holding every
   // robot, sloamNode.cpp:912-1002).  sep_off[slot] = offset of the slot's tangent coordinates in the separator (global, every rank
-  // the same; sep_off[nslots] = its dimension m).
+  // the same; sep_off[nslots] = its dimension m; the slots may be laid out in any order).
   std::vector<int> sep_off;
   struct ArrowState {
     std::vector<double> L, W, yp;     // factor of A_a (row-major lower, n x n), W = L^-1 B_a (n x ma, row-major), y_p = L^-1 b_p

@@ -522,8 +522,17 @@ void CholBatch::free_separator() {
   if (sepS) (void)hipFree(sepS);
   sepS = nullptr; sep_len = 0;
   for (double** p : {&sep_Ld, &sep_Winv, &sep_yv, &sep_dp, &sep_bord, &lamS, &lam_Ld, &lam_Winv, &lam_yv, &lam_dp, &lam_scratch}) if (*p) { (void)hipFree(*p); *p = nullptr; }
-  for (int** p : {&sep_status, &sep_ctr, &d_sep_off, &lam_status, &lam_ctr}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  for (int** p : {&sep_status, &sep_ctr, &d_sep_off, &lam_status, &lam_ctr, &d_sep_prof}) if (*p) { (void)hipFree(*p); *p = nullptr; }
   sep_cap = 0; lam_cap = -1;
+}
+int CholBatch::set_separator_profile(const int32_t* prof, int n) {
+  std::lock_guard<std::mutex> pl(pass_mtx);
+  std::lock_guard<std::mutex> lk(mtx);
+  for (int c = 0; c < n; ++c)
+    if (prof[c] < c || prof[c] >= n || (c && prof[c] < prof[c - 1])) { g_last_error = "separator profile: prof[c] must be monotone with c <= prof[c] < n"; return SLIDE_ERR_INVALID; }
+  h_sep_prof.assign(prof, prof + n);
+  pass_dirty = true;
+  return SLIDE_OK;
 }
 int CholBatch::set_arrow(bool on, double* sep_buf, long long len) {
   std::lock_guard<std::mutex> pl(pass_mtx);
@@ -602,6 +611,14 @@ int CholBatch::prepare_separator() {
   // zero once: the strict upper triangle and the idle rows of the right-hand-side tile are never written by the gather
   SL_HIP(hipMemset(sepS, 0, (size_t)need * sizeof(double)));
   if (sep_x) SL_HIP(hipMemset(sep_x, 0, (size_t)sep_buffer_len(sep_m, sep_lam) * sizeof(double)));
+  // tile profile of the landmark part (the caller's, from the robots' observer sets — two shared landmarks couple only if some robot
+  // observes both); absent or of another size: dense
+  if (d_sep_prof) { SL_HIP(hipFree(d_sep_prof)); d_sep_prof = nullptr; }
+  sep_prof_on = (int)h_sep_prof.size() == sep_Ts && sep_Ts > 0;
+  if (sep_prof_on) {
+    SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_prof), (size_t)sep_Ts * sizeof(int)));
+    SL_HIP(hipMemcpy(d_sep_prof, h_sep_prof.data(), (size_t)sep_Ts * sizeof(int), hipMemcpyHostToDevice));
+  }
   if (d_sep_off) { SL_HIP(hipFree(d_sep_off)); d_sep_off = nullptr; }
   SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_off), off.size() * sizeof(int)));
   SL_HIP(hipMemcpy(d_sep_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -660,7 +677,8 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     if (!whole) launch_sep_unpack(Y, master);
     // landmark part of the separator: the dense step kernels, the lambda coordinates' coupling rows riding as ITS border
     for (int k = 0; k < sep_Ts; ++k)
-      launch_chol_step(sepS, ld_s, k, sep_Ts, sep_Ld + (size_t)k * NB * NB, sep_Winv + (size_t)k * 1024, sep_status, sep_ctr, nullptr, nullptr, master, sep_nl);
+      launch_chol_step(sepS, ld_s, k, sep_Ts, sep_Ld + (size_t)k * NB * NB, sep_Winv + (size_t)k * 1024, sep_status, sep_ctr, nullptr,
+                       sep_prof_on ? h_sep_prof.data() : nullptr, master, sep_nl);
     launch_chol_extract_y(sepS, ld_s, sep_Ts, sep_yv, sep_dp, sep_status, master, sep_nl);
     if (sep_nl > 0) {
       // the inter-robot relative-pose factors: K22 - L21 L21^T is negative definite; factor its negative, lambda = -M^-1 (r2 - L21 z1),
@@ -678,7 +696,7 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
       const double* xl = lam_dp;
       launch_border_apply(&ss, 1, &xl, master);
     }
-    launch_chol_bwd_all(sepS, ld_s, sep_Ts, sep_Ld, sep_Winv, sep_yv, sep_dp, sep_status, nullptr, master);
+    launch_chol_bwd_all(sepS, ld_s, sep_Ts, sep_Ld, sep_Winv, sep_yv, sep_dp, sep_status, sep_prof_on ? d_sep_prof : nullptr, master);
     mark(4);
     launch_sep_xloc(n, maps, sep_m, sep_lam, sep_dp, lam_dp, xloc, master);
     launch_border_apply(sys.data(), n, xloc, master);                // y -= W x_s
@@ -1282,8 +1300,8 @@ int HostGraph::upload_new() {
     for (int i = 0; i < ns; ++i) {
       const int lid = h_sh_lid[i];
       if (lid < 0 || (size_t)lid >= Ln) continue;
-      const int dim = h_sep_off[i + 1] - h_sep_off[i];
-      if (dim != lm_dim(h_lm_type[lid])) { g_last_error = "separator offsets do not match the landmark classes of the shared slots"; return SLIDE_ERR_INVALID; }
+      const int dim = lm_dim(h_lm_type[lid]);      // (the slots' coordinates may be laid out in any order: separator_offsets orders them along the robots' adjacency)
+      if (h_sep_off[i] + dim > m) { g_last_error = "separator offsets do not match the landmark classes of the shared slots"; return SLIDE_ERR_INVALID; }
       int fp = 1 << 30;
       for (int f : lm_fids[lid]) fp = std::min(fp, h_lf_pose[f]);
       items.push_back(Item{fp == (1 << 30) ? 0 : 6 * fp / NB, 0, lid, dim, h_sep_off[i]});
@@ -1647,8 +1665,8 @@ int HostGraph::set_ghost_ids(const int32_t* ids, int n, int n_total) {
 }
 int HostGraph::set_separator(const int32_t* off, int n) {
   if (n < 0 || (n > 0 && !off)) return SLIDE_ERR_INVALID;
-  for (int i = 1; i < n; ++i)
-    if (off[i] < off[i - 1]) { g_last_error = "set_separator: offsets must be non-decreasing"; return SLIDE_ERR_INVALID; }
+  for (int i = 0; i + 1 < n; ++i)
+    if (off[i] < 0 || off[i] > off[n - 1]) { g_last_error = "set_separator: an offset lies outside the separator (the last entry is its dimension)"; return SLIDE_ERR_INVALID; }
   h_sep_off.assign(off, off + n);
   topo_dirty = true;
   return SLIDE_OK;

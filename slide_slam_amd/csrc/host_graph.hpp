@@ -163,6 +163,7 @@ class CholBatch {
   // (packed: lower tile columns only) for the cross-GPU all-reduce, and from which part 2 takes the sum; null: no exchange (the job is
   // this process alone).  Changing it invalidates the captured launch sequences.
   int set_arrow(bool on, double* sep_buf, long long sep_len);
+  int set_separator_profile(const int32_t* prof, int n);      // tile profile of the separator system's landmark part (n = its tile columns), or none: dense
   bool is_arrow() const { return arrow; }
   // packed exchange layout of the separator system: ms landmark coordinates + lam lambda coordinates (6 per inter-robot relative-pose factor)
   static long long sep_buffer_len(int ms, int lam = 0) { const long long Tt = (ms + NB - 1) / NB + (lam + NB - 1) / NB; return (long long)NB * NB * Tt * (Tt + 3) / 2; }
@@ -195,6 +196,7 @@ class CholBatch {
   double *sep_Ld = nullptr, *sep_Winv = nullptr, *sep_yv = nullptr, *sep_dp = nullptr;
   int *sep_status = nullptr, *sep_ctr = nullptr, *d_sep_off = nullptr;
   int sep_cap = 0;
+  std::vector<int> h_sep_prof; int* d_sep_prof = nullptr; bool sep_prof_on = false;
   // lambda coordinates of the inter-robot relative-pose factors: border rows of the separator system, their own small system
   int sep_lam = 0, sep_nl = 0, lam_cap = -1;
   double *lam_scratch = nullptr;      // partial products of the separator's own border product (split K)

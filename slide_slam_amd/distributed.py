@@ -106,17 +106,65 @@ def shared_slots(gid, n_global, rank):
 SLOT_DIM = {0: 7, 1: 9, 2: 3}        # tangent dimension per class: cylinder [ray, root, radius], cube [pose, scale], point
 
 
-def separator_offsets(gid, n_global):
-    """Offsets of the shared slots' tangent coordinates in the separator system of the exact joint step (len n_slots + 1, the same
-    on every rank; slot order = shared_slots' order: by class, then by global id)."""
-    off = [0]
+def slot_observers(gid, n_global):
+    """Observer robots of every shared slot, in shared_slots' slot order (by class, then by global id)."""
+    R = len(gid)
+    obs = []
     for cls in range(3):
-        count = np.zeros(n_global[cls], np.int32)
-        for g in gid:
-            count[g[cls]] += 1
-        for _ in np.nonzero(count >= 2)[0]:
-            off.append(off[-1] + SLOT_DIM[cls])
-    return np.array(off, np.int32)
+        who = [[] for _ in range(n_global[cls])]
+        for r in range(R):
+            for g in gid[r][cls]:
+                who[int(g)].append(r)
+        obs += [(cls, tuple(w)) for w in who if len(w) >= 2]
+    return obs
+
+
+def separator_offsets(gid, n_global, tile=64):
+    """Layout of the separator system of the exact joint step, the same on every rank: off[slot] = offset of the slot's tangent
+    coordinates (cylinder 7, cube 9, point 3), off[n_slots] = the dimension m; and prof = its tile-level profile (prof[c] = last tile row
+    of tile column c that can be non-zero).  Two shared landmarks couple in the separator system only if some robot observes both, so
+    the slots are laid out along a Cuthill-McKee order of the robots' adjacency graph (robots adjacent = they share a slot): on a grid of
+    robot cells the system becomes block-banded instead of dense, and the factorisation's first steps stop flooding the chip with
+    structural zeros.  Slot order itself (shared_slots) is unchanged: only the coordinates are permuted."""
+    obs = slot_observers(gid, n_global)
+    R = len(gid)
+    adj = [set() for _ in range(R)]
+    for _, w in obs:
+        for a in w:
+            adj[a].update(x for x in w if x != a)
+    # Cuthill-McKee over the robots (every connected component from its lowest-degree robot, neighbours by increasing degree)
+    pos, order = {}, []
+    for start in sorted(range(R), key=lambda r: (len(adj[r]), r)):
+        if start in pos:
+            continue
+        queue = [start]
+        pos[start] = len(order); order.append(start)
+        while queue:
+            r = queue.pop(0)
+            for x in sorted(adj[r], key=lambda q: (len(adj[q]), q)):
+                if x not in pos:
+                    pos[x] = len(order); order.append(x); queue.append(x)
+    keys = [(min(pos[r] for r in w), max(pos[r] for r in w), i) for i, (_, w) in enumerate(obs)]
+    perm = [k[2] for k in sorted(keys)]
+    off = np.zeros(len(obs) + 1, np.int64)
+    o = 0
+    for i in perm:
+        off[i] = o
+        o += SLOT_DIM[obs[i][0]]
+    off[len(obs)] = o
+    # profile: coordinate g reaches the last coordinate any of its observers observes
+    Ts = (o + tile - 1) // tile
+    last = np.zeros(R, np.int64)
+    for i, (cls, w) in enumerate(obs):
+        for r in w:
+            last[r] = max(last[r], off[i] + SLOT_DIM[cls] - 1)
+    prof = np.arange(Ts, dtype=np.int64)
+    for i, (cls, w) in enumerate(obs):
+        reach = max(last[r] for r in w) // tile
+        for t in range(off[i] // tile, (off[i] + SLOT_DIM[cls] - 1) // tile + 1):
+            prof[t] = max(prof[t], reach)
+    prof = np.maximum.accumulate(prof)
+    return off.astype(np.int32), prof.astype(np.int32)
 
 
 class DistributedGraph:
@@ -195,7 +243,7 @@ def setup_local_shards(shards, matcher, base=None, rank=0, world=1, thresh=(2.0,
     else:
         alloc = lambda n: np.zeros(n)
         handle = lambda b: b
-    sep_off = separator_offsets(gid, n_global)
+    sep_off, sep_prof = separator_offsets(gid, n_global)
     for t, sh in enumerate(shards):
         cls, idx, own = shared_slots(gid, n_global, rank * R + t)
         n_slots = len(cls)
@@ -220,7 +268,7 @@ def setup_local_shards(shards, matcher, base=None, rank=0, world=1, thresh=(2.0,
             torch.cuda.synchronize()
     for t, sh in enumerate(shards):
         sh.graph.dist_phase(11, handle(bufs[t]))
-    return bufs, dict(n_slots=n_slots, n_global=n_global, sep_dim=int(sep_off[-1]), sep_off=sep_off)
+    return bufs, dict(n_slots=n_slots, n_global=n_global, sep_dim=int(sep_off[-1]), sep_off=sep_off, sep_prof=sep_prof)
 
 
 class PassDriver:
@@ -232,7 +280,7 @@ class PassDriver:
     pass).  Without one (oracle shards on the CPU, or un-batched HIP shards): the same sequence spelled out with dist_phase calls
     and host-side sums — the CPU rehearsal of exactly this control flow."""
 
-    def __init__(self, shards, bufs, n_slots, batch=None, base=None, world=1, device=None, pcg_iters=0, pcg_tol=0.0, arrow=False, sep_dim=0):
+    def __init__(self, shards, bufs, n_slots, batch=None, base=None, world=1, device=None, pcg_iters=0, pcg_tol=0.0, arrow=False, sep_dim=0, sep_prof=None):
         self.shards, self.bufs, self.n_slots, self.batch, self.base, self.world, self.device = shards, bufs, n_slots, batch, base, world, device
         self.ptrs = [b.data_ptr() for b in bufs] if device is not None else None
         self.passes = 0
@@ -265,6 +313,8 @@ class PassDriver:
                 raise ValueError("the exact joint step of HIP shards runs as a batched pass: join the shards to a CholBatch")
         if batch is not None:
             batch.set_exact_joint(self.arrow, 0, 0)      # (the exchange buffer of a cut pass is installed on first use: _sep_exchange_buffer)
+            if self.arrow and sep_prof is not None:
+                batch.set_separator_profile(sep_prof)    # (tile profile of the separator system: the same on every rank)
         if batch is not None:           # (always pushed, zero included: a batch or graph may still hold an earlier driver's setting)
             batch.set_pcg(self.pcg_iters, self.pcg_tol)
         else:

@@ -122,7 +122,7 @@ def main_driver(R):
     pcg = int(sys.argv[6].split("=")[1]) if len(sys.argv) > 6 and sys.argv[6].startswith("pcg=") else 0
     arrow = len(sys.argv) > 6 and sys.argv[6] == "arrow"       # the exact joint step: ONE all-reduce (the separator system) per pass
     drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, base=base, world=world, device=device, pcg_iters=pcg, arrow=arrow,
-                     sep_dim=info["sep_dim"])
+                     sep_dim=info["sep_dim"], sep_prof=info.get("sep_prof"))
     drv.gauss_newton(iters)
     P = cfg.poses_per_robot
     mine = [np.array([sh.graph.get_pose12(0, k)[1] for k in range(P)]) for sh in shards]

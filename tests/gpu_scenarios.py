@@ -220,7 +220,7 @@ def c3_converge(out, preset="C3", passes=400, every=20, pcg=0, unbatched=0, arro
         for t, sh in enumerate(shards):
             sh.graph.join_chol_batch(batch, t)
     bufs, info = setup_local_shards(shards, gpu_matcher, device=dev)
-    drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, device=dev, pcg_iters=pcg, arrow=bool(arrow), sep_dim=info["sep_dim"])
+    drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, device=dev, pcg_iters=pcg, arrow=bool(arrow), sep_dim=info["sep_dim"], sep_prof=info.get("sep_prof"))
     nrm = np.linalg.norm(joint.reshape(R, -1), axis=1) if joint is not None else None
     hist = []
     t_pass = 0.0
@@ -384,8 +384,8 @@ def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1, re
         a.graph.join_chol_batch(batch, t)
     bufA, infoA = setup_local_shards(A, gpu_matcher, device=dev)
     bufO, infoO = setup_local_shards(O, oracle_matcher)
-    dA = PassDriver(A, bufA, infoA["n_slots"], batch=batch, device=dev, arrow=True, sep_dim=infoA["sep_dim"])
-    dO = PassDriver(O, bufO, infoO["n_slots"], arrow=True, sep_dim=infoO["sep_dim"])
+    dA = PassDriver(A, bufA, infoA["n_slots"], batch=batch, device=dev, arrow=True, sep_dim=infoA["sep_dim"], sep_prof=infoA.get("sep_prof"))
+    dO = PassDriver(O, bufO, infoO["n_slots"], arrow=True, sep_dim=infoO["sep_dim"], sep_prof=infoO.get("sep_prof"))
     say("associated:", infoA["n_slots"], infoO["n_slots"], "slots, separator", infoA["sep_dim"], infoO["sep_dim"])
     n_g = 0
     if relmeas:

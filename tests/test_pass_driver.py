@@ -101,7 +101,7 @@ def test_exact_joint_step_reaches_the_joint_replica_optimum_in_a_few_passes(pres
     cfg, shards, _ = oracle_shards(preset)
     bufs, info = setup_local_shards(shards, oracle_matcher)
     assert info["n_slots"] > 0 and info["sep_dim"] >= 3 * info["n_slots"]
-    drv = PassDriver(shards, bufs, info["n_slots"], arrow=True, sep_dim=info["sep_dim"])
+    drv = PassDriver(shards, bufs, info["n_slots"], arrow=True, sep_dim=info["sep_dim"], sep_prof=info.get("sep_prof"))
     P, R = cfg.poses_per_robot, cfg.robots
     steps, prev = [], poses_of(shards, P)
     for _ in range(5):
@@ -120,7 +120,7 @@ def test_exact_joint_step_two_processes_two_shards_each_gloo(tmp_path):
     """2 processes x 2 shards over gloo (one all-reduce of the separator system per pass) == four shards in one process."""
     cfg, shards, _ = oracle_shards("C4tiny")
     bufs, info = setup_local_shards(shards, oracle_matcher)
-    PassDriver(shards, bufs, info["n_slots"], arrow=True, sep_dim=info["sep_dim"]).gauss_newton(5)
+    PassDriver(shards, bufs, info["n_slots"], arrow=True, sep_dim=info["sep_dim"], sep_prof=info.get("sep_prof")).gauss_newton(5)
     one = poses_of(shards, cfg.poses_per_robot)
     z = _run_workers("oracle", "C4tiny", 5, str(tmp_path / "a22.npz"), world=2, extra=("driver=2", "arrow"))
     assert int(z["n_slots"]) == info["n_slots"]
@@ -154,7 +154,7 @@ def test_exact_joint_step_with_relative_pose_factors_is_the_joint_replicas_step(
     assert np.abs(joint - plain).max() > 1e-6            # the factors do move the optimum
     cfg, shards, logs = oracle_shards("C3rel")
     bufs, info = setup_local_shards(shards, oracle_matcher)
-    drv = PassDriver(shards, bufs, info["n_slots"], arrow=True, sep_dim=info["sep_dim"])
+    drv = PassDriver(shards, bufs, info["n_slots"], arrow=True, sep_dim=info["sep_dim"], sep_prof=info.get("sep_prof"))
     assert drv.setup_ghosts(make_relmeas(cfg, logs)) > 0
     P, R = cfg.poses_per_robot, cfg.robots
     errs = []

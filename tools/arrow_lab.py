@@ -28,7 +28,7 @@ def main():
         ingest(sh, make_robot_log(cfg, wm, r))
     bufs, info = setup_local_shards(shards, oracle_matcher)
     print("slots", info["n_slots"], "separator dim", info["sep_dim"], flush=True)
-    drv = PassDriver(shards, bufs, info["n_slots"], arrow=True, sep_dim=info["sep_dim"])
+    drv = PassDriver(shards, bufs, info["n_slots"], arrow=True, sep_dim=info["sep_dim"], sep_prof=info.get("sep_prof"))
     if len(sys.argv) > 3 and sys.argv[3] == "relmeas":
         from slide_slam_amd.synth import make_relmeas
         logs = [make_robot_log(cfg, wm, r) for r in range(R)]
