@@ -1067,7 +1067,7 @@ int CholBatch::pass_part(double* const* d_bufs, int part) {
   }
   if (arrow && hG[0].n_slots > 0 && part != 0 && part != 2 && part != 20) return SLIDE_OK;      // exact joint step: one exchange, between parts 0 and 2
   if (arrow && hG[0].n_slots > 0 && !sep_x) { g_last_error = "exact joint step: a cut pass needs the caller's separator exchange buffer (slide_chol_batch_set_exact_joint)"; return SLIDE_ERR_INVALID; }
-  if (part >= 10 && !(pcg_iters > 0 && hG[0].n_slots > 0)) return SLIDE_OK;      // no joint solve: nothing between parts 1 and 2
+  if (part >= 10 && part <= 12 && !(pcg_iters > 0 && hG[0].n_slots > 0)) return SLIDE_OK;      // no joint solve: nothing between parts 1 and 2
   if (!part_exec[slot] && (rc = capture_pass(d_bufs, part, &part_exec[slot])) != SLIDE_OK) return rc;
   SL_HIP(hipGraphLaunch(part_exec[slot], master));
   return part == 2 ? end_pass() : SLIDE_OK;

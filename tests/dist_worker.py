@@ -120,9 +120,13 @@ def main_driver(R):
             sh.graph.join_chol_batch(batch, t)
     bufs, info = setup_local_shards(shards, matcher, base=base, rank=rank, world=world, device=device)
     pcg = int(sys.argv[6].split("=")[1]) if len(sys.argv) > 6 and sys.argv[6].startswith("pcg=") else 0
-    arrow = len(sys.argv) > 6 and sys.argv[6] == "arrow"       # the exact joint step: ONE all-reduce (the separator system) per pass
+    arrow = "arrow" in sys.argv[6:]       # the exact joint step: ONE all-reduce (the separator system) per pass
     drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, base=base, world=world, device=device, pcg_iters=pcg, arrow=arrow,
                      sep_dim=info["sep_dim"], sep_prof=info.get("sep_prof"))
+    if "relmeas" in sys.argv[6:]:     # inter-robot relative-pose factors of the job (every rank regenerates the same seeded list)
+        from slide_slam_amd.synth import make_relmeas
+        all_logs = [make_robot_log(cfg, world_map, r) for r in range(cfg.robots)]
+        assert drv.setup_ghosts(make_relmeas(cfg, all_logs), rank=rank) > 0
     drv.gauss_newton(iters)
     P = cfg.poses_per_robot
     mine = [np.array([sh.graph.get_pose12(0, k)[1] for k in range(P)]) for sh in shards]

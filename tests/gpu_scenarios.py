@@ -413,6 +413,8 @@ def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1, re
         say("pass", p + 1, "GPU vs oracle", res["gpu_vs_oracle"][-1], "step", res["step"][-1], "vs joint", res["vs_joint"][-1:], "ms", res["ms"][-1], "chi2", res["chi2_pass"][-1])
     res["finite"] = bool(np.isfinite(prev).all())
     res["chi2"] = sum(x.graph.chi2()["total"] for x in A)
+    if R * P <= 2000:
+        res["final"] = prev.tolist()
     if counts is not None:
         res["joint_counts"] = [counts["cyl"], counts["cube"], counts["point"]]
     for a in A:

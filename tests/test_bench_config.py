@@ -103,6 +103,12 @@ def test_exact_joint_step_with_relative_pose_factors(gpu, tmp_path):
     assert z["finite"] and z["n_gslots"] > 0 and z["n_slots"][0] == z["n_slots"][1] > 0
     assert max(z["gpu_vs_oracle"]) < 1e-7, z["gpu_vs_oracle"]
     assert z["vs_joint"][0] < 2e-4 and max(z["vs_joint"][2:]) < 5e-6, z["vs_joint"]
+    # and as TWO ranks (one robot each, the pass cut: part 20 | all-reduce of the ghost poses | part 0 | all-reduce of the separator
+    # system incl. the lambda coordinates | part 2): the same poses as the one process above — a cut pass once skipped part 20 silently
+    from test_distributed import _run_workers
+    two = _run_workers("gpu", "C3rel", 6, str(tmp_path / "rel_two.npz"), world=2, extra=("driver=1", "arrow", "relmeas"))
+    one = np.array(z["final"])
+    assert np.abs(two["poses"] - one).max() < 1e-8 * np.abs(one).max()
 
 
 def test_c4_exact_joint_step_matches_oracle_shards_at_size(gpu, tmp_path):
