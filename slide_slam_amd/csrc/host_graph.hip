@@ -1044,6 +1044,7 @@ int CholBatch::pass_all(double* const* d_bufs) {
   if (rc != SLIDE_OK) return rc;
   if (!pass_exec && (rc = capture_pass(d_bufs, -1, &pass_exec)) != SLIDE_OK) return rc;
   SL_HIP(hipGraphLaunch(pass_exec, master));
+  last_part = -1;
   return end_pass();
 }
 
@@ -1057,7 +1058,6 @@ int CholBatch::pass_part(double* const* d_bufs, int part) {
   if (part == 20) {           // (the ghost refresh opens a pass: it brings the graphs up to date like part 0 does; part 0 then finds them unchanged)
     bool same = false;
     if ((rc = begin_pass(d_bufs, &same)) != SLIDE_OK) return rc;
-    if (hG[0].n_gslots <= 0) return SLIDE_OK;
   } else if (part == 0) {
     bool same = false;
     if ((rc = begin_pass(d_bufs, &same)) != SLIDE_OK) return rc;
@@ -1065,11 +1065,32 @@ int CholBatch::pass_part(double* const* d_bufs, int part) {
     g_last_error = "batched pass: part 0 has not run";
     return SLIDE_ERR_INVALID;
   }
-  if (arrow && hG[0].n_slots > 0 && part != 0 && part != 2 && part != 20) return SLIDE_OK;      // exact joint step: one exchange, between parts 0 and 2
-  if (arrow && hG[0].n_slots > 0 && !sep_x) { g_last_error = "exact joint step: a cut pass needs the caller's separator exchange buffer (slide_chol_batch_set_exact_joint)"; return SLIDE_ERR_INVALID; }
-  if (part >= 10 && part <= 12 && !(pcg_iters > 0 && hG[0].n_slots > 0)) return SLIDE_OK;      // no joint solve: nothing between parts 1 and 2
+  // The parts of a cut pass come in ONE order (a part that arrives out of order used to be accepted, or skipped, silently):
+  //   [20] 0 2                                   exact joint step      (20: only with ghost poses, then mandatory)
+  //   [20] 0 1 { 10 11 } x (iterations - 1) 10 12 2    PCG            [20] 0 1 2    block-Jacobi
+  const bool exact = arrow && hG[0].n_slots > 0, joint = !exact && pcg_iters > 0 && hG[0].n_slots > 0, ghosts = hG[0].n_gslots > 0;
+  bool ok;
+  switch (part) {
+    case 20: ok = (last_part == -1 || last_part == 2) && ghosts; break;
+    case 0: ok = ghosts ? last_part == 20 : (last_part == -1 || last_part == 2); break;
+    case 1: ok = !exact && last_part == 0; break;
+    case 10: ok = joint && (last_part == 1 || last_part == 11); break;
+    case 11: case 12: ok = joint && last_part == 10; break;
+    default: ok = exact ? last_part == 0 : (joint ? last_part == 12 : last_part == 1); break;      // part 2
+  }
+  if (part == 20 && !ghosts) return SLIDE_OK;                                             // (no ghost poses: nothing to refresh)
+  if (!exact && !joint && part >= 10 && part <= 12) return SLIDE_OK;                      // (no joint solve: nothing between parts 1 and 2)
+  if (!ok) {
+    g_last_error = "batched pass: part " + std::to_string(part) + " does not follow part " + std::to_string(last_part) +
+                   (exact ? " (exact joint step: [20] 0 2)" : joint ? " (PCG: [20] 0 1 {10 11} 10 12 2)" : " ([20] 0 1 2)") +
+                   (ghosts ? "; the graphs hold ghost poses: a pass opens with part 20" : "");
+    last_part = -1;
+    return SLIDE_ERR_INVALID;
+  }
+  if (exact && !sep_x) { g_last_error = "exact joint step: a cut pass needs the caller's separator exchange buffer (slide_chol_batch_set_exact_joint)"; return SLIDE_ERR_INVALID; }
   if (!part_exec[slot] && (rc = capture_pass(d_bufs, part, &part_exec[slot])) != SLIDE_OK) return rc;
   SL_HIP(hipGraphLaunch(part_exec[slot], master));
+  last_part = part;
   return part == 2 ? end_pass() : SLIDE_OK;
 }
 

@@ -186,6 +186,7 @@ class CholBatch {
   hipGraphExec_t pass_exec = nullptr;
   hipGraphExec_t part_exec[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // parts 0, 1, 2, 10, 11, 12 (exact joint step: 0 and 2 only), 20 (ghost refresh)
   int enqueue_ghost_refresh(double* const* d_bufs, int part);
+  int last_part = -1;                    // the part of a cut pass that ran last (-1: none / a whole pass): pass_part checks the order
   int pcg_iters = 0;
   double pcg_tol = 0.0;
   bool arrow = false;

@@ -494,6 +494,9 @@ class PassDriver:
             raise ValueError("timed_cut_pass: exact joint passes of a CholBatch only")
         sep = self._sep_exchange_buffer()
         out = {}
+        if getattr(self, "n_gslots", 0):
+            self.batch.pass_part(self.ptrs, 20)
+            self._exchange(12 * self.n_gslots)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         self.batch.pass_part(self.ptrs, 0)
         torch.cuda.synchronize(); t1 = time.perf_counter()
