@@ -216,6 +216,9 @@ int ClassMap::sync_device(hipStream_t s) {
 int HostBackend::refresh_maps() {
   hipStream_t s = g.stream;
   const uint64_t counters[3] = {cyl_counter, cube_counter, point_counter};
+  // (the new landmarks' cloud points, models, labels and graph ids of all three classes travel as ONE copy: up to 18 small ones otherwise)
+  if (ub.begin() != SLIDE_OK) return SLIDE_ERR_HIP;
+  struct BatchGuard { ~BatchGuard() { UploadBatch::current = nullptr; } } batch_guard;
   for (int c = 0; c < 3; ++c) {
     ClassMap& M = maps[c];
     if (M.sync_device(s) != SLIDE_OK) return SLIDE_ERR_HIP;
@@ -230,6 +233,7 @@ int HostBackend::refresh_maps() {
       M.up_lid = M.lid.size();
     }
   }
+  if (ub.flush(s) != SLIDE_OK) return SLIDE_ERR_HIP;
   launch_map_refresh(maps[0].d_model.d, (int)maps[0].lid.size(), maps[0].d_lid.d, maps[1].d_model.d, (int)maps[1].lid.size(),
                      maps[1].d_lid.d, maps[2].d_model.d, (int)maps[2].lid.size(), maps[2].d_lid.d, g.G.lm_est, s);
   SL_HIP(hipGetLastError());

@@ -1302,7 +1302,7 @@ int HostGraph::upload_new() {
   if (up_csr(d_pose_bt_ptr, d_pose_bt, pose_bt, ptr, val, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_lm_first.ensure(std::max<size_t>(Ln, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_lm_first.upload(h_lm_first.data(), 0, Ln, s) != SLIDE_OK) return SLIDE_ERR_HIP;
-  if (ub.flush(s) != SLIDE_OK) return SLIDE_ERR_HIP;   // (the host temporaries were copied into the pinned staging buffer)
+  // (the batch stays open across the profile below: its two small arrays ride in the same copy; flushed right after)
   // exact joint step: this robot's border = its shared landmarks and the lambda coordinates of its relative-pose factors
   const bool arrow_now = arrow_on();
   int nbr_new = 0;
@@ -1447,14 +1447,13 @@ int HostGraph::upload_new() {
       h_first = first;
       h_first.push_back(0);      // (one more entry: the right-hand-side row reaches every column — the catch-up product of an incremental update)
       if (d_prof.ensure(std::max<size_t>(T, 1), 0, s) != SLIDE_OK || d_first.ensure(std::max<size_t>(T + 1, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
-      if (T) {
-        SL_HIP(hipMemcpyAsync(d_prof.d, h_prof.data(), T * sizeof(int), hipMemcpyHostToDevice, s));
-        SL_HIP(hipMemcpyAsync(d_first.d, h_first.data(), (T + 1) * sizeof(int), hipMemcpyHostToDevice, s));
-        SL_HIP(hipStreamSynchronize(s));      // (pageable host vectors: the copies must have left them before they can change again)
+      if (T) {      // (into the open upload batch: staged at once, no copy or synchronisation of their own)
+        if (d_prof.upload(h_prof.data(), 0, T, s) != SLIDE_OK || d_first.upload(h_first.data(), 0, T + 1, s) != SLIDE_OK) return SLIDE_ERR_HIP;
       }
       ++prof_ver;
     }
   }
+  if (ub.flush(s) != SLIDE_OK) return SLIDE_ERR_HIP;   // (the host temporaries were copied into the pinned staging buffer)
   topo_dirty = false;
   uploaded_once = true;
   up_P = Pn; up_L = Ln; up_pr = npr; up_bt = nbt; up_lf = nlf; up_gh = ngh;
