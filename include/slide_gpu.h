@@ -418,6 +418,11 @@ void slide_clipper_default_params(slide_clipper_params_t* p);
  * projection, line-search and stopping decision in one persistent workgroup — no host round trip inside the iteration. */
 int slide_clipper_dense_clique(const double* M_upper, int n, const double* u0, const slide_clipper_params_t* p,
                                int32_t* nodes_out, int* n_nodes, double* u_out, double* score);
+/* The same for several independent problems in ONE launch, a persistent workgroup per problem — the robot pairs of a multi-robot job
+ * (semantic_clipper.cpp:227-235 once per pair; 28 pairs at eight robots).  Job j: M_upper[j] (n[j] x n[j]), u0[j] or NULL,
+ * nodes_out[j] (>= n[j] ints), u_out[j] (n[j] doubles or NULL); n_nodes[j], score[j].  Results equal n_jobs single calls. */
+int slide_clipper_dense_clique_batch(int n_jobs, const double* const* M_upper, const int* n, const double* const* u0, const slide_clipper_params_t* p,
+                                     int32_t* const* nodes_out, int* n_nodes, double* const* u_out, double* score);
 /* semantic_clipper::match_triangles / compute_triangle_diff semantic_clipper.cpp:49-118.  Triangles: 3 x (x, y) doubles each
  * (the Delaunay triangulation, observation.cpp:13-88, is the caller's).  pts_out: per matched pair three rows
  * [model x, model y, data x, data y] in ascending vertex-to-centroid distance; pairs in the reference's loop order

@@ -28,7 +28,7 @@ EXPORTS = [
     "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
     "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
-    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_chol_batch_set_pcg_tolerance", "slide_graph_set_pcg_tolerance", "slide_graph_set_separator", "slide_chol_batch_set_exact_joint", "slide_chol_batch_sep_buffer_len", "slide_chol_batch_profile_exact_joint", "slide_graph_get_border_profile", "slide_graph_get_incremental_stats", "slide_chol_batch_set_separator_profile", "slide_graph_set_incremental", "slide_graph_set_ghost_ids", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
+    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_chol_batch_set_pcg_tolerance", "slide_graph_set_pcg_tolerance", "slide_graph_set_separator", "slide_chol_batch_set_exact_joint", "slide_chol_batch_sep_buffer_len", "slide_chol_batch_profile_exact_joint", "slide_graph_get_border_profile", "slide_graph_get_incremental_stats", "slide_clipper_dense_clique_batch", "slide_chol_batch_set_separator_profile", "slide_graph_set_incremental", "slide_graph_set_ghost_ids", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
     "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
     "slide_dense_spd_solve", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device", "slide_assoc_sweep_batch",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
@@ -627,6 +627,27 @@ def clipper_dense_clique(M_upper, u0=None, params=None):
     _check(lib().slide_clipper_dense_clique(_p(M), C.c_int(n), _p(u0a) if u0a is not None else None, C.byref(p), _p(nodes),
                                             C.byref(nn), _p(u), C.byref(sc)))
     return nodes[:nn.value].copy(), u[:n].copy(), sc.value
+
+
+def clipper_dense_clique_batch(Ms, u0s=None, params=None):
+    """Several CLIPPER dense-clique problems in one launch (one persistent workgroup per problem).  Ms: list of (n_j, n_j) affinity
+    matrices; u0s: list of start vectors or None.  Returns [(nodes, u, score), ...] — what clipper_dense_clique gives for each."""
+    J = len(Ms)
+    Ma = [_d(M) for M in Ms]
+    ns = np.array([M.shape[0] for M in Ma], np.int32)
+    p = params or clipper_params()
+    nodes = [np.zeros(max(int(k), 1), np.int32) for k in ns]
+    us = [np.zeros(max(int(k), 1)) for k in ns]
+    u0a = [(_d(u) if u is not None else None) for u in (u0s or [None] * J)]
+    PP = C.POINTER(C.c_double)
+    Mp = (C.c_void_p * J)(*[M.ctypes.data for M in Ma])
+    Up = (C.c_void_p * J)(*[(u.ctypes.data if u is not None else None) for u in u0a])
+    Np = (C.c_void_p * J)(*[x.ctypes.data for x in nodes])
+    Op = (C.c_void_p * J)(*[x.ctypes.data for x in us])
+    nn = np.zeros(max(J, 1), np.int32)
+    sc = np.zeros(max(J, 1))
+    _check(lib().slide_clipper_dense_clique_batch(C.c_int(J), Mp, _p(ns), Up, C.byref(p), Np, _p(nn), Op, _p(sc)))
+    return [(nodes[j][:nn[j]].copy(), us[j][:ns[j]].copy(), float(sc[j])) for j in range(J)]
 
 
 def match_triangles(tri_model, tri_data, threshold=0.1):

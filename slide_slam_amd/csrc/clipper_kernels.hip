@@ -36,14 +36,6 @@ __global__ __launch_bounds__(256) void k_clq_csr(const double* __restrict__ Mup,
   if (!EMIT && lane == 0) rowcnt[i] = base;
 }
 
-struct ClqSolve {
-  const int* rowptr; const int* col; const double* val; int n;
-  const double* u0;               // start weights
-  double *u, *unew, *g, *gnew, *Mu, *Cu;      // n each (global; L2-resident)
-  double tol_u, tol_F, beta, eps;
-  int maxin, maxol, maxls, rescale;
-  double* out;                    // [0] F, [1] d, [2] gradient evaluations, [3] outer iterations
-};
 
 __device__ __forceinline__ double clq_block_sum(double x, double* sh) {
   const int tid = threadIdx.x;
@@ -109,7 +101,7 @@ __device__ __forceinline__ double clq_d_terms(const ClqSolve& A, const double* _
   return sc > 0.0 ? sa / sc : 0.0;
 }
 
-__global__ __launch_bounds__(1024) void k_clq_solve(ClqSolve A) {
+__device__ __forceinline__ void clq_solve_body(const ClqSolve& A) {
   __shared__ double sh[16];
   const int tid = threadIdx.x, nt = blockDim.x, n = A.n;
   // u <- normalised (M u0 + u0) or u0   (clipper.cpp:186-199)
@@ -174,6 +166,16 @@ __global__ __launch_bounds__(1024) void k_clq_solve(ClqSolve A) {
     for (int i = tid; i < n; i += nt) A.u[i] = u[i];
   }
   if (tid == 0) { A.out[0] = F; A.out[1] = d; A.out[2] = evals; A.out[3] = (double)outer; }
+}
+
+__global__ __launch_bounds__(1024) void k_clq_solve(ClqSolve A) { clq_solve_body(A); }
+// several independent problems (the robot pairs of a multi-robot job, SURVEY 8e: 28 at eight robots), one persistent workgroup each
+__global__ __launch_bounds__(1024) void k_clq_solve_b(const ClqSolve* __restrict__ jobs) {
+  const ClqSolve A = jobs[blockIdx.x];
+  if (A.n > 0) clq_solve_body(A);
+}
+void launch_clq_solve_batch(const ClqSolve* d_jobs, int n_jobs, hipStream_t s) {
+  if (n_jobs > 0) hipLaunchKernelGGL(k_clq_solve_b, dim3(n_jobs), dim3(1024), 0, s, d_jobs);
 }
 
 void launch_clq_csr_count(const double* Mup, int n, int* rowcnt, hipStream_t s) {

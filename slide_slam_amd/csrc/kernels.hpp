@@ -147,6 +147,15 @@ void launch_tri_match(bool emit, const double* dm, const double* xm, int ntm, co
 // clipper_kernels.hip — CLIPPER dense clique on the device: CSR of the symmetric affinity matrix from its dense upper triangle (count,
 // host prefix sum, fill), then the whole projected-gradient solve in one persistent workgroup.  work6n: 6 n doubles (u comes back in the
 // first n), out4: {F, d, gradient evaluations, outer iterations}
+struct ClqSolve {
+  const int* rowptr; const int* col; const double* val; int n;
+  const double* u0;               // start weights
+  double *u, *unew, *g, *gnew, *Mu, *Cu;      // n each (global; L2-resident)
+  double tol_u, tol_F, beta, eps;
+  int maxin, maxol, maxls, rescale;
+  double* out;                    // [0] F, [1] d, [2] gradient evaluations, [3] outer iterations
+};
+void launch_clq_solve_batch(const ClqSolve* d_jobs, int n_jobs, hipStream_t s);      // one persistent workgroup per job (grid = n_jobs)
 void launch_clq_csr_count(const double* Mup, int n, int* rowcnt, hipStream_t s);
 void launch_clq_csr_fill(const double* Mup, int n, const int* rowptr, int* col, double* val, hipStream_t s);
 void launch_clq_solve(const int* rowptr, const int* col, const double* val, int n, const double* u0, double* work6n, double tol_u, double tol_F,

@@ -242,6 +242,37 @@ def test_dense_clique_matches_oracle(gpu):
 
 
 @pytest.mark.gpu
+def test_dense_clique_batch_equals_single_solves(gpu):
+    """slide_clipper_dense_clique_batch: the 28 robot-pair problems of an eight-robot job as ONE launch, a persistent
+    workgroup per problem — every problem's clique, weights and score equal the single-problem call's (the same device code per job),
+    problems of different sizes, an empty one among them."""
+    rng = np.random.default_rng(5)
+    p = gpu.clipper_params(sigma=0.1, epsilon=0.3)
+    Ms, u0s = [], []
+    for j in range(28):
+        n1 = int(rng.integers(12, 40))
+        D1 = rng.uniform(-10, 10, (n1, 2))
+        k = int(rng.integers(6, n1))
+        perm = rng.permutation(n1)[:k]
+        D2 = D1[perm] + rng.normal(0, 0.02, (k, 2))
+        A = np.array([(i, jj) for i in range(n1) for jj in range(k)], np.int32)[::3].copy()
+        for q, i in enumerate(perm[:min(6, k)]):
+            A[q] = (i, q)
+        Ms.append(gpu.clipper_affinity(D1, D2, A, sigma=0.1, epsilon=0.3))
+        u0s.append(rng.uniform(0, 1, len(A)))
+    Ms.insert(7, np.zeros((0, 0))); u0s.insert(7, None)      # an empty problem
+    res = gpu.clipper_dense_clique_batch(Ms, u0s, p)
+    assert len(res) == 29 and len(res[7][0]) == 0
+    for j, (M, u0) in enumerate(zip(Ms, u0s)):
+        if M.shape[0] == 0:
+            continue
+        nodes, u, score = gpu.clipper_dense_clique(M, u0, p)
+        bn, bu, bs = res[j]
+        assert sorted(bn.tolist()) == sorted(nodes.tolist()), j
+        assert np.array_equal(bu, u) and bs == score, j
+
+
+@pytest.mark.gpu
 def test_dense_clique_large_planted(gpu):
     """m = 4000 putative associations (a 128 MB dense affinity matrix on the host, ~1 % of it non-zero): a planted set of 60 mutually
     consistent associations among random pairwise-consistent noise — the device-resident solve (CSR + one persistent workgroup)
