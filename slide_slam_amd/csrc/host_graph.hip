@@ -636,12 +636,12 @@ int CholBatch::enqueue_ghost_refresh(double* const* d_bufs, int part) {
   if (ng <= 0) return SLIDE_OK;
   const bool whole = part < 0;
   if (whole || part == 20) {
-    for (int i = 0; i < n; ++i) launch_ghost_exchange(hG[i], 0, d_bufs[i], master);
+    launch_ghost_exchange_batched(d_Gs, n, ng, 0, d_bufs, master);
     launch_sum_bcast(d_bufs, n, 12 * ng, master);
   }
   if (whole || part == 0) {
     if (!whole) launch_bcast(d_bufs, n, 12 * ng, master);
-    for (int i = 0; i < n; ++i) launch_ghost_exchange(hG[i], 1, d_bufs[i], master);
+    launch_ghost_exchange_batched(d_Gs, n, ng, 1, d_bufs, master);
   }
   return SLIDE_OK;
 }
@@ -660,7 +660,7 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     if (sep_nl > 0) launch_ints_clear(lam_status, 8, master);
     const int rg = enqueue_ghost_refresh(d_bufs, part);
     if (rg != SLIDE_OK) return rg;
-    launch_phase0_batched(d_Gs, hG.data(), n, d_bufs, master);      // relinearise, linearise, the robots' own per-landmark sums
+    launch_phase0_batched(d_Gs, hG.data(), n, d_bufs, master, false);      // relinearise, linearise, the robots' own per-landmark sums (nothing to pack: no exchange of them)
     launch_phase3_arrow_batched(d_Gs, hG.data(), n, master);         // private landmarks eliminated, reduced pose systems, borders
     if (e0) (void)hipEventRecord(e0, master);
     mark(0);

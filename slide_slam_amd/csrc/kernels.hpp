@@ -24,11 +24,12 @@ void launch_scatter(const void* stage, unsigned desc_off, int nseg, hipStream_t 
 void launch_gather(void* stage, unsigned desc_off, int nseg, hipStream_t s);
 void launch_sum_bcast(double* const* bufs, int n, int count, hipStream_t s);   // local all-reduce(sum) of up to 8 buffers
 void launch_bcast(double* const* bufs, int n, int count, hipStream_t s);       // bufs[0] -> the others
-void launch_phase0_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s);   // the per-robot phases 0 / 4 / 2 of a batched pass,
+void launch_phase0_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s, bool pack = true);   // the per-robot phases 0 / 4 / 2 of a batched pass,
 void launch_phase4_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s);   // blockIdx.z = robot
 void launch_phase2_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s);
 void launch_phase3_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s);   // blockIdx.z = robot               // local all-reduce(sum) of up to 8 buffers             // device arrays -> one staging buffer (DownloadBatch)   // staged upload -> destinations (UploadBatch)
 void launch_ghost_exchange(const GraphDev& G, int what, double* buf, hipStream_t s);   // what: 0 pack owned poses, 1 adopt
+void launch_ghost_exchange_batched(const GraphDev* d, int n, int n_gslots, int what, double* const* bufs, hipStream_t s);   // all robots of a batched pass in one launch
 // exact joint step ("arrow", graph_dev.hpp): border rows + border block of every robot; the separator system of all shared landmarks
 // gathered from the robots' border blocks (maps[i]: m ints, global separator coordinate -> robot i's border coordinate or -1); its
 // solution handed back

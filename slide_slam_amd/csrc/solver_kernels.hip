@@ -1180,6 +1180,27 @@ __global__ void k_ghost_exchange(GraphDev G, int what, double* __restrict__ buf)
   }
 }
 
+// the same for all robots of a batched pass in one launch (blockIdx.z = robot): sixteen 2-us launches per pass otherwise
+struct GhostBufs { double* p[8]; };
+__global__ void k_ghost_exchange_b(const GraphDev* __restrict__ Gs, int what, GhostBufs B) {
+  const GraphDev G = Gs[blockIdx.z];
+  double* buf = B.p[blockIdx.z];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 12 * G.n_gslots) return;
+  if (what == 0) {
+    const int p = G.gslot_pose[t / 12];
+    buf[t] = p >= 0 ? G.pose_est[12 * (size_t)p + t % 12] : 0.0;
+  } else {
+    G.ghost_val[t] = buf[t];
+  }
+}
+void launch_ghost_exchange_batched(const GraphDev* d, int n, int n_gslots, int what, double* const* bufs, hipStream_t s) {
+  if (n_gslots <= 0 || n <= 0) return;
+  GhostBufs B{};
+  for (int i = 0; i < n; ++i) B.p[i] = bufs[i];
+  hipLaunchKernelGGL(k_ghost_exchange_b, dim3((12 * n_gslots + 127) / 128, 1, n), dim3(128), 0, s, d, what, B);
+}
+
 __device__ __forceinline__ void k_estimate_body(const GraphDev& G) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < G.P) {
@@ -1319,7 +1340,7 @@ __global__ void k_shared_pack_b(const GraphDev* __restrict__ Gs, int what, BufPt
 // The per-robot phases of a batched pass in ONE launch sequence for all robots (blockIdx.z = robot, grids sized for the largest graph):
 // forking every robot's phase onto its own stream and joining again cost three cross-stream joins of ~15 us per pass.
 // phase 0: relinearise, linearise, per-landmark partial sums, pack H_ll / g_l of the shared slots
-void launch_phase0_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s) {
+void launch_phase0_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s, bool pack) {
   int L = 0, P = 0, slots = 0, npf = 0;
   long long nlf = 0;
   for (int i = 0; i < n; ++i) {
@@ -1333,7 +1354,7 @@ void launch_phase0_batched(const GraphDev* d, const GraphDev* h, int n, double* 
   if (npf > 0) hipLaunchKernelGGL(k_lin_pose_factors_b, dim3(blocks_for(npf, 128), 1, n), dim3(128), 0, s, d);
   if (nlf > 0) hipLaunchKernelGGL(k_lin_lf_b, dim3(blocks_for(32LL * nlf, 256), 1, n), dim3(256), 0, s, d);
   if (L > 0) hipLaunchKernelGGL(k_landmark_b<1>, dim3(blocks_for(L, 4), 1, n), dim3(256), 0, s, d);
-  if (slots > 0) hipLaunchKernelGGL(k_shared_pack_b, dim3(blocks_for(54LL * slots, 128), 1, n), dim3(128), 0, s, d, 0, B);
+  if (slots > 0 && pack) hipLaunchKernelGGL(k_shared_pack_b, dim3(blocks_for(54LL * slots, 128), 1, n), dim3(128), 0, s, d, 0, B);
 }
 // phase 4: t_l = sum E^T delta_p per landmark, packed for the exchange
 void launch_phase4_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s) {
