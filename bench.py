@@ -397,7 +397,7 @@ def main():
         drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, base=base, world=wdev, device=device,
                          pcg_iters=args.pcg if args.joint == "pcg" else 0, pcg_tol=args.pcg_tol, arrow=args.joint == "exact", sep_dim=info["sep_dim"], sep_prof=info.get("sep_prof"))
         info["relmeas"] = "none"
-        if not args.no_relmeas and robots == cfg.robots and args.frames is None:
+        if not args.no_relmeas and args.joint == "exact" and robots == cfg.robots and args.frames is None:      # (the PCG / block-Jacobi passes' un-batched parity path carries no ghosts)
             from slide_slam_amd.synth import make_relmeas
             all_logs = logs if world == 1 else [make_robot_log(cfg, world_map, r) for r in range(cfg.robots)]
             rel = make_relmeas(cfg, all_logs)
