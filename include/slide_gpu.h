@@ -209,6 +209,15 @@ int slide_chol_batch_set_exact_joint(slide_chol_batch_t* b, int on, double* sep_
  * coordinates laid out along the robots' adjacency (slide_graph_set_separator takes any layout) the system is block-banded; the caller
  * knows every robot's observer set (the cross-robot association), the batch only its own robots'.  Not set: dense. */
 int slide_chol_batch_set_separator_profile(slide_chol_batch_t* b, const int32_t* prof, int n);
+/* Nested dissection of every robot's own pose chain inside an exact joint pass: the banded pose system of a robot is a serial chain of
+ * block columns (one launch each); cut into n_seg segments at windows of poses as wide as the band is (every coupling across a window
+ * passes through it), the segments are factored side by side as systems of their own, and the windows' poses — moved into the border
+ * next to the shared landmarks — are eliminated at a second level before the robot's Schur complement joins the separator system.
+ * Same step (the elimination order changes, not the system); n_seg = 1 (default) factors every band as one chain; at most 4. */
+int slide_chol_batch_set_segments(slide_chol_batch_t* b, int n_seg);
+/* The cut of this graph's band: returns the number of segments (1: not cut — the batch does not ask for it, or the chain is too short);
+ * out[2 i], out[2 i + 1] = tile columns [t0, t1) of segment i, out[2 n] = number of separator poses (cap >= 2 n + 1 ints). */
+int slide_graph_get_segments(slide_graph_t* g, int* out, int cap);
 long long slide_chol_batch_sep_buffer_len(int m, int n_relmeas);
 /* Inter-robot relative-pose factors in an exact joint pass: the factor between pose a of robot A and pose b of robot B is the rank-6
  * term U U^T, U = [J_a^T; J_b^T], of the joint normal equations; it is carried as six further separator coordinates "lambda" (the

@@ -659,6 +659,7 @@ struct CholBatchArgs {
   int nP[CHOL_BATCH_MAX], g0[CHOL_BATCH_MAX], g1[CHOL_BATCH_MAX], nX[CHOL_BATCH_MAX], a_split[CHOL_BATCH_MAX];
   int nbr[CHOL_BATCH_MAX];             // border row tiles below the profile (b_decode)
   int nbA[CHOL_BATCH_MAX], nbB[CHOL_BATCH_MAX], nbX[CHOL_BATCH_MAX];      // ... of which active for column k / the pair's pass / the column items
+  int B0[CHOL_BATCH_MAX];              // tile row at which the border rows start (T, or further down for a segment view: CholSystem::b0)
   int a_base[CHOL_BATCH_MAX + 1];      // prefix sums of the type-A workgroup counts
   int b_base[CHOL_BATCH_MAX + 1];      // prefix sums of the type-B item counts
 };
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int 
     int r = 0;
     while (bid >= A.a_base[r + 1]) ++r;
     const int local = bid - A.a_base[r], sp = A.a_split[r];
-    step_type_a(A.S[r], A.ld[r], k, A.T[r], A.TvA[r], local >> sp, sp ? (local & 1) : -1, A.Ld[r] + (size_t)k * NB * NB,
+    step_type_a(A.S[r], A.ld[r], k, A.B0[r], A.TvA[r], local >> sp, sp ? (local & 1) : -1, A.Ld[r] + (size_t)k * NB * NB,
                 A.Winv[r] + (size_t)k * 1024, A.status[r], L, A.L32[r], A.nbr[r], A.nbA[r]);
     if (!a_joins) return;
   }
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int 
     while (g >= A.b_base[r + 1]) ++r;
     const int gl = g - A.b_base[r], nR = A.g1[r] - A.g0[r];
     const long long nG = (long long)A.nP[r] * (A.nP[r] + 1) / 2;
-    const BItem it = b_decode(gl, nR + A.nX[r], nR, A.g0[r], k, kb, A.T[r], A.TvB[r], A.TvX[r], A.nP[r], nG, wave, A.nbr[r], A.nbB[r], A.nbX[r]);
+    const BItem it = b_decode(gl, nR + A.nX[r], nR, A.g0[r], k, kb, A.B0[r], A.TvB[r], A.TvX[r], A.nP[r], nG, wave, A.nbr[r], A.nbB[r], A.nbX[r]);
     if (!it.ok) continue;
     if (it.ks == 32) b_quadrant<32>(A.S[r], A.ld[r], it, wave & 3);
     else b_quadrant<16>(A.S[r], A.ld[r], it, wave & 3);
@@ -1492,8 +1493,8 @@ void launch_border_apply(const CholSystem* d, int n, const double* const* xloc, 
 // k-2, k-1 over the trailing matrix, odd launches finish the pass their predecessor started and bring column k+1 up to panel k-1.
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp,
                          int* status, const int* prof, hipStream_t s);
-void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s, int nbr) {
-  hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, T + nbr, yv, dp, status);
+void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s, int nbr, int b0) {
+  hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, (b0 > 0 ? b0 : T) + nbr, yv, dp, status);
 }
 struct StepPlan { int kb, nP, g0, g1, nX, TvA, TvB, TvX, nbA, nbB, nbX; long long nA, nB; };
 static int chol_n_cu() {
@@ -1511,7 +1512,7 @@ static int chol_n_cu() {
 // column items of an odd launch (panel k-1 onto column k+1) rows <= prof[k-1].  Everything else is structurally zero and skipped.
 // bfirst (host, nbr ints, non-decreasing, or null): first block column in which border tile row i is non-zero; a row whose first column lies
 // beyond the panels a launch handles is all-zero there and skipped
-static StepPlan plan_step(int k, int T, const int* prof, int nbr = 0, const int* bfirst = nullptr) {
+static StepPlan plan_step(int k, int T, const int* prof, int nbr = 0, const int* bfirst = nullptr, int kofs = 0) {
   static const double frac = getenv("SLIDE_CHOL_FRAC") ? atof(getenv("SLIDE_CHOL_FRAC")) : 0.5;   // diagnostic: share of a pass done by its first launch
   StepPlan p{};
   p.kb = k & ~1;                                                // base of the pair
@@ -1521,7 +1522,7 @@ static StepPlan plan_step(int k, int T, const int* prof, int nbr = 0, const int*
     if (p.kb >= 1) p.TvB = prof[p.kb - 1] + 1;
     if (k >= 1) p.TvX = prof[k - 1] + 1;
   }
-  auto active = [&](int upto) { int c = 0; while (c < nbr && (!bfirst || bfirst[c] <= upto)) ++c; return c; };
+  auto active = [&](int upto) { int c = 0; while (c < nbr && (!bfirst || bfirst[c] <= upto + kofs)) ++c; return c; };
   p.nbA = active(k); p.nbB = active(p.kb - 1); p.nbX = active(k - 1);
   p.nA = k < T ? p.TvA - k + p.nbA : 0;                         // column-k tiles below the diagonal (+ active border tiles + RHS tile)
   if (k >= 2 && k < T) {
@@ -1572,7 +1573,7 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
     A.n = n;
     long long nA2 = 0, nBt = 0;
     StepPlan pl[CHOL_BATCH_MAX];
-    for (int i = 0; i < n; ++i) { pl[i] = plan_step(k, d[i].T, d[i].h_prof, d[i].nbr, d[i].h_bfirst); nA2 += 2 * pl[i].nA; nBt += pl[i].nB; }
+    for (int i = 0; i < n; ++i) { pl[i] = plan_step(k, d[i].T, d[i].h_prof, d[i].nbr, d[i].h_bfirst, d[i].kofs); nA2 += 2 * pl[i].nA; nBt += pl[i].nB; }
     const int a_split = (k > 0 && nA2 + nBt <= n_cu) ? 1 : 0;
     A.a_base[0] = A.b_base[0] = 0;
     for (int i = 0; i < n; ++i) {
@@ -1581,6 +1582,7 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
       A.TvA[i] = pl[i].TvA; A.TvB[i] = pl[i].TvB; A.TvX[i] = pl[i].TvX;
       A.nP[i] = pl[i].nP; A.g0[i] = pl[i].g0; A.g1[i] = pl[i].g1; A.nX[i] = pl[i].nX; A.a_split[i] = a_split;
       A.nbr[i] = d[i].nbr; A.nbA[i] = pl[i].nbA; A.nbB[i] = pl[i].nbB; A.nbX[i] = pl[i].nbX;
+      A.B0[i] = d[i].b0 > 0 ? d[i].b0 : d[i].T;      // (a view with its border further down carries no f32 factor copy: L32's tile index uses T)
       A.a_base[i + 1] = A.a_base[i] + (int)(pl[i].nA << a_split);
       A.b_base[i + 1] = A.b_base[i] + (int)pl[i].nB;
     }
@@ -1592,7 +1594,7 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
   }
   if (after_steps) (void)hipEventRecord(after_steps, s);
   if (!solve) {       // the caller continues with the border (k_border_syrk, the separator system) and runs launch_chol_bwd_batch itself
-    for (int i = 0; i < n; ++i) launch_chol_extract_y(d[i].S, d[i].ld, d[i].T, d[i].yv, d[i].dp, d[i].status, s, d[i].nbr);
+    for (int i = 0; i < n; ++i) launch_chol_extract_y(d[i].S, d[i].ld, d[i].T, d[i].yv, d[i].dp, d[i].status, s, d[i].nbr, d[i].b0);
     return;
   }
   launch_chain_tables(d, n, s);

@@ -101,6 +101,13 @@ struct GraphDev {
   const int* lm_bord; // L   offset of a shared landmark's tangent coordinates in this robot's border, or -1
   double* bord;      // ((nbr + 1) * NB) x (nbr * NB), column-major, ldb: border x border block (lower) + right-hand-side row at nbr * NB
   int ldb;
+  const int* pose_sep; // P   border offset of a SEPARATOR POSE's six coordinates, or -1 / null.  Nested dissection of the robot's own pose
+                      //     chain: the poses of a window as wide as the band is (every coupling across it passes through it) are moved
+                      //     out of the band into the first nsep border row tiles (k_sep_extract), the chain falls into independent
+                      //     segments that are factored side by side, and the window's own system (nsep tile columns, the rest of the
+                      //     border as ITS border) is eliminated at a second level — the serial chain is as long as one segment
+  int nsep;           // border row tiles taken by the separator poses (padded to whole tiles; 0: no segmentation)
+  int nsep_dim;       // their coordinates (6 per separator pose)
   const int* gh_bord; // n_ghost  border offset of a ghost (inter-robot relative-pose) factor's six "lambda" coordinates, or null: the
                       // factor then enters H_pp / g_p with the other pose frozen (block-Jacobi); non-null (exact joint step): it
                       // enters through the border only — rows J (its Jacobian w.r.t. the own pose), the first-key side adds -I and -r

@@ -416,6 +416,7 @@ CholBatch::~CholBatch() {
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (pass_exec) (void)hipGraphExecDestroy(pass_exec);
   free_separator();
+  if (d_ctr2) (void)hipFree(d_ctr2);
   if (d_Gs) (void)hipFree(d_Gs);
   if (d_status_all) (void)hipFree(d_status_all);
   if (ev_aux0) (void)hipEventDestroy(ev_aux0);
@@ -514,7 +515,41 @@ int CholBatch::prepare_pass() {
   if (!d_Gs) SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_Gs), CHOL_BATCH_HOST_MAX * sizeof(GraphDev)));
   if (!d_status_all) SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_status_all), CHOL_BATCH_HOST_MAX * 8 * sizeof(int)));
   SL_HIP(hipMemcpy(d_Gs, hG.data(), n * sizeof(GraphDev), hipMemcpyHostToDevice));
-  if (arrow && hG[0].n_slots > 0) return prepare_separator();
+  // exact joint passes: the systems the steps run on — every graph's segments (views of its S; the whole band when it is not cut) — and
+  // the second-level systems of the graphs that are cut (the separator poses' block inside the border block, the rest of the border
+  // as its border)
+  seg_sys.clear(); l2_sys.clear(); l2_graph.clear();
+  if (arrow && hG[0].n_slots > 0) {
+    for (int i = 0; i < n; ++i) {
+      HostGraph* g = graphs[i];
+      const GraphDev& G = hG[i];
+      if (G.nsep <= 0 || g->segs.empty()) { seg_sys.push_back(sys[i]); continue; }
+      for (size_t k = 0; k < g->segs.size(); ++k) {
+        const HostGraph::Seg sg = g->segs[k];
+        CholSystem c = sys[i];
+        c.S = G.S + (size_t)sg.t0 * NB * G.ld + (size_t)sg.t0 * NB;
+        c.T = sg.t1 - sg.t0;
+        c.Ld = G.Ld + (size_t)sg.t0 * NB * NB; c.Winv = G.Winv + (size_t)sg.t0 * 1024;
+        c.yv = G.yv + (size_t)sg.t0 * NB; c.dp = G.dp + (size_t)sg.t0 * NB;
+        c.h_prof = g->seg_prof[k].data(); c.prof = g->d_seg_prof.d + g->seg_prof_off[k]; c.first = nullptr;
+        c.b0 = G.T - sg.t0; c.kofs = sg.t0;
+        c.L32 = nullptr; c.ctab = nullptr;
+        seg_sys.push_back(c);
+      }
+      CholSystem l2{};
+      l2.S = G.bord; l2.ld = G.ldb; l2.T = G.nsep; l2.Ld = g->d_Ld2.d; l2.Winv = g->d_Winv2.d; l2.yv = g->d_yv2.d; l2.dp = g->d_dp2.d;
+      l2.status = G.status; l2.nbr = G.nbr - G.nsep;
+      l2.bord = G.bord + (size_t)G.nsep * NB * G.ldb + (size_t)G.nsep * NB; l2.ldb = G.ldb;
+      l2_sys.push_back(l2);
+      l2_graph.push_back(i);
+    }
+    if (!d_ctr2) {
+      SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_ctr2), 64 * sizeof(int)));
+      SL_HIP(hipMemset(d_ctr2, 0, 64 * sizeof(int)));
+    }
+    if ((int)seg_sys.size() > 4 * CHOL_BATCH_HOST_MAX || (int)l2_sys.size() > CHOL_BATCH_HOST_MAX) { g_last_error = "exact joint step: too many segment systems"; return SLIDE_ERR_CAPACITY; }
+    return prepare_separator();
+  }
   return SLIDE_OK;
 }
 // ---- exact joint step: the separator system of all shared landmarks -------------------------------------------------------------------
@@ -524,6 +559,18 @@ void CholBatch::free_separator() {
   for (double** p : {&sep_Ld, &sep_Winv, &sep_yv, &sep_dp, &sep_bord, &lamS, &lam_Ld, &lam_Winv, &lam_yv, &lam_dp, &lam_scratch}) if (*p) { (void)hipFree(*p); *p = nullptr; }
   for (int** p : {&sep_status, &sep_ctr, &d_sep_off, &lam_status, &lam_ctr, &d_sep_prof}) if (*p) { (void)hipFree(*p); *p = nullptr; }
   sep_cap = 0; lam_cap = -1;
+}
+void CholBatch::set_segments(int n) {
+  std::lock_guard<std::mutex> pl(pass_mtx);
+  std::vector<HostGraph*> gs;
+  {
+    std::lock_guard<std::mutex> lk(mtx);
+    n_seg = n < 1 ? 1 : (n > 4 ? 4 : n);
+    pass_dirty = true;
+    gs.assign(graphs.begin(), graphs.end());
+  }
+  for (HostGraph* g : gs)
+    if (g) { std::lock_guard<std::mutex> gl(g->mtx); g->topo_dirty = true; }
 }
 int CholBatch::set_separator_profile(const int32_t* prof, int n) {
   std::lock_guard<std::mutex> pl(pass_mtx);
@@ -662,12 +709,22 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     if (rg != SLIDE_OK) return rg;
     launch_phase0_batched(d_Gs, hG.data(), n, d_bufs, master, false);      // relinearise, linearise, the robots' own per-landmark sums (nothing to pack: no exchange of them)
     launch_phase3_arrow_batched(d_Gs, hG.data(), n, master);         // private landmarks eliminated, reduced pose systems, borders
+    {
+      int nq[CHOL_BATCH_HOST_MAX];
+      for (int i = 0; i < n; ++i) nq[i] = graphs[i]->n_sep_poses;
+      launch_sep_extract_batched(d_Gs, hG.data(), n, nq, master);    // nested dissection: the separator poses out of the bands
+    }
     if (e0) (void)hipEventRecord(e0, master);
     mark(0);
-    const int rc = factor_all(e1);                                   // the bands' steps: W^T and y in the border rows
+    const int rc = factor_all(e1);                                   // the segments' steps: W^T and y in the border rows
     if (rc != SLIDE_OK) return rc;
     mark(1);
     launch_border_syrk(sys.data(), n, master);                       // border blocks: C_a - W^T W, b_s - W^T y
+    if (!l2_sys.empty()) {
+      // second level: the separator poses' own system (dense, nsep block columns) with the rest of the border as its border
+      launch_chol_batch(l2_sys.data(), (int)l2_sys.size(), d_ctr2, master, nullptr, false);
+      launch_border_syrk(l2_sys.data(), (int)l2_sys.size(), master);
+    }
     mark(2);
     // a cut pass leaves this GPU's partial sum in the caller's exchange buffer (packed), a whole pass writes the system itself
     launch_sep_gather(hG.data(), n, maps, Y, !whole, master);
@@ -699,8 +756,22 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     launch_chol_bwd_all(sepS, ld_s, sep_Ts, sep_Ld, sep_Winv, sep_yv, sep_dp, sep_status, sep_prof_on ? d_sep_prof : nullptr, master);
     mark(4);
     launch_sep_xloc(n, maps, sep_m, sep_lam, sep_dp, lam_dp, xloc, master);
+    if (!l2_sys.empty()) {
+      // second level back: y2 -= W2 x (shared landmarks, lambdas), L2^T x_sep = y2, x_sep into the head of the border vector
+      const double* x2[CHOL_BATCH_HOST_MAX];
+      for (size_t i = 0; i < l2_sys.size(); ++i) x2[i] = xloc[l2_graph[i]] + (size_t)hG[l2_graph[i]].nsep * NB;
+      launch_border_apply(l2_sys.data(), (int)l2_sys.size(), x2, master);
+      launch_chol_bwd_batch(l2_sys.data(), (int)l2_sys.size(), master);
+      launch_ints_clear(l2_sys[0].status + 4, 1, master);            // (the chain's ticket counter: the segments' chains of that graph draw from it next)
+      for (size_t i = 0; i < l2_sys.size(); ++i) {
+        double* two[2] = {l2_sys[i].dp, xloc[l2_graph[i]]};
+        launch_bcast(two, 2, hG[l2_graph[i]].nsep * NB, master);
+      }
+    }
     launch_border_apply(sys.data(), n, xloc, master);                // y -= W x_s
-    launch_chol_bwd_batch(sys.data(), n, master);                    // L^T dp = y
+    for (size_t lo = 0; lo < seg_sys.size(); lo += CHOL_BATCH_HOST_MAX)      // L^T dp = y, segment by segment
+      launch_chol_bwd_batch(seg_sys.data() + lo, (int)std::min<size_t>(CHOL_BATCH_HOST_MAX, seg_sys.size() - lo), master);
+    launch_sep_pose_scatter_batched(d_Gs, hG.data(), n, xloc, master);
     launch_arrow_finish_batched(d_Gs, hG.data(), n, sep_dp, d_sep_off, master);
     launch_status_or(hG[0].status, sep_status, 8, master);           // (the separator's not-SPD / chain flags are reported with graph 0's)
     if (sep_nl > 0) launch_status_or(hG[0].status, lam_status, 8, master);
@@ -933,23 +1004,27 @@ int CholBatch::factor_all(hipEvent_t after) {
   // wide profiles: two sequences (the floods share the CUs; four measured slower); narrow profiles (every launch is a handful of
   // chain-bound workgroups): four sequences of two systems — more launches in flight hide each other's gaps and prologues (eight
   // robots: 3.67 ms per pass with two sequences, 3.50 with four, 4.29 with eight: the cross-stream joins then cost more than they hide)
+  const bool exact = arrow && hG[0].n_slots > 0;      // exact joint step: the systems are the graphs' segments; the backward substitutions wait for the separator's solution
+  const std::vector<CholSystem>& S_ = exact ? seg_sys : sys;
+  const int ns = (int)S_.size();
   bool narrow = true;
   for (int i = 0; i < n; ++i) narrow = narrow && hG[i].schur_split == 1;
   int groups = env_groups > 0 ? env_groups : (narrow ? 4 : 2);
-  if (groups > (env_groups > 0 ? n : n / 2)) groups = env_groups > 0 ? n : n / 2;      // (at least two systems per sequence by default)
+  if (groups > (env_groups > 0 ? ns : ns / 2)) groups = env_groups > 0 ? ns : ns / 2;      // (at least two systems per sequence by default)
+  while (groups > 0 && (ns + groups - 1) / groups > CHOL_BATCH_HOST_MAX) ++groups;           // (at most eight systems per launch)
   if (groups > 8) groups = 8;
   last_groups = groups < 1 ? 1 : groups;
-  const bool solve = !(arrow && hG[0].n_slots > 0);      // exact joint step: the backward substitutions wait for the separator's solution
+  const bool solve = !exact;
   if (groups < 2) {
-    launch_chol_batch(sys.data(), n, d_ctr, master, nullptr, solve);
+    launch_chol_batch(S_.data(), ns, d_ctr, master, nullptr, solve);
     if (after) SL_HIP(hipEventRecord(after, master));
     return SLIDE_OK;
   }
   if (!ev_aux0) SL_HIP(hipEventCreateWithFlags(&ev_aux0, hipEventDisableTiming));
   SL_HIP(hipEventRecord(ev_aux0, master));
-  const int per = (n + groups - 1) / groups;
+  const int per = (ns + groups - 1) / groups;
   for (int g = 0; g < groups; ++g) {
-    const int lo = g * per, hi = std::min(n, lo + per);
+    const int lo = g * per, hi = std::min(ns, lo + per);
     if (lo >= hi) break;
     hipStream_t st = master;
     if (g > 0) {
@@ -960,7 +1035,7 @@ int CholBatch::factor_all(hipEvent_t after) {
       st = aux[g];
       SL_HIP(hipStreamWaitEvent(st, ev_aux0, 0));
     }
-    launch_chol_batch(sys.data() + lo, hi - lo, d_ctr + (size_t)g * (ctr_cap / CHOL_BATCH_HOST_MAX), st, nullptr, solve);
+    launch_chol_batch(S_.data() + lo, hi - lo, d_ctr + (size_t)g * (ctr_cap / CHOL_BATCH_HOST_MAX), st, nullptr, solve);
     if (g > 0) {
       SL_HIP(hipEventRecord(ev_aux1[g], st));
       SL_HIP(hipStreamWaitEvent(master, ev_aux1[g], 0));
@@ -1316,6 +1391,51 @@ int HostGraph::upload_new() {
     // border items: this robot's shared landmarks and the lambda coordinates of its relative-pose factors, ordered by the first block
     // column of the band in which their coupling row is non-zero (the first observing key frame) — the rows that are still all-zero at a
     // block column are then a SUFFIX of the border, which the steps and the border product skip (the maps below carry the permutation)
+    // Nested dissection of the own pose chain (CholBatch::set_segments): cut the chain at n_seg - 1 places; the separator behind a cut at
+    // pose q0 is [q0, q1) with q1 = 1 + the furthest pose any pose before q0 couples to (a landmark both observe, a relative-pose factor):
+    // nothing couples across it.  Its poses become the FIRST border rows (whole tiles: the second level factors them as a dense system).
+    segs.clear();
+    h_pose_sep.assign(std::max<size_t>(Pn, 1), -1);
+    nsep = nsep_dim = n_sep_poses = 0;
+    const int want_seg = batch ? batch->segments() : 1;
+    if (want_seg >= 2 && Pn >= 64) {
+      std::vector<int> lm_last(Ln, -1), reach(Pn);
+      for (size_t f = 0; f < nlf; ++f) lm_last[h_lf_lm[f]] = std::max(lm_last[h_lf_lm[f]], h_lf_pose[f]);
+      for (size_t p = 0; p < Pn; ++p) reach[p] = (int)p;
+      for (size_t f = 0; f < nlf; ++f) reach[h_lf_pose[f]] = std::max(reach[h_lf_pose[f]], lm_last[h_lf_lm[f]]);
+      for (size_t b = 0; b < nbt; ++b) {
+        const int lo = std::min(h_bt_i[b], h_bt_j[b]), hi = std::max(h_bt_i[b], h_bt_j[b]);
+        reach[lo] = std::max(reach[lo], hi);
+      }
+      std::vector<int> run(Pn);                       // furthest reach of the poses 0 .. p
+      for (size_t p = 0; p < Pn; ++p) run[p] = std::max(reach[p], p ? run[p - 1] : 0);
+      std::vector<std::pair<int, int>> cuts;
+      int seg_start = 0;
+      bool ok = true;
+      std::vector<Seg> tmp;
+      for (int i = 1; i < want_seg && ok; ++i) {
+        const int q0 = (int)(Pn * (size_t)i / want_seg);
+        if (q0 <= seg_start + 8) continue;
+        const int q1 = run[q0 - 1] + 1;
+        if (q1 <= q0 || q1 + 8 >= (int)Pn) continue;      // (nothing couples across q0: no separator needed — or no room for a segment behind it)
+        const Seg sg{6 * seg_start / NB, (6 * q0 + NB - 1) / NB};
+        if (!tmp.empty() && sg.t0 < tmp.back().t1) { ok = false; break; }      // (a separator narrower than a tile: segments would share one)
+        tmp.push_back(sg);
+        cuts.emplace_back(q0, q1);
+        seg_start = q1;
+      }
+      if (ok && !cuts.empty()) {
+        const Seg last{6 * seg_start / NB, (int)((6 * Pn + NB - 1) / NB)};
+        if (last.t0 >= tmp.back().t1) {
+          tmp.push_back(last);
+          segs = tmp;
+          for (const auto& c : cuts)
+            for (int q = c.first; q < c.second; ++q) { h_pose_sep[q] = 6 * n_sep_poses; ++n_sep_poses; }
+          nsep_dim = 6 * n_sep_poses;
+          nsep = (nsep_dim + NB - 1) / NB;
+        }
+      }
+    }
     struct Item { int cb, kind, id, dim, goff; };
     std::vector<Item> items;
     for (int i = 0; i < ns; ++i) {
@@ -1335,7 +1455,7 @@ int HostGraph::upload_new() {
         items.push_back(Item{6 * h_gh_pose[q] / NB, 1, (int)q, 6, m + 6 * h_gh_gid[q]});
       }
     std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.cb < y.cb; });
-    int o = 0;
+    int o = nsep * NB;                                 // (the separator poses' rows come first, in whole tiles)
     for (const Item& it : items) {
       if (it.kind == 0) h_lm_bord[it.id] = o; else h_gh_bord[it.id] = o;
       for (int k = 0; k < it.dim; ++k) h_sep_map[it.goff + k] = o + k;
@@ -1343,14 +1463,20 @@ int HostGraph::upload_new() {
     }
     nbr_new = (o + NB - 1) / NB;
     h_bfirst.assign(nbr_new + 1, 0);
-    for (int t = 0; t < nbr_new; ++t) h_bfirst[t] = 1 << 30;
-    o = 0;
+    for (int t = nsep; t < nbr_new; ++t) h_bfirst[t] = 1 << 30;      // (separator-pose rows: always active, 0)
+    o = nsep * NB;
     for (const Item& it : items) {
       for (int t = o / NB; t <= (o + it.dim - 1) / NB; ++t) h_bfirst[t] = std::min(h_bfirst[t], it.cb);
       o += it.dim;
     }
     for (int t = 0; t < nbr_new; ++t) if (h_bfirst[t] == (1 << 30)) h_bfirst[t] = 0;
     for (int t = 1; t < nbr_new; ++t) h_bfirst[t] = std::max(h_bfirst[t], h_bfirst[t - 1]);      // (non-decreasing by construction; kept so by force)
+    if (d_pose_sep.ensure(h_pose_sep.size(), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    SL_HIP(hipMemcpyAsync(d_pose_sep.d, h_pose_sep.data(), h_pose_sep.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    if (nsep > 0) {
+      if (d_Ld2.ensure((size_t)nsep * NB * NB, 0, s) != SLIDE_OK || d_Winv2.ensure((size_t)nsep * 1024, 0, s) != SLIDE_OK ||
+          d_yv2.ensure((size_t)nsep * NB, 0, s) != SLIDE_OK || d_dp2.ensure((size_t)nsep * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+    }
     if (d_lm_bord.ensure(h_lm_bord.size(), 0, s) != SLIDE_OK || d_sep_map.ensure(h_sep_map.size(), 0, s) != SLIDE_OK ||
         d_bfirst.ensure(h_bfirst.size(), 0, s) != SLIDE_OK || d_gh_bord.ensure(h_gh_bord.size(), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     SL_HIP(hipMemcpyAsync(d_gh_bord.d, h_gh_bord.data(), h_gh_bord.size() * sizeof(int), hipMemcpyHostToDevice, s));
@@ -1491,6 +1617,22 @@ int HostGraph::upload_new() {
   G.arrow = arrow_now ? 1 : 0; G.nbr = nbr; G.lm_bord = arrow_now ? d_lm_bord.d : nullptr; G.bord = arrow_now ? d_bord.d : nullptr;
   G.ldb = (nbr + 1) * NB;
   G.gh_bord = (arrow_now && lam_total > 0) ? d_gh_bord.d : nullptr;
+  G.pose_sep = (arrow_now && nsep > 0) ? d_pose_sep.d : nullptr; G.nsep = arrow_now ? nsep : 0; G.nsep_dim = arrow_now ? nsep_dim : 0;
+  // the segments' own profiles (their rows end where the separator begins: what lay beyond moved into the border)
+  seg_prof.clear(); seg_prof_off.clear();
+  if (arrow_now && nsep > 0) {
+    std::vector<int> flat;
+    for (const Seg& sg : segs) {
+      std::vector<int> pv(sg.t1 - sg.t0);
+      for (int c = sg.t0; c < sg.t1; ++c) pv[c - sg.t0] = std::min(h_prof[c], sg.t1 - 1) - sg.t0;
+      seg_prof_off.push_back(flat.size());
+      flat.insert(flat.end(), pv.begin(), pv.end());
+      seg_prof.push_back(pv);
+    }
+    if (d_seg_prof.ensure(std::max<size_t>(flat.size(), 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    SL_HIP(hipMemcpyAsync(d_seg_prof.d, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    SL_HIP(hipStreamSynchronize(s));
+  }
   G.status = d_status.d;
   G.lm_first = d_lm_first.d; G.col0 = 0;
   G.chart = P.pose_chart;
@@ -1981,6 +2123,15 @@ int HostGraph::get_border_profile(int* out, int cap) {
   if (!arrow_on()) return 0;
   for (int i = 0; i < nbr && i < cap; ++i) out[i] = h_bfirst[i];
   return nbr;
+}
+int HostGraph::get_segments(int* out, int cap) {
+  int rc = merge_pending();
+  if (rc == SLIDE_OK) rc = upload_new();
+  if (rc != SLIDE_OK) return rc < 0 ? rc : -rc;
+  if (!arrow_on() || nsep <= 0) return 1;
+  for (size_t i = 0; i < segs.size() && 2 * (int)i + 1 < cap; ++i) { out[2 * i] = segs[i].t0; out[2 * i + 1] = segs[i].t1; }
+  if (2 * (int)segs.size() < cap) out[2 * segs.size()] = n_sep_poses;
+  return (int)segs.size();
 }
 void HostGraph::set_dense_profile(bool on) {
   if (force_dense == on) return;

@@ -163,7 +163,11 @@ class CholBatch {
   // (packed: lower tile columns only) for the cross-GPU all-reduce, and from which part 2 takes the sum; null: no exchange (the job is
   // this process alone).  Changing it invalidates the captured launch sequences.
   int set_arrow(bool on, double* sep_buf, long long sep_len);
-  int set_separator_profile(const int32_t* prof, int n);      // tile profile of the separator system's landmark part (n = its tile columns), or none: dense
+  int set_separator_profile(const int32_t* prof, int n);
+  // Nested dissection of every robot's own pose chain in exact joint passes: `n` segments per robot factored side by side, the windows
+  // of poses between them (as wide as the band) eliminated at a second level (graph_dev.hpp pose_sep).  1: off.
+  void set_segments(int n_seg);
+  int segments() const { return n_seg; }      // tile profile of the separator system's landmark part (n = its tile columns), or none: dense
   bool is_arrow() const { return arrow; }
   // packed exchange layout of the separator system: ms landmark coordinates + lam lambda coordinates (6 per inter-robot relative-pose factor)
   static long long sep_buffer_len(int ms, int lam = 0) { const long long Tt = (ms + NB - 1) / NB + (lam + NB - 1) / NB; return (long long)NB * NB * Tt * (Tt + 3) / 2; }
@@ -190,6 +194,10 @@ class CholBatch {
   int pcg_iters = 0;
   double pcg_tol = 0.0;
   bool arrow = false;
+  int n_seg = 1;
+  std::vector<CholSystem> seg_sys, l2_sys;          // the segments of all joined graphs as systems of their own (views); the second-level systems
+  std::vector<int> l2_graph;                        // l2_sys[i] belongs to graphs[l2_graph[i]]
+  int* d_ctr2 = nullptr;
   // separator system of the exact joint step: m coordinates, Ts tile columns; factored by the un-batched step kernels on the pass's stream
   double* sepS = nullptr; long long sep_len = 0;          // the system in the factorisation's layout (owned)
   double* sep_x = nullptr; long long sep_x_len = 0;       // the caller's exchange buffer (packed layout), or null: no exchange
@@ -282,7 +290,8 @@ class HostGraph {
   void set_incremental(bool on) { inc_enabled = on; }
   void incremental_stats(int64_t* out4) const { out4[0] = n_inc; out4[1] = n_full; out4[2] = last_cd; out4[3] = G.T; }
   int get_tile_profile(int* out, int cap);
-  int get_border_profile(int* out, int cap);   // nbr (>= 0) or a negative error; out[i] = first block column of border tile row i, i < min(nbr, cap)     // T (>= 0) or a negative error; out[c] = prof[c] for c < min(T, cap)
+  int get_border_profile(int* out, int cap);
+  int get_segments(int* out, int cap);          // number of segments of the band in exact joint passes (1: not cut); out[2 i], out[2 i + 1] = tile range of segment i; out[2 n] = separator poses   // nbr (>= 0) or a negative error; out[i] = first block column of border tile row i, i < min(nbr, cap)     // T (>= 0) or a negative error; out[c] = prof[c] for c < min(T, cap)
   void set_dense_profile(bool on);        // ignore the structure of the reduced system (measurement aid)
   int pcg_stats(double* out8);            // scalars of the last joint solve: gamma_old, alpha_old, alpha, beta, first gamma, last gamma               // entries merge_pending refused since creation
 
@@ -365,6 +374,15 @@ class HostGraph {
   // exact joint step: this robot's border = its shared landmarks in slot order
   std::vector<int> h_sep_off;                          // global offsets (n_slots + 1) or empty
   std::vector<int> h_lm_bord, h_sep_map, h_bfirst;     // landmark -> border offset; global separator coordinate -> border coordinate; first column block per border tile row
+  // nested dissection of the own pose chain (exact joint passes; CholBatch::set_segments)
+  struct Seg { int t0, t1; };                          // tile columns [t0, t1) of a segment
+  std::vector<Seg> segs;
+  std::vector<int> h_pose_sep;                         // pose -> border offset of a separator pose, or -1
+  std::vector<std::vector<int>> seg_prof;              // per segment: its profile in its own numbering (host; plan_step)
+  DevArr<int> d_pose_sep, d_seg_prof;
+  std::vector<size_t> seg_prof_off;
+  int nsep = 0, nsep_dim = 0, n_sep_poses = 0;
+  DevArr<double> d_Ld2, d_Winv2, d_yv2, d_dp2;
   std::vector<int> h_gh_gid, h_gh_bord;                // ghost factor -> index in the job's relative-pose list; -> border offset of its lambda coordinates
   int lam_total = 0;
   DevArr<int> d_lm_bord, d_sep_map, d_bfirst, d_gh_bord;

@@ -34,6 +34,8 @@ void launch_ghost_exchange_batched(const GraphDev* d, int n, int n_gslots, int w
 // gathered from the robots' border blocks (maps[i]: m ints, global separator coordinate -> robot i's border coordinate or -1); its
 // solution handed back
 void launch_border_assemble_batched(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);
+void launch_sep_extract_batched(const GraphDev* d, const GraphDev* h, int n, const int* n_sep_poses, hipStream_t s);      // separator poses out of the band (k_sep_extract_b)
+void launch_sep_pose_scatter_batched(const GraphDev* d, const GraphDev* h, int n, double* const* xloc, hipStream_t s);  // their solution into dp
 // Separator system: Ts tile columns of landmark coordinates (ms real) in sys (ld = (Ts + nl + 1) * NB: band, nl border row tiles = the
 // coupling rows of the lam "lambda" coordinates of the inter-robot relative-pose factors, right-hand-side tile row), the lambda x lambda
 // block + its right-hand-side row in bord (ldb = (nl + 1) * NB); packed: the exchange buffer (lower tile columns of the whole)
@@ -49,7 +51,7 @@ void launch_phase3_arrow_batched(const GraphDev* d, const GraphDev* h, int n, hi
 // leading dimension ld = (T+1)*NB; the extra row tile carries the right-hand side), tile edge NB = 64.
 // ctr: T + 2 ints, zero before the first factorisation (each step clears the next step's work counter itself)
 void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, float* L32, const int* h_prof, hipStream_t s, int nbr = 0);   // L32, h_prof: see CholSystem
-void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s, int nbr = 0);   // also clears status[4], the ticket counter of launch_chol_bwd_all
+void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s, int nbr = 0, int b0 = 0);   // also clears status[4], the ticket counter of launch_chol_bwd_all
 // A quiet-NaN payload no solution value can equal bit for bit: the outputs of the chained substitutions are pre-filled with it and the
 // workgroups poll the blocks they depend on ("flag in data").
 constexpr unsigned long long CHAIN_SENTINEL = 0x7FF8DEADBEEF0BADull;
@@ -61,7 +63,10 @@ struct CholSystem { double* S; int ld, T; double* Ld; double* Winv; double* yv; 
                     int nbr;                     // border row tiles between the band and the right-hand-side row (exact joint step: the separator's coupling rows), see b_decode
                     double* bord; int ldb;       // border x border block of the system ((nbr + 1) * NB rows, nbr * NB columns, column-major) — k_border_syrk
                     const int* bfirst;           // device, nbr + 1 ints: first block column of the band in which border tile row i can be non-zero (non-decreasing)
-                    const int* h_bfirst; };      // host copy (plan_step: the border rows still all-zero at a block column are skipped) or null: every row always
+                    const int* h_bfirst;         // host copy (plan_step: the border rows still all-zero at a block column are skipped) or null: every row always
+                    int b0;                      // tile row (in the system's own row numbering) at which its border rows start; 0: right behind the band (= T).  A SEGMENT of
+                                                 // a robot's band factored as a system of its own (a view: shifted S, profile) has its border further down: b0 = T_robot - first tile
+                    int kofs; };                 // the view's first block column in the robot's numbering (bfirst is in that numbering)
 void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps = nullptr, bool solve = true);            // up to 8 systems, one launch per block column; solve = false: steps + extraction of y only
 void launch_chol_bwd_batch(const CholSystem* d, int n, hipStream_t s);       // yv -> dp of up to 8 factored systems (chained backward substitution)
 // Exact joint step (the border of the systems = the separator's coupling rows, W^T after the steps):

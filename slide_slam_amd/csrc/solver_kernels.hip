@@ -13,6 +13,8 @@
 
 namespace sl {
 
+struct BufPtrs { double* p[8]; };      // per-robot buffers of a batched launch (blockIdx.z = robot)
+
 // ------------------------------------------------------------------------------------------------
 // variable (+) tangent, per variable type
 // ------------------------------------------------------------------------------------------------
@@ -1061,6 +1063,81 @@ __global__ __launch_bounds__(256) void k_border_fill_b(const GraphDev* __restric
   }
   if (lane < D) G.bord[(size_t)(o + lane) * G.ldb + (size_t)G.nbr * NB] = -acc[45 + lane];
 }
+// Separator poses out of the band (nested dissection of the robot's pose chain, graph_dev.hpp pose_sep).  The assembly wrote the
+// whole reduced system in pose order; for every separator pose q (one workgroup) its entries move to where a border variable lives:
+//   S(r, c), c in q's columns, r >= c:   pose(r) a separator pose too -> bord(o_r, o_c)           (separator x separator block)
+//                                        else (a pose of the segment behind) -> border row o_c + ., column r   (transposed)
+//   S(r, c), r in q's rows, c < r, pose(c) NOT a separator pose (the segment before) -> border row o_r + ., column c
+//   border rows (shared landmarks, lambdas) at q's columns -> bord(row, o_c);   right-hand side at q's columns -> bord's RHS row
+// and the band keeps a unit diagonal / zeros / a zero right-hand side there: the segments on both sides no longer couple.  Every entry
+// has ONE owner (the column strip owns separator x separator entries), so nothing is read after another workgroup cleared it.
+__global__ __launch_bounds__(256) void k_sep_extract_b(const GraphDev* __restrict__ Gs, int max_sep) {
+  const GraphDev G = Gs[blockIdx.z];
+  if (!G.arrow || !G.pose_sep || G.nsep <= 0) return;
+  // the blockIdx.x-th separator pose of this robot
+  __shared__ int s_q;
+  if (threadIdx.x == 0) {
+    int cnt = -1, q = -1;
+    for (int p = 0; p < G.P; ++p)
+      if (G.pose_sep[p] >= 0 && ++cnt == (int)blockIdx.x) { q = p; break; }
+    s_q = q;
+  }
+  __syncthreads();
+  const int q = s_q;
+  if (q < 0) return;
+  (void)max_sep;
+  const int tid = threadIdx.x, oq = G.pose_sep[q], NT = G.T * NB;
+  const size_t ld = G.ld, ldb = G.ldb;
+  const size_t brow = (size_t)G.T * NB;                      // first border row of S
+  const int nb_rows = G.nbr * NB;                            // border rows (the separator poses' own rows among them: nothing there yet)
+  // (1) column strip: rows 6q .. end of the profile of q's last column's tile, plus the border rows and the right-hand side
+  const int r_end = G.prof ? min(NT, (G.prof[(6 * q + 5) / NB] + 1) * NB) : NT;
+  for (int e = tid; e < 6 * (r_end - 6 * q); e += 256) {
+    const int a = e % 6, r = 6 * q + e / 6, c = 6 * q + a;
+    if (r < c) continue;
+    double* src = G.S + (size_t)c * ld + r;
+    const double v = *src;
+    const int pr = r / 6;
+    if (pr < G.P) {
+      const int orr = G.pose_sep[pr];
+      if (orr >= 0) G.bord[(size_t)(oq + a) * ldb + orr + (r - 6 * pr)] = v;                     // separator x separator (o_r >= o_c: lower)
+      else G.S[(size_t)r * ld + brow + oq + a] = v;                                             // segment behind: border row of q, column r
+    }
+    *src = (r == c) ? 1.0 : 0.0;
+  }
+  for (int e = tid; e < 6 * nb_rows; e += 256) {             // border rows at q's columns -> bord(row, o_c)
+    const int a = e % 6, b = e / 6;
+    double* src = G.S + (size_t)(6 * q + a) * ld + brow + b;
+    const double v = *src;
+    if (v != 0.0) { G.bord[(size_t)(oq + a) * ldb + b] = v; *src = 0.0; }
+  }
+  if (tid < 6) {                                             // right-hand side
+    double* src = G.S + (size_t)(6 * q + tid) * ld + brow + (size_t)G.nbr * NB;
+    G.bord[(size_t)(oq + tid) * ldb + (size_t)G.nbr * NB] = *src;
+    *src = 0.0;
+  }
+  if (blockIdx.x == 0)                                       // unit diagonal on the padding of the separator part (whole tiles)
+    for (int p = G.nsep_dim + tid; p < G.nsep * NB; p += 256) G.bord[(size_t)p * ldb + p] = 1.0;
+  // (2) row strip: columns from the first column the profile lets reach q's rows, poses that are no separator poses only
+  const int c_beg = G.first ? G.first[(6 * q) / NB] * NB : 0;
+  for (int e = tid; e < 6 * (6 * q - c_beg); e += 256) {
+    const int a = e % 6, c = c_beg + e / 6, r = 6 * q + a;
+    const int pc = c / 6;
+    if (pc >= G.P || G.pose_sep[pc] >= 0) continue;
+    double* src = G.S + (size_t)c * ld + r;
+    G.S[(size_t)c * ld + brow + oq + a] = *src;                                                  // border row of q, column c
+    *src = 0.0;
+  }
+}
+// the separator poses' solution (the second level's) into the band's solution vector, which holds zeros there
+__global__ __launch_bounds__(256) void k_sep_pose_scatter_b(const GraphDev* __restrict__ Gs, BufPtrs X) {
+  const GraphDev G = Gs[blockIdx.z];
+  if (!G.arrow || !G.pose_sep || G.nsep <= 0) return;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 6 * G.P) return;
+  const int o = G.pose_sep[t / 6];
+  if (o >= 0) G.dp[t] = X.p[blockIdx.z][o + t % 6];
+}
 // lambda rows of the inter-robot relative-pose factors: 36 threads per ghost factor write J (6 x 6, whitened, w.r.t. the own pose) into
 // the border rows at the pose's columns; the first-key side also writes -I onto the border block's diagonal and -r into its RHS row
 __global__ __launch_bounds__(256) void k_border_fill_lam_b(const GraphDev* __restrict__ Gs) {
@@ -1278,7 +1355,6 @@ void launch_backsub(const GraphDev& G, int mode, hipStream_t s) {
   else if (mode == 1) hipLaunchKernelGGL(k_backsub<1>, dim3(nb), dim3(256), 0, s, G);
   else hipLaunchKernelGGL(k_backsub<2>, dim3(nb), dim3(256), 0, s, G);
 }
-struct BufPtrs { double* p[8]; };
 __global__ void k_shared_unpack_b(const GraphDev* __restrict__ Gs, int what, BufPtrs B) {
   const GraphDev G = Gs[blockIdx.z];
   const int w = what == 0 ? 54 : (what == 1 ? 9 : 15);
@@ -1391,6 +1467,20 @@ void launch_estimate(const GraphDev& G, hipStream_t s) {
   hipLaunchKernelGGL(k_estimate, dim3(blocks_for(G.P + G.L, 256)), dim3(256), 0, s, G);
 }
 
+void launch_sep_extract_batched(const GraphDev* d, const GraphDev* h, int n, const int* n_sep_poses, hipStream_t s) {
+  int mx = 0;
+  for (int i = 0; i < n; ++i) mx = std::max(mx, (h[i].arrow && h[i].pose_sep) ? n_sep_poses[i] : 0);
+  if (mx > 0) hipLaunchKernelGGL(k_sep_extract_b, dim3(mx, 1, n), dim3(256), 0, s, d, mx);
+}
+void launch_sep_pose_scatter_batched(const GraphDev* d, const GraphDev* h, int n, double* const* xloc, hipStream_t s) {
+  int P = 0;
+  bool any = false;
+  for (int i = 0; i < n; ++i) { P = std::max(P, h[i].P); any = any || (h[i].arrow && h[i].pose_sep && h[i].nsep > 0); }
+  if (!any || P == 0) return;
+  BufPtrs X{};
+  for (int i = 0; i < n; ++i) X.p[i] = xloc[i];
+  hipLaunchKernelGGL(k_sep_pose_scatter_b, dim3(blocks_for(6LL * P, 256), 1, n), dim3(256), 0, s, d, X);
+}
 void launch_border_assemble_batched(const GraphDev* d, const GraphDev* h, int n, hipStream_t s) {
   int slots = 0;
   long long work = 0;

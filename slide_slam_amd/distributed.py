@@ -315,6 +315,8 @@ class PassDriver:
             batch.set_exact_joint(self.arrow, 0, 0)      # (the exchange buffer of a cut pass is installed on first use: _sep_exchange_buffer)
             if self.arrow and sep_prof is not None:
                 batch.set_separator_profile(sep_prof)    # (tile profile of the separator system: the same on every rank)
+            import os
+            batch.set_segments(int(os.environ.get("SLIDE_SEGMENTS", "1")) if self.arrow else 1)
         if batch is not None:           # (always pushed, zero included: a batch or graph may still hold an earlier driver's setting)
             batch.set_pcg(self.pcg_iters, self.pcg_tol)
         else:

@@ -412,6 +412,8 @@ def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1, re
         res.setdefault("chi2_pass", []).append(sum(x.graph.chi2()["total"] for x in A))
         say("pass", p + 1, "GPU vs oracle", res["gpu_vs_oracle"][-1], "step", res["step"][-1], "vs joint", res["vs_joint"][-1:], "ms", res["ms"][-1], "chi2", res["chi2_pass"][-1])
     res["finite"] = bool(np.isfinite(prev).all())
+    res["segments"] = [a.graph.segments() for a in A]
+    say("segments of the bands:", res["segments"][:2])
     res["chi2"] = sum(x.graph.chi2()["total"] for x in A)
     if R * P <= 2000:
         res["final"] = prev.tolist()

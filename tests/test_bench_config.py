@@ -125,6 +125,27 @@ def test_c4_exact_joint_step_matches_oracle_shards_at_size(gpu, tmp_path):
     assert abs(z["chi2_pass"][3] - z["chi2_pass"][2]) < 1e-4 * z["chi2_pass"][3], z["chi2_pass"]
 
 
+@pytest.mark.parametrize("n_seg", [2, 4])
+def test_exact_joint_step_with_segmented_bands(gpu, tmp_path, n_seg):
+    """Nested dissection of every robot's own pose chain inside the exact joint pass (slide_chol_batch_set_segments; opt-in through
+    SLIDE_SEGMENTS): the band is cut at windows of poses as wide as the band's reach, the windows' poses move into the border
+    (k_sep_extract_b), the segments are factored side by side as views of S, the windows' own dense system is eliminated at a second
+    level inside the border block, and the substitutions run back through both levels.  Only the elimination order changes: C3 at size
+    (2 x 500 poses) against oracle shards, pass by pass, as without the cut."""
+    out = str(tmp_path / "seg.json")
+    os.environ["SLIDE_SEGMENTS"] = str(n_seg)
+    try:
+        _scenario("arrow_parity", out, "C3", 4, "ingest", 0, 1)
+    finally:
+        os.environ.pop("SLIDE_SEGMENTS", None)
+    z = json.load(open(out))
+    assert z["finite"] and max(z["gpu_vs_oracle"]) < 1e-6, z["gpu_vs_oracle"]
+    for segs, n_sep in z["segments"]:
+        assert len(segs) == n_seg and n_sep > 10, z["segments"]
+        assert all(a[1] <= b[0] for a, b in zip(segs, segs[1:])) and segs[0][0] == 0
+    assert z["step"][3] < 1e-2 * z["step"][1], z["step"]
+
+
 def test_c3_full_size_exact_joint_step_reaches_the_replica_optimum_1e4_on_poses(gpu, tmp_path):
     """configs[2] at size, the bar VERDICT r2 asked to restore: 2 robots x 500 poses, 188 shared landmarks; the sharded passes with the
     exact joint step end within 1e-4 RELATIVE ON POSES of the optimum of the joint graph a single host replica holds (streaming build +
