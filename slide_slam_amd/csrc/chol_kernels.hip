@@ -1349,9 +1349,15 @@ struct SyrkArgs {
   const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX]; int nbr[CHOL_BATCH_MAX];
   double* bord[CHOL_BATCH_MAX]; int ldb[CHOL_BATCH_MAX]; const int* bfirst[CHOL_BATCH_MAX];
   int ks; double* scratch;
+  const int* jobs;       // or null: (system << 20 | ib << 10 | jb) per workgroup, longest sums first (launch_border_syrk_jobs)
 };
 __global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
-  const int r = A.ks > 1 ? 0 : blockIdx.z, q = A.ks > 1 ? blockIdx.z : 0, ib = blockIdx.x, jb = blockIdx.y;
+  int r = A.ks > 1 ? 0 : blockIdx.z, ib = blockIdx.x, jb = blockIdx.y;
+  const int q = A.ks > 1 ? blockIdx.z : 0;
+  if (A.jobs) {
+    const int j = A.jobs[blockIdx.x];
+    r = j >> 20; ib = (j >> 10) & 1023; jb = j & 1023;
+  }
   const int nbr = A.nbr[r];
   if (ib > nbr || jb >= nbr || ib < jb) return;
   const int T = A.T[r], ld = A.ld[r];
@@ -1367,6 +1373,7 @@ __global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
   const double* S = A.S[r];
   const int wq = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
   const int ch = (wq >> 1) & 1, rh = wq & 1;      // column half, row half of the tile
+  if (A.jobs && ib == nbr && rh == 1) return;     // right-hand-side row tile: only its first row is in use (the others are zero and stay zero)
   const double* pjh = S + (size_t)(c0 * NB + lk) * ld + (size_t)(T + jb) * NB + 32 * ch + 2 * lr;
   const double* pih = S + (size_t)(c0 * NB + lk) * ld + (size_t)(T + ib) * NB + 32 * rh + 2 * lr;
   double* cbh = A.bord[r] + (size_t)(jb * NB + 32 * ch + 2 * lk) * ldb + (size_t)ib * NB + 32 * rh + 2 * lr;
@@ -1455,6 +1462,21 @@ void launch_border_syrk(const CholSystem* d, int n, hipStream_t s, double* scrat
   }
   A.ks = 1; A.scratch = nullptr;
   hipLaunchKernelGGL(k_border_syrk, dim3(nb + 1, nb, n), dim3(256), 0, s, A);
+}
+// The same product with the workgroups in the order of a job table (all systems' lower tiles + right-hand-side rows, longest sum first)
+// and lds_pad bytes of idle dynamic LDS per workgroup to bound the workgroups resident on a CU: the hardware dispatcher then hands the
+// next job to whichever slot frees first — longest-processing-time list scheduling.  With the plain (ib, jb, system) grid all ~1800
+// workgroups of eight robots become resident at once, six or seven per CU, and a CU's finishing time is the sum of whatever it was
+// dealt (sums of 0 .. T column blocks: the slowest CU carries ~1.6 x the mean).
+void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int njobs, int lds_pad, hipStream_t s) {
+  SyrkArgs A{};
+  A.n = n;
+  for (int i = 0; i < n; ++i) {
+    A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.nbr[i] = d[i].nbr; A.bord[i] = d[i].bord; A.ldb[i] = d[i].ldb; A.bfirst[i] = d[i].bfirst;
+  }
+  if (njobs <= 0) return;
+  A.ks = 1; A.scratch = nullptr; A.jobs = jobs;
+  hipLaunchKernelGGL(k_border_syrk, dim3(njobs), dim3(256), lds_pad, s, A);
 }
 // y -= W x_loc before the backward substitution of the band (x_loc: the separator's solution in the system's own border order, zeros
 // in the padding): one wave per column of the band, lanes over the border rows (contiguous down a column of S)

@@ -417,6 +417,7 @@ CholBatch::~CholBatch() {
   if (pass_exec) (void)hipGraphExecDestroy(pass_exec);
   free_separator();
   if (d_ctr2) (void)hipFree(d_ctr2);
+  if (d_syrk_jobs) (void)hipFree(d_syrk_jobs);
   if (d_Gs) (void)hipFree(d_Gs);
   if (d_status_all) (void)hipFree(d_status_all);
   if (ev_aux0) (void)hipEventDestroy(ev_aux0);
@@ -542,6 +543,53 @@ int CholBatch::prepare_pass() {
       l2.bord = G.bord + (size_t)G.nsep * NB * G.ldb + (size_t)G.nsep * NB; l2.ldb = G.ldb;
       l2_sys.push_back(l2);
       l2_graph.push_back(i);
+    }
+    {
+      // the border product's job table: its order only schedules (the kernel takes the sums' ranges from the device's bfirst)
+      std::vector<std::pair<int, int>> jl;
+      for (int i = 0; i < n; ++i) {
+        const int nb = sys[i].nbr, T = sys[i].T;
+        const int* hb = sys[i].h_bfirst;
+        if (nb > 1023 || n > 2047) { jl.clear(); break; }
+        for (int jb = 0; jb < nb; ++jb)
+          for (int ib = jb; ib <= nb; ++ib) jl.emplace_back(T - (hb ? std::max(hb[ib], hb[jb]) : 0), i << 20 | ib << 10 | jb);
+      }
+      std::stable_sort(jl.begin(), jl.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
+      if (getenv("SLIDE_SYRK_XCD") && !jl.empty()) {
+        // (experiment, off: workgroup p of a launch runs on XCD p % 8; position p takes the next (longest) job of "its" robot while that
+        // robot has any left, else of the robot with the most left, so that the jobs of a robot — which read the same ~20 row panels —
+        // meet in ONE L2.  tools/syrk_bench.hip on eight equal robots: 0.632 -> 0.604 ms; on C4's unequal ones 0.435 -> 0.468 ms)
+        std::vector<std::vector<std::pair<int, int>>> q(n);
+        for (const auto& e : jl) q[e.second >> 20].push_back(e);
+        std::vector<size_t> head(n, 0);
+        std::vector<std::pair<int, int>> out;
+        out.reserve(jl.size());
+        for (size_t p = 0; p < jl.size(); ++p) {
+          int r = (int)(p % 8) % n;
+          if (head[r] >= q[r].size()) {
+            size_t best = 0;
+            for (int t = 0; t < n; ++t)
+              if (q[t].size() - head[t] > best) { best = q[t].size() - head[t]; r = t; }
+          }
+          out.push_back(q[r][head[r]++]);
+        }
+        jl.swap(out);
+      }
+      n_syrk_jobs = (int)jl.size();
+      if (n_syrk_jobs > syrk_jobs_cap) {
+        if (d_syrk_jobs) { SL_HIP(hipStreamSynchronize(master)); SL_HIP(hipFree(d_syrk_jobs)); d_syrk_jobs = nullptr; }
+        syrk_jobs_cap = 2 * n_syrk_jobs;
+        SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_syrk_jobs), (size_t)syrk_jobs_cap * sizeof(int)));
+      }
+      if (n_syrk_jobs > 0) {
+        std::vector<int> codes(jl.size());
+        for (size_t k = 0; k < jl.size(); ++k) codes[k] = jl[k].second;
+        SL_HIP(hipStreamSynchronize(master));
+        SL_HIP(hipMemcpy(d_syrk_jobs, codes.data(), codes.size() * sizeof(int), hipMemcpyHostToDevice));
+      }
+      const char* e = getenv("SLIDE_SYRK_LDS");
+      syrk_lds_pad = e ? atoi(e) : 0;
+      if (getenv("SLIDE_SYRK_PLAIN")) n_syrk_jobs = 0;
     }
     if (!d_ctr2) {
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_ctr2), 64 * sizeof(int)));
@@ -719,7 +767,8 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     const int rc = factor_all(e1);                                   // the segments' steps: W^T and y in the border rows
     if (rc != SLIDE_OK) return rc;
     mark(1);
-    launch_border_syrk(sys.data(), n, master);                       // border blocks: C_a - W^T W, b_s - W^T y
+    if (n_syrk_jobs > 0) launch_border_syrk_jobs(sys.data(), n, d_syrk_jobs, n_syrk_jobs, syrk_lds_pad, master);      // border blocks: C_a - W^T W, b_s - W^T y
+    else launch_border_syrk(sys.data(), n, master);
     if (!l2_sys.empty()) {
       // second level: the separator poses' own system (dense, nsep block columns) with the rest of the border as its border
       launch_chol_batch(l2_sys.data(), (int)l2_sys.size(), d_ctr2, master, nullptr, false);

@@ -198,6 +198,8 @@ class CholBatch {
   std::vector<CholSystem> seg_sys, l2_sys;          // the segments of all joined graphs as systems of their own (views); the second-level systems
   std::vector<int> l2_graph;                        // l2_sys[i] belongs to graphs[l2_graph[i]]
   int* d_ctr2 = nullptr;
+  int* d_syrk_jobs = nullptr;                       // border product: (system << 20 | ib << 10 | jb) of every lower tile + right-hand-side row, longest sum first
+  int n_syrk_jobs = 0, syrk_jobs_cap = 0, syrk_lds_pad = 0;
   // separator system of the exact joint step: m coordinates, Ts tile columns; factored by the un-batched step kernels on the pass's stream
   double* sepS = nullptr; long long sep_len = 0;          // the system in the factorisation's layout (owned)
   double* sep_x = nullptr; long long sep_x_len = 0;       // the caller's exchange buffer (packed layout), or null: no exchange

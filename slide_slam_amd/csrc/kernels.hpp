@@ -71,6 +71,7 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
 void launch_chol_bwd_batch(const CholSystem* d, int n, hipStream_t s);       // yv -> dp of up to 8 factored systems (chained backward substitution)
 // Exact joint step (the border of the systems = the separator's coupling rows, W^T after the steps):
 void launch_border_syrk(const CholSystem* d, int n, hipStream_t s, double* scratch = nullptr, int ks = 1);          // bord(i, j) -= sum_c W^T(i, c) W^T(j, c)^T, i >= j, right-hand-side row included; scratch + ks: split K (one system)
+void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int njobs, int lds_pad, hipStream_t s);      // the same, workgroups in the order of a job table (system << 20 | ib << 10 | jb), lds_pad bytes of idle LDS per workgroup (bounds the residency)
 void launch_border_apply(const CholSystem* d, int n, const double* const* xloc, hipStream_t s);   // yv -= W x_loc (x_loc: nbr * NB doubles per system)
 // one of the two triangular solves with the finished factors of up to 8 systems on arbitrary vectors (T * NB doubles each): out = L^-1 in
 // (fwd) or L^-T in (bwd); the preconditioner of the joint solve (pcg_kernels.hip)

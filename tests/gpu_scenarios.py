@@ -222,7 +222,7 @@ def c3_converge(out, preset="C3", passes=400, every=20, pcg=0, unbatched=0, arro
     bufs, info = setup_local_shards(shards, gpu_matcher, device=dev)
     drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, device=dev, pcg_iters=pcg, arrow=bool(arrow), sep_dim=info["sep_dim"], sep_prof=info.get("sep_prof"))
     nrm = np.linalg.norm(joint.reshape(R, -1), axis=1) if joint is not None else None
-    hist = []
+    hist, chi2_hist = [], []
     t_pass = 0.0
     for p in range(passes):
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -232,7 +232,8 @@ def c3_converge(out, preset="C3", passes=400, every=20, pcg=0, unbatched=0, arro
             d = poses_of(shards, P)
             e = float((np.linalg.norm((d - joint).reshape(R, -1), axis=1) / nrm).max()) if joint is not None else float("nan")
             hist.append((p + 1, e))
-            say("pass", p + 1, "rel err vs joint", e, "chi2 sum", sum(sh.graph.chi2()["total"] for sh in shards), "ms/pass so far", 1e3 * t_pass / (p + 1),
+            chi2_hist.append(float(sum(sh.graph.chi2()["total"] for sh in shards)))
+            say("pass", p + 1, "rel err vs joint", e, "chi2 sum", chi2_hist[-1], "ms/pass so far", 1e3 * t_pass / (p + 1),
                 shards[0].graph.pcg_stats() if pcg else "")
     cs = [sh.graph.chi2() for sh in shards]
     say("shards chi2 after", cs, "sum", sum(c["total"] for c in cs))
@@ -253,7 +254,7 @@ def c3_converge(out, preset="C3", passes=400, every=20, pcg=0, unbatched=0, arro
     if batch is not None:
         for sh in shards:
             sh.graph.join_chol_batch(None)
-    json.dump(dict(hist=hist, n_slots=info["n_slots"], final=poses_of(shards, P).tolist(), chi2_shards=sum(c["total"] for c in cs),
+    json.dump(dict(hist=hist, chi2_hist=chi2_hist, worst_copy=worst, n_slots=info["n_slots"], final=poses_of(shards, P).tolist(), chi2_shards=sum(c["total"] for c in cs),
                    chi2_joint=(float(chi2_joint) if joint is not None else None), ms_per_pass=1e3 * t_pass / max(passes, 1),
                    n_global=[int(v) for v in info["n_global"]], joint_counts=joint_counts), open(out, "w"))
 

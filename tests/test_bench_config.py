@@ -160,6 +160,22 @@ def test_c3_full_size_exact_joint_step_reaches_the_replica_optimum_1e4_on_poses(
     assert abs(z["chi2_shards"] - z["chi2_joint"]) <= 1e-5 * z["chi2_joint"], (z["chi2_shards"], z["chi2_joint"])
 
 
+def test_c3_with_the_surveys_noise_values_does_not_diverge(gpu, tmp_path):
+    """SURVEY 8d's noise values taken literally (preset C3spec: the yaml's noise-model sigmas used as the synthetic noise, 20 x the
+    odometry and 10 x the detection noise of C3).  The robots' independently built maps then drift metres apart and the reference's own
+    matcher rule pairs only a fraction of the landmarks both robots saw, so the sharded passes end at the optimum of a
+    different association than the joint replica's — but the exact joint passes must not diverge: the cost falls monotonically (to
+    rounding) and is stationary from the third pass on."""
+    out = str(tmp_path / "c3spec.json")
+    _scenario("c3_converge", out, "C3spec", 8, 1, 0, 0, 1)
+    z = json.load(open(out))
+    c = z["chi2_hist"]
+    assert z["n_slots"] > 0 and np.isfinite(c).all() and np.isfinite(np.array(z["final"])).all()
+    assert all(b <= a * (1 + 1e-6) for a, b in zip(c, c[1:])), c
+    assert abs(c[-1] - c[2]) < 1e-4 * c[-1], c
+    assert z["hist"][-1][1] < 0.1, z["hist"]                 # a different association's optimum, centimetres from the replica's
+
+
 def test_exact_joint_step_two_ranks_equal_one_process(gpu, tmp_path):
     """configs[2] and configs[3] as TWO ranks on the one visible GPU (1 resp. 4 robots per rank; the pass cut at its ONE exchange, the
     all-reduce of the packed separator system through gloo staged on the host standing in for RCCL) == one process holding all robots."""
