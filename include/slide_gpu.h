@@ -209,6 +209,15 @@ int slide_chol_batch_set_exact_joint(slide_chol_batch_t* b, int on, double* sep_
  * coordinates laid out along the robots' adjacency (slide_graph_set_separator takes any layout) the system is block-banded; the caller
  * knows every robot's observer set (the cross-robot association), the batch only its own robots'.  Not set: dense. */
 int slide_chol_batch_set_separator_profile(slide_chol_batch_t* b, const int32_t* prof, int n);
+/* Nested dissection of the separator system itself.  The robots split into two sets; a shared landmark seen only by robots of one set
+ * couples with none seen only by robots of the other, so the layout puts those two "leaf" blocks first (Ta, Tb tile columns; each
+ * starts at a tile boundary, used_a / used_b coordinates of it carry slots, the rest of its last tile is padding and gets a unit
+ * diagonal) and the landmarks seen from both sets ("top" block) behind them.  The leaves are factored side by side — half the serial
+ * chain of block columns, and no arithmetic on the structural zeros between them — with the top block's rows riding as their border
+ * (as the lambda rows do), then the top block.  The profile (above) must end each leaf at its own last tile row.  Same step: only the
+ * elimination order changes.  (0, 0, 0, 0): not dissected (default).  The reference has no counterpart: its replica solves the joint
+ * system inside GTSAM (graph.cpp:260-272), whose elimination order is COLAMD's. */
+int slide_chol_batch_set_separator_blocks(slide_chol_batch_t* b, int Ta, int Tb, int used_a, int used_b);
 /* Nested dissection of every robot's own pose chain inside an exact joint pass: the banded pose system of a robot is a serial chain of
  * block columns (one launch each); cut into n_seg segments at windows of poses as wide as the band is (every coupling across a window
  * passes through it), the segments are factored side by side as systems of their own, and the windows' poses — moved into the border

@@ -1461,6 +1461,10 @@ inline int Graph::dist_phase(int phase, double* buf) {
       for (int i = 0; i < m; ++i) xs[i] = buf[(size_t)m * m + i];
       std::vector<double> K11((size_t)ms * ms);
       for (int i = 0; i < ms; ++i) std::memcpy(&K11[(size_t)i * ms], &Ks[(size_t)i * m], sizeof(double) * ms);
+      // a coordinate of the layout that no slot uses (the padding between the blocks of a dissected layout, distributed.py
+      // separator_offsets) receives no contribution at all: unit pivot, solution 0
+      for (int i = 0; i < ms; ++i)
+        if (K11[(size_t)i * ms + i] == 0.0 && xs[i] == 0.0) K11[(size_t)i * ms + i] = 1.0;
       if (ms > 0 && chol_lower(K11.data(), ms, ms, P.num_threads) != 0) return -4;
       for (int i = 0; i < ms; ++i) {          // z1
         double s2 = xs[i];

@@ -1430,18 +1430,20 @@ __global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
 }
 __global__ __launch_bounds__(256) void k_border_syrk_reduce(double* __restrict__ bord, int ldb, int nbr, int ks, const double* __restrict__ scratch,
                                                             const int* __restrict__ bfirst, int T) {
-  const int ib = blockIdx.x, jb = blockIdx.y;
+  // one element per thread: blockIdx.x = 16 ib + the tile's sixteenth (a workgroup per tile looping over its 4096 elements took 54 us
+  // for ~180 tiles, all of it load latency); gridDim.y may stop short of nbr: only the tile columns the product was run for
+  const int ib = blockIdx.x >> 4, jb = blockIdx.y;
   if (ib > nbr || jb >= nbr || ib < jb) return;
   int c0 = 0;
   if (bfirst) c0 = max(bfirst[ib], bfirst[jb]);
   const int len = (T - c0 + ks - 1) / ks;
-  for (int e = threadIdx.x; e < NB * NB; e += 256) {
-    const int col = e / NB, row = e - col * NB;
-    double v = bord[(size_t)(jb * NB + col) * ldb + (size_t)ib * NB + row];
-    for (int q = 1; q < ks; ++q)
-      if (c0 + q * len < T) v += scratch[((size_t)(jb * (nbr + 1) + ib) * (ks - 1) + (q - 1)) * (NB * NB) + (size_t)col * NB + row];
-    bord[(size_t)(jb * NB + col) * ldb + (size_t)ib * NB + row] = v;
-  }
+  const int e = (blockIdx.x & 15) * 256 + threadIdx.x;
+  const int col = e / NB, row = e - col * NB;
+  double* dst = bord + (size_t)(jb * NB + col) * ldb + (size_t)ib * NB + row;
+  double v = *dst;
+  for (int q = 1; q < ks; ++q)
+    if (c0 + q * len < T) v += scratch[((size_t)(jb * (nbr + 1) + ib) * (ks - 1) + (q - 1)) * (NB * NB) + (size_t)col * NB + row];
+  *dst = v;
 }
 // scratch (or null): (nbr + 1) * nbr * (ks - 1) tiles of NB * NB doubles — with it, ONE system's product is split over ks chunks of its
 // column blocks (a system with a handful of border tiles would otherwise occupy a handful of CUs for the whole K)
@@ -1457,7 +1459,7 @@ void launch_border_syrk(const CholSystem* d, int n, hipStream_t s, double* scrat
   if (scratch && n == 1 && ks > 1) {
     A.ks = ks; A.scratch = scratch;
     hipLaunchKernelGGL(k_border_syrk, dim3(nb + 1, nb, ks), dim3(256), 0, s, A);
-    hipLaunchKernelGGL(k_border_syrk_reduce, dim3(nb + 1, nb), dim3(256), 0, s, d[0].bord, d[0].ldb, d[0].nbr, ks, scratch, d[0].bfirst, d[0].T);
+    hipLaunchKernelGGL(k_border_syrk_reduce, dim3(16 * (nb + 1), nb), dim3(256), 0, s, d[0].bord, d[0].ldb, d[0].nbr, ks, scratch, d[0].bfirst, d[0].T);
     return;
   }
   A.ks = 1; A.scratch = nullptr;
@@ -1468,7 +1470,9 @@ void launch_border_syrk(const CholSystem* d, int n, hipStream_t s, double* scrat
 // next job to whichever slot frees first — longest-processing-time list scheduling.  With the plain (ib, jb, system) grid all ~1800
 // workgroups of eight robots become resident at once, six or seven per CU, and a CU's finishing time is the sum of whatever it was
 // dealt (sums of 0 .. T column blocks: the slowest CU carries ~1.6 x the mean).
-void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int njobs, int lds_pad, hipStream_t s) {
+// scratch + ks > 1 (one system): split K as in launch_border_syrk; jb_end >= 0: the table holds the tile columns jb < jb_end only (the
+// rest of the border block is somebody else's: the lambda block of the separator system)
+void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int njobs, int lds_pad, hipStream_t s, double* scratch, int ks, int jb_end) {
   SyrkArgs A{};
   A.n = n;
   for (int i = 0; i < n; ++i) {
@@ -1476,13 +1480,20 @@ void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int nj
   }
   if (njobs <= 0) return;
   A.ks = 1; A.scratch = nullptr; A.jobs = jobs;
+  if (scratch && n == 1 && ks > 1) {
+    A.ks = ks; A.scratch = scratch;
+    hipLaunchKernelGGL(k_border_syrk, dim3(njobs, 1, ks), dim3(256), lds_pad, s, A);
+    const int nb = d[0].nbr;
+    hipLaunchKernelGGL(k_border_syrk_reduce, dim3(16 * (nb + 1), jb_end >= 0 ? jb_end : nb), dim3(256), 0, s, d[0].bord, d[0].ldb, nb, ks, scratch, d[0].bfirst, d[0].T);
+    return;
+  }
   hipLaunchKernelGGL(k_border_syrk, dim3(njobs), dim3(256), lds_pad, s, A);
 }
 // y -= W x_loc before the backward substitution of the band (x_loc: the separator's solution in the system's own border order, zeros
 // in the padding): one wave per column of the band, lanes over the border rows (contiguous down a column of S)
 struct BorderApplyArgs {
   int n;
-  const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX]; int nbr[CHOL_BATCH_MAX];
+  const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX]; int nbr[CHOL_BATCH_MAX]; int b0[CHOL_BATCH_MAX];
   double* yv[CHOL_BATCH_MAX]; const double* x[CHOL_BATCH_MAX];
 };
 __global__ __launch_bounds__(256) void k_border_apply(BorderApplyArgs A) {
@@ -1490,7 +1501,7 @@ __global__ __launch_bounds__(256) void k_border_apply(BorderApplyArgs A) {
   const int col = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (col >= A.T[r] * NB) return;
   const int nrow = A.nbr[r] * NB;
-  const double* w = A.S[r] + (size_t)col * A.ld[r] + (size_t)A.T[r] * NB;
+  const double* w = A.S[r] + (size_t)col * A.ld[r] + (size_t)A.b0[r] * NB;      // (b0: first border tile row — T, or further down for a view)
   const double* x = A.x[r];
   double acc = 0.0;
   for (int q = lane; q < nrow; q += 64) acc += w[q] * x[q];
@@ -1504,6 +1515,7 @@ void launch_border_apply(const CholSystem* d, int n, const double* const* xloc, 
   int Tmax = 0;
   for (int i = 0; i < n; ++i) {
     A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.nbr[i] = d[i].nbr; A.yv[i] = d[i].yv; A.x[i] = xloc[i];
+    A.b0[i] = d[i].b0 > 0 ? d[i].b0 : d[i].T;
     Tmax = d[i].T > Tmax ? d[i].T : Tmax;
   }
   if (Tmax > 0) hipLaunchKernelGGL(k_border_apply, dim3(Tmax * NB / 4, 1, n), dim3(256), 0, s, A);

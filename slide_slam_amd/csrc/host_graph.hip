@@ -605,7 +605,8 @@ void CholBatch::free_separator() {
   if (sepS) (void)hipFree(sepS);
   sepS = nullptr; sep_len = 0;
   for (double** p : {&sep_Ld, &sep_Winv, &sep_yv, &sep_dp, &sep_bord, &lamS, &lam_Ld, &lam_Winv, &lam_yv, &lam_dp, &lam_scratch}) if (*p) { (void)hipFree(*p); *p = nullptr; }
-  for (int** p : {&sep_status, &sep_ctr, &d_sep_off, &lam_status, &lam_ctr, &d_sep_prof}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  for (int** p : {&sep_status, &sep_ctr, &d_sep_off, &lam_status, &lam_ctr, &d_sep_prof, &d_leaf_prof, &sep_ctr2, &d_sep_jobs}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (sep_scratch) { (void)hipFree(sep_scratch); sep_scratch = nullptr; }
   sep_cap = 0; lam_cap = -1;
 }
 void CholBatch::set_segments(int n) {
@@ -626,6 +627,17 @@ int CholBatch::set_separator_profile(const int32_t* prof, int n) {
   for (int c = 0; c < n; ++c)
     if (prof[c] < c || prof[c] >= n || (c && prof[c] < prof[c - 1])) { g_last_error = "separator profile: prof[c] must be monotone with c <= prof[c] < n"; return SLIDE_ERR_INVALID; }
   h_sep_prof.assign(prof, prof + n);
+  pass_dirty = true;
+  return SLIDE_OK;
+}
+int CholBatch::set_separator_blocks(int Ta, int Tb, int used_a, int used_b) {
+  std::lock_guard<std::mutex> pl(pass_mtx);
+  std::lock_guard<std::mutex> lk(mtx);
+  if (Ta < 0 || Tb < 0 || (Ta > 0) != (Tb > 0) || used_a < 0 || used_b < 0 || used_a > Ta * NB || used_b > Tb * NB || (Ta > 0 && (used_a <= (Ta - 1) * NB || used_b <= (Tb - 1) * NB))) {
+    g_last_error = "separator blocks: two leaf blocks of Ta, Tb > 0 tile columns whose last tiles hold at least one used coordinate (or 0, 0: not dissected)";
+    return SLIDE_ERR_INVALID;
+  }
+  sep_leafT[0] = Ta; sep_leafT[1] = Tb; sep_used[0] = used_a; sep_used[1] = used_b;
   pass_dirty = true;
   return SLIDE_OK;
 }
@@ -714,6 +726,45 @@ int CholBatch::prepare_separator() {
     SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_prof), (size_t)sep_Ts * sizeof(int)));
     SL_HIP(hipMemcpy(d_sep_prof, h_sep_prof.data(), (size_t)sep_Ts * sizeof(int), hipMemcpyHostToDevice));
   }
+  if (sep_dissected()) {
+    const int Ta = sep_leafT[0], Tb = sep_leafT[1], TL = Ta + Tb, Tt = sep_Ts - TL, nb = Tt + sep_nl;
+    if (Tt <= 0 || !sep_prof_on || h_sep_prof[Ta - 1] != Ta - 1 || h_sep_prof[TL - 1] != TL - 1 || sep_m <= TL * NB) {
+      g_last_error = "separator blocks: they need a profile (slide_chol_batch_set_separator_profile) that ends each leaf block at its own last tile row, and a top block behind them";
+      return SLIDE_ERR_INVALID;
+    }
+    SL_HIP(hipStreamSynchronize(master));
+    for (int** p : {&d_leaf_prof, &sep_ctr2, &d_sep_jobs}) if (*p) { SL_HIP(hipFree(*p)); *p = nullptr; }
+    if (sep_scratch) { SL_HIP(hipFree(sep_scratch)); sep_scratch = nullptr; }
+    std::vector<int> both;
+    for (int b = 0; b < 2; ++b) {
+      const int t0 = b ? Ta : 0, T = sep_leafT[b];
+      h_leaf_prof[b].resize(T);
+      for (int c = 0; c < T; ++c) h_leaf_prof[b][c] = h_sep_prof[t0 + c] - t0;
+      both.insert(both.end(), h_leaf_prof[b].begin(), h_leaf_prof[b].end());
+    }
+    SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_leaf_prof), both.size() * sizeof(int)));
+    SL_HIP(hipMemcpy(d_leaf_prof, both.data(), both.size() * sizeof(int), hipMemcpyHostToDevice));
+    SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_ctr2), ((size_t)std::max(Ta, Tb) + 2) * sizeof(int)));
+    SL_HIP(hipMemset(sep_ctr2, 0, ((size_t)std::max(Ta, Tb) + 2) * sizeof(int)));
+    // the top block's product over the leaves' TL column blocks: tile columns of the top block only (the lambda x lambda block is
+    // formed after the top block's own steps, over all Ts column blocks), K split so that the launch fills the chip
+    std::vector<int> codes;
+    for (int jb = 0; jb < Tt; ++jb)
+      for (int ib = jb; ib <= nb; ++ib) codes.push_back(ib << 10 | jb);
+    n_sep_jobs = (int)codes.size();
+    SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_jobs), codes.size() * sizeof(int)));
+    SL_HIP(hipMemcpy(d_sep_jobs, codes.data(), codes.size() * sizeof(int), hipMemcpyHostToDevice));
+    sep_ks = std::max(1, std::min({8, TL / 4, (1024 + n_sep_jobs - 1) / std::max(n_sep_jobs, 1)}));
+    if (sep_ks > 1) {
+      const size_t len = (size_t)(nb + 1) * nb * (sep_ks - 1) * NB * NB * sizeof(double);
+      SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_scratch), len));
+      SL_HIP(hipMemset(sep_scratch, 0, len));      // (the idle half of a right-hand-side tile's partials is never written: it must read as zero)
+    }
+    // the backward substitution runs over the whole system: its profile must cover the top block's rows under the leaves' columns
+    std::vector<int> cover(h_sep_prof);
+    for (int c = 0; c < TL; ++c) cover[c] = sep_Ts - 1;
+    SL_HIP(hipMemcpy(d_sep_prof, cover.data(), (size_t)sep_Ts * sizeof(int), hipMemcpyHostToDevice));
+  }
   if (d_sep_off) { SL_HIP(hipFree(d_sep_off)); d_sep_off = nullptr; }
   SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_off), off.size() * sizeof(int)));
   SL_HIP(hipMemcpy(d_sep_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -782,10 +833,37 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
   if (whole || part == 2) {
     if (!whole) launch_sep_unpack(Y, master);
     // landmark part of the separator: the dense step kernels, the lambda coordinates' coupling rows riding as ITS border
-    for (int k = 0; k < sep_Ts; ++k)
-      launch_chol_step(sepS, ld_s, k, sep_Ts, sep_Ld + (size_t)k * NB * NB, sep_Winv + (size_t)k * 1024, sep_status, sep_ctr, nullptr,
-                       sep_prof_on ? h_sep_prof.data() : nullptr, master, sep_nl);
-    launch_chol_extract_y(sepS, ld_s, sep_Ts, sep_yv, sep_dp, sep_status, master, sep_nl);
+    // (dissected separator) the two leaf blocks as systems of their own: views of sepS, the top block's and the lambdas' rows as border
+    CholSystem lv[2];
+    const int sTa = sep_leafT[0], sTL = sTa + sep_leafT[1], sTt = sep_Ts - sTL;
+    if (sep_dissected())
+      for (int b = 0; b < 2; ++b) {
+        const int t0 = b ? sTa : 0;
+        CholSystem c{};
+        c.S = sepS + (size_t)t0 * NB * ld_s + (size_t)t0 * NB; c.ld = ld_s; c.T = sep_leafT[b];
+        c.Ld = sep_Ld + (size_t)t0 * NB * NB; c.Winv = sep_Winv + (size_t)t0 * 1024; c.yv = sep_yv + (size_t)t0 * NB; c.dp = sep_dp + (size_t)t0 * NB;
+        c.status = sep_status; c.h_prof = h_leaf_prof[b].data(); c.prof = d_leaf_prof + (b ? sTa : 0);
+        c.nbr = sTt + sep_nl; c.b0 = sTL - t0; c.kofs = t0;
+        lv[b] = c;
+      }
+    if (sep_dissected()) {
+      // the leaves side by side (no robot couples them); the top block's Schur complement; the top block's own steps
+      const int TL = sTL, Tt = sTt;
+      launch_chol_batch(lv, 2, sep_ctr2, master, nullptr, false);
+      CholSystem top{};
+      top.S = sepS; top.ld = ld_s; top.T = TL; top.nbr = Tt + sep_nl;
+      top.bord = sepS + (size_t)TL * NB * ld_s + (size_t)TL * NB; top.ldb = ld_s;
+      launch_border_syrk_jobs(&top, 1, d_sep_jobs, n_sep_jobs, 0, master, sep_scratch, sep_ks, Tt);
+      double* St = sepS + (size_t)TL * NB * ld_s + (size_t)TL * NB;
+      for (int k = 0; k < Tt; ++k)
+        launch_chol_step(St, ld_s, k, Tt, sep_Ld + (size_t)(TL + k) * NB * NB, sep_Winv + (size_t)(TL + k) * 1024, sep_status, sep_ctr, nullptr, nullptr, master, sep_nl);
+      launch_chol_extract_y(St, ld_s, Tt, sep_yv + (size_t)TL * NB, sep_dp + (size_t)TL * NB, sep_status, master, sep_nl);
+    } else {
+      for (int k = 0; k < sep_Ts; ++k)
+        launch_chol_step(sepS, ld_s, k, sep_Ts, sep_Ld + (size_t)k * NB * NB, sep_Winv + (size_t)k * 1024, sep_status, sep_ctr, nullptr,
+                         sep_prof_on ? h_sep_prof.data() : nullptr, master, sep_nl);
+      launch_chol_extract_y(sepS, ld_s, sep_Ts, sep_yv, sep_dp, sep_status, master, sep_nl);
+    }
     if (sep_nl > 0) {
       // the inter-robot relative-pose factors: K22 - L21 L21^T is negative definite; factor its negative, lambda = -M^-1 (r2 - L21 z1),
       // then z1 -= L21^T lambda before the landmark part's backward substitution
@@ -802,7 +880,20 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
       const double* xl = lam_dp;
       launch_border_apply(&ss, 1, &xl, master);
     }
-    launch_chol_bwd_all(sepS, ld_s, sep_Ts, sep_Ld, sep_Winv, sep_yv, sep_dp, sep_status, sep_prof_on ? d_sep_prof : nullptr, master);
+    if (sep_dissected()) {
+      // back through the levels: the top block, y_leaf -= W_top^T x_top, the two leaves side by side (37 hops instead of 60)
+      double* St = sepS + (size_t)sTL * NB * ld_s + (size_t)sTL * NB;
+      launch_chol_bwd_all(St, ld_s, sTt, sep_Ld + (size_t)sTL * NB * NB, sep_Winv + (size_t)sTL * 1024, sep_yv + (size_t)sTL * NB, sep_dp + (size_t)sTL * NB,
+                          sep_status, nullptr, master);
+      launch_ints_clear(sep_status + 4, 1, master);                  // (the chain's ticket counter: the leaves' chains draw from it next)
+      CholSystem ap[2] = {lv[0], lv[1]};
+      ap[0].nbr = ap[1].nbr = sTt;                                    // (the lambdas' part went onto y above, over all column blocks)
+      const double* xt[2] = {sep_dp + (size_t)sTL * NB, sep_dp + (size_t)sTL * NB};
+      launch_border_apply(ap, 2, xt, master);
+      launch_chol_bwd_batch(lv, 2, master);
+    } else {
+      launch_chol_bwd_all(sepS, ld_s, sep_Ts, sep_Ld, sep_Winv, sep_yv, sep_dp, sep_status, sep_prof_on ? d_sep_prof : nullptr, master);
+    }
     mark(4);
     launch_sep_xloc(n, maps, sep_m, sep_lam, sep_dp, lam_dp, xloc, master);
     if (!l2_sys.empty()) {

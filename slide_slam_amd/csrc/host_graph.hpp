@@ -164,6 +164,7 @@ class CholBatch {
   // this process alone).  Changing it invalidates the captured launch sequences.
   int set_arrow(bool on, double* sep_buf, long long sep_len);
   int set_separator_profile(const int32_t* prof, int n);
+  int set_separator_blocks(int Ta, int Tb, int used_a, int used_b);      // nested dissection of the separator system: two leaf blocks + top block (zeros: off)
   // Nested dissection of every robot's own pose chain in exact joint passes: `n` segments per robot factored side by side, the windows
   // of poses between them (as wide as the band) eliminated at a second level (graph_dev.hpp pose_sep).  1: off.
   void set_segments(int n_seg);
@@ -208,12 +209,27 @@ class CholBatch {
   int *sep_status = nullptr, *sep_ctr = nullptr, *d_sep_off = nullptr;
   int sep_cap = 0;
   std::vector<int> h_sep_prof; int* d_sep_prof = nullptr; bool sep_prof_on = false;
+  // nested dissection of the separator system (set_separator_blocks): two leaf blocks of sep_leafT[0], sep_leafT[1] tile columns that no
+  // robot couples, factored side by side as views of sepS with the top block's rows (and the lambda rows) as their border, then the top
+  // block; sep_used[b]: coordinates of leaf b that carry a slot (the rest of its last tile is padding with a unit diagonal)
+  int sep_leafT[2] = {0, 0}, sep_used[2] = {0, 0};
+  std::vector<int> h_leaf_prof[2];                  // the leaves' own profiles (relative to the view)
+  int* d_leaf_prof = nullptr;                       // both, one after the other (backward substitutions of the views)
+  int* sep_ctr2 = nullptr; int* d_sep_jobs = nullptr; int n_sep_jobs = 0; double* sep_scratch = nullptr; int sep_ks = 1;
+  bool sep_dissected() const { return sep_leafT[0] > 0 && sep_leafT[1] > 0; }
   // lambda coordinates of the inter-robot relative-pose factors: border rows of the separator system, their own small system
   int sep_lam = 0, sep_nl = 0, lam_cap = -1;
   double *lam_scratch = nullptr;      // partial products of the separator's own border product (split K)
   double *sep_bord = nullptr, *lamS = nullptr, *lam_Ld = nullptr, *lam_Winv = nullptr, *lam_yv = nullptr, *lam_dp = nullptr;
   int *lam_status = nullptr, *lam_ctr = nullptr;
-  SepLayout sep_layout() const { return SepLayout{sepS, sep_bord, sep_x, sep_Ts, sep_nl, sep_m, sep_lam}; }
+  SepLayout sep_layout() const {
+    SepLayout Y{sepS, sep_bord, sep_x, sep_Ts, sep_nl, sep_m, sep_lam, {0, 0, 0, 0}};
+    if (sep_dissected()) {
+      Y.gap[0] = sep_used[0]; Y.gap[1] = sep_leafT[0] * NB;
+      Y.gap[2] = sep_leafT[0] * NB + sep_used[1]; Y.gap[3] = (sep_leafT[0] + sep_leafT[1]) * NB;
+    }
+    return Y;
+  }
   int prepare_separator();
   int enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hipEvent_t e1);
   hipEvent_t prof_ev[6] = {};

@@ -39,7 +39,7 @@ void launch_sep_pose_scatter_batched(const GraphDev* d, const GraphDev* h, int n
 // Separator system: Ts tile columns of landmark coordinates (ms real) in sys (ld = (Ts + nl + 1) * NB: band, nl border row tiles = the
 // coupling rows of the lam "lambda" coordinates of the inter-robot relative-pose factors, right-hand-side tile row), the lambda x lambda
 // block + its right-hand-side row in bord (ldb = (nl + 1) * NB); packed: the exchange buffer (lower tile columns of the whole)
-struct SepLayout { double* sys; double* bord; double* packed; int Ts, nl, ms, lam; };
+struct SepLayout { double* sys; double* bord; double* packed; int Ts, nl, ms, lam; int gap[4]; };      // gap: two ranges [lo, hi) of landmark coordinates no slot uses (padding between the blocks of a dissected layout): unit diagonal
 void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, const SepLayout& Y, bool packed, hipStream_t s);
 void launch_sep_unpack(const SepLayout& Y, hipStream_t s);
 void launch_lam_prepare(const double* bord, int nl, int lam, double* out, hipStream_t s);      // M = -(K22 - L21 L21^T), rhs = -(r2 - L21 z1)
@@ -71,7 +71,7 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
 void launch_chol_bwd_batch(const CholSystem* d, int n, hipStream_t s);       // yv -> dp of up to 8 factored systems (chained backward substitution)
 // Exact joint step (the border of the systems = the separator's coupling rows, W^T after the steps):
 void launch_border_syrk(const CholSystem* d, int n, hipStream_t s, double* scratch = nullptr, int ks = 1);          // bord(i, j) -= sum_c W^T(i, c) W^T(j, c)^T, i >= j, right-hand-side row included; scratch + ks: split K (one system)
-void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int njobs, int lds_pad, hipStream_t s);      // the same, workgroups in the order of a job table (system << 20 | ib << 10 | jb), lds_pad bytes of idle LDS per workgroup (bounds the residency)
+void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int njobs, int lds_pad, hipStream_t s, double* scratch = nullptr, int ks = 1, int jb_end = -1);      // the same, workgroups in the order of a job table (system << 20 | ib << 10 | jb), lds_pad bytes of idle LDS per workgroup (bounds the residency)
 void launch_border_apply(const CholSystem* d, int n, const double* const* xloc, hipStream_t s);   // yv -= W x_loc (x_loc: nbr * NB doubles per system)
 // one of the two triangular solves with the finished factors of up to 8 systems on arbitrary vectors (T * NB doubles each): out = L^-1 in
 // (fwd) or L^-T in (bwd); the preconditioner of the joint solve (pcg_kernels.hip)

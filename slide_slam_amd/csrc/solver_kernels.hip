@@ -1194,6 +1194,8 @@ __global__ __launch_bounds__(256) void k_sep_gather(SepGatherArgs A) {
   double s = 0.0;
   if (gc < 0 || gr < 0) {
     s = (vr == vc && vc < NL) ? 1.0 : 0.0;      // unit diagonal on the landmark padding (the lambda padding is set by k_lam_prepare)
+  } else if (vr == vc && ((vc >= Y.gap[0] && vc < Y.gap[1]) || (vc >= Y.gap[2] && vc < Y.gap[3]))) {
+    s = A.packed ? 0.0 : 1.0;                   // padding between the blocks of a dissected layout (a packed partial sum gets it in k_sep_unpack)
   } else {
     for (int r = 0; r < A.n; ++r) {
       const int lc = A.map[r][gc];
@@ -1209,7 +1211,9 @@ __global__ __launch_bounds__(256) void k_sep_unpack(SepLayout Y) {
   const int vr = blockIdx.x * 256 + threadIdx.x, vc = blockIdx.y;
   const int NT = (Y.Ts + Y.nl) * NB;
   if (vr > NT || vc >= NT || vr < vc / NB * NB) return;
-  *sep_slot(Y, vr, vc, false) = *sep_slot(Y, vr, vc, true);
+  double v = *sep_slot(Y, vr, vc, true);
+  if (vr == vc && ((vc >= Y.gap[0] && vc < Y.gap[1]) || (vc >= Y.gap[2] && vc < Y.gap[3]))) v = 1.0;
+  *sep_slot(Y, vr, vc, false) = v;
 }
 // the lambda coordinates' own system after the landmark part is eliminated: bord holds K22 - L21 L21^T (negative definite) and
 // r2 - L21 z1; M = -(that) is positive definite and M lambda = -(r2 - L21 z1).  out: Tl = nl tile columns, ld = (nl + 1) * NB, unit
