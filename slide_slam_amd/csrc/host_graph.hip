@@ -605,7 +605,7 @@ void CholBatch::free_separator() {
   if (sepS) (void)hipFree(sepS);
   sepS = nullptr; sep_len = 0;
   for (double** p : {&sep_Ld, &sep_Winv, &sep_yv, &sep_dp, &sep_bord, &lamS, &lam_Ld, &lam_Winv, &lam_yv, &lam_dp, &lam_scratch}) if (*p) { (void)hipFree(*p); *p = nullptr; }
-  for (int** p : {&sep_status, &sep_ctr, &d_sep_off, &lam_status, &lam_ctr, &d_sep_prof, &d_leaf_prof, &sep_ctr2, &d_sep_jobs}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  for (int** p : {&sep_status, &sep_ctr, &d_sep_off, &lam_status, &lam_ctr, &d_sep_prof, &d_leaf_prof, &sep_ctr2, &d_sep_jobs, &d_sep_tmask}) if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (sep_scratch) { (void)hipFree(sep_scratch); sep_scratch = nullptr; }
   sep_cap = 0; lam_cap = -1;
 }
@@ -765,6 +765,20 @@ int CholBatch::prepare_separator() {
     for (int c = 0; c < TL; ++c) cover[c] = sep_Ts - 1;
     SL_HIP(hipMemcpy(d_sep_prof, cover.data(), (size_t)sep_Ts * sizeof(int), hipMemcpyHostToDevice));
   }
+  {
+    // which graphs hold coordinates of which tile (landmark tiles, then the lambdas' tiles at virtual index Ts * NB + b)
+    std::vector<int> tm(sep_Ts + sep_nl, 0);
+    for (int i = 0; i < n && i < 32; ++i) {
+      const std::vector<int>& mp = graphs[i]->h_sep_map;
+      for (int g = 0; g < sep_m + sep_lam && g < (int)mp.size(); ++g)
+        if (mp[g] >= 0) tm[g < sep_m ? g / NB : sep_Ts + (g - sep_m) / NB] |= 1 << i;
+    }
+    if (d_sep_tmask) { SL_HIP(hipStreamSynchronize(master)); SL_HIP(hipFree(d_sep_tmask)); d_sep_tmask = nullptr; }
+    if (n <= 32 && !tm.empty()) {
+      SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_tmask), tm.size() * sizeof(int)));
+      SL_HIP(hipMemcpy(d_sep_tmask, tm.data(), tm.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+  }
   if (d_sep_off) { SL_HIP(hipFree(d_sep_off)); d_sep_off = nullptr; }
   SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_off), off.size() * sizeof(int)));
   SL_HIP(hipMemcpy(d_sep_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -827,7 +841,7 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     }
     mark(2);
     // a cut pass leaves this GPU's partial sum in the caller's exchange buffer (packed), a whole pass writes the system itself
-    launch_sep_gather(hG.data(), n, maps, Y, !whole, master);
+    launch_sep_gather(hG.data(), n, maps, Y, !whole, master, d_sep_tmask);
     mark(3);
   }
   if (whole || part == 2) {

@@ -215,6 +215,7 @@ class CholBatch {
   int sep_leafT[2] = {0, 0}, sep_used[2] = {0, 0};
   std::vector<int> h_leaf_prof[2];                  // the leaves' own profiles (relative to the view)
   int* d_leaf_prof = nullptr;                       // both, one after the other (backward substitutions of the views)
+  int* d_sep_tmask = nullptr;                       // per (virtual) tile of the separator: which joined graphs hold coordinates of it (k_sep_gather)
   int* sep_ctr2 = nullptr; int* d_sep_jobs = nullptr; int n_sep_jobs = 0; double* sep_scratch = nullptr; int sep_ks = 1;
   bool sep_dissected() const { return sep_leafT[0] > 0 && sep_leafT[1] > 0; }
   // lambda coordinates of the inter-robot relative-pose factors: border rows of the separator system, their own small system

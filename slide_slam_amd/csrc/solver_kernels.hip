@@ -1180,6 +1180,7 @@ struct SepGatherArgs {
   int n, packed;
   SepLayout Y;
   const double* bord[8]; int ldb[8]; int nbr[8]; const int* map[8];      // map: ms + lam ints, separator coordinate -> robot's border coordinate or -1
+  const int* tmask;      // or null: per virtual tile (Ts landmark + nl lambda tiles), bit r set = robot r holds a coordinate of the tile
 };
 __global__ __launch_bounds__(256) void k_sep_gather(SepGatherArgs A) {
   const SepLayout& Y = A.Y;
@@ -1197,7 +1198,10 @@ __global__ __launch_bounds__(256) void k_sep_gather(SepGatherArgs A) {
   } else if (vr == vc && ((vc >= Y.gap[0] && vc < Y.gap[1]) || (vc >= Y.gap[2] && vc < Y.gap[3]))) {
     s = A.packed ? 0.0 : 1.0;                   // padding between the blocks of a dissected layout (a packed partial sum gets it in k_sep_unpack)
   } else {
+    // only the robots that hold coordinates of BOTH tiles can contribute (two or three of eight on a grid of robot cells)
+    unsigned cand = A.tmask ? (unsigned)A.tmask[vc / NB] & (rhs ? ~0u : (unsigned)A.tmask[vr / NB]) : ~0u;
     for (int r = 0; r < A.n; ++r) {
+      if (!((cand >> r) & 1u)) continue;
       const int lc = A.map[r][gc];
       if (lc < 0) continue;
       const int lr = rhs ? A.nbr[r] * NB : A.map[r][gr];
@@ -1503,9 +1507,9 @@ void launch_sep_unpack(const SepLayout& Y, hipStream_t s) {
   const int NT = (Y.Ts + Y.nl) * NB;
   if (NT > 0) hipLaunchKernelGGL(k_sep_unpack, dim3((NT + 1 + 255) / 256, NT), dim3(256), 0, s, Y);
 }
-void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, const SepLayout& Y, bool packed, hipStream_t s) {
+void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, const SepLayout& Y, bool packed, hipStream_t s, const int* tmask) {
   SepGatherArgs A{};
-  A.n = n; A.Y = Y; A.packed = packed ? 1 : 0;
+  A.n = n; A.Y = Y; A.packed = packed ? 1 : 0; A.tmask = tmask;
   for (int i = 0; i < n; ++i) { A.bord[i] = h[i].bord; A.ldb[i] = h[i].ldb; A.nbr[i] = h[i].nbr; A.map[i] = maps[i]; }
   const int NT = (Y.Ts + Y.nl) * NB;
   if (NT > 0) hipLaunchKernelGGL(k_sep_gather, dim3((NT + 1 + 255) / 256, NT), dim3(256), 0, s, A);
