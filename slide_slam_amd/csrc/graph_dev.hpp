@@ -116,6 +116,11 @@ struct GraphDev {
                        //     rows of the reduced system a relinearisation changes) — 0: nothing was relinearised
   int col0;            // columns of S below it hold the factor of the last solve and are left alone by the assembly (k_schur, k_pad_rhs);
                        // their right-hand-side entries are the forward-substituted ones of that solve (yv).  0: assemble everything.
+  // ---- Schur assembly from pair lists (batched exact passes: the topology is fixed between the passes) ------------------------------
+  const int* sp_idx;        // or null.  (start, count) into sp_pairs of block (row pose pj + d, column pose pj) at 2 (pj * sp_w + d), d < sp_w
+  const long long* sp_pairs;// 2 per pair: pose_ed of the row pose's factor (its F record), pose_ed of the column pose's factor (its E record) —
+                            // every pair of factors of the two poses on the same private landmark, in the order of the two poses' lists
+  int sp_w;                 // widest strip of a pose column inside the profile, in poses
   int* status;       // [0] not-SPD flag (landmark), [1] not-SPD flag (chol), [2] #relinearised, [6] see lm_first
   // ---- parameters ------------------------------------------------------------------------
   int chart;

@@ -1792,7 +1792,67 @@ int HostGraph::upload_new() {
   G.chart = P.pose_chart;
   G.bearing_sigma = P.bearing_range_sigma; G.cyl_sigma = P.cylinder_sigma; G.numdiff_delta = P.numdiff_delta;
   launch_pose_adj(G, s);             // the topology changed: rebuild the pose adjacency of the Schur assembly
+  G.sp_idx = nullptr; G.sp_pairs = nullptr; G.sp_w = 0;
+  if (arrow_now && !getenv("SLIDE_SCHUR_WALK")) {
+    const int rc = build_schur_pairs(s);
+    if (rc != SLIDE_OK) return rc;
+  }
   return sync_lm_slot();
+}
+// Pair lists of the Schur assembly.  k_schur's block (pi, pj) is the sum over the pairs (factor x of pose pi, factor y of pose pj) on one
+// landmark of F_x E_y^T; walking pose pi's list and looking every landmark up in pose pj's costs ~20 probes per block for ~2 hits.  Between
+// the passes of a batched job the topology does not change, so the hits are listed once, in the order the walk finds them (x ascending
+// in pi's list, y ascending in pj's).  Separator landmarks are left out (H_ll^-1 = 0 there: their F is zero).  Only inside a monotone
+// profile whose strips are at most 256 poses wide; otherwise (and on every streaming update, which changes the topology) k_schur walks.
+int HostGraph::build_schur_pairs(hipStream_t s) {
+  const int Pn = (int)pose_fids.size();
+  if (Pn == 0 || h_prof.empty() || !G.prof) return SLIDE_OK;
+  auto p_end = [&](int pj) { return std::min(Pn, ((h_prof[(6 * pj + 5) / NB] + 1) * NB + 5) / 6); };
+  int W = 1;
+  for (int pj = 0; pj < Pn; ++pj) W = std::max(W, p_end(pj) - pj);
+  if (W > 256) return SLIDE_OK;
+  std::vector<int> idx((size_t)2 * Pn * W, 0);
+  std::vector<long long> pairs;
+  auto ed_of = [&](int f) {
+    const int ty = h_lm_type[h_lf_lm[f]];
+    return ((long long)h_lf_eoff[f] << 4) | (ty == VT_POINT ? 3 : (ty == VT_CUBE ? 9 : 7));
+  };
+  const bool have_bord = !h_lm_bord.empty();
+  std::vector<std::vector<std::pair<int, int>>> rows(W);      // per d = pi - pj: (x, y) factor ids
+  for (int pj = 0; pj < Pn; ++pj) {
+    const int pe = p_end(pj);
+    for (auto& r : rows) r.clear();
+    // every factor y of pose pj: the other factors x of its landmark on poses pi in [pj, pe)
+    for (int y : pose_fids[pj]) {
+      const int l = h_lf_lm[y];
+      if (have_bord && (size_t)l < h_lm_bord.size() && h_lm_bord[l] >= 0) continue;
+      for (int x : lm_fids[l]) {
+        const int pi = h_lf_pose[x];
+        if (pi >= pj && pi < pe) rows[pi - pj].emplace_back(x, y);
+      }
+    }
+    for (int d = 0; d < pe - pj; ++d) {
+      auto& r = rows[d];
+      if (r.empty()) continue;
+      // the walk's order: x in the order of pose pi's list (landmark id, factor id), then y in the order of pose pj's list
+      std::sort(r.begin(), r.end(), [&](const std::pair<int, int>& a, const std::pair<int, int>& b) {
+        const int la = h_lf_lm[a.first], lb = h_lf_lm[b.first];
+        if (la != lb) return la < lb;
+        if (a.first != b.first) return a.first < b.first;
+        return a.second < b.second;
+      });
+      idx[2 * ((size_t)pj * W + d)] = (int)(pairs.size() / 2);
+      idx[2 * ((size_t)pj * W + d) + 1] = (int)r.size();
+      for (const auto& xy : r) { pairs.push_back(ed_of(xy.first)); pairs.push_back(ed_of(xy.second)); }
+    }
+  }
+  if (pairs.size() / 2 > (size_t)0x7fffffff) return SLIDE_OK;
+  if (d_sp_idx.ensure(idx.size(), 0, s) != SLIDE_OK || d_sp_pairs.ensure(std::max<size_t>(pairs.size(), 2), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  SL_HIP(hipMemcpyAsync(d_sp_idx.d, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, s));
+  if (!pairs.empty()) SL_HIP(hipMemcpyAsync(d_sp_pairs.d, pairs.data(), pairs.size() * sizeof(long long), hipMemcpyHostToDevice, s));
+  SL_HIP(hipStreamSynchronize(s));      // (pageable temporaries)
+  G.sp_idx = d_sp_idx.d; G.sp_pairs = d_sp_pairs.d; G.sp_w = W;
+  return SLIDE_OK;
 }
 int HostGraph::sync_lm_slot() {
   if (h_sh_lid.empty()) {            // no shared slots (single-robot graphs, replicas): nothing reads the table

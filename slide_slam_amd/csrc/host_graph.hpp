@@ -367,7 +367,9 @@ class HostGraph {
   size_t up_gh = 0;
   DevArr<int> d_lf_type, d_lf_pose, d_lf_lm, d_lf_slot;
   DevArr<int64_t> d_lf_joff, d_lf_eoff;
-  DevArr<long long> d_pose_ed;
+  DevArr<long long> d_pose_ed, d_sp_pairs;
+  DevArr<int> d_sp_idx;                   // pair lists of the Schur assembly (GraphDev::sp_idx), rebuilt by upload_new for graphs in an exact joint batch
+  int build_schur_pairs(hipStream_t s);
   DevArr<unsigned> d_pose_adj;
   DevArr<double> d_br_z, d_cu_z, d_cu_sigma, d_cy_z, d_jbuf, d_ebuf;
   DevArr<int> d_lm_ptr, d_lm_fids, d_pose_ptr, d_pose_fids, d_pose_lms, d_pose_bt_ptr, d_pose_bt;

@@ -659,6 +659,7 @@ void launch_pose_adj(const GraphDev& G, hipStream_t s) {
   if (G.P > 0) hipLaunchKernelGGL(k_pose_adj, dim3(G.P), dim3(256), (size_t)G.adj_words * sizeof(unsigned), s, G);
 }
 
+template <bool LISTED>
 __device__ __forceinline__ void k_schur_body(const GraphDev& G) {
   __shared__ double schur_tile[6][192];
   __shared__ long long pj_ed[SCHUR_PJ_CAP];
@@ -671,16 +672,20 @@ __device__ __forceinline__ void k_schur_body(const GraphDev& G) {
   // relative-pose factor with pose j — only those blocks of the strip are non-zero, all others are written as zeros unseen
   unsigned* adj = reinterpret_cast<unsigned*>(schur_slot + (G.L + 7) / 8 * 8);
   const int adj_words = (G.P + 31) / 32 + 1;
-  for (int t = tid; t < G.L; t += 256) schur_slot[t] = -1;
-  __syncthreads();
+  constexpr bool listed = LISTED;               // pair lists (HostGraph::build_schur_pairs): nothing to look up
+  if (!listed) {
+    for (int t = tid; t < G.L; t += 256) schur_slot[t] = -1;
+    __syncthreads();
+  }
   // (the bitmap depends on the topology only: k_pose_adj builds it once per change of the graph, not in every pass)
   for (int t = tid; t < adj_words; t += 256) adj[t] = G.pose_adj[(size_t)pj * G.adj_words + t];
   const int b0 = G.pose_ptr[pj], nb = G.pose_ptr[pj + 1] - b0;
-  for (int q = tid; q < nb; q += 256) {
-    const int l = G.pose_lms[b0 + q];
-    if (q == 0 || G.pose_lms[b0 + q - 1] != l) schur_slot[l] = (short)q;
-    if (q < SCHUR_PJ_CAP) { pj_lm[q] = l; pj_ed[q] = G.pose_ed[b0 + q]; }
-  }
+  if (!listed)
+    for (int q = tid; q < nb; q += 256) {
+      const int l = G.pose_lms[b0 + q];
+      if (q == 0 || G.pose_lms[b0 + q - 1] != l) schur_slot[l] = (short)q;
+      if (q < SCHUR_PJ_CAP) { pj_lm[q] = l; pj_ed[q] = G.pose_ed[b0 + q]; }
+    }
   __syncthreads();
   const int sub = tid & 7;
   // rows below the profile of this column's tile are structurally zero and stay untouched (zero since the last change of profile)
@@ -741,8 +746,37 @@ __device__ __forceinline__ void k_schur_body(const GraphDev& G) {
         }
       }
     }
+    if (listed) {
+      // own share of the block's pair list, two pairs at a time: F_x E_y^T
+      const int q0 = G.sp_idx[2 * ((size_t)pj * G.sp_w + (pi - pj))], q1 = q0 + G.sp_idx[2 * ((size_t)pj * G.sp_w + (pi - pj)) + 1];
+      for (int x = q0 + sub; x < q1; x += 8) {
+        const long long ex = G.sp_pairs[2 * (size_t)x], ey = G.sp_pairs[2 * (size_t)x + 1];
+        const int D = (int)(ex & 15);
+        const double* F = G.ebuf + (ex >> 4) + 6 * D;
+        const double* E = G.ebuf + (ey >> 4);
+        if (D == 3) {
+          double e[18], f[18];
+#pragma unroll
+          for (int k = 0; k < 18; ++k) { e[k] = E[k]; f[k] = F[k]; }
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[6 * a + c] -= f[3 * a] * e[3 * c] + f[3 * a + 1] * e[3 * c + 1] + f[3 * a + 2] * e[3 * c + 2];
+        } else {
+          for (int k = 0; k < D; ++k) {
+            double fk[6], ek[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { fk[a] = F[a * D + k]; ek[a] = E[a * D + k]; }
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+              for (int c = 0; c < 6; ++c) acc[6 * a + c] -= fk[a] * ek[c];
+          }
+        }
+      }
+    }
     // own share of pose i's list, three entries at a time: first all index loads and LDS look-ups, then the records
-    const int a0 = G.pose_ptr[pi], a1 = G.pose_ptr[pi + 1];
+    const int a0 = listed ? 0 : G.pose_ptr[pi], a1 = listed ? 0 : G.pose_ptr[pi + 1];
     for (int x0 = a0 + sub; x0 < a1; x0 += 24) {
       int sl[3];
       long long ed[3];
@@ -818,10 +852,16 @@ __device__ __forceinline__ void k_schur_body(const GraphDev& G) {
   __syncthreads();      // the tile is reused by the next chunk
   }
 }
-__global__ __launch_bounds__(256) void k_schur(GraphDev G) { k_schur_body(G); }
+__global__ __launch_bounds__(256) void k_schur(GraphDev G) { k_schur_body<false>(G); }
 __global__ __launch_bounds__(256) void k_schur_b(const GraphDev* __restrict__ Gs) {
   const GraphDev G = Gs[blockIdx.z];
-  k_schur_body(G);
+  k_schur_body<false>(G);
+}
+// the same from pair lists (every graph of the launch has them: launch_phase3_arrow_batched) — a kernel of its own: the walk's tables and
+// its three-deep staging would set this one's register budget too
+__global__ __launch_bounds__(256) void k_schur_lb(const GraphDev* __restrict__ Gs) {
+  const GraphDev G = Gs[blockIdx.z];
+  k_schur_body<true>(G);
 }
 
 // padding (identity) between 6P and T*NB, and the RHS row (-g) at row T*NB
@@ -1327,6 +1367,7 @@ static inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + 
 
 void init_solver_kernels() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_b), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_lb), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);   // 60000 landmarks (the capacity check in HostGraph::upload_new) beside 12 KB of static LDS
 }
 void launch_relin(const GraphDev& G, hipStream_t s) {
@@ -1413,9 +1454,11 @@ void launch_phase3_arrow_batched(const GraphDev* d, const GraphDev* h, int n, hi
   if (P > 0) {
     hipLaunchKernelGGL(k_pose_b, dim3(blocks_for(P, 4), 1, n), dim3(256), 0, s, d);
     int split = 1;
-    for (int i = 0; i < n; ++i) split = std::max(split, h[i].schur_split > 0 ? h[i].schur_split : 2);
-    hipLaunchKernelGGL(k_schur_b, dim3(P, split > 0 ? split : 1, n), dim3(256),
-                       (size_t)((L + 7) / 8 * 8) * sizeof(short) + (size_t)((P + 31) / 32 + 1) * sizeof(unsigned), s, d);
+    bool listed = true;
+    for (int i = 0; i < n; ++i) { split = std::max(split, h[i].schur_split > 0 ? h[i].schur_split : 2); listed = listed && h[i].sp_idx != nullptr; }
+    const size_t lds = (size_t)((L + 7) / 8 * 8) * sizeof(short) + (size_t)((P + 31) / 32 + 1) * sizeof(unsigned);
+    if (listed) hipLaunchKernelGGL(k_schur_lb, dim3(P, split > 0 ? split : 1, n), dim3(256), lds, s, d);
+    else hipLaunchKernelGGL(k_schur_b, dim3(P, split > 0 ? split : 1, n), dim3(256), lds, s, d);
     hipLaunchKernelGGL(k_pad_rhs_b, dim3(blocks_for(pad, 256), 1, n), dim3(256), 0, s, d);
   }
   launch_border_assemble_batched(d, h, n, s);
