@@ -410,7 +410,8 @@ def main():
                                f"; {ng} ghost pose slots (linearisation points) refreshed at the start of every pass")
         info["totals"] = {k: int(sum(gb.graph.stats()[k] for gb in shards)) for k in ("n_pose", "n_lm", "n_factors")}
         info["totals"]["shared_slots"] = int(info["n_slots"])
-        info["sep_exchange_bytes"] = int(8 * s.CholBatch.sep_buffer_len(info["sep_dim"], info.get("n_relmeas", 0))) if info.get("sep_dim") else 0
+        _blk = info["sep_prof"][1] if isinstance(info.get("sep_prof"), tuple) else (0, 0)
+        info["sep_exchange_bytes"] = int(8 * s.CholBatch.sep_exchange_len(info["sep_dim"], info.get("n_relmeas", 0), _blk[0], _blk[1])) if info.get("sep_dim") else 0
         if sync_coll:
             drv.stream_ordered = False
         if os.environ.get("SLIDE_BENCH_FORCE_PARTS") == "1":      # rehearsal of the N > 1 control flow (cut pass + RCCL on the batch's stream) on one rank

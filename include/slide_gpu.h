@@ -228,6 +228,9 @@ int slide_chol_batch_set_segments(slide_chol_batch_t* b, int n_seg);
  * out[2 i], out[2 i + 1] = tile columns [t0, t1) of segment i, out[2 n] = number of separator poses (cap >= 2 n + 1 ints). */
 int slide_graph_get_segments(slide_graph_t* g, int* out, int cap);
 long long slide_chol_batch_sep_buffer_len(int m, int n_relmeas);
+/* Doubles at the head of that buffer a cut pass has to all-reduce: all of it, less the block between the two leaves of a dissected
+ * layout (slide_chol_batch_set_separator_blocks: Ta x Tb tiles that are structurally zero and left out of the packed layout). */
+long long slide_chol_batch_sep_exchange_len(int m, int n_relmeas, int Ta, int Tb);
 /* Inter-robot relative-pose factors in an exact joint pass: the factor between pose a of robot A and pose b of robot B is the rank-6
  * term U U^T, U = [J_a^T; J_b^T], of the joint normal equations; it is carried as six further separator coordinates "lambda" (the
  * factor's linearised residual) of the bordered system [H_rest U; U^T -I] [delta; lambda] = [b; -r]: every robot couples to them through

@@ -171,6 +171,8 @@ class CholBatch {
   int segments() const { return n_seg; }      // tile profile of the separator system's landmark part (n = its tile columns), or none: dense
   bool is_arrow() const { return arrow; }
   // packed exchange layout of the separator system: ms landmark coordinates + lam lambda coordinates (6 per inter-robot relative-pose factor)
+  // doubles of it a cut pass exchanges: a dissected layout (Ta, Tb tile columns in its leaves) leaves the zero block between the leaves out
+  static long long sep_exchange_len(int ms, int lam, int Ta, int Tb) { return sep_buffer_len(ms, lam) - (long long)NB * NB * Ta * Tb; }
   static long long sep_buffer_len(int ms, int lam = 0) { const long long Tt = (ms + NB - 1) / NB + (lam + NB - 1) / NB; return (long long)NB * NB * Tt * (Tt + 3) / 2; }
   hipStream_t pass_stream();                             // the stream the passes run on (created on first use)
   int profile_pass(double* const* d_bufs, double* ms_steps, int* n_launches);
@@ -224,10 +226,11 @@ class CholBatch {
   double *sep_bord = nullptr, *lamS = nullptr, *lam_Ld = nullptr, *lam_Winv = nullptr, *lam_yv = nullptr, *lam_dp = nullptr;
   int *lam_status = nullptr, *lam_ctr = nullptr;
   SepLayout sep_layout() const {
-    SepLayout Y{sepS, sep_bord, sep_x, sep_Ts, sep_nl, sep_m, sep_lam, {0, 0, 0, 0}};
+    SepLayout Y{sepS, sep_bord, sep_x, sep_Ts, sep_nl, sep_m, sep_lam, {0, 0, 0, 0}, 0, 0};
     if (sep_dissected()) {
       Y.gap[0] = sep_used[0]; Y.gap[1] = sep_leafT[0] * NB;
       Y.gap[2] = sep_leafT[0] * NB + sep_used[1]; Y.gap[3] = (sep_leafT[0] + sep_leafT[1]) * NB;
+      Y.hTa = sep_leafT[0]; Y.hTL = sep_leafT[0] + sep_leafT[1];
     }
     return Y;
   }

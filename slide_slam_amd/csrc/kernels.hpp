@@ -39,7 +39,7 @@ void launch_sep_pose_scatter_batched(const GraphDev* d, const GraphDev* h, int n
 // Separator system: Ts tile columns of landmark coordinates (ms real) in sys (ld = (Ts + nl + 1) * NB: band, nl border row tiles = the
 // coupling rows of the lam "lambda" coordinates of the inter-robot relative-pose factors, right-hand-side tile row), the lambda x lambda
 // block + its right-hand-side row in bord (ldb = (nl + 1) * NB); packed: the exchange buffer (lower tile columns of the whole)
-struct SepLayout { double* sys; double* bord; double* packed; int Ts, nl, ms, lam; int gap[4]; };      // gap: two ranges [lo, hi) of landmark coordinates no slot uses (padding between the blocks of a dissected layout): unit diagonal
+struct SepLayout { double* sys; double* bord; double* packed; int Ts, nl, ms, lam; int gap[4]; int hTa, hTL; };      // gap: two ranges [lo, hi) of landmark coordinates no slot uses (padding between the blocks of a dissected layout): unit diagonal; hTa, hTL: tile rows [hTa, hTL) of the tile columns < hTa are structurally zero (leaf b's rows under leaf a's columns) and absent from the packed layout
 void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, const SepLayout& Y, bool packed, hipStream_t s, const int* tmask = nullptr);      // tmask: Ts + nl ints, bit r = robot r holds a coordinate of the (virtual) tile
 void launch_sep_unpack(const SepLayout& Y, hipStream_t s);
 void launch_lam_prepare(const double* bord, int nl, int lam, double* out, hipStream_t s);      // M = -(K22 - L21 L21^T), rhs = -(r2 - L21 z1)

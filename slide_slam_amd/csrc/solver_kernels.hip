@@ -1200,11 +1200,17 @@ __global__ __launch_bounds__(256) void k_border_fill_lam_b(const GraphDev* __res
 // right-hand side as first row of tile row Ts); the padding up to Ts * NB gets a unit diagonal.  Fixed summation order.
 // packed: the exchange buffer of a job that spans GPUs — tile column j holds its tile rows j .. Ts only (column-major inside, height
 // (Ts + 1 - j) * NB), 4096 * Ts (Ts + 3) / 2 doubles instead of the full rectangle; k_sep_unpack copies it into the factorisation's layout
-__device__ __forceinline__ size_t sep_packed_addr(int row, int col, int Ts) {
-  const int tj = col / NB, cc = col - tj * NB;
-  const size_t off = (size_t)(NB * NB) * ((size_t)tj * (Ts + 1) - (size_t)tj * (tj - 1) / 2);
-  return off + (size_t)cc * ((size_t)(Ts + 1 - tj) * NB) + (size_t)(row - tj * NB);
+// A dissected layout (hTa < hTL): the tile rows [hTa, hTL) of the tile columns < hTa — leaf b's rows under leaf a's columns — are
+// structurally zero and left out: 4096 * (hTL - hTa) * hTa doubles fewer to all-reduce.
+__device__ __forceinline__ size_t sep_packed_addr(int row, int col, int Ts, int hTa, int hTL) {
+  const int tj = col / NB, cc = col - tj * NB, hb = hTL - hTa;
+  const size_t off = (size_t)(NB * NB) * ((size_t)tj * (Ts + 1) - (size_t)tj * (tj - 1) / 2 - (size_t)hb * min(tj, hTa));
+  const int height = Ts + 1 - tj - (tj < hTa ? hb : 0);
+  int r = row - tj * NB;
+  if (tj < hTa && row >= hTL * NB) r -= hb * NB;
+  return off + (size_t)cc * ((size_t)height * NB) + (size_t)r;
 }
+__device__ __forceinline__ bool sep_packed_hole(int row, int col, int hTa, int hTL) { return col < hTa * NB && row >= hTa * NB && row < hTL * NB; }
 // Layout of the separator system the kernels below write: Ts tile columns of landmark coordinates (ms real ones, unit diagonal on the
 // padding) in `sys` (column-major, ld = (Ts + nl + 1) * NB: band rows, then nl border row tiles = the lambda coordinates' coupling rows,
 // then the right-hand side as first row of tile row Ts + nl), and the lambda x lambda block with its right-hand-side row in `bord`
@@ -1212,7 +1218,7 @@ __device__ __forceinline__ size_t sep_packed_addr(int row, int col, int Ts) {
 // Tt = Ts + nl.  The packed exchange layout is sep_packed_addr over the virtual indices with Tt tile columns.
 __device__ __forceinline__ double* sep_slot(const SepLayout& Y, int vr, int vc, bool packed) {
   const int Tt = Y.Ts + Y.nl;
-  if (packed) return Y.packed + sep_packed_addr(vr, vc, Tt);
+  if (packed) return Y.packed + sep_packed_addr(vr, vc, Tt, Y.hTa, Y.hTL);
   if (vc < Y.Ts * NB) return Y.sys + (size_t)vc * ((size_t)(Tt + 1) * NB) + vr;
   return Y.bord + (size_t)(vc - Y.Ts * NB) * ((size_t)(Y.nl + 1) * NB) + (vr - Y.Ts * NB);
 }
@@ -1229,6 +1235,7 @@ __global__ __launch_bounds__(256) void k_sep_gather(SepGatherArgs A) {
   if (vr > NT || vc >= NT) return;
   const bool rhs = vr == NT;
   if (!rhs && vr < vc) return;
+  if (A.packed && sep_packed_hole(vr, vc, Y.hTa, Y.hTL)) return;
   // separator coordinate of a virtual index, or -1 on the padding
   const int gc = vc < NL ? (vc < Y.ms ? vc : -1) : (vc - NL < Y.lam ? Y.ms + vc - NL : -1);
   const int gr = rhs ? 0 : (vr < NL ? (vr < Y.ms ? vr : -1) : (vr - NL < Y.lam ? Y.ms + vr - NL : -1));
@@ -1255,6 +1262,7 @@ __global__ __launch_bounds__(256) void k_sep_unpack(SepLayout Y) {
   const int vr = blockIdx.x * 256 + threadIdx.x, vc = blockIdx.y;
   const int NT = (Y.Ts + Y.nl) * NB;
   if (vr > NT || vc >= NT || vr < vc / NB * NB) return;
+  if (sep_packed_hole(vr, vc, Y.hTa, Y.hTL)) return;      // (never written in the factorisation's layout either: zero since allocation)
   double v = *sep_slot(Y, vr, vc, true);
   if (vr == vc && ((vc >= Y.gap[0] && vc < Y.gap[1]) || (vc >= Y.gap[2] && vc < Y.gap[3]))) v = 1.0;
   *sep_slot(Y, vr, vc, false) = v;

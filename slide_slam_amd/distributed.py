@@ -375,6 +375,7 @@ class PassDriver:
                     sep_prof, blocks = sep_prof
                 batch.set_separator_profile(sep_prof)    # (tile profile of the separator system: the same on every rank)
                 batch.set_separator_blocks(*(blocks if blocks is not None else (0, 0, 0, 0)))
+                self.sep_blocks = blocks
             import os
             batch.set_segments(int(os.environ.get("SLIDE_SEGMENTS", "1")) if self.arrow else 1)
         if batch is not None:           # (always pushed, zero included: a batch or graph may still hold an earlier driver's setting)
@@ -445,6 +446,9 @@ class PassDriver:
             self.sep_len = self.batch.sep_buffer_len(self.sep_dim, getattr(self, "n_relmeas", 0))
             self.sep = torch.zeros(max(self.sep_len, 1), dtype=torch.float64, device=self.device)
             self.batch.set_exact_joint(True, self.sep.data_ptr(), self.sep_len)
+            blocks = getattr(self, "sep_blocks", None)
+            if blocks is not None:      # (a dissected layout: the zero block between the leaves is not part of the packed exchange)
+                self.sep_len = self.batch.sep_exchange_len(self.sep_dim, getattr(self, "n_relmeas", 0), blocks[0], blocks[1])
         return self.sep
 
     def _exchange(self, count):
