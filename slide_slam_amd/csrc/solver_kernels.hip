@@ -754,15 +754,7 @@ __device__ __forceinline__ void k_schur_body(const GraphDev& G) {
         const int D = (int)(ex & 15);
         const double* F = G.ebuf + (ex >> 4) + 6 * D;
         const double* E = G.ebuf + (ey >> 4);
-        if (D == 3) {
-          double e[18], f[18];
-#pragma unroll
-          for (int k = 0; k < 18; ++k) { e[k] = E[k]; f[k] = F[k]; }
-#pragma unroll
-          for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) acc[6 * a + c] -= f[3 * a] * e[3 * c] + f[3 * a + 1] * e[3 * c + 1] + f[3 * a + 2] * e[3 * c + 2];
-        } else {
+        {
           for (int k = 0; k < D; ++k) {
             double fk[6], ek[6];
 #pragma unroll
