@@ -298,6 +298,8 @@ __global__ __launch_bounds__(256) void k_lin_lf_b(const GraphDev* __restrict__ G
 // registers, then each lane finishes its own factors.  (M == D for all three landmark factor kinds.)
 // MODE 0: everything (single GPU).  MODE 1: accumulate only, partial sums -> lm_Hacc (54 per landmark:
 // packed lower H then g) for the cross-robot all-reduce.  MODE 2: start from the (all-reduced) sums in lm_Hacc.
+// MODE 3: everything in one launch as MODE 0, the sums also left in lm_Hacc and separator landmarks treated as in MODE 2 (exact joint
+// pass: nothing is exchanged between the two halves, k_border_fill reads the robot's own H_ll from lm_Hacc).
 __shared__ double lm_hs[4][96];   // per wave of k_landmark: H_ll^-1 (81) + g_l (9)
 
 template <int D, int MODE>
@@ -343,14 +345,14 @@ __device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
       for (int i = 0; i < D; ++i) g[i] += __shfl_xor(g[i], off);
     }
   }
-  if (MODE == 1) {
+  if (MODE == 1 || MODE == 3) {
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < NH; ++i) acc[i] = h[i];
 #pragma unroll
       for (int i = 0; i < D; ++i) acc[45 + i] = g[i];
     }
-    return;
+    if (MODE == 1) return;
   }
   double* Hinv = G.lm_Hinv + 81 * (size_t)l;
   double* gout = G.lm_g + 9 * (size_t)l;
@@ -360,8 +362,8 @@ __device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
   }
   // exact joint step: a separator landmark is not eliminated here — H_ll^-1 = 0 makes F and u vanish (nothing of it enters the pose
   // system), E = Jp^T Jl is still written: it is the landmark's coupling row in the border (k_border_fill)
-  const bool sep = MODE == 2 && G.arrow && G.lm_slot && G.lm_slot[l] >= 0;
-  if (nf == 0 && MODE == 0) {
+  const bool sep = (MODE == 2 || MODE == 3) && G.arrow && G.lm_slot && G.lm_slot[l] >= 0;
+  if (nf == 0 && (MODE == 0 || MODE == 3)) {
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < D * D; ++i) Hinv[i] = 0.0;
@@ -1450,7 +1452,7 @@ void launch_phase3_arrow_batched(const GraphDev* d, const GraphDev* h, int n, hi
     const long long NT = (long long)h[i].T * NB;
     pad = std::max(pad, NT + (NT - 6LL * h[i].P) * NT);
   }
-  if (L > 0) hipLaunchKernelGGL(k_landmark_b<2>, dim3(blocks_for(L, 4), 1, n), dim3(256), 0, s, d);
+  if (L > 0) hipLaunchKernelGGL(k_landmark_b<3>, dim3(blocks_for(L, 4), 1, n), dim3(256), 0, s, d);
   if (P > 0) {
     hipLaunchKernelGGL(k_pose_b, dim3(blocks_for(P, 4), 1, n), dim3(256), 0, s, d);
     int split = 1;
@@ -1480,7 +1482,7 @@ void launch_phase0_batched(const GraphDev* d, const GraphDev* h, int n, double* 
   if (P + L > 0) hipLaunchKernelGGL(k_relin_b, dim3(blocks_for(P + L, 256), 1, n), dim3(256), 0, s, d);
   if (npf > 0) hipLaunchKernelGGL(k_lin_pose_factors_b, dim3(blocks_for(npf, 128), 1, n), dim3(128), 0, s, d);
   if (nlf > 0) hipLaunchKernelGGL(k_lin_lf_b, dim3(blocks_for(32LL * nlf, 256), 1, n), dim3(256), 0, s, d);
-  if (L > 0) hipLaunchKernelGGL(k_landmark_b<1>, dim3(blocks_for(L, 4), 1, n), dim3(256), 0, s, d);
+  if (L > 0 && pack) hipLaunchKernelGGL(k_landmark_b<1>, dim3(blocks_for(L, 4), 1, n), dim3(256), 0, s, d);      // (!pack: the exact joint pass sums and finishes in one launch, k_landmark_b<3>)
   if (slots > 0 && pack) hipLaunchKernelGGL(k_shared_pack_b, dim3(blocks_for(54LL * slots, 128), 1, n), dim3(128), 0, s, d, 0, B);
 }
 // phase 4: t_l = sum E^T delta_p per landmark, packed for the exchange
