@@ -714,6 +714,18 @@ __global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, in
   }
 }
 
+// the same for up to 8 systems in one launch (blockIdx.y = system): eight 5 us launches in a row at the end of the bands' steps otherwise
+struct ExtractArgs { int n; const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX]; int Tr[CHOL_BATCH_MAX]; double* yv[CHOL_BATCH_MAX]; double* dp[CHOL_BATCH_MAX]; int* status[CHOL_BATCH_MAX]; };
+__global__ void k_chol_extract_y_b(ExtractArgs A) {
+  const int r = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) A.status[r][4] = 0;
+  if (c < A.T[r] * NB) {
+    A.yv[r][c] = A.S[r][(size_t)c * A.ld[r] + (size_t)A.Tr[r] * NB];
+    A.dp[r][c] = __longlong_as_double((long long)BWD_SENT);
+  }
+}
+
 // Backward substitution L^T x = y as ONE launch: workgroup b owns block c = T-1-b.  It accumulates
 //   y_c - sum_{j > c} L(j, c)^T x_j
 // in descending j as the x_j appear in dp, then x_c = (L_cc^-1)^T (.) and publishes it.  Block ids are TICKETS drawn from an
@@ -1628,7 +1640,13 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
   }
   if (after_steps) (void)hipEventRecord(after_steps, s);
   if (!solve) {       // the caller continues with the border (k_border_syrk, the separator system) and runs launch_chol_bwd_batch itself
-    for (int i = 0; i < n; ++i) launch_chol_extract_y(d[i].S, d[i].ld, d[i].T, d[i].yv, d[i].dp, d[i].status, s, d[i].nbr, d[i].b0);
+    ExtractArgs E{};
+    E.n = n;
+    for (int i = 0; i < n; ++i) {
+      E.S[i] = d[i].S; E.ld[i] = d[i].ld; E.T[i] = d[i].T; E.Tr[i] = (d[i].b0 > 0 ? d[i].b0 : d[i].T) + d[i].nbr;
+      E.yv[i] = d[i].yv; E.dp[i] = d[i].dp; E.status[i] = d[i].status;
+    }
+    if (Tmax > 0) hipLaunchKernelGGL(k_chol_extract_y_b, dim3((Tmax * NB + 255) / 256, n), dim3(256), 0, s, E);
     return;
   }
   launch_chain_tables(d, n, s);
