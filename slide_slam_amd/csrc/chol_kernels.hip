@@ -151,7 +151,7 @@ __device__ __forceinline__ void b_quadrant(double* __restrict__ S, int ld, const
 // nbB / nbX: the border rows that are active in the pass / for the column items — the rows whose coupling starts at a later block column
 // are still all-zero and form a suffix of the border (plan_step); the right-hand side is virtual row Tv + (active rows).
 __device__ __forceinline__ BItem b_decode(int g, int nItems, int nR, int g0, int k, int kb, int T, int TvB, int TvX, int nP, long long nG, int wave,
-                                          int nbr, int nbB, int nbX) {
+                                          int nbr, int nbB, int nbX, const int* __restrict__ ord = nullptr) {
   BItem it;
   it.ok = false; it.i = it.j = it.pcb = 0; it.ks = 32;
   if (g >= nItems) return it;
@@ -165,14 +165,14 @@ __device__ __forceinline__ BItem b_decode(int g, int nItems, int nR, int g0, int
     it.j = kb + 1 + 2 * bj + (wave >> 2);
     it.pcb = kb - 2;
     it.ok = !(it.i > TvB + nbB || it.j > TvB - 1 || it.i < it.j);
-    if (it.i >= TvB) it.i = (it.i - TvB < nbB) ? T + (it.i - TvB) : T + nbr;
+    if (it.i >= TvB) it.i = (it.i - TvB < nbB) ? T + (ord ? ord[it.i - TvB] : it.i - TvB) : T + nbr;
   } else {
     const int c = g - nR;
     it.j = k + 1;
     it.i = k + 1 + 2 * c + (wave >> 2);
     it.pcb = k - 1; it.ks = 16;
     it.ok = !(it.i > TvX + nbX || it.j > TvX - 1);
-    if (it.i >= TvX) it.i = (it.i - TvX < nbX) ? T + (it.i - TvX) : T + nbr;
+    if (it.i >= TvX) it.i = (it.i - TvX < nbX) ? T + (ord ? ord[it.i - TvX] : it.i - TvX) : T + nbr;
   }
   return it;
 }
@@ -607,9 +607,10 @@ __device__ __forceinline__ void step_type_a_impl(double* __restrict__ S, int ld,
 // L32 (or null): packed f32 copy of the factor's off-diagonal tiles, written along with the panel (the preconditioner of the joint solve
 // streams it, see bwd_chain_body): tile (i, k), k < i < T, at 4096 * (k (T-1) - k (k-1) / 2 + i - k - 1)
 __device__ __forceinline__ void step_type_a(double* __restrict__ S, int ld, int k, int T, int TvA, int ia, int half, double* __restrict__ Ld,
-                                            double* __restrict__ Winv, int* status, ALds& L, float* __restrict__ L32, int nbr, int nbA) {
+                                            double* __restrict__ Winv, int* status, ALds& L, float* __restrict__ L32, int nbr, int nbA,
+                                            const int* __restrict__ ord = nullptr) {
   const int vi = k + 1 + ia - TvA;      // rows k+1 .. TvA-1 of the profile, then the nbA active border rows, then the right-hand-side row
-  const int it = vi < 0 ? k + 1 + ia : (vi < nbA ? T + vi : T + nbr);
+  const int it = vi < 0 ? k + 1 + ia : (vi < nbA ? T + (ord ? ord[vi] : vi) : T + nbr);
   float* L32t = (L32 && it < T) ? L32 + ((size_t)k * (T - 1) - (size_t)k * (k - 1) / 2 + (it - k - 1)) * (NB * NB) : nullptr;
   if (k > 0) step_type_a_impl<1>(S, ld, k, ia, it, half, Ld, Winv, status, L, L32t);
   else step_type_a_impl<0>(S, ld, k, ia, it, half, Ld, Winv, status, L, L32t);
@@ -660,6 +661,7 @@ struct CholBatchArgs {
   int nbr[CHOL_BATCH_MAX];             // border row tiles below the profile (b_decode)
   int nbA[CHOL_BATCH_MAX], nbB[CHOL_BATCH_MAX], nbX[CHOL_BATCH_MAX];      // ... of which active for column k / the pair's pass / the column items
   int B0[CHOL_BATCH_MAX];              // tile row at which the border rows start (T, or further down for a segment view: CholSystem::b0)
+  const int* ord[CHOL_BATCH_MAX];      // order of the active border rows of a view (CholSystem::ord) or null
   int a_base[CHOL_BATCH_MAX + 1];      // prefix sums of the type-A workgroup counts
   int b_base[CHOL_BATCH_MAX + 1];      // prefix sums of the type-B item counts
 };
@@ -673,7 +675,7 @@ __global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int 
     while (bid >= A.a_base[r + 1]) ++r;
     const int local = bid - A.a_base[r], sp = A.a_split[r];
     step_type_a(A.S[r], A.ld[r], k, A.B0[r], A.TvA[r], local >> sp, sp ? (local & 1) : -1, A.Ld[r] + (size_t)k * NB * NB,
-                A.Winv[r] + (size_t)k * 1024, A.status[r], L, A.L32[r], A.nbr[r], A.nbA[r]);
+                A.Winv[r] + (size_t)k * 1024, A.status[r], L, A.L32[r], A.nbr[r], A.nbA[r], A.ord[r]);
     if (!a_joins) return;
   }
   const int nItems = A.b_base[A.n];
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int 
     while (g >= A.b_base[r + 1]) ++r;
     const int gl = g - A.b_base[r], nR = A.g1[r] - A.g0[r];
     const long long nG = (long long)A.nP[r] * (A.nP[r] + 1) / 2;
-    const BItem it = b_decode(gl, nR + A.nX[r], nR, A.g0[r], k, kb, A.B0[r], A.TvB[r], A.TvX[r], A.nP[r], nG, wave, A.nbr[r], A.nbB[r], A.nbX[r]);
+    const BItem it = b_decode(gl, nR + A.nX[r], nR, A.g0[r], k, kb, A.B0[r], A.TvB[r], A.TvX[r], A.nP[r], nG, wave, A.nbr[r], A.nbB[r], A.nbX[r], A.ord[r]);
     if (!it.ok) continue;
     if (it.ks == 32) b_quadrant<32>(A.S[r], A.ld[r], it, wave & 3);
     else b_quadrant<16>(A.S[r], A.ld[r], it, wave & 3);
@@ -905,13 +907,14 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chol_bwd_chain(const double* 
   if (t >= T) return;
   bwd_chain_body<false>(W, S, ld, T, Ld, Winv, yv, dp, status, t, nullptr, prof);
 }
+constexpr int BWD_BATCH_MAX = 32;     // systems per batched backward substitution (the segments of eight robots' bands: up to 32)
 struct BwdBatchArgs {
   int n;
-  const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX];
-  const double* Ld[CHOL_BATCH_MAX]; const double* Winv[CHOL_BATCH_MAX]; const double* yv[CHOL_BATCH_MAX]; double* dp[CHOL_BATCH_MAX];
-  int* status[CHOL_BATCH_MAX];
-  const int* prof[CHOL_BATCH_MAX];     // device: profile of the factor (see plan_step) or null
-  int base[CHOL_BATCH_MAX + 1];        // prefix sums of T (grid size = base[n])
+  const double* S[BWD_BATCH_MAX]; int ld[BWD_BATCH_MAX]; int T[BWD_BATCH_MAX];
+  const double* Ld[BWD_BATCH_MAX]; const double* Winv[BWD_BATCH_MAX]; const double* yv[BWD_BATCH_MAX]; double* dp[BWD_BATCH_MAX];
+  int* status[BWD_BATCH_MAX];
+  const int* prof[BWD_BATCH_MAX];      // device: profile of the factor (see plan_step) or null
+  int base[BWD_BATCH_MAX + 1];         // prefix sums of T (grid size = base[n])
   int Tmax;
 };
 // ticket t -> system t % n, block t / n of it: the chains of all systems advance side by side; a ticket beyond a shorter system's
@@ -1362,6 +1365,7 @@ struct SyrkArgs {
   double* bord[CHOL_BATCH_MAX]; int ldb[CHOL_BATCH_MAX]; const int* bfirst[CHOL_BATCH_MAX];
   int ks; double* scratch;
   const int* jobs;       // or null: (system << 20 | ib << 10 | jb) per workgroup, longest sums first (launch_border_syrk_jobs)
+  const int* segtab[CHOL_BATCH_MAX];      // or null: CholSystem::segtab — the sum runs over the segments in which both tile rows are non-zero
 };
 __global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
   int r = A.ks > 1 ? 0 : blockIdx.z, ib = blockIdx.x, jb = blockIdx.y;
@@ -1375,19 +1379,21 @@ __global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
   const int T = A.T[r], ld = A.ld[r];
   int ldb = A.ldb[r];
   int c0 = 0, c1 = T;                             // column blocks [c0, c1) of the band
-  if (A.bfirst[r]) c0 = max(A.bfirst[r][ib], A.bfirst[r][jb]);
+  const int* st = A.segtab[r];                    // a segmented band: one range per segment in which both tile rows are non-zero
+  const int nseg = st ? st[0] : 1;
+  if (!st && A.bfirst[r]) c0 = max(A.bfirst[r][ib], A.bfirst[r][jb]);
   if (A.ks > 1) {
     const int len = (T - c0 + A.ks - 1) / A.ks;
     c0 += q * len;
     c1 = min(T, c0 + len);
   }
-  if (c0 >= c1) return;
+  if (!st && c0 >= c1) return;
   const double* S = A.S[r];
   const int wq = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
   const int ch = (wq >> 1) & 1, rh = wq & 1;      // column half, row half of the tile
   if (A.jobs && ib == nbr && rh == 1) return;     // right-hand-side row tile: only its first row is in use (the others are zero and stay zero)
-  const double* pjh = S + (size_t)(c0 * NB + lk) * ld + (size_t)(T + jb) * NB + 32 * ch + 2 * lr;
-  const double* pih = S + (size_t)(c0 * NB + lk) * ld + (size_t)(T + ib) * NB + 32 * rh + 2 * lr;
+  const double* pj0 = S + (size_t)lk * ld + (size_t)(T + jb) * NB + 32 * ch + 2 * lr;
+  const double* pi0 = S + (size_t)lk * ld + (size_t)(T + ib) * NB + 32 * rh + 2 * lr;
   double* cbh = A.bord[r] + (size_t)(jb * NB + 32 * ch + 2 * lk) * ldb + (size_t)ib * NB + 32 * rh + 2 * lr;
   if (q > 0) {       // partial of a later chunk: a 64 x 64 scratch tile (leading dimension NB)
     ldb = NB;
@@ -1403,32 +1409,42 @@ __global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
       if (q == 0) c2 = *(const v2d*)(cbh + (size_t)(8 * e + a) * ldb);
       acc[a][0][e] = c2[0]; acc[a][1][e] = c2[1];
     }
-  const int KS = (c1 - c0) * 16;                  // k-steps of four columns (a multiple of 16)
-  constexpr int RD = 4;
-  v2d pa[RD], pb[RD];
+  for (int sg = 0; sg < nseg; ++sg) {
+    if (st) {
+      const int* sf = st + 1 + nseg + sg * (nbr + 1);
+      c0 = max(sf[ib], sf[jb]);
+      c1 = st[1 + sg];
+      if (c0 >= c1) continue;                     // (1 << 30: zero in this segment)
+    }
+    const double* pjh = pj0 + (size_t)c0 * NB * ld;
+    const double* pih = pi0 + (size_t)c0 * NB * ld;
+    const int KS = (c1 - c0) * 16;                // k-steps of four columns (a multiple of 16)
+    constexpr int RD = 4;
+    v2d pa[RD], pb[RD];
 #pragma unroll
-  for (int pre = 0; pre < RD - 1; ++pre) {
-    const size_t off = (size_t)(4 * pre) * ld;
-    pa[pre] = *(const v2d*)(pjh + off);
-    pb[pre] = *(const v2d*)(pih + off);
-  }
-  for (int ks0 = 0; ks0 < KS; ks0 += RD) {
+    for (int pre = 0; pre < RD - 1; ++pre) {
+      const size_t off = (size_t)(4 * pre) * ld;
+      pa[pre] = *(const v2d*)(pjh + off);
+      pb[pre] = *(const v2d*)(pih + off);
+    }
+    for (int ks0 = 0; ks0 < KS; ks0 += RD) {
 #pragma unroll
-    for (int u = 0; u < RD; ++u) {
-      const int ks = ks0 + u;
-      if (ks + RD - 1 < KS) {
-        const size_t off = (size_t)(4 * (ks + RD - 1)) * ld;
-        pa[(u + RD - 1) % RD] = *(const v2d*)(pjh + off);
-        pb[(u + RD - 1) % RD] = *(const v2d*)(pih + off);
+      for (int u = 0; u < RD; ++u) {
+        const int ks = ks0 + u;
+        if (ks + RD - 1 < KS) {
+          const size_t off = (size_t)(4 * (ks + RD - 1)) * ld;
+          pa[(u + RD - 1) % RD] = *(const v2d*)(pjh + off);
+          pb[(u + RD - 1) % RD] = *(const v2d*)(pih + off);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const double na = -pa[u][a];
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = mfma_f64(na, pb[u][b], acc[a][b]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const double na = -pa[u][a];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = mfma_f64(na, pb[u][b], acc[a][b]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll
@@ -1465,6 +1481,7 @@ void launch_border_syrk(const CholSystem* d, int n, hipStream_t s, double* scrat
   int nb = 0;
   for (int i = 0; i < n; ++i) {
     A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.nbr[i] = d[i].nbr; A.bord[i] = d[i].bord; A.ldb[i] = d[i].ldb; A.bfirst[i] = d[i].bfirst;
+    A.segtab[i] = d[i].segtab;
     nb = d[i].nbr > nb ? d[i].nbr : nb;
   }
   if (nb <= 0) return;
@@ -1489,6 +1506,7 @@ void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int nj
   A.n = n;
   for (int i = 0; i < n; ++i) {
     A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.nbr[i] = d[i].nbr; A.bord[i] = d[i].bord; A.ldb[i] = d[i].ldb; A.bfirst[i] = d[i].bfirst;
+    A.segtab[i] = d[i].segtab;
   }
   if (njobs <= 0) return;
   A.ks = 1; A.scratch = nullptr; A.jobs = jobs;
@@ -1629,6 +1647,7 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
       A.nP[i] = pl[i].nP; A.g0[i] = pl[i].g0; A.g1[i] = pl[i].g1; A.nX[i] = pl[i].nX; A.a_split[i] = a_split;
       A.nbr[i] = d[i].nbr; A.nbA[i] = pl[i].nbA; A.nbB[i] = pl[i].nbB; A.nbX[i] = pl[i].nbX;
       A.B0[i] = d[i].b0 > 0 ? d[i].b0 : d[i].T;      // (a view with its border further down carries no f32 factor copy: L32's tile index uses T)
+      A.ord[i] = d[i].ord;
       A.a_base[i + 1] = A.a_base[i] + (int)(pl[i].nA << a_split);
       A.b_base[i + 1] = A.b_base[i] + (int)pl[i].nB;
     }
@@ -1664,6 +1683,10 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
 }
 // the chained backward substitutions yv -> dp of up to 8 factored systems in one launch (after launch_chol_extract_y)
 void launch_chol_bwd_batch(const CholSystem* d, int n, hipStream_t s) {
+  if (n > BWD_BATCH_MAX) {      // (more systems than one launch takes: in chunks)
+    for (int lo = 0; lo < n; lo += BWD_BATCH_MAX) launch_chol_bwd_batch(d + lo, n - lo < BWD_BATCH_MAX ? n - lo : BWD_BATCH_MAX, s);
+    return;
+  }
   BwdBatchArgs B{};
   B.n = n;
   B.base[0] = 0;

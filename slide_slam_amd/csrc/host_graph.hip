@@ -535,8 +535,13 @@ int CholBatch::prepare_pass() {
         c.h_prof = g->seg_prof[k].data(); c.prof = g->d_seg_prof.d + g->seg_prof_off[k]; c.first = nullptr;
         c.b0 = G.T - sg.t0; c.kofs = sg.t0;
         c.L32 = nullptr; c.ctab = nullptr;
+        if (k < g->seg_ord.size() && !getenv("SLIDE_SEG_PLAIN")) {      // the segment's own set and order of active border rows
+          c.h_bfirst = g->seg_sfirst[k].data();
+          c.ord = g->d_seg_ord.d + k * (size_t)G.nbr;
+        }
         seg_sys.push_back(c);
       }
+      if (!g->seg_tab.empty() && !getenv("SLIDE_SEG_PLAIN")) sys[i].segtab = g->d_seg_tab.d;      // (the border product sums per segment)
       CholSystem l2{};
       l2.S = G.bord; l2.ld = G.ldb; l2.T = G.nsep; l2.Ld = g->d_Ld2.d; l2.Winv = g->d_Winv2.d; l2.yv = g->d_yv2.d; l2.dp = g->d_dp2.d;
       l2.status = G.status; l2.nbr = G.nbr - G.nsep;
@@ -551,8 +556,22 @@ int CholBatch::prepare_pass() {
         const int nb = sys[i].nbr, T = sys[i].T;
         const int* hb = sys[i].h_bfirst;
         if (nb > 1023 || n > 2047) { jl.clear(); break; }
+        const std::vector<int>& stb = graphs[i]->seg_tab;
+        const bool seg = sys[i].segtab != nullptr && !stb.empty();
         for (int jb = 0; jb < nb; ++jb)
-          for (int ib = jb; ib <= nb; ++ib) jl.emplace_back(T - (hb ? std::max(hb[ib], hb[jb]) : 0), i << 20 | ib << 10 | jb);
+          for (int ib = jb; ib <= nb; ++ib) {
+            int K = T - (hb ? std::max(hb[ib], hb[jb]) : 0);
+            if (seg) {      // (the lengths only order the table)
+              K = 0;
+              const int NS = stb[0];
+              for (int q = 0; q < NS; ++q) {
+                const int* sf = stb.data() + 1 + NS + (size_t)q * (nb + 1);
+                const int c0 = std::max(sf[ib], sf[jb]);
+                if (c0 < stb[1 + q]) K += stb[1 + q] - c0;
+              }
+            }
+            jl.emplace_back(K, i << 20 | ib << 10 | jb);
+          }
       }
       std::stable_sort(jl.begin(), jl.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
       if (getenv("SLIDE_SYRK_XCD") && !jl.empty()) {
@@ -917,14 +936,14 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
       launch_border_apply(l2_sys.data(), (int)l2_sys.size(), x2, master);
       launch_chol_bwd_batch(l2_sys.data(), (int)l2_sys.size(), master);
       launch_ints_clear(l2_sys[0].status + 4, 1, master);            // (the chain's ticket counter: the segments' chains of that graph draw from it next)
-      for (size_t i = 0; i < l2_sys.size(); ++i) {
-        double* two[2] = {l2_sys[i].dp, xloc[l2_graph[i]]};
-        launch_bcast(two, 2, hG[l2_graph[i]].nsep * NB, master);
+      {
+        const double* src[CHOL_BATCH_HOST_MAX]; double* dst[CHOL_BATCH_HOST_MAX]; int cnt[CHOL_BATCH_HOST_MAX];
+        for (size_t i = 0; i < l2_sys.size(); ++i) { src[i] = l2_sys[i].dp; dst[i] = xloc[l2_graph[i]]; cnt[i] = hG[l2_graph[i]].nsep * NB; }
+        launch_copy_pairs(src, dst, cnt, (int)l2_sys.size(), master);
       }
     }
     launch_border_apply(sys.data(), n, xloc, master);                // y -= W x_s
-    for (size_t lo = 0; lo < seg_sys.size(); lo += CHOL_BATCH_HOST_MAX)      // L^T dp = y, segment by segment
-      launch_chol_bwd_batch(seg_sys.data() + lo, (int)std::min<size_t>(CHOL_BATCH_HOST_MAX, seg_sys.size() - lo), master);
+    launch_chol_bwd_batch(seg_sys.data(), (int)seg_sys.size(), master);      // L^T dp = y, all segments side by side
     launch_sep_pose_scatter_batched(d_Gs, hG.data(), n, xloc, master);
     launch_arrow_finish_batched(d_Gs, hG.data(), n, sep_dp, d_sep_off, master);
     launch_status_or(hG[0].status, sep_status, 8, master);           // (the separator's not-SPD / chain flags are reported with graph 0's)
@@ -1552,8 +1571,11 @@ int HostGraph::upload_new() {
     h_pose_sep.assign(std::max<size_t>(Pn, 1), -1);
     nsep = nsep_dim = n_sep_poses = 0;
     const int want_seg = batch ? batch->segments() : 1;
+    std::vector<std::pair<int, int>> seg_cuts;        // the windows [q0, q1) of poses behind the segments (all but the last)
+    std::vector<int> reach;
     if (want_seg >= 2 && Pn >= 64) {
-      std::vector<int> lm_last(Ln, -1), reach(Pn);
+      std::vector<int> lm_last(Ln, -1);
+      reach.assign(Pn, 0);
       for (size_t f = 0; f < nlf; ++f) lm_last[h_lf_lm[f]] = std::max(lm_last[h_lf_lm[f]], h_lf_pose[f]);
       for (size_t p = 0; p < Pn; ++p) reach[p] = (int)p;
       for (size_t f = 0; f < nlf; ++f) reach[h_lf_pose[f]] = std::max(reach[h_lf_pose[f]], lm_last[h_lf_lm[f]]);
@@ -1583,6 +1605,7 @@ int HostGraph::upload_new() {
         if (last.t0 >= tmp.back().t1) {
           tmp.push_back(last);
           segs = tmp;
+          seg_cuts = cuts;
           for (const auto& c : cuts)
             for (int q = c.first; q < c.second; ++q) { h_pose_sep[q] = 6 * n_sep_poses; ++n_sep_poses; }
           nsep_dim = 6 * n_sep_poses;
@@ -1625,6 +1648,57 @@ int HostGraph::upload_new() {
     }
     for (int t = 0; t < nbr_new; ++t) if (h_bfirst[t] == (1 << 30)) h_bfirst[t] = 0;
     for (int t = 1; t < nbr_new; ++t) h_bfirst[t] = std::max(h_bfirst[t], h_bfirst[t - 1]);      // (non-decreasing by construction; kept so by force)
+    // per-segment activity of the border rows (see host_graph.hpp)
+    seg_ord.clear(); seg_sfirst.clear(); seg_tab.clear();
+    if (!segs.empty()) {
+      const int NS = (int)segs.size(), INF = 1 << 30;
+      std::vector<std::vector<int>> sf(NS, std::vector<int>(nbr_new + 1, INF));
+      auto seg_of = [&](int col) { for (int q = 0; q < NS; ++q) if (col >= segs[q].t0 && col < segs[q].t1) return q; return -1; };
+      auto touch = [&](int t_lo, int t_hi, int pose) {
+        if (pose < 0 || (size_t)pose >= Pn || h_pose_sep[pose] >= 0) return;      // (a cut's pose: that coupling lives in the border block)
+        const int c = 6 * pose / NB, q = seg_of(c);
+        if (q < 0) return;
+        for (int t = t_lo; t <= t_hi; ++t) sf[q][t] = std::min(sf[q][t], c);
+      };
+      int o2 = nsep * NB;
+      for (const Item& it : items) {
+        const int t_lo = o2 / NB, t_hi = (o2 + it.dim - 1) / NB;
+        if (it.kind == 0) { for (int f : lm_fids[it.id]) touch(t_lo, t_hi, h_lf_pose[f]); }
+        else touch(t_lo, t_hi, h_gh_pose[it.id]);
+        o2 += it.dim;
+      }
+      // the cuts' poses: window w lies between segment w and segment w + 1; before it, the poses whose reach crosses its start couple to
+      // it (contiguous up to the cut); behind it, the segment's first block columns do
+      int nb4 = 0;
+      for (size_t w = 0; w < seg_cuts.size(); ++w) {
+        const int q0 = seg_cuts[w].first, q1 = seg_cuts[w].second;
+        const int t_lo = 6 * nb4 / NB, t_hi = (6 * (nb4 + q1 - q0) - 1) / NB;
+        int pf = q0;
+        for (int pz = q0 - 1; pz >= 0 && 6 * pz / NB >= segs[w].t0; --pz) if (reach[pz] >= q0) pf = pz;
+        if (pf < q0) for (int t = t_lo; t <= t_hi; ++t) sf[w][t] = std::min(sf[w][t], std::max(6 * pf / NB, segs[w].t0));
+        if (w + 1 < segs.size()) for (int t = t_lo; t <= t_hi; ++t) sf[w + 1][t] = std::min(sf[w + 1][t], segs[w + 1].t0);
+        nb4 += q1 - q0;
+      }
+      seg_tab.push_back(NS);
+      for (int q = 0; q < NS; ++q) seg_tab.push_back(segs[q].t1);
+      std::vector<int> flat_ord;
+      for (int q = 0; q < NS; ++q) {
+        sf[q][nbr_new] = segs[q].t0;                  // the right-hand-side row rides from the segment's first block column
+        std::vector<int> ord(nbr_new);
+        for (int t = 0; t < nbr_new; ++t) ord[t] = t;
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return sf[q][a] < sf[q][b]; });
+        std::vector<int> sorted(nbr_new + 1);
+        for (int j = 0; j < nbr_new; ++j) sorted[j] = sf[q][ord[j]];
+        sorted[nbr_new] = segs[q].t0;
+        seg_ord.push_back(ord); seg_sfirst.push_back(sorted);
+        flat_ord.insert(flat_ord.end(), ord.begin(), ord.end());
+        seg_tab.insert(seg_tab.end(), sf[q].begin(), sf[q].end());
+      }
+      if (d_seg_ord.ensure(std::max<size_t>(flat_ord.size(), 1), 0, s) != SLIDE_OK || d_seg_tab.ensure(seg_tab.size(), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+      if (!flat_ord.empty()) SL_HIP(hipMemcpyAsync(d_seg_ord.d, flat_ord.data(), flat_ord.size() * sizeof(int), hipMemcpyHostToDevice, s));
+      SL_HIP(hipMemcpyAsync(d_seg_tab.d, seg_tab.data(), seg_tab.size() * sizeof(int), hipMemcpyHostToDevice, s));
+      SL_HIP(hipStreamSynchronize(s));      // (pageable temporaries)
+    }
     if (d_pose_sep.ensure(h_pose_sep.size(), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     SL_HIP(hipMemcpyAsync(d_pose_sep.d, h_pose_sep.data(), h_pose_sep.size() * sizeof(int), hipMemcpyHostToDevice, s));
     if (nsep > 0) {

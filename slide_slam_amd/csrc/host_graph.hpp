@@ -405,6 +405,14 @@ class HostGraph {
   std::vector<std::vector<int>> seg_prof;              // per segment: its profile in its own numbering (host; plan_step)
   DevArr<int> d_pose_sep, d_seg_prof;
   std::vector<size_t> seg_prof_off;
+  // per segment: which border tile rows are non-zero in it and from which block column on (a shared landmark seen only from the first
+  // half of the trajectory has no coupling to the second segment's poses; the poses of a cut couple to the few block columns before it and
+  // to the segment behind it).  seg_ord[s]: the border tile rows in the order of that first column (the rows still all-zero at a block
+  // column are then a suffix again, per segment); seg_sfirst[s]: the first columns in that order (plan_step); seg_tab: what the border
+  // product reads — nseg, the segments' last block columns + 1, then per segment the first column of every tile row + the right-hand side
+  std::vector<std::vector<int>> seg_ord, seg_sfirst;
+  std::vector<int> seg_tab;
+  DevArr<int> d_seg_ord, d_seg_tab;
   int nsep = 0, nsep_dim = 0, n_sep_poses = 0;
   DevArr<double> d_Ld2, d_Winv2, d_yv2, d_dp2;
   std::vector<int> h_gh_gid, h_gh_bord;                // ghost factor -> index in the job's relative-pose list; -> border offset of its lambda coordinates

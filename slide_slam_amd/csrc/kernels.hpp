@@ -40,6 +40,7 @@ void launch_sep_pose_scatter_batched(const GraphDev* d, const GraphDev* h, int n
 // coupling rows of the lam "lambda" coordinates of the inter-robot relative-pose factors, right-hand-side tile row), the lambda x lambda
 // block + its right-hand-side row in bord (ldb = (nl + 1) * NB); packed: the exchange buffer (lower tile columns of the whole)
 struct SepLayout { double* sys; double* bord; double* packed; int Ts, nl, ms, lam; int gap[4]; int hTa, hTL; };      // gap: two ranges [lo, hi) of landmark coordinates no slot uses (padding between the blocks of a dissected layout): unit diagonal; hTa, hTL: tile rows [hTa, hTL) of the tile columns < hTa are structurally zero (leaf b's rows under leaf a's columns) and absent from the packed layout
+void launch_copy_pairs(const double* const* src, double* const* dst, const int* count, int n, hipStream_t s);      // up to 8 small device-to-device copies in one launch
 void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, const SepLayout& Y, bool packed, hipStream_t s, const int* tmask = nullptr);      // tmask: Ts + nl ints, bit r = robot r holds a coordinate of the (virtual) tile
 void launch_sep_unpack(const SepLayout& Y, hipStream_t s);
 void launch_lam_prepare(const double* bord, int nl, int lam, double* out, hipStream_t s);      // M = -(K22 - L21 L21^T), rhs = -(r2 - L21 z1)
@@ -66,7 +67,11 @@ struct CholSystem { double* S; int ld, T; double* Ld; double* Winv; double* yv; 
                     const int* h_bfirst;         // host copy (plan_step: the border rows still all-zero at a block column are skipped) or null: every row always
                     int b0;                      // tile row (in the system's own row numbering) at which its border rows start; 0: right behind the band (= T).  A SEGMENT of
                                                  // a robot's band factored as a system of its own (a view: shifted S, profile) has its border further down: b0 = T_robot - first tile
-                    int kofs; };                 // the view's first block column in the robot's numbering (bfirst is in that numbering)
+                    int kofs;                    // the view's first block column in the robot's numbering (bfirst is in that numbering)
+                    const int* ord;              // device, nbr ints, or null: the j-th ACTIVE border row of this view is tile row b0 + ord[j] (a segment has its own order
+                                                 // of first columns: h_bfirst is then that segment's sorted list)
+                    const int* segtab; };        // device or null (border product of a segmented band): nseg, the segments' end columns, per segment the first column of
+                                                 // every border tile row + the right-hand side (1 << 30: the row is zero in that segment)
 void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps = nullptr, bool solve = true);            // up to 8 systems, one launch per block column; solve = false: steps + extraction of y only
 void launch_chol_bwd_batch(const CholSystem* d, int n, hipStream_t s);       // yv -> dp of up to 8 factored systems (chained backward substitution)
 // Exact joint step (the border of the systems = the separator's coupling rows, W^T after the steps):

@@ -920,6 +920,20 @@ void launch_bcast(double* const* bufs, int n, int count, hipStream_t s) {
   hipLaunchKernelGGL(k_bcast, dim3((count + 255) / 256), dim3(256), 0, s, A, count);
 }
 
+// n independent small copies dst[i][0 .. count[i]) = src[i][.] in one launch (blockIdx.y = i)
+struct CopyPairsArgs { int n; const double* src[8]; double* dst[8]; int count[8]; };
+__global__ __launch_bounds__(256) void k_copy_pairs(CopyPairsArgs A) {
+  const int r = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i < A.count[r]) A.dst[r][i] = A.src[r][i];
+}
+void launch_copy_pairs(const double* const* src, double* const* dst, const int* count, int n, hipStream_t s) {
+  CopyPairsArgs A{};
+  A.n = n;
+  int mx = 0;
+  for (int r = 0; r < n && r < 8; ++r) { A.src[r] = src[r]; A.dst[r] = dst[r]; A.count[r] = count[r]; mx = std::max(mx, count[r]); }
+  if (mx > 0) hipLaunchKernelGGL(k_copy_pairs, dim3((mx + 255) / 256, n), dim3(256), 0, s, A);
+}
+
 // the reverse: device arrays gathered into one staging buffer for ONE device -> host copy (DownloadBatch); `dst` of a
 // descriptor is the source pointer here
 __global__ __launch_bounds__(256) void k_gather(unsigned char* __restrict__ stage, unsigned desc_off) {
@@ -1110,12 +1124,10 @@ __global__ __launch_bounds__(256) void k_sep_extract_b(const GraphDev* __restric
   if (!G.arrow || !G.pose_sep || G.nsep <= 0) return;
   // the blockIdx.x-th separator pose of this robot
   __shared__ int s_q;
-  if (threadIdx.x == 0) {
-    int cnt = -1, q = -1;
-    for (int p = 0; p < G.P; ++p)
-      if (G.pose_sep[p] >= 0 && ++cnt == (int)blockIdx.x) { q = p; break; }
-    s_q = q;
-  }
+  if (threadIdx.x == 0) s_q = -1;
+  __syncthreads();
+  for (int p = threadIdx.x; p < G.P; p += 256)      // (pose_sep numbers the separator poses in pose order: offset 6 i for the i-th)
+    if (G.pose_sep[p] == 6 * (int)blockIdx.x) s_q = p;
   __syncthreads();
   const int q = s_q;
   if (q < 0) return;
@@ -1126,8 +1138,9 @@ __global__ __launch_bounds__(256) void k_sep_extract_b(const GraphDev* __restric
   const int nb_rows = G.nbr * NB;                            // border rows (the separator poses' own rows among them: nothing there yet)
   // (1) column strip: rows 6q .. end of the profile of q's last column's tile, plus the border rows and the right-hand side
   const int r_end = G.prof ? min(NT, (G.prof[(6 * q + 5) / NB] + 1) * NB) : NT;
-  for (int e = tid; e < 6 * (r_end - 6 * q); e += 256) {
-    const int a = e % 6, r = 6 * q + e / 6, c = 6 * q + a;
+  const int n_strip = r_end - 6 * q;
+  for (int e = tid; e < 6 * n_strip; e += 256) {             // (consecutive threads walk down one column of S)
+    const int a = e / n_strip, r = 6 * q + e % n_strip, c = 6 * q + a;
     if (r < c) continue;
     double* src = G.S + (size_t)c * ld + r;
     const double v = *src;
@@ -1140,7 +1153,7 @@ __global__ __launch_bounds__(256) void k_sep_extract_b(const GraphDev* __restric
     *src = (r == c) ? 1.0 : 0.0;
   }
   for (int e = tid; e < 6 * nb_rows; e += 256) {             // border rows at q's columns -> bord(row, o_c)
-    const int a = e % 6, b = e / 6;
+    const int a = e / nb_rows, b = e % nb_rows;
     double* src = G.S + (size_t)(6 * q + a) * ld + brow + b;
     const double v = *src;
     if (v != 0.0) { G.bord[(size_t)(oq + a) * ldb + b] = v; *src = 0.0; }
