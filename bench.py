@@ -286,6 +286,26 @@ def band_flops(T, prof, nbr):
     return tot
 
 
+def segmented_flops(segs, seg_prof_of, ends, first):
+    """The same two counts for a band cut into segments (slide_graph_get_segments / _get_segment_table): every segment is a bordered band
+    of its own whose border rows are the tile rows that are non-zero in it (first[s][i] <= column), the border product sums per segment."""
+    INF = 1 << 29
+    nbr = first.shape[1] - 1
+    band = done = 0.0
+    for s_, (t0, t1) in enumerate(segs):
+        f = first[s_]
+        for k in range(t0, t1):
+            v = (seg_prof_of(s_, k) - k) * 64
+            w = 64 * int(sum(1 for i in range(nbr) if f[i] <= k)) + 1
+            band += (v * v + 2.0 * v * w) * 64.0 + (v + w) * 64.0 * 64.0 + 64.0 ** 3 / 3.0
+        for j in range(nbr):
+            for i in range(j, nbr + 1):
+                c0 = max(int(f[i]), int(f[j]))
+                if c0 < INF:
+                    done += 2.0 * 64 ** 3 * max(0, ends[s_] - c0)
+    return band, done
+
+
 def border_flops(T, first):
     """FLOPs of the border product bord(i, j) -= sum_c W^T(i, c) W^T(j, c)^T over the tiles i >= j (i = nbr: the right-hand-side row):
     2 * 64^3 per tile and column block c >= max(first[i], first[j]) — (performed, the same with no column skipped)."""
@@ -454,7 +474,8 @@ def main():
         ptrs = [b.data_ptr() for b in bufs]
         if drv.arrow:
             info["border"] = [dict(first=[int(v) for v in gb.graph.border_profile()], T=int(gb.graph.stats()["chol_dim"] // 64),
-                                   prof=[int(v) for v in gb.graph.tile_profile()]) for gb in shards]
+                                   prof=[int(v) for v in gb.graph.tile_profile()], segs=gb.graph.segments(), segtab=gb.graph.segment_table())
+                              for gb in shards]
             if wdev == 1 and not drv.force_parts:
                 runs = [batch.profile_exact_joint(ptrs) for _ in range(7)]
                 info["exact_joint_stages_ms"] = {k: float(np.median([r[0][k] for r in runs])) for k in runs[0][0]}
@@ -620,8 +641,28 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
         # ---- the exact joint pass, stage by stage (HIP events on the pass's stream, un-captured passes after the timed region) ----
         bd = info["border"]
         groups = max(1, bt["launches"] // max(T, 1))
-        fl_band = sum(band_flops(b["T"], b["prof"], len(b["first"])) for b in bd)
-        fl_done, fl_dense = (sum(v) for v in zip(*[border_flops(b["T"], b["first"]) for b in bd]))
+        fl_band = fl_done = fl_dense = 0.0
+        n_seg = 1
+        for b in bd:
+            dn, de = border_flops(b["T"], b["first"])
+            fl_dense += de
+            if b.get("segtab") is not None and b["segs"][0]:
+                # a cut band: the segments' steps, the second level (the cuts' poses: a dense system of nsep block columns with the rest
+                # of the border as its border — counted with the band), the border product per segment
+                segs, n_sep_poses = b["segs"]
+                ends, first = b["segtab"]
+                n_seg = max(n_seg, len(segs))
+                fb, fd = segmented_flops(segs, lambda s_, k, b=b, segs=segs: min(b["prof"][k], segs[s_][1] - 1), ends, first)
+                nsep = (6 * n_sep_poses + 63) // 64
+                w2 = 64.0 * (len(b["first"]) - nsep) + 1
+                fl_band += fb + chol_flops(nsep) + w2 * (64.0 * nsep) ** 2 + w2 * w2 * 64.0 * nsep
+                fl_done += fd
+            else:
+                fl_band += band_flops(b["T"], b["prof"], len(b["first"]))
+                fl_done += dn
+        if n_seg > 1:      # launch sequences of the segments: bt["launches"] = sequences x the longest segment
+            seq_len = max(t1 - t0 for b in bd if b.get("segtab") is not None for (t0, t1) in b["segs"][0])
+            groups = max(1, round(bt["launches"] / max(seq_len, 1)))
         Ts = info["separator_block_columns"]
         blocks = info["sep_prof"][1] if isinstance(info.get("sep_prof"), tuple) else None
         if blocks is None:
@@ -643,7 +684,10 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
         exact = {
             "stages_ms": stages, "stages_sum_ms": float(sum(stages.values())),
             "band_factorisations": {
-                "kernel": f"k_chol_step_batched ({max(1, bt['robots'] // groups)} bordered systems per launch, {groups} overlapping launch sequences of {T} launches)",
+                "kernel": (f"k_chol_step_batched ({max(1, bt['robots'] // groups)} bordered systems per launch, {groups} overlapping launch sequences of {T} launches)"
+                           if n_seg == 1 else
+                           f"k_chol_step_batched (every band cut into {n_seg} segments factored side by side — nested dissection, the cuts' poses at a second "
+                           f"level: {bt['launches']} launches in the overlapping sequences of the segments, then the second level's)"),
                 "bound": "latency", "flops": fl_band, "window_ms": ms_band, "launches": bt["launches"],
                 "flops_per_launch": fl_band / max(bt["launches"], 1), "avg_launch_ms": ms_band * groups / max(bt["launches"], 1),
                 "achieved": tf(fl_band / groups, ms_band), "aggregate": tf(fl_band, ms_band), "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS,

@@ -222,11 +222,16 @@ int slide_chol_batch_set_separator_blocks(slide_chol_batch_t* b, int Ta, int Tb,
  * block columns (one launch each); cut into n_seg segments at windows of poses as wide as the band is (every coupling across a window
  * passes through it), the segments are factored side by side as systems of their own, and the windows' poses — moved into the border
  * next to the shared landmarks — are eliminated at a second level before the robot's Schur complement joins the separator system.
- * Same step (the elimination order changes, not the system); n_seg = 1 (default) factors every band as one chain; at most 4. */
+ * Same step (the elimination order changes, not the system); n_seg = 1 (default) factors every band as one chain; at most 8. */
 int slide_chol_batch_set_segments(slide_chol_batch_t* b, int n_seg);
 /* The cut of this graph's band: returns the number of segments (1: not cut — the batch does not ask for it, or the chain is too short);
  * out[2 i], out[2 i + 1] = tile columns [t0, t1) of segment i, out[2 n] = number of separator poses (cap >= 2 n + 1 ints). */
 int slide_graph_get_segments(slide_graph_t* g, int* out, int cap);
+/* Which border tile rows are non-zero in which segment of the cut band, and from which block column on (measurement aid: the flop count
+ * of the steps and of the border product follows from it).  Returns the table's length (0: the band is not cut) and fills out[0 .. cap):
+ * nseg, the segments' last block columns + 1, then per segment nbr + 1 ints = the first block column of every border tile row and of the
+ * right-hand side (1 << 30: the row is all-zero in that segment). */
+int slide_graph_get_segment_table(slide_graph_t* g, int* out, int cap);
 long long slide_chol_batch_sep_buffer_len(int m, int n_relmeas);
 /* Doubles at the head of that buffer a cut pass has to all-reduce: all of it, less the block between the two leaves of a dissected
  * layout (slide_chol_batch_set_separator_blocks: Ta x Tb tiles that are structurally zero and left out of the packed layout). */

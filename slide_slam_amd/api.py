@@ -28,7 +28,7 @@ EXPORTS = [
     "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
     "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
-    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_chol_batch_set_pcg_tolerance", "slide_graph_set_pcg_tolerance", "slide_graph_set_separator", "slide_chol_batch_set_exact_joint", "slide_chol_batch_sep_buffer_len", "slide_chol_batch_sep_exchange_len", "slide_chol_batch_profile_exact_joint", "slide_graph_get_border_profile", "slide_graph_get_incremental_stats", "slide_graph_get_segments", "slide_chol_batch_set_segments", "slide_clipper_dense_clique_batch", "slide_chol_batch_set_separator_profile", "slide_chol_batch_set_separator_blocks", "slide_graph_set_incremental", "slide_graph_set_ghost_ids", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
+    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_chol_batch_set_pcg_tolerance", "slide_graph_set_pcg_tolerance", "slide_graph_set_separator", "slide_chol_batch_set_exact_joint", "slide_chol_batch_sep_buffer_len", "slide_chol_batch_sep_exchange_len", "slide_chol_batch_profile_exact_joint", "slide_graph_get_border_profile", "slide_graph_get_incremental_stats", "slide_graph_get_segments", "slide_graph_get_segment_table", "slide_chol_batch_set_segments", "slide_clipper_dense_clique_batch", "slide_chol_batch_set_separator_profile", "slide_chol_batch_set_separator_blocks", "slide_graph_set_incremental", "slide_graph_set_ghost_ids", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
     "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
     "slide_dense_spd_solve", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device", "slide_assoc_sweep_batch",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
@@ -295,13 +295,27 @@ class SlideGraph:
 
     def segments(self):
         """Exact joint passes: (tile ranges of the band's segments, separator poses); ([], 0) when the band is not cut."""
-        out = np.zeros(16, np.int32)
-        n = self.L.slide_graph_get_segments(self.h, _p(out), C.c_int(16))
+        out = np.zeros(32, np.int32)
+        n = self.L.slide_graph_get_segments(self.h, _p(out), C.c_int(32))
         if n < 0:
             _check(-n)
         if n <= 1:
             return [], 0
         return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)], int(out[2 * n])
+
+    def segment_table(self):
+        """Exact joint passes over a cut band: (ends, first) — ends[s] = last block column + 1 of segment s, first[s][i] = first block
+        column of segment s in which border tile row i is non-zero (i = nbr: the right-hand side; 1 << 30: never) — or None."""
+        n = self.L.slide_graph_get_segment_table(self.h, None, C.c_int(0))
+        if n < 0:
+            _check(-n)
+        if n == 0:
+            return None
+        out = np.zeros(n, np.int32)
+        self.L.slide_graph_get_segment_table(self.h, _p(out), C.c_int(n))
+        ns = int(out[0])
+        w = (n - 1 - ns) // ns
+        return [int(v) for v in out[1:1 + ns]], out[1 + ns:].reshape(ns, w).astype(np.int64)
 
     def border_profile(self):
         """Exact joint step: first[i] = first block column of the band in which border tile row i can be non-zero (len = border row tiles)."""

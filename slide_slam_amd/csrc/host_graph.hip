@@ -614,7 +614,7 @@ int CholBatch::prepare_pass() {
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_ctr2), 64 * sizeof(int)));
       SL_HIP(hipMemset(d_ctr2, 0, 64 * sizeof(int)));
     }
-    if ((int)seg_sys.size() > 4 * CHOL_BATCH_HOST_MAX || (int)l2_sys.size() > CHOL_BATCH_HOST_MAX) { g_last_error = "exact joint step: too many segment systems"; return SLIDE_ERR_CAPACITY; }
+    if ((int)seg_sys.size() > 8 * CHOL_BATCH_HOST_MAX || (int)l2_sys.size() > CHOL_BATCH_HOST_MAX) { g_last_error = "exact joint step: too many segment systems"; return SLIDE_ERR_CAPACITY; }
     return prepare_separator();
   }
   return SLIDE_OK;
@@ -633,7 +633,7 @@ void CholBatch::set_segments(int n) {
   std::vector<HostGraph*> gs;
   {
     std::lock_guard<std::mutex> lk(mtx);
-    n_seg = n < 1 ? 1 : (n > 4 ? 4 : n);
+    n_seg = n < 1 ? 1 : (n > 8 ? 8 : n);
     pass_dirty = true;
     gs.assign(graphs.begin(), graphs.end());
   }
@@ -853,6 +853,7 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     mark(1);
     if (n_syrk_jobs > 0) launch_border_syrk_jobs(sys.data(), n, d_syrk_jobs, n_syrk_jobs, syrk_lds_pad, master);      // border blocks: C_a - W^T W, b_s - W^T y
     else launch_border_syrk(sys.data(), n, master);
+    mark(6);
     if (!l2_sys.empty()) {
       // second level: the separator poses' own system (dense, nsep block columns) with the rest of the border as its border
       launch_chol_batch(l2_sys.data(), (int)l2_sys.size(), d_ctr2, master, nullptr, false);
@@ -969,13 +970,13 @@ int CholBatch::profile_arrow(double* const* d_bufs, double* out6, int* n_sep_ste
   rc = enqueue_arrow(d_bufs, -1, nullptr, nullptr);
   const hipError_t es = hipStreamSynchronize(master);
   if (rc == SLIDE_OK && es == hipSuccess) {
-    hipEvent_t prev = start;
-    for (int i = 0; i < 6; ++i) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, prev, prof_ev[i]) != hipSuccess) rc = SLIDE_ERR_HIP;
-      out6[i] = ms;
-      prev = prof_ev[i];
-    }
+    // stages: assembly | segments' steps | robots' border product | second level of the bands (steps + its product) | gather |
+    // separator | back-substitution; the second level counts as band factorisation
+    hipEvent_t seq[8] = {start, prof_ev[0], prof_ev[1], prof_ev[6], prof_ev[2], prof_ev[3], prof_ev[4], prof_ev[5]};
+    float d[7] = {};
+    for (int i = 0; i < 7; ++i)
+      if (hipEventElapsedTime(&d[i], seq[i], seq[i + 1]) != hipSuccess) rc = SLIDE_ERR_HIP;
+    out6[0] = d[0]; out6[1] = d[1] + d[3]; out6[2] = d[2]; out6[3] = d[4]; out6[4] = d[5]; out6[5] = d[6];
     if (n_sep_steps) *n_sep_steps = sep_Ts;
   } else if (rc == SLIDE_OK) rc = SLIDE_ERR_HIP;
   (void)hipEventDestroy(start);
@@ -2411,6 +2412,15 @@ int HostGraph::get_border_profile(int* out, int cap) {
   if (!arrow_on()) return 0;
   for (int i = 0; i < nbr && i < cap; ++i) out[i] = h_bfirst[i];
   return nbr;
+}
+// the per-segment activity table of the border rows (seg_tab, host_graph.hpp): returns its length, 0 when the band is not cut
+int HostGraph::get_segment_table(int* out, int cap) {
+  int rc = merge_pending();
+  if (rc == SLIDE_OK) rc = upload_new();
+  if (rc != SLIDE_OK) return rc < 0 ? rc : -rc;
+  if (!arrow_on() || nsep <= 0 || seg_tab.empty()) return 0;
+  for (size_t i = 0; i < seg_tab.size() && (int)i < cap; ++i) out[i] = seg_tab[i];
+  return (int)seg_tab.size();
 }
 int HostGraph::get_segments(int* out, int cap) {
   int rc = merge_pending();

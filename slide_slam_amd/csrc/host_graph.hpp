@@ -236,7 +236,7 @@ class CholBatch {
   }
   int prepare_separator();
   int enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hipEvent_t e1);
-  hipEvent_t prof_ev[6] = {};
+  hipEvent_t prof_ev[7] = {};       // (profile_arrow: [6] = behind the robots' border product, before the bands' second level)
   void free_separator();
   int enqueue_pcg_head(double* const* d_bufs);                   // r = b, u = M^-1 b, t_l(u) packed + local sum
   int enqueue_pcg_mid(double* const* d_bufs, bool whole);                    // w = S u, partial dots + local sum
@@ -313,7 +313,8 @@ class HostGraph {
   void incremental_stats(int64_t* out4) const { out4[0] = n_inc; out4[1] = n_full; out4[2] = last_cd; out4[3] = G.T; }
   int get_tile_profile(int* out, int cap);
   int get_border_profile(int* out, int cap);
-  int get_segments(int* out, int cap);          // number of segments of the band in exact joint passes (1: not cut); out[2 i], out[2 i + 1] = tile range of segment i; out[2 n] = separator poses   // nbr (>= 0) or a negative error; out[i] = first block column of border tile row i, i < min(nbr, cap)     // T (>= 0) or a negative error; out[c] = prof[c] for c < min(T, cap)
+  int get_segments(int* out, int cap);
+  int get_segment_table(int* out, int cap);          // number of segments of the band in exact joint passes (1: not cut); out[2 i], out[2 i + 1] = tile range of segment i; out[2 n] = separator poses   // nbr (>= 0) or a negative error; out[i] = first block column of border tile row i, i < min(nbr, cap)     // T (>= 0) or a negative error; out[c] = prof[c] for c < min(T, cap)
   void set_dense_profile(bool on);        // ignore the structure of the reduced system (measurement aid)
   int pcg_stats(double* out8);            // scalars of the last joint solve: gamma_old, alpha_old, alpha, beta, first gamma, last gamma               // entries merge_pending refused since creation
 

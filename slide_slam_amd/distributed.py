@@ -377,12 +377,12 @@ class PassDriver:
                 batch.set_separator_blocks(*(blocks if blocks is not None else (0, 0, 0, 0)))
                 self.sep_blocks = blocks
             import os
-            # nested dissection of the robots' own bands (slide_chol_batch_set_segments): it pays when few robots share the GPU — the
-            # segments' type-A workgroups then still fit the chip side by side (measured: 2 robots x 500 poses 1.44 -> 1.25 ms per
-            # pass with 2 segments, 1.28 with 4; 8 robots x 625 poses 3.69 -> 3.94: DESIGN 0) — so a process with one or two robots
-            # cuts every band once, which is the per-GPU load of a job spread over four or eight GPUs
+            # nested dissection of the robots' own bands (slide_chol_batch_set_segments; every segment carries only the border rows that
+            # are non-zero in it).  Measured on one MI355X: 8 robots x 625 poses 3.06 ms per pass uncut, 2.64 / 2.54 / 2.60 with
+            # 2 / 3 / 4 segments; 2 robots x 500 poses 1.37 uncut, 1.12 / 1.08 / 1.04 / 1.04 with 2 / 3 / 4 / 6 — the fewer robots share
+            # the GPU, the more segments fit side by side
             seg = os.environ.get("SLIDE_SEGMENTS")
-            batch.set_segments((int(seg) if seg else (2 if len(shards) <= 2 else 1)) if self.arrow else 1)
+            batch.set_segments((int(seg) if seg else (4 if len(shards) <= 4 else 3)) if self.arrow else 1)
         if batch is not None:           # (always pushed, zero included: a batch or graph may still hold an earlier driver's setting)
             batch.set_pcg(self.pcg_iters, self.pcg_tol)
         else:
