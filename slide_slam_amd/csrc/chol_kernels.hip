@@ -1628,7 +1628,7 @@ void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv,
 }
 // The factorisations + solves of several systems as one launch sequence (max T step launches, the extractions, one chained backward
 // substitution): d[i] describes system i; ctr is the work counter array of the batch (max T + 2 ints, zeroed once).
-void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps, bool solve) {
+void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps, bool solve, int cu_share) {
   const int n_cu = chol_n_cu();
   int Tmax = 0;
   for (int i = 0; i < n; ++i) Tmax = d[i].T > Tmax ? d[i].T : Tmax;
@@ -1638,7 +1638,11 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
     long long nA2 = 0, nBt = 0;
     StepPlan pl[CHOL_BATCH_MAX];
     for (int i = 0; i < n; ++i) { pl[i] = plan_step(k, d[i].T, d[i].h_prof, d[i].nbr, d[i].h_bfirst, d[i].kofs); nA2 += 2 * pl[i].nA; nBt += pl[i].nB; }
-    const int a_split = (k > 0 && nA2 + nBt <= n_cu) ? 1 : 0;
+    // two workgroups per type-A tile only while the launch's share of the chip holds them: `cu_share` percent of the CUs (the launch
+    // sequences that run side by side divide the chip: three sequences of eight cut bands at 100 % each 0.63 ms, at 33 - 50 % 0.54)
+    static const int env_share = getenv("SLIDE_CHOL_BSPLIT") ? atoi(getenv("SLIDE_CHOL_BSPLIT")) : -1;
+    const int share = env_share >= 0 ? env_share : cu_share;
+    const int a_split = (k > 0 && (nA2 + nBt) * 100 <= (long long)n_cu * share) ? 1 : 0;
     A.a_base[0] = A.b_base[0] = 0;
     for (int i = 0; i < n; ++i) {
       A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.Ld[i] = d[i].Ld; A.Winv[i] = d[i].Winv; A.status[i] = d[i].status;

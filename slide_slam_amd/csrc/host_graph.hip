@@ -1213,7 +1213,7 @@ int CholBatch::factor_all(hipEvent_t after) {
       st = aux[g];
       SL_HIP(hipStreamWaitEvent(st, ev_aux0, 0));
     }
-    launch_chol_batch(S_.data() + lo, hi - lo, d_ctr + (size_t)g * (ctr_cap / CHOL_BATCH_HOST_MAX), st, nullptr, solve);
+    launch_chol_batch(S_.data() + lo, hi - lo, d_ctr + (size_t)g * (ctr_cap / CHOL_BATCH_HOST_MAX), st, nullptr, solve, std::max(25, 100 / groups));
     if (g > 0) {
       SL_HIP(hipEventRecord(ev_aux1[g], st));
       SL_HIP(hipStreamWaitEvent(master, ev_aux1[g], 0));
