@@ -99,6 +99,8 @@ struct GraphDev {
                      //    rows E^T ride below the band as nbr border row tiles of S, their own blocks start the border x border block
   int nbr;           // border row tiles: physical tile rows T .. T + nbr - 1 of S; the right-hand-side row is tile row T + nbr
   const int* lm_bord; // L   offset of a shared landmark's tangent coordinates in this robot's border, or -1
+  const int* seg_tab; // or null: the band is cut — nseg, the segments' last block columns + 1, then per segment the first block column of every
+                      // border tile row + the right-hand side (HostGraph::seg_tab): what lies outside is never written and stays zero
   double* bord;      // ((nbr + 1) * NB) x (nbr * NB), column-major, ldb: border x border block (lower) + right-hand-side row at nbr * NB
   int ldb;
   const int* pose_sep; // P   border offset of a SEPARATOR POSE's six coordinates, or -1 / null.  Nested dissection of the robot's own pose

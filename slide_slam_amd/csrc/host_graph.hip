@@ -1850,6 +1850,12 @@ int HostGraph::upload_new() {
   G.arrow = arrow_now ? 1 : 0; G.nbr = nbr; G.lm_bord = arrow_now ? d_lm_bord.d : nullptr; G.bord = arrow_now ? d_bord.d : nullptr;
   G.ldb = (nbr + 1) * NB;
   G.gh_bord = (arrow_now && lam_total > 0) ? d_gh_bord.d : nullptr;
+  G.seg_tab = nullptr;
+  if (arrow_now && !seg_tab.empty() && nbr > 0 && !getenv("SLIDE_FULL_CLEAR")) {
+    // the per-pass clear of the border rows is restricted to what the segments work on; whatever an earlier layout left elsewhere goes now
+    G.seg_tab = d_seg_tab.d;
+    SL_HIP(hipMemset2DAsync(d_S.d + (size_t)T * NB, (size_t)(Tcap + nbr_alloc + 1) * NB * sizeof(double), 0, (size_t)(nbr + 1) * NB * sizeof(double), (size_t)T * NB, s));
+  }
   G.pose_sep = (arrow_now && nsep > 0) ? d_pose_sep.d : nullptr; G.nsep = arrow_now ? nsep : 0; G.nsep_dim = arrow_now ? nsep_dim : 0;
   // the segments' own profiles (their rows end where the separator begins: what lay beyond moved into the border)
   seg_prof.clear(); seg_prof_off.clear();

@@ -1078,6 +1078,22 @@ __global__ __launch_bounds__(256) void k_border_clear_b(const GraphDev* __restri
   if (!G.arrow || G.nbr <= 0) return;
   const long long nrow = (long long)G.nbr * NB, ncol = (long long)G.T * NB;
   const long long nb = (long long)(G.nbr + 1) * NB * G.nbr * NB;
+  if (G.seg_tab) {
+    // a cut band: only the (tile row, block column) pairs some segment works on — a row's tiles from its first block column in a segment to
+    // that segment's end; everything else is never written by fill, extraction or steps and holds the zeros of the allocation
+    const int* st = G.seg_tab;
+    const int nseg = st[0], ntile = G.nbr * G.T;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+      const int t = tile % G.nbr, c = tile / G.nbr;
+      bool on = false;
+      for (int q = 0; q < nseg; ++q) on = on || (st[1 + nseg + q * (G.nbr + 1) + t] <= c && c < st[1 + q]);
+      if (!on) continue;
+      double* base = G.S + (size_t)c * NB * G.ld + (size_t)(G.T + t) * NB;
+      for (int e = threadIdx.x; e < NB * NB; e += 256) base[(size_t)(e >> 6) * G.ld + (e & 63)] = 0.0;
+    }
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < nb; t += (long long)gridDim.x * 256) G.bord[t] = 0.0;
+    return;
+  }
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < nrow * ncol + nb; t += (long long)gridDim.x * 256) {
     if (t < nrow * ncol) G.S[(size_t)(t / nrow) * G.ld + (size_t)G.T * NB + (size_t)(t % nrow)] = 0.0;
     else G.bord[t - nrow * ncol] = 0.0;
