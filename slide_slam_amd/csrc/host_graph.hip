@@ -814,6 +814,7 @@ int CholBatch::enqueue_ghost_refresh(double* const* d_bufs, int part) {
     if (hG[i].n_gslots != ng) { g_last_error = "batched pass: the graphs disagree on the ghost slots"; return SLIDE_ERR_INVALID; }
   if (ng <= 0) return SLIDE_OK;
   const bool whole = part < 0;
+  if (whole) { launch_ghost_refresh_local(d_Gs, n, ng, master); return SLIDE_OK; }
   if (whole || part == 20) {
     launch_ghost_exchange_batched(d_Gs, n, ng, 0, d_bufs, master);
     launch_sum_bcast(d_bufs, n, 12 * ng, master);
@@ -834,9 +835,7 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
   const int ld_s = (sep_Ts + sep_nl + 1) * NB;
   const SepLayout Y = sep_layout();
   if (whole || part == 0) {
-    launch_status_clear(d_Gs, n, master);
-    launch_ints_clear(sep_status, 8, master);
-    if (sep_nl > 0) launch_ints_clear(lam_status, 8, master);
+    launch_status_clear(d_Gs, n, master, sep_status, sep_nl > 0 ? lam_status : nullptr);
     const int rg = enqueue_ghost_refresh(d_bufs, part);
     if (rg != SLIDE_OK) return rg;
     launch_phase0_batched(d_Gs, hG.data(), n, d_bufs, master, false);      // relinearise, linearise, the robots' own per-landmark sums (nothing to pack: no exchange of them)
@@ -947,9 +946,7 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     launch_chol_bwd_batch(seg_sys.data(), (int)seg_sys.size(), master);      // L^T dp = y, all segments side by side
     launch_sep_pose_scatter_batched(d_Gs, hG.data(), n, xloc, master);
     launch_arrow_finish_batched(d_Gs, hG.data(), n, sep_dp, d_sep_off, master);
-    launch_status_or(hG[0].status, sep_status, 8, master);           // (the separator's not-SPD / chain flags are reported with graph 0's)
-    if (sep_nl > 0) launch_status_or(hG[0].status, lam_status, 8, master);
-    launch_status_gather(d_Gs, n, d_status_all, master);
+    launch_status_gather(d_Gs, n, d_status_all, master, sep_status, sep_nl > 0 ? lam_status : nullptr);      // (the separator's not-SPD / chain flags are reported with graph 0's)
     mark(5);
   }
   return SLIDE_OK;

@@ -40,6 +40,7 @@ void launch_sep_pose_scatter_batched(const GraphDev* d, const GraphDev* h, int n
 // coupling rows of the lam "lambda" coordinates of the inter-robot relative-pose factors, right-hand-side tile row), the lambda x lambda
 // block + its right-hand-side row in bord (ldb = (nl + 1) * NB); packed: the exchange buffer (lower tile columns of the whole)
 struct SepLayout { double* sys; double* bord; double* packed; int Ts, nl, ms, lam; int gap[4]; int hTa, hTL; };      // gap: two ranges [lo, hi) of landmark coordinates no slot uses (padding between the blocks of a dissected layout): unit diagonal; hTa, hTL: tile rows [hTa, hTL) of the tile columns < hTa are structurally zero (leaf b's rows under leaf a's columns) and absent from the packed layout
+void launch_ghost_refresh_local(const GraphDev* d, int n, int n_gslots, hipStream_t s);      // ghost poses of a whole pass on one GPU: pack + sum + adopt in one launch
 void launch_copy_pairs(const double* const* src, double* const* dst, const int* count, int n, hipStream_t s);      // up to 8 small device-to-device copies in one launch
 void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, const SepLayout& Y, bool packed, hipStream_t s, const int* tmask = nullptr);      // tmask: Ts + nl ints, bit r = robot r holds a coordinate of the (virtual) tile
 void launch_sep_unpack(const SepLayout& Y, hipStream_t s);
@@ -94,8 +95,8 @@ int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double
 // pcg_kernels.hip — joint Gauss-Newton step of the robots of a GPU (and, through the caller's exchanges, of the job): PCG on the
 // global reduced pose system with the robots' own factors as preconditioner.  d: device array of the n graphs' views, h: host copy.
 enum { PCG_VEC_R = 0, PCG_VEC_U = 1, PCG_VEC_W = 2, PCG_VEC_P = 3, PCG_VEC_S = 4, PCG_VEC_X = 5, PCG_VEC_Y = 6, PCG_VEC_COUNT = 7 };
-void launch_status_clear(const GraphDev* d, int n, hipStream_t s);             // status[0..7] = 0 for every graph of the batch
-void launch_status_gather(const GraphDev* d, int n, int* out, hipStream_t s);  // out[8 i ..] = graph i's status words
+void launch_status_clear(const GraphDev* d, int n, hipStream_t s, int* x0 = nullptr, int* x1 = nullptr);      // x0 / x1: two more 8-word status blocks cleared in the same launch             // status[0..7] = 0 for every graph of the batch
+void launch_status_gather(const GraphDev* d, int n, int* out, hipStream_t s, const int* x0 = nullptr, const int* x1 = nullptr);      // x0 / x1: OR-ed into graph 0's flags first  // out[8 i ..] = graph i's status words
 void launch_ints_clear(int* p, int n, hipStream_t s);                          // p[0 .. n-1] = 0 (a kernel node: see launch_status_clear)
 void launch_status_or(int* dst, const int* src, int n, hipStream_t s);         // dst[i] |= src[i]
 void launch_pcg_init(const GraphDev* d, const GraphDev* h, int n, hipStream_t s);

@@ -888,21 +888,37 @@ void launch_sum_bcast(double* const* bufs, int n, int count, hipStream_t s) {
 
 // status words of the joined graphs: cleared by the first node of a batched pass, gathered into one array by its last (one device ->
 // host copy per pass instead of one per robot)
-__global__ void k_status_clear(const GraphDev* __restrict__ Gs) {
-  if (threadIdx.x < 8) Gs[blockIdx.x].status[threadIdx.x] = 0;
+// x0 / x1 (or null): two more status blocks of eight words (the separator's, the lambdas') handled by workgroup 0 in the same launch:
+// cleared with the graphs' — or, at the end of a pass, OR-ed into graph 0's flags before the gather (words 4 / 5 are ticket counters)
+__global__ void k_status_clear(const GraphDev* __restrict__ Gs, int* x0, int* x1) {
+  if (threadIdx.x < 8) {
+    Gs[blockIdx.x].status[threadIdx.x] = 0;
+    if (blockIdx.x == 0) {
+      if (x0) x0[threadIdx.x] = 0;
+      if (x1) x1[threadIdx.x] = 0;
+    }
+  }
 }
-__global__ void k_status_gather(const GraphDev* __restrict__ Gs, int* __restrict__ out) {
-  if (threadIdx.x < 8) out[8 * blockIdx.x + threadIdx.x] = Gs[blockIdx.x].status[threadIdx.x];
+__global__ void k_status_gather(const GraphDev* __restrict__ Gs, int* __restrict__ out, const int* x0, const int* x1) {
+  if (threadIdx.x < 8) {
+    int v = Gs[blockIdx.x].status[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x != 4 && threadIdx.x != 5) {
+      if (x0) v |= x0[threadIdx.x];
+      if (x1) v |= x1[threadIdx.x];
+      Gs[0].status[threadIdx.x] = v;
+    }
+    out[8 * blockIdx.x + threadIdx.x] = v;
+  }
 }
 __global__ void k_ints_clear(int* p, int n) { if ((int)threadIdx.x < n) p[threadIdx.x] = 0; }
 __global__ void k_status_or(int* dst, const int* src, int n) { if ((int)threadIdx.x < n && threadIdx.x != 4 && threadIdx.x != 5) dst[threadIdx.x] |= src[threadIdx.x]; }   // (words 4 / 5 are ticket counters)
 void launch_ints_clear(int* p, int n, hipStream_t s) { hipLaunchKernelGGL(k_ints_clear, dim3(1), dim3(64), 0, s, p, n); }
 void launch_status_or(int* dst, const int* src, int n, hipStream_t s) { hipLaunchKernelGGL(k_status_or, dim3(1), dim3(64), 0, s, dst, src, n); }
-void launch_status_clear(const GraphDev* d, int n, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_status_clear, dim3(n), dim3(64), 0, s, d);
+void launch_status_clear(const GraphDev* d, int n, hipStream_t s, int* x0, int* x1) {
+  if (n > 0) hipLaunchKernelGGL(k_status_clear, dim3(n), dim3(64), 0, s, d, x0, x1);
 }
-void launch_status_gather(const GraphDev* d, int n, int* out, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_status_gather, dim3(n), dim3(64), 0, s, d, out);
+void launch_status_gather(const GraphDev* d, int n, int* out, hipStream_t s, const int* x0, const int* x1) {
+  if (n > 0) hipLaunchKernelGGL(k_status_gather, dim3(n), dim3(64), 0, s, d, out, x0, x1);
 }
 
 // buf[0] -> buf[1 .. n-1]: hands the result of a cross-GPU all-reduce (done on buf[0]) to the other robots of this GPU
@@ -1349,6 +1365,23 @@ __global__ void k_ghost_exchange_b(const GraphDev* __restrict__ Gs, int what, Gh
   } else {
     G.ghost_val[t] = buf[t];
   }
+}
+// whole pass on one GPU: every robot adopts the owners' current estimates directly (pack, sum over the robots in their order, adopt
+// in one launch instead of three)
+__global__ void k_ghost_refresh_local(const GraphDev* __restrict__ Gs, int n) {
+  const GraphDev G = Gs[blockIdx.z];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 12 * G.n_gslots) return;
+  double v = 0.0;
+  for (int q = 0; q < n; ++q) {
+    const int p = Gs[q].gslot_pose[t / 12];
+    v += p >= 0 ? Gs[q].pose_est[12 * (size_t)p + t % 12] : 0.0;
+  }
+  G.ghost_val[t] = v;
+}
+void launch_ghost_refresh_local(const GraphDev* d, int n, int n_gslots, hipStream_t s) {
+  if (n_gslots <= 0 || n <= 0) return;
+  hipLaunchKernelGGL(k_ghost_refresh_local, dim3((12 * n_gslots + 127) / 128, 1, n), dim3(128), 0, s, d, n);
 }
 void launch_ghost_exchange_batched(const GraphDev* d, int n, int n_gslots, int what, double* const* bufs, hipStream_t s) {
   if (n_gslots <= 0 || n <= 0) return;
