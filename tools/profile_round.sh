@@ -21,7 +21,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/apmc_w -- python3 tools/a
 echo "assoc done"
 fi
 python3 tools/profile_summary.py $OUT $R
-python3 tools/trace_batched.py $OUT/trace 59 > profiles/${R}_bench_chol_step_batched_by_k.txt 2>&1
+python3 tools/trace_batched.py $OUT/trace 15 > profiles/${R}_bench_chol_step_batched_by_k.txt 2>&1
 python3 tools/trace_exact.py $OUT/trace 15 > profiles/${R}_exact_pass_kernels.txt 2>&1
 # the raw traces are hundreds of MB: keep the summaries only (profiles/ is what is committed; a copy goes back through gpurun_out/)
 rm -rf $OUT/trace $OUT/pmc_f $OUT/pmc_w $OUT/atrace $OUT/apmc_f $OUT/apmc_w
