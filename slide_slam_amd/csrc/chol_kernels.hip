@@ -653,17 +653,17 @@ __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ S, int l
 // then one work queue over the type-B items of all of them.  Same device code as k_chol_step, per-system parameters by value.
 struct CholBatchArgs {
   int n;
-  double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX];
-  double* Ld[CHOL_BATCH_MAX]; double* Winv[CHOL_BATCH_MAX]; int* status[CHOL_BATCH_MAX];
-  float* L32[CHOL_BATCH_MAX];
-  int TvA[CHOL_BATCH_MAX], TvB[CHOL_BATCH_MAX], TvX[CHOL_BATCH_MAX];      // virtual sizes of the step (profile), see b_decode
-  int nP[CHOL_BATCH_MAX], g0[CHOL_BATCH_MAX], g1[CHOL_BATCH_MAX], nX[CHOL_BATCH_MAX], a_split[CHOL_BATCH_MAX];
-  int nbr[CHOL_BATCH_MAX];             // border row tiles below the profile (b_decode)
-  int nbA[CHOL_BATCH_MAX], nbB[CHOL_BATCH_MAX], nbX[CHOL_BATCH_MAX];      // ... of which active for column k / the pair's pass / the column items
-  int B0[CHOL_BATCH_MAX];              // tile row at which the border rows start (T, or further down for a segment view: CholSystem::b0)
-  const int* ord[CHOL_BATCH_MAX];      // order of the active border rows of a view (CholSystem::ord) or null
-  int a_base[CHOL_BATCH_MAX + 1];      // prefix sums of the type-A workgroup counts
-  int b_base[CHOL_BATCH_MAX + 1];      // prefix sums of the type-B item counts
+  double* S[CHOL_STEP_BATCH_MAX]; int ld[CHOL_STEP_BATCH_MAX]; int T[CHOL_STEP_BATCH_MAX];
+  double* Ld[CHOL_STEP_BATCH_MAX]; double* Winv[CHOL_STEP_BATCH_MAX]; int* status[CHOL_STEP_BATCH_MAX];
+  float* L32[CHOL_STEP_BATCH_MAX];
+  int TvA[CHOL_STEP_BATCH_MAX], TvB[CHOL_STEP_BATCH_MAX], TvX[CHOL_STEP_BATCH_MAX];      // virtual sizes of the step (profile), see b_decode
+  int nP[CHOL_STEP_BATCH_MAX], g0[CHOL_STEP_BATCH_MAX], g1[CHOL_STEP_BATCH_MAX], nX[CHOL_STEP_BATCH_MAX], a_split[CHOL_STEP_BATCH_MAX];
+  int nbr[CHOL_STEP_BATCH_MAX];             // border row tiles below the profile (b_decode)
+  int nbA[CHOL_STEP_BATCH_MAX], nbB[CHOL_STEP_BATCH_MAX], nbX[CHOL_STEP_BATCH_MAX];      // ... of which active for column k / the pair's pass / the column items
+  int B0[CHOL_STEP_BATCH_MAX];              // tile row at which the border rows start (T, or further down for a segment view: CholSystem::b0)
+  const int* ord[CHOL_STEP_BATCH_MAX];      // order of the active border rows of a view (CholSystem::ord) or null
+  int a_base[CHOL_STEP_BATCH_MAX + 1];      // prefix sums of the type-A workgroup counts
+  int b_base[CHOL_STEP_BATCH_MAX + 1];      // prefix sums of the type-B item counts
 };
 __global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int k, int kb, int* __restrict__ ctr, int a_joins) {
   __shared__ ALds L;
@@ -717,7 +717,7 @@ __global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, in
 }
 
 // the same for up to 8 systems in one launch (blockIdx.y = system): eight 5 us launches in a row at the end of the bands' steps otherwise
-struct ExtractArgs { int n; const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX]; int Tr[CHOL_BATCH_MAX]; double* yv[CHOL_BATCH_MAX]; double* dp[CHOL_BATCH_MAX]; int* status[CHOL_BATCH_MAX]; };
+struct ExtractArgs { int n; const double* S[CHOL_STEP_BATCH_MAX]; int ld[CHOL_STEP_BATCH_MAX]; int T[CHOL_STEP_BATCH_MAX]; int Tr[CHOL_STEP_BATCH_MAX]; double* yv[CHOL_STEP_BATCH_MAX]; double* dp[CHOL_STEP_BATCH_MAX]; int* status[CHOL_STEP_BATCH_MAX]; };
 __global__ void k_chol_extract_y_b(ExtractArgs A) {
   const int r = blockIdx.y;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1636,7 +1636,7 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
     CholBatchArgs A{};
     A.n = n;
     long long nA2 = 0, nBt = 0;
-    StepPlan pl[CHOL_BATCH_MAX];
+    StepPlan pl[CHOL_STEP_BATCH_MAX];
     for (int i = 0; i < n; ++i) { pl[i] = plan_step(k, d[i].T, d[i].h_prof, d[i].nbr, d[i].h_bfirst, d[i].kofs); nA2 += 2 * pl[i].nA; nBt += pl[i].nB; }
     // two workgroups per type-A tile only while the launch's share of the chip holds them: `cu_share` percent of the CUs (the launch
     // sequences that run side by side divide the chip: three sequences of eight cut bands at 100 % each 0.63 ms, at 33 - 50 % 0.54)

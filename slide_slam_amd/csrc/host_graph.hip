@@ -1182,11 +1182,11 @@ int CholBatch::factor_all(hipEvent_t after) {
   bool narrow = true;
   for (int i = 0; i < n; ++i) narrow = narrow && hG[i].schur_split == 1;
   int groups = env_groups > 0 ? env_groups : (narrow ? 4 : 2);
-  // cut bands: three times the systems, a third of the launches each — as few sequences as hold them (24 systems: 0.62 ms in three
-  // sequences of eight, 0.65 in four of six, 0.85 in six of four)
-  if (env_groups <= 0 && exact && ns > n) groups = std::max(2, (ns + CHOL_BATCH_HOST_MAX - 1) / CHOL_BATCH_HOST_MAX);
+  // cut bands: three times the systems, a third of the launches each — few sequences, but two: one alone leaves every dispatch gap
+  // open (24 systems: 0.60 ms in one sequence, 0.53 in two of twelve, 0.54 in three of eight, 0.65 in four of six, 0.85 in six of four)
+  if (env_groups <= 0 && exact && ns > n) groups = std::max(2, (ns + 11) / 12);
   if (groups > (env_groups > 0 ? ns : ns / 2)) groups = env_groups > 0 ? ns : ns / 2;      // (at least two systems per sequence by default)
-  while (groups > 0 && (ns + groups - 1) / groups > CHOL_BATCH_HOST_MAX) ++groups;           // (at most eight systems per launch)
+  while (groups > 0 && (ns + groups - 1) / groups > CHOL_STEP_BATCH_MAX) ++groups;          // (the step kernel's argument block holds that many systems)
   if (groups > 8) groups = 8;
   last_groups = groups < 1 ? 1 : groups;
   const bool solve = !exact;

@@ -73,6 +73,7 @@ struct CholSystem { double* S; int ld, T; double* Ld; double* Winv; double* yv; 
                                                  // of first columns: h_bfirst is then that segment's sorted list)
                     const int* segtab; };        // device or null (border product of a segmented band): nseg, the segments' end columns, per segment the first column of
                                                  // every border tile row + the right-hand side (1 << 30: the row is zero in that segment)
+constexpr int CHOL_STEP_BATCH_MAX = 32;      // systems per launch of the batched step kernel (the segments of eight robots' bands in one launch sequence)
 void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps = nullptr, bool solve = true, int cu_share = 100);            // up to 8 systems, one launch per block column; solve = false: steps + extraction of y only; cu_share: percent of the CUs this launch sequence may count on (sequences running side by side)
 void launch_chol_bwd_batch(const CholSystem* d, int n, hipStream_t s);       // yv -> dp of up to 8 factored systems (chained backward substitution)
 // Exact joint step (the border of the systems = the separator's coupling rows, W^T after the steps):
