@@ -218,6 +218,16 @@ int slide_chol_batch_set_separator_profile(slide_chol_batch_t* b, const int32_t*
  * elimination order changes.  (0, 0, 0, 0): not dissected (default).  The reference has no counterpart: its replica solves the joint
  * system inside GTSAM (graph.cpp:260-272), whose elimination order is COLAMD's. */
 int slide_chol_batch_set_separator_blocks(slide_chol_batch_t* b, int Ta, int Tb, int used_a, int used_b);
+/* A job that spans GPUs whose ranks split in two halves ALONG the dissection (the robots of the first half of the ranks see leaf a and
+ * the top block only, those of the second half leaf b and the top block): this rank owns leaf `leaf` (0 / 1; -1: none, the default).  It
+ * factors that leaf only, and only the top block of the separator system crosses between the halves.  A cut pass then runs
+ *   [20 | AR ghosts |] part 0 | all-reduce of the OWN leaf's segment of sep_buf within the own half (nothing when the half is one rank) |
+ *   part 1 | all-reduce of the top segment over all ranks | part 2
+ * (slide_chol_batch_sep_segment gives the segments' offsets and lengths in doubles: which = 0 leaf a, 1 leaf b, 2 top block + lambdas).
+ * leader: non-zero on ONE rank of each half — the one that adds the leaf's Schur complement to the top block's sum.  C4 on two GPUs:
+ * 5 MB cross the link per pass instead of 45. */
+int slide_chol_batch_set_separator_owner(slide_chol_batch_t* b, int leaf, int leader);
+int slide_chol_batch_sep_segment(int m, int n_relmeas, int Ta, int Tb, int which, long long out2[2]);
 /* Nested dissection of every robot's own pose chain inside an exact joint pass: the banded pose system of a robot is a serial chain of
  * block columns (one launch each); cut into n_seg segments at windows of poses as wide as the band is (every coupling across a window
  * passes through it), the segments are factored side by side as systems of their own, and the windows' poses — moved into the border

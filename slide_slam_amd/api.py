@@ -28,7 +28,7 @@ EXPORTS = [
     "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
     "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
-    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_chol_batch_set_pcg_tolerance", "slide_graph_set_pcg_tolerance", "slide_graph_set_separator", "slide_chol_batch_set_exact_joint", "slide_chol_batch_sep_buffer_len", "slide_chol_batch_sep_exchange_len", "slide_chol_batch_profile_exact_joint", "slide_graph_get_border_profile", "slide_graph_get_incremental_stats", "slide_graph_get_segments", "slide_graph_get_segment_table", "slide_chol_batch_set_segments", "slide_clipper_dense_clique_batch", "slide_chol_batch_set_separator_profile", "slide_chol_batch_set_separator_blocks", "slide_graph_set_incremental", "slide_graph_set_ghost_ids", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
+    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_chol_batch_set_pcg_tolerance", "slide_graph_set_pcg_tolerance", "slide_graph_set_separator", "slide_chol_batch_set_exact_joint", "slide_chol_batch_sep_buffer_len", "slide_chol_batch_sep_exchange_len", "slide_chol_batch_profile_exact_joint", "slide_graph_get_border_profile", "slide_graph_get_incremental_stats", "slide_graph_get_segments", "slide_graph_get_segment_table", "slide_chol_batch_set_segments", "slide_clipper_dense_clique_batch", "slide_chol_batch_set_separator_profile", "slide_chol_batch_set_separator_blocks", "slide_chol_batch_set_separator_owner", "slide_chol_batch_sep_segment", "slide_graph_set_incremental", "slide_graph_set_ghost_ids", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
     "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
     "slide_dense_spd_solve", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device", "slide_assoc_sweep_batch",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
@@ -403,6 +403,18 @@ class CholBatch:
         L = lib()
         L.slide_chol_batch_sep_buffer_len.restype = C.c_longlong
         return int(L.slide_chol_batch_sep_buffer_len(C.c_int(int(m)), C.c_int(int(n_relmeas))))
+
+    def set_separator_owner(self, leaf, leader=True):
+        """Cut passes of a job whose ranks split in two halves along the separator's dissection: this rank factors leaf `leaf` only
+        (-1: off); `leader`: the one rank of its half that adds the leaf's Schur complement to the top block's sum."""
+        _check(self.L.slide_chol_batch_set_separator_owner(C.c_void_p(self.h), C.c_int(int(leaf)), C.c_int(1 if leader else 0)))
+
+    @staticmethod
+    def sep_segment(m, n_relmeas, Ta, Tb, which):
+        """(offset, length) in doubles of leaf a (0), leaf b (1) or the top block + lambdas (2) inside the packed exchange buffer."""
+        out = (C.c_longlong * 2)()
+        _check(lib().slide_chol_batch_sep_segment(C.c_int(int(m)), C.c_int(int(n_relmeas)), C.c_int(int(Ta)), C.c_int(int(Tb)), C.c_int(int(which)), out))
+        return int(out[0]), int(out[1])
 
     @staticmethod
     def sep_exchange_len(m, n_relmeas=0, Ta=0, Tb=0):

@@ -1362,6 +1362,7 @@ void launch_pose_covariance(const double* S, int ld, int T, const double* Ld, co
 struct SyrkArgs {
   int n;
   const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX]; int nbr[CHOL_BATCH_MAX];
+  int b0[CHOL_BATCH_MAX];              // tile row of the first border row (T, or CholSystem::b0 for a view that covers a range of the columns only)
   double* bord[CHOL_BATCH_MAX]; int ldb[CHOL_BATCH_MAX]; const int* bfirst[CHOL_BATCH_MAX];
   int ks; double* scratch;
   const int* jobs;       // or null: (system << 20 | ib << 10 | jb) per workgroup, longest sums first (launch_border_syrk_jobs)
@@ -1392,8 +1393,9 @@ __global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
   const int wq = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
   const int ch = (wq >> 1) & 1, rh = wq & 1;      // column half, row half of the tile
   if (A.jobs && ib == nbr && rh == 1) return;     // right-hand-side row tile: only its first row is in use (the others are zero and stay zero)
-  const double* pj0 = S + (size_t)lk * ld + (size_t)(T + jb) * NB + 32 * ch + 2 * lr;
-  const double* pi0 = S + (size_t)lk * ld + (size_t)(T + ib) * NB + 32 * rh + 2 * lr;
+  const int B0 = A.b0[r];
+  const double* pj0 = S + (size_t)lk * ld + (size_t)(B0 + jb) * NB + 32 * ch + 2 * lr;
+  const double* pi0 = S + (size_t)lk * ld + (size_t)(B0 + ib) * NB + 32 * rh + 2 * lr;
   double* cbh = A.bord[r] + (size_t)(jb * NB + 32 * ch + 2 * lk) * ldb + (size_t)ib * NB + 32 * rh + 2 * lr;
   if (q > 0) {       // partial of a later chunk: a 64 x 64 scratch tile (leading dimension NB)
     ldb = NB;
@@ -1481,7 +1483,7 @@ void launch_border_syrk(const CholSystem* d, int n, hipStream_t s, double* scrat
   int nb = 0;
   for (int i = 0; i < n; ++i) {
     A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.nbr[i] = d[i].nbr; A.bord[i] = d[i].bord; A.ldb[i] = d[i].ldb; A.bfirst[i] = d[i].bfirst;
-    A.segtab[i] = d[i].segtab;
+    A.segtab[i] = d[i].segtab; A.b0[i] = d[i].b0 > 0 ? d[i].b0 : d[i].T;
     nb = d[i].nbr > nb ? d[i].nbr : nb;
   }
   if (nb <= 0) return;
@@ -1506,7 +1508,7 @@ void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int nj
   A.n = n;
   for (int i = 0; i < n; ++i) {
     A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.nbr[i] = d[i].nbr; A.bord[i] = d[i].bord; A.ldb[i] = d[i].ldb; A.bfirst[i] = d[i].bfirst;
-    A.segtab[i] = d[i].segtab;
+    A.segtab[i] = d[i].segtab; A.b0[i] = d[i].b0 > 0 ? d[i].b0 : d[i].T;
   }
   if (njobs <= 0) return;
   A.ks = 1; A.scratch = nullptr; A.jobs = jobs;

@@ -660,6 +660,24 @@ int CholBatch::set_separator_blocks(int Ta, int Tb, int used_a, int used_b) {
   pass_dirty = true;
   return SLIDE_OK;
 }
+int CholBatch::set_separator_owner(int leaf, bool leader) {
+  std::lock_guard<std::mutex> pl(pass_mtx);
+  std::lock_guard<std::mutex> lk(mtx);
+  if (leaf < -1 || leaf > 1) { g_last_error = "separator owner: leaf 0, 1 or -1 (none)"; return SLIDE_ERR_INVALID; }
+  sep_owner = leaf; sep_leader = leader;
+  pass_dirty = true;
+  return SLIDE_OK;
+}
+// packed exchange buffer of a dissected layout: tile columns [0, Ta) | [Ta, Ta + Tb) | [Ta + Tb, Ts + nl), each a contiguous run
+void CholBatch::sep_segment(int ms, int lam, int Ta, int Tb, int which, long long* off, long long* len) {
+  const long long Tt = (ms + NB - 1) / NB + (lam + NB - 1) / NB;
+  auto upto = [&](long long tj) {      // doubles in front of tile column tj (sep_packed_addr)
+    return (long long)NB * NB * (tj * (Tt + 1) - tj * (tj - 1) / 2 - (long long)Tb * std::min<long long>(tj, Ta));
+  };
+  const long long b[4] = {0, Ta, (long long)Ta + Tb, Tt};
+  *off = upto(b[which]);
+  *len = upto(b[which + 1]) - upto(b[which]);
+}
 int CholBatch::set_arrow(bool on, double* sep_buf, long long len) {
   std::lock_guard<std::mutex> pl(pass_mtx);
   std::vector<HostGraph*> gs;
@@ -834,6 +852,42 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
   for (int i = 0; i < n; ++i) { maps[i] = graphs[i]->d_sep_map.d; xloc[i] = graphs[i]->d_xloc.d; }
   const int ld_s = (sep_Ts + sep_nl + 1) * NB;
   const SepLayout Y = sep_layout();
+  // (dissected separator) the two leaf blocks as systems of their own: views of sepS, the top block's and the lambdas' rows as border
+  CholSystem lv[2];
+  const int sTa = sep_leafT[0], sTL = sTa + sep_leafT[1], sTt = sep_Ts - sTL;
+  if (sep_dissected())
+    for (int b = 0; b < 2; ++b) {
+      const int t0 = b ? sTa : 0;
+      CholSystem c{};
+      c.S = sepS + (size_t)t0 * NB * ld_s + (size_t)t0 * NB; c.ld = ld_s; c.T = sep_leafT[b];
+      c.Ld = sep_Ld + (size_t)t0 * NB * NB; c.Winv = sep_Winv + (size_t)t0 * 1024; c.yv = sep_yv + (size_t)t0 * NB; c.dp = sep_dp + (size_t)t0 * NB;
+      c.status = sep_status; c.h_prof = h_leaf_prof[b].data(); c.prof = d_leaf_prof + (b ? sTa : 0);
+      c.nbr = sTt + sep_nl; c.b0 = sTL - t0; c.kofs = t0;
+      lv[b] = c;
+    }
+  // a rank that owns a leaf (set_separator_owner; cut passes only): part 1 between the exchanges
+  const bool owned = !whole && sep_dissected() && sep_owner >= 0;
+  const int own = owned ? sep_owner : 0, own_t0 = own ? sTa : 0, own_T = sep_leafT[own];
+  CholSystem top{};      // the top block's Schur complement over a range of the leaves' column blocks (all of them, or the own leaf's)
+  top.S = sepS + (owned ? (size_t)own_t0 * NB * ld_s : 0); top.ld = ld_s; top.T = owned ? own_T : sTL; top.b0 = sTL; top.nbr = sTt + sep_nl;
+  top.bord = sepS + (size_t)sTL * NB * ld_s + (size_t)sTL * NB; top.ldb = ld_s;
+  if (part == 1) {
+    if (!owned) return SLIDE_OK;
+    if (sep_leader) launch_sep_unpack(Y, master, sTL, sep_Ts + sep_nl);      // this rank's own partial sum of the top block (and the lambdas')
+    launch_sep_unpack(Y, master, own_t0, own_t0 + own_T);                      // the leaf, summed over the ranks of this half
+    launch_chol_batch(&lv[own], 1, sep_ctr2, master, nullptr, false);
+    if (sep_leader) {
+      launch_border_syrk_jobs(&top, 1, d_sep_jobs, n_sep_jobs, 0, master, sep_scratch, sep_ks, sTt);
+      if (sep_nl > 0) {
+        CholSystem sl{};      // the lambdas' own block: this leaf's part of - W W^T
+        sl.S = sepS + (size_t)own_t0 * NB * ld_s; sl.ld = ld_s; sl.T = own_T; sl.b0 = sep_Ts; sl.nbr = sep_nl; sl.bord = sep_bord; sl.ldb = (sep_nl + 1) * NB;
+        const int ks = (sep_nl + 1) * sep_nl <= 32 ? std::max(1, std::min(16, own_T / 2)) : 1;
+        launch_border_syrk(&sl, 1, master, lam_scratch, ks);
+      }
+      launch_sep_unpack(Y, master, sTL, sep_Ts + sep_nl, true);               // the top block (with this leaf's Schur complement) back into the exchange buffer
+    }
+    return SLIDE_OK;
+  }
   if (whole || part == 0) {
     launch_status_clear(d_Gs, n, master, sep_status, sep_nl > 0 ? lam_status : nullptr);
     const int rg = enqueue_ghost_refresh(d_bufs, part);
@@ -864,29 +918,16 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     mark(3);
   }
   if (whole || part == 2) {
-    if (!whole) launch_sep_unpack(Y, master);
+    if (!whole && !owned) launch_sep_unpack(Y, master);
+    if (owned) launch_sep_unpack(Y, master, sTL, sep_Ts + sep_nl);            // the top block summed over all ranks (the leaf was unpacked and factored in part 1)
     // landmark part of the separator: the dense step kernels, the lambda coordinates' coupling rows riding as ITS border
-    // (dissected separator) the two leaf blocks as systems of their own: views of sepS, the top block's and the lambdas' rows as border
-    CholSystem lv[2];
-    const int sTa = sep_leafT[0], sTL = sTa + sep_leafT[1], sTt = sep_Ts - sTL;
-    if (sep_dissected())
-      for (int b = 0; b < 2; ++b) {
-        const int t0 = b ? sTa : 0;
-        CholSystem c{};
-        c.S = sepS + (size_t)t0 * NB * ld_s + (size_t)t0 * NB; c.ld = ld_s; c.T = sep_leafT[b];
-        c.Ld = sep_Ld + (size_t)t0 * NB * NB; c.Winv = sep_Winv + (size_t)t0 * 1024; c.yv = sep_yv + (size_t)t0 * NB; c.dp = sep_dp + (size_t)t0 * NB;
-        c.status = sep_status; c.h_prof = h_leaf_prof[b].data(); c.prof = d_leaf_prof + (b ? sTa : 0);
-        c.nbr = sTt + sep_nl; c.b0 = sTL - t0; c.kofs = t0;
-        lv[b] = c;
-      }
     if (sep_dissected()) {
       // the leaves side by side (no robot couples them); the top block's Schur complement; the top block's own steps
       const int TL = sTL, Tt = sTt;
-      launch_chol_batch(lv, 2, sep_ctr2, master, nullptr, false);
-      CholSystem top{};
-      top.S = sepS; top.ld = ld_s; top.T = TL; top.nbr = Tt + sep_nl;
-      top.bord = sepS + (size_t)TL * NB * ld_s + (size_t)TL * NB; top.ldb = ld_s;
-      launch_border_syrk_jobs(&top, 1, d_sep_jobs, n_sep_jobs, 0, master, sep_scratch, sep_ks, Tt);
+      if (!owned) {
+        launch_chol_batch(lv, 2, sep_ctr2, master, nullptr, false);
+        launch_border_syrk_jobs(&top, 1, d_sep_jobs, n_sep_jobs, 0, master, sep_scratch, sep_ks, Tt);
+      }
       double* St = sepS + (size_t)TL * NB * ld_s + (size_t)TL * NB;
       for (int k = 0; k < Tt; ++k)
         launch_chol_step(St, ld_s, k, Tt, sep_Ld + (size_t)(TL + k) * NB * NB, sep_Winv + (size_t)(TL + k) * 1024, sep_status, sep_ctr, nullptr, nullptr, master, sep_nl);
@@ -902,8 +943,10 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
       // then z1 -= L21^T lambda before the landmark part's backward substitution
       CholSystem ss{};
       ss.S = sepS; ss.ld = ld_s; ss.T = sep_Ts; ss.yv = sep_yv; ss.nbr = sep_nl; ss.bord = sep_bord; ss.ldb = (sep_nl + 1) * NB; ss.bfirst = nullptr;
-      const int ks = (sep_nl + 1) * sep_nl <= 32 ? std::max(1, std::min(16, sep_Ts / 2)) : 1;      // few border tiles: split the column blocks
-      launch_border_syrk(&ss, 1, master, lam_scratch, ks);
+      CholSystem sr = ss;      // the column blocks whose part of - W W^T is still missing: all, or (a rank that owns a leaf) the top block's
+      if (owned) { sr.S = sepS + (size_t)sTL * NB * ld_s; sr.T = sTt; sr.b0 = sep_Ts; }
+      const int ks = (sep_nl + 1) * sep_nl <= 32 ? std::max(1, std::min(16, sr.T / 2)) : 1;      // few border tiles: split the column blocks
+      launch_border_syrk(&sr, 1, master, lam_scratch, ks);
       launch_lam_prepare(sep_bord, sep_nl, sep_lam, lamS, master);
       const int ld_l = (sep_nl + 1) * NB;
       for (int k = 0; k < sep_nl; ++k)
@@ -911,7 +954,14 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
       launch_chol_extract_y(lamS, ld_l, sep_nl, lam_yv, lam_dp, lam_status, master);
       launch_chol_bwd_all(lamS, ld_l, sep_nl, lam_Ld, lam_Winv, lam_yv, lam_dp, lam_status, nullptr, master);
       const double* xl = lam_dp;
-      launch_border_apply(&ss, 1, &xl, master);
+      if (!owned) launch_border_apply(&ss, 1, &xl, master);
+      else {      // the own leaf's and the top block's columns only (the other leaf's hold nothing of this pass)
+        CholSystem ap2[2] = {ss, ss};
+        ap2[0].S = sepS + (size_t)own_t0 * NB * ld_s; ap2[0].T = own_T; ap2[0].b0 = sep_Ts; ap2[0].yv = sep_yv + (size_t)own_t0 * NB;
+        ap2[1].S = sepS + (size_t)sTL * NB * ld_s; ap2[1].T = sTt; ap2[1].b0 = sep_Ts; ap2[1].yv = sep_yv + (size_t)sTL * NB;
+        const double* xl2[2] = {xl, xl};
+        launch_border_apply(ap2, 2, xl2, master);
+      }
     }
     if (sep_dissected()) {
       // back through the levels: the top block, y_leaf -= W_top^T x_top, the two leaves side by side (37 hops instead of 60)
@@ -922,8 +972,13 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
       CholSystem ap[2] = {lv[0], lv[1]};
       ap[0].nbr = ap[1].nbr = sTt;                                    // (the lambdas' part went onto y above, over all column blocks)
       const double* xt[2] = {sep_dp + (size_t)sTL * NB, sep_dp + (size_t)sTL * NB};
-      launch_border_apply(ap, 2, xt, master);
-      launch_chol_bwd_batch(lv, 2, master);
+      if (!owned) {
+        launch_border_apply(ap, 2, xt, master);
+        launch_chol_bwd_batch(lv, 2, master);
+      } else {
+        launch_border_apply(&ap[own], 1, xt, master);
+        launch_chol_bwd_batch(&lv[own], 1, master);
+      }
     } else {
       launch_chol_bwd_all(sepS, ld_s, sep_Ts, sep_Ld, sep_Winv, sep_yv, sep_dp, sep_status, sep_prof_on ? d_sep_prof : nullptr, master);
     }
@@ -1323,10 +1378,10 @@ int CholBatch::pass_part(double* const* d_bufs, int part) {
   switch (part) {
     case 20: ok = (last_part == -1 || last_part == 2) && ghosts; break;
     case 0: ok = ghosts ? last_part == 20 : (last_part == -1 || last_part == 2); break;
-    case 1: ok = !exact && last_part == 0; break;
+    case 1: ok = (!exact || (sep_dissected() && sep_owner >= 0)) && last_part == 0; break;
     case 10: ok = joint && (last_part == 1 || last_part == 11); break;
     case 11: case 12: ok = joint && last_part == 10; break;
-    default: ok = exact ? last_part == 0 : (joint ? last_part == 12 : last_part == 1); break;      // part 2
+    default: ok = exact ? last_part == ((sep_dissected() && sep_owner >= 0) ? 1 : 0) : (joint ? last_part == 12 : last_part == 1); break;      // part 2
   }
   if (part == 20 && !ghosts) return SLIDE_OK;                                             // (no ghost poses: nothing to refresh)
   if (!exact && !joint && part >= 10 && part <= 12) return SLIDE_OK;                      // (no joint solve: nothing between parts 1 and 2)

@@ -165,6 +165,11 @@ class CholBatch {
   int set_arrow(bool on, double* sep_buf, long long sep_len);
   int set_separator_profile(const int32_t* prof, int n);
   int set_separator_blocks(int Ta, int Tb, int used_a, int used_b);      // nested dissection of the separator system: two leaf blocks + top block (zeros: off)
+  // A job that spans GPUs, its ranks split in two halves along the dissection: this rank OWNS leaf `leaf` (0 / 1; -1: none, the default) —
+  // it factors that leaf only, and of the separator system only the top block crosses between the halves (cut pass: [20] 0 1 2).
+  // leader: the one rank of its half that adds the leaf's Schur complement to the top block's sum.
+  int set_separator_owner(int leaf, bool leader);
+  static void sep_segment(int ms, int lam, int Ta, int Tb, int which, long long* off, long long* len);      // packed buffer: leaf a | leaf b | top block + lambdas
   // Nested dissection of every robot's own pose chain in exact joint passes: `n` segments per robot factored side by side, the windows
   // of poses between them (as wide as the band) eliminated at a second level (graph_dev.hpp pose_sep).  1: off.
   void set_segments(int n_seg);
@@ -215,6 +220,7 @@ class CholBatch {
   // robot couples, factored side by side as views of sepS with the top block's rows (and the lambda rows) as their border, then the top
   // block; sep_used[b]: coordinates of leaf b that carry a slot (the rest of its last tile is padding with a unit diagonal)
   int sep_leafT[2] = {0, 0}, sep_used[2] = {0, 0};
+  int sep_owner = -1; bool sep_leader = true;
   std::vector<int> h_leaf_prof[2];                  // the leaves' own profiles (relative to the view)
   int* d_leaf_prof = nullptr;                       // both, one after the other (backward substitutions of the views)
   int* d_sep_tmask = nullptr;                       // per (virtual) tile of the separator: which joined graphs hold coordinates of it (k_sep_gather)

@@ -43,7 +43,7 @@ struct SepLayout { double* sys; double* bord; double* packed; int Ts, nl, ms, la
 void launch_ghost_refresh_local(const GraphDev* d, int n, int n_gslots, hipStream_t s);      // ghost poses of a whole pass on one GPU: pack + sum + adopt in one launch
 void launch_copy_pairs(const double* const* src, double* const* dst, const int* count, int n, hipStream_t s);      // up to 8 small device-to-device copies in one launch
 void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, const SepLayout& Y, bool packed, hipStream_t s, const int* tmask = nullptr);      // tmask: Ts + nl ints, bit r = robot r holds a coordinate of the (virtual) tile
-void launch_sep_unpack(const SepLayout& Y, hipStream_t s);
+void launch_sep_unpack(const SepLayout& Y, hipStream_t s, int c0 = 0, int c1 = -1, bool to_packed = false);      // tile columns [c0, c1) (virtual: lambda tiles behind the landmarks'); to_packed: the reverse copy
 void launch_lam_prepare(const double* bord, int nl, int lam, double* out, hipStream_t s);      // M = -(K22 - L21 L21^T), rhs = -(r2 - L21 z1)
 void launch_sep_xloc(int n, const int* const* maps, int ms, int lam, const double* xs, const double* xl, double* const* xloc, hipStream_t s);
 void launch_arrow_finish_batched(const GraphDev* d, const GraphDev* h, int n, const double* xs, const int* sep_off, hipStream_t s);

@@ -1297,11 +1297,14 @@ __global__ __launch_bounds__(256) void k_sep_gather(SepGatherArgs A) {
   }
   *sep_slot(Y, vr, vc, A.packed != 0) = s;
 }
-__global__ __launch_bounds__(256) void k_sep_unpack(SepLayout Y) {
-  const int vr = blockIdx.x * 256 + threadIdx.x, vc = blockIdx.y;
+// c0, c1: the (virtual) tile columns [c0, c1) only; to_packed: the other way (the factorisation's layout -> the packed buffer: a rank that
+// owns a leaf of a dissected layout hands its top block back for the exchange)
+__global__ __launch_bounds__(256) void k_sep_unpack(SepLayout Y, int c0, int c1, int to_packed) {
+  const int vr = blockIdx.x * 256 + threadIdx.x, vc = c0 * NB + blockIdx.y;
   const int NT = (Y.Ts + Y.nl) * NB;
-  if (vr > NT || vc >= NT || vr < vc / NB * NB) return;
+  if (vr > NT || vc >= NT || vc >= c1 * NB || vr < vc / NB * NB) return;
   if (sep_packed_hole(vr, vc, Y.hTa, Y.hTL)) return;      // (never written in the factorisation's layout either: zero since allocation)
+  if (to_packed) { *sep_slot(Y, vr, vc, true) = *sep_slot(Y, vr, vc, false); return; }
   double v = *sep_slot(Y, vr, vc, true);
   if (vr == vc && ((vc >= Y.gap[0] && vc < Y.gap[1]) || (vc >= Y.gap[2] && vc < Y.gap[3]))) v = 1.0;
   *sep_slot(Y, vr, vc, false) = v;
@@ -1610,9 +1613,10 @@ void launch_border_assemble_batched(const GraphDev* d, const GraphDev* h, int n,
   for (int i = 0; i < n; ++i) ngh = std::max(ngh, h[i].gh_bord ? h[i].n_ghost : 0);
   if (ngh > 0) hipLaunchKernelGGL(k_border_fill_lam_b, dim3((36 * ngh + 255) / 256, 1, n), dim3(256), 0, s, d);
 }
-void launch_sep_unpack(const SepLayout& Y, hipStream_t s) {
+void launch_sep_unpack(const SepLayout& Y, hipStream_t s, int c0, int c1, bool to_packed) {
   const int NT = (Y.Ts + Y.nl) * NB;
-  if (NT > 0) hipLaunchKernelGGL(k_sep_unpack, dim3((NT + 1 + 255) / 256, NT), dim3(256), 0, s, Y);
+  if (c1 < 0) c1 = Y.Ts + Y.nl;
+  if (NT > 0 && c1 > c0) hipLaunchKernelGGL(k_sep_unpack, dim3((NT + 1 + 255) / 256, (c1 - c0) * NB), dim3(256), 0, s, Y, c0, c1, to_packed ? 1 : 0);
 }
 void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, const SepLayout& Y, bool packed, hipStream_t s, const int* tmask) {
   SepGatherArgs A{};

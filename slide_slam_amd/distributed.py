@@ -162,7 +162,7 @@ def _layout_block(obs, members, adj, start, off, tile):
     return used, np.maximum.accumulate(prof)
 
 
-def separator_offsets(gid, n_global, tile=64, dissect=True):
+def separator_offsets(gid, n_global, tile=64, dissect=True, force_a=None):
     """Layout of the separator system of the exact joint step, the same on every rank: off[slot] = offset of the slot's tangent
     coordinates (cylinder 7, cube 9, point 3), off[n_slots] = the dimension m; prof = its tile-level profile (prof[c] = last tile row
     of tile column c that can be non-zero); blocks = None or (Ta, Tb, used_a, used_b).  Two shared landmarks couple in the separator
@@ -172,7 +172,8 @@ def separator_offsets(gid, n_global, tile=64, dissect=True):
     only from one set form that set's LEAF block, the slots seen from both the TOP block behind them; leaf blocks start at tile
     boundaries (the coordinates between a leaf's last slot and the next tile boundary are padding no slot uses — m counts them).  The
     leaves do not couple, so slide_chol_batch_set_separator_blocks factors them side by side.  Slot order itself (shared_slots) is
-    unchanged: only the coordinates are permuted."""
+    unchanged: only the coordinates are permuted.  force_a: a set of robots that must be the first set (a job whose ranks split in two
+    halves along the dissection: slide_chol_batch_set_separator_owner) — taken if both leaves and the top block are non-empty."""
     obs = slot_observers(gid, n_global)
     R = len(gid)
     adj = [set() for _ in range(R)]
@@ -187,7 +188,8 @@ def separator_offsets(gid, n_global, tile=64, dissect=True):
     best = None
     if dissect and 3 <= R <= 16 and n > 0:
         masks = [sum(1 << r for r in w) for _, w in obs]
-        for a_mask in range(1, 1 << (R - 1)):           # robot R-1 always on the b side: every bipartition once
+        forced = sum(1 << r for r in force_a) if force_a else 0
+        for a_mask in ([forced] if forced else range(1, 1 << (R - 1))):           # robot R-1 always on the b side: every bipartition once
             da = int(dims[[i for i in range(n) if masks[i] & ~a_mask == 0]].sum())
             db = int(dims[[i for i in range(n) if masks[i] & a_mask == 0]].sum())
             if da == 0 or db == 0:
@@ -198,7 +200,7 @@ def separator_offsets(gid, n_global, tile=64, dissect=True):
             cost = max(tiles(da), tiles(db)) + tiles(dt)
             if best is None or cost < best[0]:
                 best = (cost, a_mask)
-        if best is not None and best[0] > 0.85 * tiles(total):
+        if best is not None and best[0] > 0.85 * tiles(total) and not forced:
             best = None
     if best is None:
         used, prof = _layout_block(obs, list(range(n)), adj, 0, off, tile)
@@ -297,9 +299,22 @@ def setup_local_shards(shards, matcher, base=None, rank=0, world=1, thresh=(2.0,
         alloc = lambda n: np.zeros(n)
         handle = lambda b: b
     import os
-    sep_off, sep_prof, sep_blocks = separator_offsets(gid, n_global, dissect=os.environ.get("SLIDE_SEP_DISSECT", "1") != "0")
+    dissect = os.environ.get("SLIDE_SEP_DISSECT", "1") != "0"
+    owner = None
+    sep_off = None
+    if dissect and world >= 2 and world % 2 == 0 and device is not None and os.environ.get("SLIDE_SEP_OWNED", "1") != "0":
+        # the ranks split in two halves along the dissection: every rank then factors one leaf only and only the top block crosses
+        # between the halves (slide_chol_batch_set_separator_owner)
+        sep_off, sep_prof, sep_blocks = separator_offsets(gid, n_global, dissect=True, force_a=set(range(world // 2 * R)))
+        if sep_blocks is not None:
+            half = 0 if rank < world // 2 else 1
+            owner = dict(leaf=half, leader=(rank % (world // 2) == 0), half_ranks=list(range(half * (world // 2), (half + 1) * (world // 2))))
+        else:
+            sep_off = None
+    if sep_off is None:
+        sep_off, sep_prof, sep_blocks = separator_offsets(gid, n_global, dissect=dissect)
     if sep_blocks is not None:
-        sep_prof = (sep_prof, sep_blocks)        # (travels with the profile to PassDriver: the dissection is a property of the layout)
+        sep_prof = (sep_prof, sep_blocks, owner)        # (travels with the profile to PassDriver: the dissection is a property of the layout)
     for t, sh in enumerate(shards):
         cls, idx, own = shared_slots(gid, n_global, rank * R + t)
         n_slots = len(cls)
@@ -360,6 +375,8 @@ class PassDriver:
         self.sep_dim = int(sep_dim)
         self.sbufs = None
         self.sep = None
+        self._sep_segs = None
+        self.sep_owner = None
         if self.arrow:
             self.pcg_iters = 0
             if device is None:
@@ -370,11 +387,13 @@ class PassDriver:
         if batch is not None:
             batch.set_exact_joint(self.arrow, 0, 0)      # (the exchange buffer of a cut pass is installed on first use: _sep_exchange_buffer)
             if self.arrow and sep_prof is not None:
-                blocks = None
+                blocks, owner = None, None
                 if isinstance(sep_prof, tuple):
-                    sep_prof, blocks = sep_prof
+                    sep_prof, blocks, owner = (tuple(sep_prof) + (None,))[:3]
+                self.sep_owner = owner
                 batch.set_separator_profile(sep_prof)    # (tile profile of the separator system: the same on every rank)
                 batch.set_separator_blocks(*(blocks if blocks is not None else (0, 0, 0, 0)))
+                batch.set_separator_owner(owner["leaf"] if owner else -1, owner["leader"] if owner else True)
                 self.sep_blocks = blocks
             import os
             # nested dissection of the robots' own bands (slide_chol_batch_set_segments; every segment carries only the border rows that
@@ -456,6 +475,32 @@ class PassDriver:
                 self.sep_len = self.batch.sep_exchange_len(self.sep_dim, getattr(self, "n_relmeas", 0), blocks[0], blocks[1])
         return self.sep
 
+    def _sep_exchange(self, sep, stream):
+        """The separator system's exchange(s) of a cut pass between part 0 and part 2.  Plain: ONE all-reduce of the packed system.  A
+        rank that owns a leaf (the ranks split in two halves along the dissection): all-reduce of the own leaf's segment within the
+        own half (nothing when the half is this rank alone), part 1 (the leaf is factored, its Schur complement joins the top block),
+        all-reduce of the top block's segment over all ranks."""
+        own = getattr(self, "sep_owner", None)
+        if own is None:
+            if self.world > 1 or self.base is not None:
+                self.base.all_reduce_on(sep, self.sep_len, stream)
+            return
+        if self._sep_segs is None:
+            nr = getattr(self, "n_relmeas", 0)
+            Ta, Tb = self.sep_blocks[0], self.sep_blocks[1]
+            self._sep_segs = [self.batch.sep_segment(self.sep_dim, nr, Ta, Tb, w) for w in range(3)]
+            self._half_group = None
+            if len(own["half_ranks"]) > 1:      # (both halves' groups are created by every rank, in the same order)
+                W = self.world
+                ga, gb = self.base.new_group(range(0, W // 2)), self.base.new_group(range(W // 2, W))
+                self._half_group = ga if own["leaf"] == 0 else gb
+        off, ln = self._sep_segs[own["leaf"]]
+        if self._half_group is not None:
+            self.base.all_reduce_on(sep, ln, stream, off=off, group=self._half_group)
+        self.batch.pass_part(self.ptrs, 1)
+        off, ln = self._sep_segs[2]
+        self.base.all_reduce_on(sep, ln, stream, off=off)
+
     def _exchange(self, count):
         """all-reduce(sum) of buffer 0's first `count` doubles across the processes, ordered behind the batch's stream."""
         if (self.world > 1 or (self.force_parts and self.base is not None)) and count:
@@ -490,8 +535,7 @@ class PassDriver:
                     self.batch.pass_part(self.ptrs, 20)
                     self._exchange(12 * self.n_gslots)
                 self.batch.pass_part(self.ptrs, 0)
-                if self.world > 1 or self.base is not None:
-                    self.base.all_reduce_on(sep, self.sep_len, self.batch.stream() if self.stream_ordered else None)
+                self._sep_exchange(sep, self.batch.stream() if self.stream_ordered else None)
                 self.batch.pass_part(self.ptrs, 2)
             else:
                 if getattr(self, "n_gslots", 0):
@@ -571,13 +615,14 @@ class PassDriver:
         torch.cuda.synchronize(); t0 = time.perf_counter()
         self.batch.pass_part(self.ptrs, 0)
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        if self.world > 1 or self.base is not None:
-            self.base.all_reduce_on(sep, self.sep_len, None)
+        self._sep_exchange(sep, None)      # (a rank that owns a leaf runs part 1 in here: counted with the exchange)
         torch.cuda.synchronize(); t2 = time.perf_counter()
         self.batch.pass_part(self.ptrs, 2)
         torch.cuda.synchronize(); t3 = time.perf_counter()
         self.passes += 1
-        out.update(part0_ms=(t1 - t0) * 1e3, exchange_ms=(t2 - t1) * 1e3, part2_ms=(t3 - t2) * 1e3, exchange_bytes=8 * self.sep_len)
+        own = getattr(self, "sep_owner", None)
+        xb = 8 * self.sep_len if own is None else 8 * ((self._sep_segs[own["leaf"]][1] if len(own["half_ranks"]) > 1 else 0) + self._sep_segs[2][1])
+        out.update(part0_ms=(t1 - t0) * 1e3, exchange_ms=(t2 - t1) * 1e3, part2_ms=(t3 - t2) * 1e3, exchange_bytes=xb)
         return out
 
 
@@ -606,23 +651,27 @@ class TorchComm:
     def handle(self, buf):
         return buf if self.device is None else buf.data_ptr()
 
-    def all_reduce(self, buf, n):
+    def new_group(self, ranks):
+        """A sub-group of the job's ranks (every rank of the job must make the same calls in the same order)."""
+        return self.dist.new_group(ranks=list(ranks))
+
+    def all_reduce(self, buf, n, off=0, group=None):
         if n == 0:
             return
         if self.device is None:
-            t = self.torch.from_numpy(buf[:n])
-            self.dist.all_reduce(t)
+            t = self.torch.from_numpy(buf[off:off + n])
+            self.dist.all_reduce(t, group=group)
         elif self.stage:
-            h = buf[:n].cpu()
-            self.dist.all_reduce(h)
-            buf[:n].copy_(h)
+            h = buf[off:off + n].cpu()
+            self.dist.all_reduce(h, group=group)
+            buf[off:off + n].copy_(h)
             self.torch.cuda.synchronize()
         else:
-            self.dist.all_reduce(buf[:n])
+            self.dist.all_reduce(buf[off:off + n], group=group)
             self.torch.cuda.synchronize()
 
 
-    def all_reduce_on(self, buf, n, stream_ptr=None):
+    def all_reduce_on(self, buf, n, stream_ptr=None, off=0, group=None):
         """all-reduce(sum) of buf[:n] ordered behind the work already queued on the HIP stream `stream_ptr` (and ahead of what
         is queued on it afterwards).  nccl (RCCL over xGMI): issued under torch's ExternalStream of that stream — no host
         synchronisation.  gloo / host staging (CPU tests, several ranks on one GPU): synchronous."""
@@ -631,12 +680,12 @@ class TorchComm:
         if self.device is None or self.stage or stream_ptr is None:
             if self.device is not None:
                 self.torch.cuda.synchronize()
-            return self.all_reduce(buf, n)
+            return self.all_reduce(buf, n, off, group)
         ext = self._ext.get(stream_ptr)
         if ext is None:
             ext = self._ext[stream_ptr] = self.torch.cuda.ExternalStream(stream_ptr, device=self.device)
         with self.torch.cuda.stream(ext):
-            self.dist.all_reduce(buf[:n])
+            self.dist.all_reduce(buf[off:off + n], group=group)
 
 
 class ThreadGroup:

@@ -137,7 +137,7 @@ def main_driver(R):
     dist.all_gather_object(gathered, mine)
     if rank == 0:
         np.savez(out_path, poses=np.array([p for part in gathered for p in part]), n_slots=info["n_slots"],
-                 n_global=np.array(info["n_global"]), n_gslots=0)
+                 n_global=np.array(info["n_global"]), n_gslots=0, owned=int(getattr(drv, "sep_owner", None) is not None))
     dist.barrier()
     dist.destroy_process_group()
 

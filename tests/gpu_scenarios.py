@@ -179,7 +179,7 @@ def c5_stream(out, preset="C4", ticks=None, budget_ms=100.0):
     json.dump(res, open(out, "w"))
 
 
-def c3_converge(out, preset="C3", passes=400, every=20, pcg=0, unbatched=0, arrow=0):
+def c3_converge(out, preset="C3", passes=400, every=20, pcg=0, unbatched=0, arrow=0, relmeas=0):
     """Convergence of the sharded passes (pcg = 0: block-Jacobi; > 0: joint solve by PCG; arrow = 1: the exact joint step) to the
     joint replica's optimum."""
     import torch
@@ -221,6 +221,9 @@ def c3_converge(out, preset="C3", passes=400, every=20, pcg=0, unbatched=0, arro
             sh.graph.join_chol_batch(batch, t)
     bufs, info = setup_local_shards(shards, gpu_matcher, device=dev)
     drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, device=dev, pcg_iters=pcg, arrow=bool(arrow), sep_dim=info["sep_dim"], sep_prof=info.get("sep_prof"))
+    if relmeas:      # the job's inter-robot relative-pose factors (the joint replica above was built without them: `joint` is then no reference)
+        from slide_slam_amd.synth import make_relmeas
+        assert drv.setup_ghosts(make_relmeas(cfg, data["logs"])) > 0
     nrm = np.linalg.norm(joint.reshape(R, -1), axis=1) if joint is not None else None
     hist, chi2_hist = [], []
     t_pass = 0.0

@@ -177,18 +177,55 @@ def test_c3_with_the_surveys_noise_values_does_not_diverge(gpu, tmp_path):
 
 
 def test_exact_joint_step_two_ranks_equal_one_process(gpu, tmp_path):
-    """configs[2] and configs[3] as TWO ranks on the one visible GPU (1 resp. 4 robots per rank; the pass cut at its ONE exchange, the
-    all-reduce of the packed separator system through gloo staged on the host standing in for RCCL) == one process holding all robots."""
+    """configs[2] and configs[3] as TWO ranks on the one visible GPU (1 resp. 4 robots per rank; the pass cut at its exchanges, gloo staged
+    on the host standing in for RCCL) == one process holding all robots.  C3: the plain cut (ONE all-reduce of the packed separator
+    system; two robots leave nothing to dissect).  C4: the ranks split along the separator's dissection, every rank owns one leaf
+    (slide_chol_batch_set_separator_owner): part 0 | part 1 (the own leaf factored, its Schur complement onto the top block) | all-reduce
+    of the top block's segment only | part 2 — and, with SLIDE_SEP_OWNED=0, the plain cut again."""
     from test_distributed import _run_workers
     # C4: the eight robots' contributions to the separator system are summed as (0 + 1 + 2 + 3) + (4 + 5 + 6 + 7) instead of in one
     # chain; the reduced systems carry the 1e-6 prior sigma (condition ~1e12), so the different rounding shows at ~1e-7 relative
-    for preset, per_rank, tol in (("C3", 1, 1e-9), ("C4", 4, 1e-6)):
+    for preset, per_rank, tol, owned in (("C3", 1, 1e-9, 0), ("C4", 4, 1e-6, 1), ("C4", 4, 1e-6, 0)):
         out = str(tmp_path / f"{preset}_one.json")
-        _scenario("c3_converge", out, preset, 3, 3, 0, 0, 1)
+        if not os.path.exists(out):
+            _scenario("c3_converge", out, preset, 3, 3, 0, 0, 1)
         one = np.array(json.load(open(out))["final"])
-        z = _run_workers("gpu", preset, 3, str(tmp_path / f"{preset}_two.npz"), world=2, extra=(f"driver={per_rank}", "arrow"))
+        if preset == "C4" and not owned:
+            os.environ["SLIDE_SEP_OWNED"] = "0"
+        try:
+            z = _run_workers("gpu", preset, 3, str(tmp_path / f"{preset}_two{owned}.npz"), world=2, extra=(f"driver={per_rank}", "arrow"))
+        finally:
+            os.environ.pop("SLIDE_SEP_OWNED", None)
+        assert int(z["owned"]) == owned, (preset, int(z["owned"]))
         assert z["poses"].shape == one.shape
         assert np.abs(z["poses"] - one).max() < tol * np.abs(one).max(), preset
+
+
+def test_exact_joint_step_two_ranks_own_their_leaves_with_relative_pose_factors(gpu, tmp_path):
+    """The same with the inter-robot relative-pose factors of SURVEY 8d in the job: the lambda rows ride through the own leaf's steps on
+    the rank that owns it, their own block collects - W W^T from both leaves through the top block's exchange and from the top block's
+    columns after it."""
+    from test_distributed import _run_workers
+    out = str(tmp_path / "C4rel_one.json")
+    _scenario("c3_converge", out, "C4", 3, 3, 0, 0, 1, 1)
+    one = np.array(json.load(open(out))["final"])
+    z = _run_workers("gpu", "C4", 3, str(tmp_path / "C4rel_two.npz"), world=2, extra=("driver=4", "arrow", "relmeas"))
+    assert int(z["owned"]) == 1
+    assert np.abs(z["poses"] - one).max() < 1e-6 * np.abs(one).max()
+
+
+def test_exact_joint_step_four_ranks_own_their_leaves(gpu, tmp_path):
+    """configs[3] as FOUR ranks of two robots on the one visible GPU (gloo): the halves of the job are two ranks each, so the own leaf's
+    segment is all-reduced within the half before part 1, and only one rank of a half (the leader) adds the leaf's Schur complement to
+    the top block's sum == one process holding all eight robots."""
+    from test_distributed import _run_workers
+    out = str(tmp_path / "C4_one.json")
+    _scenario("c3_converge", out, "C4", 3, 3, 0, 0, 1)
+    one = np.array(json.load(open(out))["final"])
+    z = _run_workers("gpu", "C4", 3, str(tmp_path / "C4_four.npz"), world=4, extra=("driver=2", "arrow"))
+    assert int(z["owned"]) == 1
+    assert z["poses"].shape == one.shape
+    assert np.abs(z["poses"] - one).max() < 1e-6 * np.abs(one).max()
 
 
 def test_exact_joint_step_two_ranks_rccl(gpu, tmp_path):
