@@ -432,6 +432,10 @@ def main():
         info["totals"]["shared_slots"] = int(info["n_slots"])
         _blk = info["sep_prof"][1] if isinstance(info.get("sep_prof"), tuple) else (0, 0)
         info["sep_exchange_bytes"] = int(8 * s.CholBatch.sep_exchange_len(info["sep_dim"], info.get("n_relmeas", 0), _blk[0], _blk[1])) if info.get("sep_dim") else 0
+        if getattr(drv, "sep_owner", None) is not None:
+            _segs = [s.CholBatch.sep_segment(info["sep_dim"], info.get("n_relmeas", 0), _blk[0], _blk[1], w) for w in range(3)]
+            info["sep_owned"] = dict(leaf=drv.sep_owner["leaf"], leaf_bytes=8 * _segs[drv.sep_owner["leaf"]][1] if len(drv.sep_owner["half_ranks"]) > 1 else 0,
+                                     top_bytes=8 * _segs[2][1])
         if sync_coll:
             drv.stream_ordered = False
         if os.environ.get("SLIDE_BENCH_FORCE_PARTS") == "1":      # rehearsal of the N > 1 control flow (cut pass + RCCL on the batch's stream) on one rank
@@ -737,8 +741,12 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
                    "devices": devs,
                    "collective": None if not n_slots else (
                        ((f"{backend} " if wdev > 1 else "device-side gather, no inter-GPU ") +
-                        f"all-reduce x1 per pass: the packed separator system of the {n_slots} shared-landmark slots "
-                        f"({info.get('sep_dim')} coordinates, {info.get('sep_exchange_bytes')} B)" +
+                        (f"all-reduce x1 per pass: the packed separator system of the {n_slots} shared-landmark slots "
+                         f"({info.get('sep_dim')} coordinates, {info.get('sep_exchange_bytes')} B)" if not info.get("sep_owned") else
+                         f"the ranks split in two halves along the dissection of the separator system ({info.get('sep_dim')} coordinates over "
+                         f"{n_slots} shared-landmark slots), every rank factors the leaf its half's robots see: all-reduce of that leaf's segment "
+                         f"within the half ({info['sep_owned']['leaf_bytes']} B; none when the half is one rank) + all-reduce of the top block over "
+                         f"all ranks ({info['sep_owned']['top_bytes']} B) per pass, instead of the whole packed system ({info.get('sep_exchange_bytes')} B)") +
                         (f"; {'stream-ordered on the pass stream' if info.get('stream_ordered_collectives') else 'host-synchronous'}" if wdev > 1 else ""))
                        if info.get("sep_dim") and args.joint == "exact" else
                        ((f"{backend} " if wdev > 1 else "device-side local sum, no inter-GPU ") +
