@@ -209,7 +209,8 @@ struct ALds {
   double mop[16][64];   // iteration n: A operand of the panel MFMAs, lane image
   double xm[16][64];    // iteration n: masked X of the diagonal sub-tile = A operand of the in-phase updates, lane image
   double Lt[6][4][64];  // finished off-diagonal sub-tiles L(I, J), I > J, at index I (I - 1) / 2 + J, register, lane
-  double Dh[3][4][64];  // hand-off of the updated diagonal sub-tile (J, J), J = 1..3
+  double Dh[3][4][64];  // hand-off of the diagonal sub-tile (J, J), J = 1..3, updated up to the LAST BUT ONE iteration of phase J - 1
+  double Dh3[3][64];    // ... with the worker's register 3 of sub-tile (J, J - 1) at that point: the chain wave applies the last iteration itself
   double Wi[4][256];    // Wi[b][c * 16 + r] = (L_bb^-1)[r][c]
   int it_done;          // iterations published by the chain wave
   int col_done[4];      // col_done[I]: columns J of row I published in Lt
@@ -267,15 +268,10 @@ __device__ __forceinline__ void a_chain_wave(int ia, int* status, ALds& L, int l
   }
   bool ok = true;
   STAMPW(3);
+  v4d Dnext = zero;
 #pragma unroll
   for (int JQ = 0; JQ < 4; ++JQ) {
-    if (JQ > 0) {
-      STAMPW(3 + 2 * JQ - 1);
-      lds_wait(&L.d_ready[JQ], 1);
-      STAMPW(3 + 2 * JQ);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Dt[r] = L.Dh[JQ - 1][r][lane];
-    }
+    if (JQ > 0) Dt = Dnext;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (lr < lk + 4 * r) Dt[r] = 0.0;          // upper triangle: never read for a result, keep it finite
@@ -316,6 +312,18 @@ __device__ __forceinline__ void a_chain_wave(int ia, int* status, ALds& L, int l
       lds_post(&L.it_done, n + 1, lane);
       if (n < 4) STAMPW(32 + n);
       if (s < 3) Dt = mfma_f64(-xm, xm, Dt);
+      if (s == 3 && JQ < 3) {
+        // the next diagonal sub-tile: the worker of row JQ + 1 handed it over after the last but one iteration of this phase (long
+        // since: it follows one iteration behind), with its register 3 of sub-tile (JQ + 1, JQ) — the last iteration's panel step and
+        // rank-4 update are two MFMAs here instead of a round trip through the worker (~0.5 us per phase, on every launch's chain)
+        STAMPW(3 + 2 * JQ + 1);
+        lds_wait(&L.d_ready[JQ + 1], 1);
+        STAMPW(3 + 2 * JQ + 2);
+        const double x3 = mfma_f64(mop, L.Dh3[JQ][lane], zero)[0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Dnext[r] = L.Dh[JQ][r][lane];
+        Dnext = mfma_f64(-x3, x3, Dnext);
+      }
     }
   }
   STAMPW(10);
@@ -381,14 +389,16 @@ __device__ __forceinline__ void a_worker_wave(int ia, double* __restrict__ Ld, d
 #pragma unroll
       for (int J = 0; J <= W; ++J) pin(R[J]);
       if (W == WT) pin(Wt);
-    }
-    if (JQ == W - 1) {
-      // hand-off first, publication of the finished column block after it
+      if (JQ == W - 1 && s == 2) {
+        // hand-off of the own diagonal sub-tile one iteration early: everything but the last iteration's rank-4 update is in it, and
+        // register 3 of (W, JQ) as it stands goes along — the chain wave finishes both itself (a_chain_wave)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) L.Dh[W - 1][r][lane] = R[W][r];
-      lds_post(&L.d_ready[W], 1, lane);
-      if (W == 1) STAMPW(13);
-      if (W == 2) STAMPW(36);
+        for (int r = 0; r < 4; ++r) L.Dh[W - 1][r][lane] = R[W][r];
+        L.Dh3[W - 1][lane] = R[JQ][3];
+        lds_post(&L.d_ready[W], 1, lane);
+        if (W == 1) STAMPW(13);
+        if (W == 2) STAMPW(36);
+      }
     }
     // column block JQ of row W is final
 #pragma unroll
