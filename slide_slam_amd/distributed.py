@@ -475,7 +475,7 @@ class PassDriver:
                 self.sep_len = self.batch.sep_exchange_len(self.sep_dim, getattr(self, "n_relmeas", 0), blocks[0], blocks[1])
         return self.sep
 
-    def _sep_exchange(self, sep, stream):
+    def _sep_exchange(self, sep, stream, times=None):
         """The separator system's exchange(s) of a cut pass between part 0 and part 2.  Plain: ONE all-reduce of the packed system.  A
         rank that owns a leaf (the ranks split in two halves along the dissection): all-reduce of the own leaf's segment within the
         own half (nothing when the half is this rank alone), part 1 (the leaf is factored, its Schur complement joins the top block),
@@ -494,12 +494,23 @@ class PassDriver:
                 W = self.world
                 ga, gb = self.base.new_group(range(0, W // 2)), self.base.new_group(range(W // 2, W))
                 self._half_group = ga if own["leaf"] == 0 else gb
+        def lap(key):      # (timed_cut_pass: a device synchronisation after every step)
+            if times is not None:
+                import time
+                import torch
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                times[key] = (now - times["_t"]) * 1e3
+                times["_t"] = now
         off, ln = self._sep_segs[own["leaf"]]
         if self._half_group is not None:
             self.base.all_reduce_on(sep, ln, stream, off=off, group=self._half_group)
+        lap("exchange_leaf_ms")
         self.batch.pass_part(self.ptrs, 1)
+        lap("part1_ms")
         off, ln = self._sep_segs[2]
         self.base.all_reduce_on(sep, ln, stream, off=off)
+        lap("exchange_top_ms")
 
     def _exchange(self, count):
         """all-reduce(sum) of buffer 0's first `count` doubles across the processes, ordered behind the batch's stream."""
@@ -615,8 +626,12 @@ class PassDriver:
         torch.cuda.synchronize(); t0 = time.perf_counter()
         self.batch.pass_part(self.ptrs, 0)
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        self._sep_exchange(sep, None)      # (a rank that owns a leaf runs part 1 in here: counted with the exchange)
+        times = {"_t": t1} if getattr(self, "sep_owner", None) is not None else None
+        self._sep_exchange(sep, None, times)      # (a rank that owns a leaf runs part 1 in here: its own entry below)
         torch.cuda.synchronize(); t2 = time.perf_counter()
+        if times:
+            times.pop("_t")
+            out.update(times)
         self.batch.pass_part(self.ptrs, 2)
         torch.cuda.synchronize(); t3 = time.perf_counter()
         self.passes += 1
