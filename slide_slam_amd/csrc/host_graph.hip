@@ -1495,9 +1495,13 @@ int DownloadBatch::run(hipStream_t s) {
     SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_stage), h_cap));
     d_cap = h_cap;
   }
-  std::memcpy(h_pin + desc_off, segs.data(), segs.size() * sizeof(Seg));
-  SL_HIP(hipMemcpyAsync(d_stage + desc_off, h_pin + desc_off, segs.size() * sizeof(Seg), hipMemcpyHostToDevice, s));
-  launch_gather(d_stage, (unsigned)desc_off, (int)segs.size(), s);
+  if (segs.size() <= 16) {
+    launch_gather_args(d_stage, segs.data(), (int)segs.size(), s);      // (the per-frame read-backs: the descriptors travel as kernel arguments)
+  } else {
+    std::memcpy(h_pin + desc_off, segs.data(), segs.size() * sizeof(Seg));
+    SL_HIP(hipMemcpyAsync(d_stage + desc_off, h_pin + desc_off, segs.size() * sizeof(Seg), hipMemcpyHostToDevice, s));
+    launch_gather(d_stage, (unsigned)desc_off, (int)segs.size(), s);
+  }
   SL_HIP(hipMemcpyAsync(h_pin, d_stage, used, hipMemcpyDeviceToHost, s));
   SL_HIP(hipStreamSynchronize(s));
   for (size_t i = 0; i < segs.size(); ++i) std::memcpy(host_dst[i], h_pin + segs[i].off, segs[i].bytes);

@@ -22,6 +22,7 @@ void launch_chi2(const GraphDev& G, double* out4, hipStream_t s);   // sum of sq
 void launch_pose_adj(const GraphDev& G, hipStream_t s);        // pose adjacency bitmap of the Schur assembly (topology only)
 void launch_scatter(const void* stage, unsigned desc_off, int nseg, hipStream_t s);
 void launch_gather(void* stage, unsigned desc_off, int nseg, hipStream_t s);
+void launch_gather_args(void* stage, const void* segs, int nseg, hipStream_t s);      // the same, up to 16 descriptors as kernel arguments
 void launch_sum_bcast(double* const* bufs, int n, int count, hipStream_t s);   // local all-reduce(sum) of up to 8 buffers
 void launch_bcast(double* const* bufs, int n, int count, hipStream_t s);       // bufs[0] -> the others
 void launch_phase0_batched(const GraphDev* d, const GraphDev* h, int n, double* const* bufs, hipStream_t s, bool pack = true);   // the per-robot phases 0 / 4 / 2 of a batched pass,

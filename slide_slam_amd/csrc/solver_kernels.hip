@@ -6,6 +6,7 @@
 // order (no floating-point atomics) so results are bit-stable run to run.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstring>
 
 #include "graph_dev.hpp"
 #include "kernels.hpp"
@@ -958,6 +959,20 @@ __global__ __launch_bounds__(256) void k_gather(unsigned char* __restrict__ stag
   const unsigned* src = reinterpret_cast<const unsigned*>(sg.dst);
   const unsigned n = sg.bytes >> 2;
   for (unsigned i = blockIdx.y * 256 + threadIdx.x; i < n; i += 256 * gridDim.y) dst[i] = src[i];
+}
+// the same with the descriptors as kernel arguments (up to 16 segments: the per-frame read-backs) — no descriptor copy in front
+struct GatherArgs { ScatterSeg seg[16]; };
+__global__ __launch_bounds__(256) void k_gather_args(unsigned char* __restrict__ stage, GatherArgs A) {
+  const ScatterSeg sg = A.seg[blockIdx.x];
+  unsigned* dst = reinterpret_cast<unsigned*>(stage + sg.off);
+  const unsigned* src = reinterpret_cast<const unsigned*>(sg.dst);
+  const unsigned n = sg.bytes >> 2;
+  for (unsigned i = blockIdx.y * 256 + threadIdx.x; i < n; i += 256 * gridDim.y) dst[i] = src[i];
+}
+void launch_gather_args(void* stage, const void* segs, int nseg, hipStream_t s) {
+  GatherArgs A{};
+  std::memcpy(A.seg, segs, (size_t)nseg * sizeof(ScatterSeg));
+  if (nseg > 0) hipLaunchKernelGGL(k_gather_args, dim3(nseg, 4), dim3(256), 0, s, static_cast<unsigned char*>(stage), A);
 }
 void launch_gather(void* stage, unsigned desc_off, int nseg, hipStream_t s) {
   if (nseg > 0) hipLaunchKernelGGL(k_gather, dim3(nseg, 4), dim3(256), 0, s, static_cast<unsigned char*>(stage), desc_off);
