@@ -302,6 +302,8 @@ __global__ __launch_bounds__(256) void k_lin_lf_b(const GraphDev* __restrict__ G
 // MODE 3: everything in one launch as MODE 0, the sums also left in lm_Hacc and separator landmarks treated as in MODE 2 (exact joint
 // pass: nothing is exchanged between the two halves, k_border_fill reads the robot's own H_ll from lm_Hacc).
 __shared__ double lm_hs[4][96];   // per wave of k_landmark: H_ll^-1 (81) + g_l (9)
+constexpr int LM_RED_MAX = 24;    // k_landmark<3>: landmarks with at most that many factors reduce their partial sums through LDS
+__shared__ double lm_red[4][54 * LM_RED_MAX];
 
 template <int D, int MODE>
 __device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
@@ -338,12 +340,44 @@ __device__ inline void landmark_wave(const GraphDev& G, int l, int lane) {
     }
   }
   if (MODE != 2) {
+    if (MODE == 3) {
+      // the partial sums meet through LDS instead of a six-level shuffle tree over all 64 lanes: in rounds of LM_RED_MAX lanes (one round
+      // for the usual landmark with a dozen factors) lane f (a factor) writes its NH + D partials, lane e adds entry e of the round's
+      // lanes in lane order, and at the end every lane reads the totals (~130 LDS operations per lane against 6 x 2 x (NH + D) = 648
+      // cross-lane ones)
+      double* red = lm_red[threadIdx.x >> 6];
+      const int nl = nf < 64 ? nf : 64;      // lanes that hold partial sums
+      double tot = 0.0;
+      for (int base = 0; base < nl; base += LM_RED_MAX) {
+        const int cnt = nl - base < LM_RED_MAX ? nl - base : LM_RED_MAX;
+        if (lane >= base && lane < base + cnt) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+          for (int i = 0; i < NH; ++i) red[i * LM_RED_MAX + lane - base] = h[i];
 #pragma unroll
-      for (int i = 0; i < NH; ++i) h[i] += __shfl_xor(h[i], off);
+          for (int i = 0; i < D; ++i) red[(NH + i) * LM_RED_MAX + lane - base] = g[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (lane < NH + D)
+          for (int q = 0; q < cnt; ++q) tot += red[lane * LM_RED_MAX + q];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+      }
+      if (lane < NH + D) red[lane] = tot;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
-      for (int i = 0; i < D; ++i) g[i] += __shfl_xor(g[i], off);
+      for (int i = 0; i < NH; ++i) h[i] = red[i];
+#pragma unroll
+      for (int i = 0; i < D; ++i) g[i] = red[NH + i];
+    } else {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int i = 0; i < NH; ++i) h[i] += __shfl_xor(h[i], off);
+#pragma unroll
+        for (int i = 0; i < D; ++i) g[i] += __shfl_xor(g[i], off);
+      }
     }
   }
   if (MODE == 1 || MODE == 3) {
