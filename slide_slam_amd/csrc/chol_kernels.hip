@@ -1537,6 +1537,7 @@ struct BorderApplyArgs {
   int n;
   const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX]; int nbr[CHOL_BATCH_MAX]; int b0[CHOL_BATCH_MAX];
   double* yv[CHOL_BATCH_MAX]; const double* x[CHOL_BATCH_MAX];
+  const int* segtab[CHOL_BATCH_MAX];      // or null: CholSystem::segtab — a cut band's border rows are non-zero in some block columns only
 };
 __global__ __launch_bounds__(256) void k_border_apply(BorderApplyArgs A) {
   const int r = blockIdx.z;
@@ -1546,7 +1547,19 @@ __global__ __launch_bounds__(256) void k_border_apply(BorderApplyArgs A) {
   const double* w = A.S[r] + (size_t)col * A.ld[r] + (size_t)A.b0[r] * NB;      // (b0: first border tile row — T, or further down for a view)
   const double* x = A.x[r];
   double acc = 0.0;
-  for (int q = lane; q < nrow; q += 64) acc += w[q] * x[q];
+  const int* st = A.segtab[r];
+  const int* msk = st ? st + 1 + st[0] + st[0] * (A.nbr[r] + 1) : nullptr;      // (behind the segments' table: T, then a 64-bit mask per block column)
+  if (msk && msk[0] > 0) {
+    const int c = col / NB;
+    unsigned long long m = (unsigned long long)(unsigned)msk[1 + 2 * c] | ((unsigned long long)(unsigned)msk[2 + 2 * c] << 32);
+    while (m) {      // the tile rows some segment works on in this block column: the others are zero
+      const int t = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      acc += w[t * NB + lane] * x[t * NB + lane];
+    }
+  } else {
+    for (int q = lane; q < nrow; q += 64) acc += w[q] * x[q];
+  }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
   if (lane == 0) A.yv[r][col] -= acc;
@@ -1558,6 +1571,7 @@ void launch_border_apply(const CholSystem* d, int n, const double* const* xloc, 
   for (int i = 0; i < n; ++i) {
     A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.nbr[i] = d[i].nbr; A.yv[i] = d[i].yv; A.x[i] = xloc[i];
     A.b0[i] = d[i].b0 > 0 ? d[i].b0 : d[i].T;
+    A.segtab[i] = d[i].segtab;
     Tmax = d[i].T > Tmax ? d[i].T : Tmax;
   }
   if (Tmax > 0) hipLaunchKernelGGL(k_border_apply, dim3(Tmax * NB / 4, 1, n), dim3(256), 0, s, A);

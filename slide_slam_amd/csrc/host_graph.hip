@@ -418,6 +418,7 @@ CholBatch::~CholBatch() {
   free_separator();
   if (d_ctr2) (void)hipFree(d_ctr2);
   if (d_syrk_jobs) (void)hipFree(d_syrk_jobs);
+  if (d_l2_jobs) (void)hipFree(d_l2_jobs);
   if (d_Gs) (void)hipFree(d_Gs);
   if (d_status_all) (void)hipFree(d_status_all);
   if (ev_aux0) (void)hipEventDestroy(ev_aux0);
@@ -609,6 +610,26 @@ int CholBatch::prepare_pass() {
       const char* e = getenv("SLIDE_SYRK_LDS");
       syrk_lds_pad = e ? atoi(e) : 0;
       if (getenv("SLIDE_SYRK_PLAIN")) n_syrk_jobs = 0;
+    }
+    {
+      // the second level's border products: one workgroup per real tile (the plain grid launches as many idle ones)
+      std::vector<int> codes;
+      for (size_t i = 0; i < l2_sys.size() && i < 2047; ++i) {
+        const int nb = l2_sys[i].nbr;
+        if (nb > 1023) { codes.clear(); break; }
+        for (int jb = 0; jb < nb; ++jb)
+          for (int ib = jb; ib <= nb; ++ib) codes.push_back((int)i << 20 | ib << 10 | jb);
+      }
+      n_l2_jobs = (int)codes.size();
+      if (n_l2_jobs > l2_jobs_cap) {
+        if (d_l2_jobs) { SL_HIP(hipStreamSynchronize(master)); SL_HIP(hipFree(d_l2_jobs)); d_l2_jobs = nullptr; }
+        l2_jobs_cap = 2 * n_l2_jobs;
+        SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_l2_jobs), (size_t)l2_jobs_cap * sizeof(int)));
+      }
+      if (n_l2_jobs > 0) {
+        SL_HIP(hipStreamSynchronize(master));
+        SL_HIP(hipMemcpy(d_l2_jobs, codes.data(), codes.size() * sizeof(int), hipMemcpyHostToDevice));
+      }
     }
     if (!d_ctr2) {
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_ctr2), 64 * sizeof(int)));
@@ -910,7 +931,8 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     if (!l2_sys.empty()) {
       // second level: the separator poses' own system (dense, nsep block columns) with the rest of the border as its border
       launch_chol_batch(l2_sys.data(), (int)l2_sys.size(), d_ctr2, master, nullptr, false);
-      launch_border_syrk(l2_sys.data(), (int)l2_sys.size(), master);
+      if (n_l2_jobs > 0) launch_border_syrk_jobs(l2_sys.data(), (int)l2_sys.size(), d_l2_jobs, n_l2_jobs, 0, master);
+      else launch_border_syrk(l2_sys.data(), (int)l2_sys.size(), master);
     }
     mark(2);
     // a cut pass leaves this GPU's partial sum in the caller's exchange buffer (packed), a whole pass writes the system itself
@@ -1755,6 +1777,24 @@ int HostGraph::upload_new() {
         flat_ord.insert(flat_ord.end(), ord.begin(), ord.end());
         seg_tab.insert(seg_tab.end(), sf[q].begin(), sf[q].end());
       }
+      {
+        // and, behind it, per block column of the band the set of border tile rows some segment works on there (k_border_apply reads
+        // only those): T, then T x (low, high) words of a 64-bit mask — T = 0: more than 64 border tile rows, no masks
+        const int Tb = (int)((6 * Pn + NB - 1) / NB);
+        seg_tab_head = (int)seg_tab.size();
+        if (nbr_new <= 64) {
+          seg_tab.push_back(Tb);
+          for (int c = 0; c < Tb; ++c) {
+            unsigned long long m = 0;
+            for (int q = 0; q < NS; ++q)
+              if (c < segs[q].t1)
+                for (int t = 0; t < nbr_new; ++t)
+                  if (sf[q][t] <= c && c >= segs[q].t0) m |= 1ull << t;
+            seg_tab.push_back((int)(unsigned)(m & 0xffffffffull));
+            seg_tab.push_back((int)(unsigned)(m >> 32));
+          }
+        } else seg_tab.push_back(0);
+      }
       if (d_seg_ord.ensure(std::max<size_t>(flat_ord.size(), 1), 0, s) != SLIDE_OK || d_seg_tab.ensure(seg_tab.size(), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
       if (!flat_ord.empty()) SL_HIP(hipMemcpyAsync(d_seg_ord.d, flat_ord.data(), flat_ord.size() * sizeof(int), hipMemcpyHostToDevice, s));
       SL_HIP(hipMemcpyAsync(d_seg_tab.d, seg_tab.data(), seg_tab.size() * sizeof(int), hipMemcpyHostToDevice, s));
@@ -2485,8 +2525,8 @@ int HostGraph::get_segment_table(int* out, int cap) {
   if (rc == SLIDE_OK) rc = upload_new();
   if (rc != SLIDE_OK) return rc < 0 ? rc : -rc;
   if (!arrow_on() || nsep <= 0 || seg_tab.empty()) return 0;
-  for (size_t i = 0; i < seg_tab.size() && (int)i < cap; ++i) out[i] = seg_tab[i];
-  return (int)seg_tab.size();
+  for (int i = 0; i < seg_tab_head && i < cap; ++i) out[i] = seg_tab[i];      // (the per-column masks behind it are the kernels' business)
+  return seg_tab_head;
 }
 int HostGraph::get_segments(int* out, int cap) {
   int rc = merge_pending();

@@ -208,6 +208,7 @@ class CholBatch {
   int* d_ctr2 = nullptr;
   int* d_syrk_jobs = nullptr;                       // border product: (system << 20 | ib << 10 | jb) of every lower tile + right-hand-side row, longest sum first
   int n_syrk_jobs = 0, syrk_jobs_cap = 0, syrk_lds_pad = 0;
+  int* d_l2_jobs = nullptr; int n_l2_jobs = 0, l2_jobs_cap = 0;      // the same for the border products of the bands' second level
   // separator system of the exact joint step: m coordinates, Ts tile columns; factored by the un-batched step kernels on the pass's stream
   double* sepS = nullptr; long long sep_len = 0;          // the system in the factorisation's layout (owned)
   double* sep_x = nullptr; long long sep_x_len = 0;       // the caller's exchange buffer (packed layout), or null: no exchange
@@ -419,6 +420,7 @@ class HostGraph {
   // product reads — nseg, the segments' last block columns + 1, then per segment the first column of every tile row + the right-hand side
   std::vector<std::vector<int>> seg_ord, seg_sfirst;
   std::vector<int> seg_tab;
+  int seg_tab_head = 0;                               // ints of seg_tab in front of the per-column activity masks
   DevArr<int> d_seg_ord, d_seg_tab;
   int nsep = 0, nsep_dim = 0, n_sep_poses = 0;
   DevArr<double> d_Ld2, d_Winv2, d_yv2, d_dp2;
