@@ -813,6 +813,7 @@ int CholBatch::prepare_separator() {
     SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_jobs), codes.size() * sizeof(int)));
     SL_HIP(hipMemcpy(d_sep_jobs, codes.data(), codes.size() * sizeof(int), hipMemcpyHostToDevice));
     sep_ks = std::max(1, std::min({8, TL / 4, (1024 + n_sep_jobs - 1) / std::max(n_sep_jobs, 1)}));
+    if (getenv("SLIDE_SEP_KS")) sep_ks = std::max(1, std::min(16, atoi(getenv("SLIDE_SEP_KS"))));      // (diagnostic)
     if (sep_ks > 1) {
       const size_t len = (size_t)(nb + 1) * nb * (sep_ks - 1) * NB * NB * sizeof(double);
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_scratch), len));
