@@ -1327,35 +1327,40 @@ struct SepGatherArgs {
   const double* bord[8]; int ldb[8]; int nbr[8]; const int* map[8];      // map: ms + lam ints, separator coordinate -> robot's border coordinate or -1
   const int* tmask;      // or null: per virtual tile (Ts landmark + nl lambda tiles), bit r set = robot r holds a coordinate of the tile
 };
+constexpr int SEP_GATHER_COLS = 8;      // columns per workgroup (a workgroup per column: 62 000 workgroups, half of them above the diagonal)
 __global__ __launch_bounds__(256) void k_sep_gather(SepGatherArgs A) {
   const SepLayout& Y = A.Y;
-  const int vr = blockIdx.x * 256 + threadIdx.x, vc = blockIdx.y;
+  const int vr = blockIdx.x * 256 + threadIdx.x;
   const int NL = Y.Ts * NB, NT = (Y.Ts + Y.nl) * NB;
-  if (vr > NT || vc >= NT) return;
+  if (vr > NT) return;
   const bool rhs = vr == NT;
-  if (!rhs && vr < vc) return;
-  if (A.packed && sep_packed_hole(vr, vc, Y.hTa, Y.hTL)) return;
-  // separator coordinate of a virtual index, or -1 on the padding
-  const int gc = vc < NL ? (vc < Y.ms ? vc : -1) : (vc - NL < Y.lam ? Y.ms + vc - NL : -1);
   const int gr = rhs ? 0 : (vr < NL ? (vr < Y.ms ? vr : -1) : (vr - NL < Y.lam ? Y.ms + vr - NL : -1));
-  double s = 0.0;
-  if (gc < 0 || gr < 0) {
-    s = (vr == vc && vc < NL) ? 1.0 : 0.0;      // unit diagonal on the landmark padding (the lambda padding is set by k_lam_prepare)
-  } else if (vr == vc && ((vc >= Y.gap[0] && vc < Y.gap[1]) || (vc >= Y.gap[2] && vc < Y.gap[3]))) {
-    s = A.packed ? 0.0 : 1.0;                   // padding between the blocks of a dissected layout (a packed partial sum gets it in k_sep_unpack)
-  } else {
-    // only the robots that hold coordinates of BOTH tiles can contribute (two or three of eight on a grid of robot cells)
-    unsigned cand = A.tmask ? (unsigned)A.tmask[vc / NB] & (rhs ? ~0u : (unsigned)A.tmask[vr / NB]) : ~0u;
-    for (int r = 0; r < A.n; ++r) {
-      if (!((cand >> r) & 1u)) continue;
-      const int lc = A.map[r][gc];
-      if (lc < 0) continue;
-      const int lr = rhs ? A.nbr[r] * NB : A.map[r][gr];
-      if (lr < 0) continue;
-      s += A.bord[r][(size_t)min(lr, lc) * A.ldb[r] + max(lr, lc)];      // (lower triangle of the robot's block)
+  const unsigned rmask = A.tmask ? (rhs ? ~0u : (unsigned)A.tmask[vr / NB]) : ~0u;
+  for (int vc = blockIdx.y * SEP_GATHER_COLS; vc < (int)(blockIdx.y + 1) * SEP_GATHER_COLS && vc < NT; ++vc) {
+    if (!rhs && vr < vc) continue;
+    // (the block between the leaves of a dissected layout: nobody ever writes it, in either layout — zero since allocation)
+    if (sep_packed_hole(vr, vc, Y.hTa, Y.hTL)) continue;
+    // separator coordinate of a virtual index, or -1 on the padding
+    const int gc = vc < NL ? (vc < Y.ms ? vc : -1) : (vc - NL < Y.lam ? Y.ms + vc - NL : -1);
+    double s = 0.0;
+    if (gc < 0 || gr < 0) {
+      s = (vr == vc && vc < NL) ? 1.0 : 0.0;      // unit diagonal on the landmark padding (the lambda padding is set by k_lam_prepare)
+    } else if (vr == vc && ((vc >= Y.gap[0] && vc < Y.gap[1]) || (vc >= Y.gap[2] && vc < Y.gap[3]))) {
+      s = A.packed ? 0.0 : 1.0;                   // padding between the blocks of a dissected layout (a packed partial sum gets it in k_sep_unpack)
+    } else {
+      // only the robots that hold coordinates of BOTH tiles can contribute (two or three of eight on a grid of robot cells)
+      const unsigned cand = A.tmask ? (unsigned)A.tmask[vc / NB] & rmask : ~0u;
+      for (int r = 0; r < A.n; ++r) {
+        if (!((cand >> r) & 1u)) continue;
+        const int lc = A.map[r][gc];
+        if (lc < 0) continue;
+        const int lr = rhs ? A.nbr[r] * NB : A.map[r][gr];
+        if (lr < 0) continue;
+        s += A.bord[r][(size_t)min(lr, lc) * A.ldb[r] + max(lr, lc)];      // (lower triangle of the robot's block)
+      }
     }
+    *sep_slot(Y, vr, vc, A.packed != 0) = s;
   }
-  *sep_slot(Y, vr, vc, A.packed != 0) = s;
 }
 // c0, c1: the (virtual) tile columns [c0, c1) only; to_packed: the other way (the factorisation's layout -> the packed buffer: a rank that
 // owns a leaf of a dissected layout hands its top block back for the exchange)
@@ -1683,7 +1688,7 @@ void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, const S
   A.n = n; A.Y = Y; A.packed = packed ? 1 : 0; A.tmask = tmask;
   for (int i = 0; i < n; ++i) { A.bord[i] = h[i].bord; A.ldb[i] = h[i].ldb; A.nbr[i] = h[i].nbr; A.map[i] = maps[i]; }
   const int NT = (Y.Ts + Y.nl) * NB;
-  if (NT > 0) hipLaunchKernelGGL(k_sep_gather, dim3((NT + 1 + 255) / 256, NT), dim3(256), 0, s, A);
+  if (NT > 0) hipLaunchKernelGGL(k_sep_gather, dim3((NT + 1 + 255) / 256, (NT + SEP_GATHER_COLS - 1) / SEP_GATHER_COLS), dim3(256), 0, s, A);
 }
 void launch_lam_prepare(const double* bord, int nl, int lam, double* out, hipStream_t s) {
   if (nl > 0) hipLaunchKernelGGL(k_lam_prepare, dim3((nl * NB + 1 + 255) / 256, nl * NB), dim3(256), 0, s, bord, nl, lam, out);
