@@ -1231,7 +1231,10 @@ __global__ __launch_bounds__(256) void k_sep_extract_b(const GraphDev* __restric
   // (1) column strip: rows 6q .. end of the profile of q's last column's tile, plus the border rows and the right-hand side
   const int r_end = G.prof ? min(NT, (G.prof[(6 * q + 5) / NB] + 1) * NB) : NT;
   const int n_strip = r_end - 6 * q;
-  for (int e = tid; e < 6 * n_strip; e += 256) {             // (consecutive threads walk down one column of S)
+  // the three strips of a cut pose on three workgroups (blockIdx.y): every entry has one owner, so they need no order among them —
+  // one workgroup walking through all of them one after the other is a chain of ~10 global round trips
+  const int part = blockIdx.y;
+  for (int e = tid; part == 0 && e < 6 * n_strip; e += 256) {             // (consecutive threads walk down one column of S)
     const int a = e / n_strip, r = 6 * q + e % n_strip, c = 6 * q + a;
     if (r < c) continue;
     double* src = G.S + (size_t)c * ld + r;
@@ -1244,22 +1247,22 @@ __global__ __launch_bounds__(256) void k_sep_extract_b(const GraphDev* __restric
     }
     *src = (r == c) ? 1.0 : 0.0;
   }
-  for (int e = tid; e < 6 * nb_rows; e += 256) {             // border rows at q's columns -> bord(row, o_c)
+  for (int e = tid; part == 1 && e < 6 * nb_rows; e += 256) {             // border rows at q's columns -> bord(row, o_c)
     const int a = e / nb_rows, b = e % nb_rows;
     double* src = G.S + (size_t)(6 * q + a) * ld + brow + b;
     const double v = *src;
     if (v != 0.0) { G.bord[(size_t)(oq + a) * ldb + b] = v; *src = 0.0; }
   }
-  if (tid < 6) {                                             // right-hand side
+  if (part == 0 && tid < 6) {                                // right-hand side
     double* src = G.S + (size_t)(6 * q + tid) * ld + brow + (size_t)G.nbr * NB;
     G.bord[(size_t)(oq + tid) * ldb + (size_t)G.nbr * NB] = *src;
     *src = 0.0;
   }
-  if (blockIdx.x == 0)                                       // unit diagonal on the padding of the separator part (whole tiles)
+  if (part == 0 && blockIdx.x == 0)                          // unit diagonal on the padding of the separator part (whole tiles)
     for (int p = G.nsep_dim + tid; p < G.nsep * NB; p += 256) G.bord[(size_t)p * ldb + p] = 1.0;
   // (2) row strip: columns from the first column the profile lets reach q's rows, poses that are no separator poses only
   const int c_beg = G.first ? G.first[(6 * q) / NB] * NB : 0;
-  for (int e = tid; e < 6 * (6 * q - c_beg); e += 256) {
+  for (int e = tid; part == 2 && e < 6 * (6 * q - c_beg); e += 256) {
     const int a = e % 6, c = c_beg + e / 6, r = 6 * q + a;
     const int pc = c / 6;
     if (pc >= G.P || G.pose_sep[pc] >= 0) continue;
@@ -1653,7 +1656,7 @@ void launch_estimate(const GraphDev& G, hipStream_t s) {
 void launch_sep_extract_batched(const GraphDev* d, const GraphDev* h, int n, const int* n_sep_poses, hipStream_t s) {
   int mx = 0;
   for (int i = 0; i < n; ++i) mx = std::max(mx, (h[i].arrow && h[i].pose_sep) ? n_sep_poses[i] : 0);
-  if (mx > 0) hipLaunchKernelGGL(k_sep_extract_b, dim3(mx, 1, n), dim3(256), 0, s, d, mx);
+  if (mx > 0) hipLaunchKernelGGL(k_sep_extract_b, dim3(mx, 3, n), dim3(256), 0, s, d, mx);
 }
 void launch_sep_pose_scatter_batched(const GraphDev* d, const GraphDev* h, int n, double* const* xloc, hipStream_t s) {
   int P = 0;
