@@ -20,9 +20,26 @@ V_POSE, V_POINT, V_CUBE, V_CYL = range(4)
 CHART_CAYLEY, CHART_EXPMAP = 0, 1
 
 
+def _cpu_tag() -> str:
+    """Short hash of this host's CPU model and feature flags: a -march=native build made on another machine (the build travels with
+    the tree to the GPU box) must not be loaded there."""
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as fh:
+            txt = fh.read()
+        keep = [ln for ln in txt.splitlines() if ln.startswith(("model name", "flags"))][:2]
+    except OSError:
+        keep = []
+    return hashlib.sha1("\n".join(keep).encode()).hexdigest()[:10]
+
+
+def _native_name() -> str:
+    return f"liboracle_native_{_cpu_tag()}.so"
+
+
 def build(native: bool = False) -> str:
-    """Compile the oracle (g++).  native=True builds a -march=native copy for CPU-baseline timing."""
-    out = "_build/liboracle_native.so" if native else "_build/liboracle.so"
+    """Compile the oracle (g++).  native=True builds a -march=native copy for CPU-baseline timing (one per kind of host CPU)."""
+    out = f"_build/{_native_name()}" if native else "_build/liboracle.so"
     flags = "-O3 -march=native" if native else "-O3 -march=x86-64-v3"
     cmd = ["make", "-C", _HERE, f"OUT={out}",
            f"CXXFLAGS={flags} -ffp-contract=off -fopenmp -std=c++17 -fPIC -Wall -Wno-unused-function"]
@@ -34,7 +51,7 @@ def lib(native: bool = False):
     global _LIB
     if _LIB is not None and not native:
         return _LIB
-    path = os.path.join(_HERE, "_build", "liboracle_native.so" if native else "liboracle.so")
+    path = os.path.join(_HERE, "_build", _native_name() if native else "liboracle.so")
     try:
         path = build(native)          # make: a no-op when the library is newer than its sources, so a stale build cannot be loaded
     except (subprocess.CalledProcessError, OSError):
