@@ -319,6 +319,21 @@ def border_flops(T, first):
     return done, dense
 
 
+def self_launch(n):
+    """Run this script as n ranks under torch.distributed.run (child process; stdout / stderr inherited) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (the host driver only supports dmabuf IPC: RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -353,8 +368,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver may call it: start the N ranks ourselves (torch.distributed.run, one process per GPU)
+        # as a CHILD process, before torch or anything that touches the GPU is imported here, relay its output (rank 0 prints the JSON
+        # line) and leave with its exit code.
+        raise SystemExit(self_launch(args.gpus))
     import torch            # torch first: it must initialise the device before this library's HIP runtime is loaded
     dist = None
     # SLIDE_BENCH_BACKEND=gloo rehearses the N > 1 path with every rank on GPU 0 (collectives staged through the
@@ -565,12 +583,55 @@ def main():
                               "number of passes through slide_graph_dist_phase (no batch, no captured graph, host-side sums); tolerance "
                               "1e-6 relative (only the summation order of the exchange differs)"}
             del ref_shards, rdrv, rbufs
+    if multi and use_dist and world > 1 and drv.arrow and not args.no_parity:
+        parity = n1_replica_parity(args, s, cfg, world_map, rank, world, device, dist, final, n_probe, n_passes, info)
     report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build, info, mode, batched_prof, parity, conv, finite, dist, T, dense_leg)
     if use_dist:
         dist.destroy_process_group()
     if rank == 0 and ((parity is not None and not parity["ok"]) or not finite or
                       (multi and conv is not None and args.joint == "exact" and conv["passes_to_1e-4_pose"] is None)):
         raise SystemExit(1)
+
+
+def n1_replica_parity(args, s, cfg, world_map, rank, world, device, dist, final, n_probe, n_passes, info):
+    """N > 1: every line verifies itself against N = 1.  The ranks' final poses are gathered; rank 0 builds ALL robots of the job once
+    more on its own GPU (the same streaming builds), merges them as one process (one CholBatch, the whole pass one replayed hipGraph,
+    no collective) and drives the same number of exact joint passes — the N = 1 job of this very code — and the poses are compared:
+    parity.vs_n1_max_rel, relative per robot, the worst; the bench exits 1 above 1e-6."""
+    from slide_slam_amd.distributed import PassDriver, gpu_matcher, setup_local_shards
+    from slide_slam_amd.synth import make_relmeas, make_robot_log
+    gathered = [None] * world
+    dist.all_gather_object(gathered, final)
+    if rank != 0:
+        return None
+    job = np.concatenate(gathered, axis=0)
+    robots = job.shape[0]
+    if robots > 8:                   # (a CholBatch holds eight graphs)
+        return {"vs_n1_max_rel": None, "ok": True, "what": f"not run: {robots} robots do not fit one CholBatch (8)"}
+    P = job.shape[1]
+    logs = [make_robot_log(cfg, world_map, r % cfg.robots) for r in range(robots)]
+    ref = [build_shard(s, lg, args.frames, args.ingest_only)[0] for lg in logs]
+    batch = s.CholBatch(robots)
+    for t, gb in enumerate(ref):
+        gb.graph.join_chol_batch(batch, t)
+    bufs, rinfo = setup_local_shards(ref, gpu_matcher, device=device)
+    drv = PassDriver(ref, bufs, rinfo["n_slots"], batch=batch, device=device, arrow=True, sep_dim=rinfo["sep_dim"], sep_prof=rinfo.get("sep_prof"))
+    if info.get("n_relmeas"):
+        drv.setup_ghosts(make_relmeas(cfg, logs))
+    for i in range(n_passes):
+        drv.one_pass()
+        if i < n_probe:              # (the probe read the cost after each of its passes, which commits delta into theta: same here)
+            for gb in ref:
+                gb.graph.chi2()
+    one = np.stack([all_poses(gb, P) for gb in ref])
+    for gb in ref:
+        gb.graph.join_chol_batch(None)
+    rel = float((np.linalg.norm((job - one).reshape(robots, -1), axis=1) / np.linalg.norm(one.reshape(robots, -1), axis=1)).max())
+    same = bool(rinfo["n_slots"] == info["n_slots"] and rinfo["sep_dim"] == info["sep_dim"])
+    return {"vs_n1_max_rel": rel, "passes_compared": n_passes, "slots_equal": same, "ok": bool(np.isfinite(rel) and rel < 1e-6 and same),
+            "what": f"poses of every robot after the probe + warm-up + timed passes of this {world}-rank job vs the SAME job run as one process "
+                    "on rank 0's GPU (all robots in one CholBatch, no collective) — relative, per robot, the worst; tolerance 1e-6 (only the "
+                    "summation order of the separator system's exchange differs; north-star bar 1e-4)"}
 
 
 def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build, info, mode, bt, parity, conv, finite, dist, T, dense_leg=None):

@@ -301,6 +301,10 @@ int slide_backend_landmark_table(slide_backend_t* b, int cls, double* xyz, int32
  * GTSAM's CHOLESKY factorisation, graph.cpp:15).  ms_out (may be NULL): device time of `repeats`
  * factor+solve passes measured with HIP events on the launch stream. */
 int slide_dense_spd_solve(const double* A, int n, const double* b, double* x, int repeats, double* ms_out);
+/* The same solve by an explicit schedule of the factorisation: method 0 = one step launch per 64-column block (what
+ * slide_dense_spd_solve runs), 1 = the left-looking persistent factorisation (ONE launch for all block columns, flags between
+ * workgroups instead of kernel boundaries: what the exact joint passes use, ISAM2Params::CHOLESKY of graph.cpp:15 all the same). */
+int slide_dense_spd_solve_ex(const double* A, int n, const double* b, double* x, int repeats, double* ms_out, int method);
 
 /* ------------------------------------------------------------------------------------------------
  * S3 — association (include/core/sloam.h:88-108, src/core/sloam.cpp:73-306; *MapManager::getSubmap)

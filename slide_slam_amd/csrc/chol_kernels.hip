@@ -13,7 +13,10 @@
 // D[row = (lane>>4) + 4*reg][col = lane&15].
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
+#include <utility>
+#include <vector>
 
 #include "graph_dev.hpp"
 #include "kernels.hpp"
@@ -705,6 +708,290 @@ __global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int 
     if (!it.ok) continue;
     if (it.ks == 32) b_quadrant<32>(A.S[r], A.ld[r], it, wave & 3);
     else b_quadrant<16>(A.S[r], A.ld[r], it, wave & 3);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// LEFT-LOOKING PERSISTENT factorisation: ALL block columns of up to 64 systems in ONE launch (round 4).
+// The step kernels above pay a kernel boundary per block column: ~3 us of dispatch gap, ~1.5 us of loads and staging, ~1.8 us of
+// closing on top of the ~8 us chain of a 64-column diagonal block — and an exact joint pass runs 58 such launches in a row.  Here the
+// boundary is a FLAG.  The work is cut into tasks, one workgroup each, started in ticket order (an atomic counter: a task only ever
+// waits for tasks with lower tickets, i.e. for workgroups that have started — no assumption about the dispatcher):
+//   chain task (k):    the type-A workgroup of the step kernel for the first tile row of column k — pending panel (k, k-1) through LDS,
+//                      the diagonal block's chain on wave 0, its sub-tile rows on waves 1-3, the tile's rows on the panel waves —
+//                      preceded by the LEFT-LOOKING sum over the older panels c < k-1 (operands straight from L2: they were final
+//                      long ago and are summed while the chain task of column k-1 still runs).  Publishes L_kk's pieces (Ld, Winv)
+//                      and its tile.
+//   tile task (k, i):  one or two further tile rows of column k, eight waves of sixteen rows: A(i, k) - sum_c L(i, c) L(k, c)^T over the
+//                      columns c in which both are non-zero (ready except for the last one or two), then, once L_kk is published,
+//                      X = A L_kk^-T by blocked substitution with the 16x16 inverses — the arithmetic of panel_rows.
+// Every tile is written exactly once, by its task, and read by others only behind its flag: producers close with a release fence at
+// agent scope (L2 write-back towards the memory side: the XCDs' L2s are not coherent with each other) before one lane raises the flag
+// (relaxed agent-scope atomic), consumers poll the flags (agent-scope atomic loads, a lane per pending column) and pass an acquire
+// fence before they read — the message-passing pattern of the AMDGPU memory model; tools/tile_hop_bench.hip measures the hand-over
+// and counts stale values per protocol.  No trailing updates are written back at all (the right-looking flood of the step kernels
+// re-reads and re-writes every trailing tile once per two columns).
+// Exit condition every wave reaches: polls are bounded; a workgroup that gives up raises status bit 2 and the launch's abort word,
+// which every other poll loop checks.
+struct LLSys { double* S; double* Ld; double* Winv; int* status; int* flags; int ld, T, B0, nbr, frows; };
+struct LLTask { int sys, k, kind, it0, it1, clo_d, clo0, clo1; };      // kind 0: chain task (tile row it0), 1: tile task (rows it0, it1 or -1)
+constexpr int LL_SPIN_MAX = 1 << 19;
+
+// flags f0[c * stride] (and f1[c * stride] unless null), c0 <= c < c1, all raised?  One lane per column, the whole wave spins.
+__device__ __forceinline__ bool ll_wait_cols(const int* f0, const int* f1, int stride, int c0, int c1, int* ctl, int* status) {
+  const int lane = threadIdx.x & 63;
+  bool ok = true;
+  for (int base = c0; base < c1 && ok; base += 64) {
+    const int c = base + lane;
+    const bool in = c < c1;
+    int spins = 0;
+    for (;;) {
+      int a = 1, b = 1;
+      if (in) {
+        a = __hip_atomic_load(f0 + (size_t)c * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f1) b = __hip_atomic_load(f1 + (size_t)c * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (__all(a != 0 && b != 0)) break;
+      ++spins;
+      if (spins > LL_SPIN_MAX || ((spins & 63) == 0 && __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        if (lane == 0) {
+          atomicOr(&status[1], 2);
+          __hip_atomic_store(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return ok;
+}
+// sixteen rows (16 q ..) of tile row `it` of column k in the T-layout of panel_rows: Tq[b][r] = A[16 q + lr][16 b + lk + 4 r]
+__device__ __forceinline__ void ll_rows_load(const double* __restrict__ S, int ld, int k, int it, int q, int lr, int lk, v4d (&Tq)[4]) {
+  const double* tcol = S + (size_t)(k * NB) * ld + (size_t)it * NB + 16 * q + lr;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Tq[b][r] = tcol[(size_t)(16 * b + lk + 4 * r) * ld];
+}
+// Tq -= L(it, c)[rows 16 q ..] L(k, c)^T for one finished block column c: operands straight from memory (A: the own rows of tile
+// (it, c), B: tile (k, c), sixteen-lane runs down its columns)
+__device__ __forceinline__ void ll_rows_term(const double* __restrict__ S, int ld, int k, int it, int q, int c, int lr, int lk, v4d (&Tq)[4]) {
+  const double* pa = S + (size_t)(c * NB + lk) * ld + (size_t)it * NB + 16 * q + lr;
+  const double* pb = S + (size_t)(c * NB + lk) * ld + (size_t)k * NB + lr;
+#pragma unroll 8
+  for (int ks = 0; ks < 16; ++ks) {
+    const size_t o = (size_t)(4 * ks) * ld;
+    const double a = pa[o];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) Tq[bb] = mfma_f64(-pb[o + 16 * bb], a, Tq[bb]);
+  }
+}
+// sub-tile row w of the diagonal block: R[J] -= L(k, c)[rows 16 w ..] L(k, c)[rows 16 J ..]^T, J <= w
+__device__ __forceinline__ void ll_diag_term(const double* __restrict__ S, int ld, int k, int w, int c, int lr, int lk, v4d (&R)[4]) {
+  const double* pc = S + (size_t)(c * NB + lk) * ld + (size_t)k * NB + lr;
+#pragma unroll 8
+  for (int ks = 0; ks < 16; ++ks) {
+    const size_t o = (size_t)(4 * ks) * ld;
+    const double a = pc[o + 16 * w];
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+      if (J <= w) R[J] = mfma_f64(-pc[o + 16 * J], a, R[J]);
+  }
+}
+
+// ---- tile task: tile rows it0 (waves 0..3) and it1 (waves 4..7; -1: none) of column k ----
+__device__ __forceinline__ void ll_tile_task(const LLSys& Y, const LLTask& tk, int* ctl) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  const int slot = wave >> 2, q = wave & 3;
+  const int it = slot ? tk.it1 : tk.it0;
+  const int clo = slot ? tk.clo1 : tk.clo0;
+  const int k = tk.k, ld = Y.ld, fr = Y.frows;
+  double* S = Y.S;
+  if (it >= 0) {
+    v4d Tq[4];
+    ll_rows_load(S, ld, k, it, q, lr, lk, Tq);
+    const int* fk = Y.flags + k;
+    const int* fi = Y.flags + it;
+    if (clo < k - 1) {
+      ll_wait_cols(fk, fi, fr, clo, k - 1, ctl, Y.status);
+      for (int c = clo; c < k - 1; ++c) ll_rows_term(S, ld, k, it, q, c, lr, lk, Tq);
+    }
+    if (clo <= k - 1) {
+      ll_wait_cols(fk, fi, fr, k - 1, k, ctl, Y.status);
+      ll_rows_term(S, ld, k, it, q, k - 1, lr, lk, Tq);
+    }
+    // L_kk: the off-diagonal 16x16 sub-tiles (Ld) and the 16x16 inverses (Winv) the chain task of this column published
+    ll_wait_cols(fk, nullptr, fr, k, k + 1, ctl, Y.status);
+    const double* Ldk = Y.Ld + (size_t)k * NB * NB;
+    const double* Wk = Y.Winv + (size_t)k * 1024;
+    double wi[4][4], lt[6][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) wi[b][s4] = Wk[(size_t)b * 256 + (4 * s4 + lk) * 16 + lr];                 // (L_bb^-1)[lr][4 s4 + lk]
+#pragma unroll
+    for (int I = 1; I < 4; ++I)
+#pragma unroll
+      for (int J = 0; J < I; ++J)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) lt[oidx(I, J)][s4] = Ldk[(size_t)(16 * J + lk + 4 * s4) * NB + 16 * I + lr];   // L[16 I + lr][16 J + lk + 4 s4]
+    double* tcol = S + (size_t)(k * NB) * ld + (size_t)it * NB + 16 * q + lr;
+    v4d xt[4];
+    v4d t = Tq[0];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      v4d x = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(wi[b][s4], t[s4], x);
+      xt[b] = x;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tcol[(size_t)(16 * b + lk + 4 * r) * ld] = x[r];
+      if (b < 3) {
+        v4d tn = Tq[b + 1];
+#pragma unroll
+        for (int c = 0; c <= b; ++c)
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) tn = mfma_f64(-lt[oidx(b + 1, c)][s4], xt[c][s4], tn);
+        t = tn;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  }
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_store(Y.flags + (size_t)k * fr + tk.it0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk.it1 >= 0) __hip_atomic_store(Y.flags + (size_t)k * fr + tk.it1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---- chain task: the diagonal block of column k and tile row it0 (step_type_a_impl behind a flag instead of a kernel boundary) ----
+template <int NPAN>
+__device__ __forceinline__ void ll_chain_task(const LLSys& Y, const LLTask& tk, ALds& L, int* ctl) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..7
+  const int lr = lane & 15, lk = lane >> 4;
+  const int k = tk.k, it = tk.it0, ld = Y.ld, fr = Y.frows;
+  double* S = Y.S;
+  double* Ld = Y.Ld + (size_t)k * NB * NB;
+  double* Winv = Y.Winv + (size_t)k * 1024;
+  const int* fk = Y.flags + k;
+  const int* fi = Y.flags + it;
+  const bool row_prev = tk.clo0 <= k - 1;        // tile (it, k-1) exists (else its contribution is zero)
+  if (tid == 0) L.it_done = 0;
+  if (tid < 4) { L.col_done[tid] = 0; L.d_ready[tid] = 0; }
+  if (tid == 4) L.w_done = 0;
+  const int kold = k - 1;                        // panels c < kold are summed left-looking before the pending panel k-1 arrives
+  if (wave < 4) {
+    // ---------------- factor waves: own sub-tile row of D ----------------
+    const double* dcol = S + (size_t)(k * NB) * ld + (size_t)k * NB + 16 * wave + lr;
+    v4d R[4];
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) R[J][r] = (J <= wave) ? dcol[(size_t)(16 * J + lk + 4 * r) * ld] : 0.0;
+    v4d Tq[4];
+    double tb[16];
+    if (wave == 1) ll_rows_load(S, ld, k, it, 0, lr, lk, Tq);
+    if (tk.clo_d < kold) {
+      ll_wait_cols(fk, nullptr, fr, tk.clo_d, kold, ctl, Y.status);
+      for (int c = tk.clo_d; c < kold; ++c) ll_diag_term(S, ld, k, wave, c, lr, lk, R);
+    }
+    if (wave == 1 && tk.clo0 < kold) {
+      ll_wait_cols(fi, nullptr, fr, tk.clo0, kold, ctl, Y.status);
+      for (int c = tk.clo0; c < kold; ++c) ll_rows_term(S, ld, k, it, 0, c, lr, lk, Tq);
+    }
+    if (NPAN > 0) {
+      ll_wait_cols(fk, (wave == 1 && row_prev) ? fi : nullptr, fr, k - 1, k, ctl, Y.status);
+      constexpr int NC = 8;
+      const double* pq = S + (size_t)((k - 1) * NB + NC * wave) * ld + (size_t)k * NB + lane;
+      double stage[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) stage[c] = pq[(size_t)c * ld];
+      if (wave == 1) {
+        const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)it * NB + lr;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) tb[ks] = row_prev ? pi[(size_t)(4 * ks + lk) * ld] : 0.0;
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) L.Pk[NC * wave + c][lane] = stage[c];
+    }
+    __syncthreads();
+    if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);   // ahead of the panel wave sharing the SIMD
+    if (wave == 0) {
+      a_chain_wave<NPAN>(0, Y.status, L, lane, R[0]);
+    } else if (wave == 1) {
+      v4d R1[2] = {R[0], R[1]};
+      a_worker_wave<1, NPAN>(0, Ld, Winv, L, lane, R1);
+      panel_rows<NPAN, false>(S, ld, k, it, 0, 0, lane, L, Tq, tb, nullptr);
+    } else if (wave == 2) {
+      v4d R2[3] = {R[0], R[1], R[2]};
+      a_worker_wave<2, NPAN>(0, Ld, Winv, L, lane, R2);
+    } else {
+      a_worker_wave<3, NPAN>(0, Ld, Winv, L, lane, R);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+  } else {
+    // ---------------- panel waves 5..7: rows 16..63 of tile (it, k) (rows 0..15: worker 1 after its hand-off; wave 4 idles so that
+    // the chain wave has its SIMD to itself) ----------------
+    const int q = wave - 4;
+    const bool rows = q > 0;
+    v4d Tq[4];
+    double tb[16];
+    if (rows) {
+      ll_rows_load(S, ld, k, it, q, lr, lk, Tq);
+      if (tk.clo0 < kold) {
+        ll_wait_cols(fk, fi, fr, tk.clo0, kold, ctl, Y.status);
+        for (int c = tk.clo0; c < kold; ++c) ll_rows_term(S, ld, k, it, q, c, lr, lk, Tq);
+      }
+    }
+    if (NPAN > 0) {
+      ll_wait_cols(fk, (rows && row_prev) ? fi : nullptr, fr, k - 1, k, ctl, Y.status);
+      constexpr int NC = 8;
+      const double* pq = S + (size_t)((k - 1) * NB + NC * wave) * ld + (size_t)k * NB + lane;
+      double stage[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) stage[c] = pq[(size_t)c * ld];
+      if (rows) {
+        const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)it * NB + 16 * q + lr;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) tb[ks] = row_prev ? pi[(size_t)(4 * ks + lk) * ld] : 0.0;
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) L.Pk[NC * wave + c][lane] = stage[c];
+    }
+    __syncthreads();
+    if (rows) panel_rows<NPAN, true>(S, ld, k, it, q, wave - 4, lane, L, Tq, tb, nullptr);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+  }
+  if (tid == 0) {
+    __hip_atomic_store(Y.flags + (size_t)k * fr + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(Y.flags + (size_t)k * fr + it, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ctl[0]: ticket counter, ctl[1]: abort word (both cleared with the flags before the launch)
+__global__ __launch_bounds__(512) void k_chol_ll(const LLSys* __restrict__ sysv, const LLTask* __restrict__ tasks, int n_tasks, int* ctl) {
+  __shared__ ALds L;
+  __shared__ int s_t;
+  if (threadIdx.x == 0) s_t = atomicAdd(&ctl[0], 1);
+  __syncthreads();
+  const int t = __builtin_amdgcn_readfirstlane(s_t);
+  if (t >= n_tasks) return;
+  const LLTask tk = tasks[t];
+  const LLSys Y = sysv[tk.sys];
+  if (tk.kind == 0) {
+    if (tk.clo_d <= tk.k - 1) ll_chain_task<1>(Y, tk, L, ctl);
+    else ll_chain_task<0>(Y, tk, L, ctl);
+  } else {
+    ll_tile_task(Y, tk, ctl);
   }
 }
 
@@ -1746,6 +2033,116 @@ void launch_chol_solve_bwd(const CholSystem& cs, hipStream_t s) {
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp,
                          int* status, const int* prof, hipStream_t s) {
   hipLaunchKernelGGL(k_chol_bwd_chain, dim3(T), dim3(CHAIN_THREADS), 0, s, S, ld, T, Ld, Winv, yv, dp, status, prof);
+}
+
+// ---- plan and launch of the left-looking persistent factorisation (k_chol_ll) ------------------------------------------------------
+// Task table of n systems, in ticket order: block column by block column over all systems (every system's chain task of column k, then
+// every system's tile tasks of column k) — a topological order of the dependence graph that lets all systems advance side by side.
+// Rows of column k of a system (plan_step / step_type_a): the band's tile rows k+1 .. prof[k], the border rows active at k (first
+// column <= k; the j-th active row of a view is tile row B0 + ord[j]), the right-hand-side row B0 + nbr.  Pending columns of a tile
+// (i, k): those c < k in which both L(i, c) and L(k, c) are structurally non-zero — from first[k] (the first column whose profile
+// reaches row k) resp. first[i] / the border row's first column on.
+struct CholLLPlan {
+  LLSys* d_sys = nullptr; LLTask* d_tasks = nullptr; int* d_ints = nullptr;
+  int n_sys = 0, n_tasks = 0, n_ints = 0, n_chain = 0, max_cols = 0;
+};
+CholLLPlan* chol_ll_plan_create(const CholSystem* d, int n, const int* const* h_ord) {
+  std::vector<LLSys> sys(n);
+  std::vector<std::vector<int>> first(n), bf(n), bphys(n), profv(n);
+  size_t n_ints = 16;                                   // [0] ticket counter, [1] abort word; flags from 16 on
+  int Tmax = 0;
+  for (int i = 0; i < n; ++i) {
+    const CholSystem& c = d[i];
+    LLSys& y = sys[i];
+    y.S = c.S; y.Ld = c.Ld; y.Winv = c.Winv; y.status = c.status; y.ld = c.ld; y.T = c.T; y.B0 = c.b0 > 0 ? c.b0 : c.T; y.nbr = c.nbr;
+    y.frows = y.B0 + y.nbr + 1;
+    y.flags = reinterpret_cast<int*>(n_ints);           // offset for now: the pool is allocated below
+    n_ints += (size_t)y.T * y.frows;
+    Tmax = c.T > Tmax ? c.T : Tmax;
+    profv[i].resize(c.T);
+    for (int k = 0; k < c.T; ++k) profv[i][k] = c.h_prof ? std::min(c.h_prof[k], c.T - 1) : c.T - 1;
+    first[i].assign(c.T, 0);
+    for (int r = 0, col = 0; r < c.T; ++r) {            // first[r] = min { col : prof[col] >= r } (prof monotone, prof[col] >= col)
+      while (col < r && profv[i][col] < r) ++col;
+      first[i][r] = col;
+    }
+    // border rows in the order in which they become active: (first column in the view's numbering, physical tile row)
+    for (int j = 0; j < c.nbr; ++j) {
+      long long f = c.h_bfirst ? (long long)c.h_bfirst[j] - c.kofs : 0;
+      if (c.h_bfirst && j > 0 && c.h_bfirst[j] < c.h_bfirst[j - 1]) f = (long long)1 << 40;      // (not sorted: plan_step's count stops here too)
+      if (f >= c.T) break;                              // this row and all later ones are all-zero in this system
+      bf[i].push_back(f < 0 ? 0 : (int)f);
+      bphys[i].push_back(y.B0 + ((h_ord && h_ord[i]) ? h_ord[i][j] : j));
+    }
+  }
+  std::vector<LLTask> tasks;
+  int n_chain = 0;
+  for (int k = 0; k < Tmax; ++k) {
+    for (int pass = 0; pass < 2; ++pass)
+      for (int i = 0; i < n; ++i) {
+        const LLSys& y = sys[i];
+        if (k >= y.T) continue;
+        const int fk = first[i][k];
+        std::vector<std::pair<int, int>> rows;            // (physical tile row, first pending column)
+        for (int r = k + 1; r <= profv[i][k]; ++r) rows.emplace_back(r, std::max(first[i][r], fk));
+        for (size_t j = 0; j < bf[i].size() && bf[i][j] <= k; ++j) rows.emplace_back(bphys[i][j], std::max(bf[i][j], fk));
+        rows.emplace_back(y.B0 + y.nbr, fk);
+        if (pass == 0) {
+          tasks.push_back(LLTask{i, k, 0, rows[0].first, -1, fk, rows[0].second, k});
+          ++n_chain;
+        } else {
+          for (size_t r = 1; r < rows.size(); r += 2) {
+            const bool two = r + 1 < rows.size();
+            tasks.push_back(LLTask{i, k, 1, rows[r].first, two ? rows[r + 1].first : -1, fk, rows[r].second, two ? rows[r + 1].second : k});
+          }
+        }
+      }
+  }
+  CholLLPlan* p = new CholLLPlan();
+  p->n_sys = n; p->n_tasks = (int)tasks.size(); p->n_ints = (int)n_ints; p->n_chain = n_chain; p->max_cols = Tmax;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&p->d_ints), n_ints * sizeof(int)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&p->d_sys), std::max<size_t>(1, sys.size()) * sizeof(LLSys)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&p->d_tasks), std::max<size_t>(1, tasks.size()) * sizeof(LLTask)) == hipSuccess;
+  if (ok) {
+    for (LLSys& y : sys) y.flags = p->d_ints + reinterpret_cast<size_t>(y.flags);
+    ok = hipMemcpy(p->d_sys, sys.data(), sys.size() * sizeof(LLSys), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(p->d_tasks, tasks.data(), tasks.size() * sizeof(LLTask), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemset(p->d_ints, 0, n_ints * sizeof(int)) == hipSuccess;
+  }
+  if (!ok) { chol_ll_plan_destroy(p); return nullptr; }
+  return p;
+}
+void chol_ll_plan_destroy(CholLLPlan* p) {
+  if (!p) return;
+  if (p->d_ints) (void)hipFree(p->d_ints);
+  if (p->d_sys) (void)hipFree(p->d_sys);
+  if (p->d_tasks) (void)hipFree(p->d_tasks);
+  delete p;
+}
+int chol_ll_plan_tasks(const CholLLPlan* p) { return p ? p->n_tasks : 0; }
+int chol_ll_plan_columns(const CholLLPlan* p) { return p ? p->max_cols : 0; }
+__global__ void k_ll_clear(int* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+// the factorisations of the plan's systems (the steps of launch_chol_batch(.., solve = false) in ONE launch) + the extraction of y
+void launch_chol_ll(const CholLLPlan* p, const CholSystem* d, int n, hipStream_t s) {
+  if (!p || p->n_tasks <= 0) return;
+  hipLaunchKernelGGL(k_ll_clear, dim3((p->n_ints + 255) / 256), dim3(256), 0, s, p->d_ints, p->n_ints);
+  hipLaunchKernelGGL(k_chol_ll, dim3((unsigned)p->n_tasks), dim3(512), 0, s, p->d_sys, p->d_tasks, p->n_tasks, p->d_ints);
+  int Tmax = 0;
+  for (int lo = 0; lo < n; lo += CHOL_STEP_BATCH_MAX) {
+    ExtractArgs E{};
+    E.n = std::min(n - lo, CHOL_STEP_BATCH_MAX);
+    Tmax = 0;
+    for (int i = 0; i < E.n; ++i) {
+      const CholSystem& c = d[lo + i];
+      E.S[i] = c.S; E.ld[i] = c.ld; E.T[i] = c.T; E.Tr[i] = (c.b0 > 0 ? c.b0 : c.T) + c.nbr;
+      E.yv[i] = c.yv; E.dp[i] = c.dp; E.status[i] = c.status;
+      Tmax = c.T > Tmax ? c.T : Tmax;
+    }
+    if (Tmax > 0) hipLaunchKernelGGL(k_chol_extract_y_b, dim3((Tmax * NB + 255) / 256, E.n), dim3(256), 0, s, E);
+  }
 }
 
 int chol_factor_solve(double* S, int ld, int T, double* Ld, double* Winv, double* yv, double* dp, int* status, int* ctr, hipStream_t s) {

@@ -97,8 +97,13 @@ HostGraph::~HostGraph() {
 }
 int HostGraph::init() {
   if (P.device >= 0) SL_HIP(hipSetDevice(P.device));
-  SL_HIP(hipStreamCreate(&stream));
-  SL_HIP(hipStreamCreate(&stream2));
+  // SLIDE_NONBLOCKING_STREAMS=1: the graph's own streams do not synchronise with the legacy (null) stream.  Needed when several host
+  // threads drive graphs of ONE process side by side (the ranks-as-threads rehearsal of a multi-rank job): a thread-local stream capture
+  // on a blocking stream makes every legacy-stream call of any other thread (a synchronous hipMemcpy, a torch kernel) fail with
+  // "operation would make the legacy stream depend on a capturing blocking stream".
+  static const bool nonblocking = getenv("SLIDE_NONBLOCKING_STREAMS") && getenv("SLIDE_NONBLOCKING_STREAMS")[0] == '1';
+  SL_HIP(hipStreamCreateWithFlags(&stream, nonblocking ? hipStreamNonBlocking : hipStreamDefault));
+  SL_HIP(hipStreamCreateWithFlags(&stream2, nonblocking ? hipStreamNonBlocking : hipStreamDefault));
   init_solver_kernels();
   if (d_status.ensure(8, 0, stream, true) != SLIDE_OK) return SLIDE_ERR_HIP;
   return SLIDE_OK;
@@ -380,6 +385,7 @@ static CholSystem chol_system_of(const GraphDev& G, bool joint, float* L32, cons
   c.h_bfirst = (G.arrow && G.nbr > 0) ? h_bfirst : nullptr;
   return c;
 }
+static bool chol_ll_enabled();
 CholBatch::CholBatch(int n_) : n(n_ < 1 ? 1 : (n_ > 8 ? 8 : n_)), sys(n), ev_in(n, nullptr), bufs(n, nullptr), graphs(n, nullptr) {}
 void CholBatch::set_graph(int slot, HostGraph* g) {
   std::lock_guard<std::mutex> lk(mtx);
@@ -416,6 +422,7 @@ CholBatch::~CholBatch() {
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (pass_exec) (void)hipGraphExecDestroy(pass_exec);
   free_separator();
+  free_ll_band_plans();
   if (d_ctr2) (void)hipFree(d_ctr2);
   if (d_syrk_jobs) (void)hipFree(d_syrk_jobs);
   if (d_l2_jobs) (void)hipFree(d_l2_jobs);
@@ -520,12 +527,13 @@ int CholBatch::prepare_pass() {
   // exact joint passes: the systems the steps run on — every graph's segments (views of its S; the whole band when it is not cut) — and
   // the second-level systems of the graphs that are cut (the separator poses' block inside the border block, the rest of the border
   // as its border)
-  seg_sys.clear(); l2_sys.clear(); l2_graph.clear();
+  seg_sys.clear(); l2_sys.clear(); l2_graph.clear(); seg_hord.clear();
+  free_ll_band_plans();
   if (arrow && hG[0].n_slots > 0) {
     for (int i = 0; i < n; ++i) {
       HostGraph* g = graphs[i];
       const GraphDev& G = hG[i];
-      if (G.nsep <= 0 || g->segs.empty()) { seg_sys.push_back(sys[i]); continue; }
+      if (G.nsep <= 0 || g->segs.empty()) { seg_sys.push_back(sys[i]); seg_hord.push_back(nullptr); continue; }
       for (size_t k = 0; k < g->segs.size(); ++k) {
         const HostGraph::Seg sg = g->segs[k];
         CholSystem c = sys[i];
@@ -536,11 +544,14 @@ int CholBatch::prepare_pass() {
         c.h_prof = g->seg_prof[k].data(); c.prof = g->d_seg_prof.d + g->seg_prof_off[k]; c.first = nullptr;
         c.b0 = G.T - sg.t0; c.kofs = sg.t0;
         c.L32 = nullptr; c.ctab = nullptr;
+        const int* hord = nullptr;
         if (k < g->seg_ord.size() && !getenv("SLIDE_SEG_PLAIN")) {      // the segment's own set and order of active border rows
           c.h_bfirst = g->seg_sfirst[k].data();
           c.ord = g->d_seg_ord.d + k * (size_t)G.nbr;
+          hord = g->seg_ord[k].data();
         }
         seg_sys.push_back(c);
+        seg_hord.push_back(hord);
       }
       if (!g->seg_tab.empty() && !getenv("SLIDE_SEG_PLAIN")) sys[i].segtab = g->d_seg_tab.d;      // (the border product sums per segment)
       CholSystem l2{};
@@ -636,12 +647,52 @@ int CholBatch::prepare_pass() {
       SL_HIP(hipMemset(d_ctr2, 0, 64 * sizeof(int)));
     }
     if ((int)seg_sys.size() > 8 * CHOL_BATCH_HOST_MAX || (int)l2_sys.size() > CHOL_BATCH_HOST_MAX) { g_last_error = "exact joint step: too many segment systems"; return SLIDE_ERR_CAPACITY; }
+    if (chol_ll_enabled()) {
+      SL_HIP(hipStreamSynchronize(master));
+      ll_seg = chol_ll_plan_create(seg_sys.data(), (int)seg_sys.size(), seg_hord.data());
+      if (!l2_sys.empty()) ll_l2 = chol_ll_plan_create(l2_sys.data(), (int)l2_sys.size());
+      if (!ll_seg || (!l2_sys.empty() && !ll_l2)) { g_last_error = "exact joint step: the left-looking factorisation's tables could not be allocated"; return SLIDE_ERR_HIP; }
+    }
     return prepare_separator();
   }
   return SLIDE_OK;
 }
 // ---- exact joint step: the separator system of all shared landmarks -------------------------------------------------------------------
+static bool chol_ll_enabled() {
+  static const bool on = getenv("SLIDE_CHOL_LL") && getenv("SLIDE_CHOL_LL")[0] == '1';      // (opt-in until validated on the GPU)
+  return on;
+}
+void CholBatch::free_ll_band_plans() {
+  for (CholLLPlan** p : {&ll_seg, &ll_l2}) if (*p) { if (master) (void)hipStreamSynchronize(master); chol_ll_plan_destroy(*p); *p = nullptr; }
+}
+void CholBatch::free_ll_sep_plans() {
+  for (CholLLPlan** p : {&ll_leaves, &ll_leaf_own[0], &ll_leaf_own[1], &ll_top}) if (*p) { if (master) (void)hipStreamSynchronize(master); chol_ll_plan_destroy(*p); *p = nullptr; }
+}
+void CholBatch::sep_leaf_systems(CholSystem* lv) const {
+  const int ld_s = (sep_Ts + sep_nl + 1) * NB;
+  const int sTa = sep_leafT[0], sTL = sTa + sep_leafT[1], sTt = sep_Ts - sTL;
+  for (int b = 0; b < 2; ++b) {
+    const int t0 = b ? sTa : 0;
+    CholSystem c{};
+    c.S = sepS + (size_t)t0 * NB * ld_s + (size_t)t0 * NB; c.ld = ld_s; c.T = sep_leafT[b];
+    c.Ld = sep_Ld + (size_t)t0 * NB * NB; c.Winv = sep_Winv + (size_t)t0 * 1024; c.yv = sep_yv + (size_t)t0 * NB; c.dp = sep_dp + (size_t)t0 * NB;
+    c.status = sep_status; c.h_prof = h_leaf_prof[b].data(); c.prof = d_leaf_prof + (b ? sTa : 0);
+    c.nbr = sTt + sep_nl; c.b0 = sTL - t0; c.kofs = t0;
+    lv[b] = c;
+  }
+}
+CholSystem CholBatch::sep_top_system() const {
+  const int ld_s = (sep_Ts + sep_nl + 1) * NB;
+  const int TL = sep_dissected() ? sep_leafT[0] + sep_leafT[1] : 0;
+  CholSystem c{};
+  c.S = sepS + (size_t)TL * NB * ld_s + (size_t)TL * NB; c.ld = ld_s; c.T = sep_Ts - TL;
+  c.Ld = sep_Ld + (size_t)TL * NB * NB; c.Winv = sep_Winv + (size_t)TL * 1024; c.yv = sep_yv + (size_t)TL * NB; c.dp = sep_dp + (size_t)TL * NB;
+  c.status = sep_status; c.nbr = sep_nl;
+  if (!sep_dissected() && sep_prof_on) c.h_prof = h_sep_prof.data();
+  return c;
+}
 void CholBatch::free_separator() {
+  free_ll_sep_plans();
   if (sepS) (void)hipFree(sepS);
   sepS = nullptr; sep_len = 0;
   for (double** p : {&sep_Ld, &sep_Winv, &sep_yv, &sep_dp, &sep_bord, &lamS, &lam_Ld, &lam_Winv, &lam_yv, &lam_dp, &lam_scratch}) if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -841,6 +892,21 @@ int CholBatch::prepare_separator() {
   if (d_sep_off) { SL_HIP(hipFree(d_sep_off)); d_sep_off = nullptr; }
   SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_off), off.size() * sizeof(int)));
   SL_HIP(hipMemcpy(d_sep_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+  free_ll_sep_plans();
+  if (chol_ll_enabled() && sep_Ts > 0) {
+    const CholSystem top = sep_top_system();
+    ll_top = chol_ll_plan_create(&top, 1);
+    bool ok = ll_top != nullptr;
+    if (sep_dissected()) {
+      CholSystem lv[2];
+      sep_leaf_systems(lv);
+      ll_leaves = chol_ll_plan_create(lv, 2);
+      ll_leaf_own[0] = chol_ll_plan_create(&lv[0], 1);
+      ll_leaf_own[1] = chol_ll_plan_create(&lv[1], 1);
+      ok = ok && ll_leaves && ll_leaf_own[0] && ll_leaf_own[1];
+    }
+    if (!ok) { g_last_error = "exact joint step: the left-looking factorisation's tables could not be allocated"; return SLIDE_ERR_HIP; }
+  }
   return SLIDE_OK;
 }
 // One exact joint Gauss-Newton pass of all joined graphs.  part -1: the whole pass; 0: up to this GPU's partial sum of the separator
@@ -877,16 +943,7 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
   // (dissected separator) the two leaf blocks as systems of their own: views of sepS, the top block's and the lambdas' rows as border
   CholSystem lv[2];
   const int sTa = sep_leafT[0], sTL = sTa + sep_leafT[1], sTt = sep_Ts - sTL;
-  if (sep_dissected())
-    for (int b = 0; b < 2; ++b) {
-      const int t0 = b ? sTa : 0;
-      CholSystem c{};
-      c.S = sepS + (size_t)t0 * NB * ld_s + (size_t)t0 * NB; c.ld = ld_s; c.T = sep_leafT[b];
-      c.Ld = sep_Ld + (size_t)t0 * NB * NB; c.Winv = sep_Winv + (size_t)t0 * 1024; c.yv = sep_yv + (size_t)t0 * NB; c.dp = sep_dp + (size_t)t0 * NB;
-      c.status = sep_status; c.h_prof = h_leaf_prof[b].data(); c.prof = d_leaf_prof + (b ? sTa : 0);
-      c.nbr = sTt + sep_nl; c.b0 = sTL - t0; c.kofs = t0;
-      lv[b] = c;
-    }
+  if (sep_dissected()) sep_leaf_systems(lv);
   // a rank that owns a leaf (set_separator_owner; cut passes only): part 1 between the exchanges
   const bool owned = !whole && sep_dissected() && sep_owner >= 0;
   const int own = owned ? sep_owner : 0, own_t0 = own ? sTa : 0, own_T = sep_leafT[own];
@@ -897,7 +954,8 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     if (!owned) return SLIDE_OK;
     if (sep_leader) launch_sep_unpack(Y, master, sTL, sep_Ts + sep_nl);      // this rank's own partial sum of the top block (and the lambdas')
     launch_sep_unpack(Y, master, own_t0, own_t0 + own_T);                      // the leaf, summed over the ranks of this half
-    launch_chol_batch(&lv[own], 1, sep_ctr2, master, nullptr, false);
+    if (ll_leaf_own[own]) launch_chol_ll(ll_leaf_own[own], &lv[own], 1, master);
+    else launch_chol_batch(&lv[own], 1, sep_ctr2, master, nullptr, false);
     if (sep_leader) {
       launch_border_syrk_jobs(&top, 1, d_sep_jobs, n_sep_jobs, 0, master, sep_scratch, sep_ks, sTt);
       if (sep_nl > 0) {
@@ -923,15 +981,22 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     }
     if (e0) (void)hipEventRecord(e0, master);
     mark(0);
-    const int rc = factor_all(e1);                                   // the segments' steps: W^T and y in the border rows
-    if (rc != SLIDE_OK) return rc;
+    if (ll_seg) {                                                    // the segments' factorisations: W^T and y in the border rows
+      launch_chol_ll(ll_seg, seg_sys.data(), (int)seg_sys.size(), master);
+      last_groups = 1;
+      if (e1) (void)hipEventRecord(e1, master);
+    } else {
+      const int rc = factor_all(e1);
+      if (rc != SLIDE_OK) return rc;
+    }
     mark(1);
     if (n_syrk_jobs > 0) launch_border_syrk_jobs(sys.data(), n, d_syrk_jobs, n_syrk_jobs, syrk_lds_pad, master);      // border blocks: C_a - W^T W, b_s - W^T y
     else launch_border_syrk(sys.data(), n, master);
     mark(6);
     if (!l2_sys.empty()) {
       // second level: the separator poses' own system (dense, nsep block columns) with the rest of the border as its border
-      launch_chol_batch(l2_sys.data(), (int)l2_sys.size(), d_ctr2, master, nullptr, false);
+      if (ll_l2) launch_chol_ll(ll_l2, l2_sys.data(), (int)l2_sys.size(), master);
+      else launch_chol_batch(l2_sys.data(), (int)l2_sys.size(), d_ctr2, master, nullptr, false);
       if (n_l2_jobs > 0) launch_border_syrk_jobs(l2_sys.data(), (int)l2_sys.size(), d_l2_jobs, n_l2_jobs, 0, master);
       else launch_border_syrk(l2_sys.data(), (int)l2_sys.size(), master);
     }
@@ -948,13 +1013,22 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
       // the leaves side by side (no robot couples them); the top block's Schur complement; the top block's own steps
       const int TL = sTL, Tt = sTt;
       if (!owned) {
-        launch_chol_batch(lv, 2, sep_ctr2, master, nullptr, false);
+        if (ll_leaves) launch_chol_ll(ll_leaves, lv, 2, master);
+        else launch_chol_batch(lv, 2, sep_ctr2, master, nullptr, false);
         launch_border_syrk_jobs(&top, 1, d_sep_jobs, n_sep_jobs, 0, master, sep_scratch, sep_ks, Tt);
       }
-      double* St = sepS + (size_t)TL * NB * ld_s + (size_t)TL * NB;
-      for (int k = 0; k < Tt; ++k)
-        launch_chol_step(St, ld_s, k, Tt, sep_Ld + (size_t)(TL + k) * NB * NB, sep_Winv + (size_t)(TL + k) * 1024, sep_status, sep_ctr, nullptr, nullptr, master, sep_nl);
-      launch_chol_extract_y(St, ld_s, Tt, sep_yv + (size_t)TL * NB, sep_dp + (size_t)TL * NB, sep_status, master, sep_nl);
+      if (ll_top) {
+        const CholSystem ts = sep_top_system();
+        launch_chol_ll(ll_top, &ts, 1, master);
+      } else {
+        double* St = sepS + (size_t)TL * NB * ld_s + (size_t)TL * NB;
+        for (int k = 0; k < Tt; ++k)
+          launch_chol_step(St, ld_s, k, Tt, sep_Ld + (size_t)(TL + k) * NB * NB, sep_Winv + (size_t)(TL + k) * 1024, sep_status, sep_ctr, nullptr, nullptr, master, sep_nl);
+        launch_chol_extract_y(St, ld_s, Tt, sep_yv + (size_t)TL * NB, sep_dp + (size_t)TL * NB, sep_status, master, sep_nl);
+      }
+    } else if (ll_top) {
+      const CholSystem ts = sep_top_system();
+      launch_chol_ll(ll_top, &ts, 1, master);
     } else {
       for (int k = 0; k < sep_Ts; ++k)
         launch_chol_step(sepS, ld_s, k, sep_Ts, sep_Ld + (size_t)k * NB * NB, sep_Winv + (size_t)k * 1024, sep_status, sep_ctr, nullptr,

@@ -206,6 +206,15 @@ class CholBatch {
   std::vector<CholSystem> seg_sys, l2_sys;          // the segments of all joined graphs as systems of their own (views); the second-level systems
   std::vector<int> l2_graph;                        // l2_sys[i] belongs to graphs[l2_graph[i]]
   int* d_ctr2 = nullptr;
+  // left-looking persistent factorisations (k_chol_ll): one launch per level instead of one per block column — the segments of all
+  // joined graphs, the bands' second level, the separator's leaves (both / the own one of a rank that owns a leaf), its top block.
+  // SLIDE_CHOL_LL=0: the step kernels, one launch per block column (round 3's path)
+  CholLLPlan *ll_seg = nullptr, *ll_l2 = nullptr, *ll_leaves = nullptr, *ll_leaf_own[2] = {nullptr, nullptr}, *ll_top = nullptr;
+  std::vector<const int*> seg_hord;                 // host copies of the segments' border-row orders (CholSystem::ord)
+  void free_ll_band_plans();
+  void free_ll_sep_plans();
+  void sep_leaf_systems(CholSystem* lv) const;      // the two leaf blocks of a dissected separator as systems (views of sepS)
+  CholSystem sep_top_system() const;                // its top block (the lambdas' rows as border)
   int* d_syrk_jobs = nullptr;                       // border product: (system << 20 | ib << 10 | jb) of every lower tile + right-hand-side row, longest sum first
   int n_syrk_jobs = 0, syrk_jobs_cap = 0, syrk_lds_pad = 0;
   int* d_l2_jobs = nullptr; int n_l2_jobs = 0, l2_jobs_cap = 0;      // the same for the border products of the bands' second level

@@ -77,6 +77,16 @@ struct CholSystem { double* S; int ld, T; double* Ld; double* Winv; double* yv; 
 constexpr int CHOL_STEP_BATCH_MAX = 32;      // systems per launch of the batched step kernel (the segments of eight robots' bands in one launch sequence)
 void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps = nullptr, bool solve = true, int cu_share = 100);            // up to 8 systems, one launch per block column; solve = false: steps + extraction of y only; cu_share: percent of the CUs this launch sequence may count on (sequences running side by side)
 void launch_chol_bwd_batch(const CholSystem* d, int n, hipStream_t s);       // yv -> dp of up to 8 factored systems (chained backward substitution)
+// Left-looking persistent factorisation (k_chol_ll): ALL block columns of the n systems in ONE launch, the kernel boundary per block
+// column replaced by flags between workgroups that start in ticket order.  The plan (task table, flags, device copies of the systems'
+// parameters) depends on the systems' pointers, profiles and border tables: rebuild it when any of them changes.  h_ord[i]: host copy of
+// d[i].ord (or null).  launch_chol_ll = the steps of launch_chol_batch(.., solve = false): factorisation + extraction of y.
+struct CholLLPlan;
+CholLLPlan* chol_ll_plan_create(const CholSystem* d, int n, const int* const* h_ord = nullptr);
+void chol_ll_plan_destroy(CholLLPlan* p);
+int chol_ll_plan_tasks(const CholLLPlan* p);
+int chol_ll_plan_columns(const CholLLPlan* p);
+void launch_chol_ll(const CholLLPlan* p, const CholSystem* d, int n, hipStream_t s);
 // Exact joint step (the border of the systems = the separator's coupling rows, W^T after the steps):
 void launch_border_syrk(const CholSystem* d, int n, hipStream_t s, double* scratch = nullptr, int ks = 1);          // bord(i, j) -= sum_c W^T(i, c) W^T(j, c)^T, i >= j, right-hand-side row included; scratch + ks: split K (one system)
 void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int njobs, int lds_pad, hipStream_t s, double* scratch = nullptr, int ks = 1, int jb_end = -1);      // the same, workgroups in the order of a job table (system << 20 | ib << 10 | jb), lds_pad bytes of idle LDS per workgroup (bounds the residency)

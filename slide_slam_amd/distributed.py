@@ -188,10 +188,14 @@ def separator_offsets(gid, n_global, tile=64, dissect=True, force_a=None):
     best = None
     if dissect and 3 <= R <= 16 and n > 0:
         masks = [sum(1 << r for r in w) for _, w in obs]
+        mk = np.array(masks, np.int64)
+        # (slots with the same observer set move together: the search works on the distinct sets' summed dimensions)
+        umask, inv = np.unique(mk, return_inverse=True)
+        udim = np.bincount(inv, weights=dims.astype(np.float64), minlength=len(umask)).astype(np.int64)
         forced = sum(1 << r for r in force_a) if force_a else 0
         for a_mask in ([forced] if forced else range(1, 1 << (R - 1))):           # robot R-1 always on the b side: every bipartition once
-            da = int(dims[[i for i in range(n) if masks[i] & ~a_mask == 0]].sum())
-            db = int(dims[[i for i in range(n) if masks[i] & a_mask == 0]].sum())
+            da = int(udim[(umask & ~a_mask) == 0].sum())
+            db = int(udim[(umask & a_mask) == 0].sum())
             if da == 0 or db == 0:
                 continue
             dt = total - da - db
@@ -377,6 +381,7 @@ class PassDriver:
         self.sep = None
         self._sep_segs = None
         self.sep_owner = None
+        self._half_group = None
         if self.arrow:
             self.pcg_iters = 0
             if device is None:
@@ -395,6 +400,19 @@ class PassDriver:
                 batch.set_separator_blocks(*(blocks if blocks is not None else (0, 0, 0, 0)))
                 batch.set_separator_owner(owner["leaf"] if owner else -1, owner["leader"] if owner else True)
                 self.sep_blocks = blocks
+            if self.arrow and world > 1 and base is not None:
+                # every rank must have taken the same layout decisions (per-rank SLIDE_SEP_OWNED / SLIDE_SEP_DISSECT settings would hang the
+                # job inside the first pass instead of failing here), and the halves' groups are created NOW, by every rank, in the same
+                # order (they used to be created lazily inside the first pass)
+                mine = (int(self.sep_dim), int(n_slots), tuple(int(v) for v in (getattr(self, "sep_blocks", None) or ())),
+                        None if self.sep_owner is None else (int(self.sep_owner["leaf"]), tuple(self.sep_owner["half_ranks"])))
+                seen = base.all_gather_object(mine)
+                lay = {(m[0], m[1], m[2], m[3] is None) for m in seen}
+                if len(lay) != 1:
+                    raise RuntimeError(f"exact joint step: the ranks disagree on the separator layout (dimension, slots, blocks, owned): {sorted(map(str, lay))}")
+                if self.sep_owner is not None and len(self.sep_owner["half_ranks"]) > 1:
+                    ga, gb = base.new_group(range(0, world // 2)), base.new_group(range(world // 2, world))
+                    self._half_group = ga if self.sep_owner["leaf"] == 0 else gb
             import os
             # nested dissection of the robots' own bands (slide_chol_batch_set_segments; every segment carries only the border rows that
             # are non-zero in it).  Measured on one MI355X: 8 robots x 625 poses 3.06 ms per pass uncut, 2.64 / 2.54 / 2.60 with
@@ -489,11 +507,6 @@ class PassDriver:
             nr = getattr(self, "n_relmeas", 0)
             Ta, Tb = self.sep_blocks[0], self.sep_blocks[1]
             self._sep_segs = [self.batch.sep_segment(self.sep_dim, nr, Ta, Tb, w) for w in range(3)]
-            self._half_group = None
-            if len(own["half_ranks"]) > 1:      # (both halves' groups are created by every rank, in the same order)
-                W = self.world
-                ga, gb = self.base.new_group(range(0, W // 2)), self.base.new_group(range(W // 2, W))
-                self._half_group = ga if own["leaf"] == 0 else gb
         def lap(key):      # (timed_cut_pass: a device synchronisation after every step)
             if times is not None:
                 import time
@@ -564,12 +577,19 @@ class PassDriver:
                 self.batch.pass_part(self.ptrs, 2)
         else:
             h = (lambda b: b.data_ptr()) if self.device is not None else (lambda b: b)
-            if getattr(self, "n_gslots", 0) and self.device is None:
-                self._ghost_refresh_host()
 
             def each(ph):
                 for sh, b in zip(self.shards, self.bufs):
                     sh.graph.dist_phase(ph, h(b))
+            if getattr(self, "n_gslots", 0):
+                if self.device is None:
+                    self._ghost_refresh_host()
+                else:
+                    # un-batched HIP shards: the same 20 | all-reduce of 12 doubles per ghost slot | 21 sequence through the shards'
+                    # exchange buffers (these passes used to linearise the relative-pose factors at the stale first ghosts)
+                    each(20)
+                    self._all(12 * self.n_gslots)
+                    each(21)
             each(0)
             if self.arrow:
                 m = self.sep_dim + getattr(self, "lam_dim", 0)
@@ -701,6 +721,104 @@ class TorchComm:
             ext = self._ext[stream_ptr] = self.torch.cuda.ExternalStream(stream_ptr, device=self.device)
         with self.torch.cuda.stream(ext):
             self.dist.all_reduce(buf[off:off + n], group=group)
+
+
+class LocalRanks:
+    """The ranks of a job as THREADS of one process (all on the process's GPU, or on the host): the TorchComm interface over barriers.
+    A rehearsal vehicle — the GPU boxes allow few processes on the card, so the 8-rank arrangement of BASELINE configs[3] (one robot
+    per rank, the halves of the job four ranks each) is driven as eight threads with one CholBatch each; collectives are sums in rank
+    order (deterministic), sub-groups as in torch.distributed.  comm(rank) is what a rank passes as `base`."""
+
+    def __init__(self, world, device=None, timeout=600.0):
+        import threading
+        self.world, self.device, self.timeout = world, device, timeout
+        self.lock = threading.Lock()
+        self.barriers = {}
+        self.slots = {}
+
+    def barrier_of(self, ranks):
+        import threading
+        with self.lock:
+            b = self.barriers.get(ranks)
+            if b is None:
+                b = self.barriers[ranks] = threading.Barrier(len(ranks))
+            return b
+
+    def comm(self, rank):
+        return LocalRankComm(self, rank)
+
+    def abort(self):
+        with self.lock:
+            for b in self.barriers.values():
+                b.abort()
+
+
+class LocalRankComm:
+    def __init__(self, job, rank):
+        self.job, self.rank, self.device = job, rank, job.device
+        self.all = tuple(range(job.world))
+        if self.device is not None:
+            import torch
+            self.torch = torch
+
+    def _sync(self):
+        if self.device is not None:
+            self.torch.cuda.synchronize()
+
+    def _rendezvous(self, ranks, item, reduce_fn):
+        """Every rank of `ranks` deposits `item`; the lowest rank runs reduce_fn(items in rank order); returns its result to all."""
+        job = self.job
+        bar = job.barrier_of(ranks)
+        key = (ranks, "in")
+        with job.lock:
+            job.slots.setdefault(key, {})[self.rank] = item
+        bar.wait(job.timeout)
+        if self.rank == ranks[0]:
+            with job.lock:
+                items = [job.slots[key][r] for r in ranks]
+            res = reduce_fn(items)
+            with job.lock:
+                job.slots[(ranks, "out")] = res
+        bar.wait(job.timeout)
+        with job.lock:
+            res = job.slots[(ranks, "out")]
+        bar.wait(job.timeout)       # (nobody deposits the next item before everybody has read this result)
+        return res
+
+    def all_gather_object(self, obj):
+        return self._rendezvous(self.all, obj, list)
+
+    def alloc(self, n):
+        if self.device is None:
+            return np.zeros(n)
+        return self.torch.zeros(n, dtype=self.torch.float64, device=self.device)
+
+    def handle(self, buf):
+        return buf if self.device is None else buf.data_ptr()
+
+    def new_group(self, ranks):
+        return tuple(ranks)
+
+    def all_reduce(self, buf, n, off=0, group=None):
+        if n == 0:
+            return
+        ranks = self.all if group is None else tuple(group)
+        if self.rank not in ranks:
+            return
+        self._sync()
+
+        def total(views):
+            tot = views[0].copy() if self.device is None else views[0].clone()
+            for v in views[1:]:
+                tot += v
+            for v in views:
+                v[:] = tot
+            self._sync()
+            return None
+        self._rendezvous(ranks, buf[off:off + n], total)
+
+    def all_reduce_on(self, buf, n, stream_ptr=None, off=0, group=None):
+        return self.all_reduce(buf, n, off, group)
 
 
 class ThreadGroup:

@@ -72,6 +72,9 @@ class SynthConfig:
         if name == "C4tiny":   # four robots on a 2 x 2 grid: CPU-test size for several robots per process x several processes
             return SynthConfig(name="C4tiny", robots=4, poses_per_robot=30, landmarks=200, grid=(2, 2), cell=30.0,
                                overlap=8.0)
+        if name == "C8tiny":   # eight robots on the 2 x 4 grid of C4 at CPU-test size, with inter-robot relative-pose measurements
+            return SynthConfig(name="C8tiny", robots=8, poses_per_robot=30, landmarks=400, grid=(2, 4), cell=30.0,
+                               overlap=8.0, relmeas_every=6)
         if name == "C4":       # configs[3]: 8 robots, 10 k landmarks, 5 k poses
             return SynthConfig(name="C4", robots=8, poses_per_robot=625, landmarks=10000, grid=(2, 4), cell=110.0,
                                overlap=15.0, **MULTI_ROBOT_NOISE)

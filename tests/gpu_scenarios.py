@@ -428,7 +428,68 @@ def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1, re
     json.dump(res, open(out, "w"))
 
 
+def rank_threads(out, preset="C4", world=8, passes=3, relmeas=0, mode="ingest"):
+    """BASELINE configs[3]'s own arrangement on the ONE visible GPU: `world` ranks of cfg.robots / world robots, every rank a thread
+    with its own CholBatch (LocalRanks: the TorchComm interface over barriers — the box allows few processes on the card), the pass cut
+    at its exchanges exactly as a multi-process job cuts it (rank-owned leaves of the separator, the half's all-reduce among its
+    ranks, one leader per half) — against ONE process holding all robots."""
+    os.environ["SLIDE_NONBLOCKING_STREAMS"] = "1"      # several host threads capture and copy side by side (HostGraph::init)
+    import torch
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)
+    import slide_slam_amd as s
+    from slide_slam_amd.distributed import PassDriver, gpu_matcher, setup_local_shards
+    from slide_slam_amd.replay import replay_single
+    from slide_slam_amd.synth import SynthConfig, make_relmeas, make_robot_log, make_world
+    from test_pass_driver import run_thread_ranks
+    cfg = SynthConfig.preset(preset)
+    wm = make_world(cfg)
+    R, P = cfg.robots, cfg.poses_per_robot
+    logs = [make_robot_log(cfg, wm, r) for r in range(R)]
+    rel = make_relmeas(cfg, logs) if relmeas else None
+
+    def build():
+        sh = [s.SlideBackend(s.default_params(), 1) for _ in range(R)]
+        for a, lg in zip(sh, logs):
+            if mode == "ingest":
+                ingest(a, lg, s.FRAME_FOREIGN)
+            else:
+                replay_single(a, lg, collect=False)
+        return sh
+    A, B = build(), build()
+    say("2 x", R, "shards built")
+    batch = s.CholBatch(R)
+    for t, a in enumerate(A):
+        a.graph.join_chol_batch(batch, t)
+    bufs, info = setup_local_shards(A, gpu_matcher, device=dev)
+    drv = PassDriver(A, bufs, info["n_slots"], batch=batch, device=dev, arrow=True, sep_dim=info["sep_dim"], sep_prof=info.get("sep_prof"))
+    if rel:
+        assert drv.setup_ghosts(rel) > 0
+    drv.gauss_newton(passes)
+    one = poses_of(A, P)
+    for a in A:
+        a.graph.join_chol_batch(None)
+    say("one process:", passes, "passes done;", info["n_slots"], "slots")
+    batches = []
+
+    def factory(mine):
+        b = s.CholBatch(len(mine))
+        for t, a in enumerate(mine):
+            a.graph.join_chol_batch(b, t)
+        batches.append(b)
+        return b
+    infos = run_thread_ranks(B, gpu_matcher, world, device=dev, passes=passes, relmeas=rel, batch_factory=factory)
+    many = poses_of(B, P)
+    for b in B:
+        b.graph.join_chol_batch(None)
+    relerr = float((np.linalg.norm((many - one).reshape(R, -1), axis=1) / np.linalg.norm(one.reshape(R, -1), axis=1)).max())
+    say(world, "thread ranks vs one process:", relerr, "owned:", [i["owned"] for i in infos])
+    json.dump(dict(rel=relerr, finite=bool(np.isfinite(many).all()), n_slots=[int(info["n_slots"])] + [int(i["n_slots"]) for i in infos],
+                   owned=[bool(i["owned"]) for i in infos], n_relmeas=len(rel) if rel else 0), open(out, "w"))
+
+
 if __name__ == "__main__":
-    fn = {"arrow_parity": arrow_parity, "c4_parity": c4_parity, "c3_joint": c3_joint, "c5_stream": c5_stream, "c3_converge": c3_converge, "c3_assoc_check": c3_assoc_check, "tiny_pcg": tiny_pcg}[sys.argv[1]]
+    fn = {"rank_threads": rank_threads, "arrow_parity": arrow_parity, "c4_parity": c4_parity, "c3_joint": c3_joint, "c5_stream": c5_stream, "c3_converge": c3_converge, "c3_assoc_check": c3_assoc_check, "tiny_pcg": tiny_pcg}[sys.argv[1]]
     extra = [int(a) if a.lstrip("-").isdigit() else a for a in sys.argv[3:]]
     fn(sys.argv[2], *extra)

@@ -228,6 +228,20 @@ def test_exact_joint_step_four_ranks_own_their_leaves(gpu, tmp_path):
     assert np.abs(z["poses"] - one).max() < 1e-6 * np.abs(one).max()
 
 
+@pytest.mark.parametrize("relmeas", [0, 1])
+def test_exact_joint_step_eight_ranks_of_one_robot(gpu, tmp_path, relmeas):
+    """configs[3] in the arrangement north_star names — EIGHT ranks, ONE robot each — on the one visible GPU: the ranks are threads
+    with a CholBatch each (LocalRanks; the box allows six processes on the card), the halves of the job are four ranks, so the own
+    leaf's segment is all-reduced among four before part 1 and one leader per half adds the leaf's Schur complement to the top block.
+    == one process holding all eight robots, with and without the inter-robot relative-pose factors."""
+    out = str(tmp_path / f"r8_{relmeas}.json")
+    _scenario("rank_threads", out, "C4", 8, 3, relmeas)
+    z = json.load(open(out))
+    assert z["finite"] and len(set(z["n_slots"])) == 1 and z["n_slots"][0] > 500 and all(z["owned"])
+    assert (z["n_relmeas"] > 0) == bool(relmeas)
+    assert z["rel"] < 1e-6, z["rel"]
+
+
 def test_exact_joint_step_two_ranks_rccl(gpu, tmp_path):
     """the multi-GPU path with MORE THAN ONE RCCL rank — configs[2] as two ranks on two GPUs (one robot each), the pass cut
     at its exchange, the all-reduce of the packed separator system over RCCL, host-synchronous AND stream-ordered on the pass's stream —

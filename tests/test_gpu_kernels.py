@@ -26,6 +26,31 @@ def test_dense_spd_solve(gpu, n):
     assert np.linalg.norm(x - ref) <= 1e-9 * np.linalg.norm(ref)
 
 
+@pytest.mark.parametrize("n", [6, 64, 65, 130, 200, 330, 1000, 1990, 3776])   # T = 1, 1, 2, 3, 4, 6, 16, 32, 59 block columns
+def test_dense_spd_solve_left_looking_persistent(gpu, n):
+    """The left-looking persistent factorisation (k_chol_ll: ONE launch for all block columns, chain and tile tasks started in ticket
+    order, flags + release / acquire fences between them instead of kernel boundaries) vs numpy AND vs the step kernels' result:
+    the same arithmetic per tile, only the order of the left-looking sums differs."""
+    rng = np.random.default_rng(n)
+    A = _spd(n, rng)
+    b = rng.normal(size=n)
+    x, _ = gpu.dense_spd_solve(A, b, method=1)
+    ref = np.linalg.solve(A, b)
+    assert np.linalg.norm(x - ref) <= 1e-9 * np.linalg.norm(ref)
+    x0, _ = gpu.dense_spd_solve(A, b, method=0)
+    assert np.linalg.norm(x - x0) <= 1e-10 * np.linalg.norm(ref)
+    # and again on the same buffers (the flags and the ticket counter are cleared per launch), timed
+    x2, ms = gpu.dense_spd_solve(A, b, repeats=3, method=1)
+    assert np.array_equal(x2, x), "the persistent factorisation is not deterministic"
+
+
+def test_dense_spd_solve_left_looking_rejects_indefinite(gpu):
+    A = np.eye(200)
+    A[140, 140] = -1.0
+    with pytest.raises(gpu.SlideError):
+        gpu.dense_spd_solve(A, np.ones(200), method=1)
+
+
 def test_dense_spd_solve_more_block_columns_than_cus(gpu):
     """T = 261 block columns: more workgroups in the chained backward substitution than the part has CUs (its waits are on
     workgroups of lower index only) and several rounds of type-A workgroups in the first step kernels; residual check."""

@@ -163,3 +163,61 @@ def test_exact_joint_step_with_relative_pose_factors_is_the_joint_replicas_step(
         cur = poses_of(shards, P)
         errs.append(float((np.linalg.norm((cur - joint).reshape(R, -1), axis=1) / np.linalg.norm(joint.reshape(R, -1), axis=1)).max()))
     assert errs[0] < 2e-4 and errs[2] < 1e-6 and max(errs[2:]) < 5e-6, errs
+
+
+def run_thread_ranks(shards, matcher, world, device=None, passes=3, relmeas=None, batch_factory=None):
+    """The job's shards as `world` ranks, each a THREAD with len(shards) / world shards (LocalRanks: the TorchComm interface over
+    barriers): setup_local_shards + PassDriver per rank, exactly as a rank of a multi-process job runs them."""
+    import threading
+    from slide_slam_amd.distributed import LocalRanks
+    per = len(shards) // world
+    job = LocalRanks(world, device=device, timeout=300.0)
+    infos, err = [None] * world, []
+
+    def rank_main(r):
+        try:
+            mine = shards[r * per:(r + 1) * per]
+            batch = batch_factory(mine) if batch_factory else None
+            base = job.comm(r)
+            bufs, info = setup_local_shards(mine, matcher, base=base, rank=r, world=world, device=device)
+            drv = PassDriver(mine, bufs, info["n_slots"], batch=batch, base=base, world=world, device=device, arrow=True,
+                             sep_dim=info["sep_dim"], sep_prof=info.get("sep_prof"))
+            if relmeas:
+                assert drv.setup_ghosts(relmeas, rank=r) > 0
+            drv.gauss_newton(passes)
+            info["owned"] = drv.sep_owner is not None
+            infos[r] = info
+        except BaseException as e:      # noqa: BLE001
+            err.append(e)
+            job.abort()
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    if err:
+        raise err[0]
+    return infos
+
+
+@pytest.mark.parametrize("with_relmeas", [False, True])
+def test_exact_joint_step_eight_ranks_of_one_robot_equal_one_process(with_relmeas):
+    """BASELINE configs[3]'s arrangement — EIGHT ranks, one robot each — at CPU-test size (C8tiny: the 2 x 4 grid of C4), the ranks as
+    threads over LocalRanks, oracle shards: the same poses as one process holding all eight (only the order of the exchange's sums
+    differs), with and without the inter-robot relative-pose factors (dozens of them: hundreds of lambda coordinates)."""
+    from slide_slam_amd.synth import make_relmeas
+    cfg, shards, logs = oracle_shards("C8tiny")
+    rel = make_relmeas(cfg, logs) if with_relmeas else None
+    assert not with_relmeas or len(rel) >= 20
+    bufs, info = setup_local_shards(shards, oracle_matcher)
+    drv = PassDriver(shards, bufs, info["n_slots"], arrow=True, sep_dim=info["sep_dim"], sep_prof=info.get("sep_prof"))
+    if rel:
+        drv.setup_ghosts(rel)
+    drv.gauss_newton(3)
+    one = poses_of(shards, cfg.poses_per_robot)
+    _, again, _ = oracle_shards("C8tiny")
+    infos = run_thread_ranks(again, oracle_matcher, 8, passes=3, relmeas=rel)
+    assert all(i["n_slots"] == info["n_slots"] > 0 and i["sep_dim"] == info["sep_dim"] for i in infos)
+    eight = poses_of(again, cfg.poses_per_robot)
+    assert np.isfinite(eight).all()
+    assert np.abs(eight - one).max() < 1e-9 * np.abs(one).max()
