@@ -46,6 +46,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak, public spec (MI355X_MI
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
+CHART = 0                      # --chart: 0 = SLIDE_CHART_CAYLEY (the default, what cubeFactor.h:96-97 names), 1 = SLIDE_CHART_EXPMAP; product and oracle alike
 DENSE_LEG = True               # roofline.dense_profile: the same kernels on the same graphs with the structure ignored
 DENSE_PROFILE = False          # --dense-profile: every graph of the run ignores the structure of its reduced system (profiling aid)
 
@@ -55,7 +56,7 @@ def build_shard(s, log, frames=None, ingest_only=False):
     ingest_only (profiling aid): add every frame without solving (association against the un-refined map at the ground-truth
     poses, as the cpu_baseline leg does), then one solve — every k_chol_step launch of the run is then full-size."""
     from slide_slam_amd.replay import replay_single
-    gb = s.SlideBackend(s.default_params(), 1)
+    gb = s.SlideBackend(s.default_params(pose_chart=CHART), 1)
     if DENSE_PROFILE:
         gb.graph.set_dense_profile(True)
     if not ingest_only:
@@ -79,7 +80,7 @@ def all_poses(gb, P):
 
 def _oracle_shard(L, po, log, frames, threads):
     from slide_slam_amd.synth import frame_detections
-    ob = po.OracleBackend(po.OrcParams.default(num_threads=threads), 1, L=L)
+    ob = po.OracleBackend(po.OrcParams.default(num_threads=threads, pose_chart=CHART), 1, L=L)
     P = len(log["rel7"]) if frames is None else frames
     for k in range(P):
         ob.process_frame(0, log["rel7"][k], log["gt7"][k], frame_detections(log, k), 2)
@@ -174,8 +175,8 @@ def cpu_exact_joint_leg(s, logs, frames, passes=3, relmeas=None):
     P = len(logs[0]["rel7"]) if frames is None else frames
     O, A = [], []
     for lg in logs:
-        o = po.OracleBackend(po.OrcParams.default(num_threads=ncpu), 1, L=L)
-        a = s.SlideBackend(s.default_params(), 1)
+        o = po.OracleBackend(po.OrcParams.default(num_threads=ncpu, pose_chart=CHART), 1, L=L)
+        a = s.SlideBackend(s.default_params(pose_chart=CHART), 1)
         for k in range(P):
             o.process_frame(0, lg["rel7"][k], lg["gt7"][k], frame_detections(lg, k), 2)
             a.process_frame(0, lg["rel7"][k], lg["gt7"][k], frame_detections(lg, k), s.FRAME_FOREIGN)
@@ -358,10 +359,14 @@ def main():
                          "iterations on the global reduced pose system per pass (inexact); jacobi = every robot's own block solve only")
     ap.add_argument("--no-relmeas", action="store_true",
                     help="leave out the inter-robot relative-pose factors (SURVEY 8d: one per robot pair within 60 m every 50 frames)")
+    ap.add_argument("--chart", choices=("cayley", "expmap"), default="cayley",
+                    help="Pose3 retraction chart of product AND oracle: cayley = GTSAM 4.0.3's default (cubeFactor.h:96-97), expmap = GTSAM_POSE3_EXPMAP builds")
+    ap.add_argument("--no-dense-relmeas", action="store_true", help="skip the leg with SURVEY 8d's relative-pose density (reported beside the headline)")
     ap.add_argument("--pcg", type=int, default=8, help="--joint pcg: PCG iterations per pass")
     ap.add_argument("--pcg-tol", type=float, default=0.0, help="--joint pcg: relative tolerance on sqrt(r^T M^-1 r) (0: every iteration counts)")
     args = ap.parse_args()
-    global DENSE_PROFILE, DENSE_LEG
+    global DENSE_PROFILE, DENSE_LEG, CHART
+    CHART = 1 if args.chart == "expmap" else 0
     DENSE_PROFILE = args.dense_profile
     DENSE_LEG = not (args.no_dense_leg or args.dense_profile)
 
@@ -585,6 +590,36 @@ def main():
             del ref_shards, rdrv, rbufs
     if multi and use_dist and world > 1 and drv.arrow and not args.no_parity:
         parity = n1_replica_parity(args, s, cfg, world_map, rank, world, device, dist, final, n_probe, n_passes, info)
+    if multi and drv.arrow and wdev == 1 and not drv.force_parts and not args.no_relmeas and args.frames is None and not args.no_dense_relmeas and robots == cfg.robots:
+        # ---- the same job with SURVEY 8d's relative-pose DENSITY (the timed headline carries the 2 factors the lock-step generator finds):
+        # identically built shards, one factor per adjacent robot pair every 50 frames near the other's trajectory ----
+        from slide_slam_amd.synth import make_relmeas_dense
+        rel2 = make_relmeas_dense(cfg, logs)
+        sh2, _, _ = build_all()
+        b2 = s.CholBatch(R)
+        for t, gb in enumerate(sh2):
+            gb.graph.join_chol_batch(b2, t)
+        bufs2, info2 = setup_local_shards(sh2, gpu_matcher, device=device)
+        d2 = PassDriver(sh2, bufs2, info2["n_slots"], batch=b2, device=device, arrow=True, sep_dim=info2["sep_dim"], sep_prof=info2.get("sep_prof"))
+        ng2 = d2.setup_ghosts(rel2)
+        for _ in range(5):
+            d2.one_pass()
+        barrier()
+        t2 = time.perf_counter()
+        nd2 = max(5, min(args.steps, 50))
+        for _ in range(nd2):
+            d2.one_pass()
+        barrier()
+        t2 = (time.perf_counter() - t2) / nd2
+        fin2 = bool(np.isfinite(np.stack([all_poses(gb, P) for gb in sh2])).all())
+        for gb in sh2:
+            gb.graph.join_chol_batch(None)
+        info["dense_relmeas"] = dict(n_relmeas=len(rel2), lambda_coordinates=6 * len(rel2), ghost_slots=int(ng2), ms_per_step=t2 * 1e3, finite=fin2,
+                                     what="the same job with one addRelativeMeasFactor (graph.cpp:247-258) per ADJACENT robot pair every 50 frames "
+                                          "while the observer is within 40 m of the other robot's trajectory, paired with that robot's spatially closest "
+                                          "pose (the reference pairs by time stamp, sloam.cpp:321-412: two different indices) — SURVEY 8d's density; "
+                                          "parity of this variant: tests/test_bench_config.py::test_c4_exact_joint_step_with_dense_relative_pose_factors_at_size")
+        del d2, b2, sh2, bufs2
     report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build, info, mode, batched_prof, parity, conv, finite, dist, T, dense_leg)
     if use_dist:
         dist.destroy_process_group()
@@ -793,6 +828,7 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
         "config": {"workload": f"{cfg.name} (BASELINE configs[3]): {robots} robot sub-graphs, {R} per GPU ({mode}) "
                                f"({st['n_pose']} poses, {st['n_lm']} landmarks, {st['n_factors']} factors in robot 0's); "
                                "a step = one Gauss-Newton pass of all of them, value = robot pose-graph updates/s; "
+                               f"Pose3 chart: {args.chart} (product and oracle; --chart, both charts are parity-tested: tests/test_golden.py, test_bench_config.py); "
                                f"graph totals of this rank's {R} robots: {info.get('totals')}; synthetic noise: odometry sigma per metre "
                                f"{tuple(cfg.sigma_odom)} [rot, trans], detection position {cfg.sigma_det_pos} m, cube yaw {cfg.sigma_cube_yaw} rad, "
                                f"scale {cfg.sigma_scale} (SURVEY 8d specifies 20x / 10x more: with it the cross-robot association finds 15 % of the "
@@ -853,6 +889,8 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
                                     "exact_joint_pass (border_product = the pass's FP64-MFMA GEMM)"}
     if info.get("cut_pass_ms"):
         res["cut_pass_ms"] = info["cut_pass_ms"]
+    if info.get("dense_relmeas"):
+        res["dense_relmeas"] = info["dense_relmeas"]
     if parity is not None:
         res["parity"] = parity
     if conv is not None:

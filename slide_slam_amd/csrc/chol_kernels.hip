@@ -738,6 +738,212 @@ struct LLSys { double* S; double* Ld; double* Winv; int* status; int* flags; int
 struct LLTask { int sys, k, kind, it0, it1, clo_d, clo0, clo1; };      // kind 0: chain task (tile row it0), 1: tile task (rows it0, it1 or -1)
 constexpr int LL_SPIN_MAX = 1 << 19;
 
+// Copies of a_worker_wave / panel_rows for the persistent kernel (the step kernels' own stay byte for byte what round 3 measured: their
+// code is sensitive to the compiler's scheduling).  The only difference: results other workgroups read inside the SAME launch — the
+// panel tile, Ld, Winv — are stored write-through at agent scope (global_store .. sc1), so that the release fence in front of the flag has
+// nothing left to write back (tools/tile_hop_bench.hip: 1.16 us for a tile's stores + fence against 1.44 us with plain stores, and the
+// stores of the early column blocks are long through by then).
+__device__ __forceinline__ void st_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int W, int NPAN>
+__device__ __forceinline__ void ll_worker_wave(int ia, double* __restrict__ Ld, double* __restrict__ Winv, ALds& L, int lane,
+                                              v4d (&R)[W + 1]) {
+  const int lr = lane & 15, lk = lane >> 4;
+  const v4d zero = v4d{0.0, 0.0, 0.0, 0.0};
+  if (NPAN > 0) {
+    // the whole sub-tile row before the first iteration, in the order of need: a worker answers an iteration of the
+    // chain wave in about 500 cycles but needs twice that with a quarter of a sub-tile update on top, so it is better
+    // late for the first iterations (it catches up well before its hand-off) than slow in all of them
+    // (a chain of dependent MFMAs fed from LDS runs at ~150 cycles per link: 2 (W + 1) independent chains, k-steps outermost)
+    v4d e[W + 1];
+#pragma unroll
+    for (int J = 0; J <= W; ++J) e[J] = zero;
+#pragma unroll
+    for (int ks = 0; ks < 16 * NPAN; ks += 2) {
+      const double w0 = L.Pk[4 * ks + lk][16 * W + lr], w1 = L.Pk[4 * ks + 4 + lk][16 * W + lr];
+#pragma unroll
+      for (int J = 0; J <= W; ++J) {
+        R[J] = mfma_f64(-L.Pk[4 * ks + lk][16 * J + lr], w0, R[J]);
+        e[J] = mfma_f64(-L.Pk[4 * ks + 4 + lk][16 * J + lr], w1, e[J]);
+      }
+    }
+#pragma unroll
+    for (int J = 0; J <= W; ++J) {
+      R[J] += e[J];
+      pin(R[J]);
+    }
+  }
+  v4d Wt = zero;                   // identity pseudo-tile (worker WT only)
+#pragma unroll
+  for (int JQ = 0; JQ < W; ++JQ) {
+    if (W == WT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Wt[r] = (lr == lk + 4 * r) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int n = 4 * JQ + s;
+      lds_wait(&L.it_done, n + 1);
+      const double mop = L.mop[n][lane], xm = L.xm[n][lane];
+      const double x = mfma_f64(mop, R[JQ][s], zero)[0];
+      double xw = 0.0;
+      if (W == WT) xw = mfma_f64(mop, Wt[s], zero)[0];
+      R[JQ][s] = x;
+      if (W == WT) Wt[s] = xw;
+      if (s < 3) {
+        R[JQ] = mfma_f64(-xm, x, R[JQ]);
+        if (W == WT) Wt = mfma_f64(-xm, xw, Wt);
+      }
+      // the rank-16 update of the diagonal sub-tile one k-step at a time: register s of (W, JQ) is final from here on
+      R[W] = mfma_f64(-R[JQ][s], R[JQ][s], R[W]);
+#pragma unroll
+      for (int J = 0; J <= W; ++J) pin(R[J]);
+      if (W == WT) pin(Wt);
+      if (JQ == W - 1 && s == 2) {
+        // hand-off of the own diagonal sub-tile one iteration early: everything but the last iteration's rank-4 update is in it, and
+        // register 3 of (W, JQ) as it stands goes along — the chain wave finishes both itself (a_chain_wave)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) L.Dh[W - 1][r][lane] = R[W][r];
+        L.Dh3[W - 1][lane] = R[JQ][3];
+        lds_post(&L.d_ready[W], 1, lane);
+      }
+    }
+    // column block JQ of row W is final
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      L.Lt[oidx(W, JQ)][r][lane] = R[JQ][r];
+      st_wt(&Ld[(size_t)(16 * JQ + lk + 4 * r) * NB + 16 * W + lr], R[JQ][r]);
+    }
+    lds_post(&L.col_done[W], JQ + 1, lane);
+    // rank-16 updates of the other sub-tiles right of this phase
+#pragma unroll
+    for (int J = JQ + 1; J < W; ++J) {
+      lds_wait(&L.col_done[J], JQ + 1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) R[J] = mfma_f64(-L.Lt[oidx(J, JQ)][ks][lane], R[JQ][ks], R[J]);
+    }
+    if (W == WT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double v = (lk + 4 * r >= lr) ? Wt[r] : 0.0;      // Wt lane (lr, lk) reg r = (L_JQ,JQ^-1)[lk + 4r][lr]
+        L.Wi[JQ][lr * 16 + lk + 4 * r] = v;
+        st_wt(&Winv[(size_t)JQ * 256 + lr * 16 + lk + 4 * r], v);
+      }
+      lds_post(&L.w_done, JQ + 1, lane);
+    }
+  }
+  static_assert(W >= 1 && W <= 3, "worker index");
+  if (W == WT) {
+    // identity pseudo-tiles of the phases after the own ones
+#pragma unroll
+    for (int JQ = WT; JQ < 4; ++JQ) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Wt[r] = (lr == lk + 4 * r) ? 1.0 : 0.0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int n = 4 * JQ + s;
+        lds_wait(&L.it_done, n + 1);
+        const double mop = L.mop[n][lane], xm = L.xm[n][lane];
+        const double xw = mfma_f64(mop, Wt[s], zero)[0];
+        Wt[s] = xw;
+        if (s < 3) Wt = mfma_f64(-xm, xw, Wt);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double v = (lk + 4 * r >= lr) ? Wt[r] : 0.0;
+        L.Wi[JQ][lr * 16 + lk + 4 * r] = v;
+        st_wt(&Winv[(size_t)JQ * 256 + lr * 16 + lk + 4 * r], v);
+      }
+      lds_post(&L.w_done, JQ + 1, lane);
+    }
+  }
+}
+
+template <int NPAN, bool EARLY>
+__device__ __forceinline__ void ll_panel_rows(double* __restrict__ S, int ld, int k, int it, int q, int gate, int lane, ALds& L, v4d (&Tq)[4],
+                                           const double (&tb)[16], float* __restrict__ L32t) {
+  const int lr = lane & 15, lk = lane >> 4;
+  double* tcol = S + (size_t)(k * NB) * ld + (size_t)it * NB + 16 * q + lr;
+  float* pcol = L32t ? L32t + lk * NB + 16 * q + lr : nullptr;      // packed f32 copy of the tile (element (row, col) at col * 64 + row)
+  v4d xt[4], t[4];
+  // order: | T(0) x(0) T(1) t(1) | x(1) T(2) t(2) | x(2) T(3) t(3) | x(3): after the last phase only the four MFMAs with the
+  // last inverse are left.  t(b) = A_b - sum_{c<b} X_c L(b,c)^T needs phase b-1, x(b) = t(b) L_bb^-T the inverse of phase b.
+  // This wave shares its SIMD with a worker that answers the chain wave with two or three MFMAs per iteration: the
+  // throughput work here goes in bursts of four MFMAs with a pause after each, so the matrix pipe is free half the time.
+#define PANEL_YIELD() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_sched_barrier(0); } while (0)
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    if (b == 0) {
+      if (NPAN > 0 && EARLY) {
+        if (gate == 1) lds_wait(&L.d_ready[1], 1);   // wave 5 / 6 share their SIMD with worker 1 / 2: not before that one's hand-off
+        if (gate == 2) lds_wait(&L.d_ready[2], 1);   // (worker 3 has two phases of slack: wave 7 starts at once)
+        // the whole pending update at once, while the factor waves are in their own: the phases that follow then see
+        // only the short substitution bursts of this wave on their SIMD
+#pragma unroll
+        for (int ks = 0; ks < 16 * NPAN; ++ks) {
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) Tq[bb] = mfma_f64(-L.Pk[4 * ks + lk][16 * bb + lr], tb[ks], Tq[bb]);
+        }
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) pin(Tq[bb]);
+      }
+      lds_wait(&L.it_done, 4);
+      if (NPAN > 0 && !EARLY) {
+#pragma unroll
+        for (int ks = 0; ks < 16 * NPAN; ++ks) {
+          Tq[0] = mfma_f64(-L.Pk[4 * ks + lk][lr], tb[ks], Tq[0]);
+          if ((ks & 3) == 3) PANEL_YIELD();
+        }
+      }
+      t[0] = Tq[0];
+    }
+    lds_wait(&L.w_done, b + 1);
+    v4d x = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(L.Wi[b][(4 * s4 + lk) * 16 + lr], t[b][s4], x);   // (L_bb^-1)[lr][4 s4 + lk]
+    xt[b] = x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st_wt(&tcol[(size_t)(16 * b + lk + 4 * r) * ld], x[r]);
+    if (pcol) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pcol[(16 * b + 4 * r) * NB] = (float)x[r];
+    }
+    if (b < 3) {
+      PANEL_YIELD();
+      if (NPAN > 0 && !EARLY) {
+#pragma unroll
+        for (int ks = 0; ks < 16 * NPAN; ++ks) {
+          Tq[b + 1] = mfma_f64(-L.Pk[4 * ks + lk][16 * (b + 1) + lr], tb[ks], Tq[b + 1]);
+          if ((ks & 3) == 3) PANEL_YIELD();
+        }
+      }
+      lds_wait(&L.col_done[b + 1], b + 1);
+      v4d tn = Tq[b + 1];
+#pragma unroll
+      for (int c = 0; c <= b; ++c) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) tn = mfma_f64(-L.Lt[oidx(b + 1, c)][s4][lane], xt[c][s4], tn);   // -L[16(b+1) + lr][16c + lk + 4 s4]
+        if (b < 2 || c < b) PANEL_YIELD();        // (not before the closing x(3))
+      }
+      t[b + 1] = tn;
+      pin(t[b + 1]);
+    }
+  }
+#undef PANEL_YIELD
+}
+
+// diagnostic (tools/ll_trace.py): host-pinned progress words per task, written at system scope so that the host can read them while
+// the launch is still running: [0] stage reached by wave 0 (1 started, 2 older panels summed, 3 staged, 4 factored, 5 published),
+// [1] kind, [2] k, [3] first tile row, [4] / [5] bit w: wave w is behind the first / second barrier, [6] wait calls that gave up
+__device__ __forceinline__ void ll_mark(int* tr, int word, int v) {
+  if (tr && (threadIdx.x & 63) == 0) __hip_atomic_store(tr + word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void ll_time(int* tr, int word) {      // [8 + ..]: wall clock (100 MHz, low 32 bits) at a stage / event
+  if (tr && (threadIdx.x & 63) == 0) __hip_atomic_store(tr + word, (int)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void ll_stage(int* tr, int v) { ll_mark(tr, 0, v); ll_time(tr, 8 + v); }
+__device__ __forceinline__ void ll_mark_or(int* tr, int word, int v) {
+  if (tr && (threadIdx.x & 63) == 0) __hip_atomic_fetch_or(tr + word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // flags f0[c * stride] (and f1[c * stride] unless null), c0 <= c < c1, all raised?  One lane per column, the whole wave spins.
 __device__ __forceinline__ bool ll_wait_cols(const int* f0, const int* f1, int stride, int c0, int c1, int* ctl, int* status) {
   const int lane = threadIdx.x & 63;
@@ -803,7 +1009,7 @@ __device__ __forceinline__ void ll_diag_term(const double* __restrict__ S, int l
 }
 
 // ---- tile task: tile rows it0 (waves 0..3) and it1 (waves 4..7; -1: none) of column k ----
-__device__ __forceinline__ void ll_tile_task(const LLSys& Y, const LLTask& tk, int* ctl) {
+__device__ __forceinline__ void ll_tile_task(const LLSys& Y, const LLTask& tk, int* ctl, int* tr) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
@@ -826,7 +1032,9 @@ __device__ __forceinline__ void ll_tile_task(const LLSys& Y, const LLTask& tk, i
       ll_rows_term(S, ld, k, it, q, k - 1, lr, lk, Tq);
     }
     // L_kk: the off-diagonal 16x16 sub-tiles (Ld) and the 16x16 inverses (Winv) the chain task of this column published
+    if (wave == 0) ll_time(tr, 10);                         // (tile task: the sums over the finished columns are through)
     ll_wait_cols(fk, nullptr, fr, k, k + 1, ctl, Y.status);
+    if (wave == 0) ll_time(tr, 15);
     const double* Ldk = Y.Ld + (size_t)k * NB * NB;
     const double* Wk = Y.Winv + (size_t)k * 1024;
     double wi[4][4], lt[6][4];
@@ -850,7 +1058,7 @@ __device__ __forceinline__ void ll_tile_task(const LLSys& Y, const LLTask& tk, i
       for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(wi[b][s4], t[s4], x);
       xt[b] = x;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tcol[(size_t)(16 * b + lk + 4 * r) * ld] = x[r];
+      for (int r = 0; r < 4; ++r) st_wt(&tcol[(size_t)(16 * b + lk + 4 * r) * ld], x[r]);
       if (b < 3) {
         v4d tn = Tq[b + 1];
 #pragma unroll
@@ -862,16 +1070,18 @@ __device__ __forceinline__ void ll_tile_task(const LLSys& Y, const LLTask& tk, i
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   }
+  ll_mark_or(tr, 4, 1 << wave);
   __syncthreads();
   if (tid == 0) {
     __hip_atomic_store(Y.flags + (size_t)k * fr + tk.it0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tk.it1 >= 0) __hip_atomic_store(Y.flags + (size_t)k * fr + tk.it1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (wave == 0) ll_stage(tr, 5);
 }
 
 // ---- chain task: the diagonal block of column k and tile row it0 (step_type_a_impl behind a flag instead of a kernel boundary) ----
 template <int NPAN>
-__device__ __forceinline__ void ll_chain_task(const LLSys& Y, const LLTask& tk, ALds& L, int* ctl) {
+__device__ __forceinline__ void ll_chain_task(const LLSys& Y, const LLTask& tk, ALds& L, int* ctl, int* tr) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..7
   const int lr = lane & 15, lk = lane >> 4;
@@ -905,38 +1115,48 @@ __device__ __forceinline__ void ll_chain_task(const LLSys& Y, const LLTask& tk, 
       ll_wait_cols(fi, nullptr, fr, tk.clo0, kold, ctl, Y.status);
       for (int c = tk.clo0; c < kold; ++c) ll_rows_term(S, ld, k, it, 0, c, lr, lk, Tq);
     }
+    if (wave == 0) ll_stage(tr, 2);
     if (NPAN > 0) {
-      ll_wait_cols(fk, (wave == 1 && row_prev) ? fi : nullptr, fr, k - 1, k, ctl, Y.status);
+      // the pending panel: tile (k, k-1), the previous chain task's own tile — the one flag the chain waits for
+      ll_wait_cols(fk, nullptr, fr, k - 1, k, ctl, Y.status);
+      if (wave == 0) ll_time(tr, 14);
       constexpr int NC = 8;
       const double* pq = S + (size_t)((k - 1) * NB + NC * wave) * ld + (size_t)k * NB + lane;
       double stage[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) stage[c] = pq[(size_t)c * ld];
-      if (wave == 1) {
-        const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)it * NB + lr;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) tb[ks] = row_prev ? pi[(size_t)(4 * ks + lk) * ld] : 0.0;
-      }
 #pragma unroll
       for (int c = 0; c < NC; ++c) L.Pk[NC * wave + c][lane] = stage[c];
     }
+    ll_mark_or(tr, 4, 1 << wave);
     __syncthreads();
+    if (wave == 0) ll_stage(tr, 3);
     if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);   // ahead of the panel wave sharing the SIMD
     if (wave == 0) {
       a_chain_wave<NPAN>(0, Y.status, L, lane, R[0]);
     } else if (wave == 1) {
       v4d R1[2] = {R[0], R[1]};
-      a_worker_wave<1, NPAN>(0, Ld, Winv, L, lane, R1);
-      panel_rows<NPAN, false>(S, ld, k, it, 0, 0, lane, L, Tq, tb, nullptr);
+      ll_worker_wave<1, NPAN>(0, Ld, Winv, L, lane, R1);
+      if (NPAN > 0) {
+        // the own rows of tile (it, k-1) — a TILE task of column k-1, through some microseconds after that column's chain task: waited
+        // for here, not in front of the chain
+        if (row_prev) ll_wait_cols(fi, nullptr, fr, k - 1, k, ctl, Y.status);
+        const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)it * NB + lr;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) tb[ks] = row_prev ? pi[(size_t)(4 * ks + lk) * ld] : 0.0;
+      }
+      ll_panel_rows<NPAN, false>(S, ld, k, it, 0, 0, lane, L, Tq, tb, nullptr);
     } else if (wave == 2) {
       v4d R2[3] = {R[0], R[1], R[2]};
-      a_worker_wave<2, NPAN>(0, Ld, Winv, L, lane, R2);
+      ll_worker_wave<2, NPAN>(0, Ld, Winv, L, lane, R2);
     } else {
-      a_worker_wave<3, NPAN>(0, Ld, Winv, L, lane, R);
+      ll_worker_wave<3, NPAN>(0, Ld, Winv, L, lane, R);
     }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    ll_mark_or(tr, 5, 1 << wave);
     __syncthreads();
+    if (wave == 0) ll_stage(tr, 4);
   } else {
     // ---------------- panel waves 5..7: rows 16..63 of tile (it, k) (rows 0..15: worker 1 after its hand-off; wave 4 idles so that
     // the chain wave has its SIMD to itself) ----------------
@@ -952,33 +1172,37 @@ __device__ __forceinline__ void ll_chain_task(const LLSys& Y, const LLTask& tk, 
       }
     }
     if (NPAN > 0) {
-      ll_wait_cols(fk, (rows && row_prev) ? fi : nullptr, fr, k - 1, k, ctl, Y.status);
+      ll_wait_cols(fk, nullptr, fr, k - 1, k, ctl, Y.status);
       constexpr int NC = 8;
       const double* pq = S + (size_t)((k - 1) * NB + NC * wave) * ld + (size_t)k * NB + lane;
       double stage[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) stage[c] = pq[(size_t)c * ld];
-      if (rows) {
-        const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)it * NB + 16 * q + lr;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) tb[ks] = row_prev ? pi[(size_t)(4 * ks + lk) * ld] : 0.0;
-      }
 #pragma unroll
       for (int c = 0; c < NC; ++c) L.Pk[NC * wave + c][lane] = stage[c];
     }
+    ll_mark_or(tr, 4, 1 << wave);
     __syncthreads();
-    if (rows) panel_rows<NPAN, true>(S, ld, k, it, q, wave - 4, lane, L, Tq, tb, nullptr);
+    if (NPAN > 0 && rows) {      // (the own rows of tile (it, k-1): see worker 1)
+      if (row_prev) ll_wait_cols(fi, nullptr, fr, k - 1, k, ctl, Y.status);
+      const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)it * NB + 16 * q + lr;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) tb[ks] = row_prev ? pi[(size_t)(4 * ks + lk) * ld] : 0.0;
+    }
+    if (rows) ll_panel_rows<NPAN, true>(S, ld, k, it, q, wave - 4, lane, L, Tq, tb, nullptr);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    ll_mark_or(tr, 5, 1 << wave);
     __syncthreads();
   }
   if (tid == 0) {
     __hip_atomic_store(Y.flags + (size_t)k * fr + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(Y.flags + (size_t)k * fr + it, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (wave == 0) ll_stage(tr, 5);
 }
 
-// ctl[0]: ticket counter, ctl[1]: abort word (both cleared with the flags before the launch)
-__global__ __launch_bounds__(512) void k_chol_ll(const LLSys* __restrict__ sysv, const LLTask* __restrict__ tasks, int n_tasks, int* ctl) {
+// ctl[0]: ticket counter, ctl[1]: abort word (both cleared with the flags before the launch); trace: null, or 16 host-pinned ints per task
+__global__ __launch_bounds__(512) void k_chol_ll(const LLSys* __restrict__ sysv, const LLTask* __restrict__ tasks, int n_tasks, int* ctl, int* trace) {
   __shared__ ALds L;
   __shared__ int s_t;
   if (threadIdx.x == 0) s_t = atomicAdd(&ctl[0], 1);
@@ -987,11 +1211,13 @@ __global__ __launch_bounds__(512) void k_chol_ll(const LLSys* __restrict__ sysv,
   if (t >= n_tasks) return;
   const LLTask tk = tasks[t];
   const LLSys Y = sysv[tk.sys];
+  int* tr = trace ? trace + 16 * (size_t)t : nullptr;
+  if (tr && threadIdx.x == 0) { ll_mark(tr, 1, tk.kind); ll_mark(tr, 2, tk.k); ll_mark(tr, 3, tk.it0); ll_stage(tr, 1); }
   if (tk.kind == 0) {
-    if (tk.clo_d <= tk.k - 1) ll_chain_task<1>(Y, tk, L, ctl);
-    else ll_chain_task<0>(Y, tk, L, ctl);
+    if (tk.clo_d <= tk.k - 1) ll_chain_task<1>(Y, tk, L, ctl, tr);
+    else ll_chain_task<0>(Y, tk, L, ctl, tr);
   } else {
-    ll_tile_task(Y, tk, ctl);
+    ll_tile_task(Y, tk, ctl, tr);
   }
 }
 
@@ -2046,7 +2272,7 @@ struct CholLLPlan {
   LLSys* d_sys = nullptr; LLTask* d_tasks = nullptr; int* d_ints = nullptr;
   int n_sys = 0, n_tasks = 0, n_ints = 0, n_chain = 0, max_cols = 0;
 };
-CholLLPlan* chol_ll_plan_create(const CholSystem* d, int n, const int* const* h_ord) {
+CholLLPlan* chol_ll_plan_create(const CholSystem* d, int n, const int* const* h_ord, hipStream_t up) {
   std::vector<LLSys> sys(n);
   std::vector<std::vector<int>> first(n), bf(n), bphys(n), profv(n);
   size_t n_ints = 16;                                   // [0] ticket counter, [1] abort word; flags from 16 on
@@ -2098,6 +2324,47 @@ CholLLPlan* chol_ll_plan_create(const CholSystem* d, int n, const int* const* h_
         }
       }
   }
+  {
+    // self-check of the table (host, once per plan): replay the tasks in ticket order against a host copy of the flags — every flag a
+    // task waits for must have been raised by an EARLIER task (else the launch could only end by its time-out), every tile of every
+    // column must be produced exactly once
+    std::vector<std::vector<char>> fl(n);
+    for (int i = 0; i < n; ++i) fl[i].assign((size_t)sys[i].T * sys[i].frows, 0);
+    auto need = [&](const LLTask& t, int c, int row) {
+      const LLSys& y = sys[t.sys];
+      if (c < 0 || c >= y.T || row < 0 || row >= y.frows || !fl[t.sys][(size_t)c * y.frows + row]) {
+        fprintf(stderr, "slide_slam_amd: left-looking plan: task (system %d, column %d, kind %d, rows %d %d) waits for tile (%d, %d) that no earlier task produces\n",
+                t.sys, t.k, t.kind, t.it0, t.it1, row, c);
+        return false;
+      }
+      return true;
+    };
+    auto raise = [&](const LLTask& t, int row) {
+      const LLSys& y = sys[t.sys];
+      char& f = fl[t.sys][(size_t)t.k * y.frows + row];
+      if (f) { fprintf(stderr, "slide_slam_amd: left-looking plan: tile (%d, %d) of system %d is produced twice\n", row, t.k, t.sys); return false; }
+      f = 1;
+      return true;
+    };
+    bool good = true;
+    for (const LLTask& t : tasks) {
+      if (t.kind == 0) {
+        for (int c = t.clo_d; c < t.k && good; ++c) good = need(t, c, t.k);
+        for (int c = t.clo0; c < t.k && good; ++c) good = need(t, c, t.it0) && need(t, c, t.k);
+        good = good && t.clo_d >= 0 && t.clo0 >= t.clo_d && raise(t, t.k) && raise(t, t.it0);
+      } else {
+        for (int sl = 0; sl < 2 && good; ++sl) {
+          const int it = sl ? t.it1 : t.it0, clo = sl ? t.clo1 : t.clo0;
+          if (it < 0) continue;
+          for (int c = clo; c < t.k && good; ++c) good = need(t, c, it) && need(t, c, t.k);
+          good = good && clo >= t.clo_d && need(t, t.k, t.k);
+        }
+        good = good && raise(t, t.it0) && (t.it1 < 0 || raise(t, t.it1));
+      }
+      if (!good) break;
+    }
+    if (!good) return nullptr;
+  }
   CholLLPlan* p = new CholLLPlan();
   p->n_sys = n; p->n_tasks = (int)tasks.size(); p->n_ints = (int)n_ints; p->n_chain = n_chain; p->max_cols = Tmax;
   bool ok = hipMalloc(reinterpret_cast<void**>(&p->d_ints), n_ints * sizeof(int)) == hipSuccess &&
@@ -2105,9 +2372,10 @@ CholLLPlan* chol_ll_plan_create(const CholSystem* d, int n, const int* const* h_
             hipMalloc(reinterpret_cast<void**>(&p->d_tasks), std::max<size_t>(1, tasks.size()) * sizeof(LLTask)) == hipSuccess;
   if (ok) {
     for (LLSys& y : sys) y.flags = p->d_ints + reinterpret_cast<size_t>(y.flags);
-    ok = hipMemcpy(p->d_sys, sys.data(), sys.size() * sizeof(LLSys), hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(p->d_tasks, tasks.data(), tasks.size() * sizeof(LLTask), hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemset(p->d_ints, 0, n_ints * sizeof(int)) == hipSuccess;
+    // (on the caller's stream, not the legacy stream: other host threads of the process may be capturing)
+    ok = hipMemcpyAsync(p->d_sys, sys.data(), sys.size() * sizeof(LLSys), hipMemcpyHostToDevice, up) == hipSuccess &&
+         hipMemcpyAsync(p->d_tasks, tasks.data(), tasks.size() * sizeof(LLTask), hipMemcpyHostToDevice, up) == hipSuccess &&
+         hipMemsetAsync(p->d_ints, 0, n_ints * sizeof(int), up) == hipSuccess && hipStreamSynchronize(up) == hipSuccess;
   }
   if (!ok) { chol_ll_plan_destroy(p); return nullptr; }
   return p;
@@ -2126,10 +2394,10 @@ __global__ void k_ll_clear(int* __restrict__ p, int n) {
   if (i < n) p[i] = 0;
 }
 // the factorisations of the plan's systems (the steps of launch_chol_batch(.., solve = false) in ONE launch) + the extraction of y
-void launch_chol_ll(const CholLLPlan* p, const CholSystem* d, int n, hipStream_t s) {
+void launch_chol_ll(const CholLLPlan* p, const CholSystem* d, int n, hipStream_t s, int* trace) {
   if (!p || p->n_tasks <= 0) return;
   hipLaunchKernelGGL(k_ll_clear, dim3((p->n_ints + 255) / 256), dim3(256), 0, s, p->d_ints, p->n_ints);
-  hipLaunchKernelGGL(k_chol_ll, dim3((unsigned)p->n_tasks), dim3(512), 0, s, p->d_sys, p->d_tasks, p->n_tasks, p->d_ints);
+  hipLaunchKernelGGL(k_chol_ll, dim3((unsigned)p->n_tasks), dim3(512), 0, s, p->d_sys, p->d_tasks, p->n_tasks, p->d_ints, trace);
   int Tmax = 0;
   for (int lo = 0; lo < n; lo += CHOL_STEP_BATCH_MAX) {
     ExtractArgs E{};

@@ -104,6 +104,12 @@ int HostGraph::init() {
   static const bool nonblocking = getenv("SLIDE_NONBLOCKING_STREAMS") && getenv("SLIDE_NONBLOCKING_STREAMS")[0] == '1';
   SL_HIP(hipStreamCreateWithFlags(&stream, nonblocking ? hipStreamNonBlocking : hipStreamDefault));
   SL_HIP(hipStreamCreateWithFlags(&stream2, nonblocking ? hipStreamNonBlocking : hipStreamDefault));
+  if (nonblocking) {
+    static bool said = false;
+    unsigned fl = 0;
+    SL_HIP(hipStreamGetFlags(stream, &fl));
+    if (!said) { said = true; fprintf(stderr, "slide_slam_amd: graph streams are non-blocking (SLIDE_NONBLOCKING_STREAMS=1; flags %u)\n", fl); }
+  }
   init_solver_kernels();
   if (d_status.ensure(8, 0, stream, true) != SLIDE_OK) return SLIDE_ERR_HIP;
   return SLIDE_OK;
@@ -523,7 +529,8 @@ int CholBatch::prepare_pass() {
   }
   if (!d_Gs) SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_Gs), CHOL_BATCH_HOST_MAX * sizeof(GraphDev)));
   if (!d_status_all) SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_status_all), CHOL_BATCH_HOST_MAX * 8 * sizeof(int)));
-  SL_HIP(hipMemcpy(d_Gs, hG.data(), n * sizeof(GraphDev), hipMemcpyHostToDevice));
+  SL_HIP(hipMemcpyAsync(d_Gs, hG.data(), n * sizeof(GraphDev), hipMemcpyHostToDevice, master));      // (not the legacy stream: other host threads may be capturing)
+  SL_HIP(hipStreamSynchronize(master));
   // exact joint passes: the systems the steps run on — every graph's segments (views of its S; the whole band when it is not cut) — and
   // the second-level systems of the graphs that are cut (the separator poses' block inside the border block, the rest of the border
   // as its border)
@@ -616,7 +623,7 @@ int CholBatch::prepare_pass() {
         std::vector<int> codes(jl.size());
         for (size_t k = 0; k < jl.size(); ++k) codes[k] = jl[k].second;
         SL_HIP(hipStreamSynchronize(master));
-        SL_HIP(hipMemcpy(d_syrk_jobs, codes.data(), codes.size() * sizeof(int), hipMemcpyHostToDevice));
+        SL_HIP(hipMemcpyAsync(d_syrk_jobs, codes.data(), codes.size() * sizeof(int), hipMemcpyHostToDevice, master)); SL_HIP(hipStreamSynchronize(master));
       }
       const char* e = getenv("SLIDE_SYRK_LDS");
       syrk_lds_pad = e ? atoi(e) : 0;
@@ -639,18 +646,18 @@ int CholBatch::prepare_pass() {
       }
       if (n_l2_jobs > 0) {
         SL_HIP(hipStreamSynchronize(master));
-        SL_HIP(hipMemcpy(d_l2_jobs, codes.data(), codes.size() * sizeof(int), hipMemcpyHostToDevice));
+        SL_HIP(hipMemcpyAsync(d_l2_jobs, codes.data(), codes.size() * sizeof(int), hipMemcpyHostToDevice, master)); SL_HIP(hipStreamSynchronize(master));
       }
     }
     if (!d_ctr2) {
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_ctr2), 64 * sizeof(int)));
-      SL_HIP(hipMemset(d_ctr2, 0, 64 * sizeof(int)));
+      SL_HIP(hipMemsetAsync(d_ctr2, 0, 64 * sizeof(int), master)); SL_HIP(hipStreamSynchronize(master));
     }
     if ((int)seg_sys.size() > 8 * CHOL_BATCH_HOST_MAX || (int)l2_sys.size() > CHOL_BATCH_HOST_MAX) { g_last_error = "exact joint step: too many segment systems"; return SLIDE_ERR_CAPACITY; }
     if (chol_ll_enabled()) {
       SL_HIP(hipStreamSynchronize(master));
-      ll_seg = chol_ll_plan_create(seg_sys.data(), (int)seg_sys.size(), seg_hord.data());
-      if (!l2_sys.empty()) ll_l2 = chol_ll_plan_create(l2_sys.data(), (int)l2_sys.size());
+      ll_seg = chol_ll_plan_create(seg_sys.data(), (int)seg_sys.size(), seg_hord.data(), master);
+      if (!l2_sys.empty()) ll_l2 = chol_ll_plan_create(l2_sys.data(), (int)l2_sys.size(), nullptr, master);
       if (!ll_seg || (!l2_sys.empty() && !ll_l2)) { g_last_error = "exact joint step: the left-looking factorisation's tables could not be allocated"; return SLIDE_ERR_HIP; }
     }
     return prepare_separator();
@@ -792,16 +799,16 @@ int CholBatch::prepare_separator() {
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_bord), nb * sizeof(double)));
       if ((sep_nl + 1) * sep_nl <= 32) SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_scratch), (size_t)(sep_nl + 1) * sep_nl * 15 * NB * NB * sizeof(double)));
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&lamS), nb * sizeof(double)));
-      SL_HIP(hipMemset(sep_bord, 0, nb * sizeof(double)));
-      SL_HIP(hipMemset(lamS, 0, nb * sizeof(double)));
+      SL_HIP(hipMemsetAsync(sep_bord, 0, nb * sizeof(double), master)); SL_HIP(hipStreamSynchronize(master));
+      SL_HIP(hipMemsetAsync(lamS, 0, nb * sizeof(double), master)); SL_HIP(hipStreamSynchronize(master));
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_Ld), (size_t)sep_nl * NB * NB * sizeof(double)));
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_Winv), (size_t)sep_nl * 1024 * sizeof(double)));
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_yv), (size_t)sep_nl * NB * sizeof(double)));
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_dp), (size_t)sep_nl * NB * sizeof(double)));
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_status), 8 * sizeof(int)));
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_ctr), ((size_t)sep_nl + 2) * sizeof(int)));
-      SL_HIP(hipMemset(lam_ctr, 0, ((size_t)sep_nl + 2) * sizeof(int)));
-      SL_HIP(hipMemset(lam_status, 0, 8 * sizeof(int)));
+      SL_HIP(hipMemsetAsync(lam_ctr, 0, ((size_t)sep_nl + 2) * sizeof(int), master)); SL_HIP(hipStreamSynchronize(master));
+      SL_HIP(hipMemsetAsync(lam_status, 0, 8 * sizeof(int), master)); SL_HIP(hipStreamSynchronize(master));
     }
   }
   if (sep_x && sep_x_len < sep_buffer_len(sep_m, sep_lam)) { g_last_error = "exact joint step: the separator exchange buffer is too small (slide_chol_batch_sep_buffer_len)"; return SLIDE_ERR_INVALID; }
@@ -821,19 +828,19 @@ int CholBatch::prepare_separator() {
     SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_dp), (size_t)sep_cap * NB * sizeof(double)));
     SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_status), 8 * sizeof(int)));
     SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_ctr), ((size_t)sep_cap + 2) * sizeof(int)));
-    SL_HIP(hipMemset(sep_ctr, 0, ((size_t)sep_cap + 2) * sizeof(int)));
-    SL_HIP(hipMemset(sep_status, 0, 8 * sizeof(int)));
+    SL_HIP(hipMemsetAsync(sep_ctr, 0, ((size_t)sep_cap + 2) * sizeof(int), master)); SL_HIP(hipStreamSynchronize(master));
+    SL_HIP(hipMemsetAsync(sep_status, 0, 8 * sizeof(int), master)); SL_HIP(hipStreamSynchronize(master));
   }
   // zero once: the strict upper triangle and the idle rows of the right-hand-side tile are never written by the gather
-  SL_HIP(hipMemset(sepS, 0, (size_t)need * sizeof(double)));
-  if (sep_x) SL_HIP(hipMemset(sep_x, 0, (size_t)sep_buffer_len(sep_m, sep_lam) * sizeof(double)));
+  SL_HIP(hipMemsetAsync(sepS, 0, (size_t)need * sizeof(double), master)); SL_HIP(hipStreamSynchronize(master));
+  if (sep_x) SL_HIP(hipMemsetAsync(sep_x, 0, (size_t)sep_buffer_len(sep_m, sep_lam) * sizeof(double), master)); SL_HIP(hipStreamSynchronize(master));
   // tile profile of the landmark part (the caller's, from the robots' observer sets — two shared landmarks couple only if some robot
   // observes both); absent or of another size: dense
   if (d_sep_prof) { SL_HIP(hipFree(d_sep_prof)); d_sep_prof = nullptr; }
   sep_prof_on = (int)h_sep_prof.size() == sep_Ts && sep_Ts > 0;
   if (sep_prof_on) {
     SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_prof), (size_t)sep_Ts * sizeof(int)));
-    SL_HIP(hipMemcpy(d_sep_prof, h_sep_prof.data(), (size_t)sep_Ts * sizeof(int), hipMemcpyHostToDevice));
+    SL_HIP(hipMemcpyAsync(d_sep_prof, h_sep_prof.data(), (size_t)sep_Ts * sizeof(int), hipMemcpyHostToDevice, master)); SL_HIP(hipStreamSynchronize(master));
   }
   if (sep_dissected()) {
     const int Ta = sep_leafT[0], Tb = sep_leafT[1], TL = Ta + Tb, Tt = sep_Ts - TL, nb = Tt + sep_nl;
@@ -852,9 +859,9 @@ int CholBatch::prepare_separator() {
       both.insert(both.end(), h_leaf_prof[b].begin(), h_leaf_prof[b].end());
     }
     SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_leaf_prof), both.size() * sizeof(int)));
-    SL_HIP(hipMemcpy(d_leaf_prof, both.data(), both.size() * sizeof(int), hipMemcpyHostToDevice));
+    SL_HIP(hipMemcpyAsync(d_leaf_prof, both.data(), both.size() * sizeof(int), hipMemcpyHostToDevice, master)); SL_HIP(hipStreamSynchronize(master));
     SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_ctr2), ((size_t)std::max(Ta, Tb) + 2) * sizeof(int)));
-    SL_HIP(hipMemset(sep_ctr2, 0, ((size_t)std::max(Ta, Tb) + 2) * sizeof(int)));
+    SL_HIP(hipMemsetAsync(sep_ctr2, 0, ((size_t)std::max(Ta, Tb) + 2) * sizeof(int), master)); SL_HIP(hipStreamSynchronize(master));
     // the top block's product over the leaves' TL column blocks: tile columns of the top block only (the lambda x lambda block is
     // formed after the top block's own steps, over all Ts column blocks), K split so that the launch fills the chip
     std::vector<int> codes;
@@ -862,18 +869,18 @@ int CholBatch::prepare_separator() {
       for (int ib = jb; ib <= nb; ++ib) codes.push_back(ib << 10 | jb);
     n_sep_jobs = (int)codes.size();
     SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_jobs), codes.size() * sizeof(int)));
-    SL_HIP(hipMemcpy(d_sep_jobs, codes.data(), codes.size() * sizeof(int), hipMemcpyHostToDevice));
+    SL_HIP(hipMemcpyAsync(d_sep_jobs, codes.data(), codes.size() * sizeof(int), hipMemcpyHostToDevice, master)); SL_HIP(hipStreamSynchronize(master));
     sep_ks = std::max(1, std::min({8, TL / 4, (1024 + n_sep_jobs - 1) / std::max(n_sep_jobs, 1)}));
     if (getenv("SLIDE_SEP_KS")) sep_ks = std::max(1, std::min(16, atoi(getenv("SLIDE_SEP_KS"))));      // (diagnostic)
     if (sep_ks > 1) {
       const size_t len = (size_t)(nb + 1) * nb * (sep_ks - 1) * NB * NB * sizeof(double);
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_scratch), len));
-      SL_HIP(hipMemset(sep_scratch, 0, len));      // (the idle half of a right-hand-side tile's partials is never written: it must read as zero)
+      SL_HIP(hipMemsetAsync(sep_scratch, 0, len, master)); SL_HIP(hipStreamSynchronize(master));      // (the idle half of a right-hand-side tile's partials is never written: it must read as zero)
     }
     // the backward substitution runs over the whole system: its profile must cover the top block's rows under the leaves' columns
     std::vector<int> cover(h_sep_prof);
     for (int c = 0; c < TL; ++c) cover[c] = sep_Ts - 1;
-    SL_HIP(hipMemcpy(d_sep_prof, cover.data(), (size_t)sep_Ts * sizeof(int), hipMemcpyHostToDevice));
+    SL_HIP(hipMemcpyAsync(d_sep_prof, cover.data(), (size_t)sep_Ts * sizeof(int), hipMemcpyHostToDevice, master)); SL_HIP(hipStreamSynchronize(master));
   }
   {
     // which graphs hold coordinates of which tile (landmark tiles, then the lambdas' tiles at virtual index Ts * NB + b)
@@ -886,23 +893,23 @@ int CholBatch::prepare_separator() {
     if (d_sep_tmask) { SL_HIP(hipStreamSynchronize(master)); SL_HIP(hipFree(d_sep_tmask)); d_sep_tmask = nullptr; }
     if (n <= 32 && !tm.empty()) {
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_tmask), tm.size() * sizeof(int)));
-      SL_HIP(hipMemcpy(d_sep_tmask, tm.data(), tm.size() * sizeof(int), hipMemcpyHostToDevice));
+      SL_HIP(hipMemcpyAsync(d_sep_tmask, tm.data(), tm.size() * sizeof(int), hipMemcpyHostToDevice, master)); SL_HIP(hipStreamSynchronize(master));
     }
   }
   if (d_sep_off) { SL_HIP(hipFree(d_sep_off)); d_sep_off = nullptr; }
   SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_off), off.size() * sizeof(int)));
-  SL_HIP(hipMemcpy(d_sep_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+  SL_HIP(hipMemcpyAsync(d_sep_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice, master)); SL_HIP(hipStreamSynchronize(master));
   free_ll_sep_plans();
   if (chol_ll_enabled() && sep_Ts > 0) {
     const CholSystem top = sep_top_system();
-    ll_top = chol_ll_plan_create(&top, 1);
+    ll_top = chol_ll_plan_create(&top, 1, nullptr, master);
     bool ok = ll_top != nullptr;
     if (sep_dissected()) {
       CholSystem lv[2];
       sep_leaf_systems(lv);
-      ll_leaves = chol_ll_plan_create(lv, 2);
-      ll_leaf_own[0] = chol_ll_plan_create(&lv[0], 1);
-      ll_leaf_own[1] = chol_ll_plan_create(&lv[1], 1);
+      ll_leaves = chol_ll_plan_create(lv, 2, nullptr, master);
+      ll_leaf_own[0] = chol_ll_plan_create(&lv[0], 1, nullptr, master);
+      ll_leaf_own[1] = chol_ll_plan_create(&lv[1], 1, nullptr, master);
       ok = ok && ll_leaves && ll_leaf_own[0] && ll_leaf_own[1];
     }
     if (!ok) { g_last_error = "exact joint step: the left-looking factorisation's tables could not be allocated"; return SLIDE_ERR_HIP; }

@@ -82,11 +82,11 @@ void launch_chol_bwd_batch(const CholSystem* d, int n, hipStream_t s);       // 
 // parameters) depends on the systems' pointers, profiles and border tables: rebuild it when any of them changes.  h_ord[i]: host copy of
 // d[i].ord (or null).  launch_chol_ll = the steps of launch_chol_batch(.., solve = false): factorisation + extraction of y.
 struct CholLLPlan;
-CholLLPlan* chol_ll_plan_create(const CholSystem* d, int n, const int* const* h_ord = nullptr);
+CholLLPlan* chol_ll_plan_create(const CholSystem* d, int n, const int* const* h_ord = nullptr, hipStream_t upload_stream = nullptr);
 void chol_ll_plan_destroy(CholLLPlan* p);
 int chol_ll_plan_tasks(const CholLLPlan* p);
 int chol_ll_plan_columns(const CholLLPlan* p);
-void launch_chol_ll(const CholLLPlan* p, const CholSystem* d, int n, hipStream_t s);
+void launch_chol_ll(const CholLLPlan* p, const CholSystem* d, int n, hipStream_t s, int* trace = nullptr);      // trace: diagnostic, 16 host-pinned ints per task (ll_mark / ll_time) or null
 // Exact joint step (the border of the systems = the separator's coupling rows, W^T after the steps):
 void launch_border_syrk(const CholSystem* d, int n, hipStream_t s, double* scratch = nullptr, int ks = 1);          // bord(i, j) -= sum_c W^T(i, c) W^T(j, c)^T, i >= j, right-hand-side row included; scratch + ks: split K (one system)
 void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int njobs, int lds_pad, hipStream_t s, double* scratch = nullptr, int ks = 1, int jb_end = -1);      // the same, workgroups in the order of a job table (system << 20 | ib << 10 | jb), lds_pad bytes of idle LDS per workgroup (bounds the residency)

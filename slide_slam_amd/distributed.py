@@ -247,19 +247,21 @@ class DistributedGraph:
         return dict(n_slots=self.n_slots, n_global=n_global)
 
     def setup_ghosts(self, relmeas, local_robot=0):
-        """relmeas: the job's inter-robot measurements [(pose index k, robot a, robot b, rel7 a->b)], identical on every
-        rank.  Ghost slots = the sorted (robot, k) pairs they touch; this rank adds the factors that involve its robot."""
-        keys = sorted({(a, k) for (k, a, b, _) in relmeas} | {(b, k) for (k, a, b, _) in relmeas})
+        """relmeas: the job's inter-robot measurements [(pose index k, robot a, robot b, rel7 a->b)] (or with a fifth entry: the
+        other robot's pose index), identical on every rank.  Ghost slots = the sorted (robot, k) pairs they touch; this rank adds the factors that involve its robot."""
+        from .synth import relmeas_keys
+        rm = [relmeas_keys(e) for e in relmeas]          # (ka, a, kb, b, rel7)
+        keys = sorted({(a, ka) for (ka, a, kb, b, _) in rm} | {(b, kb) for (ka, a, kb, b, _) in rm})
         slot = {key: i for i, key in enumerate(keys)}
         self.n_gslots = len(keys)
         own_robot = np.array([local_robot if r == self.rank else -1 for (r, _) in keys], np.int32)
         own_idx = np.array([k for (_, k) in keys], np.int64)
         self.shard.graph.set_ghosts(own_robot, own_idx)
-        for (k, a, b, rel) in relmeas:
+        for (ka, a, kb, b, rel) in rm:
             if a == self.rank:
-                self.shard.graph.add_relative_meas_ghost(rel, k, local_robot, slot[(b, k)], True)
+                self.shard.graph.add_relative_meas_ghost(rel, ka, local_robot, slot[(b, kb)], True)
             if b == self.rank:
-                self.shard.graph.add_relative_meas_ghost(rel, k, local_robot, slot[(a, k)], False)
+                self.shard.graph.add_relative_meas_ghost(rel, kb, local_robot, slot[(a, ka)], False)
         self.gbuf = self.comm.alloc(max(self.n_gslots, 1) * 12)
         return self.n_gslots
 
@@ -433,21 +435,23 @@ class PassDriver:
         at which the factor is linearised.  Exact joint step: the factor's six linearised residuals join the separator ("lambda"
         coordinates), each robot couples to them through its own Jacobian, and the step is exactly the joint replica's.  PCG / block-Jacobi
         passes: the cross block J_a^T J_b is left out of the step (gradient exact).  Virtual robot of local shard t = rank * R + t."""
+        from .synth import relmeas_keys
         R = len(self.shards)
-        keys = sorted({(a, k) for (k, a, b, _) in relmeas} | {(b, k) for (k, a, b, _) in relmeas})
+        rm = [relmeas_keys(e) for e in relmeas]          # (ka, a, kb, b, rel7): pose ka of robot a sees pose kb of robot b (ka == kb for 4-tuples)
+        keys = sorted({(a, ka) for (ka, a, kb, b, _) in rm} | {(b, kb) for (ka, a, kb, b, _) in rm})
         slot = {key: i for i, key in enumerate(keys)}
         self.n_gslots = len(keys)
-        self.n_relmeas = len(relmeas)
+        self.n_relmeas = len(rm)
         for t, sh in enumerate(self.shards):
             v = rank * R + t
             sh.graph.set_ghosts(np.array([0 if r == v else -1 for (r, _) in keys], np.int32), np.array([k for (_, k) in keys], np.int64))
             ids = []
-            for i, (k, a, b, rel) in enumerate(relmeas):
+            for i, (ka, a, kb, b, rel) in enumerate(rm):
                 if a == v:
-                    sh.graph.add_relative_meas_ghost(rel, k, 0, slot[(b, k)], True)
+                    sh.graph.add_relative_meas_ghost(rel, ka, 0, slot[(b, kb)], True)
                     ids.append(i)
                 if b == v:
-                    sh.graph.add_relative_meas_ghost(rel, k, 0, slot[(a, k)], False)
+                    sh.graph.add_relative_meas_ghost(rel, kb, 0, slot[(a, ka)], False)
                     ids.append(i)
             if self.arrow:
                 # exact joint step: the factor enters through six separator coordinates of its own (its linearised residual), coupled to

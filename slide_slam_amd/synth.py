@@ -317,6 +317,39 @@ def make_relmeas(cfg: SynthConfig, logs):
     return out
 
 
+def make_relmeas_dense(cfg: SynthConfig, logs, every=50, max_range=40.0):
+    """SURVEY 8d's density — one relative-pose measurement per ADJACENT robot pair per `every` frames while the observing robot is
+    near the other's trajectory ("in the overlap") — regardless of simultaneity: pose ka of robot a is paired with the pose kb of robot b
+    that is closest to it in space (the reference pairs by time stamp, sloam.cpp:321-412, so the two indices differ in general; the
+    synthetic robots all sweep in lock step, which is why make_relmeas, pairing equal indices, finds only two on C4).
+    Entries (ka, a, b, rel7 a@ka -> b@kb, kb); consumed by PassDriver.setup_ghosts / addRelativeMeasFactor (graph.cpp:247-258)."""
+    rng = np.random.default_rng(cfg.seed + 8888)
+    rows, cols = cfg.grid
+    out = []
+    pos = [np.array([pose7_to_Rt(g)[1] for g in lg["gt7"]]) for lg in logs]
+    for a in range(cfg.robots):
+        ra, ca = divmod(a, cols)
+        for b in range(a + 1, cfg.robots):
+            rb, cb = divmod(b, cols)
+            if abs(ra - rb) + abs(ca - cb) != 1:
+                continue
+            for ka in range(every, cfg.poses_per_robot, every):
+                d = np.linalg.norm(pos[b] - pos[a][ka], axis=1)
+                kb = int(np.argmin(d))
+                if d[kb] > max_range:
+                    continue
+                Ra, ta = pose7_to_Rt(logs[a]["gt7"][ka]); Rb, tb = pose7_to_Rt(logs[b]["gt7"][kb])
+                dR, dt = Ra.T @ Rb, Ra.T @ (tb - ta)
+                nz = rng.normal(0, 1, 6) * np.array([0.005, 0.005, 0.005, 0.02, 0.02, 0.02])
+                out.append((ka, a, b, pose7(dR @ expmap_so3(nz[0:3]), dt + nz[3:6]), kb))
+    return out
+
+
+def relmeas_keys(e):
+    """(ka, a, kb, b, rel7) of a relative-pose measurement entry: (k, a, b, rel7) pairs equal indices, (ka, a, b, rel7, kb) any two."""
+    return (e[0], e[1], e[4] if len(e) > 4 else e[0], e[2], e[3])
+
+
 def make_dataset(cfg: SynthConfig):
     world = make_world(cfg)
     logs = [make_robot_log(cfg, world, r) for r in range(cfg.robots)]

@@ -12,6 +12,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+from chart_env import chart_kw, chart_name  # noqa: E402
+
 T0 = time.perf_counter()
 
 
@@ -50,7 +52,7 @@ def c4_parity(out, preset="C4", passes=3):
     R, P = cfg.robots, cfg.poses_per_robot
 
     def gpu_shards():
-        sh = [s.SlideBackend(s.default_params(), 1) for _ in range(R)]
+        sh = [s.SlideBackend(s.default_params(**chart_kw(s)), 1) for _ in range(R)]
         for a, lg in zip(sh, logs):
             ingest(a, lg, s.FRAME_FOREIGN)
         return sh
@@ -66,7 +68,7 @@ def c4_parity(out, preset="C4", passes=3):
     dB = PassDriver(B, bufB, infoB["n_slots"], device=dev)
     say("GPU shards associated:", infoA["n_slots"], "slots")
     L = po.lib(native=True)
-    O = [po.OracleBackend(po.OrcParams.default(num_threads=min(os.cpu_count() or 1, 16)), 1, L=L) for _ in range(R)]
+    O = [po.OracleBackend(po.OrcParams.default(num_threads=min(os.cpu_count() or 1, 16), **chart_kw(po)), 1, L=L) for _ in range(R)]
     for o, lg in zip(O, logs):
         ingest(o, lg, 2)
     say("oracle shards built")
@@ -117,9 +119,9 @@ def c3_joint(out, preset="C3", gn=12):
     cfg = SynthConfig.preset(preset)
     data = make_dataset(cfg)
     data["relmeas"] = []
-    gb = s.SlideBackend(s.default_params(number_of_robots=cfg.robots), cfg.robots)
+    gb = s.SlideBackend(s.default_params(number_of_robots=cfg.robots, **chart_kw(s)), cfg.robots)
     t0 = time.perf_counter()
-    replay_multi(gb, data, own_node_factory=lambda: s.SlideBackend(s.default_params(), 1))
+    replay_multi(gb, data, own_node_factory=lambda: s.SlideBackend(s.default_params(**chart_kw(s)), 1))
     t_replay = time.perf_counter() - t0
     say("joint replica replayed", t_replay)
     gb.graph.gauss_newton(gn)
@@ -147,10 +149,10 @@ def c5_stream(out, preset="C4", ticks=None, budget_ms=100.0):
     logs = [make_robot_log(cfg, wm, r) for r in range(R)]
     T = cfg.poses_per_robot if ticks is None else ticks
     # what every robot's own node publishes per key frame (PoseMstPair.keyPose, sloamNode.cpp:793-800)
-    kposes = [foreign_key_poses(s.SlideBackend(s.default_params(), 1), lg) for lg in logs]
+    kposes = [foreign_key_poses(s.SlideBackend(s.default_params(**chart_kw(s)), 1), lg) for lg in logs]
     cols = cfg.grid[1]
     nbr = [(r + 1) if (r % cols) + 1 < cols else (r - 1) for r in range(R)]       # the neighbour in the same row of the grid
-    nodes = [s.SlideBackend(s.default_params(number_of_robots=2), 2) for _ in range(R)]
+    nodes = [s.SlideBackend(s.default_params(number_of_robots=2, **chart_kw(s)), 2) for _ in range(R)]
     prev = [IDENT7.copy() for _ in range(R)]
     lat = np.zeros((T, R))
     say("key poses of the", R, "own nodes replayed")
@@ -196,8 +198,8 @@ def c3_converge(out, preset="C3", passes=400, every=20, pcg=0, unbatched=0, arro
     R, P = cfg.robots, cfg.poses_per_robot
     joint, chi2_joint, joint_counts = None, None, None
     if R <= 2:          # (the 8-robot replica's streaming build takes minutes: n = 30016 solved per frame)
-        gb = s.SlideBackend(s.default_params(number_of_robots=R), R)
-        replay_multi(gb, data, own_node_factory=lambda: s.SlideBackend(s.default_params(), 1))
+        gb = s.SlideBackend(s.default_params(number_of_robots=R, **chart_kw(s)), R)
+        replay_multi(gb, data, own_node_factory=lambda: s.SlideBackend(s.default_params(**chart_kw(s)), 1))
         prevj = None
         for it in range(30):
             gb.graph.gauss_newton(1)
@@ -211,7 +213,7 @@ def c3_converge(out, preset="C3", passes=400, every=20, pcg=0, unbatched=0, arro
         joint_counts = [cnt["cyl"], cnt["cube"], cnt["point"]]
         say("joint replica chi2", cj, gb.graph.stats(), cnt, "rejected", gb.graph.rejected_count())
         del gb
-    shards = [s.SlideBackend(s.default_params(), 1) for _ in range(R)]
+    shards = [s.SlideBackend(s.default_params(**chart_kw(s)), 1) for _ in range(R)]
     for sh, lg in zip(shards, data["logs"]):
         replay_single(sh, lg, collect=False)
     say("shards chi2 before", [sh.graph.chi2() for sh in shards], [sh.graph.stats() for sh in shards], [sh.counts() for sh in shards])
@@ -277,11 +279,11 @@ def c3_assoc_check(out, preset="C3"):
     data = make_dataset(cfg)
     data["relmeas"] = []
     R, P = cfg.robots, cfg.poses_per_robot
-    gb = s.SlideBackend(s.default_params(number_of_robots=R), R)
-    jo = replay_multi(gb, data, own_node_factory=lambda: s.SlideBackend(s.default_params(), 1))
+    gb = s.SlideBackend(s.default_params(number_of_robots=R, **chart_kw(s)), R)
+    jo = replay_multi(gb, data, own_node_factory=lambda: s.SlideBackend(s.default_params(**chart_kw(s)), 1))
     shards, outs = [], []
     for lg in data["logs"]:
-        sh = s.SlideBackend(s.default_params(), 1)
+        sh = s.SlideBackend(s.default_params(**chart_kw(s)), 1)
         outs.append(replay_single(sh, lg))
         shards.append(sh)
     tables = [[sh.landmark_table(c) for c in range(3)] for sh in shards]
@@ -324,7 +326,7 @@ def tiny_pcg(out, preset="C3tiny", passes=15, pcg=8):
     R, P = cfg.robots, cfg.poses_per_robot
     res = {}
     for mode in ("batched", "unbatched"):
-        shards = [s.SlideBackend(s.default_params(), 1) for _ in range(R)]
+        shards = [s.SlideBackend(s.default_params(**chart_kw(s)), 1) for _ in range(R)]
         for r, sh in enumerate(shards):
             replay_single(sh, make_robot_log(cfg, wm, r), collect=False)
         batch = s.CholBatch(R) if mode == "batched" else None
@@ -363,7 +365,7 @@ def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1, re
     from dist_worker import oracle_matcher
     from slide_slam_amd.distributed import PassDriver, gpu_matcher, setup_local_shards
     from slide_slam_amd.replay import replay_single
-    from slide_slam_amd.synth import SynthConfig, make_relmeas, make_robot_log, make_world
+    from slide_slam_amd.synth import SynthConfig, make_relmeas, make_relmeas_dense, make_robot_log, make_world
     cfg = SynthConfig.preset(preset)
     wm = make_world(cfg)
     R, P = cfg.robots, cfg.poses_per_robot
@@ -372,9 +374,9 @@ def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1, re
     if with_joint:
         from test_distributed import _joint_optimum
         joint, counts = _joint_optimum(preset, relmeas=bool(relmeas))
-    A = [s.SlideBackend(s.default_params(), 1) for _ in range(R)]
+    A = [s.SlideBackend(s.default_params(**chart_kw(s)), 1) for _ in range(R)]
     L = po.lib(native=True)
-    O = [po.OracleBackend(po.OrcParams.default(num_threads=min(os.cpu_count() or 1, 16)), 1, L=L) for _ in range(R)]
+    O = [po.OracleBackend(po.OrcParams.default(num_threads=min(os.cpu_count() or 1, 16), **chart_kw(po)), 1, L=L) for _ in range(R)]
     for a, o, lg in zip(A, O, logs):
         if mode == "ingest":
             ingest(a, lg, s.FRAME_FOREIGN)
@@ -394,11 +396,14 @@ def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1, re
     n_g = 0
     if relmeas:
         # inter-robot relative-pose factors (graph.cpp:247-258): ghost poses refreshed at the start of every pass, on both sides
-        rel = make_relmeas(cfg, logs)
+        # (relmeas == 2: SURVEY 8d's density — every adjacent robot pair every 50 frames near the other's trajectory, two different
+        # pose indices per factor)
+        rel = make_relmeas_dense(cfg, logs) if relmeas == 2 else make_relmeas(cfg, logs)
         n_g = dA.setup_ghosts(rel)
         assert dO.setup_ghosts(rel) == n_g
+        res_n_rel = len(rel)
         say("relative-pose measurements:", len(rel), "ghost slots:", n_g)
-    res = dict(n_gslots=n_g, n_slots=[infoA["n_slots"], infoO["n_slots"]], sep_dim=[infoA["sep_dim"], infoO["sep_dim"]],
+    res = dict(n_gslots=n_g, n_relmeas=(res_n_rel if relmeas else 0), chart=chart_name(), n_slots=[infoA["n_slots"], infoO["n_slots"]], sep_dim=[infoA["sep_dim"], infoO["sep_dim"]],
                n_global=[list(map(int, infoA["n_global"])), list(map(int, infoO["n_global"]))], gpu_vs_oracle=[], step=[], vs_joint=[], ms=[])
     prev = None
     for p in range(passes):
@@ -450,7 +455,7 @@ def rank_threads(out, preset="C4", world=8, passes=3, relmeas=0, mode="ingest"):
     rel = make_relmeas(cfg, logs) if relmeas else None
 
     def build():
-        sh = [s.SlideBackend(s.default_params(), 1) for _ in range(R)]
+        sh = [s.SlideBackend(s.default_params(**chart_kw(s)), 1) for _ in range(R)]
         for a, lg in zip(sh, logs):
             if mode == "ingest":
                 ingest(a, lg, s.FRAME_FOREIGN)

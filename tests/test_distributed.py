@@ -14,6 +14,8 @@ from slide_slam_amd.replay import replay_multi
 from slide_slam_amd.synth import SynthConfig, make_dataset
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from chart_env import chart_kw  # noqa: E402
 
 
 def _free_port():
@@ -38,12 +40,15 @@ def _joint_optimum(preset, gn_iters=25, relmeas=False):
     data = make_dataset(cfg)
     rel = data["relmeas"]
     data["relmeas"] = []        # streaming without them: the shards associate without them too (same factor graph)
-    ob = po.OracleBackend(po.OrcParams.default(), cfg.robots)
-    replay_multi(ob, data, own_node_factory=lambda: po.OracleBackend(po.OrcParams.default(), 1))
+    ob = po.OracleBackend(po.OrcParams.default(**chart_kw(po)), cfg.robots)
+    replay_multi(ob, data, own_node_factory=lambda: po.OracleBackend(po.OrcParams.default(**chart_kw(po)), 1))
     if relmeas:
+        from slide_slam_amd.synth import relmeas_keys
+        if not isinstance(relmeas, bool):
+            rel = relmeas                                   # the caller's own list (e.g. make_relmeas_dense: two different pose indices)
         assert len(rel) > 0
-        for (k, a, b, r7) in rel:
-            ob.graph.add_relative_meas(r7, k, a, k, b)     # ordinary Between factors of the joint replica
+        for (ka, a, kb, b, r7) in map(relmeas_keys, rel):
+            ob.graph.add_relative_meas(r7, ka, a, kb, b)    # ordinary Between factors of the joint replica
     ob.graph.set_relin_threshold(0.0)
     for _ in range(gn_iters):
         assert ob.graph.solve() == 0

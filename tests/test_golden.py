@@ -40,12 +40,41 @@ def test_oracle_reproduces_golden(path):
     assert [c["cyl"], c["cube"], c["point"], c["factors"]] == list(z["counts"])
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("path", FIXTURES, ids=os.path.basename)
-def test_gpu_reproduces_golden(gpu, path):
-    """Identical landmark-id associations, optimised poses <= 1e-4 relative (BASELINE.json north_star)."""
+def _expmap_outputs(path):
+    """Outputs of the same replay under the Expmap chart (tests/golden/chart_expmap_<preset>.npz, make_golden.py --chart=expmap) or None."""
+    alt = os.path.join(os.path.dirname(path), os.path.basename(path).replace("replay_", "chart_expmap_"))
+    return np.load(alt) if os.path.exists(alt) else None
+
+
+@pytest.mark.parametrize("path", [f for f in FIXTURES if "small" in f], ids=os.path.basename)
+def test_oracle_reproduces_golden_under_the_expmap_chart(path):
+    """The chart question stays open (the reference's only numeric evidence passes under Expmap, its comment names Cayley):
+    both charts are pinned by fixtures.  The two charts' replays are NOT the same numbers (iSAM2's relinearisation threshold leaves
+    second-order terms of the retraction in the estimate), so a chart mix-up cannot pass."""
+    from oracle import pyoracle as po
     z, log = _load(path)
-    gb = gpu.SlideBackend(gpu.default_params(), 1)
+    ze = _expmap_outputs(path)
+    assert ze is not None
+    ob = po.OracleBackend(po.OrcParams.default(pose_chart=po.CHART_EXPMAP), 1)
+    out = replay_single(ob, log)
+    _check(out, ze, 1e-9)
+    assert np.abs(ze["pose7"] - z["pose7"]).max() > 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chart", ["cayley", "expmap"])
+@pytest.mark.parametrize("path", FIXTURES, ids=os.path.basename)
+def test_gpu_reproduces_golden(gpu, path, chart):
+    """Identical landmark-id associations, optimised poses <= 1e-4 relative (BASELINE.json north_star) — under BOTH Pose3 charts
+    (SLIDE_CHART_CAYLEY: what cubeFactor.h:96-97 names, the default; SLIDE_CHART_EXPMAP: GTSAM_POSE3_EXPMAP builds)."""
+    z, log = _load(path)
+    kw = {}
+    if chart == "expmap":
+        z = _expmap_outputs(path)
+        if z is None:
+            pytest.skip("no Expmap fixture for this preset")
+        kw = dict(pose_chart=gpu.api.CHART_EXPMAP)
+    gb = gpu.SlideBackend(gpu.default_params(**kw), 1)
     out = replay_single(gb, log)
     _check(out, z, 1e-4)
     c = gb.counts()
