@@ -735,7 +735,7 @@ __global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int 
 // Exit condition every wave reaches: polls are bounded; a workgroup that gives up raises status bit 2 and the launch's abort word,
 // which every other poll loop checks.
 struct LLSys { double* S; double* Ld; double* Winv; int* status; int* flags; int ld, T, B0, nbr, frows; };
-struct LLTask { int sys, k, kind, it0, it1, clo_d, clo0, clo1; };      // kind 0: chain task (tile row it0), 1: tile task (rows it0, it1 or -1)
+struct LLTask { int sys, k, kind, it0, it1, clo_d, clo0, clo1; };      // kind 0: chain task (tile row it0), 1: tile task (rows it0, it1 or -1), 2: follower chain task (row it0; factors D_k for itself)
 constexpr int LL_SPIN_MAX = 1 << 19;
 
 // Copies of a_worker_wave / panel_rows for the persistent kernel (the step kernels' own stay byte for byte what round 3 measured: their
@@ -811,7 +811,7 @@ __device__ __forceinline__ void ll_worker_wave(int ia, double* __restrict__ Ld, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       L.Lt[oidx(W, JQ)][r][lane] = R[JQ][r];
-      st_wt(&Ld[(size_t)(16 * JQ + lk + 4 * r) * NB + 16 * W + lr], R[JQ][r]);
+      if (ia == 0) st_wt(&Ld[(size_t)(16 * JQ + lk + 4 * r) * NB + 16 * W + lr], R[JQ][r]);
     }
     lds_post(&L.col_done[W], JQ + 1, lane);
     // rank-16 updates of the other sub-tiles right of this phase
@@ -826,7 +826,7 @@ __device__ __forceinline__ void ll_worker_wave(int ia, double* __restrict__ Ld, 
       for (int r = 0; r < 4; ++r) {
         const double v = (lk + 4 * r >= lr) ? Wt[r] : 0.0;      // Wt lane (lr, lk) reg r = (L_JQ,JQ^-1)[lk + 4r][lr]
         L.Wi[JQ][lr * 16 + lk + 4 * r] = v;
-        st_wt(&Winv[(size_t)JQ * 256 + lr * 16 + lk + 4 * r], v);
+        if (ia == 0) st_wt(&Winv[(size_t)JQ * 256 + lr * 16 + lk + 4 * r], v);
       }
       lds_post(&L.w_done, JQ + 1, lane);
     }
@@ -851,7 +851,7 @@ __device__ __forceinline__ void ll_worker_wave(int ia, double* __restrict__ Ld, 
       for (int r = 0; r < 4; ++r) {
         const double v = (lk + 4 * r >= lr) ? Wt[r] : 0.0;
         L.Wi[JQ][lr * 16 + lk + 4 * r] = v;
-        st_wt(&Winv[(size_t)JQ * 256 + lr * 16 + lk + 4 * r], v);
+        if (ia == 0) st_wt(&Winv[(size_t)JQ * 256 + lr * 16 + lk + 4 * r], v);
       }
       lds_post(&L.w_done, JQ + 1, lane);
     }
@@ -971,7 +971,10 @@ __device__ __forceinline__ bool ll_wait_cols(const int* f0, const int* f1, int s
       __builtin_amdgcn_s_sleep(2);
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // No acquire-side invalidation (buffer_inv sc1) here: every tile has ONE writer and no workgroup reads it before its flag, so no cache
+  // of the reading CU / XCD can hold a line of it from before the write (tools/tile_hop_bench.hip: stale values only with a read ahead
+  // of the flag) — and the invalidation empties the XCD's L2 under every other workgroup's operands.
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
   return ok;
 }
 // sixteen rows (16 q ..) of tile row `it` of column k in the T-layout of panel_rows: Tq[b][r] = A[16 q + lr][16 b + lk + 4 r]
@@ -1008,8 +1011,52 @@ __device__ __forceinline__ void ll_diag_term(const double* __restrict__ S, int l
   }
 }
 
+// The older pending panels of a chain task (c < k-1), one at a time through LDS by the WHOLE workgroup: every wave loads eight columns of
+// tile (k, c) in full-line runs and the sixteen values of its own rows of tile (it, c), the tile is staged in L.Pk (what the pending
+// panel k-1 uses afterwards), the factor waves update their sub-tile row of D with both operands from LDS, the row waves their rows of
+// tile (it, k).  (Operands straight from memory — one 128-byte run per MFMA operand — cost ~50 us per term under the flood of
+// acquire-side invalidations of a persistent launch: tools/ll_trace.py.)  All waves of the workgroup call this together (barriers).
+__device__ __forceinline__ void ll_chain_presum(const double* __restrict__ S, int ld, int k, int it, int c_lo_d, int c_lo_row, int c_end, ALds& L,
+                                                int wave, int lane, bool factor, int w, bool rows, int q, v4d (&R)[4], v4d (&Tq)[4]) {
+  const int lr = lane & 15, lk = lane >> 4;
+  for (int c = c_lo_d; c < c_end; ++c) {
+    constexpr int NC = 8;
+    const double* pq = S + (size_t)(c * NB + NC * wave) * ld + (size_t)k * NB + lane;
+    double stage[NC];
+#pragma unroll
+    for (int e = 0; e < NC; ++e) stage[e] = pq[(size_t)e * ld];
+    const bool row_on = rows && c >= c_lo_row;
+    double ta[16];
+    if (row_on) {
+      const double* pi = S + (size_t)(c * NB) * ld + (size_t)it * NB + 16 * q + lr;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) ta[ks] = pi[(size_t)(4 * ks + lk) * ld];
+    }
+    __syncthreads();                      // (everybody is through with the previous panel in L.Pk)
+#pragma unroll
+    for (int e = 0; e < NC; ++e) L.Pk[NC * wave + e][lane] = stage[e];
+    __syncthreads();
+    if (factor) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const double w0 = L.Pk[4 * ks + lk][16 * w + lr];
+#pragma unroll
+        for (int J = 0; J < 4; ++J)
+          if (J <= w) R[J] = mfma_f64(-L.Pk[4 * ks + lk][16 * J + lr], w0, R[J]);
+      }
+    }
+    if (row_on) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) Tq[bb] = mfma_f64(-L.Pk[4 * ks + lk][16 * bb + lr], ta[ks], Tq[bb]);
+    }
+  }
+  __syncthreads();                        // (L.Pk is free for the pending panel k-1)
+}
+
 // ---- tile task: tile rows it0 (waves 0..3) and it1 (waves 4..7; -1: none) of column k ----
-__device__ __forceinline__ void ll_tile_task(const LLSys& Y, const LLTask& tk, int* ctl, int* tr) {
+__device__ __forceinline__ void ll_tile_task(const LLSys& Y, const LLTask& tk, ALds& L, int* ctl, int* tr) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
@@ -1018,23 +1065,32 @@ __device__ __forceinline__ void ll_tile_task(const LLSys& Y, const LLTask& tk, i
   const int clo = slot ? tk.clo1 : tk.clo0;
   const int k = tk.k, ld = Y.ld, fr = Y.frows;
   double* S = Y.S;
-  if (it >= 0) {
-    v4d Tq[4];
-    ll_rows_load(S, ld, k, it, q, lr, lk, Tq);
-    const int* fk = Y.flags + k;
-    const int* fi = Y.flags + it;
-    if (clo < k - 1) {
-      ll_wait_cols(fk, fi, fr, clo, k - 1, ctl, Y.status);
-      for (int c = clo; c < k - 1; ++c) ll_rows_term(S, ld, k, it, q, c, lr, lk, Tq);
+  const int* fk = Y.flags + k;
+  v4d Tq[4];
+  if (it >= 0) ll_rows_load(S, ld, k, it, q, lr, lk, Tq);
+  // sums over the finished columns, the tile (k, c) both rows share staged through LDS by the whole workgroup (ll_chain_presum); wave 0
+  // polls the flags for everybody: first all columns but the last (through long ago), then the last one
+  const int cmin = tk.it1 >= 0 ? min(tk.clo0, tk.clo1) : tk.clo0;
+  for (int half = 0; half < 2; ++half) {
+    const int c0 = half ? max(cmin, k - 1) : cmin, c1 = half ? k : k - 1;
+    if (c0 >= c1) continue;
+    if (wave == 0) {
+      ll_wait_cols(fk, nullptr, fr, c0, c1, ctl, Y.status);
+      if (max(tk.clo0, c0) < c1) ll_wait_cols(Y.flags + tk.it0, nullptr, fr, max(tk.clo0, c0), c1, ctl, Y.status);
+      if (tk.it1 >= 0 && max(tk.clo1, c0) < c1) ll_wait_cols(Y.flags + tk.it1, nullptr, fr, max(tk.clo1, c0), c1, ctl, Y.status);
     }
-    if (clo <= k - 1) {
-      ll_wait_cols(fk, fi, fr, k - 1, k, ctl, Y.status);
-      ll_rows_term(S, ld, k, it, q, k - 1, lr, lk, Tq);
-    }
-    // L_kk: the off-diagonal 16x16 sub-tiles (Ld) and the 16x16 inverses (Winv) the chain task of this column published
-    if (wave == 0) ll_time(tr, 10);                         // (tile task: the sums over the finished columns are through)
+    __syncthreads();
+    v4d Rdummy[4];
+    ll_chain_presum(S, ld, k, it, c0, clo, c1, L, wave, lane, false, 0, it >= 0, q, Rdummy, Tq);
+  }
+  if (wave == 0) {
+    ll_time(tr, 10);                         // (tile task: the sums over the finished columns are through)
     ll_wait_cols(fk, nullptr, fr, k, k + 1, ctl, Y.status);
-    if (wave == 0) ll_time(tr, 15);
+    ll_time(tr, 15);
+  }
+  __syncthreads();
+  if (it >= 0) {
+    // L_kk: the off-diagonal 16x16 sub-tiles (Ld) and the 16x16 inverses (Winv) the chain task of this column published
     const double* Ldk = Y.Ld + (size_t)k * NB * NB;
     const double* Wk = Y.Winv + (size_t)k * 1024;
     double wi[4][4], lt[6][4];
@@ -1081,7 +1137,7 @@ __device__ __forceinline__ void ll_tile_task(const LLSys& Y, const LLTask& tk, i
 
 // ---- chain task: the diagonal block of column k and tile row it0 (step_type_a_impl behind a flag instead of a kernel boundary) ----
 template <int NPAN>
-__device__ __forceinline__ void ll_chain_task(const LLSys& Y, const LLTask& tk, ALds& L, int* ctl, int* tr) {
+__device__ __forceinline__ void ll_chain_task(const LLSys& Y, const LLTask& tk, ALds& L, int& row_ok, int* ctl, int* tr) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..7
   const int lr = lane & 15, lk = lane >> 4;
@@ -1092,9 +1148,11 @@ __device__ __forceinline__ void ll_chain_task(const LLSys& Y, const LLTask& tk, 
   const int* fk = Y.flags + k;
   const int* fi = Y.flags + it;
   const bool row_prev = tk.clo0 <= k - 1;        // tile (it, k-1) exists (else its contribution is zero)
+  const int ia = tk.kind == 0 ? 0 : 1;           // 0: the column's LEAD chain task publishes L_kk's pieces; followers (kind 2) factor the block for themselves only
   if (tid == 0) L.it_done = 0;
   if (tid < 4) { L.col_done[tid] = 0; L.d_ready[tid] = 0; }
   if (tid == 4) L.w_done = 0;
+  if (tid == 5) row_ok = 0;
   const int kold = k - 1;                        // panels c < kold are summed left-looking before the pending panel k-1 arrives
   if (wave < 4) {
     // ---------------- factor waves: own sub-tile row of D ----------------
@@ -1107,19 +1165,25 @@ __device__ __forceinline__ void ll_chain_task(const LLSys& Y, const LLTask& tk, 
     v4d Tq[4];
     double tb[16];
     if (wave == 1) ll_rows_load(S, ld, k, it, 0, lr, lk, Tq);
+    // ONE wave of the workgroup polls (wave 0 the panels' flags, wave 4 — otherwise idle — the own rows' last flag), the others wait at
+    // a barrier: eight polling waves per workgroup and ~170 workgroups per block column load the memory-side path that the flags and the
+    // tiles themselves travel on
     if (tk.clo_d < kold) {
-      ll_wait_cols(fk, nullptr, fr, tk.clo_d, kold, ctl, Y.status);
-      for (int c = tk.clo_d; c < kold; ++c) ll_diag_term(S, ld, k, wave, c, lr, lk, R);
-    }
-    if (wave == 1 && tk.clo0 < kold) {
-      ll_wait_cols(fi, nullptr, fr, tk.clo0, kold, ctl, Y.status);
-      for (int c = tk.clo0; c < kold; ++c) ll_rows_term(S, ld, k, it, 0, c, lr, lk, Tq);
+      if (wave == 0) {
+        ll_wait_cols(fk, nullptr, fr, tk.clo_d, kold, ctl, Y.status);
+        if (tk.clo0 < kold) ll_wait_cols(fi, nullptr, fr, tk.clo0, kold, ctl, Y.status);      // (tile (it, c) exists from column clo0 on only)
+      }
+      __syncthreads();
+      ll_chain_presum(S, ld, k, it, tk.clo_d, tk.clo0, kold, L, wave, lane, true, wave, wave == 1, 0, R, Tq);
     }
     if (wave == 0) ll_stage(tr, 2);
     if (NPAN > 0) {
       // the pending panel: tile (k, k-1), the previous chain task's own tile — the one flag the chain waits for
-      ll_wait_cols(fk, nullptr, fr, k - 1, k, ctl, Y.status);
-      if (wave == 0) ll_time(tr, 14);
+      if (wave == 0) {
+        ll_wait_cols(fk, nullptr, fr, k - 1, k, ctl, Y.status);
+        ll_time(tr, 14);
+      }
+      __syncthreads();
       constexpr int NC = 8;
       const double* pq = S + (size_t)((k - 1) * NB + NC * wave) * ld + (size_t)k * NB + lane;
       double stage[NC];
@@ -1133,14 +1197,14 @@ __device__ __forceinline__ void ll_chain_task(const LLSys& Y, const LLTask& tk, 
     if (wave == 0) ll_stage(tr, 3);
     if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);   // ahead of the panel wave sharing the SIMD
     if (wave == 0) {
-      a_chain_wave<NPAN>(0, Y.status, L, lane, R[0]);
+      a_chain_wave<NPAN>(ia, Y.status, L, lane, R[0]);
     } else if (wave == 1) {
       v4d R1[2] = {R[0], R[1]};
-      ll_worker_wave<1, NPAN>(0, Ld, Winv, L, lane, R1);
+      ll_worker_wave<1, NPAN>(ia, Ld, Winv, L, lane, R1);
       if (NPAN > 0) {
         // the own rows of tile (it, k-1) — a TILE task of column k-1, through some microseconds after that column's chain task: waited
         // for here, not in front of the chain
-        if (row_prev) ll_wait_cols(fi, nullptr, fr, k - 1, k, ctl, Y.status);
+        if (row_prev) lds_wait(&row_ok, 1);
         const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)it * NB + lr;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) tb[ks] = row_prev ? pi[(size_t)(4 * ks + lk) * ld] : 0.0;
@@ -1148,9 +1212,9 @@ __device__ __forceinline__ void ll_chain_task(const LLSys& Y, const LLTask& tk, 
       ll_panel_rows<NPAN, false>(S, ld, k, it, 0, 0, lane, L, Tq, tb, nullptr);
     } else if (wave == 2) {
       v4d R2[3] = {R[0], R[1], R[2]};
-      ll_worker_wave<2, NPAN>(0, Ld, Winv, L, lane, R2);
+      ll_worker_wave<2, NPAN>(ia, Ld, Winv, L, lane, R2);
     } else {
-      ll_worker_wave<3, NPAN>(0, Ld, Winv, L, lane, R);
+      ll_worker_wave<3, NPAN>(ia, Ld, Winv, L, lane, R);
     }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1164,15 +1228,14 @@ __device__ __forceinline__ void ll_chain_task(const LLSys& Y, const LLTask& tk, 
     const bool rows = q > 0;
     v4d Tq[4];
     double tb[16];
-    if (rows) {
-      ll_rows_load(S, ld, k, it, q, lr, lk, Tq);
-      if (tk.clo0 < kold) {
-        ll_wait_cols(fk, fi, fr, tk.clo0, kold, ctl, Y.status);
-        for (int c = tk.clo0; c < kold; ++c) ll_rows_term(S, ld, k, it, q, c, lr, lk, Tq);
-      }
+    if (rows) ll_rows_load(S, ld, k, it, q, lr, lk, Tq);
+    if (tk.clo_d < kold) {
+      v4d Rdummy[4];
+      __syncthreads();                      // (wave 0 has seen the older panels' flags)
+      ll_chain_presum(S, ld, k, it, tk.clo_d, tk.clo0, kold, L, wave, lane, false, 0, rows, q, Rdummy, Tq);
     }
     if (NPAN > 0) {
-      ll_wait_cols(fk, nullptr, fr, k - 1, k, ctl, Y.status);
+      __syncthreads();                      // (wave 0 has seen the flag of tile (k, k-1))
       constexpr int NC = 8;
       const double* pq = S + (size_t)((k - 1) * NB + NC * wave) * ld + (size_t)k * NB + lane;
       double stage[NC];
@@ -1183,8 +1246,12 @@ __device__ __forceinline__ void ll_chain_task(const LLSys& Y, const LLTask& tk, 
     }
     ll_mark_or(tr, 4, 1 << wave);
     __syncthreads();
+    if (NPAN > 0 && row_prev && wave == 4) {      // the poller of the own rows' last flag
+      ll_wait_cols(fi, nullptr, fr, k - 1, k, ctl, Y.status);
+      lds_post(&row_ok, 1, lane);
+    }
     if (NPAN > 0 && rows) {      // (the own rows of tile (it, k-1): see worker 1)
-      if (row_prev) ll_wait_cols(fi, nullptr, fr, k - 1, k, ctl, Y.status);
+      if (row_prev) lds_wait(&row_ok, 1);
       const double* pi = S + (size_t)((k - 1) * NB) * ld + (size_t)it * NB + 16 * q + lr;
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) tb[ks] = row_prev ? pi[(size_t)(4 * ks + lk) * ld] : 0.0;
@@ -1195,7 +1262,7 @@ __device__ __forceinline__ void ll_chain_task(const LLSys& Y, const LLTask& tk, 
     __syncthreads();
   }
   if (tid == 0) {
-    __hip_atomic_store(Y.flags + (size_t)k * fr + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ia == 0) __hip_atomic_store(Y.flags + (size_t)k * fr + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(Y.flags + (size_t)k * fr + it, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (wave == 0) ll_stage(tr, 5);
@@ -1204,7 +1271,7 @@ __device__ __forceinline__ void ll_chain_task(const LLSys& Y, const LLTask& tk, 
 // ctl[0]: ticket counter, ctl[1]: abort word (both cleared with the flags before the launch); trace: null, or 16 host-pinned ints per task
 __global__ __launch_bounds__(512) void k_chol_ll(const LLSys* __restrict__ sysv, const LLTask* __restrict__ tasks, int n_tasks, int* ctl, int* trace) {
   __shared__ ALds L;
-  __shared__ int s_t;
+  __shared__ int s_t, s_row_ok;
   if (threadIdx.x == 0) s_t = atomicAdd(&ctl[0], 1);
   __syncthreads();
   const int t = __builtin_amdgcn_readfirstlane(s_t);
@@ -1213,11 +1280,11 @@ __global__ __launch_bounds__(512) void k_chol_ll(const LLSys* __restrict__ sysv,
   const LLSys Y = sysv[tk.sys];
   int* tr = trace ? trace + 16 * (size_t)t : nullptr;
   if (tr && threadIdx.x == 0) { ll_mark(tr, 1, tk.kind); ll_mark(tr, 2, tk.k); ll_mark(tr, 3, tk.it0); ll_stage(tr, 1); }
-  if (tk.kind == 0) {
-    if (tk.clo_d <= tk.k - 1) ll_chain_task<1>(Y, tk, L, ctl, tr);
-    else ll_chain_task<0>(Y, tk, L, ctl, tr);
+  if (tk.kind != 1) {
+    if (tk.clo_d <= tk.k - 1) ll_chain_task<1>(Y, tk, L, s_row_ok, ctl, tr);
+    else ll_chain_task<0>(Y, tk, L, s_row_ok, ctl, tr);
   } else {
-    ll_tile_task(Y, tk, ctl, tr);
+    ll_tile_task(Y, tk, L, ctl, tr);
   }
 }
 
@@ -2273,6 +2340,14 @@ struct CholLLPlan {
   int n_sys = 0, n_tasks = 0, n_ints = 0, n_chain = 0, max_cols = 0;
 };
 CholLLPlan* chol_ll_plan_create(const CholSystem* d, int n, const int* const* h_ord, hipStream_t up) {
+  // SLIDE_LL_MODE: how the rows of a column beyond the chain task's own are factored.  0: tile tasks (wait for the published L_kk, blocked
+  // substitution; two tile rows per workgroup); 1: FOLLOWER chain tasks — every tile row its own workgroup that factors the diagonal
+  // block redundantly beside the lead (the type-A workgroups of the step kernels): no row lags the chain by a hand-over + substitution,
+  // at the price of a CU per row for the length of the chain; 2: followers for systems with a profile (bands) and for short dense ones
+  // (T <= 8), tile tasks for long dense ones
+  // 3: followers for the band's own tile rows, tile tasks for border rows.  Measured (profiles/r04_ll_experiments.txt): 0 is the fastest
+  // on the cut bands of C4 (0.775 ms against 0.98 / 0.84 for 1 / 3) — and none beats the step kernels (0.52 ms)
+  static const int ll_mode = getenv("SLIDE_LL_MODE") ? atoi(getenv("SLIDE_LL_MODE")) : 0;
   std::vector<LLSys> sys(n);
   std::vector<std::vector<int>> first(n), bf(n), bphys(n), profv(n);
   size_t n_ints = 16;                                   // [0] ticket counter, [1] abort word; flags from 16 on
@@ -2316,6 +2391,19 @@ CholLLPlan* chol_ll_plan_create(const CholSystem* d, int n, const int* const* h_
         if (pass == 0) {
           tasks.push_back(LLTask{i, k, 0, rows[0].first, -1, fk, rows[0].second, k});
           ++n_chain;
+        } else if (ll_mode == 1 || (ll_mode == 2 && (d[i].h_prof != nullptr || d[i].T <= 8))) {      // (bands, and short dense systems: few older panels per row)
+          for (size_t r = 1; r < rows.size(); ++r) tasks.push_back(LLTask{i, k, 2, rows[r].first, -1, fk, rows[r].second, k});
+        } else if (ll_mode == 3) {
+          // followers for the BAND's tile rows (the next chain tasks' own rows come from them: no row of the diagonal chain then lags a
+          // column's chain by a hand-over + substitution), tile tasks for the border rows and the right-hand side (nobody on the chain
+          // waits for those)
+          const size_t nband = (size_t)std::max(0, profv[i][k] - k);
+          size_t r = 1;
+          for (; r < rows.size() && r <= nband; ++r) tasks.push_back(LLTask{i, k, 2, rows[r].first, -1, fk, rows[r].second, k});
+          for (; r < rows.size(); r += 2) {
+            const bool two = r + 1 < rows.size();
+            tasks.push_back(LLTask{i, k, 1, rows[r].first, two ? rows[r + 1].first : -1, fk, rows[r].second, two ? rows[r + 1].second : k});
+          }
         } else {
           for (size_t r = 1; r < rows.size(); r += 2) {
             const bool two = r + 1 < rows.size();
@@ -2348,10 +2436,10 @@ CholLLPlan* chol_ll_plan_create(const CholSystem* d, int n, const int* const* h_
     };
     bool good = true;
     for (const LLTask& t : tasks) {
-      if (t.kind == 0) {
+      if (t.kind != 1) {
         for (int c = t.clo_d; c < t.k && good; ++c) good = need(t, c, t.k);
         for (int c = t.clo0; c < t.k && good; ++c) good = need(t, c, t.it0) && need(t, c, t.k);
-        good = good && t.clo_d >= 0 && t.clo0 >= t.clo_d && raise(t, t.k) && raise(t, t.it0);
+        good = good && t.clo_d >= 0 && t.clo0 >= t.clo_d && (t.kind != 0 || raise(t, t.k)) && raise(t, t.it0);
       } else {
         for (int sl = 0; sl < 2 && good; ++sl) {
           const int it = sl ? t.it1 : t.it0, clo = sl ? t.clo1 : t.clo0;

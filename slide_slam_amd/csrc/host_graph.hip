@@ -391,6 +391,7 @@ static CholSystem chol_system_of(const GraphDev& G, bool joint, float* L32, cons
   c.h_bfirst = (G.arrow && G.nbr > 0) ? h_bfirst : nullptr;
   return c;
 }
+static int chol_ll_mask();
 static bool chol_ll_enabled();
 CholBatch::CholBatch(int n_) : n(n_ < 1 ? 1 : (n_ > 8 ? 8 : n_)), sys(n), ev_in(n, nullptr), bufs(n, nullptr), graphs(n, nullptr) {}
 void CholBatch::set_graph(int slot, HostGraph* g) {
@@ -656,19 +657,22 @@ int CholBatch::prepare_pass() {
     if ((int)seg_sys.size() > 8 * CHOL_BATCH_HOST_MAX || (int)l2_sys.size() > CHOL_BATCH_HOST_MAX) { g_last_error = "exact joint step: too many segment systems"; return SLIDE_ERR_CAPACITY; }
     if (chol_ll_enabled()) {
       SL_HIP(hipStreamSynchronize(master));
-      ll_seg = chol_ll_plan_create(seg_sys.data(), (int)seg_sys.size(), seg_hord.data(), master);
-      if (!l2_sys.empty()) ll_l2 = chol_ll_plan_create(l2_sys.data(), (int)l2_sys.size(), nullptr, master);
-      if (!ll_seg || (!l2_sys.empty() && !ll_l2)) { g_last_error = "exact joint step: the left-looking factorisation's tables could not be allocated"; return SLIDE_ERR_HIP; }
+      if (chol_ll_mask() & 1) ll_seg = chol_ll_plan_create(seg_sys.data(), (int)seg_sys.size(), seg_hord.data(), master);
+      if (!l2_sys.empty() && (chol_ll_mask() & 2)) ll_l2 = chol_ll_plan_create(l2_sys.data(), (int)l2_sys.size(), nullptr, master);
+      if (((chol_ll_mask() & 1) && !ll_seg) || (!l2_sys.empty() && (chol_ll_mask() & 2) && !ll_l2)) { g_last_error = "exact joint step: the left-looking factorisation's tables could not be allocated"; return SLIDE_ERR_HIP; }
     }
     return prepare_separator();
   }
   return SLIDE_OK;
 }
 // ---- exact joint step: the separator system of all shared landmarks -------------------------------------------------------------------
-static bool chol_ll_enabled() {
-  static const bool on = getenv("SLIDE_CHOL_LL") && getenv("SLIDE_CHOL_LL")[0] == '1';      // (opt-in until validated on the GPU)
-  return on;
+// SLIDE_CHOL_LL: bit mask of the levels of an exact joint pass that run the left-looking persistent factorisation (k_chol_ll) instead
+// of one step launch per block column — 1: the bands' segments, 2: the bands' second level, 4: the separator's leaves, 8: its top block
+static int chol_ll_mask() {
+  static const int m = getenv("SLIDE_CHOL_LL") ? atoi(getenv("SLIDE_CHOL_LL")) : 0;      // (opt-in until measured)
+  return m;
 }
+static bool chol_ll_enabled() { return chol_ll_mask() != 0; }
 void CholBatch::free_ll_band_plans() {
   for (CholLLPlan** p : {&ll_seg, &ll_l2}) if (*p) { if (master) (void)hipStreamSynchronize(master); chol_ll_plan_destroy(*p); *p = nullptr; }
 }
@@ -902,9 +906,9 @@ int CholBatch::prepare_separator() {
   free_ll_sep_plans();
   if (chol_ll_enabled() && sep_Ts > 0) {
     const CholSystem top = sep_top_system();
-    ll_top = chol_ll_plan_create(&top, 1, nullptr, master);
-    bool ok = ll_top != nullptr;
-    if (sep_dissected()) {
+    bool ok = true;
+    if (chol_ll_mask() & 8) { ll_top = chol_ll_plan_create(&top, 1, nullptr, master); ok = ll_top != nullptr; }
+    if (sep_dissected() && (chol_ll_mask() & 4)) {
       CholSystem lv[2];
       sep_leaf_systems(lv);
       ll_leaves = chol_ll_plan_create(lv, 2, nullptr, master);
@@ -1215,7 +1219,11 @@ int CholBatch::enqueue_pass(double* const* d_bufs, hipEvent_t e0, hipEvent_t e1,
   }
   return rc;
 }
+// One capture at a time in the process: batches driven by different host threads (the ranks-as-threads rehearsal) capture their passes
+// thread-locally, but concurrent captures were seen to fail on this stack ("stream capture failed"); a capture takes milliseconds, once.
+static std::mutex g_capture_mtx;
 int CholBatch::capture_pass(double* const* d_bufs, int part, hipGraphExec_t* exec) {
+  std::lock_guard<std::mutex> cap(g_capture_mtx);
   if (*exec) { (void)hipGraphExecDestroy(*exec); *exec = nullptr; }
   hipGraph_t graph = nullptr;
   SL_HIP(hipStreamBeginCapture(master, hipStreamCaptureModeThreadLocal));
@@ -1224,7 +1232,7 @@ int CholBatch::capture_pass(double* const* d_bufs, int part, hipGraphExec_t* exe
   if (rc != SLIDE_OK || e != hipSuccess || graph == nullptr) {
     (void)hipGetLastError();
     if (graph) (void)hipGraphDestroy(graph);
-    g_last_error = "batched pass: stream capture failed";
+    g_last_error = std::string("batched pass: stream capture failed (") + hipGetErrorString(e) + ", enqueue rc " + std::to_string(rc) + ")";
     return rc != SLIDE_OK ? rc : SLIDE_ERR_HIP;
   }
   const hipError_t ei = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
@@ -1497,8 +1505,15 @@ int CholBatch::pass_part(double* const* d_bufs, int part) {
     return SLIDE_ERR_INVALID;
   }
   if (exact && !sep_x) { g_last_error = "exact joint step: a cut pass needs the caller's separator exchange buffer (slide_chol_batch_set_exact_joint)"; return SLIDE_ERR_INVALID; }
-  if (!part_exec[slot] && (rc = capture_pass(d_bufs, part, &part_exec[slot])) != SLIDE_OK) return rc;
-  SL_HIP(hipGraphLaunch(part_exec[slot], master));
+  // SLIDE_PASS_DIRECT=1: the part's launches issued directly instead of a replayed hipGraph (several host threads driving batches of one
+  // process side by side — the ranks-as-threads rehearsal: stream captures of concurrent threads fail on this stack)
+  static const bool direct = getenv("SLIDE_PASS_DIRECT") && getenv("SLIDE_PASS_DIRECT")[0] == '1';
+  if (direct) {
+    if ((rc = enqueue_pass(d_bufs, nullptr, nullptr, part)) != SLIDE_OK) return rc;
+  } else {
+    if (!part_exec[slot] && (rc = capture_pass(d_bufs, part, &part_exec[slot])) != SLIDE_OK) return rc;
+    SL_HIP(hipGraphLaunch(part_exec[slot], master));
+  }
   last_part = part;
   return part == 2 ? end_pass() : SLIDE_OK;
 }
@@ -2193,6 +2208,7 @@ int HostGraph::run_update(double relin_thr, int iterations) {
   if (use_graph && !(gexec && std::memcmp(&G_cap, &G, sizeof(GraphDev)) == 0)) {
     if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
     hipGraph_t graph = nullptr;
+    std::lock_guard<std::mutex> cap(g_capture_mtx);
     SL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = enqueue_iteration(env_look);
     const hipError_t e = hipStreamEndCapture(s, &graph);
@@ -2395,6 +2411,7 @@ int HostGraph::launch_phase(int phase, double* d_buf) {
   if (use_graph && !(pg.exec && pg.buf == d_buf && std::memcmp(&pg.G, &G, sizeof(GraphDev)) == 0)) {
     if (pg.exec) { (void)hipGraphExecDestroy(pg.exec); pg.exec = nullptr; }
     hipGraph_t graph = nullptr;
+    std::lock_guard<std::mutex> cap(g_capture_mtx);
     SL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = enqueue_phase(phase, d_buf);
     const hipError_t e = hipStreamEndCapture(s, &graph);

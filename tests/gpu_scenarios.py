@@ -439,6 +439,7 @@ def rank_threads(out, preset="C4", world=8, passes=3, relmeas=0, mode="ingest"):
     at its exchanges exactly as a multi-process job cuts it (rank-owned leaves of the separator, the half's all-reduce among its
     ranks, one leader per half) — against ONE process holding all robots."""
     os.environ["SLIDE_NONBLOCKING_STREAMS"] = "1"      # several host threads capture and copy side by side (HostGraph::init)
+    os.environ["SLIDE_PASS_DIRECT"] = "1"              # ... and their passes are issued directly, not as replayed hipGraphs (CholBatch::pass_part)
     import torch
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
