@@ -252,7 +252,7 @@ def _pmc_traffic(kernel, **match):
     """HBM-side bytes per launch of `kernel` from the committed PMC summaries (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     passes, gfx950 corrections applied; a PMC pass cannot run inside the timed bench): newest round first."""
     pdir = os.path.join(ROOT, "profiles")
-    for rnd in ("r03", "r02_dense", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02_dense", "r02", "r01"):
         for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
             if not (name.startswith(rnd + "_pmc_traffic") and name.endswith(".json")):
                 continue
@@ -458,7 +458,7 @@ def main():
         if getattr(drv, "sep_owner", None) is not None:
             _segs = [s.CholBatch.sep_segment(info["sep_dim"], info.get("n_relmeas", 0), _blk[0], _blk[1], w) for w in range(3)]
             info["sep_owned"] = dict(leaf=drv.sep_owner["leaf"], leaf_bytes=8 * _segs[drv.sep_owner["leaf"]][1] if len(drv.sep_owner["half_ranks"]) > 1 else 0,
-                                     top_bytes=8 * _segs[2][1])
+                                     top_bytes=8 * _segs[2][1], rounds_inside_half=len(drv._pair_groups) - 1)
         if sync_coll:
             drv.stream_ordered = False
         if os.environ.get("SLIDE_BENCH_FORCE_PARTS") == "1":      # rehearsal of the N > 1 control flow (cut pass + RCCL on the batch's stream) on one rank
@@ -841,9 +841,11 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
                         (f"all-reduce x1 per pass: the packed separator system of the {n_slots} shared-landmark slots "
                          f"({info.get('sep_dim')} coordinates, {info.get('sep_exchange_bytes')} B)" if not info.get("sep_owned") else
                          f"the ranks split in two halves along the dissection of the separator system ({info.get('sep_dim')} coordinates over "
-                         f"{n_slots} shared-landmark slots), every rank factors the leaf its half's robots see: all-reduce of that leaf's segment "
-                         f"within the half ({info['sep_owned']['leaf_bytes']} B; none when the half is one rank) + all-reduce of the top block over "
-                         f"all ranks ({info['sep_owned']['top_bytes']} B) per pass, instead of the whole packed system ({info.get('sep_exchange_bytes')} B)") +
+                         f"{n_slots} shared-landmark slots), every rank factors the leaf its half's robots see; PAIRWISE exchanges only (two-rank "
+                         f"all-reduces: the sums follow one binary tree over the robot index at every rank count, bit for bit the N = 1 job's): "
+                         f"{info['sep_owned']['rounds_inside_half']} round(s) inside the half over the own leaf's segment "
+                         f"({info['sep_owned']['leaf_bytes']} B) and the top block's ({info['sep_owned']['top_bytes']} B), then one round between the "
+                         f"halves over the top block — per pass, instead of the whole packed system ({info.get('sep_exchange_bytes')} B)") +
                         (f"; {'stream-ordered on the pass stream' if info.get('stream_ordered_collectives') else 'host-synchronous'}" if wdev > 1 else ""))
                        if info.get("sep_dim") and args.joint == "exact" else
                        ((f"{backend} " if wdev > 1 else "device-side local sum, no inter-GPU ") +
@@ -876,6 +878,21 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
                           "what": "robot 0's streaming build alone on the GPU: associate + add + iSAM2-equivalent update per frame, PCIe included"},
         "finite": finite,
     }
+    try:
+        # the same streaming build with iSAM2's bounded back-substitution (wildfire threshold 1e-3: what the reference's GTSAM runs with;
+        # off by default here — the parity tests compare exact updates)
+        from slide_slam_amd.replay import replay_single
+        from slide_slam_amd.synth import make_robot_log, make_world
+        gw = s.SlideBackend(s.default_params(pose_chart=CHART), 1)
+        gw.graph.set_wildfire(1e-3)
+        rw = replay_single(gw, make_robot_log(cfg, make_world(cfg), 0), n_frames=args.frames, collect=False)
+        tw = rw["t_frame"]
+        res["stream_replay"]["wildfire_1e-3"] = {"updates_per_s": len(tw) / max(sum(tw), 1e-9), "ms_last_frame": tw[-1] * 1e3,
+                                                 "ms_mean_last_100": float(np.mean(tw[-100:]) * 1e3), "blocks_kept": gw.graph.wildfire_stats()["kept_total"]}
+        res["stream_replay"]["ms_mean_last_100"] = float(np.mean(rep["t_frame"][-100:]) * 1e3)
+        del gw
+    except Exception as e:      # noqa: BLE001
+        res["stream_replay"]["wildfire_1e-3"] = {"error": repr(e)}
     if exact:
         d = exact[exact["dominant_by_time"]]
         res["roofline"] = {"bound": "mfma", "limited_by": d["bound"],      # (priced against the FP64 matrix pipe; "latency": a serial chain, not the pipe, sets the time)

@@ -271,6 +271,14 @@ int slide_graph_get_tile_profile(slide_graph_t* g, int* prof, int cap);
  * SLIDE_NO_INCREMENTAL=1 for the whole process) re-factors everything at every update: the same result up to the summation order of
  * the kept columns' panels. */
 int slide_graph_get_incremental_stats(slide_graph_t* g, int64_t out4[4]);
+/* iSAM2's bounded back-substitution (ISAM2GaussNewtonParams::wildfireThreshold — 1e-3 in the GTSAM 4.0.3 the reference links, used by
+ * every ISAM2::update + calculateEstimate() of SemanticFactorGraph::solve, graph.cpp:15-18, 260-272): on an incremental update a block
+ * of the reduced system below the first re-factored block column keeps the last solve's solution when every block it depends on moved
+ * by less than `threshold` (infinity norm), and so does everything below it; the chained substitution then ends there.  threshold 0 (the
+ * default): off — every update solves its linear system exactly, which is what the parity tests compare.  out2 = {blocks kept over all
+ * updates, blocks kept by the last update}. */
+int slide_graph_set_wildfire(slide_graph_t* g, double threshold);
+int slide_graph_get_wildfire_stats(slide_graph_t* g, int64_t out2[2]);
 int slide_graph_set_incremental(slide_graph_t* g, int on);
 int slide_graph_set_dense_profile(slide_graph_t* g, int on);
 /* Exact joint step: the border of this graph's reduced system — returns the number of border row tiles (64 separator coordinates each;

@@ -254,7 +254,10 @@ class SemanticFactorGraphWrapper : public SemanticFactorGraph {
       detail::to3(ellipsoids[i].model.pose.translation(), w);
       detail::to_body(curr.v, w, b);
       const double range = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
-      const double bearing[3] = {b[0] / range, b[1] / range, b[2] / range};
+      // (an ellipsoid AT the sensor: Eigen's .normalized() of the reference, graphWrapper.cpp:176-184, leaves the zero vector as it is —
+      // dividing would hand NaNs to the solve)
+      const double inv = range > 0.0 ? 1.0 / range : 0.0;
+      const double bearing[3] = {b[0] * inv, b[1] * inv, b[2] * inv};
       if (ellipsoid_matches[i] == -1) {
         addPointLandmarkKey(point_landmark_counter_, w);
         addRangeBearingFactor(pose_counter, point_landmark_counter_, bearing, range, robotID);

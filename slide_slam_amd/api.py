@@ -28,7 +28,7 @@ EXPORTS = [
     "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
     "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
-    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_chol_batch_set_pcg_tolerance", "slide_graph_set_pcg_tolerance", "slide_graph_set_separator", "slide_chol_batch_set_exact_joint", "slide_chol_batch_sep_buffer_len", "slide_chol_batch_sep_exchange_len", "slide_chol_batch_profile_exact_joint", "slide_graph_get_border_profile", "slide_graph_get_incremental_stats", "slide_graph_get_segments", "slide_graph_get_segment_table", "slide_chol_batch_set_segments", "slide_clipper_dense_clique_batch", "slide_chol_batch_set_separator_profile", "slide_chol_batch_set_separator_blocks", "slide_chol_batch_set_separator_owner", "slide_chol_batch_sep_segment", "slide_graph_set_incremental", "slide_graph_set_ghost_ids", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
+    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_chol_batch_set_pcg_tolerance", "slide_graph_set_pcg_tolerance", "slide_graph_set_separator", "slide_chol_batch_set_exact_joint", "slide_chol_batch_sep_buffer_len", "slide_chol_batch_sep_exchange_len", "slide_chol_batch_profile_exact_joint", "slide_graph_get_border_profile", "slide_graph_get_incremental_stats", "slide_graph_set_wildfire", "slide_graph_get_wildfire_stats", "slide_graph_get_segments", "slide_graph_get_segment_table", "slide_chol_batch_set_segments", "slide_clipper_dense_clique_batch", "slide_chol_batch_set_separator_profile", "slide_chol_batch_set_separator_blocks", "slide_chol_batch_set_separator_owner", "slide_chol_batch_sep_segment", "slide_graph_set_incremental", "slide_graph_set_ghost_ids", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
     "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
     "slide_dense_spd_solve", "slide_dense_spd_solve_ex", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device", "slide_assoc_sweep_batch",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
@@ -286,6 +286,15 @@ class SlideGraph:
     def set_incremental(self, on=True):
         """False: every update re-factors all block columns (the reference behaviour of round 2; same result to rounding)."""
         _check(self.L.slide_graph_set_incremental(self.h, C.c_int(int(on))))
+
+    def set_wildfire(self, threshold):
+        """iSAM2's wildfire threshold on the back-substitution of incremental updates (0: off, the default; the reference's GTSAM: 1e-3)."""
+        _check(self.L.slide_graph_set_wildfire(self.h, C.c_double(threshold)))
+
+    def wildfire_stats(self):
+        out = np.zeros(2, np.int64)
+        _check(self.L.slide_graph_get_wildfire_stats(self.h, _p(out)))
+        return dict(kept_total=int(out[0]), kept_last=int(out[1]))
 
     def incremental_stats(self):
         """Updates that re-factored a suffix of the block columns only / everything, first re-factored column of the last, block columns."""

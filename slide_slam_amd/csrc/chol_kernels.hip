@@ -1297,11 +1297,13 @@ extern "C" void slide_debug_chain_stamps(unsigned long long* out) { (void)hipMem
 // whose workgroups poll the entries of the blocks they depend on ("flag in data": one round trip per link of the chain).
 constexpr unsigned long long BWD_SENT = CHAIN_SENTINEL;      // (kernels.hpp: k_pcg_update pre-fills the forward chain's output with it)
 
-__global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, int Tr, double* __restrict__ yv, double* __restrict__ dp, int* status) {
+__global__ void k_chol_extract_y(const double* __restrict__ S, int ld, int T, int Tr, double* __restrict__ yv, double* __restrict__ dp, int* status,
+                                 double* __restrict__ prev) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0) status[4] = 0;            // ticket counter of the chained backward substitution that follows
   if (c < T * NB) {
     yv[c] = S[(size_t)c * ld + (size_t)Tr * NB];      // (Tr: tile row of the right-hand side, T + border rows)
+    if (prev) prev[c] = dp[c];                        // (bounded back-substitution: the last solve's solution, see bwd_chain_body<.., true>)
     dp[c] = __longlong_as_double((long long)BWD_SENT);
   }
 }
@@ -1346,15 +1348,30 @@ struct alignas(16) ChainLds {     // one per workgroup, shared by every instanti
   alignas(16) double tmp[3][256];
   alignas(16) double Ms[NB][NB + 1];   // M = L_cc^-1 (lower triangle), Ms[row][col]
 };
-template <bool F32>
+// BOUNDED variant (WFIRE; iSAM2's wildfire threshold, ISAM2GaussNewtonParams::wildfireThreshold = 1e-3 in GTSAM 4.0.3, which the
+// reference's ISAM2 runs with: graph.cpp:15-18, 260-272).  iSAM2 does not re-solve a clique whose parents' delta changed by less than
+// the threshold; on the block chain of the banded reduced system: block c keeps the solution of the LAST solve (wf_prev) when every
+// block it depends on (c+1 .. prof[c]) changed by less than wf_thr in the infinity norm — and, the profile being monotone, so does
+// every block below it: the first such block (walking down) raises the stop word (status[7]) and all workgroups below leave with their
+// previous values at once instead of passing the chain on hop by hop.  wf_Tprev: blocks >= it have no previous value (new key frames).
+// status[3] counts the blocks that were kept.  Off (the default): the chain always runs in full — the linear system is solved exactly.
+template <bool F32, bool WFIRE = false>
 __device__ __forceinline__ void bwd_chain_body(ChainLds& W, const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
                                                const double* __restrict__ Winv, const double* __restrict__ yv, double* dp, int* status, int bidx,
-                                               const float* __restrict__ L32, const int* __restrict__ prof) {
+                                               const float* __restrict__ L32, const int* __restrict__ prof,
+                                               const double* __restrict__ wf_prev = nullptr, double wf_thr = 0.0, int wf_Tprev = 0,
+                                               int* wf_lds = nullptr) {
+  int dummy_state = 0;
+  int& wf_state = WFIRE ? *wf_lds : dummy_state;      // (LDS word of the bounded kernel) 0: compute, 1: a block above raised the stop word, 2: all inputs quiet (this block raises it)
   auto& Ms = W.Ms; auto& Lo = W.Lo; auto& Ws = W.Ws; auto& tmp = W.tmp; auto& xs = W.xs; auto& ys = W.ys;
   const int tid = threadIdx.x;
   const bool worker = tid < 256;                       // waves 0..3: the tiles; wave 4 only polls (see CHAIN_THREADS)
   CSTAMP(0);
   const int c = T - 1 - bidx;
+  if (WFIRE) {
+    if (tid == 0) wf_state = 0;
+    __syncthreads();
+  }
   const int col = tid >> 2, part = tid & 3;            // tile work: column col, rows 16 part .. 16 part + 15
   const int jtop = prof ? prof[c] : T - 1;             // last tile row of column c inside the factor's profile (dense: T - 1)
   const int nj = jtop - c;                             // tiles (j, c), j = jtop-q, q = 0 .. nj-1
@@ -1432,21 +1449,25 @@ __device__ __forceinline__ void bwd_chain_body(ChainLds& W, const double* __rest
 #pragma unroll
   for (int r = 0; r < 16; ++r) mreg[r] = (worker && 16 * part + r >= col) ? Ms[16 * part + r][col] : 0.0;
   double acc = 0.0;
+  bool wf_quiet = WFIRE && nj > 0 && c < wf_Tprev;      // (polling wave: every block this one depends on changed by less than the threshold, so far)
+  bool wf_leave = false;
   CSTAMP(1);
-  for (int q0 = 0; q0 < nj; q0 += RB) {
+  for (int q0 = 0; q0 < nj && !wf_leave; q0 += RB) {
 #pragma unroll
     for (int qq = 0; qq < RB; ++qq) {
       const int q = q0 + qq;
-      if (q < nj) {
+      if (q < nj && !wf_leave) {
         const int j = jtop - q;
         if (q == nj - 1) CSTAMPP(2);
         if (!worker) {                          // the polling wave has no other vector-memory traffic: its loads are not queued behind tile prefetches
           const int lane = tid - 256;
           double v;
           int spins = 0;
+          bool stopped = false;
           for (;;) {
             v = __hip_atomic_load(dp + (size_t)j * NB + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned long long)__double_as_longlong(v) != BWD_SENT) break;
+            if (WFIRE && (spins & 3) == 3 && __hip_atomic_load(status + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > c) { stopped = true; break; }
             if (++spins > (1 << 21)) {          // exit condition every wave reaches: give up (seconds), flag the solve as failed
               v = __builtin_nan("");
               atomicOr(&status[1], 2);
@@ -1454,11 +1475,24 @@ __device__ __forceinline__ void bwd_chain_body(ChainLds& W, const double* __rest
             }
             __builtin_amdgcn_s_sleep(1);
           }
+          if (WFIRE) {
+            stopped = __any(stopped);
+            if (stopped) {
+              if (lane == 0) wf_state = 1;
+            } else {
+              double dv = fabs(v - ((j < wf_Tprev) ? wf_prev[(size_t)j * NB + lane] : 1e300));
+#pragma unroll
+              for (int m = 32; m >= 1; m >>= 1) dv = fmax(dv, __shfl_xor(dv, m));
+              wf_quiet = wf_quiet && (dv < wf_thr);
+              if (q == nj - 1 && wf_quiet && lane == 0) wf_state = 2;
+            }
+          }
           xs[q & 1][lane] = v;
           if (q == nj - 1) CSTAMPP(3);
           if (q == nj - 2) CSTAMPP(7);
         }
         __syncthreads();
+        if (WFIRE && wf_state == 1) { wf_leave = true; continue; }
         if (worker) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc += (double)tr[qq][r] * xs[q & 1][16 * part + r];
@@ -1468,6 +1502,17 @@ __device__ __forceinline__ void bwd_chain_body(ChainLds& W, const double* __rest
     }
   }
   CSTAMP(4);
+  if (WFIRE && wf_state != 0) {
+    // this block keeps the last solve's values: a block above raised the stop word (1), or all of this block's inputs are quiet (2) —
+    // then it raises the stop word for everything below.  (A block without a previous value never gets here: wf_quiet needs c < Tprev,
+    // and the stop word is only raised at a block with one; the blocks below it are older still.)
+    if (tid < NB) __hip_atomic_store(dp + (size_t)c * NB + tid, wf_prev[(size_t)c * NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      if (wf_state == 2) atomicMax(status + 7, c);
+      atomicAdd(status + 3, 1);
+    }
+    return;
+  }
   acc += __shfl_xor(acc, 1);
   acc += __shfl_xor(acc, 2);
   if (worker && part == 0) ys[col] = y0 - acc;
@@ -1496,6 +1541,16 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chol_bwd_chain(const double* 
   const int t = bwd_ticket(&status[4]);
   if (t >= T) return;
   bwd_chain_body<false>(W, S, ld, T, Ld, Winv, yv, dp, status, t, nullptr, prof);
+}
+// the bounded variant (streaming updates with a wildfire threshold; status[7] = stop word, status[3] = blocks kept, both 0 before)
+__global__ __launch_bounds__(CHAIN_THREADS) void k_chol_bwd_chain_wf(const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
+                                                           const double* __restrict__ Winv, const double* __restrict__ yv, double* dp, int* status,
+                                                           const int* __restrict__ prof, const double* __restrict__ prev, double thr, int Tprev) {
+  __shared__ ChainLds W;
+  __shared__ int s_wf;
+  const int t = bwd_ticket(&status[4]);
+  if (t >= T) return;
+  bwd_chain_body<false, true>(W, S, ld, T, Ld, Winv, yv, dp, status, t, nullptr, prof, prev, thr, Tprev, &s_wf);
 }
 constexpr int BWD_BATCH_MAX = 32;     // systems per batched backward substitution (the segments of eight robots' bands: up to 32)
 struct BwdBatchArgs {
@@ -1955,6 +2010,7 @@ struct SyrkArgs {
   int b0[CHOL_BATCH_MAX];              // tile row of the first border row (T, or CholSystem::b0 for a view that covers a range of the columns only)
   double* bord[CHOL_BATCH_MAX]; int ldb[CHOL_BATCH_MAX]; const int* bfirst[CHOL_BATCH_MAX];
   int ks; double* scratch;
+  size_t scratch_stride;     // split K with two systems in one launch: system r's partial tiles start at scratch + r * scratch_stride
   const int* jobs;       // or null: (system << 20 | ib << 10 | jb) per workgroup, longest sums first (launch_border_syrk_jobs)
   const int* segtab[CHOL_BATCH_MAX];      // or null: CholSystem::segtab — the sum runs over the segments in which both tile rows are non-zero
 };
@@ -1989,7 +2045,7 @@ __global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
   double* cbh = A.bord[r] + (size_t)(jb * NB + 32 * ch + 2 * lk) * ldb + (size_t)ib * NB + 32 * rh + 2 * lr;
   if (q > 0) {       // partial of a later chunk: a 64 x 64 scratch tile (leading dimension NB)
     ldb = NB;
-    cbh = A.scratch + ((size_t)(jb * (nbr + 1) + ib) * (A.ks - 1) + (q - 1)) * (NB * NB) + (size_t)(32 * ch + 2 * lk) * NB + 32 * rh + 2 * lr;
+    cbh = A.scratch + (size_t)r * A.scratch_stride + ((size_t)(jb * (nbr + 1) + ib) * (A.ks - 1) + (q - 1)) * (NB * NB) + (size_t)(32 * ch + 2 * lk) * NB + 32 * rh + 2 * lr;
   }
   v4d acc[2][2];
 #pragma unroll
@@ -2102,6 +2158,17 @@ void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int nj
   }
   if (njobs <= 0) return;
   A.ks = 1; A.scratch = nullptr; A.jobs = jobs;
+  if (scratch && n == 2 && ks > 1 && d[0].nbr == d[1].nbr) {
+    // two systems with the same border, split K, ONE launch (the two leaves' Schur complements onto the two halves' partial top blocks
+    // of a canonical whole pass): the job table names the system, each system's partial tiles have their own half of the scratch
+    const int nb = d[0].nbr;
+    A.ks = ks; A.scratch = scratch; A.scratch_stride = (size_t)(nb + 1) * nb * (ks - 1) * NB * NB;
+    hipLaunchKernelGGL(k_border_syrk, dim3(njobs, 1, ks), dim3(256), lds_pad, s, A);
+    for (int r = 0; r < 2; ++r)
+      hipLaunchKernelGGL(k_border_syrk_reduce, dim3(16 * (nb + 1), jb_end >= 0 ? jb_end : nb), dim3(256), 0, s, d[r].bord, d[r].ldb, nb, ks,
+                         scratch + r * A.scratch_stride, d[r].bfirst, d[r].T);
+    return;
+  }
   if (scratch && n == 1 && ks > 1) {
     A.ks = ks; A.scratch = scratch;
     hipLaunchKernelGGL(k_border_syrk, dim3(njobs, 1, ks), dim3(256), lds_pad, s, A);
@@ -2162,9 +2229,9 @@ void launch_border_apply(const CholSystem* d, int n, const double* const* xloc, 
 // from then on every launch k takes the one pending panel k-1 in its column, even launches start the rank-128 pass of panels
 // k-2, k-1 over the trailing matrix, odd launches finish the pass their predecessor started and bring column k+1 up to panel k-1.
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp,
-                         int* status, const int* prof, hipStream_t s);
-void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s, int nbr, int b0) {
-  hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, (b0 > 0 ? b0 : T) + nbr, yv, dp, status);
+                         int* status, const int* prof, hipStream_t s, const double* wf_prev, double wf_thr, int wf_Tprev);
+void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s, int nbr, int b0, double* prev) {
+  hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, (b0 > 0 ? b0 : T) + nbr, yv, dp, status, prev);
 }
 struct StepPlan { int kb, nP, g0, g1, nX, TvA, TvB, TvX, nbA, nbB, nbX; long long nA, nB; };
 static int chol_n_cu() {
@@ -2324,8 +2391,11 @@ void launch_chol_solve_bwd(const CholSystem& cs, hipStream_t s) {
   launch_chol_bwd_all(cs.S, cs.ld, cs.T, cs.Ld, cs.Winv, cs.yv, cs.dp, cs.status, cs.prof, s);
 }
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp,
-                         int* status, const int* prof, hipStream_t s) {
-  hipLaunchKernelGGL(k_chol_bwd_chain, dim3(T), dim3(CHAIN_THREADS), 0, s, S, ld, T, Ld, Winv, yv, dp, status, prof);
+                         int* status, const int* prof, hipStream_t s, const double* wf_prev, double wf_thr, int wf_Tprev) {
+  if (wf_prev && wf_thr > 0.0 && wf_Tprev > 0)
+    hipLaunchKernelGGL(k_chol_bwd_chain_wf, dim3(T), dim3(CHAIN_THREADS), 0, s, S, ld, T, Ld, Winv, yv, dp, status, prof, wf_prev, wf_thr, wf_Tprev);
+  else
+    hipLaunchKernelGGL(k_chol_bwd_chain, dim3(T), dim3(CHAIN_THREADS), 0, s, S, ld, T, Ld, Winv, yv, dp, status, prof);
 }
 
 // ---- plan and launch of the left-looking persistent factorisation (k_chol_ll) ------------------------------------------------------

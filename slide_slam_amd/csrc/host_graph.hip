@@ -709,6 +709,8 @@ void CholBatch::free_separator() {
   for (double** p : {&sep_Ld, &sep_Winv, &sep_yv, &sep_dp, &sep_bord, &lamS, &lam_Ld, &lam_Winv, &lam_yv, &lam_dp, &lam_scratch}) if (*p) { (void)hipFree(*p); *p = nullptr; }
   for (int** p : {&sep_status, &sep_ctr, &d_sep_off, &lam_status, &lam_ctr, &d_sep_prof, &d_leaf_prof, &sep_ctr2, &d_sep_jobs, &d_sep_tmask}) if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (sep_scratch) { (void)hipFree(sep_scratch); sep_scratch = nullptr; }
+  for (double** p : {&sep_top2, &sep_bord2}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (d_sep_jobs2) { (void)hipFree(d_sep_jobs2); d_sep_jobs2 = nullptr; }
   sep_cap = 0; lam_cap = -1;
 }
 void CholBatch::set_segments(int n) {
@@ -876,12 +878,40 @@ int CholBatch::prepare_separator() {
     SL_HIP(hipMemcpyAsync(d_sep_jobs, codes.data(), codes.size() * sizeof(int), hipMemcpyHostToDevice, master)); SL_HIP(hipStreamSynchronize(master));
     sep_ks = std::max(1, std::min({8, TL / 4, (1024 + n_sep_jobs - 1) / std::max(n_sep_jobs, 1)}));
     if (getenv("SLIDE_SEP_KS")) sep_ks = std::max(1, std::min(16, atoi(getenv("SLIDE_SEP_KS"))));      // (diagnostic)
+    {
+      std::vector<int> codes2;
+      for (int sy = 0; sy < 2; ++sy)
+        for (int c : codes) codes2.push_back(sy << 20 | c);
+      if (d_sep_jobs2) { SL_HIP(hipFree(d_sep_jobs2)); d_sep_jobs2 = nullptr; }
+      n_sep_jobs2 = (int)codes2.size();
+      SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sep_jobs2), codes2.size() * sizeof(int)));
+      SL_HIP(hipMemcpyAsync(d_sep_jobs2, codes2.data(), codes2.size() * sizeof(int), hipMemcpyHostToDevice, master)); SL_HIP(hipStreamSynchronize(master));
+    }
     if (sep_ks > 1) {
-      const size_t len = (size_t)(nb + 1) * nb * (sep_ks - 1) * NB * NB * sizeof(double);
+      const size_t len = 2 * (size_t)(nb + 1) * nb * (sep_ks - 1) * NB * NB * sizeof(double);      // (two systems' partial tiles: launch_border_syrk_jobs with n = 2)
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_scratch), len));
       SL_HIP(hipMemsetAsync(sep_scratch, 0, len, master)); SL_HIP(hipStreamSynchronize(master));      // (the idle half of a right-hand-side tile's partials is never written: it must read as zero)
     }
     // the backward substitution runs over the whole system: its profile must cover the top block's rows under the leaves' columns
+    // the other half's partial top block (canonical sums of a whole pass) and which joined graphs hold leaf b
+    for (double** p : {&sep_top2, &sep_bord2}) if (*p) { SL_HIP(hipFree(*p)); *p = nullptr; }
+    sep_ld2 = (Tt + sep_nl + 1) * NB;
+    SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_top2), (size_t)sep_ld2 * Tt * NB * sizeof(double)));
+    SL_HIP(hipMemsetAsync(sep_top2, 0, (size_t)sep_ld2 * Tt * NB * sizeof(double), master));
+    if (sep_nl > 0) {
+      const size_t nb2 = (size_t)(sep_nl + 1) * NB * sep_nl * NB;
+      SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_bord2), nb2 * sizeof(double)));
+      SL_HIP(hipMemsetAsync(sep_bord2, 0, nb2 * sizeof(double), master));
+    }
+    SL_HIP(hipStreamSynchronize(master));
+    sep_mask_b = 0;
+    unsigned mask_a = 0;
+    for (int i = 0; i < n && i < 8; ++i) {
+      const std::vector<int>& mp = graphs[i]->h_sep_map;
+      for (int g = 0; g < TL * NB && g < sep_m && g < (int)mp.size(); ++g)
+        if (mp[g] >= 0) { if (g < Ta * NB) mask_a |= 1u << i; else sep_mask_b |= 1u << i; }
+    }
+    if (mask_a & sep_mask_b) { g_last_error = "separator blocks: a robot holds coordinates of both leaves"; return SLIDE_ERR_INVALID; }
     std::vector<int> cover(h_sep_prof);
     for (int c = 0; c < TL; ++c) cover[c] = sep_Ts - 1;
     SL_HIP(hipMemcpyAsync(d_sep_prof, cover.data(), (size_t)sep_Ts * sizeof(int), hipMemcpyHostToDevice, master)); SL_HIP(hipStreamSynchronize(master));
@@ -1013,7 +1043,10 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     }
     mark(2);
     // a cut pass leaves this GPU's partial sum in the caller's exchange buffer (packed), a whole pass writes the system itself
-    launch_sep_gather(hG.data(), n, maps, Y, !whole, master, d_sep_tmask);
+    static const bool env_canon = !(getenv("SLIDE_SEP_CANONICAL") && getenv("SLIDE_SEP_CANONICAL")[0] == '0');
+    const bool canon = whole && sep_dissected() && env_canon && n <= 8;      // (see sep_top2)
+    if (canon) launch_sep_gather(hG.data(), n, maps, Y, false, master, d_sep_tmask, sTL * NB, sep_mask_b, sep_top2, sep_ld2, sep_bord2);
+    else launch_sep_gather(hG.data(), n, maps, Y, !whole, master, d_sep_tmask);
     mark(3);
   }
   if (whole || part == 2) {
@@ -1023,10 +1056,34 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     if (sep_dissected()) {
       // the leaves side by side (no robot couples them); the top block's Schur complement; the top block's own steps
       const int TL = sTL, Tt = sTt;
+      static const bool env_canon2 = !(getenv("SLIDE_SEP_CANONICAL") && getenv("SLIDE_SEP_CANONICAL")[0] == '0');
+      const bool canon2 = whole && env_canon2 && n <= 8;
       if (!owned) {
         if (ll_leaves) launch_chol_ll(ll_leaves, lv, 2, master);
         else launch_chol_batch(lv, 2, sep_ctr2, master, nullptr, false);
-        launch_border_syrk_jobs(&top, 1, d_sep_jobs, n_sep_jobs, 0, master, sep_scratch, sep_ks, Tt);
+        if (canon2) {
+          // each half's partial top block minus ITS leaf's Schur complement, with the split of the column blocks a rank owning that leaf
+          // uses (part 1), then the sum of the two — the arithmetic of a two-rank job, bit for bit
+          CholSystem tp2[2] = {top, top};
+          for (int hh = 0; hh < 2; ++hh) {
+            tp2[hh].S = sepS + (size_t)(hh ? sTa : 0) * NB * ld_s; tp2[hh].T = sep_leafT[hh]; tp2[hh].b0 = sTL;
+            if (hh) { tp2[hh].bord = sep_top2; tp2[hh].ldb = sep_ld2; }
+          }
+          if (sep_ks > 1) launch_border_syrk_jobs(tp2, 2, d_sep_jobs2, n_sep_jobs2, 0, master, sep_scratch, sep_ks, Tt);      // (both leaves, one launch)
+          else for (int hh = 0; hh < 2; ++hh) launch_border_syrk_jobs(&tp2[hh], 1, d_sep_jobs, n_sep_jobs, 0, master, sep_scratch, sep_ks, Tt);
+          for (int hh = 0; hh < 2; ++hh) {
+            const int t0 = hh ? sTa : 0, Th = sep_leafT[hh];
+            if (sep_nl > 0) {
+              CholSystem sl{};
+              sl.S = sepS + (size_t)t0 * NB * ld_s; sl.ld = ld_s; sl.T = Th; sl.b0 = sep_Ts; sl.nbr = sep_nl; sl.bord = hh ? sep_bord2 : sep_bord; sl.ldb = (sep_nl + 1) * NB;
+              const int ks = (sep_nl + 1) * sep_nl <= 32 ? std::max(1, std::min(16, Th / 2)) : 1;
+              launch_border_syrk(&sl, 1, master, lam_scratch, ks);
+            }
+          }
+          launch_sep_top_add(Y, sTL, sep_top2, sep_ld2, sep_bord2, master);
+        } else {
+          launch_border_syrk_jobs(&top, 1, d_sep_jobs, n_sep_jobs, 0, master, sep_scratch, sep_ks, Tt);
+        }
       }
       if (ll_top) {
         const CholSystem ts = sep_top_system();
@@ -1051,8 +1108,9 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
       // then z1 -= L21^T lambda before the landmark part's backward substitution
       CholSystem ss{};
       ss.S = sepS; ss.ld = ld_s; ss.T = sep_Ts; ss.yv = sep_yv; ss.nbr = sep_nl; ss.bord = sep_bord; ss.ldb = (sep_nl + 1) * NB; ss.bfirst = nullptr;
-      CholSystem sr = ss;      // the column blocks whose part of - W W^T is still missing: all, or (a rank that owns a leaf) the top block's
-      if (owned) { sr.S = sepS + (size_t)sTL * NB * ld_s; sr.T = sTt; sr.b0 = sep_Ts; }
+      CholSystem sr = ss;      // the column blocks whose part of - W W^T is still missing: all, or (a rank that owns a leaf / a canonical whole pass) the top block's
+      static const bool env_canon3 = !(getenv("SLIDE_SEP_CANONICAL") && getenv("SLIDE_SEP_CANONICAL")[0] == '0');
+      if (owned || (whole && sep_dissected() && env_canon3 && n <= 8)) { sr.S = sepS + (size_t)sTL * NB * ld_s; sr.T = sTt; sr.b0 = sep_Ts; }
       const int ks = (sep_nl + 1) * sep_nl <= 32 ? std::max(1, std::min(16, sr.T / 2)) : 1;      // few border tiles: split the column blocks
       launch_border_syrk(&sr, 1, master, lam_scratch, ks);
       launch_lam_prepare(sep_bord, sep_nl, sep_lam, lamS, master);
@@ -1795,11 +1853,16 @@ int HostGraph::upload_new() {
     }
     struct Item { int cb, kind, id, dim, goff; };
     std::vector<Item> items;
+    std::vector<char> taken((size_t)std::max(m, 0), 0);      // (a caller's own layout with overlapping slots would add two landmarks into the same separator coordinates)
     for (int i = 0; i < ns; ++i) {
       const int lid = h_sh_lid[i];
       if (lid < 0 || (size_t)lid >= Ln) continue;
       const int dim = lm_dim(h_lm_type[lid]);      // (the slots' coordinates may be laid out in any order: separator_offsets orders them along the robots' adjacency)
       if (h_sep_off[i] + dim > m) { g_last_error = "separator offsets do not match the landmark classes of the shared slots"; return SLIDE_ERR_INVALID; }
+      for (int k = 0; k < dim; ++k) {
+        if (taken[(size_t)h_sep_off[i] + k]) { g_last_error = "separator offsets: the coordinate ranges of two shared slots overlap"; return SLIDE_ERR_INVALID; }
+        taken[(size_t)h_sep_off[i] + k] = 1;
+      }
       int fp = 1 << 30;
       for (int f : lm_fids[lid]) fp = std::min(fp, h_lf_pose[f]);
       items.push_back(Item{fp == (1 << 30) ? 0 : 6 * fp / NB, 0, lid, dim, h_sep_off[i]});
@@ -1941,6 +2004,8 @@ int HostGraph::upload_new() {
     if (d_cctr.ensure((size_t)Tcap + 2, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_yv.ensure((size_t)Tcap * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_dp.ensure((size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_dp_prev.ensure((size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+    wf_T = 0;                // (the last solve's solution did not survive the re-allocation)
     joint_Tcap = 0;      // (the joint-solve buffers follow S's leading dimension)
   }
   // Buffers of the joint solve (the saved system, the f32 factor copy, the chain tables): only for graphs that take part in one —
@@ -2181,8 +2246,17 @@ int HostGraph::enqueue_iteration(bool lookahead, bool skip_relin, int c_d) {
     for (int k = 0; k < G.T; ++k)
       STAGE(5, launch_chol_step(G.S, G.ld, k, G.T, G.Ld + (size_t)k * NB * NB, G.Winv + (size_t)k * 1024, G.status, G.chol_ctr, nullptr, h_prof.data(), s));
   }
-  STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, G.status, s));
-  STAGE(8, launch_chol_solve_bwd(CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, nullptr, h_prof.data(), G.prof, G.first, d_ctab.d}, s));
+  // bounded back-substitution (iSAM2's wildfire threshold; set_wildfire): on an incremental update only, and only below the first
+  // re-factored block column — there a block's factor column and forward-substituted right-hand side are the last solve's, so its
+  // solution moves only through the blocks above it (bwd_chain_body<.., true>)
+  const int wf_Tp = (skip_relin && wildfire_thr > 0.0 && c_d > 0) ? std::min(std::min(wf_T, c_d), G.T) : 0;
+  if (wf_Tp > 0) {
+    STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, G.status, s, 0, 0, d_dp_prev.d));
+    STAGE(8, launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, G.prof, s, d_dp_prev.d, wildfire_thr, wf_Tp));
+  } else {
+    STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, G.status, s));
+    STAGE(8, launch_chol_solve_bwd(CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, nullptr, h_prof.data(), G.prof, G.first, d_ctab.d}, s));
+  }
   STAGE(9, launch_backsub(G, 0, s));
   STAGE(10, launch_estimate(G, s));
 #undef STAGE
@@ -2269,6 +2343,9 @@ int HostGraph::run_update(double relin_thr, int iterations) {
   factor_valid = true;
   fact_gen = S_gen;
   dirty_min_pose = 1 << 30;
+  wf_T = G.T;                       // (dp holds this solve's solution for every block column)
+  last_wf_kept = st[3];
+  n_wf_kept += st[3];
   return SLIDE_OK;
 }
 

@@ -235,6 +235,11 @@ class CholBatch {
   int* d_leaf_prof = nullptr;                       // both, one after the other (backward substitutions of the views)
   int* d_sep_tmask = nullptr;                       // per (virtual) tile of the separator: which joined graphs hold coordinates of it (k_sep_gather)
   int* sep_ctr2 = nullptr; int* d_sep_jobs = nullptr; int n_sep_jobs = 0; double* sep_scratch = nullptr; int sep_ks = 1;
+  // a WHOLE pass over a dissected separator takes the same arithmetic as two ranks owning a leaf each: per-half partial sums of the top
+  // block (sepS's own top block: the first half's, sep_top2 / sep_bord2: the other's), each minus its leaf's Schur complement, added —
+  // so that 1, 2, 4 and 8 ranks give the same bits (SURVEY 7 hard part 5).  sep_mask_b: the joined graphs that hold leaf b.
+  double *sep_top2 = nullptr, *sep_bord2 = nullptr; int sep_ld2 = 0; unsigned sep_mask_b = 0;
+  int* d_sep_jobs2 = nullptr; int n_sep_jobs2 = 0;      // the top block's product over BOTH leaves as two systems of one launch (system << 20 | ib << 10 | jb)
   bool sep_dissected() const { return sep_leafT[0] > 0 && sep_leafT[1] > 0; }
   // lambda coordinates of the inter-robot relative-pose factors: border rows of the separator system, their own small system
   int sep_lam = 0, sep_nl = 0, lam_cap = -1;
@@ -327,6 +332,10 @@ class HostGraph {
   int chi2(double* out4);                 // sum of squared whitened residuals at the current estimate: total, priors, betweens, landmark factors
   void set_incremental(bool on) { inc_enabled = on; }
   void incremental_stats(int64_t* out4) const { out4[0] = n_inc; out4[1] = n_full; out4[2] = last_cd; out4[3] = G.T; }
+  // iSAM2's wildfire threshold on the back-substitution of a streaming update (ISAM2GaussNewtonParams::wildfireThreshold, 1e-3 in the
+  // reference's GTSAM 4.0.3 build; graph.cpp:15-18, 260-272).  0 (the default here): every update solves the linear system exactly.
+  void set_wildfire(double thr) { wildfire_thr = thr > 0.0 ? thr : 0.0; }
+  void wildfire_stats(int64_t* out2) const { out2[0] = n_wf_kept; out2[1] = last_wf_kept; }      // blocks kept: all updates / the last one
   int get_tile_profile(int* out, int cap);
   int get_border_profile(int* out, int cap);
   int get_segments(int* out, int cap);
@@ -358,6 +367,10 @@ class HostGraph {
   DevArr<int> d_lm_first;
   unsigned long long S_gen = 0, fact_gen = ~0ull;
   int64_t n_inc = 0, n_full = 0, last_cd = 0;
+  double wildfire_thr = 0.0;
+  DevArr<double> d_dp_prev;            // the last solve's reduced solution (bounded back-substitution: k_chol_extract_y keeps it)
+  int wf_T = 0;                        // block columns of it that are valid (0: none — first solve, or the buffers were re-allocated)
+  int64_t n_wf_kept = 0, last_wf_kept = 0;
   bool inc_enabled = true;
 
   std::vector<PendVar> pend_vars;

@@ -43,7 +43,9 @@ void launch_sep_pose_scatter_batched(const GraphDev* d, const GraphDev* h, int n
 struct SepLayout { double* sys; double* bord; double* packed; int Ts, nl, ms, lam; int gap[4]; int hTa, hTL; };      // gap: two ranges [lo, hi) of landmark coordinates no slot uses (padding between the blocks of a dissected layout): unit diagonal; hTa, hTL: tile rows [hTa, hTL) of the tile columns < hTa are structurally zero (leaf b's rows under leaf a's columns) and absent from the packed layout
 void launch_ghost_refresh_local(const GraphDev* d, int n, int n_gslots, hipStream_t s);      // ghost poses of a whole pass on one GPU: pack + sum + adopt in one launch
 void launch_copy_pairs(const double* const* src, double* const* dst, const int* count, int n, hipStream_t s);      // up to 8 small device-to-device copies in one launch
-void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, const SepLayout& Y, bool packed, hipStream_t s, const int* tmask = nullptr);      // tmask: Ts + nl ints, bit r = robot r holds a coordinate of the (virtual) tile
+void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, const SepLayout& Y, bool packed, hipStream_t s, const int* tmask = nullptr,
+                       int split_col = -1, unsigned mask_b = 0, double* sys2 = nullptr, int ld2 = 0, double* bord2 = nullptr);      // tmask: Ts + nl ints, bit r = robot r holds a coordinate of the (virtual) tile; split_col ..: per-half partial sums of the top block (k_sep_gather)
+void launch_sep_top_add(const SepLayout& Y, int c0, const double* sys2, int ld2, const double* bord2, hipStream_t s);      // tile columns >= c0 of the system (and the lambda block) += the other half's partial
 void launch_sep_unpack(const SepLayout& Y, hipStream_t s, int c0 = 0, int c1 = -1, bool to_packed = false);      // tile columns [c0, c1) (virtual: lambda tiles behind the landmarks'); to_packed: the reverse copy
 void launch_lam_prepare(const double* bord, int nl, int lam, double* out, hipStream_t s);      // M = -(K22 - L21 L21^T), rhs = -(r2 - L21 z1)
 void launch_sep_xloc(int n, const int* const* maps, int ms, int lam, const double* xs, const double* xl, double* const* xloc, hipStream_t s);
@@ -54,7 +56,7 @@ void launch_phase3_arrow_batched(const GraphDev* d, const GraphDev* h, int n, hi
 // leading dimension ld = (T+1)*NB; the extra row tile carries the right-hand side), tile edge NB = 64.
 // ctr: T + 2 ints, zero before the first factorisation (each step clears the next step's work counter itself)
 void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv, int* status, int* ctr, float* L32, const int* h_prof, hipStream_t s, int nbr = 0);   // L32, h_prof: see CholSystem
-void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s, int nbr = 0, int b0 = 0);   // also clears status[4], the ticket counter of launch_chol_bwd_all
+void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s, int nbr = 0, int b0 = 0, double* prev = nullptr);   // prev: dp's old content is kept there (bounded back-substitution)   // also clears status[4], the ticket counter of launch_chol_bwd_all
 // A quiet-NaN payload no solution value can equal bit for bit: the outputs of the chained substitutions are pre-filled with it and the
 // workgroups poll the blocks they depend on ("flag in data").
 constexpr unsigned long long CHAIN_SENTINEL = 0x7FF8DEADBEEF0BADull;
@@ -96,7 +98,8 @@ void launch_border_apply(const CholSystem* d, int n, const double* const* xloc, 
 void launch_chain_batch(const CholSystem* d, int n, const double* const* in, double* const* out, bool fwd, bool f32, bool prepared,
                         double* const* next_out, hipStream_t s);   // needs the tables (launch_chain_tables) of this factorisation
 void launch_chain_tables(const CholSystem* d, int n, hipStream_t s);
-void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp, int* status, const int* prof, hipStream_t s);
+void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp, int* status, const int* prof, hipStream_t s,
+                         const double* wf_prev = nullptr, double wf_thr = 0.0, int wf_Tprev = 0);      // wf_*: iSAM2's wildfire bound (bwd_chain_body): blocks whose inputs changed by < wf_thr keep wf_prev; status[7] / status[3] must be 0
 // marginal covariance of the pose whose first tangent row is row0 (Y: 6 * T * NB scratch doubles holding the six unit columns)
 void launch_pose_covariance(const double* S, int ld, int T, const double* Ld, const double* Winv, double* Y, int row0, double* cov36,
                             hipStream_t s);

@@ -202,10 +202,17 @@ __device__ inline void cyl_err(const SE3& X, const double* q, const double* z, d
 // evaluations of the error function per factor — one per lane (lane = 2 column + sign; lanes 30/31 evaluate the
 // unperturbed error), paired by a lane swap.  Every lane runs the same code on its own perturbation (a zero tangent
 // retracts to the value itself, exactly), so a thread no longer walks through thirty evaluations one after the other.
-__device__ __forceinline__ void k_lin_lf_body(const GraphDev& G) {
-  const int f = (blockIdx.x * 256 + threadIdx.x) >> 5, j = threadIdx.x & 31;
+// Thread map (round 4): the first nb1 workgroups give every factor ONE thread and linearise the bearing-range factors (analytic
+// Jacobians: one lane's work — with 32 lanes per factor a wavefront held two of them, 2 of 64 lanes active, and bearing-range
+// factors are most of a SLAM graph); the workgroups behind them give every factor 32 lanes and linearise cubes / cylinders by the
+// reference's central differences (one error evaluation per lane) — wavefronts whose two factors are bearing-range leave at once.
+__device__ __forceinline__ void k_lin_lf_body(const GraphDev& G, int nb1) {
+  const bool br_region = (int)blockIdx.x < nb1;
+  const int f = br_region ? (int)(blockIdx.x * 256 + threadIdx.x) : (int)((((int)blockIdx.x - nb1) * 256 + threadIdx.x) >> 5);
+  const int j = br_region ? 0 : (threadIdx.x & 31);
   if (f >= G.n_lf) return;
   const int type = G.lf_type[f];
+  if ((type == FT_BR) != br_region) return;
   const int p = G.lf_pose[f], l = G.lf_lm[f], slot = G.lf_slot[f];
   double* out = G.jbuf + G.lf_joff[f];
   const SE3 X = from12(G.pose_val + 12 * (size_t)p);
@@ -214,7 +221,6 @@ __device__ __forceinline__ void k_lin_lf_body(const GraphDev& G) {
   const double dl = G.numdiff_delta, fac = 1.0 / (2.0 * dl);
   const double d = (j & 1) ? -dl : dl;
   if (type == FT_BR) {
-    if (j != 0) return;
     // [GTSAM BearingRangeFactor<Pose3,Point3>] r = [sphere-local(z_b, b) ; rho - z_rho] / sigma
     const double* z = G.br_z + 4 * (size_t)slot;
     const double w = 1.0 / G.bearing_sigma;
@@ -300,8 +306,8 @@ __device__ __forceinline__ void k_lin_lf_body(const GraphDev& G) {
     }
   }
 }
-__global__ __launch_bounds__(256) void k_lin_lf(GraphDev G) { k_lin_lf_body(G); }
-__global__ __launch_bounds__(256) void k_lin_lf_b(const GraphDev* __restrict__ Gs) { k_lin_lf_body(Gs[blockIdx.z]); }
+__global__ __launch_bounds__(256) void k_lin_lf(GraphDev G, int nb1) { k_lin_lf_body(G, nb1); }
+__global__ __launch_bounds__(256) void k_lin_lf_b(const GraphDev* __restrict__ Gs, int nb1) { k_lin_lf_body(Gs[blockIdx.z], nb1); }
 
 // ------------------------------------------------------------------------------------------------
 // landmark reduce: H_ll = sum Jl^T Jl, g_l = sum Jl^T r, H_ll^-1, and per factor
@@ -1329,6 +1335,12 @@ struct SepGatherArgs {
   SepLayout Y;
   const double* bord[8]; int ldb[8]; int nbr[8]; const int* map[8];      // map: ms + lam ints, separator coordinate -> robot's border coordinate or -1
   const int* tmask;      // or null: per virtual tile (Ts landmark + nl lambda tiles), bit r set = robot r holds a coordinate of the tile
+  unsigned robot_mask;   // the robots (bits) whose contributions this launch sums
+  // per-half partial sums of the TOP block (a whole pass on one GPU, dissected layout): for the columns from split_col on, the robots in
+  // mask_b are summed into sys2 / bord2 (the top block's own shape: ld2 rows per column, first row = row split_col; the lambda block like
+  // Y.bord) and the others into the system itself — the two halves of the job then subtract their leaf's Schur complement each and are
+  // added, exactly as two ranks owning a leaf each would (enqueue_arrow); split_col < 0: off
+  int split_col; unsigned mask_b; double* sys2; int ld2; double* bord2;
 };
 constexpr int SEP_GATHER_COLS = 8;      // columns per workgroup (a workgroup per column: 62 000 workgroups, half of them above the diagonal)
 __global__ __launch_bounds__(256) void k_sep_gather(SepGatherArgs A) {
@@ -1345,24 +1357,43 @@ __global__ __launch_bounds__(256) void k_sep_gather(SepGatherArgs A) {
     if (sep_packed_hole(vr, vc, Y.hTa, Y.hTL)) continue;
     // separator coordinate of a virtual index, or -1 on the padding
     const int gc = vc < NL ? (vc < Y.ms ? vc : -1) : (vc - NL < Y.lam ? Y.ms + vc - NL : -1);
-    double s = 0.0;
+    double s = 0.0, s2 = 0.0;
     if (gc < 0 || gr < 0) {
       s = (vr == vc && vc < NL) ? 1.0 : 0.0;      // unit diagonal on the landmark padding (the lambda padding is set by k_lam_prepare)
     } else if (vr == vc && ((vc >= Y.gap[0] && vc < Y.gap[1]) || (vc >= Y.gap[2] && vc < Y.gap[3]))) {
       s = A.packed ? 0.0 : 1.0;                   // padding between the blocks of a dissected layout (a packed partial sum gets it in k_sep_unpack)
     } else {
       // only the robots that hold coordinates of BOTH tiles can contribute (two or three of eight on a grid of robot cells)
-      const unsigned cand = A.tmask ? (unsigned)A.tmask[vc / NB] & rmask : ~0u;
-      for (int r = 0; r < A.n; ++r) {
-        if (!((cand >> r) & 1u)) continue;
-        const int lc = A.map[r][gc];
-        if (lc < 0) continue;
-        const int lr = rhs ? A.nbr[r] * NB : A.map[r][gr];
-        if (lr < 0) continue;
-        s += A.bord[r][(size_t)min(lr, lc) * A.ldb[r] + max(lr, lc)];      // (lower triangle of the robot's block)
+      // The robots' contributions are added along a BINARY TREE over the robot index — ((0 + 1) + (2 + 3)) + ((4 + 5) + (6 + 7)) — whatever
+      // the number of robots on this GPU: a rank that holds an aligned power-of-two range of the job's robots computes a subtree of the
+      // same tree, the pairwise exchanges between the ranks (distributed.py) its upper levels, and the job's sums are bit for bit the same
+      // at 1, 2, 4 and 8 ranks (an absent contribution is an exact zero; SURVEY 7, hard part 5).  A.first_robot masks the range to sum.
+      const unsigned cand = (A.tmask ? (unsigned)A.tmask[vc / NB] & rmask : ~0u) & A.robot_mask;
+      double v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        v[r] = 0.0;
+        if (r < A.n && ((cand >> r) & 1u)) {
+          const int lc = A.map[r][gc];
+          const int lr = lc < 0 ? -1 : (rhs ? A.nbr[r] * NB : A.map[r][gr]);
+          if (lr >= 0) v[r] = A.bord[r][(size_t)min(lr, lc) * A.ldb[r] + max(lr, lc)];      // (lower triangle of the robot's block)
+        }
+      }
+      if (A.split_col >= 0 && vc >= A.split_col) {
+        double va[8], vb[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const bool b = (A.mask_b >> r) & 1u; va[r] = b ? 0.0 : v[r]; vb[r] = b ? v[r] : 0.0; }
+        s = ((va[0] + va[1]) + (va[2] + va[3])) + ((va[4] + va[5]) + (va[6] + va[7]));
+        s2 = ((vb[0] + vb[1]) + (vb[2] + vb[3])) + ((vb[4] + vb[5]) + (vb[6] + vb[7]));
+      } else {
+        s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
       }
     }
     *sep_slot(Y, vr, vc, A.packed != 0) = s;
+    if (A.split_col >= 0 && vc >= A.split_col) {      // the other half's partial sum (zero on the padding)
+      if (vc < NL) A.sys2[(size_t)(vc - A.split_col) * A.ld2 + (vr - A.split_col)] = s2;
+      else A.bord2[(size_t)(vc - NL) * ((size_t)(Y.nl + 1) * NB) + (vr - NL)] = s2;
+    }
   }
 }
 // c0, c1: the (virtual) tile columns [c0, c1) only; to_packed: the other way (the factorisation's layout -> the packed buffer: a rank that
@@ -1512,7 +1543,7 @@ void launch_relin(const GraphDev& G, hipStream_t s) {
 void launch_linearize(const GraphDev& G, hipStream_t s) {
   if (G.n_prior + G.n_between + G.n_ghost > 0)
     hipLaunchKernelGGL(k_lin_pose_factors, dim3(blocks_for(G.n_prior + G.n_between + G.n_ghost, 128)), dim3(128), 0, s, G);
-  if (G.n_lf > 0) hipLaunchKernelGGL(k_lin_lf, dim3(blocks_for(32LL * G.n_lf, 256)), dim3(256), 0, s, G);
+  if (G.n_lf > 0) hipLaunchKernelGGL(k_lin_lf, dim3(blocks_for(G.n_lf, 256) + blocks_for(32LL * G.n_lf, 256)), dim3(256), 0, s, G, (int)blocks_for(G.n_lf, 256));
 }
 void launch_landmark(const GraphDev& G, int mode, hipStream_t s) {
   if (G.L == 0) return;
@@ -1614,7 +1645,7 @@ void launch_phase0_batched(const GraphDev* d, const GraphDev* h, int n, double* 
   for (int i = 0; i < n; ++i) B.p[i] = bufs[i];
   if (P + L > 0) hipLaunchKernelGGL(k_relin_b, dim3(blocks_for(P + L, 256), 1, n), dim3(256), 0, s, d);
   if (npf > 0) hipLaunchKernelGGL(k_lin_pose_factors_b, dim3(blocks_for(npf, 128), 1, n), dim3(128), 0, s, d);
-  if (nlf > 0) hipLaunchKernelGGL(k_lin_lf_b, dim3(blocks_for(32LL * nlf, 256), 1, n), dim3(256), 0, s, d);
+  if (nlf > 0) hipLaunchKernelGGL(k_lin_lf_b, dim3(blocks_for(nlf, 256) + blocks_for(32LL * nlf, 256), 1, n), dim3(256), 0, s, d, (int)blocks_for(nlf, 256));
   if (L > 0 && pack) hipLaunchKernelGGL(k_landmark_b<1>, dim3(blocks_for(L, 4), 1, n), dim3(256), 0, s, d);      // (!pack: the exact joint pass sums and finishes in one launch, k_landmark_b<3>)
   if (slots > 0 && pack) hipLaunchKernelGGL(k_shared_pack_b, dim3(blocks_for(54LL * slots, 128), 1, n), dim3(128), 0, s, d, 0, B);
 }
@@ -1686,9 +1717,25 @@ void launch_sep_unpack(const SepLayout& Y, hipStream_t s, int c0, int c1, bool t
   if (c1 < 0) c1 = Y.Ts + Y.nl;
   if (NT > 0 && c1 > c0) hipLaunchKernelGGL(k_sep_unpack, dim3((NT + 1 + 255) / 256, (c1 - c0) * NB), dim3(256), 0, s, Y, c0, c1, to_packed ? 1 : 0);
 }
-void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, const SepLayout& Y, bool packed, hipStream_t s, const int* tmask) {
+// top block of the separator system += the other half's partial (k_sep_gather's split): columns [c0, Ts) of the system and the lambda block
+__global__ __launch_bounds__(256) void k_sep_top_add(SepLayout Y, int c0, const double* __restrict__ sys2, int ld2, const double* __restrict__ bord2) {
+  const int vr = blockIdx.x * 256 + threadIdx.x, vc = c0 * NB + blockIdx.y;
+  const int NL = Y.Ts * NB, NT = (Y.Ts + Y.nl) * NB;
+  if (vr > NT || vc >= NT || vr < vc / NB * NB) return;
+  double* dst = sep_slot(Y, vr, vc, false);
+  if (vc < NL) *dst += sys2[(size_t)(vc - c0 * NB) * ld2 + (vr - c0 * NB)];
+  else *dst += bord2[(size_t)(vc - NL) * ((size_t)(Y.nl + 1) * NB) + (vr - NL)];
+}
+void launch_sep_top_add(const SepLayout& Y, int c0, const double* sys2, int ld2, const double* bord2, hipStream_t s) {
+  const int NT = (Y.Ts + Y.nl) * NB;
+  const int ncol = NT - c0 * NB;
+  if (ncol > 0) hipLaunchKernelGGL(k_sep_top_add, dim3((NT + 1 + 255) / 256, ncol), dim3(256), 0, s, Y, c0, sys2, ld2, bord2);
+}
+void launch_sep_gather(const GraphDev* h, int n, const int* const* maps, const SepLayout& Y, bool packed, hipStream_t s, const int* tmask,
+                       int split_col, unsigned mask_b, double* sys2, int ld2, double* bord2) {
   SepGatherArgs A{};
   A.n = n; A.Y = Y; A.packed = packed ? 1 : 0; A.tmask = tmask;
+  A.robot_mask = ~0u; A.split_col = split_col; A.mask_b = mask_b; A.sys2 = sys2; A.ld2 = ld2; A.bord2 = bord2;
   for (int i = 0; i < n; ++i) { A.bord[i] = h[i].bord; A.ldb[i] = h[i].ldb; A.nbr[i] = h[i].nbr; A.map[i] = maps[i]; }
   const int NT = (Y.Ts + Y.nl) * NB;
   if (NT > 0) hipLaunchKernelGGL(k_sep_gather, dim3((NT + 1 + 255) / 256, (NT + SEP_GATHER_COLS - 1) / SEP_GATHER_COLS), dim3(256), 0, s, A);

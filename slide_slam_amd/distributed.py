@@ -308,17 +308,23 @@ def setup_local_shards(shards, matcher, base=None, rank=0, world=1, thresh=(2.0,
     dissect = os.environ.get("SLIDE_SEP_DISSECT", "1") != "0"
     owner = None
     sep_off = None
-    if dissect and world >= 2 and world % 2 == 0 and device is not None and os.environ.get("SLIDE_SEP_OWNED", "1") != "0":
-        # the ranks split in two halves along the dissection: every rank then factors one leaf only and only the top block crosses
-        # between the halves (slide_chol_batch_set_separator_owner)
-        sep_off, sep_prof, sep_blocks = separator_offsets(gid, n_global, dissect=True, force_a=set(range(world // 2 * R)))
-        if sep_blocks is not None:
-            half = 0 if rank < world // 2 else 1
-            owner = dict(leaf=half, leader=(rank % (world // 2) == 0), half_ranks=list(range(half * (world // 2), (half + 1) * (world // 2))))
-        else:
+    n_robots = world * R
+    # The dissection is the SAME at every rank count: the first half of the job's robots against the second (on the 2 x 4 grid of C4: its
+    # two rows — also the best of all bipartitions), so that the sums of a job are the same bits at 1, 2, 4 and 8 ranks (a whole pass on
+    # one GPU takes per-half partial sums too: CholBatch::enqueue_arrow).  SLIDE_SEP_FREE_SPLIT=1: a single process searches all
+    # bipartitions instead (the shortest chain; not comparable bit for bit with a job of several ranks).
+    if dissect and n_robots >= 4 and n_robots % 2 == 0 and not (world == 1 and os.environ.get("SLIDE_SEP_FREE_SPLIT") == "1"):
+        sep_off, sep_prof, sep_blocks = separator_offsets(gid, n_global, dissect=True, force_a=set(range(n_robots // 2)))
+        if sep_blocks is None:
             sep_off = None
+        elif world >= 2 and world % 2 == 0 and device is not None and os.environ.get("SLIDE_SEP_OWNED", "1") != "0":
+            # the ranks split in two halves along the dissection: every rank then factors one leaf only and only the top block crosses
+            # between the halves (slide_chol_batch_set_separator_owner); every rank of a half computes the half's result (no leader:
+            # the exchanges are pairwise, PassDriver._sep_exchange)
+            half = 0 if rank < world // 2 else 1
+            owner = dict(leaf=half, leader=True, rank=rank, half_ranks=list(range(half * (world // 2), (half + 1) * (world // 2))))
     if sep_off is None:
-        sep_off, sep_prof, sep_blocks = separator_offsets(gid, n_global, dissect=dissect)
+        sep_off, sep_prof, sep_blocks = separator_offsets(gid, n_global, dissect=dissect and world == 1 and os.environ.get("SLIDE_SEP_FREE_SPLIT") == "1")
     if sep_blocks is not None:
         sep_prof = (sep_prof, sep_blocks, owner)        # (travels with the profile to PassDriver: the dissection is a property of the layout)
     for t, sh in enumerate(shards):
@@ -383,7 +389,7 @@ class PassDriver:
         self.sep = None
         self._sep_segs = None
         self.sep_owner = None
-        self._half_group = None
+        self._pair_groups = None
         if self.arrow:
             self.pcg_iters = 0
             if device is None:
@@ -412,16 +418,33 @@ class PassDriver:
                 lay = {(m[0], m[1], m[2], m[3] is None) for m in seen}
                 if len(lay) != 1:
                     raise RuntimeError(f"exact joint step: the ranks disagree on the separator layout (dimension, slots, blocks, owned): {sorted(map(str, lay))}")
-                if self.sep_owner is not None and len(self.sep_owner["half_ranks"]) > 1:
-                    ga, gb = base.new_group(range(0, world // 2)), base.new_group(range(world // 2, world))
-                    self._half_group = ga if self.sep_owner["leaf"] == 0 else gb
+                if self.sep_owner is not None:
+                    # PAIRWISE exchanges only (a sum of two operands is the same bits on both sides and in either order): round j inside a
+                    # half pairs rank r with r ^ (1 << j) — with the robots laid out rank-major that is the binary tree over the robot index
+                    # which k_sep_gather sums along on every GPU — and one more round pairs the halves.  Every rank creates every group,
+                    # in the same order.
+                    hs = len(self.sep_owner["half_ranks"])
+                    assert hs & (hs - 1) == 0, "the ranks of a half must be a power of two"
+                    self._pair_groups = []
+                    j = 1
+                    while j < world:
+                        mine = None
+                        for r in range(world):
+                            if not r & j:
+                                g = base.new_group((r, r | j))
+                                if self.sep_owner["rank"] in (r, r | j):
+                                    mine = g
+                        self._pair_groups.append(mine)
+                        j <<= 1
             import os
             # nested dissection of the robots' own bands (slide_chol_batch_set_segments; every segment carries only the border rows that
             # are non-zero in it).  Measured on one MI355X: 8 robots x 625 poses 3.06 ms per pass uncut, 2.64 / 2.54 / 2.60 with
             # 2 / 3 / 4 segments; 2 robots x 500 poses 1.37 uncut, 1.12 / 1.08 / 1.04 / 1.04 with 2 / 3 / 4 / 6 — the fewer robots share
             # the GPU, the more segments fit side by side
             seg = os.environ.get("SLIDE_SEGMENTS")
-            batch.set_segments((int(seg) if seg else (4 if len(shards) <= 4 else 3)) if self.arrow else 1)
+            # (the count is the same whatever the number of robots on this GPU — 4 segments were 4 % faster with few robots —: a job's
+            # arithmetic must not depend on how its robots are spread over ranks)
+            batch.set_segments((int(seg) if seg else 3) if self.arrow else 1)
         if batch is not None:           # (always pushed, zero included: a batch or graph may still hold an earlier driver's setting)
             batch.set_pcg(self.pcg_iters, self.pcg_tol)
         else:
@@ -519,14 +542,18 @@ class PassDriver:
                 now = time.perf_counter()
                 times[key] = (now - times["_t"]) * 1e3
                 times["_t"] = now
-        off, ln = self._sep_segs[own["leaf"]]
-        if self._half_group is not None:
-            self.base.all_reduce_on(sep, ln, stream, off=off, group=self._half_group)
+        # inside the half: the own leaf's segment AND the top block's, round by round (after log2(half) rounds every rank of the half holds
+        # the half's sums — the same bits on all of them)
+        n_in = len(self._pair_groups) - 1
+        loff, lln = self._sep_segs[own["leaf"]]
+        toff, tln = self._sep_segs[2]
+        for j in range(n_in):
+            self.base.all_reduce_on(sep, lln, stream, off=loff, group=self._pair_groups[j])
+            self.base.all_reduce_on(sep, tln, stream, off=toff, group=self._pair_groups[j])
         lap("exchange_leaf_ms")
-        self.batch.pass_part(self.ptrs, 1)
+        self.batch.pass_part(self.ptrs, 1)          # every rank: the leaf factored, its Schur complement onto the half's top block
         lap("part1_ms")
-        off, ln = self._sep_segs[2]
-        self.base.all_reduce_on(sep, ln, stream, off=off)
+        self.base.all_reduce_on(sep, tln, stream, off=toff, group=self._pair_groups[-1])      # between the halves: (A - S_a) + (B - S_b)
         lap("exchange_top_ms")
 
     def _exchange(self, count):
@@ -660,7 +687,8 @@ class PassDriver:
         torch.cuda.synchronize(); t3 = time.perf_counter()
         self.passes += 1
         own = getattr(self, "sep_owner", None)
-        xb = 8 * self.sep_len if own is None else 8 * ((self._sep_segs[own["leaf"]][1] if len(own["half_ranks"]) > 1 else 0) + self._sep_segs[2][1])
+        n_in = 0 if own is None else len(self._pair_groups) - 1
+        xb = 8 * self.sep_len if own is None else 8 * (n_in * (self._sep_segs[own["leaf"]][1] + self._sep_segs[2][1]) + self._sep_segs[2][1])
         out.update(part0_ms=(t1 - t0) * 1e3, exchange_ms=(t2 - t1) * 1e3, part2_ms=(t3 - t2) * 1e3, exchange_bytes=xb)
         return out
 
