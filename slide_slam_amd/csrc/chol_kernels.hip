@@ -2011,6 +2011,7 @@ struct SyrkArgs {
   double* bord[CHOL_BATCH_MAX]; int ldb[CHOL_BATCH_MAX]; const int* bfirst[CHOL_BATCH_MAX];
   int ks; double* scratch;
   size_t scratch_stride;     // split K with two systems in one launch: system r's partial tiles start at scratch + r * scratch_stride
+  int ks_sys[2];             // ... and each may have its own number of chunks (0: ks) — a leaf's product is cut the way a rank owning that leaf cuts it
   const int* jobs;       // or null: (system << 20 | ib << 10 | jb) per workgroup, longest sums first (launch_border_syrk_jobs)
   const int* segtab[CHOL_BATCH_MAX];      // or null: CholSystem::segtab — the sum runs over the segments in which both tile rows are non-zero
 };
@@ -2029,8 +2030,11 @@ __global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
   const int* st = A.segtab[r];                    // a segmented band: one range per segment in which both tile rows are non-zero
   const int nseg = st ? st[0] : 1;
   if (!st && A.bfirst[r]) c0 = max(A.bfirst[r][ib], A.bfirst[r][jb]);
+  int ksr = A.ks;                                 // chunks of this system's column blocks
   if (A.ks > 1) {
-    const int len = (T - c0 + A.ks - 1) / A.ks;
+    if (A.scratch_stride && r < 2 && A.ks_sys[r] > 0) ksr = A.ks_sys[r];
+    if (q >= ksr) return;
+    const int len = (T - c0 + ksr - 1) / ksr;
     c0 += q * len;
     c1 = min(T, c0 + len);
   }
@@ -2045,7 +2049,7 @@ __global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
   double* cbh = A.bord[r] + (size_t)(jb * NB + 32 * ch + 2 * lk) * ldb + (size_t)ib * NB + 32 * rh + 2 * lr;
   if (q > 0) {       // partial of a later chunk: a 64 x 64 scratch tile (leading dimension NB)
     ldb = NB;
-    cbh = A.scratch + (size_t)r * A.scratch_stride + ((size_t)(jb * (nbr + 1) + ib) * (A.ks - 1) + (q - 1)) * (NB * NB) + (size_t)(32 * ch + 2 * lk) * NB + 32 * rh + 2 * lr;
+    cbh = A.scratch + (size_t)r * A.scratch_stride + ((size_t)(jb * (nbr + 1) + ib) * (ksr - 1) + (q - 1)) * (NB * NB) + (size_t)(32 * ch + 2 * lk) * NB + 32 * rh + 2 * lr;
   }
   v4d acc[2][2];
 #pragma unroll
@@ -2121,6 +2125,25 @@ __global__ __launch_bounds__(256) void k_border_syrk_reduce(double* __restrict__
     if (c0 + q * len < T) v += scratch[((size_t)(jb * (nbr + 1) + ib) * (ks - 1) + (q - 1)) * (NB * NB) + (size_t)col * NB + row];
   *dst = v;
 }
+// Two systems with the same border whose results are ADDED (a canonical whole pass: each half's partial top block minus its leaf's Schur
+// complement): A <- (A + its partials, in chunk order) + (B + its partials, in chunk order) — what two ranks owning a leaf each compute
+// and then exchange, bit for bit, in one launch instead of two reductions and a sum
+__global__ __launch_bounds__(256) void k_border_syrk_reduce2(double* __restrict__ bordA, int ldbA, const double* __restrict__ bordB, int ldbB, int nbr,
+                                                             int ksA, int ksB, const double* __restrict__ scratchA, const double* __restrict__ scratchB,
+                                                             int TA, int TB) {
+  const int ib = blockIdx.x >> 4, jb = blockIdx.y;
+  if (ib > nbr || jb >= nbr || ib < jb) return;
+  const int e = (blockIdx.x & 15) * 256 + threadIdx.x;
+  const int col = e / NB, row = e - col * NB;
+  double* dst = bordA + (size_t)(jb * NB + col) * ldbA + (size_t)ib * NB + row;
+  double va = *dst, vb = bordB[(size_t)(jb * NB + col) * ldbB + (size_t)ib * NB + row];
+  const int lenA = (TA + ksA - 1) / ksA, lenB = (TB + ksB - 1) / ksB;
+  for (int q = 1; q < ksA; ++q)
+    if (q * lenA < TA) va += scratchA[((size_t)(jb * (nbr + 1) + ib) * (ksA - 1) + (q - 1)) * (NB * NB) + (size_t)col * NB + row];
+  for (int q = 1; q < ksB; ++q)
+    if (q * lenB < TB) vb += scratchB[((size_t)(jb * (nbr + 1) + ib) * (ksB - 1) + (q - 1)) * (NB * NB) + (size_t)col * NB + row];
+  *dst = va + vb;
+}
 // scratch (or null): (nbr + 1) * nbr * (ks - 1) tiles of NB * NB doubles — with it, ONE system's product is split over ks chunks of its
 // column blocks (a system with a handful of border tiles would otherwise occupy a handful of CUs for the whole K)
 void launch_border_syrk(const CholSystem* d, int n, hipStream_t s, double* scratch, int ks) {
@@ -2149,7 +2172,8 @@ void launch_border_syrk(const CholSystem* d, int n, hipStream_t s, double* scrat
 // dealt (sums of 0 .. T column blocks: the slowest CU carries ~1.6 x the mean).
 // scratch + ks > 1 (one system): split K as in launch_border_syrk; jb_end >= 0: the table holds the tile columns jb < jb_end only (the
 // rest of the border block is somebody else's: the lambda block of the separator system)
-void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int njobs, int lds_pad, hipStream_t s, double* scratch, int ks, int jb_end) {
+void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int njobs, int lds_pad, hipStream_t s, double* scratch, int ks, int jb_end,
+                             const int* ks_sys, bool fuse_add) {
   SyrkArgs A{};
   A.n = n;
   for (int i = 0; i < n; ++i) {
@@ -2158,15 +2182,17 @@ void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int nj
   }
   if (njobs <= 0) return;
   A.ks = 1; A.scratch = nullptr; A.jobs = jobs;
-  if (scratch && n == 2 && ks > 1 && d[0].nbr == d[1].nbr) {
-    // two systems with the same border, split K, ONE launch (the two leaves' Schur complements onto the two halves' partial top blocks
-    // of a canonical whole pass): the job table names the system, each system's partial tiles have their own half of the scratch
+  if (scratch && n == 2 && fuse_add && d[0].nbr == d[1].nbr && !d[0].bfirst && !d[1].bfirst) {
+    // two systems with the same border, split K (each with its own number of chunks: ks_sys, or ks), ONE launch — the two leaves' Schur
+    // complements onto the two halves' partial top blocks of a canonical whole pass: the job table names the system, each system's
+    // partial tiles have their own half of the scratch — and ONE reduction that also adds the second result onto the first
     const int nb = d[0].nbr;
-    A.ks = ks; A.scratch = scratch; A.scratch_stride = (size_t)(nb + 1) * nb * (ks - 1) * NB * NB;
-    hipLaunchKernelGGL(k_border_syrk, dim3(njobs, 1, ks), dim3(256), lds_pad, s, A);
-    for (int r = 0; r < 2; ++r)
-      hipLaunchKernelGGL(k_border_syrk_reduce, dim3(16 * (nb + 1), jb_end >= 0 ? jb_end : nb), dim3(256), 0, s, d[r].bord, d[r].ldb, nb, ks,
-                         scratch + r * A.scratch_stride, d[r].bfirst, d[r].T);
+    const int ka = std::max(1, ks_sys ? ks_sys[0] : ks), kb = std::max(1, ks_sys ? ks_sys[1] : ks), km = std::max(ka, kb);
+    A.ks = km; A.scratch = scratch; A.scratch_stride = std::max<size_t>(1, (size_t)(nb + 1) * nb * (km - 1) * NB * NB);
+    A.ks_sys[0] = ka; A.ks_sys[1] = kb;
+    hipLaunchKernelGGL(k_border_syrk, dim3(njobs, 1, km), dim3(256), lds_pad, s, A);
+    hipLaunchKernelGGL(k_border_syrk_reduce2, dim3(16 * (nb + 1), jb_end >= 0 ? jb_end : nb), dim3(256), 0, s, d[0].bord, d[0].ldb, d[1].bord, d[1].ldb, nb,
+                       ka, kb, scratch, scratch + A.scratch_stride, d[0].T, d[1].T);
     return;
   }
   if (scratch && n == 1 && ks > 1) {

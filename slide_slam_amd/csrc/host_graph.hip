@@ -711,6 +711,7 @@ void CholBatch::free_separator() {
   if (sep_scratch) { (void)hipFree(sep_scratch); sep_scratch = nullptr; }
   for (double** p : {&sep_top2, &sep_bord2}) if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (d_sep_jobs2) { (void)hipFree(d_sep_jobs2); d_sep_jobs2 = nullptr; }
+  if (d_lam_jobs2) { (void)hipFree(d_lam_jobs2); d_lam_jobs2 = nullptr; }
   sep_cap = 0; lam_cap = -1;
 }
 void CholBatch::set_segments(int n) {
@@ -803,7 +804,17 @@ int CholBatch::prepare_separator() {
     if (sep_nl > 0) {
       const size_t nb = (size_t)(sep_nl + 1) * NB * sep_nl * NB;
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_bord), nb * sizeof(double)));
-      if ((sep_nl + 1) * sep_nl <= 32) SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_scratch), (size_t)(sep_nl + 1) * sep_nl * 15 * NB * NB * sizeof(double)));
+      if ((sep_nl + 1) * sep_nl <= 32) SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_scratch), 2 * (size_t)(sep_nl + 1) * sep_nl * 15 * NB * NB * sizeof(double)));      // (x 2: both leaves' partial tiles in one launch)
+      {
+        std::vector<int> codes;      // the lambda block's tiles + right-hand-side row, for both leaves as two systems (launch_border_syrk_jobs)
+        for (int sy = 0; sy < 2; ++sy)
+          for (int jb = 0; jb < sep_nl; ++jb)
+            for (int ib = jb; ib <= sep_nl; ++ib) codes.push_back(sy << 20 | ib << 10 | jb);
+        if (d_lam_jobs2) { SL_HIP(hipFree(d_lam_jobs2)); d_lam_jobs2 = nullptr; }
+        n_lam_jobs2 = (int)codes.size();
+        SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_lam_jobs2), codes.size() * sizeof(int)));
+        SL_HIP(hipMemcpyAsync(d_lam_jobs2, codes.data(), codes.size() * sizeof(int), hipMemcpyHostToDevice, master)); SL_HIP(hipStreamSynchronize(master));
+      }
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&lamS), nb * sizeof(double)));
       SL_HIP(hipMemsetAsync(sep_bord, 0, nb * sizeof(double), master)); SL_HIP(hipStreamSynchronize(master));
       SL_HIP(hipMemsetAsync(lamS, 0, nb * sizeof(double), master)); SL_HIP(hipStreamSynchronize(master));
@@ -1069,18 +1080,27 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
             tp2[hh].S = sepS + (size_t)(hh ? sTa : 0) * NB * ld_s; tp2[hh].T = sep_leafT[hh]; tp2[hh].b0 = sTL;
             if (hh) { tp2[hh].bord = sep_top2; tp2[hh].ldb = sep_ld2; }
           }
-          if (sep_ks > 1) launch_border_syrk_jobs(tp2, 2, d_sep_jobs2, n_sep_jobs2, 0, master, sep_scratch, sep_ks, Tt);      // (both leaves, one launch)
-          else for (int hh = 0; hh < 2; ++hh) launch_border_syrk_jobs(&tp2[hh], 1, d_sep_jobs, n_sep_jobs, 0, master, sep_scratch, sep_ks, Tt);
-          for (int hh = 0; hh < 2; ++hh) {
-            const int t0 = hh ? sTa : 0, Th = sep_leafT[hh];
-            if (sep_nl > 0) {
-              CholSystem sl{};
-              sl.S = sepS + (size_t)t0 * NB * ld_s; sl.ld = ld_s; sl.T = Th; sl.b0 = sep_Ts; sl.nbr = sep_nl; sl.bord = hh ? sep_bord2 : sep_bord; sl.ldb = (sep_nl + 1) * NB;
-              const int ks = (sep_nl + 1) * sep_nl <= 32 ? std::max(1, std::min(16, Th / 2)) : 1;
-              launch_border_syrk(&sl, 1, master, lam_scratch, ks);
-            }
+          CholSystem sl2[2];
+          int ks_lam[2] = {1, 1};
+          for (int hh = 0; hh < 2 && sep_nl > 0; ++hh) {
+            CholSystem sl{};
+            sl.S = sepS + (size_t)(hh ? sTa : 0) * NB * ld_s; sl.ld = ld_s; sl.T = sep_leafT[hh]; sl.b0 = sep_Ts; sl.nbr = sep_nl;
+            sl.bord = hh ? sep_bord2 : sep_bord; sl.ldb = (sep_nl + 1) * NB;
+            ks_lam[hh] = (sep_nl + 1) * sep_nl <= 32 ? std::max(1, std::min(16, sep_leafT[hh] / 2)) : 1;
+            sl2[hh] = sl;
           }
-          launch_sep_top_add(Y, sTL, sep_top2, sep_ld2, sep_bord2, master);
+          if (sep_scratch && (sep_nl == 0 || (lam_scratch && d_lam_jobs2))) {
+            // both leaves in ONE launch each for the top block's columns and for the lambda block, every leaf's column blocks cut the way a
+            // rank owning that leaf cuts them, and one reduction each that also adds the second half's result onto the first
+            launch_border_syrk_jobs(tp2, 2, d_sep_jobs2, n_sep_jobs2, 0, master, sep_scratch, sep_ks, Tt, nullptr, true);
+            if (sep_nl > 0) launch_border_syrk_jobs(sl2, 2, d_lam_jobs2, n_lam_jobs2, 0, master, lam_scratch, 1, -1, ks_lam, true);
+          } else {
+            for (int hh = 0; hh < 2; ++hh) {
+              launch_border_syrk_jobs(&tp2[hh], 1, d_sep_jobs, n_sep_jobs, 0, master, sep_scratch, sep_ks, Tt);
+              if (sep_nl > 0) launch_border_syrk(&sl2[hh], 1, master, lam_scratch, ks_lam[hh]);
+            }
+            launch_sep_top_add(Y, sTL, sep_top2, sep_ld2, sep_bord2, master);
+          }
         } else {
           launch_border_syrk_jobs(&top, 1, d_sep_jobs, n_sep_jobs, 0, master, sep_scratch, sep_ks, Tt);
         }

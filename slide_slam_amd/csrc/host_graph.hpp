@@ -239,6 +239,7 @@ class CholBatch {
   // block (sepS's own top block: the first half's, sep_top2 / sep_bord2: the other's), each minus its leaf's Schur complement, added —
   // so that 1, 2, 4 and 8 ranks give the same bits (SURVEY 7 hard part 5).  sep_mask_b: the joined graphs that hold leaf b.
   double *sep_top2 = nullptr, *sep_bord2 = nullptr; int sep_ld2 = 0; unsigned sep_mask_b = 0;
+  int* d_lam_jobs2 = nullptr; int n_lam_jobs2 = 0;      // the same for the lambda block
   int* d_sep_jobs2 = nullptr; int n_sep_jobs2 = 0;      // the top block's product over BOTH leaves as two systems of one launch (system << 20 | ib << 10 | jb)
   bool sep_dissected() const { return sep_leafT[0] > 0 && sep_leafT[1] > 0; }
   // lambda coordinates of the inter-robot relative-pose factors: border rows of the separator system, their own small system

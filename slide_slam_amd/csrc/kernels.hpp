@@ -91,7 +91,8 @@ int chol_ll_plan_columns(const CholLLPlan* p);
 void launch_chol_ll(const CholLLPlan* p, const CholSystem* d, int n, hipStream_t s, int* trace = nullptr);      // trace: diagnostic, 16 host-pinned ints per task (ll_mark / ll_time) or null
 // Exact joint step (the border of the systems = the separator's coupling rows, W^T after the steps):
 void launch_border_syrk(const CholSystem* d, int n, hipStream_t s, double* scratch = nullptr, int ks = 1);          // bord(i, j) -= sum_c W^T(i, c) W^T(j, c)^T, i >= j, right-hand-side row included; scratch + ks: split K (one system)
-void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int njobs, int lds_pad, hipStream_t s, double* scratch = nullptr, int ks = 1, int jb_end = -1);      // the same, workgroups in the order of a job table (system << 20 | ib << 10 | jb), lds_pad bytes of idle LDS per workgroup (bounds the residency)
+void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int njobs, int lds_pad, hipStream_t s, double* scratch = nullptr, int ks = 1, int jb_end = -1,
+                             const int* ks_sys = nullptr, bool fuse_add = false);      // fuse_add (n = 2, same border): system 0's block += system 1's, each split its own way (ks_sys)      // the same, workgroups in the order of a job table (system << 20 | ib << 10 | jb), lds_pad bytes of idle LDS per workgroup (bounds the residency)
 void launch_border_apply(const CholSystem* d, int n, const double* const* xloc, hipStream_t s);   // yv -= W x_loc (x_loc: nbr * NB doubles per system)
 // one of the two triangular solves with the finished factors of up to 8 systems on arbitrary vectors (T * NB doubles each): out = L^-1 in
 // (fwd) or L^-T in (bwd); the preconditioner of the joint solve (pcg_kernels.hip)
