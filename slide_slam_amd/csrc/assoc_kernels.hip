@@ -398,6 +398,28 @@ __global__ __launch_bounds__(1024) void k_assoc_sweep(const float* __restrict__ 
   assoc_core(C);
 }
 
+// The same with 512-thread workgroups, two per CU (round 4): the kernel is bound by its in-CU select / match phases,
+// every one of which ends at a workgroup barrier — a second resident workgroup fills the other's barrier stalls.  64 KB of LDS each
+// (40 KB of distance words / staged models, 8 KB of keys, per-wave histograms), registers capped at 128 by the second bound.
+__global__ __launch_bounds__(512, 2) void k_assoc_sweep_512(const float* __restrict__ cx, const float* __restrict__ cy, const float* __restrict__ cz,
+                                                            const double* __restrict__ model_xyz, const int32_t* __restrict__ label, int n_map,
+                                                            const double* __restrict__ query_pos, const double* __restrict__ obs_xyz,
+                                                            const int32_t* __restrict__ obs_label, int n_obs, int K, int Kp, int cached,
+                                                            int staged, double thresh, int32_t* __restrict__ out_map_idx) {
+  const int q = blockIdx.x;
+  AssocCore C;
+  C.cx = cx; C.cy = cy; C.cz = cz; C.model = model_xyz; C.label = label; C.n = n_map; C.K = K;
+  C.gate = 1; C.Kp = Kp; C.cached = cached; C.staged = staged;
+  C.thresh = thresh; C.best_init = 1000.0; C.label_gate = 1; C.is_cyl = 0;
+  C.qpos = query_pos + 3 * (size_t)q;
+  C.det_world = obs_xyz + 3 * (size_t)q * n_obs;
+  C.det_stride = 3; C.det_off = 0;
+  C.det_label = obs_label + (size_t)q * n_obs; C.n_det = n_obs;
+  C.match_sub = nullptr; C.submap = nullptr; C.n_sub = nullptr;
+  C.match_map = out_map_idx + (size_t)q * n_obs;
+  assoc_core(C);
+}
+
 // updateFactorGraphMap (graphWrapper.cpp:239-275): optimised landmarks -> map models
 __global__ void k_map_refresh(double* cyl_model, int n_cyl, const int* cyl_lid, double* cube_xyz, int n_cube,
                               const int* cube_lid, double* ell_xyz, int n_ell, const int* ell_lid, const double* lm_est) {
@@ -421,6 +443,7 @@ static void ensure_lds_attr() {
   if (g_attr_set) return;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_frame), hipFuncAttributeMaxDynamicSharedMemorySize, ASSOC_LDS_BUDGET);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, ASSOC_LDS_BUDGET);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_sweep_512), hipFuncAttributeMaxDynamicSharedMemorySize, ASSOC_LDS_BUDGET);
   g_attr_set = true;
 }
 
@@ -454,8 +477,15 @@ int launch_assoc_sweep(const float* cx, const float* cy, const float* cz, const 
   int Kp, cached, staged;
   size_t bytes;
   if (!assoc_plan(n_map, K, 1, 3, &Kp, &cached, &staged, &bytes)) return -1;
-  hipLaunchKernelGGL(k_assoc_sweep, dim3(n_query), dim3(1024), bytes, s, cx, cy, cz, model_xyz, label, n_map, query_pos, obs_xyz,
-                     obs_label, n_obs, K, Kp, cached, staged, thresh, out_map_idx);
+  // two 512-thread workgroups per CU when the plan's LDS lets two fit (the default since round 4: 0.870 -> 0.710 ms per launch of 8192
+  // frames against a 10 k-landmark map, 1.40 -> 1.72 TB/s algorithmic; SLIDE_ASSOC_THREADS=1024: one 1024-thread workgroup per CU)
+  static const int env_thr = getenv("SLIDE_ASSOC_THREADS") ? atoi(getenv("SLIDE_ASSOC_THREADS")) : 512;
+  if (env_thr == 512 && bytes + 20 * 1024 <= 80 * 1024 && Kp <= 1024)
+    hipLaunchKernelGGL(k_assoc_sweep_512, dim3(n_query), dim3(512), bytes, s, cx, cy, cz, model_xyz, label, n_map, query_pos, obs_xyz,
+                       obs_label, n_obs, K, Kp, cached, staged, thresh, out_map_idx);
+  else
+    hipLaunchKernelGGL(k_assoc_sweep, dim3(n_query), dim3(1024), bytes, s, cx, cy, cz, model_xyz, label, n_map, query_pos, obs_xyz,
+                       obs_label, n_obs, K, Kp, cached, staged, thresh, out_map_idx);
   return 0;
 }
 
