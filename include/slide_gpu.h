@@ -466,6 +466,12 @@ void slide_clipper_default_params(slide_clipper_params_t* p);
  * projection, line-search and stopping decision in one persistent workgroup — no host round trip inside the iteration. */
 int slide_clipper_dense_clique(const double* M_upper, int n, const double* u0, const slide_clipper_params_t* p,
                                int32_t* nodes_out, int* n_nodes, double* u_out, double* score);
+/* One LARGE problem (n >= 1024 associations; SURVEY A15 speaks of m ~ 1e4) runs on several co-resident workgroups — the rows of the
+ * sparse product over the waves of up to 128 workgroups (cooperative launch), one grid barrier per gradient evaluation, everything
+ * else repeated per workgroup so that the iterates equal the one-workgroup solve's bit for bit.  SLIDE_CLIPPER_WGS=<k> in the
+ * environment forces the workgroup count (1 = one workgroup).  slide_clipper_last_solve_info: how the last
+ * slide_clipper_dense_clique call of this process ran (workgroups, gradient evaluations); either pointer may be NULL. */
+void slide_clipper_last_solve_info(int* n_workgroups, double* grad_evals);
 /* The same for several independent problems in ONE launch, a persistent workgroup per problem — the robot pairs of a multi-robot job
  * (semantic_clipper.cpp:227-235 once per pair; 28 pairs at eight robots).  Job j: M_upper[j] (n[j] x n[j]), u0[j] or NULL,
  * nodes_out[j] (>= n[j] ints), u_out[j] (n[j] doubles or NULL); n_nodes[j], score[j].  Results equal n_jobs single calls. */

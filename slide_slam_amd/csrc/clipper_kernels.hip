@@ -3,10 +3,12 @@
 // The reference keeps the affinity matrix M and the constraint pattern C (= sparsity pattern of M, clipper.cpp:55-64) as Eigen
 // sparse matrices and runs projected gradient ascent with backtracking on F(u) = u^T (M + I - d (11^T - C - I)) u; d grows in an
 // outer loop until no constraint is active.  Here: M in CSR (built on the device from the upper-filled dense affinity matrix), and
-// the WHOLE solve — every product, reduction, clamp, normalisation, line-search and stopping decision — in ONE persistent workgroup
-// of 1024 threads (k_clq_solve): the iteration is strictly sequential with O(nnz) work per evaluation, so there is nothing for more
-// than one CU to do that would outweigh a grid-wide barrier per evaluation, and no host round trip remains inside the loop (the
-// round-1 version copied three vectors over PCIe per evaluation).  Loops are bounded by maxoliters x maxiniters x maxlsiters.
+// the WHOLE solve — every product, reduction, clamp, normalisation, line-search and stopping decision — in ONE launch with no host
+// round trip inside the loop: a persistent workgroup of 1024 threads per problem (k_clq_solve, k_clq_solve_b: the iteration is
+// strictly sequential with O(nnz) work per evaluation, and the problems sloam meets — tens to hundreds of associations — leave a
+// second CU nothing to do that outweighs a grid barrier), and for ONE LARGE problem (m in the thousands) k_clq_solve_coop:
+// the rows of the product over the waves of up to 128 co-resident workgroups, one grid barrier per evaluation, iterates bit-identical
+// to the one-workgroup kernel's.  Loops are bounded by maxoliters x maxiniters x maxlsiters.
 #include <hip/hip_runtime.h>
 
 #include "kernels.hpp"
@@ -48,10 +50,59 @@ __device__ __forceinline__ double clq_block_sum(double x, double* sh) {
   for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];      // same order in every thread: identical result everywhere
   return s;
 }
-// Mu = M v, Cu = C v (C = pattern of M): wave per row
-__device__ __forceinline__ void clq_prod(const ClqSolve& A, const double* __restrict__ v) {
+
+// ---- one LARGE problem on several workgroups (COOP) ---------------------------------------------------------------------------------
+// The rows of the product are dealt to the waves of ALL workgroups; everything else — the step, the projection, every reduction,
+// the line search and the stopping decisions — each workgroup repeats for the whole vector on PRIVATE copies of u / unew / g / gnew,
+// with the very code and thread layout of the one-workgroup solve.  So every workgroup holds bit-identical iterates, takes the same
+// branches and reaches the same grid barriers, the iterates equal the one-workgroup kernel's bit for bit, and the only data crossing
+// workgroups are Mu / Cu: written with agent-scope (write-through) stores, read with agent-scope loads (the per-XCD L2s are not
+// coherent: profiles/r04_tile_hop_bench.txt has the protocol measurements), double-buffered by product parity because a fast
+// workgroup may start the next product while a slow one still reads this one's result — ONE grid barrier per product.
+struct ClqGrid {
+  int* bar;       // [0] arrivals (monotonic), [1] abort word
+  int n_wg;
+  int epoch;      // barriers passed (same in every thread of every workgroup)
+  int par;        // parity of the product being computed
+};
+template <bool COOP> __device__ __forceinline__ double clq_ld(const double* p) {
+  if (COOP) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+// false: another workgroup gave up (or this one waited too long) — every caller returns at once, so the grid drains
+__device__ __forceinline__ bool clq_grid_sync(ClqGrid& G) {
+  __shared__ int s_ok;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's Mu / Cu stores have left
+  __syncthreads();
+  G.epoch += 1;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(G.bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int target = G.epoch * G.n_wg;
+    int good = 1, spins = 0;
+    while (__hip_atomic_load(G.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (__hip_atomic_load(G.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || ++spins > (1 << 24)) {
+        __hip_atomic_store(G.bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        good = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    s_ok = good;
+  }
+  __syncthreads();
+  return s_ok != 0;
+}
+
+// Mu = M v, Cu = C v (C = pattern of M): wave per row.  COOP: rows over the waves of the whole grid, results into the buffer of this
+// product's parity, then the grid barrier; returns false when the grid is being abandoned.
+template <bool COOP>
+__device__ __forceinline__ bool clq_prod(const ClqSolve& A, ClqGrid& G, const double* __restrict__ v, double*& Mu, double*& Cu) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-  for (int i = wave; i < A.n; i += nw) {
+  Mu = A.Mu + (COOP ? (size_t)G.par * 2 * A.n : 0);
+  Cu = A.Cu + (COOP ? (size_t)G.par * 2 * A.n : 0);
+  const int first = COOP ? (int)blockIdx.x * nw + wave : wave, step = COOP ? G.n_wg * nw : nw;
+  for (int i = first; i < A.n; i += step) {
     double s1 = 0.0, s2 = 0.0;
     for (int k = A.rowptr[i] + lane; k < A.rowptr[i + 1]; k += 64) {
       const double x = v[A.col[k]];
@@ -60,37 +111,55 @@ __device__ __forceinline__ void clq_prod(const ClqSolve& A, const double* __rest
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
-    if (lane == 0) { A.Mu[i] = s1; A.Cu[i] = s2; }
+    if (lane == 0) {
+      if (COOP) {
+        __hip_atomic_store(Mu + i, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(Cu + i, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        Mu[i] = s1; Cu[i] = s2;
+      }
+    }
+  }
+  if (COOP) {
+    G.par ^= 1;
+    return clq_grid_sync(G);
   }
   __syncthreads();
+  return true;
 }
-// gradient of F at v for the current d into gout; returns F = v . gout      (clipper.cpp:224-226, 246-248)
-__device__ __forceinline__ double clq_grad(const ClqSolve& A, const double* __restrict__ v, double d, double* __restrict__ gout, double* sh) {
+// gradient of F at v for the current d into gout; F = v . gout      (clipper.cpp:224-226, 246-248)
+template <bool COOP>
+__device__ __forceinline__ bool clq_grad(const ClqSolve& A, ClqGrid& G, const double* __restrict__ v, double d, double* __restrict__ gout, double* sh,
+                                         double* F_out) {
   double part = 0.0;
   for (int i = threadIdx.x; i < A.n; i += blockDim.x) part += v[i];
   const double su = clq_block_sum(part, sh);
-  clq_prod(A, v);
+  double *Mu, *Cu;
+  if (!clq_prod<COOP>(A, G, v, Mu, Cu)) return false;
   part = 0.0;
   for (int i = threadIdx.x; i < A.n; i += blockDim.x) {
-    const double gi = (1.0 + d) * v[i] - d * su + A.Mu[i] + A.Cu[i] * d;
+    const double gi = (1.0 + d) * v[i] - d * su + clq_ld<COOP>(Mu + i) + clq_ld<COOP>(Cu + i) * d;
     gout[i] = gi;
     part += v[i] * gi;
   }
-  const double F = clq_block_sum(part, sh);
+  *F_out = clq_block_sum(part, sh);
   __syncthreads();
-  return F;
+  return true;
 }
 // mean over the active constraints of (Mu + u) / Cbu, Cbu = sum(u) - Cu - u   (clipper.cpp:201-216, 283-295)
-__device__ __forceinline__ double clq_d_terms(const ClqSolve& A, const double* __restrict__ v, bool absval, int* cnt_out, double* sh) {
+template <bool COOP>
+__device__ __forceinline__ bool clq_d_terms(const ClqSolve& A, ClqGrid& G, const double* __restrict__ v, bool absval, int* cnt_out, double* sh,
+                                            double* mean_out) {
   double part = 0.0;
   for (int i = threadIdx.x; i < A.n; i += blockDim.x) part += v[i];
   const double su = clq_block_sum(part, sh);
-  clq_prod(A, v);
+  double *Mu, *Cu;
+  if (!clq_prod<COOP>(A, G, v, Mu, Cu)) return false;
   double acc = 0.0, cnt = 0.0;
   for (int i = threadIdx.x; i < A.n; i += blockDim.x) {
-    const double cbu = su - A.Cu[i] - v[i];
+    const double cbu = su - clq_ld<COOP>(Cu + i) - v[i];
     if (cbu > A.eps && v[i] > A.eps) {
-      const double q = (A.Mu[i] + v[i]) / cbu;
+      const double q = (clq_ld<COOP>(Mu + i) + v[i]) / cbu;
       acc += absval ? fabs(q) : q;
       cnt += 1.0;
     }
@@ -98,36 +167,41 @@ __device__ __forceinline__ double clq_d_terms(const ClqSolve& A, const double* _
   const double sa = clq_block_sum(acc, sh);
   const double sc = clq_block_sum(cnt, sh);
   *cnt_out = (int)sc;
-  return sc > 0.0 ? sa / sc : 0.0;
+  *mean_out = sc > 0.0 ? sa / sc : 0.0;
+  return true;
 }
 
-__device__ __forceinline__ void clq_solve_body(const ClqSolve& A) {
+// uw: this workgroup's u / unew / g / gnew (4 n doubles; A.u itself for the one-workgroup solve)
+template <bool COOP>
+__device__ __forceinline__ void clq_solve_body(const ClqSolve& A, ClqGrid& G, double* uw) {
   __shared__ double sh[16];
   const int tid = threadIdx.x, nt = blockDim.x, n = A.n;
+  double *u = uw, *unew = uw + n, *g = uw + 2 * (size_t)n, *gnew = uw + 3 * (size_t)n;
   // u <- normalised (M u0 + u0) or u0   (clipper.cpp:186-199)
   if (A.rescale) {
-    clq_prod(A, A.u0);
-    for (int i = tid; i < n; i += nt) A.u[i] = A.Mu[i] + A.u0[i];
+    double *Mu, *Cu;
+    if (!clq_prod<COOP>(A, G, A.u0, Mu, Cu)) return;
+    for (int i = tid; i < n; i += nt) u[i] = clq_ld<COOP>(Mu + i) + A.u0[i];
   } else {
-    for (int i = tid; i < n; i += nt) A.u[i] = A.u0[i];
+    for (int i = tid; i < n; i += nt) u[i] = A.u0[i];
   }
   __syncthreads();
   {
     double part = 0.0;
-    for (int i = tid; i < n; i += nt) part += A.u[i] * A.u[i];
+    for (int i = tid; i < n; i += nt) part += u[i] * u[i];
     const double nn = sqrt(clq_block_sum(part, sh));
-    for (int i = tid; i < n; i += nt) A.u[i] /= nn;
+    for (int i = tid; i < n; i += nt) u[i] /= nn;
     __syncthreads();
   }
   double d = 0.0, F = 0.0, evals = 0.0;
   int cnt = 0, outer = 0;
   {
-    const double t = clq_d_terms(A, A.u, false, &cnt, sh);
+    double t;
+    if (!clq_d_terms<COOP>(A, G, u, false, &cnt, sh, &t)) return;
     if (cnt > 0) d = t;
   }
-  double *u = A.u, *unew = A.unew, *g = A.g, *gnew = A.gnew;
   for (outer = 0; outer < A.maxol; ++outer) {
-    F = clq_grad(A, u, d, g, sh);
+    if (!clq_grad<COOP>(A, G, u, d, g, sh, &F)) return;
     evals += 1.0;
     for (int j = 0; j < A.maxin; ++j) {
       double alpha = 1.0, Fnew = 0.0, deltaF = 0.0;
@@ -142,7 +216,7 @@ __device__ __forceinline__ void clq_solve_body(const ClqSolve& A) {
         const double nn = sqrt(clq_block_sum(part, sh));
         for (int i = tid; i < n; i += nt) unew[i] /= nn;
         __syncthreads();
-        Fnew = clq_grad(A, unew, d, gnew, sh);
+        if (!clq_grad<COOP>(A, G, unew, d, gnew, sh, &Fnew)) return;
         evals += 1.0;
         deltaF = Fnew - F;
         if (deltaF < -A.eps) alpha *= A.beta;        // backtracking line search (every thread holds the same numbers)
@@ -157,25 +231,49 @@ __device__ __forceinline__ void clq_solve_body(const ClqSolve& A) {
       __syncthreads();
       if (du < A.tol_u || fabs(deltaF) < A.tol_F) break;
     }
-    const double deltad = clq_d_terms(A, u, true, &cnt, sh);
+    double deltad;
+    if (!clq_d_terms<COOP>(A, G, u, true, &cnt, sh, &deltad)) return;
     if (cnt > 0) d += deltad;
     else break;
   }
-  // the iterate ends up in A.u for the caller
-  if (u != A.u) {
-    for (int i = tid; i < n; i += nt) A.u[i] = u[i];
+  // the iterate ends up in A.u for the caller (COOP: workgroup 0 hands over its copy)
+  if (!COOP || blockIdx.x == 0) {
+    if (u != A.u) {
+      for (int i = tid; i < n; i += nt) A.u[i] = u[i];
+    }
+    if (tid == 0) { A.out[0] = F; A.out[1] = d; A.out[2] = evals; A.out[3] = (double)outer; }
   }
-  if (tid == 0) { A.out[0] = F; A.out[1] = d; A.out[2] = evals; A.out[3] = (double)outer; }
 }
 
-__global__ __launch_bounds__(1024) void k_clq_solve(ClqSolve A) { clq_solve_body(A); }
+__global__ __launch_bounds__(1024) void k_clq_solve(ClqSolve A) {
+  ClqGrid G{nullptr, 1, 0, 0};
+  clq_solve_body<false>(A, G, A.u);
+}
 // several independent problems (the robot pairs of a multi-robot job, SURVEY 8e: 28 at eight robots), one persistent workgroup each
 __global__ __launch_bounds__(1024) void k_clq_solve_b(const ClqSolve* __restrict__ jobs) {
   const ClqSolve A = jobs[blockIdx.x];
-  if (A.n > 0) clq_solve_body(A);
+  ClqGrid G{nullptr, 1, 0, 0};
+  if (A.n > 0) clq_solve_body<false>(A, G, A.u);
+}
+// one large problem on n_wg co-resident workgroups (cooperative launch); priv: n_wg x 4 n doubles, bar: 2 ints, zero at launch;
+// A.Mu: 4 n doubles, [parity][Mu | Cu] (A.Cu = A.Mu + n); A.u receives the result
+__global__ __launch_bounds__(1024) void k_clq_solve_coop(ClqSolve A, double* priv, int* bar, int n_wg) {
+  ClqGrid G{bar, n_wg, 0, 0};
+  clq_solve_body<true>(A, G, priv + (size_t)blockIdx.x * 4 * A.n);
+  // a workgroup that left through a failed barrier reports it (out[2] < 0: the host turns it into an error)
+  if (threadIdx.x == 0 && blockIdx.x == 0 && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) A.out[2] = -1.0;
 }
 void launch_clq_solve_batch(const ClqSolve* d_jobs, int n_jobs, hipStream_t s) {
   if (n_jobs > 0) hipLaunchKernelGGL(k_clq_solve_b, dim3(n_jobs), dim3(1024), 0, s, d_jobs);
+}
+// false: the cooperative launch was refused (the caller falls back to the one-workgroup kernel)
+bool launch_clq_solve_coop(const ClqSolve& A, double* priv, int* bar2, int n_wg, hipStream_t s) {
+  if (hipMemsetAsync(bar2, 0, 2 * sizeof(int), s) != hipSuccess) return false;
+  ClqSolve a = A;
+  void* args[] = {&a, &priv, &bar2, &n_wg};
+  const hipError_t e = hipLaunchCooperativeKernel((const void*)k_clq_solve_coop, dim3(n_wg), dim3(1024), args, 0, s);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return true;
 }
 
 void launch_clq_csr_count(const double* Mup, int n, int* rowcnt, hipStream_t s) {

@@ -185,6 +185,9 @@ struct ClqSolve {
   double* out;                    // [0] F, [1] d, [2] gradient evaluations, [3] outer iterations
 };
 void launch_clq_solve_batch(const ClqSolve* d_jobs, int n_jobs, hipStream_t s);      // one persistent workgroup per job (grid = n_jobs)
+// one large problem on n_wg co-resident workgroups (cooperative launch): A.u (n) receives the result, A.Mu = 4 n doubles with A.Cu = A.Mu + n,
+// priv = n_wg x 4 n doubles, bar2 = 2 ints; false when the cooperative launch is refused.  out[2] < 0 afterwards: a grid barrier timed out.
+bool launch_clq_solve_coop(const ClqSolve& A, double* priv, int* bar2, int n_wg, hipStream_t s);
 void launch_clq_csr_count(const double* Mup, int n, int* rowcnt, hipStream_t s);
 void launch_clq_csr_fill(const double* Mup, int n, const int* rowptr, int* col, double* val, hipStream_t s);
 void launch_clq_solve(const int* rowptr, const int* col, const double* val, int n, const double* u0, double* work6n, double tol_u, double tol_F,

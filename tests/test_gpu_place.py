@@ -295,6 +295,64 @@ def test_dense_clique_large_planted(gpu):
     assert np.all(u >= 0) and abs(np.linalg.norm(u) - 1.0) < 1e-9
 
 
+def _planted_problem(m, k, density, seed):
+    rng = np.random.default_rng(seed)
+    M = np.zeros((m, m))
+    iu = np.triu_indices(m, 1)
+    mask = rng.uniform(0, 1, len(iu[0])) < density
+    M[iu[0][mask], iu[1][mask]] = rng.uniform(0.2, 0.9, int(mask.sum()))
+    planted = np.sort(rng.permutation(m)[:k])
+    for a in range(k):
+        for b in range(a + 1, k):
+            M[planted[a], planted[b]] = rng.uniform(0.9, 1.0)
+    return M, planted, rng.uniform(0, 1, m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k,density", [(1500, 40, 0.02), (4096, 60, 0.01), (6000, 80, 0.004)])
+def test_dense_clique_large_cooperative_equals_one_workgroup(gpu, m, k, density):
+    """One LARGE problem (m >= 1024): the sparse product's rows over the waves of many co-resident workgroups (k_clq_solve_coop, one
+    grid barrier per gradient evaluation) — iterate for iterate the one-workgroup solve: the same number of gradient evaluations,
+    bit-identical weights and score, the same clique; and the clique, weights and score of the oracle from the same start
+    (the tolerances of test_dense_clique_matches_oracle).  Both wall times go into the test's output."""
+    import ctypes as C
+    import os
+    import time
+    M, planted, u0 = _planted_problem(m, k, density, 17 + m)
+    p = gpu.clipper_params()
+    res = {}
+    for wgs in ("1", None, "37"):          # one workgroup; the default count (m / 64, at most 128); an odd count
+        if wgs is None:
+            os.environ.pop("SLIDE_CLIPPER_WGS", None)
+        else:
+            os.environ["SLIDE_CLIPPER_WGS"] = wgs
+        try:
+            gpu.clipper_dense_clique(M, u0, p)                 # warm (allocations, code load)
+            t0 = time.perf_counter()
+            nodes, u, score = gpu.clipper_dense_clique(M, u0, p)
+            dt = time.perf_counter() - t0
+        finally:
+            os.environ.pop("SLIDE_CLIPPER_WGS", None)
+        res[wgs] = (nodes, u, score, gpu.clipper_last_solve_info(), dt)
+    n1, u1, s1, (w1, e1), t1 = res["1"]
+    assert w1 == 1
+    for key in (None, "37"):
+        nc, uc, sc, (wc, ec), tc = res[key]
+        assert wc == (37 if key else min(128, (m + 63) // 64)) and wc > 1
+        assert ec == e1 and sc == s1 and np.array_equal(uc, u1) and np.array_equal(nc, n1), (key, ec, e1, sc - s1)
+    print(f"clipper m={m}: {int(e1)} gradient evaluations; whole call (upload + CSR + solve) {t1 * 1e3:.1f} ms on one workgroup, "
+          f"{res[None][4] * 1e3:.1f} ms on {res[None][3][0]}")
+    hit = len(set(n1.tolist()) & set(planted.tolist()))
+    assert hit >= 0.9 * k, (hit, len(n1))
+    op = _oracle_clipper_params()
+    on = np.zeros(m, np.int32); ou = np.zeros(m); osc = C.c_double(0)
+    n = po.lib().orc_clipper_solve(M.ctypes.data_as(C.c_void_p), C.c_int(m), u0.ctypes.data_as(C.c_void_p), C.byref(op),
+                                   on.ctypes.data_as(C.c_void_p), ou.ctypes.data_as(C.c_void_p), C.byref(osc))
+    assert sorted(n1.tolist()) == sorted(on[:n].tolist())
+    assert abs(s1 - osc.value) < 1e-6 * max(1.0, abs(osc.value))
+    assert np.abs(u1 - ou).max() < 1e-6
+
+
 @pytest.mark.gpu
 def test_semantic_clipper_pipeline(gpu):
     import ctypes as C
