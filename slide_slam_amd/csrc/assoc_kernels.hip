@@ -80,17 +80,65 @@ __device__ __forceinline__ unsigned dist_bits(const AssocCore& C, int i, float q
 // The K smallest (distance bits << 32 | index) keys of the cloud into sel[0 .. Ksub): ascending when `sorted` (the reference's
 // nearest-first submap), else in the order the compaction happened to place them (the matching breaks ties by the keys themselves, so
 // it needs the SET only: the bitonic sort is a quarter of a frame's time).  Returns Ksub.
+//
+// Round 4: the K-th key is found by ONE histogram over bins that are LINEAR in the squared distance (bin = floor(r * 1023.5 / r_max):
+// float multiplication by a positive constant and the conversion are monotone, so lower bin => smaller key), not by most-significant-
+// digit passes over the float's bits — the leading byte of those bits is the exponent, nearly every landmark of a map shares it, and
+// the 10 k LDS atomics of such a pass hit two or three addresses and serialise (stamps: 10.9 of a frame's 35 us in the select).  For
+// landmarks spread over a plane r is close to uniformly distributed, the atomics scatter over the bins, and the bin that holds the
+// K-th key holds a few dozen keys: those go to a candidate list and every candidate counts the candidates below it (its rank) — keys
+// in lower bins are selected outright.  A bin with more than ASSOC_CAND_CAP keys (coincident landmarks, a map on a ring around the
+// robot) falls back to the digit passes, restricted to that bin.  The compaction counts per wave first and claims its output range
+// with one atomic per wave instead of one per 64 keys (each a dependent LDS round trip: 5.4 us of the 35).
+constexpr int ASSOC_BINS = 1024, ASSOC_CAND_CAP = 1024;
 __device__ inline int knn_select(const AssocCore& C, unsigned long long* sel, unsigned* hist, unsigned* dcache, bool sorted) {
   __shared__ unsigned long long s_prefix;
-  __shared__ int s_krem, s_stop, s_cnt;
-  __shared__ unsigned whist[16 * 256];          // per-wave digit histograms of the radix select
+  __shared__ int s_krem, s_stop, s_cnt, s_ccnt, s_bin, s_before;
+  __shared__ unsigned s_wred[16];
+  __shared__ unsigned sbuf[16 * 256];           // bin counts (1024) + candidate keys (1024 x 8 B); the fallback's per-wave digit histograms
+  unsigned* lhist = sbuf;
+  unsigned long long* lcand = reinterpret_cast<unsigned long long*>(sbuf + ASSOC_BINS);
+  unsigned* whist = sbuf;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6;
   const int n = C.n, Ksub = C.K < n ? C.K : n;
   const float qx = (float)C.qpos[0], qy = (float)C.qpos[1], qz = (float)C.qpos[2];
   const int n_up = (n + nthr - 1) / nthr * nthr;
-  if (C.cached)
-    for (int i = tid; i < n; i += nthr) dcache[i] = dist_bits(C, i, qx, qy, qz);
-  if (tid == 0) { s_prefix = 0ull; s_krem = Ksub; s_stop = 0; s_cnt = 0; }
+  // distance words (kept in LDS when they fit) and their maximum; eight independent loads in flight per stream (the cloud is L2-resident
+  // across the frames of a launch: the scan is a chain of L2 round trips otherwise)
+  unsigned bmax = 0u;
+  {
+    int i = tid;
+    for (; i + 7 * nthr < n; i += 8 * nthr) {
+      unsigned b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) b[u] = dist_bits(C, i + u * nthr, qx, qy, qz);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (C.cached) dcache[i + u * nthr] = b[u];
+        bmax = b[u] > bmax ? b[u] : bmax;
+      }
+    }
+    for (; i + 3 * nthr < n; i += 4 * nthr) {
+      unsigned b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b[u] = dist_bits(C, i + u * nthr, qx, qy, qz);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (C.cached) dcache[i + u * nthr] = b[u];
+        bmax = b[u] > bmax ? b[u] : bmax;
+      }
+    }
+    for (; i < n; i += nthr) {
+      const unsigned b = dist_bits(C, i, qx, qy, qz);
+      if (C.cached) dcache[i] = b;
+      bmax = b > bmax ? b : bmax;
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)bmax, m); bmax = o > bmax ? o : bmax; }
+  if (lane == 0) s_wred[tid >> 6] = bmax;
+  for (int b = tid; b < ASSOC_BINS; b += nthr) lhist[b] = 0u;
+  if (tid == 0) { s_prefix = 0ull; s_krem = Ksub; s_stop = 0; s_cnt = 0; s_ccnt = 0; s_bin = -1; s_before = 0; }
   __syncthreads();
   ASTAMP(1);
   auto key_at = [&](int i) -> unsigned long long {
@@ -98,73 +146,192 @@ __device__ inline int knn_select(const AssocCore& C, unsigned long long* sel, un
     return ((unsigned long long)b << 32) | (unsigned)i;
   };
   int shift = 64;                   // selected <=> (key >> shift) <= (prefix >> shift); 64 = everything (K >= n)
+  int fbin = -1;                    // the bin of the K-th key; keys in lower bins are selected whatever the digit passes say
+  float scale = 0.0f;
+  auto bin_of = [&](unsigned long long key) -> int {
+    const int b = (int)(__uint_as_float((unsigned)(key >> 32)) * scale);
+    return b < ASSOC_BINS - 1 ? b : ASSOC_BINS - 1;
+  };
+  bool ranked = false;              // the candidates' ranks placed the last keys: nothing left for the compaction but the lower bins
   if (Ksub < n) {
-    for (int byte = 7; byte >= 0; --byte) {
-      shift = 8 * byte;
-      // one histogram per wave (no contention between waves; lanes of a wave that hit the same bin are serialised by the LDS
-      // atomic unit, ~1 per clock — cheaper than any software aggregation), summed into hist[0 .. 255] afterwards
-      for (int b = tid; b < 256 * nw; b += nthr) whist[b] = 0u;
+    for (int w = 0; w < nw; ++w) bmax = s_wred[w] > bmax ? s_wred[w] : bmax;
+    const float rmax = __uint_as_float(bmax);
+    scale = rmax > 0.0f ? ((float)ASSOC_BINS - 0.5f) / rmax : 0.0f;      // (r = NaN or inf: a corrupt cloud — everything lands in one bin, the fallback sorts it out)
+    if (!(scale == scale) || scale > 3.0e38f) scale = 0.0f;
+    {
+      int i = tid;
+      for (; i + 3 * nthr < n; i += 4 * nthr) {
+        int bb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bb[u] = bin_of(key_at(i + u * nthr));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) atomicAdd(&lhist[bb[u]], 1u);
+      }
+      for (; i < n; i += nthr) atomicAdd(&lhist[bin_of(key_at(i))], 1u);
+    }
+    __syncthreads();
+    ASTAMP(12);
+    {
+      // the bin at which the running count reaches K: bins `per` at a time per thread, wave scan, wave totals through LDS
+      const int per = (ASSOC_BINS + nthr - 1) / nthr;
+      unsigned own = 0;
+      for (int k = 0; k < per; ++k) { const int bb = tid * per + k; if (bb < ASSOC_BINS) own += lhist[bb]; }
+      unsigned inc = own;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = (unsigned)__shfl_up((int)inc, off);
+        if (lane >= off) inc += o;
+      }
+      if (lane == 63) s_wred[tid >> 6] = inc;
       __syncthreads();
-      const unsigned long long prefix = s_prefix;
-      unsigned* mine = whist + 256 * (tid >> 6);
-      for (int i = tid; i < n; i += nthr) {
-        const unsigned long long key = key_at(i);
-        if (byte == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&mine[(unsigned)(key >> shift) & 255u], 1u);
+      unsigned base = 0;
+      for (int w = 0; w < (tid >> 6); ++w) base += s_wred[w];
+      const unsigned before_t = base + inc - own;
+      if (before_t < (unsigned)Ksub && (unsigned)Ksub <= before_t + own) {      // exactly one thread: the counts sum to n >= K
+        unsigned before = before_t;
+        int bb = tid * per;
+        while (before + lhist[bb] < (unsigned)Ksub) { before += lhist[bb]; ++bb; }
+        s_bin = bb;
+        s_before = (int)before;
+        s_krem = Ksub - (int)before;
       }
       __syncthreads();
-      for (int b = tid; b < 256; b += nthr) {
-        unsigned t = 0;
-        for (int w = 0; w < nw; ++w) t += whist[256 * w + b];
-        hist[b] = t;
-      }
-      __syncthreads();
-      if (tid < 64) {
-        // bins 4 lane .. 4 lane + 3: the first bin at which the running count reaches the wanted rank
-        const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
-        const unsigned own = h0 + h1 + h2 + h3;
-        unsigned inc = own;
+    }
+    ASTAMP(13);
+    fbin = s_bin;
+    const int before = s_before, krem = s_krem;
+    const int ncand = (int)lhist[fbin];
+    if (ncand <= ASSOC_CAND_CAP) {
+      // ONE pass places the keys of the lower bins in sel[0 .. before) and the K-th key's bin in the candidate list (any order): a
+      // thread notes which of its keys go where (bit masks over up to 32 keys), a wave scan of the counts and one atomic per wave
+      // and list give every thread its own output range — no dependent LDS round trip per 64 keys.  Then every candidate's rank among
+      // the candidates: the krem lowest go to sel[before + rank].
+      for (int c0 = 0; c0 < n; c0 += 32 * nthr) {
+        unsigned tm = 0u, cm = 0u;
+        const int its = min(32, (n - c0 + nthr - 1) / nthr);
+#pragma unroll 4
+        for (int it = 0; it < its; ++it) {
+          const int i = c0 + it * nthr + tid;
+          if (i < n) {
+            const int b = bin_of(key_at(i));
+            tm |= (b < fbin ? 1u : 0u) << it;
+            cm |= (b == fbin ? 1u : 0u) << it;
+          }
+        }
+        const int ct = __popc(tm), cc = __popc(cm);
+        int st = ct, sc = cc;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-          const unsigned o = (unsigned)__shfl_up((int)inc, off);
-          if (lane >= off) inc += o;
+          const int o1 = __shfl_up(st, off), o2 = __shfl_up(sc, off);
+          if (lane >= off) { st += o1; sc += o2; }
         }
-        const unsigned krem = (unsigned)s_krem;
-        const unsigned long long reach = __ballot(inc >= krem);
-        const int first = __ffsll((long long)reach) - 1;        // exists: the matching keys number at least krem
-        if (lane == first) {
-          unsigned before = inc - own;
-          unsigned d = 4 * lane, cnt = h0;
-          if (before + h0 < krem) { before += h0; d += 1; cnt = h1;
-            if (before + h1 < krem) { before += h1; d += 1; cnt = h2;
-              if (before + h2 < krem) { before += h2; d += 1; cnt = h3; } } }
-          s_prefix = prefix | ((unsigned long long)d << shift);
-          s_krem = (int)(krem - before);
-          s_stop = (before + cnt == krem) ? 1 : 0;      // the whole bin goes: nothing left to decide below this byte
+        int bt = 0, bc = 0;
+        if (lane == 63) {
+          if (st > 0) bt = atomicAdd(&s_cnt, st);
+          if (sc > 0) bc = atomicAdd(&s_ccnt, sc);
+        }
+        bt = __shfl(bt, 63) + st - ct;
+        bc = __shfl(bc, 63) + sc - cc;
+        while (tm) {
+          const int it = __ffs((int)tm) - 1;
+          tm &= tm - 1u;
+          sel[bt++] = key_at(c0 + it * nthr + tid);
+        }
+        while (cm) {
+          const int it = __ffs((int)cm) - 1;
+          cm &= cm - 1u;
+          lcand[bc++] = key_at(c0 + it * nthr + tid);
         }
       }
       __syncthreads();
-      if (s_stop) break;
+      ASTAMP(14);
+      for (int j = tid; j < ncand; j += nthr) {
+        const unsigned long long kj = lcand[j];
+        int rank = 0;
+        for (int i = 0; i < ncand; ++i) rank += lcand[i] < kj ? 1 : 0;
+        if (rank < krem) sel[before + rank] = kj;
+      }
+      ranked = true;
+    } else {
+      // digit passes over the keys of that bin alone (most significant byte first, as before round 4)
+      __syncthreads();
+      for (int byte = 7; byte >= 0; --byte) {
+        shift = 8 * byte;
+        for (int b = tid; b < 256 * nw; b += nthr) whist[b] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        unsigned* mine = whist + 256 * (tid >> 6);
+        for (int i = tid; i < n; i += nthr) {
+          const unsigned long long key = key_at(i);
+          if (bin_of(key) != fbin) continue;
+          if (byte == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&mine[(unsigned)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        for (int b = tid; b < 256; b += nthr) {
+          unsigned t = 0;
+          for (int w = 0; w < nw; ++w) t += whist[256 * w + b];
+          hist[b] = t;
+        }
+        __syncthreads();
+        if (tid < 64) {
+          // bins 4 lane .. 4 lane + 3: the first bin at which the running count reaches the wanted rank
+          const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+          const unsigned own = h0 + h1 + h2 + h3;
+          unsigned inc = own;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = (unsigned)__shfl_up((int)inc, off);
+            if (lane >= off) inc += o;
+          }
+          const unsigned kr = (unsigned)s_krem;
+          const unsigned long long reach = __ballot(inc >= kr);
+          const int first = __ffsll((long long)reach) - 1;        // exists: the matching keys number at least kr
+          if (lane == first) {
+            unsigned bef = inc - own;
+            unsigned d = 4 * lane, cnt = h0;
+            if (bef + h0 < kr) { bef += h0; d += 1; cnt = h1;
+              if (bef + h1 < kr) { bef += h1; d += 1; cnt = h2;
+                if (bef + h2 < kr) { bef += h2; d += 1; cnt = h3; } } }
+            s_prefix = prefix | ((unsigned long long)d << shift);
+            s_krem = (int)(kr - bef);
+            s_stop = (bef + cnt == kr) ? 1 : 0;      // the whole digit goes: nothing left to decide below this byte
+          }
+        }
+        __syncthreads();
+        if (s_stop) break;
+      }
     }
   }
   ASTAMP(2);
-  // compaction of the selected keys (any order), then the sort that orders them
-  {
+  // what is left to place: everything when K >= n; after digit passes the keys of the lower bins and those of the K-th key's bin at or
+  // below the prefix (every wave counts its keys first and claims its range of sel with one atomic)
+  if (fbin < 0) {
+    for (int i = tid; i < n; i += nthr) sel[i] = key_at(i);
+  } else if (!ranked) {
     const unsigned long long lim = shift < 64 ? (s_prefix >> shift) : 0ull;
+    auto taken = [&](unsigned long long key) -> bool {
+      const int b = bin_of(key);
+      if (b != fbin) return b < fbin;
+      return (key >> shift) <= lim;
+    };
+    int mine = 0;
+    for (int i = tid; i < n_up; i += nthr) {
+      const bool take = i < n && taken(key_at(i));
+      mine += __popcll(__ballot(take));                 // (wave-uniform)
+    }
+    int base = 0;
+    if (lane == 0 && mine > 0) base = atomicAdd(&s_cnt, mine);
+    base = __shfl(base, 0);
     for (int i = tid; i < n_up; i += nthr) {
       unsigned long long key = 0ull;
       bool take = false;
       if (i < n) {
         key = key_at(i);
-        take = shift >= 64 || (key >> shift) <= lim;
+        take = taken(key);
       }
       const unsigned long long m = __ballot(take);
-      if (m) {
-        int base = 0;
-        const int leader = __ffsll((long long)m) - 1;
-        if (lane == leader) base = atomicAdd(&s_cnt, __popcll(m));
-        base = __shfl(base, leader);
-        if (take) sel[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
-      }
+      if (take) sel[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+      base += __popcll(m);
     }
   }
   for (int i = Ksub + tid; i < C.Kp; i += nthr) sel[i] = ~0ull;
@@ -237,34 +404,76 @@ __device__ inline void assoc_core(const AssocCore& C) {
   double* cand = reinterpret_cast<double*>(dcache);
   int* cand_lab = reinterpret_cast<int*>(cand + (size_t)Ksub * ms);
   const bool staged = C.gate && C.staged;
+  __shared__ unsigned s_cmax;
+  if (tid == 0) s_cmax = 0u;
   if (staged) {
     __syncthreads();                      // (the select's last reads of the distance words are done)
-    for (int s = tid; s < Ksub; s += nthr) {
-      const int mi = (int)(sel[s] & 0xffffffffull);
-      for (int k = 0; k < ms; ++k) cand[(size_t)s * ms + k] = C.model[(size_t)ms * mi + k];
-      cand_lab[s] = C.label[mi];
+    if (C.is_cyl) {
+      for (int s = tid; s < Ksub; s += nthr) {
+        const int mi = (int)(sel[s] & 0xffffffffull);
+        for (int k = 0; k < ms; ++k) cand[(size_t)s * ms + k] = C.model[(size_t)ms * mi + k];
+        cand_lab[s] = C.label[mi];
+      }
+    } else {
+      // boxes / points: x, y, z RELATIVE TO THE ROBOT as three float arrays, for the screening pass of the matching (a lane reads
+      // candidate s = lane + 64 u: consecutive words, no bank conflicts), and the largest coordinate magnitude for its error bound
+      float* fx = reinterpret_cast<float*>(dcache);
+      float cm = 0.0f;
+      for (int s = tid; s < Ksub; s += nthr) {
+        const int mi = (int)(sel[s] & 0xffffffffull);
+        const double* mm = C.model + 3 * (size_t)mi;
+        const float x = (float)(mm[0] - C.qpos[0]), y = (float)(mm[1] - C.qpos[1]), z = (float)(mm[2] - C.qpos[2]);
+        fx[s] = x; fx[Ksub + s] = y; fx[2 * (size_t)Ksub + s] = z;
+        reinterpret_cast<int*>(fx + 3 * (size_t)Ksub)[s] = C.label[mi];
+        cm = fmaxf(cm, fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))));
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) cm = fmaxf(cm, __shfl_xor(cm, m));
+      if ((tid & 63) == 0) atomicMax(&s_cmax, __float_as_uint(cm));      // (cm >= 0 or NaN: the bit patterns order like the values)
     }
     __syncthreads();
   }
   ASTAMP(5);
-  // one wavefront per PAIR of detections (o, o + nwave): the candidates are read once for both.  Boxes: a lane scans its
-  // candidates in ascending submap index and keeps the one with the smallest distance d = sqrt(d2), the first on ties.  The
-  // correctly rounded f64 sqrt (a long instruction sequence) stays out of the loop: a later candidate replaces the lane's best iff
-  // its d is strictly smaller; that is decided on the squared distances when they differ by more than 2^-48 relative (the rounded
-  // roots are then distinct), and by the two roots themselves inside that band.  One sqrt per lane at the end feeds the
-  // lexicographic (d, index) reduction and the threshold tests, which therefore see exactly the reference's numbers.
   const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
-  for (int o0 = wave; o0 < C.n_det; o0 += 2 * nwave) {
-    const int o1 = o0 + nwave;
-    const bool two = o1 < C.n_det;
-    const double* dw0 = C.det_world + (size_t)o0 * C.det_stride + C.det_off;
-    const double* dw1 = C.det_world + (size_t)(two ? o1 : o0) * C.det_stride + C.det_off;
-    const int ol0 = C.det_label[o0], ol1 = C.det_label[two ? o1 : o0];
-    double best[2] = {C.best_init, C.best_init};
-    int bests[2] = {INT_MAX, INT_MAX};
-    unsigned long long bkey[2] = {~0ull, ~0ull};       // order of the candidates: the select's key (gate) or the index itself
-    ASTAMPW(8);
-    if (C.is_cyl) {
+  // lexicographic (distance, key) minimum over the wave = the reference's strict-'<' first-wins rule, then the threshold test
+  auto reduce_write = [&](int o, double b, int bs, unsigned long long bk) {
+    // (a lane without a candidate holds (best_init, INT_MAX, ~0) and loses to every lane with one: when at most one lane has a
+    // candidate — the rule after the screening — there is nothing to reduce)
+    const unsigned long long have = __ballot(bs != INT_MAX);
+    if (__popcll(have) <= 1) {
+      const int w = have ? __ffsll((long long)have) - 1 : 0;
+      if (lane == w) {
+        const bool ok = (bs != INT_MAX) && (b < C.thresh);
+        if (C.match_sub) C.match_sub[o] = ok ? bs : -1;
+        C.match_map[o] = ok ? (int32_t)(bk & 0xffffffffull) : -1;
+      }
+      return;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(b, off);
+      const int os = __shfl_xor(bs, off);
+      const unsigned klo = (unsigned)__shfl_xor((int)(unsigned)bk, off), khi = (unsigned)__shfl_xor((int)(unsigned)(bk >> 32), off);
+      const unsigned long long ok_ = ((unsigned long long)khi << 32) | klo;
+      if (ob < b || (ob == b && ok_ < bk)) { b = ob; bs = os; bk = ok_; }
+    }
+    if (lane == 0) {
+      const bool ok = (bs != INT_MAX) && (b < C.thresh);
+      if (C.match_sub) C.match_sub[o] = ok ? bs : -1;      // (position in the sorted submap: the list was sorted when this is asked for)
+      C.match_map[o] = ok ? (int32_t)(bk & 0xffffffffull) : -1;
+    }
+  };
+  if (C.is_cyl) {
+    // one wavefront per PAIR of detections (o, o + nwave): the candidates are read once for both
+    for (int o0 = wave; o0 < C.n_det; o0 += 2 * nwave) {
+      const int o1 = o0 + nwave;
+      const bool two = o1 < C.n_det;
+      const double* dw0 = C.det_world + (size_t)o0 * C.det_stride + C.det_off;
+      const double* dw1 = C.det_world + (size_t)(two ? o1 : o0) * C.det_stride + C.det_off;
+      const int ol0 = C.det_label[o0], ol1 = C.det_label[two ? o1 : o0];
+      double best[2] = {C.best_init, C.best_init};
+      int bests[2] = {INT_MAX, INT_MAX};
+      unsigned long long bkey[2] = {~0ull, ~0ull};       // order of the candidates: the select's key (gate) or the index itself
       for (int s = lane; s < Ksub; s += 64) {
         const unsigned long long key = C.gate ? sel[s] : (unsigned long long)s;
         const int mi = C.gate ? (int)(key & 0xffffffffull) : s;
@@ -277,63 +486,172 @@ __device__ inline void assoc_core(const AssocCore& C) {
           if (d1 < C.best_init && (d1 < best[1] || (d1 == best[1] && key < bkey[1]))) { best[1] = d1; bests[1] = s; bkey[1] = key; }
         }
       }
-    } else {
-      double q0[3], q1[3];
+      reduce_write(o0, best[0], bests[0], bkey[0]);
+      if (two) reduce_write(o1, best[1], bests[1], bkey[1]);
+    }
+  } else {
+    // Boxes / points: one wavefront per up to THREE detections (o, o + nwave, o + 2 nwave) — the candidates are read once for all of
+    // them, and 20 detections on 8 waves are one scan per wave instead of two.  The reference's rule: the candidate with the smallest
+    // distance d = sqrt(d2) in double precision, the first in submap order on ties, label-gated.
+    //
+    // Staged submap (round 4): the rule is applied to a SCREENED set.  Pass 1 computes every candidate's squared distance in float
+    // from coordinates relative to the robot and takes the minimum m over the wave; pass 2 recomputes them (bit-identical) and hands a
+    // candidate to the exact double-precision rule iff its float distance is within the error bound of m:
+    //   with u = 2^-24, candidates / detection rounded to float with |error| <= u |coordinate|, the float result is
+    //   d_f = (|q^ - c^|)(1 + t), |t| <= 3 u, and | |q^ - c^| - |q - c| | <= sqrt(3) u (|q|_inf + |c|_inf) =: E, so every candidate
+    //   whose true distance is not above the true minimum (the arg-min and all its ties) has d_f <= (m + 2 E)(1 + 8 u).
+    // The test uses twice that E.  The exact rule then sees one or two candidates per detection instead of a sixth of the submap, on
+    // the original double-precision models: the decisions (arg-min, tie order, threshold) are the reference's, bit for bit, and the
+    // double-precision work — which bounded this phase: 64-bit vector ALU, five in six lanes idle behind the label gate — is gone.
+    constexpr int HM = 3;
+    constexpr double BAND = 1.0 - 0x1p-48;
+    const float* fx = reinterpret_cast<const float*>(dcache);
+    const float* fy = fx + Ksub;
+    const float* fz = fx + 2 * (size_t)Ksub;
+    const int* flab = reinterpret_cast<const int*>(fx + 3 * (size_t)Ksub);
+    for (int o0 = wave; o0 < C.n_det; o0 += HM * nwave) {
+      int nh = 0, ol[HM];
+      double q[HM][3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { q0[k] = dw0[k]; q1[k] = dw1[k]; }
+      for (int h = 0; h < HM; ++h) {
+        const int o = o0 + h * nwave;
+        const bool in = o < C.n_det;
+        if (in) nh = h + 1;
+        const double* dw = C.det_world + (size_t)(in ? o : o0) * C.det_stride + C.det_off;
+        ol[h] = C.det_label[in ? o : o0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) q[h][k] = dw[k];
+      }
+      ASTAMPW(8);
 #ifdef SLIDE_STAMPS
-      if (q0[0] + q1[0] == 1.2345e300) best[0] = 0.0;      // (forces the loads to complete before the stamp)
+      if (q[0][0] + q[1][0] == 1.2345e300) nh = 0;      // (forces the loads to complete before the stamp)
 #endif
       ASTAMPW(9);
-      double b2[2] = {-1.0, -1.0};          // squared distance of the lane's best (none yet: < 0)
-      constexpr double BAND = 1.0 - 0x1p-48;
-      for (int s = lane; s < Ksub; s += 64) {
-        const unsigned long long key = C.gate ? sel[s] : (unsigned long long)s;
-        const int mi = C.gate ? (int)(key & 0xffffffffull) : s;
-        const double* mm = staged ? cand + (size_t)s * ms : C.model + (size_t)ms * mi;
-        const int ml = staged ? cand_lab[s] : C.label[mi];
-        const double m0 = mm[0], m1 = mm[1], m2 = mm[2];
+      double b2[HM];                        // squared distance of the lane's best (none yet: < 0)
+      int bests[HM];
+      unsigned long long bkey[HM];          // order of the candidates: the select's key (gate) or the index itself
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          if (h == 1 && !two) continue;
-          if (C.label_gate == 1 && ml != (h ? ol1 : ol0)) continue;
-          const double* q = h ? q1 : q0;
-          const double dx = q[0] - m0, dy = q[1] - m1, dz = q[2] - m2;
-          const double d2 = dx * dx + dy * dy + dz * dz;
-          bool take = b2[h] < 0.0 || d2 < b2[h] * BAND;
-          if (!take && d2 * BAND <= b2[h]) {       // inside the band (either side): the rounded roots decide, equal roots the order
-            const double rd = sqrt(d2), rb = sqrt(b2[h]);
-            take = rd < rb || (rd == rb && key < bkey[h]);
+      for (int h = 0; h < HM; ++h) { b2[h] = -1.0; bests[h] = INT_MAX; bkey[h] = ~0ull; }
+      // the exact rule on one candidate: a later candidate replaces the lane's best iff its d is strictly smaller — decided on the
+      // squared distances when they differ by more than 2^-48 relative (the correctly rounded roots are then distinct), by the two
+      // roots themselves inside that band (equal roots: the order).  The f64 sqrt stays out of the common path.
+      auto exact = [&](int h, int s, unsigned long long key, double m0, double m1, double m2) {
+        const double dx = q[h][0] - m0, dy = q[h][1] - m1, dz = q[h][2] - m2;
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        bool take = b2[h] < 0.0 || d2 < b2[h] * BAND;
+        if (!take && d2 * BAND <= b2[h]) {
+          const double rd = sqrt(d2), rb = sqrt(b2[h]);
+          take = rd < rb || (rd == rb && key < bkey[h]);
+        }
+        if (take) { b2[h] = d2; bests[h] = s; bkey[h] = key; }
+      };
+      if (staged) {
+        constexpr float U = 0x1p-24f;
+        const float INF = __uint_as_float(0x7f800000u);
+        float qf[HM][3], mf[HM], T2[HM];
+#pragma unroll
+        for (int h = 0; h < HM; ++h) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) qf[h][k] = (float)(q[h][k] - C.qpos[k]);
+          mf[h] = INF;
+        }
+        auto screen = [&](int h, int lab, float x, float y, float z) -> float {
+          const float dx = qf[h][0] - x, dy = qf[h][1] - y, dz = qf[h][2] - z;
+          const float d2 = dx * dx + dy * dy + dz * dz;
+          return (C.label_gate == 1 && lab != ol[h]) ? INF : d2;
+        };
+        for (int s0 = lane; s0 < Ksub; s0 += 256) {
+          float x[4], y[4], z[4];
+          int lab[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int s = s0 + 64 * u;
+            const int sc = s < Ksub ? s : s0;
+            x[u] = fx[sc]; y[u] = fy[sc]; z[u] = fz[sc]; lab[u] = flab[sc];
           }
-          if (take) { b2[h] = d2; bests[h] = s; bkey[h] = key; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (s0 + 64 * u >= Ksub) continue;
+#pragma unroll
+            for (int h = 0; h < HM; ++h) mf[h] = fminf(mf[h], screen(h, lab[u], x[u], y[u], z[u]));
+          }
+        }
+        const float cmax = __uint_as_float(s_cmax);
+#pragma unroll
+        for (int h = 0; h < HM; ++h) {
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) mf[h] = fminf(mf[h], __shfl_xor(mf[h], m));
+          const float qm = fmaxf(fabsf(qf[h][0]), fmaxf(fabsf(qf[h][1]), fabsf(qf[h][2])));
+          const float E = 4.0f * U * (qm + cmax);
+          const float T = (sqrtf(mf[h]) + 2.0f * E) * (1.0f + 8.0f * U);
+          T2[h] = mf[h] < INF ? T * T * (1.0f + 4.0f * U) : -1.0f;      // (no candidate of that label: nothing passes)
+          if (h >= nh) T2[h] = -1.0f;
+        }
+        for (int s0 = lane; s0 < Ksub; s0 += 256) {
+          float x[4], y[4], z[4];
+          int lab[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int s = s0 + 64 * u;
+            const int sc = s < Ksub ? s : s0;
+            x[u] = fx[sc]; y[u] = fy[sc]; z[u] = fz[sc]; lab[u] = flab[sc];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int s = s0 + 64 * u;
+            if (s >= Ksub) continue;
+            bool pass[HM], any = false;
+#pragma unroll
+            for (int h = 0; h < HM; ++h) { pass[h] = screen(h, lab[u], x[u], y[u], z[u]) <= T2[h]; any = any || pass[h]; }
+            if (any) {
+              const unsigned long long key = sel[s];
+              const double* mm = C.model + 3 * (size_t)(key & 0xffffffffull);
+              const double m0 = mm[0], m1 = mm[1], m2 = mm[2];
+#pragma unroll
+              for (int h = 0; h < HM; ++h)
+                if (pass[h]) exact(h, s, key, m0, m1, m2);
+            }
+          }
+        }
+      } else {
+        // the submap as it lies in global memory (the pure matchers: no gate, the map itself in the caller's order); four candidates'
+        // words are loaded before the first is looked at
+        for (int s0 = lane; s0 < Ksub; s0 += 256) {
+          unsigned long long key[4];
+          int ml[4];
+          double m0[4], m1[4], m2[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int s = s0 + 64 * u;
+            const int sc = s < Ksub ? s : s0;
+            key[u] = C.gate ? sel[sc] : (unsigned long long)sc;
+            const int mi = C.gate ? (int)(key[u] & 0xffffffffull) : sc;
+            const double* mm = C.model + 3 * (size_t)mi;
+            m0[u] = mm[0]; m1[u] = mm[1]; m2[u] = mm[2];
+            ml[u] = C.label[mi];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int s = s0 + 64 * u;
+            if (s >= Ksub) continue;
+#pragma unroll
+            for (int h = 0; h < HM; ++h) {
+              if (h >= nh) continue;
+              if (C.label_gate == 1 && ml[u] != ol[h]) continue;
+              exact(h, s, key[u], m0[u], m1[u], m2[u]);
+            }
+          }
         }
       }
       ASTAMPW(10);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < HM; ++h) {
+        if (h >= nh) continue;
+        double best = C.best_init;
         const double d = b2[h] >= 0.0 ? sqrt(b2[h]) : C.best_init;
-        if (d < C.best_init) best[h] = d; else { bests[h] = INT_MAX; bkey[h] = ~0ull; }      // "if (d < bestDist)" against the initial bestDist
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      double b = best[h];
-      int bs = bests[h];
-      unsigned long long bk = bkey[h];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const double ob = __shfl_xor(b, off);
-        const int os = __shfl_xor(bs, off);
-        const unsigned klo = (unsigned)__shfl_xor((int)(unsigned)bk, off), khi = (unsigned)__shfl_xor((int)(unsigned)(bk >> 32), off);
-        const unsigned long long ok_ = ((unsigned long long)khi << 32) | klo;
-        if (ob < b || (ob == b && ok_ < bk)) { b = ob; bs = os; bk = ok_; }
-      }
-      const int o = h == 0 ? o0 : o1;
-      if (h == 1) ASTAMPW(11);
-      if (lane == 0 && (h == 0 || two)) {
-        const bool ok = (bs != INT_MAX) && (b < C.thresh);
-        if (C.match_sub) C.match_sub[o] = ok ? bs : -1;      // (position in the sorted submap: the list was sorted when this is asked for)
-        C.match_map[o] = ok ? (int32_t)(bk & 0xffffffffull) : -1;
+        if (d < C.best_init) best = d; else { bests[h] = INT_MAX; bkey[h] = ~0ull; }      // "if (d < bestDist)" against the initial bestDist
+        if (h == nh - 1) ASTAMPW(11);
+        reduce_write(o0 + h * nwave, best, bests[h], bkey[h]);
       }
     }
   }
