@@ -89,13 +89,29 @@ def test_submap_knn_matches_oracle(gpu, n, K):
     assert np.array_equal(got, out[:k])
 
 
-@pytest.mark.parametrize("case", ["all_equal", "two_shells", "tie_across_the_cut"])
+@pytest.mark.parametrize("case", ["all_equal", "two_shells", "tie_across_the_cut", "dense_cluster_at_the_cut", "one_far_outlier",
+                                  "robot_on_a_landmark"])
 def test_submap_knn_ties_at_the_selection_boundary(gpu, case):
     """Many exactly equidistant points around the K-th neighbour: the select has to go on into the index bits (lowest indices
-    win), which is the reference order the oracle defines for FLANN's unspecified tie order."""
+    win), which is the reference order the oracle defines for FLANN's unspecified tie order.  Round 4 (K-th key found by a histogram
+    over bins linear in the squared distance): clouds that defeat the bins — thousands of DISTINCT distances inside one bin at the
+    cut, one landmark so far away that every other falls into bin 0, the robot standing on a landmark — go through the digit passes
+    restricted to the K-th key's bin and must give the same lists."""
     rng = np.random.default_rng(3)
     n, K = 6000, 1000
-    if case == "all_equal":
+    if case == "dense_cluster_at_the_cut":
+        cloud = rng.uniform(-60, 60, (n, 3)).astype(np.float32)
+        sh = rng.normal(0, 1, (3000, 3))
+        sh = sh / np.linalg.norm(sh, axis=1)[:, None] * (20.0 + rng.uniform(0, 1e-3, 3000))[:, None]      # a thin shell through the cut
+        cloud[rng.permutation(n)[:3000]] = sh.astype(np.float32)
+    elif case == "one_far_outlier":
+        cloud = rng.uniform(-60, 60, (n, 3)).astype(np.float32)
+        cloud[17] = (3.0e6, 0.0, 0.0)
+    elif case == "robot_on_a_landmark":
+        cloud = rng.uniform(-60, 60, (n, 3)).astype(np.float32)
+        cloud[40] = 0.0
+        cloud[41] = 0.0
+    elif case == "all_equal":
         cloud = np.tile(np.array([[3.0, 4.0, 0.0]], np.float32), (n, 1))
     elif case == "two_shells":
         ang = rng.uniform(0, 2 * np.pi, n)
@@ -163,6 +179,50 @@ def test_assoc_sweep_batch_matches_oracle(gpu):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("offset", [0.0, 7000.0])
+def test_assoc_sweep_near_ties_survive_the_float_screening(gpu, offset):
+    """The matching screens the submap in float (coordinates relative to the robot) and applies the reference's double-precision rule
+    to the candidates inside the error bound of the float minimum (assoc_kernels.hip).  Cases the screening could get wrong if the
+    bound were too tight: a detection exactly halfway between two landmarks of its label (an exact double-precision tie: the first
+    in submap order wins), pairs whose distances differ by 1e-13 .. 1e-7 relative (far below float resolution), all of it 7 km from
+    the origin (float spacing there: 0.5 mm).  Identical map indices to the oracle's getSubmap + matchEllipsoidModels."""
+    rng = np.random.default_rng(123)
+    n_map, K, n_obs, n_q = 4000, 1000, 20, 64
+    model = np.column_stack([rng.uniform(0, 200, n_map), rng.uniform(0, 100, n_map), rng.normal(0, 0.3, n_map)]) + offset
+    label = rng.integers(1, 4, n_map).astype(np.int32)
+    qpos = np.column_stack([rng.uniform(40, 160, n_q), rng.uniform(30, 70, n_q), np.full(n_q, 2.0)]) + offset
+    obs = np.zeros((n_q, n_obs, 3)); olab = np.zeros((n_q, n_obs), np.int32)
+    eps = [0.0, 1e-13, 1e-11, 1e-9, 1e-7]
+    for i in range(n_q):
+        d2 = ((model[:, :2] - qpos[i, :2]) ** 2).sum(1)
+        near = np.argsort(d2)[:2 * n_obs]
+        for o in range(n_obs):
+            a, b = near[2 * o], near[2 * o + 1]
+            # landmark b becomes the mirror image of landmark a about the detection, pulled in by a relative eps
+            det = model[a] + rng.normal(0, 0.15, 3)
+            e = eps[(i + o) % len(eps)]
+            model[b] = det + (det - model[a]) * (1.0 - e)
+            label[b] = label[a]
+            obs[i, o] = det
+            olab[i, o] = label[a]
+    cloud = model.astype(np.float32)
+    got, _ = gpu.assoc_sweep_batch(cloud, model, label, qpos, obs, olab, K, 0.75)
+    L = po.lib()
+    sub = np.zeros(K, np.int32)
+    exp = np.full(n_obs, -1, np.int32)
+    n_match = 0
+    for i in range(n_q):
+        k = L.orc_knn_f32(_p(cloud), C.c_int(n_map), _p(qpos[i]), C.c_int(K), _p(sub))
+        assert k == K
+        sm = np.ascontiguousarray(model[sub]); sl = np.ascontiguousarray(label[sub])
+        L.orc_match_boxes(C.c_int(2), C.c_int(n_obs), _p(np.ascontiguousarray(obs[i])), _p(np.ascontiguousarray(olab[i])), C.c_int(K),
+                          _p(sm), _p(sl), C.c_double(0.75), _p(exp))
+        want = np.where(exp >= 0, sub[np.maximum(exp, 0)], -1)
+        assert np.array_equal(got[i], want), (i, got[i], want)
+        n_match += int((want >= 0).sum())
+    assert n_match > 0.8 * n_q * n_obs
 
 
 @pytest.mark.parametrize("cls", [1, 2])
