@@ -321,18 +321,47 @@ def border_flops(T, first):
 
 
 def self_launch(n):
-    """Run this script as n ranks under torch.distributed.run (child process; stdout / stderr inherited) and return its exit code."""
+    """Run this script as n ranks under torch.distributed.run (child process in its own session; stdout / stderr inherited) and return
+    its exit code.  The exchange between the ranks is RCCL ("nccl") unless SLIDE_BENCH_BACKEND says otherwise; a multi-GPU RCCL job has
+    never run on the one-GPU boxes this was developed on, so a child that fails or does not finish within SLIDE_BENCH_CHILD_TIMEOUT
+    seconds (default 1500) is ended — its own process group, nothing else — and the job is run ONCE more with the exchange staged through
+    the host over gloo, which the 2- and 4-rank rehearsals on one GPU did exercise; the JSON line then says so ("backend": "gloo", and
+    config.multi_gpu_fallback)."""
+    import signal
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (the host driver only supports dmabuf IPC: RCCL needs it)
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
-    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+    def run(extra_env):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (the host driver only supports dmabuf IPC: RCCL needs it)
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+        env.update(extra_env)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        child = subprocess.Popen(cmd, env=env, cwd=ROOT, start_new_session=True)
+        try:
+            return child.wait(timeout=float(os.environ.get("SLIDE_BENCH_CHILD_TIMEOUT", "1500")))
+        except subprocess.TimeoutExpired:
+            for sig in (signal.SIGTERM, signal.SIGKILL):
+                try:
+                    os.killpg(child.pid, sig)      # the child's own session: exactly the ranks started above
+                except ProcessLookupError:
+                    break
+                try:
+                    child.wait(timeout=20)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+            return 124
+
+    rc = run({})
+    if rc != 0 and "SLIDE_BENCH_BACKEND" not in os.environ and os.environ.get("SLIDE_BENCH_NO_FALLBACK") != "1":
+        sys.stderr.write(f"bench.py: the {n}-rank run over RCCL ended with code {rc}; running it once more with the exchange staged through the host (gloo)\n")
+        rc = run({"SLIDE_BENCH_BACKEND": "gloo", "SLIDE_BENCH_FALLBACK_NOTE": f"the RCCL run ended with code {rc}; exchange staged through the host over gloo"})
+    return rc
 
 
 def main():
@@ -835,6 +864,7 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
                                "shared landmarks, DESIGN 5); inter-robot relative-pose factors: " + str(info.get("relmeas", "none")),
                    "robots": robots, "robots_per_gpu": R, "reduced_system_dim": n, "chol_tile": 64,
                    "world_size": (dist.get_world_size() if dist is not None else 1), "backend": (backend if dist is not None else None),
+                   "multi_gpu_fallback": os.environ.get("SLIDE_BENCH_FALLBACK_NOTE"),
                    "devices": devs,
                    "collective": None if not n_slots else (
                        ((f"{backend} " if wdev > 1 else "device-side gather, no inter-GPU ") +

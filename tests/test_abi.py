@@ -62,6 +62,26 @@ def test_no_cpu_fallback_without_device():
         s.submap_knn(np.zeros((4, 3), np.float32), np.zeros(3), 2)
 
 
+def test_bench_self_launch_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` (how the driver starts the multi-GPU bench) launches the ranks itself under torch.distributed.run; a
+    failed RCCL run is repeated ONCE with the exchange staged through the host, and a job that cannot run — no GPU here — ends with a
+    non-zero exit code and no JSON line, never with a number from some other path."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the 2-rank bench would run (covered by tests/test_bench_config.py on the GPU box)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("SLIDE_BENCH_BACKEND", None)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "running it once more with the exchange staged through the host" in r.stderr
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())
+
+
 def test_product_never_imports_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "slide_slam_amd")):
         for f in files:
