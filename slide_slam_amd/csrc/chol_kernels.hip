@@ -2015,7 +2015,8 @@ struct SyrkArgs {
   const int* jobs;       // or null: (system << 20 | ib << 10 | jb) per workgroup, longest sums first (launch_border_syrk_jobs)
   const int* segtab[CHOL_BATCH_MAX];      // or null: CholSystem::segtab — the sum runs over the segments in which both tile rows are non-zero
 };
-__global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
+template <int RD>
+__device__ __forceinline__ void border_syrk_body(const SyrkArgs& A) {
   int r = A.ks > 1 ? 0 : blockIdx.z, ib = blockIdx.x, jb = blockIdx.y;
   const int q = A.ks > 1 ? blockIdx.z : 0;
   if (A.jobs) {
@@ -2051,6 +2052,48 @@ __global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
     ldb = NB;
     cbh = A.scratch + (size_t)r * A.scratch_stride + ((size_t)(jb * (nbr + 1) + ib) * (ksr - 1) + (q - 1)) * (NB * NB) + (size_t)(32 * ch + 2 * lk) * NB + 32 * rh + 2 * lr;
   }
+  // The k-steps of ALL segments as ONE sequence (round 4): the operand loads run RD - 1 steps ahead of the matrix pipe ACROSS segment
+  // boundaries — a cut band's job has three short sums (one to three block columns each), and a prefetch pipeline that drains and
+  // refills per segment shows the full load latency three times per job (the kernel is bound by that latency: RD 4 -> 16 alone took the
+  // robots' launch from 0.196 to 0.148 ms).  Same order of the sum (segments ascending, columns ascending): same bits.
+  int total = 0;                                  // k-steps of four columns
+  if (st) {
+    for (int sg = 0; sg < nseg; ++sg) {
+      const int* sf = st + 1 + nseg + sg * (nbr + 1);
+      const int a0 = max(sf[ib], sf[jb]), a1 = st[1 + sg];
+      if (a0 < a1) total += (a1 - a0) * 16;       // (1 << 30: zero in this segment)
+    }
+  } else {
+    total = (c1 - c0) * 16;
+  }
+  int sg_next = 0, rem = 0, issued = 0;           // load side: next segment to open, k-steps left in the open one, steps issued
+  const double *lpj = pj0, *lpi = pi0;
+  v2d pa[RD], pb[RD];
+  auto issue = [&](v2d& ra, v2d& rb) {            // (wave-uniform control flow)
+    while (rem == 0 && sg_next < nseg) {
+      int a0 = c0, a1 = c1;
+      if (st) {
+        const int* sf = st + 1 + nseg + sg_next * (nbr + 1);
+        a0 = max(sf[ib], sf[jb]);
+        a1 = st[1 + sg_next];
+      }
+      ++sg_next;
+      if (a0 < a1) {
+        rem = (a1 - a0) * 16;
+        lpj = pj0 + (size_t)a0 * NB * ld;
+        lpi = pi0 + (size_t)a0 * NB * ld;
+      }
+    }
+    ra = *(const v2d*)lpj;
+    rb = *(const v2d*)lpi;
+    lpj += (size_t)4 * ld;
+    lpi += (size_t)4 * ld;
+    --rem;
+    ++issued;
+  };
+#pragma unroll
+  for (int pre = 0; pre < RD - 1; ++pre)
+    if (issued < total) issue(pa[pre], pb[pre]);
   v4d acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -2061,42 +2104,18 @@ __global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
       if (q == 0) c2 = *(const v2d*)(cbh + (size_t)(8 * e + a) * ldb);
       acc[a][0][e] = c2[0]; acc[a][1][e] = c2[1];
     }
-  for (int sg = 0; sg < nseg; ++sg) {
-    if (st) {
-      const int* sf = st + 1 + nseg + sg * (nbr + 1);
-      c0 = max(sf[ib], sf[jb]);
-      c1 = st[1 + sg];
-      if (c0 >= c1) continue;                     // (1 << 30: zero in this segment)
-    }
-    const double* pjh = pj0 + (size_t)c0 * NB * ld;
-    const double* pih = pi0 + (size_t)c0 * NB * ld;
-    const int KS = (c1 - c0) * 16;                // k-steps of four columns (a multiple of 16)
-    constexpr int RD = 4;
-    v2d pa[RD], pb[RD];
+  for (int ks0 = 0; ks0 < total; ks0 += RD) {     // (every segment's length is a multiple of 16 k-steps: RD divides the total)
 #pragma unroll
-    for (int pre = 0; pre < RD - 1; ++pre) {
-      const size_t off = (size_t)(4 * pre) * ld;
-      pa[pre] = *(const v2d*)(pjh + off);
-      pb[pre] = *(const v2d*)(pih + off);
-    }
-    for (int ks0 = 0; ks0 < KS; ks0 += RD) {
+    for (int u = 0; u < RD; ++u) {
+      if (issued < total) issue(pa[(u + RD - 1) % RD], pb[(u + RD - 1) % RD]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < RD; ++u) {
-        const int ks = ks0 + u;
-        if (ks + RD - 1 < KS) {
-          const size_t off = (size_t)(4 * (ks + RD - 1)) * ld;
-          pa[(u + RD - 1) % RD] = *(const v2d*)(pjh + off);
-          pb[(u + RD - 1) % RD] = *(const v2d*)(pih + off);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      for (int a = 0; a < 2; ++a) {
+        const double na = -pa[u][a];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const double na = -pa[u][a];
-#pragma unroll
-          for (int b = 0; b < 2; ++b) acc[a][b] = mfma_f64(na, pb[u][b], acc[a][b]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int b = 0; b < 2; ++b) acc[a][b] = mfma_f64(na, pb[u][b], acc[a][b]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll
@@ -2107,6 +2126,18 @@ __global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) {
       c2[0] = acc[a][0][e]; c2[1] = acc[a][1][e];
       *(v2d*)(cbh + (size_t)(8 * e + a) * ldb) = c2;
     }
+}
+// operand loads fifteen k-steps ahead of the matrix pipe (142 VGPRs, two waves per SIMD): the kernel is bound by the latency of its
+// operand loads, not by occupancy — C4's robots' launch: 0.175 ms with loads three steps ahead (round 3's depth), 0.159 with seven,
+// 0.138 with fifteen (0.56 of the FP64 MFMA peak).  SLIDE_SYRK_RD=4 / 8: the shallower variants
+__global__ __launch_bounds__(256) void k_border_syrk(SyrkArgs A) { border_syrk_body<16>(A); }
+__global__ __launch_bounds__(256) void k_border_syrk_rd8(SyrkArgs A) { border_syrk_body<8>(A); }
+__global__ __launch_bounds__(256) void k_border_syrk_rd4(SyrkArgs A) { border_syrk_body<4>(A); }
+static void launch_syrk_kernel(dim3 grid, size_t lds, hipStream_t s, const SyrkArgs& A) {
+  static const int rd = getenv("SLIDE_SYRK_RD") ? atoi(getenv("SLIDE_SYRK_RD")) : 16;
+  if (rd == 4) hipLaunchKernelGGL(k_border_syrk_rd4, grid, dim3(256), lds, s, A);
+  else if (rd == 8) hipLaunchKernelGGL(k_border_syrk_rd8, grid, dim3(256), lds, s, A);
+  else hipLaunchKernelGGL(k_border_syrk, grid, dim3(256), lds, s, A);
 }
 __global__ __launch_bounds__(256) void k_border_syrk_reduce(double* __restrict__ bord, int ldb, int nbr, int ks, const double* __restrict__ scratch,
                                                             const int* __restrict__ bfirst, int T) {
@@ -2158,12 +2189,12 @@ void launch_border_syrk(const CholSystem* d, int n, hipStream_t s, double* scrat
   if (nb <= 0) return;
   if (scratch && n == 1 && ks > 1) {
     A.ks = ks; A.scratch = scratch;
-    hipLaunchKernelGGL(k_border_syrk, dim3(nb + 1, nb, ks), dim3(256), 0, s, A);
+    launch_syrk_kernel(dim3(nb + 1, nb, ks), 0, s, A);
     hipLaunchKernelGGL(k_border_syrk_reduce, dim3(16 * (nb + 1), nb), dim3(256), 0, s, d[0].bord, d[0].ldb, d[0].nbr, ks, scratch, d[0].bfirst, d[0].T);
     return;
   }
   A.ks = 1; A.scratch = nullptr;
-  hipLaunchKernelGGL(k_border_syrk, dim3(nb + 1, nb, n), dim3(256), 0, s, A);
+  launch_syrk_kernel(dim3(nb + 1, nb, n), 0, s, A);
 }
 // The same product with the workgroups in the order of a job table (all systems' lower tiles + right-hand-side rows, longest sum first)
 // and lds_pad bytes of idle dynamic LDS per workgroup to bound the workgroups resident on a CU: the hardware dispatcher then hands the
@@ -2190,19 +2221,19 @@ void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int nj
     const int ka = std::max(1, ks_sys ? ks_sys[0] : ks), kb = std::max(1, ks_sys ? ks_sys[1] : ks), km = std::max(ka, kb);
     A.ks = km; A.scratch = scratch; A.scratch_stride = std::max<size_t>(1, (size_t)(nb + 1) * nb * (km - 1) * NB * NB);
     A.ks_sys[0] = ka; A.ks_sys[1] = kb;
-    hipLaunchKernelGGL(k_border_syrk, dim3(njobs, 1, km), dim3(256), lds_pad, s, A);
+    launch_syrk_kernel(dim3(njobs, 1, km), lds_pad, s, A);
     hipLaunchKernelGGL(k_border_syrk_reduce2, dim3(16 * (nb + 1), jb_end >= 0 ? jb_end : nb), dim3(256), 0, s, d[0].bord, d[0].ldb, d[1].bord, d[1].ldb, nb,
                        ka, kb, scratch, scratch + A.scratch_stride, d[0].T, d[1].T);
     return;
   }
   if (scratch && n == 1 && ks > 1) {
     A.ks = ks; A.scratch = scratch;
-    hipLaunchKernelGGL(k_border_syrk, dim3(njobs, 1, ks), dim3(256), lds_pad, s, A);
+    launch_syrk_kernel(dim3(njobs, 1, ks), lds_pad, s, A);
     const int nb = d[0].nbr;
     hipLaunchKernelGGL(k_border_syrk_reduce, dim3(16 * (nb + 1), jb_end >= 0 ? jb_end : nb), dim3(256), 0, s, d[0].bord, d[0].ldb, nb, ks, scratch, d[0].bfirst, d[0].T);
     return;
   }
-  hipLaunchKernelGGL(k_border_syrk, dim3(njobs), dim3(256), lds_pad, s, A);
+  launch_syrk_kernel(dim3(njobs), lds_pad, s, A);
 }
 // y -= W x_loc before the backward substitution of the band (x_loc: the separator's solution in the system's own border order, zeros
 // in the padding): one wave per column of the band, lanes over the border rows (contiguous down a column of S)
