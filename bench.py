@@ -236,7 +236,7 @@ def assoc_roofline(s, n_map=10000, K=1000, n_obs=20, n_query=8192, repeats=5):
     bytes_per_frame = 12 * n_map + 28 * k_eff + 36 * n_obs
     per_launch_s = ms * 1e-3 / repeats
     ach = bytes_per_frame * n_query / per_launch_s / 1e9
-    return {"bound": "hbm", "kernel": "k_assoc_sweep_512 (float32 K-NN scan, K-select by one histogram over bins linear in the squared distance + ranks inside the K-th key's bin, label-gated nearest neighbour: float screening, the exact double-precision rule on the one or two candidates inside the error bound; two 512-thread workgroups per CU)",
+    return {"bound": "hbm", "kernel": "k_assoc_sweep_512 (float32 K-NN scan, K-select by one histogram over bins linear in the squared distance + ranks inside the K-th key's bin, label-gated nearest neighbour: survivors grouped by label, float screening, the exact double-precision rule on the one or two candidates inside the error bound; two 512-thread workgroups per CU)",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "bytes_per_frame": bytes_per_frame, "frames_per_launch": n_query, "avg_launch_ms": per_launch_s * 1e3,
             "frames_per_s": n_query / per_launch_s, "matched_fraction": float((out >= 0).mean()),

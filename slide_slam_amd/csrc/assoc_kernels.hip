@@ -103,35 +103,23 @@ __device__ inline int knn_select(const AssocCore& C, unsigned long long* sel, un
   const int n = C.n, Ksub = C.K < n ? C.K : n;
   const float qx = (float)C.qpos[0], qy = (float)C.qpos[1], qz = (float)C.qpos[2];
   const int n_up = (n + nthr - 1) / nthr * nthr;
-  // distance words (kept in LDS when they fit) and their maximum; eight independent loads in flight per stream (the cloud is L2-resident
+  // distance words (kept in LDS when they fit) and their maximum; ten independent loads in flight per stream (the cloud is L2-resident
   // across the frames of a launch: the scan is a chain of L2 round trips otherwise)
   unsigned bmax = 0u;
-  {
-    int i = tid;
-    for (; i + 7 * nthr < n; i += 8 * nthr) {
-      unsigned b[8];
+  for (int i0 = tid; i0 < n; i0 += 10 * nthr) {       // ten loads in flight per stream (10 k landmarks on 512 threads: two rounds)
+    unsigned b[10];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) b[u] = dist_bits(C, i + u * nthr, qx, qy, qz);
+    for (int u = 0; u < 10; ++u) {
+      const int i = i0 + u * nthr;
+      b[u] = dist_bits(C, i < n ? i : i0, qx, qy, qz);
+    }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (C.cached) dcache[i + u * nthr] = b[u];
+    for (int u = 0; u < 10; ++u) {
+      const int i = i0 + u * nthr;
+      if (i < n) {
+        if (C.cached) dcache[i] = b[u];
         bmax = b[u] > bmax ? b[u] : bmax;
       }
-    }
-    for (; i + 3 * nthr < n; i += 4 * nthr) {
-      unsigned b[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) b[u] = dist_bits(C, i + u * nthr, qx, qy, qz);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (C.cached) dcache[i + u * nthr] = b[u];
-        bmax = b[u] > bmax ? b[u] : bmax;
-      }
-    }
-    for (; i < n; i += nthr) {
-      const unsigned b = dist_bits(C, i, qx, qy, qz);
-      if (C.cached) dcache[i] = b;
-      bmax = b > bmax ? b : bmax;
     }
   }
 #pragma unroll
@@ -382,9 +370,15 @@ __device__ inline int knn_select(const AssocCore& C, unsigned long long* sel, un
   return Ksub;
 }
 
+constexpr int ASSOC_GMAX = 64;     // detections per (frame, class) up to which the staged submap is grouped by label
 __device__ inline void assoc_core(const AssocCore& C) {
   const int tid = threadIdx.x, nthr = blockDim.x;
   ASTAMP(0);
+  // label groups of the staged submap (see the staging below): a group is named by the FIRST detection that carries its label
+  // s_dl: the detections' labels; s_dgrp: a detection's group; s_glab: a group's label; s_gcnt / s_goff: its survivors; s_ng: groups
+  __shared__ int s_dl[ASSOC_GMAX], s_dgrp[ASSOC_GMAX], s_glab[ASSOC_GMAX], s_gcnt[ASSOC_GMAX], s_gcur[ASSOC_GMAX], s_goff[ASSOC_GMAX], s_ng;
+  const bool grouped = C.gate && C.staged && !C.is_cyl && C.label_gate == 1 && C.n_det <= ASSOC_GMAX && (C.K < C.n ? C.K : C.n) <= 4 * nthr;
+  if (grouped && tid < ASSOC_GMAX) { s_dl[tid] = tid < C.n_det ? C.det_label[tid] : 0; s_gcnt[tid] = 0; s_gcur[tid] = 0; }      // (visible after the select's barriers)
   unsigned long long* sel = assoc_lds;
   unsigned* hist = reinterpret_cast<unsigned*>(assoc_lds + (C.gate ? C.Kp : 0));
   unsigned* dcache = hist + 256;
@@ -414,6 +408,120 @@ __device__ inline void assoc_core(const AssocCore& C) {
         for (int k = 0; k < ms; ++k) cand[(size_t)s * ms + k] = C.model[(size_t)ms * mi + k];
         cand_lab[s] = C.label[mi];
       }
+    } else if (grouped) {
+      // boxes / points, label-gated (round 4): the survivors GROUPED BY LABEL — x, y, z relative to the robot as three float arrays
+      // and the survivor's position in sel, group after group, so that a detection scans the ~K / (number of labels) survivors that
+      // carry its label instead of all K behind a label test (five in six lanes idle on the headline map).  Survivors whose label no
+      // detection carries are dropped.  The groups (distinct detection labels, in order of first appearance) are found by wave 0
+      // with lane-to-lane reads while everybody's gathers are in flight; counting and placing go group by group with ballots — a
+      // lane per group keeps the wave's count, ONE LDS atomic instruction per wave and pass (a lane per group, distinct addresses).
+      float* fx = reinterpret_cast<float*>(dcache);
+      float* fy = fx + Ksub;
+      float* fz = fx + 2 * (size_t)Ksub;
+      int* sidx = reinterpret_cast<int*>(fx + 3 * (size_t)Ksub);
+      double* dmx = reinterpret_cast<double*>(fx + 4 * (size_t)Ksub);
+      const int lane_ = tid & 63;
+      double mx[4], my[4], mz[4];
+      int lab[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int s = tid + it * nthr;
+        lab[it] = 0;
+        mx[it] = my[it] = mz[it] = 0.0;
+        if (s < Ksub) {
+          const int mi = (int)(sel[s] & 0xffffffffull);
+          const double* mm = C.model + 3 * (size_t)mi;
+          mx[it] = mm[0]; my[it] = mm[1]; mz[it] = mm[2];
+          lab[it] = C.label[mi];
+        }
+      }
+      if (tid < 64) {
+        // (lane-to-lane reads with a uniform lane number: v_readlane, no LDS round trip)
+        const int mylab = s_dl[lane_];
+        const bool in = lane_ < C.n_det;
+        bool first = in;
+        for (int p = 0; p < C.n_det; ++p) {
+          const int lp = __builtin_amdgcn_readlane(mylab, p);
+          if (p < lane_ && lp == mylab) first = false;
+        }
+        const unsigned long long fm = __ballot(first);
+        int jj = __popcll(fm & ((1ull << lane_) - 1ull));      // a first detection's group: its rank among the firsts
+        if (first) s_glab[jj] = mylab;
+        const int jf = jj;
+        for (int p = 0; p < C.n_det; ++p) {
+          const int lp = __builtin_amdgcn_readlane(mylab, p), jp = __builtin_amdgcn_readlane(jf, p);
+          if (((fm >> p) & 1ull) && lp == mylab) jj = jp;
+        }
+        if (in) s_dgrp[lane_] = jj;
+        if (lane_ == 0) s_ng = __popcll(fm);
+      }
+      __syncthreads();
+      ASTAMP(7);
+      const int ng = s_ng;
+      const int glab_l = lane_ < ng ? s_glab[lane_] : 0;       // lane j: group j's label
+      float x[4], y[4], z[4], cm = 0.0f;
+      int g[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        g[it] = -1;
+        x[it] = (float)(mx[it] - C.qpos[0]); y[it] = (float)(my[it] - C.qpos[1]); z[it] = (float)(mz[it] - C.qpos[2]);
+      }
+      for (int j = 0; j < ng; ++j) {
+        const int gl = __builtin_amdgcn_readlane(glab_l, j);
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          if (tid + it * nthr < Ksub && lab[it] == gl) g[it] = j;
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        if (g[it] >= 0) cm = fmaxf(cm, fmaxf(fabsf(x[it]), fmaxf(fabsf(y[it]), fabsf(z[it]))));
+      // counts: lane j of every wave holds the wave's number of survivors of group j
+      int wc[4] = {0, 0, 0, 0};
+      for (int j = 0; j < ng; ++j) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          if (it * nthr >= Ksub) continue;               // (uniform)
+          const int c = __popcll(__ballot(g[it] == j));
+          if (lane_ == j) wc[it] = c;
+        }
+      }
+      const int wtot = wc[0] + wc[1] + wc[2] + wc[3];
+      if (lane_ < ng && wtot > 0) atomicAdd(&s_gcnt[lane_], wtot);
+      __syncthreads();
+      ASTAMP(15);
+      {
+        // every wave scans the group sizes itself (lane j: group j); wave 0 leaves the offsets for the matching
+        const int v = lane_ < ng ? s_gcnt[lane_] : 0;
+        int inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int o = __shfl_up(inc, off);
+          if (lane_ >= off) inc += o;
+        }
+        if (tid < ng) s_goff[tid] = inc - v;
+        int base = inc - v;                             // lane j: where this wave's survivors of group j start
+        if (lane_ < ng && wtot > 0) base += atomicAdd(&s_gcur[lane_], wtot);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          if (it * nthr >= Ksub) continue;
+          int rank = 0;
+          for (int j = 0; j < ng; ++j) {
+            const unsigned long long m = __ballot(g[it] == j);
+            if (g[it] == j) rank = __popcll(m & ((1ull << lane_) - 1ull));
+          }
+          const int gb = __shfl(base, g[it] >= 0 ? g[it] : 0);
+          if (g[it] >= 0) {
+            const int pos = gb + rank;
+            fx[pos] = x[it]; fy[pos] = y[it]; fz[pos] = z[it];
+            sidx[pos] = tid + it * nthr;
+            dmx[pos] = mx[it]; dmx[Ksub + pos] = my[it]; dmx[2 * (size_t)Ksub + pos] = mz[it];      // the model itself, for the exact rule
+          }
+          base += wc[it];                               // (lane j: the next iteration's survivors of group j follow this one's)
+        }
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) cm = fmaxf(cm, __shfl_xor(cm, m));
+      if (lane_ == 0) atomicMax(&s_cmax, __float_as_uint(cm));
     } else {
       // boxes / points: x, y, z RELATIVE TO THE ROBOT as three float arrays, for the screening pass of the matching (a lane reads
       // candidate s = lane + 64 u: consecutive words, no bank conflicts), and the largest coordinate magnitude for its error bound
@@ -509,6 +617,97 @@ __device__ inline void assoc_core(const AssocCore& C) {
     const float* fy = fx + Ksub;
     const float* fz = fx + 2 * (size_t)Ksub;
     const int* flab = reinterpret_cast<const int*>(fx + 3 * (size_t)Ksub);
+    if (grouped) {
+      // label groups (see the staging): a wavefront per detection (HG > 1 interleaves several: spills at the 128 registers of this kernel;
+      // interleaved), each over the survivors of ITS label only — float distances of up to 256 of them stay in registers between the
+      // two passes
+      const int* sidx = flab;
+      const double* dmx = reinterpret_cast<const double*>(fx + 4 * (size_t)Ksub);
+      constexpr float U = 0x1p-24f;
+      const float INF = __uint_as_float(0x7f800000u);
+      const float cmax = __uint_as_float(s_cmax);
+      constexpr int HG = 1;
+      for (int o0 = wave; o0 < C.n_det; o0 += HG * nwave) {
+        double q[HG][3];
+        float qf[HG][3], d2r[HG][4], mf[HG], T2[HG];
+        int lo[HG], cnt[HG];
+#pragma unroll
+        for (int h = 0; h < HG; ++h) {
+          const int o = o0 + h * nwave;
+          const bool in = o < C.n_det;
+          const double* dw = C.det_world + (size_t)(in ? o : o0) * C.det_stride + C.det_off;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { q[h][k] = dw[k]; qf[h][k] = (float)(q[h][k] - C.qpos[k]); }
+          const int g = s_dgrp[in ? o : o0];
+          lo[h] = s_goff[g];
+          cnt[h] = in ? s_gcnt[g] : 0;
+          mf[h] = INF;
+        }
+        ASTAMPW(8);
+        ASTAMPW(9);
+        auto fd2 = [&](int h, int t) -> float {
+          const float dx = qf[h][0] - fx[lo[h] + t], dy = qf[h][1] - fy[lo[h] + t], dz = qf[h][2] - fz[lo[h] + t];
+          return dx * dx + dy * dy + dz * dz;
+        };
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int h = 0; h < HG; ++h) {
+            const int t = lane + 64 * u;
+            d2r[h][u] = t < cnt[h] ? fd2(h, t) : INF;
+            mf[h] = fminf(mf[h], d2r[h][u]);
+          }
+#pragma unroll
+        for (int h = 0; h < HG; ++h)
+          for (int t = lane + 256; t < cnt[h]; t += 64) mf[h] = fminf(mf[h], fd2(h, t));
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+          for (int h = 0; h < HG; ++h) mf[h] = fminf(mf[h], __shfl_xor(mf[h], m));
+        double b2[HG];                        // squared distance of the lane's best (none yet: < 0)
+        int bests[HG];
+        unsigned long long bkey[HG];
+#pragma unroll
+        for (int h = 0; h < HG; ++h) {
+          const float qm = fmaxf(fabsf(qf[h][0]), fmaxf(fabsf(qf[h][1]), fabsf(qf[h][2])));
+          const float E = 4.0f * U * (qm + cmax);
+          const float T = (sqrtf(mf[h]) + 2.0f * E) * (1.0f + 8.0f * U);
+          T2[h] = mf[h] < INF ? T * T * (1.0f + 4.0f * U) : -1.0f;      // (no survivor of that label: nothing passes)
+          b2[h] = -1.0; bests[h] = INT_MAX; bkey[h] = ~0ull;
+        }
+        auto exact1 = [&](int h, int t) {     // the exact rule (see below) on survivor lo + t
+          const int s = sidx[lo[h] + t];
+          const unsigned long long key = sel[s];
+          const double dx = q[h][0] - dmx[lo[h] + t], dy = q[h][1] - dmx[Ksub + lo[h] + t], dz = q[h][2] - dmx[2 * (size_t)Ksub + lo[h] + t];
+          const double d2 = dx * dx + dy * dy + dz * dz;
+          bool take = b2[h] < 0.0 || d2 < b2[h] * BAND;
+          if (!take && d2 * BAND <= b2[h]) {
+            const double rd = sqrt(d2), rb = sqrt(b2[h]);
+            take = rd < rb || (rd == rb && key < bkey[h]);
+          }
+          if (take) { b2[h] = d2; bests[h] = s; bkey[h] = key; }
+        };
+#pragma unroll
+        for (int h = 0; h < HG; ++h) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (d2r[h][u] <= T2[h]) exact1(h, lane + 64 * u);
+          for (int t = lane + 256; t < cnt[h]; t += 64)
+            if (fd2(h, t) <= T2[h]) exact1(h, t);
+        }
+        ASTAMPW(10);
+#pragma unroll
+        for (int h = 0; h < HG; ++h) {
+          const int o = o0 + h * nwave;
+          if (o >= C.n_det) continue;
+          double best = C.best_init;
+          const double d = b2[h] >= 0.0 ? sqrt(b2[h]) : C.best_init;
+          if (d < C.best_init) best = d; else { bests[h] = INT_MAX; bkey[h] = ~0ull; }      // "if (d < bestDist)" against the initial bestDist
+          ASTAMPW(11);
+          reduce_write(o, best, bests[h], bkey[h]);
+        }
+      }
+    } else
     for (int o0 = wave; o0 < C.n_det; o0 += HM * nwave) {
       int nh = 0, ol[HM];
       double q[HM][3];
@@ -719,7 +918,7 @@ __global__ __launch_bounds__(1024) void k_assoc_sweep(const float* __restrict__ 
 // The same with 512-thread workgroups, two per CU (round 4): the kernel is bound by its in-CU select / match phases,
 // every one of which ends at a workgroup barrier — a second resident workgroup fills the other's barrier stalls.  64 KB of LDS each
 // (40 KB of distance words / staged models, 8 KB of keys, per-wave histograms), registers capped at 128 by the second bound.
-__global__ __launch_bounds__(512, 2) void k_assoc_sweep_512(const float* __restrict__ cx, const float* __restrict__ cy, const float* __restrict__ cz,
+__global__ __launch_bounds__(512, 4) void k_assoc_sweep_512(const float* __restrict__ cx, const float* __restrict__ cy, const float* __restrict__ cz,
                                                             const double* __restrict__ model_xyz, const int32_t* __restrict__ label, int n_map,
                                                             const double* __restrict__ query_pos, const double* __restrict__ obs_xyz,
                                                             const int32_t* __restrict__ obs_label, int n_obs, int K, int Kp, int cached,
@@ -776,7 +975,8 @@ bool assoc_plan(int n, int K, int gate, int model_stride, int* Kp, int* cached, 
   while (p < Ksub) p <<= 1;
   *Kp = p;
   const size_t fixed = (size_t)p * 8 + 256 * 4;
-  const size_t dc = (size_t)n * 4, st = ((size_t)Ksub * (model_stride * 8 + 4) + 7) / 8 * 8;
+  // staged survivors: cylinders 7 doubles + label; boxes / points 3 floats + an int (label, or position in sel) + the 3 doubles of the model
+  const size_t dc = (size_t)n * 4, st = ((size_t)Ksub * (model_stride == 3 ? 40 : model_stride * 8 + 4) + 7) / 8 * 8;
   *cached = fixed + dc <= (size_t)ASSOC_LDS_BUDGET ? 1 : 0;
   *staged = fixed + st <= (size_t)ASSOC_LDS_BUDGET ? 1 : 0;
   *bytes = fixed + std::max(*cached ? dc : 0, *staged ? st : 0);

@@ -10,6 +10,17 @@
 
 namespace sl {
 
+// Chunks the column blocks of a lambda-block product are cut into at most (split K, launch_border_syrk): the lambda block has nl tile
+// rows, (nl + 1) nl tiles — a handful of workgroups for a sum over the whole separator unless it is split; up to 16 chunks while the
+// tiles are few, about 256 workgroups in all beyond that (SURVEY 8d's density of relative-pose factors on C4: nl = 6, 42 tiles, 6 chunks —
+// unsplit, each of the three products of a pass kept 42 CUs busy for 35 - 60 us).  The same rule on every rank and in a whole pass: the
+// order of the sum is part of the bit-stable arithmetic.
+static inline int lam_ks_cap(int nl) {
+  const int tiles = (nl + 1) * nl;
+  if (tiles <= 0) return 1;
+  return tiles <= 32 ? 16 : std::max(1, std::min(16, 256 / tiles));
+}
+
 thread_local std::string g_last_error;
 
 bool hip_ok(hipError_t e, const char* what) {
@@ -863,7 +874,8 @@ int CholBatch::prepare_separator() {
     if (sep_nl > 0) {
       const size_t nb = (size_t)(sep_nl + 1) * NB * sep_nl * NB;
       SL_HIP(hipMalloc(reinterpret_cast<void**>(&sep_bord), nb * sizeof(double)));
-      if ((sep_nl + 1) * sep_nl <= 32) SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_scratch), 2 * (size_t)(sep_nl + 1) * sep_nl * 15 * NB * NB * sizeof(double)));      // (x 2: both leaves' partial tiles in one launch)
+      if (lam_ks_cap(sep_nl) > 1)
+        SL_HIP(hipMalloc(reinterpret_cast<void**>(&lam_scratch), 2 * (size_t)(sep_nl + 1) * sep_nl * (lam_ks_cap(sep_nl) - 1) * NB * NB * sizeof(double)));      // (x 2: both leaves' partial tiles in one launch)
       {
         std::vector<int> codes;      // the lambda block's tiles + right-hand-side row, for both leaves as two systems (launch_border_syrk_jobs)
         for (int sy = 0; sy < 2; ++sy)
@@ -1072,7 +1084,7 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
       if (sep_nl > 0) {
         CholSystem sl{};      // the lambdas' own block: this leaf's part of - W W^T
         sl.S = sepS + (size_t)own_t0 * NB * ld_s; sl.ld = ld_s; sl.T = own_T; sl.b0 = sep_Ts; sl.nbr = sep_nl; sl.bord = sep_bord; sl.ldb = (sep_nl + 1) * NB;
-        const int ks = (sep_nl + 1) * sep_nl <= 32 ? std::max(1, std::min(16, own_T / 2)) : 1;
+        const int ks = std::max(1, std::min(lam_ks_cap(sep_nl), own_T / 2));
         launch_border_syrk(&sl, 1, master, lam_scratch, ks);
       }
       launch_sep_unpack(Y, master, sTL, sep_Ts + sep_nl, true);               // the top block (with this leaf's Schur complement) back into the exchange buffer
@@ -1145,7 +1157,7 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
             CholSystem sl{};
             sl.S = sepS + (size_t)(hh ? sTa : 0) * NB * ld_s; sl.ld = ld_s; sl.T = sep_leafT[hh]; sl.b0 = sep_Ts; sl.nbr = sep_nl;
             sl.bord = hh ? sep_bord2 : sep_bord; sl.ldb = (sep_nl + 1) * NB;
-            ks_lam[hh] = (sep_nl + 1) * sep_nl <= 32 ? std::max(1, std::min(16, sep_leafT[hh] / 2)) : 1;
+            ks_lam[hh] = std::max(1, std::min(lam_ks_cap(sep_nl), sep_leafT[hh] / 2));
             sl2[hh] = sl;
           }
           if (sep_scratch && (sep_nl == 0 || (lam_scratch && d_lam_jobs2))) {
@@ -1190,7 +1202,7 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
       CholSystem sr = ss;      // the column blocks whose part of - W W^T is still missing: all, or (a rank that owns a leaf / a canonical whole pass) the top block's
       static const bool env_canon3 = !(getenv("SLIDE_SEP_CANONICAL") && getenv("SLIDE_SEP_CANONICAL")[0] == '0');
       if (owned || (whole && sep_dissected() && env_canon3 && n <= 8)) { sr.S = sepS + (size_t)sTL * NB * ld_s; sr.T = sTt; sr.b0 = sep_Ts; }
-      const int ks = (sep_nl + 1) * sep_nl <= 32 ? std::max(1, std::min(16, sr.T / 2)) : 1;      // few border tiles: split the column blocks
+      const int ks = std::max(1, std::min(lam_ks_cap(sep_nl), sr.T / 2));      // few border tiles: split the column blocks
       launch_border_syrk(&sr, 1, master, lam_scratch, ks);
       launch_lam_prepare(sep_bord, sep_nl, sep_lam, lamS, master);
       const int ld_l = (sep_nl + 1) * NB;

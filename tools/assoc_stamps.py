@@ -26,6 +26,9 @@ x = np.array(st[12:15], dtype=np.float64)
 if x[0] > 0:
     print("  select: histogram over linear bins done at %.2f us, K-th key's bin found +%.2f us, lower bins + candidates placed +%.2f us, ranks + padding +%.2f us" %
           ((x[0] - t[0]) * 0.01, (x[1] - x[0]) * 0.01, (x[2] - x[1]) * 0.01, (t[3] - x[2]) * 0.01))
+if st[7] and st[15]:
+    print("  staging by label: gathers issued + groups found at +%.2f us, labels mapped + counted +%.2f us, scanned + placed +%.2f us" %
+          ((st[7] - t[4]) * 0.01, (st[15] - st[7]) * 0.01, (t[5] - st[15]) * 0.01))
 w = np.array(st[8:12], dtype=np.float64)
 print("  matching, wave 0: detection data loaded +%.2f us, candidate loop +%.2f us, roots + reduction +%.2f us (first at %.2f us)" %
       ((w[1] - w[0]) * 0.01, (w[2] - w[1]) * 0.01, (w[3] - w[2]) * 0.01, (w[0] - t[0]) * 0.01))

@@ -7,7 +7,7 @@ R=${1:-r03}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT profiles
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-BENCH="python3 bench.py --steps 20 --warmup 3 --probe 0 --no-cpu --no-parity --no-dense-leg --ingest-only ${BENCH_ARGS}"      # BENCH_ARGS=--dense-profile: the dense-profile configuration
+BENCH="python3 bench.py --steps 20 --warmup 3 --probe 0 --no-cpu --no-parity --no-dense-leg --no-dense-relmeas --ingest-only ${BENCH_ARGS}"      # BENCH_ARGS=--dense-profile: the dense-profile configuration
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || exit 1
 echo "trace done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f -- $BENCH > $OUT/pmc_f.log 2>&1 || exit 1

@@ -40,3 +40,15 @@ for a, b in zip(sel[:-1], sel[1:]):
         steps[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 print("separator k_chol_step by block column (median us):")
 print(" | ".join(f"{k} {sorted(v)[len(v) // 2]:.1f}" for k, v in sorted(steps.items())))
+# the border products of a pass in launch order (the robots', the bands' second level's, the separator's leaves', lambda block's, top block's)
+prods = collections.defaultdict(list)
+for a, b in zip(sel[:-1], sel[1:]):
+    ks = [r for r in rows[a:b] if name(r).endswith('k_border_syrk')]
+    for k, r in enumerate(ks):
+        prods[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+print("k_border_syrk by position in the pass (median us; grid):")
+grid = {}
+for r in rows[sel[-2]:sel[-1]]:
+    if name(r).endswith('k_border_syrk'):
+        grid[len(grid)] = "x".join(str(r.get(k, "?")) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
+print(" | ".join(f"{k} {sorted(v)[len(v) // 2]:.1f} ({grid.get(k, '?')})" for k, v in sorted(prods.items())))
