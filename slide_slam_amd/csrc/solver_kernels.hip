@@ -1351,6 +1351,15 @@ __global__ __launch_bounds__(256) void k_sep_gather(SepGatherArgs A) {
   const bool rhs = vr == NT;
   const int gr = rhs ? 0 : (vr < NL ? (vr < Y.ms ? vr : -1) : (vr - NL < Y.lam ? Y.ms + vr - NL : -1));
   const unsigned rmask = A.tmask ? (rhs ? ~0u : (unsigned)A.tmask[vr / NB]) : ~0u;
+  // this row's coordinate in every robot's border block (the same for all columns of the workgroup: loaded once, not once per column
+  // in front of the value it addresses)
+  int lrow[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    lrow[r] = -1;
+    if (r < A.n && gr >= 0 && ((rmask >> r) & 1u) && ((A.robot_mask >> r) & 1u)) lrow[r] = rhs ? A.nbr[r] * NB : A.map[r][gr];
+  }
+#pragma unroll 2
   for (int vc = blockIdx.y * SEP_GATHER_COLS; vc < (int)(blockIdx.y + 1) * SEP_GATHER_COLS && vc < NT; ++vc) {
     if (!rhs && vr < vc) continue;
     // (the block between the leaves of a dissected layout: nobody ever writes it, in either layout — zero since allocation)
@@ -1373,10 +1382,10 @@ __global__ __launch_bounds__(256) void k_sep_gather(SepGatherArgs A) {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         v[r] = 0.0;
-        if (r < A.n && ((cand >> r) & 1u)) {
+        if (r < A.n && ((cand >> r) & 1u) && lrow[r] >= 0) {
           const int lc = A.map[r][gc];
-          const int lr = lc < 0 ? -1 : (rhs ? A.nbr[r] * NB : A.map[r][gr]);
-          if (lr >= 0) v[r] = A.bord[r][(size_t)min(lr, lc) * A.ldb[r] + max(lr, lc)];      // (lower triangle of the robot's block)
+          const int lr = lrow[r];
+          if (lc >= 0) v[r] = A.bord[r][(size_t)min(lr, lc) * A.ldb[r] + max(lr, lc)];      // (lower triangle of the robot's block)
         }
       }
       if (A.split_col >= 0 && vc >= A.split_col) {
