@@ -827,7 +827,7 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
                         "profiles/r03_*kernel_stats.csv"},
             "border_product": {
                 "kernel": "k_border_syrk (v_mfma_f64_16x16x4_f64; one launch per pass: every robot's Schur complement onto the separator, K = 64 T; "
-                          "workgroups from a job table, longest sums first)",
+                          "workgroups from a job table balanced over the XCD queues, operand loads fifteen k-steps ahead across the segments of a cut band)",
                 "bound": "mfma", "flops_per_launch": fl_done, "flops_dense_equivalent": fl_dense, "avg_launch_ms": ms_syrk,
                 "achieved": tf(fl_done, ms_syrk), "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS, "frac": tf(fl_done, ms_syrk) / FP64_MFMA_PEAK_TFLOPS,
                 "traffic": _pmc_traffic("k_border_syrk"),
