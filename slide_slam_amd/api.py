@@ -83,7 +83,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise SlideError(f"{LIB_PATH} is missing: run `python -m slide_slam_amd.build` (hipcc, gfx950). "
                              "There is no CPU fallback.")
-        L = C.CDLL(LIB_PATH)
+        # (SLIDE_LIB_VARIANT=<name>: an experiment build _lib/<name>.so of the SAME sources with other compile-time constants,
+        # tools/build_variant.py — kernel tuning only; it is a build of this library, not another path)
+        var = os.environ.get("SLIDE_LIB_VARIANT")
+        path = os.path.join(_HERE, "_lib", var + ".so") if var else LIB_PATH
+        if var and not os.path.exists(path):
+            raise SlideError(f"{path} is missing (SLIDE_LIB_VARIANT)")
+        L = C.CDLL(path)
         L.slide_last_error.restype = C.c_char_p
         L.slide_version.restype = C.c_char_p
         L.slide_graph_create.restype = C.c_void_p

@@ -108,7 +108,10 @@ __device__ __forceinline__ void b_quadrant(double* __restrict__ S, int ld, const
       const v2d c2 = *(const v2d*)(cbh + (size_t)(8 * r + a) * ld);
       acc[a][0][r] = c2[0]; acc[a][1][r] = c2[1];
     }
-  constexpr int RD = 4;                      // operand ring: loads run RD - 1 k-steps ahead
+#ifndef SLIDE_B_RD
+#define SLIDE_B_RD 4
+#endif
+  constexpr int RD = SLIDE_B_RD;             // operand ring: loads run RD - 1 k-steps ahead
   v2d pa[RD], pb[RD];
 #pragma unroll
   for (int pre = 0; pre < RD - 1; ++pre) {
