@@ -61,7 +61,10 @@ struct GraphParams {
   double relmeas_sigma[6] = {0.1, 0.1, 0.1, 0.1, 0.1, 0.1};      // :34
   double cyl_sigma = 400.0;          // graphWrapper.cpp:60  (100 * ones * 4)
   double bearing_sigma = 1.0;        // graphWrapper.cpp:63-64
-  double numdiff_delta = 1e-6;       // cubeFactor.cpp:43,48 ; cylinderFactor.cpp:41,46
+#ifndef ORC_NUMDIFF_DELTA
+#define ORC_NUMDIFF_DELTA 1e-6       // (sensitivity experiments build a second library with another value: tools/chart_sensitivity.py)
+#endif
+  double numdiff_delta = ORC_NUMDIFF_DELTA;       // 1e-6: cubeFactor.cpp:43,48 ; cylinderFactor.cpp:41,46
   int num_threads = 1;
 };
 

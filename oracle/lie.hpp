@@ -25,6 +25,19 @@ struct Pose {
 };
 
 enum PoseChart { CHART_CAYLEY = 0, CHART_EXPMAP = 1 };
+// Sensitivity experiment only (tools/chart_sensitivity.py builds a second library with -DORC_PERTURB_TRIG): the transcendental functions
+// of the Pose3 chart return the next representable number — what another correctly working libm (the device's) may return.  The
+// default build calls the standard functions.
+#ifdef ORC_PERTURB_TRIG
+inline double orc_up(double x) { return std::nextafter(x, x > 0 ? 1e300 : -1e300); }
+#define ORC_SIN(x) orc_up(std::sin(x))
+#define ORC_ACOS(x) orc_up(std::acos(x))
+#define ORC_TAN(x) orc_up(std::tan(x))
+#else
+#define ORC_SIN(x) std::sin(x)
+#define ORC_ACOS(x) std::acos(x)
+#define ORC_TAN(x) std::tan(x)
+#endif
 
 inline void mat3_identity(double* R) {
   for (int i = 0; i < 9; ++i) R[i] = 0.0;
@@ -79,8 +92,8 @@ inline void so3_expmap(const double* w, double* R) {
     return;
   }
   const double theta = std::sqrt(theta2);
-  const double s = std::sin(theta);
-  const double s2 = std::sin(0.5 * theta);
+  const double s = ORC_SIN(theta);
+  const double s2 = ORC_SIN(0.5 * theta);
   const double omc = 2.0 * s2 * s2;
   double K[9], KK[9];
   for (int i = 0; i < 9; ++i) K[i] = W[i] / theta;
@@ -114,8 +127,8 @@ inline void so3_logmap(const double* R, double* w) {
     double c = (tr - 1.0) / 2.0;
     if (c > 1.0) c = 1.0;
     if (c < -1.0) c = -1.0;
-    const double theta = std::acos(c);
-    magnitude = theta / (2.0 * std::sin(theta));
+    const double theta = ORC_ACOS(c);
+    magnitude = theta / (2.0 * ORC_SIN(theta));
   } else {
     magnitude = 0.5 - tr_3 / 12.0;
   }
@@ -214,7 +227,7 @@ inline void pose_logmap(const Pose& p, double* xi) {
   double wn[3] = {w[0] / t, w[1] / t, w[2] / t};
   double W[9];
   skew(wn, W);
-  const double Tan = std::tan(0.5 * t);
+  const double Tan = ORC_TAN(0.5 * t);
   double WT[3], WWT[3];
   mat3_vec(W, p.t, WT);
   mat3_vec(W, WT, WWT);

@@ -125,9 +125,11 @@ def test_c4_exact_joint_step_matches_oracle_shards_at_size(gpu, tmp_path, chart)
     z = json.load(open(out))
     assert z["finite"] and z["n_slots"][0] == z["n_slots"][1] > 500 and z["sep_dim"][0] == z["sep_dim"][1] > 1500 and z["n_gslots"] > 0
     # Cayley: 1e-8 .. 4e-8 on every pass.  Expmap (first run at size in round 4): the FIRST pass from the un-refined ingest state
-    # (steps of 0.2 m) differs by 4.3e-6, passes 2 - 4 by 2.4e-8 / 1.5e-8 / 6e-9 — the same formulas on both sides (Rodrigues, the
-    # SE(3) exponential's (w x v - R w x v + w w^T v) / theta^2, whose cancellation at small rotations amplifies the last bit of the
-    # two libm / device sin implementations); cause not isolated further, 1e-5 asserted there (the bar is 1e-4)
+    # (steps of 0.2 m) differs by 4.3e-6, passes 2 - 4 by 2.4e-8 / 1.5e-8 / 6e-9.  Isolated (profiles/r04_chart_sensitivity.txt): the two
+    # sides' SE(3) functions agree to 1e-14; their STARTING states differ by 1e-7 (rounding noise of the cube factors' central
+    # differences), and the first pass from the merged state amplifies that thirtyfold under Expmap only — the oracle against a copy
+    # of itself with the numerical-Jacobian step at 1.00001e-6 shows the same 4.25e-6 (tools/chart_sensitivity.py).  1e-5 asserted
+    # for that pass (the bar is 1e-4)
     assert max(z["gpu_vs_oracle"]) < (1e-6 if chart == "cayley" else 1e-5), z["gpu_vs_oracle"]
     assert max(z["gpu_vs_oracle"][1:]) < 1e-6, z["gpu_vs_oracle"]
     assert z["step"][3] < 5e-3 * z["step"][1], z["step"]
