@@ -181,6 +181,75 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def test_submap_knn_randomized_clouds(gpu):
+    """The select over clouds of many shapes and sizes (uniform, Gaussian clusters, a lattice with thousands of exact ties, a line, a
+    cloud of duplicates, distances spanning twelve orders of magnitude), K from 1 to beyond n: identical lists to the oracle.  Covers
+    the histogram path, the candidate ranks, the digit-pass fallback and the uncached map (n beyond the LDS cache)."""
+    rng = np.random.default_rng(2024)
+    kinds = ["uniform", "clusters", "lattice", "line", "duplicates", "wide"]
+    for case in range(48):
+        kind = kinds[case % len(kinds)]
+        n = int(rng.choice([1, 2, 63, 64, 65, 500, 1023, 1025, 4000, 9000, 20000, 41000]))
+        K = int(rng.choice([1, 2, 50, 63, 64, 65, 1000, 1024, 2500]))
+        if kind == "uniform":
+            cloud = rng.uniform(-80, 80, (n, 3))
+        elif kind == "clusters":
+            c = rng.uniform(-80, 80, (8, 3))
+            cloud = c[rng.integers(0, 8, n)] + rng.normal(0, 0.5, (n, 3))
+        elif kind == "lattice":
+            cloud = rng.integers(-6, 7, (n, 3)).astype(np.float64) * 2.0
+        elif kind == "line":
+            cloud = np.zeros((n, 3)); cloud[:, 0] = rng.uniform(-200, 200, n)
+        elif kind == "duplicates":
+            base = rng.uniform(-30, 30, (max(1, n // 50), 3))
+            cloud = base[rng.integers(0, len(base), n)]
+        else:
+            cloud = rng.normal(0, 1, (n, 3)) * 10.0 ** rng.uniform(-6, 6, (n, 1))
+        cloud = np.ascontiguousarray(cloud.astype(np.float32))
+        q = rng.uniform(-5, 5, 3) if kind != "lattice" else np.zeros(3)
+        got = gpu.submap_knn(cloud, q, K)
+        out = np.zeros(max(min(K, n), 1), np.int32)
+        k = po.lib().orc_knn_f32(cloud.ctypes.data_as(C.c_void_p), C.c_int(n), q.ctypes.data_as(C.c_void_p), C.c_int(K),
+                                 out.ctypes.data_as(C.c_void_p))
+        assert k == len(got) == min(K, n), (case, kind, n, K)
+        assert np.array_equal(got, out[:k]), (case, kind, n, K)
+
+
+@pytest.mark.parametrize("n_obs,n_labels,lab0", [(1, 1, 5), (20, 12, -3), (64, 7, 1000000), (70, 3, 1), (33, 40, 0)])
+def test_assoc_sweep_label_groups_and_detection_counts(gpu, n_obs, n_labels, lab0):
+    """The matching groups the staged survivors by label when a frame has at most 64 detections and scans all survivors behind a label
+    select beyond that; labels are arbitrary integers.  One detection, 64, 70 (ungrouped), more distinct labels than detections can
+    carry, negative and large labels, detections whose label no landmark has: identical map indices to the oracle."""
+    rng = np.random.default_rng(n_obs * 131 + n_labels)
+    n_map, K, n_q = 5000, 1000, 40
+    model = np.column_stack([rng.uniform(0, 150, n_map), rng.uniform(0, 150, n_map), rng.normal(0, 0.3, n_map)])
+    cloud = (model + rng.normal(0, 0.05, model.shape)).astype(np.float32)
+    label = (lab0 + 7 * rng.integers(0, n_labels, n_map)).astype(np.int32)
+    qpos = np.column_stack([rng.uniform(30, 120, n_q), rng.uniform(30, 120, n_q), np.full(n_q, 2.0)])
+    obs = np.zeros((n_q, n_obs, 3)); olab = np.zeros((n_q, n_obs), np.int32)
+    for i in range(n_q):
+        d2 = ((model[:, :2] - qpos[i, :2]) ** 2).sum(1)
+        near = np.argsort(d2)[:n_obs]
+        obs[i] = model[near] + rng.normal(0, 0.1, (n_obs, 3))
+        olab[i] = label[near]
+        olab[i, ::5] = lab0 + 7 * n_labels + 3                                   # a label no landmark carries
+    got, _ = gpu.assoc_sweep_batch(cloud, model, label, qpos, obs, olab, K, 0.75)
+    L = po.lib()
+    sub = np.zeros(K, np.int32)
+    exp = np.full(n_obs, -1, np.int32)
+    n_match = 0
+    for i in range(n_q):
+        k = L.orc_knn_f32(_p(cloud), C.c_int(n_map), _p(qpos[i]), C.c_int(K), _p(sub))
+        assert k == K
+        sm = np.ascontiguousarray(model[sub]); sl = np.ascontiguousarray(label[sub])
+        L.orc_match_boxes(C.c_int(2), C.c_int(n_obs), _p(np.ascontiguousarray(obs[i])), _p(np.ascontiguousarray(olab[i])), C.c_int(K),
+                          _p(sm), _p(sl), C.c_double(0.75), _p(exp))
+        want = np.where(exp >= 0, sub[np.maximum(exp, 0)], -1)
+        assert np.array_equal(got[i], want), (i, got[i], want)
+        n_match += int((want >= 0).sum())
+    assert n_match > 0.5 * n_q * n_obs * 0.8 or n_obs == 1
+
+
 @pytest.mark.parametrize("offset", [0.0, 7000.0])
 def test_assoc_sweep_near_ties_survive_the_float_screening(gpu, offset):
     """The matching screens the submap in float (coordinates relative to the robot) and applies the reference's double-precision rule

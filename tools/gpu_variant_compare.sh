@@ -1,5 +1,5 @@
 #!/bin/bash
-# library variants compared on the default bench: bash tools/r4_var.sh "" brd8 brd16
+# library variants compared on the default bench: bash tools/gpu_variant_compare.sh "" brd8 brd16
 set -o pipefail
 mkdir -p gpurun_out
 B="python bench.py --steps 100 --warmup 10 --no-cpu --no-parity --no-dense-leg --probe 0 --no-dense-relmeas"
