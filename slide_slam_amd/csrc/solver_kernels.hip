@@ -714,11 +714,10 @@ void launch_pose_adj(const GraphDev& G, hipStream_t s) {
 }
 
 template <bool LISTED>
-__device__ __forceinline__ void k_schur_body(const GraphDev& G) {
+__device__ __forceinline__ void k_schur_body(const GraphDev& G, int pj, int yb) {
   __shared__ double schur_tile[6][192];
   __shared__ long long pj_ed[SCHUR_PJ_CAP];
   __shared__ int pj_lm[SCHUR_PJ_CAP];
-  const int pj = blockIdx.x;
   if (pj >= G.P) return;            // (a batched launch covers the largest graph)
   if (6 * pj + 5 < G.col0) return;  // incremental re-factorisation: this pose's columns hold the factor of the last solve
   const int tid = threadIdx.x;
@@ -749,7 +748,7 @@ __device__ __forceinline__ void k_schur_body(const GraphDev& G) {
     p_end = min(G.P, (rows + 5) / 6);
   }
   // the chunks of the strip are dealt out to the gridDim.y workgroups of this pose column (each builds the two tables itself)
-  for (int pi0 = pj + 32 * (int)blockIdx.y; pi0 < p_end; pi0 += 32 * (int)gridDim.y) {
+  for (int pi0 = pj + 32 * yb; pi0 < p_end; pi0 += 32 * (int)gridDim.y) {
     const int nval = 6 * min(32, G.P - pi0);
     double* Sb = G.S + (size_t)(6 * pj) * G.ld + 6 * (size_t)pi0;
     double* S0b = G.S0 + (size_t)(6 * pj) * G.ld + 6 * (size_t)pi0;      // second copy for the joint solve (save_S0)
@@ -898,16 +897,32 @@ __device__ __forceinline__ void k_schur_body(const GraphDev& G) {
   __syncthreads();      // the tile is reused by the next chunk
   }
 }
-__global__ __launch_bounds__(256) void k_schur(GraphDev G) { k_schur_body<false>(G); }
+__global__ __launch_bounds__(256) void k_schur(GraphDev G) { k_schur_body<false>(G, blockIdx.x, blockIdx.y); }
 __global__ __launch_bounds__(256) void k_schur_b(const GraphDev* __restrict__ Gs) {
   const GraphDev G = Gs[blockIdx.z];
-  k_schur_body<false>(G);
+  k_schur_body<false>(G, blockIdx.x, blockIdx.y);
 }
 // the same from pair lists (every graph of the launch has them: launch_phase3_arrow_batched) — a kernel of its own: the walk's tables and
 // its three-deep staging would set this one's register budget too
-__global__ __launch_bounds__(256) void k_schur_lb(const GraphDev* __restrict__ Gs) {
-  const GraphDev G = Gs[blockIdx.z];
-  k_schur_body<true>(G);
+// xcd != 0: the workgroups are renumbered so that the ones the hardware deals to one XCD (linear id mod 8) cover a CONTIGUOUS range of
+// (robot, chunk, pose column) — with eight robots, one robot per XCD: a landmark's E / F records are read by every pose column that
+// observes it, and with consecutive columns dealt round-robin every XCD's L2 fetched every record (PMC: 182 MB fetched per launch for
+// 35 MB of records).  Experiment (SLIDE_SCHUR_XCD=1), measured on C4: assembly 0.507 - 0.510 ms either way — the kernel is bound by
+// the latency of its dependent loads per workgroup, not by where they are served from; off by default
+__global__ __launch_bounds__(256) void k_schur_lb(const GraphDev* __restrict__ Gs, int xcd) {
+  int x = blockIdx.x, y = blockIdx.y, z = blockIdx.z;
+  if (xcd) {
+    const long long total = (long long)gridDim.x * gridDim.y * gridDim.z;
+    const long long lin = x + (long long)gridDim.x * (y + (long long)gridDim.y * z);
+    const int r = (int)(lin % 8);
+    long long l2 = lin / 8;                        // XCD r holds the ids r, r + 8, ...: (total - r + 7) / 8 of them, a contiguous range
+    for (int i = 0; i < r; ++i) l2 += (total - i + 7) / 8;
+    x = (int)(l2 % gridDim.x);
+    y = (int)((l2 / gridDim.x) % gridDim.y);
+    z = (int)(l2 / ((long long)gridDim.x * gridDim.y));
+  }
+  const GraphDev G = Gs[z];
+  k_schur_body<true>(G, x, y);
 }
 
 // padding (identity) between 6P and T*NB, and the RHS row (-g) at row T*NB
@@ -1632,7 +1647,8 @@ void launch_phase3_arrow_batched(const GraphDev* d, const GraphDev* h, int n, hi
     bool listed = true;
     for (int i = 0; i < n; ++i) { split = std::max(split, h[i].schur_split > 0 ? h[i].schur_split : 2); listed = listed && h[i].sp_idx != nullptr; }
     const size_t lds = (size_t)((L + 7) / 8 * 8) * sizeof(short) + (size_t)((P + 31) / 32 + 1) * sizeof(unsigned);
-    if (listed) hipLaunchKernelGGL(k_schur_lb, dim3(P, split > 0 ? split : 1, n), dim3(256), lds, s, d);
+    static const int schur_xcd = getenv("SLIDE_SCHUR_XCD") ? atoi(getenv("SLIDE_SCHUR_XCD")) : 0;
+    if (listed) hipLaunchKernelGGL(k_schur_lb, dim3(P, split > 0 ? split : 1, n), dim3(256), lds, s, d, schur_xcd);
     else hipLaunchKernelGGL(k_schur_b, dim3(P, split > 0 ? split : 1, n), dim3(256), lds, s, d);
     hipLaunchKernelGGL(k_pad_rhs_b, dim3(blocks_for(pad, 256), 1, n), dim3(256), 0, s, d);
   }
