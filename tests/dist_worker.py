@@ -123,10 +123,11 @@ def main_driver(R):
     arrow = "arrow" in sys.argv[6:]       # the exact joint step: ONE all-reduce (the separator system) per pass
     drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, base=base, world=world, device=device, pcg_iters=pcg, arrow=arrow,
                      sep_dim=info["sep_dim"], sep_prof=info.get("sep_prof"))
-    if "relmeas" in sys.argv[6:]:     # inter-robot relative-pose factors of the job (every rank regenerates the same seeded list)
-        from slide_slam_amd.synth import make_relmeas
+    if "relmeas" in sys.argv[6:] or "relmeas_dense" in sys.argv[6:]:     # inter-robot relative-pose factors of the job (every rank regenerates the same seeded list)
+        from slide_slam_amd.synth import make_relmeas, make_relmeas_dense
         all_logs = [make_robot_log(cfg, world_map, r) for r in range(cfg.robots)]
-        assert drv.setup_ghosts(make_relmeas(cfg, all_logs), rank=rank) > 0
+        rel = make_relmeas_dense(cfg, all_logs) if "relmeas_dense" in sys.argv[6:] else make_relmeas(cfg, all_logs)      # (dense: SURVEY 8d's density)
+        assert drv.setup_ghosts(rel, rank=rank) > 0
     drv.gauss_newton(iters)
     P = cfg.poses_per_robot
     mine = [np.array([sh.graph.get_pose12(0, k)[1] for k in range(P)]) for sh in shards]

@@ -224,8 +224,8 @@ def c3_converge(out, preset="C3", passes=400, every=20, pcg=0, unbatched=0, arro
     bufs, info = setup_local_shards(shards, gpu_matcher, device=dev)
     drv = PassDriver(shards, bufs, info["n_slots"], batch=batch, device=dev, pcg_iters=pcg, arrow=bool(arrow), sep_dim=info["sep_dim"], sep_prof=info.get("sep_prof"))
     if relmeas:      # the job's inter-robot relative-pose factors (the joint replica above was built without them: `joint` is then no reference)
-        from slide_slam_amd.synth import make_relmeas
-        assert drv.setup_ghosts(make_relmeas(cfg, data["logs"])) > 0
+        from slide_slam_amd.synth import make_relmeas, make_relmeas_dense
+        assert drv.setup_ghosts(make_relmeas_dense(cfg, data["logs"]) if relmeas == 2 else make_relmeas(cfg, data["logs"])) > 0      # (2: SURVEY 8d's density)
     nrm = np.linalg.norm(joint.reshape(R, -1), axis=1) if joint is not None else None
     hist, chi2_hist = [], []
     t_pass = 0.0

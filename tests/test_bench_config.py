@@ -243,6 +243,19 @@ def test_exact_joint_step_two_ranks_own_their_leaves_with_relative_pose_factors(
     assert np.abs(z["poses"] - one).max() < 1e-12 * np.abs(one).max()
 
 
+def test_exact_joint_step_two_ranks_with_dense_relative_pose_factors(gpu, tmp_path):
+    """SURVEY 8d's density of relative-pose factors (59 on C4: 354 lambda coordinates, six tile rows) as two ranks: the lambda block's
+    products are split over their column blocks by ONE rule on every rank and in a whole pass (host_graph.hip, lam_ks_cap) — the order
+    of those sums is part of the bit-stable arithmetic, so two ranks must still give one process's poses exactly."""
+    from test_distributed import _run_workers
+    out = str(tmp_path / "C4dense_one.json")
+    _scenario("c3_converge", out, "C4", 3, 3, 0, 0, 1, 2)
+    one = np.array(json.load(open(out))["final"])
+    z = _run_workers("gpu", "C4", 3, str(tmp_path / "C4dense_two.npz"), world=2, extra=("driver=4", "arrow", "relmeas_dense"))
+    assert int(z["owned"]) == 1
+    assert np.abs(z["poses"] - one).max() < 1e-12 * np.abs(one).max()
+
+
 def test_exact_joint_step_four_ranks_own_their_leaves(gpu, tmp_path):
     """configs[3] as FOUR ranks of two robots on the one visible GPU (gloo): the halves of the job are two ranks each, so the own leaf's
     segment is all-reduced within the half before part 1, and only one rank of a half (the leader) adds the leaf's Schur complement to
