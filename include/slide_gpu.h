@@ -311,8 +311,21 @@ int slide_backend_landmark_table(slide_backend_t* b, int cls, double* xyz, int32
 int slide_dense_spd_solve(const double* A, int n, const double* b, double* x, int repeats, double* ms_out);
 /* The same solve by an explicit schedule of the factorisation: method 0 = one step launch per 64-column block (what
  * slide_dense_spd_solve runs), 1 = the left-looking persistent factorisation (ONE launch for all block columns, flags between
- * workgroups instead of kernel boundaries: what the exact joint passes use, ISAM2Params::CHOLESKY of graph.cpp:15 all the same). */
+ * workgroups instead of kernel boundaries; opt-in for the exact joint passes, SLIDE_CHOL_LL), 2 = TWO block columns per launch
+ * (k_chol_pair_batched: every type-A workgroup carries the sub-diagonal tile and the next diagonal block as well, so that the second
+ * column's chain starts inside the launch — what the exact joint passes use; ISAM2Params::CHOLESKY of graph.cpp:15 all the same). */
 int slide_dense_spd_solve_ex(const double* A, int n, const double* b, double* x, int repeats, double* ms_out, int method);
+/* Unit-test hook of the same kernels on a BORDERED system with a profile — one system exactly as an exact joint pass hands it to the
+ * factorisation (a robot's band segment with the separator's coupling rows riding below it, a leaf of the separator system: DESIGN.md 3):
+ * S_in (ld x T*64 doubles, column-major): the band's lower tiles inside the profile, nbr border row tiles from tile row b0 on (0: right
+ * behind the band), the right-hand-side row tile behind them.  prof: T ints (last tile row of every block column inside the profile)
+ * or NULL = dense; bfirst: nbr non-decreasing ints = first block column (+ kofs) of the j-th border row in the order `ord` lists them
+ * (1 << 30: never), or NULL = every row from column 0; ord: nbr ints (the j-th active row is tile row b0 + ord[j]) or NULL.  The system
+ * is factored n_copies (<= 32) times side by side in one launch sequence; S_out / Ld_out (T x 64 x 64) / Winv_out (T x 1024) /
+ * status_out (8) receive copy 0, *max_copy_diff the largest difference of any other copy from it.  method 0: one step launch per block
+ * column, 2: two block columns per launch.  After the call the band tiles hold L, the border rows W = B L^-T, the RHS row y = L^-1 b. */
+int slide_debug_chol_bordered(const double* S_in, int ld, int T, int nbr, const int* prof, const int* bfirst, const int* ord, int b0, int kofs,
+                              int n_copies, int method, double* S_out, double* Ld_out, double* Winv_out, int* status_out, double* max_copy_diff);
 
 /* ------------------------------------------------------------------------------------------------
  * S3 — association (include/core/sloam.h:88-108, src/core/sloam.cpp:73-306; *MapManager::getSubmap)
@@ -472,6 +485,23 @@ int slide_clipper_dense_clique(const double* M_upper, int n, const double* u0, c
  * environment forces the workgroup count (1 = one workgroup).  slide_clipper_last_solve_info: how the last
  * slide_clipper_dense_clique call of this process ran (workgroups, gradient evaluations); either pointer may be NULL. */
 void slide_clipper_last_solve_info(int* n_workgroups, double* grad_evals);
+/* Measurement aid of bench.py's SlideMatch / SlideGraph / CLIPPER legs (pair-tests/s of place_recognition.cpp:98-387, triangle
+ * pairs/s of semantic_clipper.cpp:49-118, nnz * 12 B per product of clipper.cpp:172-323): what the LAST stand-alone call of this process
+ * spent in its kernels — HIP events on the launch stream right around the launches; uploads, host prefix sums and read-backs excluded —
+ * and the work those kernels were given. */
+enum {
+  SLIDE_MS_PLACE_SWEEP = 0,       /* ms: k_place_sweep + k_place_argmax of the last slide_match_maps / loop-closure search */
+  SLIDE_MS_TRI_MATCH = 1,         /* ms: k_tri_prepare x 2 + k_tri_match count and emit passes */
+  SLIDE_MS_CLQ_CSR = 2,           /* ms: k_clq_csr count + fill (CSR of the affinity matrix from its dense upper triangle) */
+  SLIDE_MS_CLQ_SOLVE = 3,         /* ms: the projected-gradient solve (k_clq_solve or k_clq_solve_coop) */
+  SLIDE_MS_AFFINITY = 4,          /* ms: k_clipper_affinity */
+  SLIDE_MS_CLQ_NNZ = 5,           /* count: non-zeros of the last solve's CSR */
+  SLIDE_MS_PLACE_PAIR_TESTS = 6,  /* count: candidates x query objects x reference objects of the last sweep (a first hit ends a query
+                                     object's scan early: upper bound of the pair tests executed) */
+  SLIDE_MS_TRI_PAIRS = 7,         /* count: model triangles x data triangles of the last triangle match */
+  SLIDE_MS_COUNT = 8
+};
+int slide_last_device_ms(int what, double* out);
 /* The same for several independent problems in ONE launch, a persistent workgroup per problem — the robot pairs of a multi-robot job
  * (semantic_clipper.cpp:227-235 once per pair; 28 pairs at eight robots).  Job j: M_upper[j] (n[j] x n[j]), u0[j] or NULL,
  * nodes_out[j] (>= n[j] ints), u_out[j] (n[j] doubles or NULL); n_nodes[j], score[j].  Results equal n_jobs single calls. */

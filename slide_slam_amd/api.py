@@ -28,9 +28,9 @@ EXPORTS = [
     "slide_graph_add_loop_closure", "slide_graph_add_relative_meas", "slide_graph_add_point_landmark",
     "slide_graph_add_range_bearing", "slide_graph_add_cube", "slide_graph_add_cylinder", "slide_graph_solve",
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
-    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_chol_batch_set_pcg_tolerance", "slide_graph_set_pcg_tolerance", "slide_graph_set_separator", "slide_chol_batch_set_exact_joint", "slide_chol_batch_sep_buffer_len", "slide_chol_batch_sep_exchange_len", "slide_chol_batch_profile_exact_joint", "slide_graph_get_border_profile", "slide_graph_get_incremental_stats", "slide_graph_set_wildfire", "slide_graph_get_wildfire_stats", "slide_graph_get_segments", "slide_graph_get_segment_table", "slide_chol_batch_set_segments", "slide_clipper_dense_clique_batch", "slide_clipper_last_solve_info", "slide_chol_batch_set_separator_profile", "slide_chol_batch_set_separator_blocks", "slide_chol_batch_set_separator_owner", "slide_chol_batch_sep_segment", "slide_graph_set_incremental", "slide_graph_set_ghost_ids", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
+    "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_chol_batch_set_pcg_tolerance", "slide_graph_set_pcg_tolerance", "slide_graph_set_separator", "slide_chol_batch_set_exact_joint", "slide_chol_batch_sep_buffer_len", "slide_chol_batch_sep_exchange_len", "slide_chol_batch_profile_exact_joint", "slide_graph_get_border_profile", "slide_graph_get_incremental_stats", "slide_graph_set_wildfire", "slide_graph_get_wildfire_stats", "slide_graph_get_segments", "slide_graph_get_segment_table", "slide_chol_batch_set_segments", "slide_clipper_dense_clique_batch", "slide_clipper_last_solve_info", "slide_last_device_ms", "slide_chol_batch_set_separator_profile", "slide_chol_batch_set_separator_blocks", "slide_chol_batch_set_separator_owner", "slide_chol_batch_sep_segment", "slide_graph_set_incremental", "slide_graph_set_ghost_ids", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
     "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
-    "slide_dense_spd_solve", "slide_dense_spd_solve_ex", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device", "slide_assoc_sweep_batch",
+    "slide_dense_spd_solve", "slide_dense_spd_solve_ex", "slide_debug_chol_bordered", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device", "slide_assoc_sweep_batch",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
     "slide_backend_end_frame", "slide_backend_graph", "slide_backend_counts", "slide_backend_map_model",
     "slide_place_default_params", "slide_match_maps", "slide_find_inter_loop_closure", "slide_find_intra_loop_closure",
@@ -540,9 +540,17 @@ class SlideBackend:
         return int(st), out[: 7 if cls == 0 else 6], hits.value, label.value
 
 
+def pair_timeouts():
+    """Flag waits of the pair kernel (two block columns per launch) that gave up since the library was loaded; 0 on a healthy run."""
+    f = lib().slide_debug_pair_timeouts
+    f.restype = C.c_int
+    return int(f())
+
+
 def dense_spd_solve(A, b, repeats=1, method=0):
     """x = A^-1 b on the GPU (blocked FP64-MFMA Cholesky); returns (x, device ms over `repeats` passes).  method 0: one step launch
-    per 64-column block; 1: the left-looking persistent factorisation (one launch, flags between workgroups)."""
+    per 64-column block; 1: the left-looking persistent factorisation (one launch, flags between workgroups); 2: two block columns
+    per launch (k_chol_pair_batched)."""
     A = np.asfortranarray(np.asarray(A, dtype=np.float64))
     n = A.shape[0]
     x = np.zeros(n)
@@ -550,6 +558,24 @@ def dense_spd_solve(A, b, repeats=1, method=0):
     _check(lib().slide_dense_spd_solve_ex(A.ctypes.data_as(C.c_void_p), C.c_int(n), _p(_d(b)), _p(x), C.c_int(repeats),
                                           C.byref(ms), C.c_int(method)))
     return x, ms.value
+
+
+def debug_chol_bordered(S, ld, T, nbr, prof=None, bfirst=None, ord=None, b0=0, kofs=0, n_copies=1, method=0):
+    """slide_debug_chol_bordered: factor one bordered system with a profile (S: flat column-major ld x T*64) n_copies times side by side.
+    Returns dict(S, Ld, Winv, status, copy_diff)."""
+    S = np.ascontiguousarray(S, dtype=np.float64).ravel()
+    assert S.size == ld * T * 64
+    So = np.zeros_like(S)
+    Ld = np.zeros(T * 64 * 64)
+    Wi = np.zeros(T * 1024)
+    st = np.zeros(8, np.int32)
+    diff = C.c_double(0)
+    ia = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+    pr, bf, od = ia(prof), ia(bfirst), ia(ord)
+    pp = lambda a: None if a is None else _p(a)
+    _check(lib().slide_debug_chol_bordered(_p(S), C.c_int(ld), C.c_int(T), C.c_int(nbr), pp(pr), pp(bf), pp(od), C.c_int(b0), C.c_int(kofs),
+                                           C.c_int(n_copies), C.c_int(method), _p(So), _p(Ld), _p(Wi), _p(st), C.byref(diff)))
+    return dict(S=So, Ld=Ld, Winv=Wi, status=st, copy_diff=diff.value)
 
 
 # ---- stand-alone association / place recognition ---------------------------------------------------------
@@ -701,6 +727,16 @@ def clipper_last_solve_info():
     w, e = C.c_int(0), C.c_double(0)
     lib().slide_clipper_last_solve_info(C.byref(w), C.byref(e))
     return w.value, e.value
+
+
+MS_PLACE_SWEEP, MS_TRI_MATCH, MS_CLQ_CSR, MS_CLQ_SOLVE, MS_AFFINITY, MS_CLQ_NNZ, MS_PLACE_PAIR_TESTS, MS_TRI_PAIRS = range(8)
+
+
+def last_device_ms(what):
+    """slide_last_device_ms: kernel time (ms) or work count of the last stand-alone SlideMatch / SlideGraph / CLIPPER call."""
+    v = C.c_double(0)
+    _check(lib().slide_last_device_ms(C.c_int(what), C.byref(v)))
+    return v.value
 
 
 def clipper_dense_clique_batch(Ms, u0s=None, params=None):

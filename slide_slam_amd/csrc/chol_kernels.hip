@@ -716,6 +716,697 @@ __global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int 
 
 
 // ------------------------------------------------------------------------------------------------
+// PAIR kernel (round 5): TWO block columns k, k + 1 (k even) per launch — the chain-bound launch train of an exact joint pass halved.
+// A launch of the step kernels above is one 64-column diagonal chain (~6.3 us) wrapped in ~3 us of dispatch gap, ~1.5 us of loads and
+// staging and ~1.8 us of closing.  Here a type-A workgroup carries, beside its own 32 rows of tile row i >= k + 2, the WHOLE sub-diagonal
+// tile (k + 1, k) and the diagonal block (k + 1, k + 1) redundantly (as it already does D_kk), so that the chain of column k + 1 starts
+// inside the same launch the moment the last rows of L(k + 1, k) exist: no cross-workgroup hop, no kernel boundary.  Right-looking kept:
+// the launch's work queue applies the panels of the PREVIOUS pair (k - 2, k - 1) to the tiles (i, j >= k + 2) in one rank-128 pass; the
+// pair's own columns take those two panels as PENDING panels inside the type-A workgroups.
+// Twelve waves (wave w runs on SIMD w & 3):
+//   0        chain wave: the 4x4 pivot chain of D_kk, then of D(k+1, k+1) (alone on SIMD 0: waves 4 and 8 only stage and leave)
+//   1, 2, 3  workers: sub-tile rows 1..3 of the diagonal block of the column at hand (a_worker_wave's protocol, flags offset per column)
+//   5, 9, 6, 7   "sub" waves q = 0..3: rows 16 q .. of tile (k + 1, k): pending panels, X = A L_kk^-T pipelined with the chain's phases; every
+//            finished 16-column block goes to LDS as lane images (Xs) for the other waves; the own sub-tile ROW q of D(k+1, k+1) is brought
+//            up to date on the side (panels k-2, k-1 from memory, the fresh panel k block by block) and handed to factor wave q (D2) —
+//            after the chain of column k only the last block's four MFMAs and the hand-over of sub-tile (0, 0) lie before the next chain
+//   10, 11   "row" waves: 16 rows each of the workgroup's half of tile row i: column k like panel_rows, then tile (i, k + 1): its pending
+//            panels k-2, k-1 (operands of tile (k+1, c) straight from memory), the fresh panel from Xs, X = A L(k+1,k+1)^-T with the
+//            second chain's phases.
+// LDS: the staged pending tiles (k, k-2), (k, k-1) (80 KB; once every wave is through with them — pend_done — their first 20 KB carry D2),
+// Xs (32 KB), the factor waves' exchange areas of ALds.  All flags count upwards over the two columns (no reset, no barrier between them).
+constexpr int PAIR_THREADS = 768;
+struct PLds {
+  double Pk[2 * NB][PSTR];  // Pk[kk][r] = L[k*NB + r][(k-2)*NB + kk]: pending panel tiles (k, k-2), (k, k-1); later D2 (see above)
+  double Xs[16][4][64];     // Xs[ks][J][lane (lr, lk)] = X[16 J + lr][4 ks + lk], X = L(k+1, k)
+  double mop[16][64];
+  double xm[16][64];
+  double Lt[6][4][64];
+  double Dh[3][4][64];
+  double Dh3[3][64];
+  double Wi[4][256];
+  int it_done;              // 1..16 column k, 17..32 column k+1
+  int col_done[4];          // 1..4, then 5..8
+  int d_ready[4];           // 1, then 2
+  int w_done;               // 1..4, then 5..8
+  int pend_done;            // waves that are through with Pk
+  int p1_done;              // sub / row waves that are through with column k's Lt / Wi
+  int xs_done[4];           // xs_done[q]: 16-column blocks of rows 16 q .. of X published in Xs
+  int d2_ready[4];          // d2_ready[q]: sub-tile row q of D(k+1, k+1) is in D2
+  int sub_loaded;           // sub waves whose loads of tile (k+1, k) have come back
+  int store_flag;           // 0: not drawn yet; 1: another workgroup stores L(k+1, k); 2: this one does (the system's last ticket)
+};
+// Bounded flag wait (every wave of the pair kernel reaches its end whatever happens): ~0.2 s of polling, then the wait is counted in
+// g_pair_timeouts (slide_debug_pair_timeouts: the tests assert 0) and the wave goes on with whatever is there.
+__device__ int g_pair_timeouts;
+__device__ __forceinline__ void lds_wait_p(int* f, int v) {
+  const unsigned off = (unsigned)(size_t)f;
+  int cur;
+  for (int spin = 0; spin < (1 << 21); ++spin) {
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cur) : "v"(off) : "memory");
+    if (__builtin_amdgcn_readfirstlane(cur) >= v) return;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if ((threadIdx.x & 63) == 0) atomicAdd(&g_pair_timeouts, 1);
+}
+__device__ __forceinline__ void lds_add1(int* f, int lane) {
+  const unsigned off = (unsigned)(size_t)f;
+  const int one = 1;
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  if (lane == 0) asm volatile("ds_add_u32 %0, %1" : : "v"(off), "v"(one) : "memory");
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+__device__ __forceinline__ constexpr int didx(int I, int J) { return I * (I + 1) / 2 + J; }   // I >= J
+typedef double (*D2Ptr)[4][64];
+// global accesses of the pair kernel: wave-uniform base (scalar registers) + one 32-bit lane offset in bytes, so that the dozens of
+// loads a wave keeps in flight share ONE address register (with 64-bit per-lane addresses they do not fit the 168 registers of
+// three waves per SIMD)
+// (the empty asm pins the base in a scalar register pair: without it the compiler, short of scalar registers, keeps whole families of
+// 64-bit per-lane addresses alive — a tile's load addresses until its stores — and spills them)
+__device__ __forceinline__ double ldu(const double* ubase, unsigned boff) {
+  asm("" : "+s"(ubase));
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ubase) + boff);
+}
+__device__ __forceinline__ void stu(double* ubase, unsigned boff, double v) {
+  asm("" : "+s"(ubase));
+  *reinterpret_cast<double*>(reinterpret_cast<char*>(ubase) + boff) = v;
+}
+__device__ __forceinline__ D2Ptr pair_d2(PLds& L) { return reinterpret_cast<D2Ptr>(&L.Pk[0][0]); }
+
+// ---- wave 0 (a_chain_wave with the flags of column PH) ---------------------------------------------------------------------------------
+template <int NPAN, int PH>
+__device__ __forceinline__ void p_chain_wave(bool report, int* status, PLds& L, int lane, v4d Dt) {
+  const int lr = lane & 15, lk = lane >> 4;
+  const v4d zero = v4d{0.0, 0.0, 0.0, 0.0};
+  const bool s00 = lr == 0 && lk == 0, s10 = lr == 1 && lk == 0, s11 = lr == 1 && lk == 1, s20 = lr == 2 && lk == 0,
+             s21 = lr == 2 && lk == 1, s22 = lr == 2 && lk == 2, s30 = lr == 3 && lk == 0, s31 = lr == 3 && lk == 1,
+             s32 = lr == 3 && lk == 2, s33 = lr == 3 && lk == 3;
+  if (NPAN > 0) {
+    v4d d1 = zero, d2 = zero, d3 = zero;
+#pragma unroll
+    for (int ks = 0; ks < 4 * NPAN; ++ks) {
+      const double q0 = L.Pk[4 * ks + lk][lr], q1 = L.Pk[16 * NPAN + 4 * ks + lk][lr], q2 = L.Pk[32 * NPAN + 4 * ks + lk][lr],
+                   q3 = L.Pk[48 * NPAN + 4 * ks + lk][lr];
+      Dt = mfma_f64(-q0, q0, Dt);
+      d1 = mfma_f64(-q1, q1, d1);
+      d2 = mfma_f64(-q2, q2, d2);
+      d3 = mfma_f64(-q3, q3, d3);
+    }
+    Dt = (Dt + d1) + (d2 + d3);
+  }
+  if (PH == 0) lds_add1(&L.pend_done, lane);
+  bool ok = true;
+  v4d Dnext = zero;
+#pragma unroll
+  for (int JQ = 0; JQ < 4; ++JQ) {
+    if (JQ > 0) Dt = Dnext;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (lr < lk + 4 * r) Dt[r] = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int n = 4 * JQ + s;
+      const double dv = Dt[s];
+      const double P00 = bcast_lane(dv, 4 * s), P10 = bcast_lane(dv, 4 * s + 1), P20 = bcast_lane(dv, 4 * s + 2), P30 = bcast_lane(dv, 4 * s + 3);
+      const double P11 = bcast_lane(dv, 4 * s + 1 + 16), P21 = bcast_lane(dv, 4 * s + 2 + 16), P31 = bcast_lane(dv, 4 * s + 3 + 16);
+      const double P22 = bcast_lane(dv, 4 * s + 2 + 32), P32 = bcast_lane(dv, 4 * s + 3 + 32), P33 = bcast_lane(dv, 4 * s + 3 + 48);
+      const double i0 = rsqrt_nr(P00);
+      const double l10 = P10 * i0, l20 = P20 * i0, l30 = P30 * i0;
+      const double d1 = P11 - l10 * l10;
+      const double i1 = rsqrt_nr(d1);
+      const double l21 = (P21 - l20 * l10) * i1, l31 = (P31 - l30 * l10) * i1;
+      const double d2 = P22 - l20 * l20 - l21 * l21;
+      const double i2 = rsqrt_nr(d2);
+      const double l32 = (P32 - l30 * l20 - l31 * l21) * i2;
+      const double d3 = P33 - l30 * l30 - l31 * l31 - l32 * l32;
+      const double i3 = rsqrt_nr(d3);
+      ok = ok && (P00 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (d3 > 0.0);
+      const double m10 = -l10 * i0 * i1;
+      const double m21 = -l21 * i1 * i2;
+      const double m20 = -(l20 * i0 + l21 * m10) * i2;
+      const double m32 = -l32 * i2 * i3;
+      const double m31 = -(l31 * i1 + l32 * m21) * i3;
+      const double m30 = -(l30 * i0 + l31 * m10 + l32 * m20) * i3;
+      double mop = 0.0;
+      mop = s00 ? i0 : mop;  mop = s11 ? i1 : mop;  mop = s10 ? m10 : mop;  mop = s22 ? i2 : mop;  mop = s21 ? m21 : mop;
+      mop = s20 ? m20 : mop; mop = s33 ? i3 : mop;  mop = s32 ? m32 : mop;  mop = s31 ? m31 : mop;  mop = s30 ? m30 : mop;
+      L.mop[n][lane] = mop;
+      const double xd = mfma_f64(mop, Dt[s], zero)[0];
+      Dt[s] = xd;
+      const double xm = (lr > 4 * s + 3) ? xd : 0.0;
+      L.xm[n][lane] = xm;
+      lds_post(&L.it_done, 16 * PH + n + 1, lane);
+      if (s < 3) Dt = mfma_f64(-xm, xm, Dt);
+      if (s == 3 && JQ < 3) {
+        lds_wait_p(&L.d_ready[JQ + 1], PH + 1);
+        const double x3 = mfma_f64(mop, L.Dh3[JQ][lane], zero)[0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Dnext[r] = L.Dh[JQ][r][lane];
+        Dnext = mfma_f64(-x3, x3, Dnext);
+      }
+    }
+  }
+  if (!ok && lane == 0 && report) atomicOr(&status[1], 1);
+}
+
+// ---- waves 1..3 (a_worker_wave with the flags of column PH; NREAD: the sub / row waves that read column k's Lt / Wi) -----------------------
+template <int W, int NPAN, int PH>
+__device__ __forceinline__ void p_worker_wave(bool store, double* __restrict__ Ld, double* __restrict__ Winv, PLds& L, int lane,
+                                              v4d (&R)[W + 1], int nread) {
+  const int lr = lane & 15, lk = lane >> 4;
+  const v4d zero = v4d{0.0, 0.0, 0.0, 0.0};
+  if (NPAN > 0) {
+    v4d e[W + 1];
+#pragma unroll
+    for (int J = 0; J <= W; ++J) e[J] = zero;
+#pragma unroll
+    for (int ks = 0; ks < 16 * NPAN; ks += 2) {
+      const double w0 = L.Pk[4 * ks + lk][16 * W + lr], w1 = L.Pk[4 * ks + 4 + lk][16 * W + lr];
+#pragma unroll
+      for (int J = 0; J <= W; ++J) {
+        R[J] = mfma_f64(-L.Pk[4 * ks + lk][16 * J + lr], w0, R[J]);
+        e[J] = mfma_f64(-L.Pk[4 * ks + 4 + lk][16 * J + lr], w1, e[J]);
+      }
+    }
+#pragma unroll
+    for (int J = 0; J <= W; ++J) {
+      R[J] += e[J];
+      pin(R[J]);
+    }
+  }
+  if (PH == 0) lds_add1(&L.pend_done, lane);
+  v4d Wt = zero;
+#pragma unroll
+  for (int JQ = 0; JQ < W; ++JQ) {
+    if (W == WT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Wt[r] = (lr == lk + 4 * r) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int n = 4 * JQ + s;
+      lds_wait_p(&L.it_done, 16 * PH + n + 1);
+      const double mop = L.mop[n][lane], xm = L.xm[n][lane];
+      const double x = mfma_f64(mop, R[JQ][s], zero)[0];
+      double xw = 0.0;
+      if (W == WT) xw = mfma_f64(mop, Wt[s], zero)[0];
+      R[JQ][s] = x;
+      if (W == WT) Wt[s] = xw;
+      if (s < 3) {
+        R[JQ] = mfma_f64(-xm, x, R[JQ]);
+        if (W == WT) Wt = mfma_f64(-xm, xw, Wt);
+      }
+      R[W] = mfma_f64(-R[JQ][s], R[JQ][s], R[W]);
+#pragma unroll
+      for (int J = 0; J <= W; ++J) pin(R[J]);
+      if (W == WT) pin(Wt);
+      if (JQ == W - 1 && s == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) L.Dh[W - 1][r][lane] = R[W][r];
+        L.Dh3[W - 1][lane] = R[JQ][3];
+        lds_post(&L.d_ready[W], PH + 1, lane);
+      }
+    }
+    // the second column overwrites Lt / Wi: not before every reader of the first column's is through (long since: they finish right
+    // behind the first chain)
+    if (PH == 1 && JQ == 0) lds_wait_p(&L.p1_done, nread);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      L.Lt[oidx(W, JQ)][r][lane] = R[JQ][r];
+      if (store) Ld[(size_t)(16 * JQ + lk + 4 * r) * NB + 16 * W + lr] = R[JQ][r];
+    }
+    lds_post(&L.col_done[W], 4 * PH + JQ + 1, lane);
+#pragma unroll
+    for (int J = JQ + 1; J < W; ++J) {
+      lds_wait_p(&L.col_done[J], 4 * PH + JQ + 1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) R[J] = mfma_f64(-L.Lt[oidx(J, JQ)][ks][lane], R[JQ][ks], R[J]);
+    }
+    if (W == WT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double v = (lk + 4 * r >= lr) ? Wt[r] : 0.0;
+        L.Wi[JQ][lr * 16 + lk + 4 * r] = v;
+        if (store) Winv[(size_t)JQ * 256 + lr * 16 + lk + 4 * r] = v;
+      }
+      lds_post(&L.w_done, 4 * PH + JQ + 1, lane);
+    }
+  }
+  static_assert(W >= 1 && W <= 3, "worker index");
+  if (W == WT) {
+#pragma unroll
+    for (int JQ = WT; JQ < 4; ++JQ) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Wt[r] = (lr == lk + 4 * r) ? 1.0 : 0.0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int n = 4 * JQ + s;
+        lds_wait_p(&L.it_done, 16 * PH + n + 1);
+        const double mop = L.mop[n][lane], xm = L.xm[n][lane];
+        const double xw = mfma_f64(mop, Wt[s], zero)[0];
+        Wt[s] = xw;
+        if (s < 3) Wt = mfma_f64(-xm, xw, Wt);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double v = (lk + 4 * r >= lr) ? Wt[r] : 0.0;
+        L.Wi[JQ][lr * 16 + lk + 4 * r] = v;
+        if (store) Winv[(size_t)JQ * 256 + lr * 16 + lk + 4 * r] = v;
+      }
+      lds_post(&L.w_done, 4 * PH + JQ + 1, lane);
+    }
+  }
+}
+
+#define PAIR_YIELD() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_sched_barrier(0); } while (0)
+// ---- sub wave Q: rows 16 Q .. of tile (k + 1, k) and sub-tile row Q of D(k+1, k+1) ----------------------------------------------------------
+// Tq[b][r] = A[16 Q + lr][16 b + lk + 4 r] (tile (k+1, k)), tb[ks] = own rows of the pending panel tiles (k+1, k-2), (k+1, k-1),
+// R2[J][r] = D(k+1,k+1)[16 Q + lr][16 J + lk + 4 r]
+// L(k+1, k) is needed, as the ORIGINAL tile, by every workgroup of the system and written back by one of them: the one that draws the
+// system's LAST ticket (`ticket`: a device counter; every workgroup draws once all its loads of the tile are back, so whoever draws
+// n_wg - 1 knows that nobody reads the tile any more — workgroups of a later round of the launch included; nobody waits for anybody).
+template <int NPAN, int Q>
+__device__ __forceinline__ void p_sub_rows(double* __restrict__ S, int ld, int k, bool zs, int* ticket, int n_wg, int lane, PLds& L, v4d (&Tq)[4],
+                                           const double (&tb)[NPAN > 0 ? 16 * NPAN : 1], v4d (&R2)[Q + 1], int nread_pk) {
+  const int lr = lane & 15, lk = lane >> 4;
+  const v4d zero = v4d{0.0, 0.0, 0.0, 0.0};
+  const unsigned boff = (unsigned)(lk * ld + lr) * 8u;
+  double* tcol = S + (size_t)(k * NB) * ld + (size_t)(k + 1) * NB + 16 * Q;      // (uniform) own rows of tile (k+1, k)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the own rows of the tile (and everything else this wave loads) are in registers
+  lds_add1(&L.sub_loaded, lane);
+  if (Q == 3) {
+    lds_wait_p(&L.sub_loaded, 4);
+    int flag = 1;
+    if (lane == 0) {
+      const int old = atomicAdd(ticket, 1);
+      if (old == n_wg - 1) { flag = 2; atomicExch(ticket, 0); }      // (the last: everybody has drawn; the counter is ready for the next launch)
+    }
+    flag = __builtin_amdgcn_readfirstlane(flag);
+    lds_post(&L.store_flag, flag, lane);
+  }
+  if (NPAN > 0) {
+    // pending panels on the own rows of the tile: A = rows of (k, c) (LDS), B = own rows of (k+1, c)
+#pragma unroll
+    for (int ks = 0; ks < 16 * NPAN; ++ks) {
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) Tq[bb] = mfma_f64(-L.Pk[4 * ks + lk][16 * bb + lr], tb[ks], Tq[bb]);
+    }
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) pin(Tq[bb]);
+  }
+  lds_add1(&L.pend_done, lane);
+  if (NPAN > 0) {
+    // ... and on the own sub-tile row of D(k+1, k+1): A = rows 16 J + lr of (k+1, c): the own rows are tb, the others come from memory
+    // (the sibling sub waves have just loaded them: L1 / L2 hits), a few k-steps at a time
+    const double* prow = S + (size_t)((k - NPAN) * NB) * ld + (size_t)(k + 1) * NB;
+    constexpr int CH = Q <= 1 ? 8 : 4;
+#pragma unroll
+    for (int k0 = 0; k0 < 16 * NPAN; k0 += CH) {
+      double a[Q > 0 ? Q : 1][CH];
+#pragma unroll
+      for (int J = 0; J < Q; ++J)
+#pragma unroll
+        for (int i = 0; i < CH; ++i) a[J][i] = ldu(prow + (size_t)(4 * (k0 + i)) * ld + 16 * J, boff);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+#pragma unroll
+        for (int J = 0; J < Q; ++J) R2[J] = mfma_f64(-a[J][i], tb[k0 + i], R2[J]);
+        R2[Q] = mfma_f64(-tb[k0 + i], tb[k0 + i], R2[Q]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int J = 0; J <= Q; ++J) pin(R2[J]);
+  }
+  // X = A L_kk^-T by blocked substitution with the first chain's phases (panel_rows); every finished block feeds Xs and D2's row
+  v4d xt[4], t[4];
+  lds_wait_p(&L.it_done, 4);
+  t[0] = Tq[0];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    lds_wait_p(&L.w_done, b + 1);
+    v4d x = zero;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(L.Wi[b][(4 * s4 + lk) * 16 + lr], t[b][s4], x);
+    xt[b] = x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) L.Xs[4 * b + r][Q][lane] = x[r];
+    lds_post(&L.xs_done[Q], b + 1, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) R2[Q] = mfma_f64(-x[r], x[r], R2[Q]);
+    if (Q == 0 && b == 3) {
+      // sub-tile (0, 0) of the next diagonal block: the second chain starts from it
+      lds_wait_p(&L.pend_done, nread_pk);
+      D2Ptr D2 = pair_d2(L);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) D2[didx(0, 0)][r][lane] = R2[0][r];
+      lds_post(&L.d2_ready[0], 1, lane);
+    }
+#pragma unroll
+    for (int J = 0; J < Q; ++J) {
+      lds_wait_p(&L.xs_done[J], b + 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) R2[J] = mfma_f64(-L.Xs[4 * b + r][J][lane], x[r], R2[J]);
+    }
+    if (b < 3) {
+      PAIR_YIELD();
+      lds_wait_p(&L.col_done[b + 1], b + 1);
+      v4d tn = Tq[b + 1];
+#pragma unroll
+      for (int c = 0; c <= b; ++c) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) tn = mfma_f64(-L.Lt[oidx(b + 1, c)][s4][lane], xt[c][s4], tn);
+        if (b < 2 || c < b) PAIR_YIELD();
+      }
+      t[b + 1] = tn;
+      pin(t[b + 1]);
+    }
+  }
+  if (Q > 0) {
+    lds_wait_p(&L.pend_done, nread_pk);
+    D2Ptr D2 = pair_d2(L);
+#pragma unroll
+    for (int J = 0; J <= Q; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) D2[didx(Q, J)][r][lane] = R2[J][r];
+    lds_post(&L.d2_ready[Q], 1, lane);
+  }
+  lds_add1(&L.p1_done, lane);
+  // the tile goes back to memory from the workgroup that drew the last ticket
+  lds_wait_p(&L.store_flag, 1);
+  int sf;
+  {
+    const unsigned off = (unsigned)(size_t)&L.store_flag;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sf) : "v"(off) : "memory");
+  }
+  if (__builtin_amdgcn_readfirstlane(sf) == 2 && !zs) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stu(tcol + (size_t)(16 * b + 4 * r) * ld, boff, xt[b][r]);
+  }
+}
+
+// ---- row wave: 16 rows (row set qq) of tile row `it`: column k, then column k + 1 -----------------------------------------------------------
+template <int NPAN>
+__device__ __forceinline__ void p_row_rows(double* __restrict__ S, int ld, int k, int it, int qq, int ncols, bool z0, int lane, PLds& L,
+                                           v4d (&Tq)[4], const double (&tb)[NPAN > 0 ? 16 * NPAN : 1], v4d (&Tq2)[4]) {
+  const int lr = lane & 15, lk = lane >> 4;
+  const v4d zero = v4d{0.0, 0.0, 0.0, 0.0};
+  const unsigned boff = (unsigned)(lk * ld + lr) * 8u;
+  double* tcol = S + (size_t)(k * NB) * ld + (size_t)it * NB + 16 * qq;
+  if (NPAN > 0 && !z0) {
+#pragma unroll
+    for (int ks = 0; ks < 16 * NPAN; ++ks) {
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) Tq[bb] = mfma_f64(-L.Pk[4 * ks + lk][16 * bb + lr], tb[ks], Tq[bb]);
+    }
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) pin(Tq[bb]);
+  }
+  lds_add1(&L.pend_done, lane);
+  if (NPAN > 0 && !z0 && ncols == 2) {
+    // the same two panels on the own rows of tile (it, k + 1): A = rows of tile (k + 1, c), straight from memory
+    const double* prow = S + (size_t)((k - NPAN) * NB) * ld + (size_t)(k + 1) * NB;
+#pragma unroll
+    for (int k0 = 0; k0 < 16 * NPAN; k0 += 2) {
+      double a[4][2];
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[bb][i] = ldu(prow + (size_t)(4 * (k0 + i)) * ld + 16 * bb, boff);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) Tq2[bb] = mfma_f64(-a[bb][i], tb[k0 + i], Tq2[bb]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) pin(Tq2[bb]);
+  }
+  v4d xt[4], t[4];
+  if (!z0) {
+    lds_wait_p(&L.it_done, 4);
+    t[0] = Tq[0];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      lds_wait_p(&L.w_done, b + 1);
+      v4d x = zero;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(L.Wi[b][(4 * s4 + lk) * 16 + lr], t[b][s4], x);
+      xt[b] = x;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stu(tcol + (size_t)(16 * b + 4 * r) * ld, boff, x[r]);
+      if (ncols == 2) {
+        // the fresh panel on the own rows of tile (it, k + 1): A = rows of X = L(k+1, k) from Xs
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          lds_wait_p(&L.xs_done[bb], b + 1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Tq2[bb] = mfma_f64(-L.Xs[4 * b + r][bb][lane], x[r], Tq2[bb]);
+        }
+      }
+      if (b < 3) {
+        PAIR_YIELD();
+        lds_wait_p(&L.col_done[b + 1], b + 1);
+        v4d tn = Tq[b + 1];
+#pragma unroll
+        for (int c = 0; c <= b; ++c) {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) tn = mfma_f64(-L.Lt[oidx(b + 1, c)][s4][lane], xt[c][s4], tn);
+          if (b < 2 || c < b) PAIR_YIELD();
+        }
+        t[b + 1] = tn;
+        pin(t[b + 1]);
+      }
+    }
+  }
+  lds_add1(&L.p1_done, lane);
+  if (ncols != 2) return;
+  // column k + 1 with the second chain's phases
+  double* tcol2 = S + (size_t)((k + 1) * NB) * ld + (size_t)it * NB + 16 * qq;
+  t[0] = Tq2[0];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    lds_wait_p(&L.w_done, 4 + b + 1);
+    v4d x = zero;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(L.Wi[b][(4 * s4 + lk) * 16 + lr], t[b][s4], x);
+    xt[b] = x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) stu(tcol2 + (size_t)(16 * b + 4 * r) * ld, boff, x[r]);
+    if (b < 3) {
+      PAIR_YIELD();
+      lds_wait_p(&L.col_done[b + 1], 4 + b + 1);
+      v4d tn = Tq2[b + 1];
+#pragma unroll
+      for (int c = 0; c <= b; ++c) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) tn = mfma_f64(-L.Lt[oidx(b + 1, c)][s4][lane], xt[c][s4], tn);
+        if (b < 2 || c < b) PAIR_YIELD();
+      }
+      t[b + 1] = tn;
+      pin(t[b + 1]);
+    }
+  }
+}
+
+// own rows (row set q of tile row `it`) of block column kc and of the NPAN panel tiles in front of column k
+template <int NPAN>
+__device__ __forceinline__ void pair_load_rows(const double* __restrict__ S, int ld, int k, int kc, int it, int q, int lr, int lk, bool zero_rows,
+                                               v4d (&Tq)[4], double (&tb)[NPAN > 0 ? 16 * NPAN : 1], bool with_tb) {
+  const unsigned boff = (unsigned)(lk * ld + lr) * 8u;
+  const double* tcol = S + (size_t)(kc * NB) * ld + (size_t)it * NB + 16 * q;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Tq[b][r] = zero_rows ? 0.0 : ldu(tcol + (size_t)(16 * b + 4 * r) * ld, boff);
+  if (NPAN > 0 && with_tb) {
+    const double* pi = S + (size_t)((k - NPAN) * NB) * ld + (size_t)it * NB + 16 * q;
+#pragma unroll
+    for (int ks = 0; ks < 16 * NPAN; ++ks) tb[ks] = zero_rows ? 0.0 : ldu(pi + (size_t)(4 * ks) * ld, boff);
+  }
+}
+
+template <int NPAN, int Q>
+__device__ __forceinline__ void pair_sub_wave(double* __restrict__ S, int ld, int k, bool zs, int* ticket, int n_wg, int lane, PLds& L, int nread_pk) {
+  const int lr = lane & 15, lk = lane >> 4;
+  v4d Tq[4];
+  double tb[NPAN > 0 ? 16 * NPAN : 1];
+  pair_load_rows<NPAN>(S, ld, k, k, k + 1, Q, lr, lk, false, Tq, tb, true);
+  v4d R2[Q + 1];
+  const unsigned boff = (unsigned)(lk * ld + lr) * 8u;
+  const double* dcol = S + (size_t)((k + 1) * NB) * ld + (size_t)(k + 1) * NB + 16 * Q;
+#pragma unroll
+  for (int J = 0; J <= Q; ++J)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) R2[J][r] = ldu(dcol + (size_t)(16 * J + 4 * r) * ld, boff);
+  __syncthreads();
+  p_sub_rows<NPAN, Q>(S, ld, k, zs, ticket, n_wg, lane, L, Tq, tb, R2, nread_pk);
+}
+
+// One type-A workgroup of the pair (k, k + 1): rows 32 half .. of tile row `it` (+ everything of the diagonal blocks).  ncols = 1: the
+// system's last column alone (no sub waves, one chain).  z0: tile (it, k) is structurally zero (the row starts at column k + 1: nothing
+// is loaded or stored there); zs: so is tile (k + 1, k) (not stored).  first: this workgroup publishes Ld / Winv / the status flag.
+template <int NPAN>
+__device__ __forceinline__ void pair_type_a(double* __restrict__ S, int ld, int k, int ncols, int it, int half, bool first, bool z0, bool zs,
+                                            double* __restrict__ Ld, double* __restrict__ Winv, int* status, int* ticket, int n_wg, PLds& L) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..11
+  const int lr = lane & 15, lk = lane >> 4;
+  if (tid == 0) { L.it_done = 0; L.w_done = 0; L.pend_done = 0; L.p1_done = 0; L.sub_loaded = 0; L.store_flag = 0; }
+  if (tid < 4) { L.col_done[tid] = 0; L.d_ready[tid] = 0; L.xs_done[tid] = 0; L.d2_ready[tid] = 0; }
+  const int nread_pk = ncols == 2 ? 10 : 6;      // waves that read Pk: four factor waves, two row waves (+ four sub waves)
+  const int nread_lt = 6;                        // sub + row waves that read the first column's Lt / Wi
+  if (NPAN > 0 && wave >= 4) {
+    // a sixteenth of the pending panel tiles (k, k-2), (k, k-1) per wave -> LDS
+    const double* pq = S + (size_t)((k - NPAN) * NB + 16 * (wave - 4)) * ld + (size_t)k * NB;
+    double stage[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) stage[c] = ldu(pq + (size_t)c * ld, (unsigned)lane * 8u);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) L.Pk[16 * (wave - 4) + c][lane] = stage[c];
+  }
+  if (wave < 4) {
+    const unsigned boff = (unsigned)(lk * ld + lr) * 8u;
+    const double* dcol = S + (size_t)(k * NB) * ld + (size_t)k * NB + 16 * wave;
+    v4d R[4];
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) R[J][r] = (J <= wave) ? ldu(dcol + (size_t)(16 * J + 4 * r) * ld, boff) : 0.0;
+    __syncthreads();
+    if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
+    D2Ptr D2 = pair_d2(L);
+    if (wave == 0) {
+      p_chain_wave<NPAN, 0>(first, status, L, lane, R[0]);
+      if (ncols == 2) {
+        lds_wait_p(&L.d2_ready[0], 1);
+        v4d D;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) D[r] = D2[didx(0, 0)][r][lane];
+        p_chain_wave<0, 1>(first, status, L, lane, D);
+      }
+    } else if (wave == 1) {
+      v4d R1[2] = {R[0], R[1]};
+      p_worker_wave<1, NPAN, 0>(first, Ld, Winv, L, lane, R1, nread_lt);
+      if (ncols == 2) {
+        lds_wait_p(&L.d2_ready[1], 1);
+#pragma unroll
+        for (int J = 0; J <= 1; ++J)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) R1[J][r] = D2[didx(1, J)][r][lane];
+        p_worker_wave<1, 0, 1>(first, Ld + NB * NB, Winv + 1024, L, lane, R1, nread_lt);
+      }
+    } else if (wave == 2) {
+      v4d R2[3] = {R[0], R[1], R[2]};
+      p_worker_wave<2, NPAN, 0>(first, Ld, Winv, L, lane, R2, nread_lt);
+      if (ncols == 2) {
+        lds_wait_p(&L.d2_ready[2], 1);
+#pragma unroll
+        for (int J = 0; J <= 2; ++J)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) R2[J][r] = D2[didx(2, J)][r][lane];
+        p_worker_wave<2, 0, 1>(first, Ld + NB * NB, Winv + 1024, L, lane, R2, nread_lt);
+      }
+    } else {
+      p_worker_wave<3, NPAN, 0>(first, Ld, Winv, L, lane, R, nread_lt);
+      if (ncols == 2) {
+        lds_wait_p(&L.d2_ready[3], 1);
+#pragma unroll
+        for (int J = 0; J <= 3; ++J)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) R[J][r] = D2[didx(3, J)][r][lane];
+        p_worker_wave<3, 0, 1>(first, Ld + NB * NB, Winv + 1024, L, lane, R, nread_lt);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  } else if (wave == 10 || wave == 11) {
+    const int qq = 2 * half + (wave - 10);
+    v4d Tq[4], Tq2[4];
+    double tb[NPAN > 0 ? 16 * NPAN : 1];
+    pair_load_rows<NPAN>(S, ld, k, k, it, qq, lr, lk, z0, Tq, tb, true);
+    if (ncols == 2) pair_load_rows<NPAN>(S, ld, k, k + 1, it, qq, lr, lk, false, Tq2, tb, false);
+    __syncthreads();
+    p_row_rows<NPAN>(S, ld, k, it, qq, ncols, z0, lane, L, Tq, tb, Tq2);
+  } else if (ncols == 2 && wave == 5) {
+    pair_sub_wave<NPAN, 0>(S, ld, k, zs, ticket, n_wg, lane, L, nread_pk);
+  } else if (ncols == 2 && wave == 9) {
+    pair_sub_wave<NPAN, 1>(S, ld, k, zs, ticket, n_wg, lane, L, nread_pk);
+  } else if (ncols == 2 && wave == 6) {
+    pair_sub_wave<NPAN, 2>(S, ld, k, zs, ticket, n_wg, lane, L, nread_pk);
+  } else if (ncols == 2 && wave == 7) {
+    pair_sub_wave<NPAN, 3>(S, ld, k, zs, ticket, n_wg, lane, L, nread_pk);
+  } else {
+    __syncthreads();      // waves 4 and 8 (and the sub waves of a single column): staging only
+  }
+}
+#undef PAIR_YIELD
+
+// Two block columns (k, k + 1) of up to 32 systems in ONE launch: the type-A workgroups of every system (two per tile row i >= k + ncols),
+// then one work queue over the rank-128 items of all of them (panels k-2, k-1 onto the tiles (i, j >= k + 2): b_decode with pair base k + 1
+// and the panel columns moved one to the left).
+struct CholPairArgs {
+  int n;
+  double* S[CHOL_STEP_BATCH_MAX]; int ld[CHOL_STEP_BATCH_MAX];
+  double* Ld[CHOL_STEP_BATCH_MAX]; double* Winv[CHOL_STEP_BATCH_MAX]; int* status[CHOL_STEP_BATCH_MAX];
+  int ncols[CHOL_STEP_BATCH_MAX];           // block columns of this launch that exist in the system: 2, 1 (its last column) or 0
+  int Tv0[CHOL_STEP_BATCH_MAX], Tv1[CHOL_STEP_BATCH_MAX];      // profile of column k / k + 1: rows below hold nothing
+  int nb0[CHOL_STEP_BATCH_MAX], nb1[CHOL_STEP_BATCH_MAX];      // active border rows at column k / k + 1
+  int TvB[CHOL_STEP_BATCH_MAX], nbB[CHOL_STEP_BATCH_MAX];      // the pass of panels k-2, k-1: profile of panel k-1, active border rows
+  int nP[CHOL_STEP_BATCH_MAX];              // 2x2 tile groups per side of that pass
+  int nbr[CHOL_STEP_BATCH_MAX]; int B0[CHOL_STEP_BATCH_MAX]; const int* ord[CHOL_STEP_BATCH_MAX];
+  int a_base[CHOL_STEP_BATCH_MAX + 1];      // prefix sums of the type-A workgroup counts
+  int b_base[CHOL_STEP_BATCH_MAX + 1];      // prefix sums of the item counts
+};
+// tickets: one int per system, zero between launches (p_sub_rows)
+__global__ __launch_bounds__(PAIR_THREADS) void k_chol_pair_batched(CholPairArgs A, int k, int* __restrict__ ctr, int* tickets, int a_joins) {
+  __shared__ PLds L;
+  __shared__ int s_g;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctr[k + 2] = 0;
+  const int bid = (int)blockIdx.x;
+  if (bid < A.a_base[A.n]) {
+    int r = 0;
+    while (bid >= A.a_base[r + 1]) ++r;
+    const int local = bid - A.a_base[r], ia = local >> 1, half = local & 1;
+    const int ncols = A.ncols[r], rbase = k + ncols;
+    const int TvL = ncols == 2 ? A.Tv1[r] : A.Tv0[r], nbL = ncols == 2 ? A.nb1[r] : A.nb0[r];
+    const int vi = rbase + ia - TvL;      // band rows rbase .. TvL - 1, then the active border rows, then the right-hand-side row
+    const int it = vi < 0 ? rbase + ia : (vi < nbL ? A.B0[r] + (A.ord[r] ? A.ord[r][vi] : vi) : A.B0[r] + A.nbr[r]);
+    const bool z0 = ncols == 2 && (vi < 0 ? rbase + ia >= A.Tv0[r] : (vi < nbL && vi >= A.nb0[r]));
+    const bool zs = k + 1 >= A.Tv0[r];
+    double* Ldk = A.Ld[r] + (size_t)k * NB * NB;
+    double* Wik = A.Winv[r] + (size_t)k * 1024;
+    const int n_wg = A.a_base[r + 1] - A.a_base[r];
+    if (k >= 2) pair_type_a<2>(A.S[r], A.ld[r], k, ncols, it, half, ia == 0, z0, zs, Ldk, Wik, A.status[r], tickets + r, n_wg, L);
+    else pair_type_a<0>(A.S[r], A.ld[r], k, ncols, it, half, ia == 0, z0, zs, Ldk, Wik, A.status[r], tickets + r, n_wg, L);
+    if (!a_joins) return;
+  }
+  const int nItems = A.b_base[A.n];
+  if (nItems <= 0) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_g = atomicAdd(&ctr[k], 1);
+    __syncthreads();
+    const int g = __builtin_amdgcn_readfirstlane(s_g);
+    if (g >= nItems) break;
+    if (wave >= 8) continue;
+    int r = 0;
+    while (g >= A.b_base[r + 1]) ++r;
+    const int gl = g - A.b_base[r], nR = A.b_base[r + 1] - A.b_base[r];
+    const long long nG = (long long)A.nP[r] * (A.nP[r] + 1) / 2;
+    BItem it = b_decode(gl, nR, nR, 0, k, k + 1, A.B0[r], A.TvB[r], 0, A.nP[r], nG, wave, A.nbr[r], A.nbB[r], 0, A.ord[r]);
+    if (!it.ok) continue;
+    it.pcb = k - 2;
+    b_quadrant<32>(A.S[r], A.ld[r], it, wave & 3);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // LEFT-LOOKING PERSISTENT factorisation: ALL block columns of up to 64 systems in ONE launch (round 4).
 // The step kernels above pay a kernel boundary per block column: ~3 us of dispatch gap, ~1.5 us of loads and staging, ~1.8 us of
 // closing on top of the ~8 us chain of a 64-column diagonal block — and an exact joint pass runs 58 such launches in a row.  Here the
@@ -1291,6 +1982,13 @@ __global__ __launch_bounds__(512) void k_chol_ll(const LLSys* __restrict__ sysv,
   }
 }
 
+// (diagnostic, not part of include/slide_gpu.h) flag waits of the pair kernel that gave up since the library was loaded: 0 unless a
+// launch was mis-planned
+extern "C" int slide_debug_pair_timeouts() {
+  int v = -1;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_pair_timeouts), sizeof(int)) != hipSuccess) return -1;
+  return v;
+}
 #ifdef SLIDE_STAMPS
 extern "C" void slide_debug_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
 extern "C" void slide_debug_chain_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_stamps), sizeof(g_chain_stamps)); }
@@ -2361,10 +3059,129 @@ void launch_chol_step(double* S, int ld, int k, int T, double* Ld, double* Winv,
 }
 // The factorisations + solves of several systems as one launch sequence (max T step launches, the extractions, one chained backward
 // substitution): d[i] describes system i; ctr is the work counter array of the batch (max T + 2 ints, zeroed once).
-void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps, bool solve, int cu_share) {
+// Pair launches (k_chol_pair_batched): plan of block columns k, k + 1 of one system.  Rows of the launch: the band's tile rows k + ncols ..
+// prof[k + ncols - 1], the border rows active at the pair's last column, the right-hand-side row — two workgroups each.  Items: the
+// rank-128 pass of panels k-2, k-1 over the tiles (i, j >= k + 2) inside the profile of panel k-1 (+ the border rows active there).
+struct PairPlan { int ncols, Tv0, Tv1, nb0, nb1, TvB, nbB, nP; long long nA, nB; };
+static PairPlan plan_pair(int k, int T, const int* prof, int nbr, const int* bfirst, int kofs) {
+  PairPlan p{};
+  p.ncols = T - k >= 2 ? 2 : (T - k == 1 ? 1 : 0);
+  if (p.ncols == 0) return p;
+  auto active = [&](int upto) { int c = 0; while (c < nbr && (!bfirst || bfirst[c] <= upto + kofs)) ++c; return c; };
+  p.Tv0 = prof ? prof[k] + 1 : T;
+  p.Tv1 = p.ncols == 2 ? (prof ? prof[k + 1] + 1 : T) : p.Tv0;
+  p.nb0 = active(k);
+  p.nb1 = p.ncols == 2 ? active(k + 1) : p.nb0;
+  const int TvL = p.ncols == 2 ? p.Tv1 : p.Tv0, nbL = p.ncols == 2 ? p.nb1 : p.nb0;
+  p.nA = (long long)(TvL - (k + p.ncols)) + nbL + 1;
+  if (k >= 2) {
+    const int kbE = k + 1;
+    p.TvB = prof ? prof[k - 1] + 1 : T;
+    p.nbB = active(k - 1);
+    p.nP = p.TvB + p.nbB > kbE ? (p.TvB + p.nbB - kbE + 1) / 2 : 0;
+    long long nG = (long long)p.nP * (p.nP + 1) / 2;
+    if (nbr > 0) {      // (plan_step: the group columns right of the profile's last column hold no item)
+      const int ncol = p.TvB - 1 >= kbE + 1 ? (p.TvB - 2 - kbE) / 2 + 1 : 0;
+      long long nv = 0;
+      for (int bj = 0; bj < ncol && bj < p.nP; ++bj) nv += p.nP - bj;
+      nG = nv;
+    }
+    p.nB = 2 * nG;
+  }
+  return p;
+}
+static void launch_chol_pair_steps(const CholSystem* d, int n, int* ctr, int* tickets, hipStream_t s) {
   const int n_cu = chol_n_cu();
   int Tmax = 0;
   for (int i = 0; i < n; ++i) Tmax = d[i].T > Tmax ? d[i].T : Tmax;
+  for (int k = 0; k < Tmax; k += 2) {
+    CholPairArgs A{};
+    A.n = n;
+    A.a_base[0] = A.b_base[0] = 0;
+    for (int i = 0; i < n; ++i) {
+      const PairPlan p = plan_pair(k, d[i].T, d[i].h_prof, d[i].nbr, d[i].h_bfirst, d[i].kofs);
+      A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.Ld[i] = d[i].Ld; A.Winv[i] = d[i].Winv; A.status[i] = d[i].status;
+      A.ncols[i] = p.ncols; A.Tv0[i] = p.Tv0; A.Tv1[i] = p.Tv1; A.nb0[i] = p.nb0; A.nb1[i] = p.nb1;
+      A.TvB[i] = p.TvB; A.nbB[i] = p.nbB; A.nP[i] = p.nP;
+      A.nbr[i] = d[i].nbr; A.B0[i] = d[i].b0 > 0 ? d[i].b0 : d[i].T; A.ord[i] = d[i].ord;
+      A.a_base[i + 1] = A.a_base[i] + (int)(2 * p.nA);
+      A.b_base[i + 1] = A.b_base[i] + (int)p.nB;
+    }
+    const long long nAw = A.a_base[n], nB = A.b_base[n];
+    if (nAw <= 0) continue;
+    const long long extra = nB < n_cu ? nB : n_cu;
+    const long long free_cu = n_cu - nAw > 8 ? n_cu - nAw : 8;
+    const int a_joins = nB > free_cu ? 1 : 0;
+    hipLaunchKernelGGL(k_chol_pair_batched, dim3((unsigned)(nAw + extra)), dim3(PAIR_THREADS), 0, s, A, k, ctr, tickets, a_joins);
+  }
+}
+bool chol_pair_supported(const CholSystem* d, int n) {
+  if (n < 1 || n > CHOL_STEP_BATCH_MAX) return false;
+  for (int i = 0; i < n; ++i)
+    if (d[i].L32) return false;      // (the f32 factor copy of the joint solve's preconditioner is written by the step kernels only)
+  return true;
+}
+void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps, bool solve, int cu_share, int* pair_tickets) {
+  const bool pair = pair_tickets != nullptr;
+  const int n_cu = chol_n_cu();
+  int Tmax = 0;
+  for (int i = 0; i < n; ++i) Tmax = d[i].T > Tmax ? d[i].T : Tmax;
+  static const bool verify = getenv("SLIDE_PAIR_VERIFY") && getenv("SLIDE_PAIR_VERIFY")[0] == '1';
+  if (pair && chol_pair_supported(d, n) && verify) {
+    // diagnostic (needs SLIDE_PASS_DIRECT=1: synchronises the stream): the same systems through the step kernels on copies, the pair
+    // kernel on the originals, tile by tile on the host — the first tiles that differ are printed
+    (void)hipStreamSynchronize(s);
+    std::vector<CholSystem> cp(d, d + n);
+    std::vector<size_t> len(n);
+    std::vector<void*> tmp;
+    auto dmal = [&](size_t bytes) { void* p = nullptr; (void)hipMalloc(&p, bytes); tmp.push_back(p); return p; };
+    for (int i = 0; i < n; ++i) {
+      const int B0 = d[i].b0 > 0 ? d[i].b0 : d[i].T;
+      len[i] = (size_t)d[i].ld * ((size_t)d[i].T * NB - 1) + (size_t)(B0 + d[i].nbr + 1) * NB;
+      cp[i].S = (double*)dmal(len[i] * sizeof(double));
+      cp[i].Ld = (double*)dmal((size_t)d[i].T * NB * NB * sizeof(double));
+      cp[i].Winv = (double*)dmal((size_t)d[i].T * 1024 * sizeof(double));
+      cp[i].status = (int*)dmal(8 * sizeof(int));
+      cp[i].yv = (double*)dmal((size_t)d[i].T * NB * sizeof(double));
+      cp[i].dp = (double*)dmal((size_t)d[i].T * NB * sizeof(double));
+      (void)hipMemset(cp[i].status, 0, 8 * sizeof(int));
+      (void)hipMemcpy(cp[i].S, d[i].S, len[i] * sizeof(double), hipMemcpyDeviceToDevice);
+    }
+    int* vctr = (int*)dmal(((size_t)Tmax + 3) * sizeof(int));
+    (void)hipMemset(vctr, 0, ((size_t)Tmax + 3) * sizeof(int));
+    launch_chol_batch(cp.data(), n, vctr, s, nullptr, false, cu_share, nullptr);
+    launch_chol_pair_steps(d, n, ctr, pair_tickets, s);
+    (void)hipStreamSynchronize(s);
+    int printed = 0;
+    for (int i = 0; i < n; ++i) {
+      std::vector<double> a(len[i]), b(len[i]);
+      (void)hipMemcpy(a.data(), cp[i].S, len[i] * sizeof(double), hipMemcpyDeviceToHost);
+      (void)hipMemcpy(b.data(), d[i].S, len[i] * sizeof(double), hipMemcpyDeviceToHost);
+      const int ld = d[i].ld, T = d[i].T, B0 = d[i].b0 > 0 ? d[i].b0 : T, rows = B0 + d[i].nbr + 1;
+      for (int c = 0; c < T; ++c)
+        for (int r = c; r < rows; ++r) {
+          if (c == T - 1 && r > B0 + d[i].nbr) continue;
+          double worst = 0.0, ref = 0.0;
+          for (int x = 0; x < NB; ++x)
+            for (int y = 0; y < NB; ++y) {
+              if (r == c) continue;      // (the diagonal tiles are not written back)
+              const size_t o = (size_t)(c * NB + x) * ld + (size_t)r * NB + y;
+              if (o >= len[i]) continue;
+              const double dd = std::fabs(a[o] - b[o]);
+              if (!(dd <= worst)) worst = dd;
+              ref = std::max(ref, std::fabs(a[o]));
+            }
+          if (worst > 1e-9 * std::max(ref, 1.0) && printed < 40) {
+            ++printed;
+            fprintf(stderr, "[pair verify] system %d (T %d, nbr %d, b0 %d, kofs %d): tile (%d, %d) differs by %.3e (step kernels' max |value| %.3e)\n", i, T, d[i].nbr, d[i].b0,
+                    d[i].kofs, r, c, worst, ref);
+          }
+        }
+    }
+    if (!printed) fprintf(stderr, "[pair verify] %d systems (Tmax %d): identical within 1e-9\n", n, Tmax);
+    for (void* p : tmp) (void)hipFree(p);
+    Tmax = Tmax > 0 ? -Tmax : 0;
+  } else if (pair && chol_pair_supported(d, n)) { launch_chol_pair_steps(d, n, ctr, pair_tickets, s); Tmax = Tmax > 0 ? -Tmax : 0; }
   for (int k = 0; k < Tmax; ++k) {
     CholBatchArgs A{};
     A.n = n;
@@ -2394,6 +3211,7 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
     const int a_joins = nB > free_cu ? 1 : 0;
     hipLaunchKernelGGL(k_chol_step_batched, dim3((unsigned)(nAw + extra)), dim3(512), 0, s, A, k, k & ~1, ctr, a_joins);
   }
+  if (Tmax < 0) Tmax = -Tmax;
   if (after_steps) (void)hipEventRecord(after_steps, s);
   if (!solve) {       // the caller continues with the border (k_border_syrk, the separator system) and runs launch_chol_bwd_batch itself
     ExtractArgs E{};

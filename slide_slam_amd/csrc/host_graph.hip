@@ -404,6 +404,7 @@ static CholSystem chol_system_of(const GraphDev& G, bool joint, float* L32, cons
 }
 static int chol_ll_mask();
 static bool chol_ll_enabled();
+static int chol_pair_mask();
 CholBatch::CholBatch(int n_) : n(n_ < 1 ? 1 : (n_ > 8 ? 8 : n_)), sys(n), ev_in(n, nullptr), bufs(n, nullptr), graphs(n, nullptr) {}
 void CholBatch::set_graph(int slot, HostGraph* g) {
   std::lock_guard<std::mutex> lk(mtx);
@@ -442,6 +443,7 @@ CholBatch::~CholBatch() {
   free_separator();
   free_ll_band_plans();
   if (d_ctr2) (void)hipFree(d_ctr2);
+  if (d_pair_tickets) (void)hipFree(d_pair_tickets);
   if (d_syrk_jobs) (void)hipFree(d_syrk_jobs);
   if (d_l2_jobs) (void)hipFree(d_l2_jobs);
   if (d_Gs) (void)hipFree(d_Gs);
@@ -537,6 +539,11 @@ int CholBatch::prepare_pass() {
     ctr_cap = CHOL_BATCH_HOST_MAX * 2 * (Tmax + 2);
     SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_ctr), ctr_cap * sizeof(int)));
     SL_HIP(hipMemsetAsync(d_ctr, 0, ctr_cap * sizeof(int), master));
+    SL_HIP(hipStreamSynchronize(master));
+  }
+  if (!d_pair_tickets && chol_pair_mask() != 0) {
+    SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_pair_tickets), 12 * CHOL_STEP_BATCH_MAX * sizeof(int)));
+    SL_HIP(hipMemsetAsync(d_pair_tickets, 0, 12 * CHOL_STEP_BATCH_MAX * sizeof(int), master));
     SL_HIP(hipStreamSynchronize(master));
   }
   if (!d_Gs) SL_HIP(hipMalloc(reinterpret_cast<void**>(&d_Gs), CHOL_BATCH_HOST_MAX * sizeof(GraphDev)));
@@ -743,6 +750,13 @@ static int chol_ll_mask() {
   return m;
 }
 static bool chol_ll_enabled() { return chol_ll_mask() != 0; }
+// SLIDE_CHOL_PAIR: bit mask (same levels) of what is factored TWO block columns per launch (k_chol_pair_batched, chol_kernels.hip):
+// half the chain-bound launches of a pass in a row.  Only the exact joint passes ask for it (the streaming path's single systems
+// keep the step kernels: a pair launch's redundant work pays on chain-bound launches only).
+static int chol_pair_mask() {
+  static const int m = getenv("SLIDE_CHOL_PAIR") ? atoi(getenv("SLIDE_CHOL_PAIR")) : 0;
+  return m;
+}
 void CholBatch::free_ll_band_plans() {
   for (CholLLPlan** p : {&ll_seg, &ll_l2}) if (*p) { if (master) (void)hipStreamSynchronize(master); chol_ll_plan_destroy(*p); *p = nullptr; }
 }
@@ -1078,7 +1092,7 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     if (sep_leader) launch_sep_unpack(Y, master, sTL, sep_Ts + sep_nl);      // this rank's own partial sum of the top block (and the lambdas')
     launch_sep_unpack(Y, master, own_t0, own_t0 + own_T);                      // the leaf, summed over the ranks of this half
     if (ll_leaf_own[own]) launch_chol_ll(ll_leaf_own[own], &lv[own], 1, master);
-    else launch_chol_batch(&lv[own], 1, sep_ctr2, master, nullptr, false);
+    else launch_chol_batch(&lv[own], 1, sep_ctr2, master, nullptr, false, 100, (chol_pair_mask() & 4) ? pair_tickets(10) : nullptr);
     if (sep_leader) {
       launch_border_syrk_jobs(&top, 1, d_sep_jobs, n_sep_jobs, 0, master, sep_scratch, sep_ks, sTt);
       if (sep_nl > 0) {
@@ -1119,7 +1133,7 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     if (!l2_sys.empty()) {
       // second level: the separator poses' own system (dense, nsep block columns) with the rest of the border as its border
       if (ll_l2) launch_chol_ll(ll_l2, l2_sys.data(), (int)l2_sys.size(), master);
-      else launch_chol_batch(l2_sys.data(), (int)l2_sys.size(), d_ctr2, master, nullptr, false);
+      else launch_chol_batch(l2_sys.data(), (int)l2_sys.size(), d_ctr2, master, nullptr, false, 100, (chol_pair_mask() & 2) ? pair_tickets(8) : nullptr);
       if (n_l2_jobs > 0) launch_border_syrk_jobs(l2_sys.data(), (int)l2_sys.size(), d_l2_jobs, n_l2_jobs, 0, master);
       else launch_border_syrk(l2_sys.data(), (int)l2_sys.size(), master);
     }
@@ -1142,7 +1156,7 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
       const bool canon2 = whole && env_canon2 && n <= 8;
       if (!owned) {
         if (ll_leaves) launch_chol_ll(ll_leaves, lv, 2, master);
-        else launch_chol_batch(lv, 2, sep_ctr2, master, nullptr, false);
+        else launch_chol_batch(lv, 2, sep_ctr2, master, nullptr, false, 100, (chol_pair_mask() & 4) ? pair_tickets(9) : nullptr);
         if (canon2) {
           // each half's partial top block minus ITS leaf's Schur complement, with the split of the column blocks a rank owning that leaf
           // uses (part 1), then the sum of the two — the arithmetic of a two-rank job, bit for bit
@@ -1179,6 +1193,9 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
       if (ll_top) {
         const CholSystem ts = sep_top_system();
         launch_chol_ll(ll_top, &ts, 1, master);
+      } else if ((chol_pair_mask() & 8) && d_pair_tickets) {
+        const CholSystem ts = sep_top_system();
+        launch_chol_batch(&ts, 1, sep_ctr, master, nullptr, false, 100, pair_tickets(11));
       } else {
         double* St = sepS + (size_t)TL * NB * ld_s + (size_t)TL * NB;
         for (int k = 0; k < Tt; ++k)
@@ -1188,6 +1205,9 @@ int CholBatch::enqueue_arrow(double* const* d_bufs, int part, hipEvent_t e0, hip
     } else if (ll_top) {
       const CholSystem ts = sep_top_system();
       launch_chol_ll(ll_top, &ts, 1, master);
+    } else if ((chol_pair_mask() & 8) && d_pair_tickets) {
+      const CholSystem ts = sep_top_system();
+      launch_chol_batch(&ts, 1, sep_ctr, master, nullptr, false, 100, pair_tickets(11));
     } else {
       for (int k = 0; k < sep_Ts; ++k)
         launch_chol_step(sepS, ld_s, k, sep_Ts, sep_Ld + (size_t)k * NB * NB, sep_Winv + (size_t)k * 1024, sep_status, sep_ctr, nullptr,
@@ -1507,7 +1527,7 @@ int CholBatch::factor_all(hipEvent_t after) {
   last_groups = groups < 1 ? 1 : groups;
   const bool solve = !exact;
   if (groups < 2) {
-    launch_chol_batch(S_.data(), ns, d_ctr, master, nullptr, solve);
+    launch_chol_batch(S_.data(), ns, d_ctr, master, nullptr, solve, 100, (exact && (chol_pair_mask() & 1)) ? pair_tickets(0) : nullptr);
     if (after) SL_HIP(hipEventRecord(after, master));
     return SLIDE_OK;
   }
@@ -1526,7 +1546,8 @@ int CholBatch::factor_all(hipEvent_t after) {
       st = aux[g];
       SL_HIP(hipStreamWaitEvent(st, ev_aux0, 0));
     }
-    launch_chol_batch(S_.data() + lo, hi - lo, d_ctr + (size_t)g * (ctr_cap / CHOL_BATCH_HOST_MAX), st, nullptr, solve, std::max(25, 100 / groups));
+    launch_chol_batch(S_.data() + lo, hi - lo, d_ctr + (size_t)g * (ctr_cap / CHOL_BATCH_HOST_MAX), st, nullptr, solve, std::max(25, 100 / groups),
+                      (exact && (chol_pair_mask() & 1)) ? pair_tickets(g) : nullptr);
     if (g > 0) {
       SL_HIP(hipEventRecord(ev_aux1[g], st));
       SL_HIP(hipStreamWaitEvent(master, ev_aux1[g], 0));

@@ -206,6 +206,9 @@ class CholBatch {
   std::vector<CholSystem> seg_sys, l2_sys;          // the segments of all joined graphs as systems of their own (views); the second-level systems
   std::vector<int> l2_graph;                        // l2_sys[i] belongs to graphs[l2_graph[i]]
   int* d_ctr2 = nullptr;
+  int* d_pair_tickets = nullptr;                    // 12 x CHOL_STEP_BATCH_MAX ints (zero between launches): the pair kernel's per-system counters — one block per launch sequence
+                                                    // of the segments (8), the second level (8), the leaves (9), the own leaf (10), the top block (11)
+  int* pair_tickets(int block) const { return d_pair_tickets ? d_pair_tickets + block * CHOL_STEP_BATCH_MAX : nullptr; }
   // left-looking persistent factorisations (k_chol_ll): one launch per level instead of one per block column — the segments of all
   // joined graphs, the bands' second level, the separator's leaves (both / the own one of a rank that owns a leaf), its top block.
   // SLIDE_CHOL_LL=0: the step kernels, one launch per block column (round 3's path)

@@ -77,7 +77,8 @@ struct CholSystem { double* S; int ld, T; double* Ld; double* Winv; double* yv; 
                     const int* segtab; };        // device or null (border product of a segmented band): nseg, the segments' end columns, per segment the first column of
                                                  // every border tile row + the right-hand side (1 << 30: the row is zero in that segment)
 constexpr int CHOL_STEP_BATCH_MAX = 32;      // systems per launch of the batched step kernel (the segments of eight robots' bands in one launch sequence)
-void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps = nullptr, bool solve = true, int cu_share = 100);            // up to 8 systems, one launch per block column; solve = false: steps + extraction of y only; cu_share: percent of the CUs this launch sequence may count on (sequences running side by side)
+void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipEvent_t after_steps = nullptr, bool solve = true, int cu_share = 100, int* pair_tickets = nullptr);      // pair_tickets (CHOL_STEP_BATCH_MAX ints, zero, used by no other launch sequence at the same time): two block columns per launch (k_chol_pair_batched) when the systems allow it (chol_pair_supported)
+bool chol_pair_supported(const CholSystem* d, int n);            // up to 8 systems, one launch per block column; solve = false: steps + extraction of y only; cu_share: percent of the CUs this launch sequence may count on (sequences running side by side)
 void launch_chol_bwd_batch(const CholSystem* d, int n, hipStream_t s);       // yv -> dp of up to 8 factored systems (chained backward substitution)
 // Left-looking persistent factorisation (k_chol_ll): ALL block columns of the n systems in ONE launch, the kernel boundary per block
 // column replaced by flags between workgroups that start in ticket order.  The plan (task table, flags, device copies of the systems'

@@ -366,3 +366,27 @@ def frame_detections(log, k):
                 cyl_label=log["cyl_label"][a:b], cube_pose7=log["cube_pose7"][c:d], cube_scale=log["cube_scale"][c:d],
                 cube_label=log["cube_label"][c:d], ell_pose7=log["ell_pose7"][e:f], ell_scale=log["ell_scale"][e:f],
                 ell_label=log["ell_label"][e:f])
+
+
+def assoc_sweep_case(seed: int, n_map: int = 10000, n_obs: int = 20, n_query: int = 5000):
+    """Inputs of the batched association sweep at the headline sizes (BASELINE configs[3]): one resident map of `n_map` point landmarks
+    on the C4 world (440 m x 220 m), `n_query` key frames, each at a uniformly drawn robot position with the `n_obs` NEAREST landmarks
+    detected (5 cm ... 10 cm noise, SURVEY 8d's "all landmarks within reach, nearest 20 kept"), every seventh detection carrying a wrong
+    label and one detection per frame displaced beyond the match threshold.  The parity test (tests/test_gpu_kernels.py::
+    test_assoc_sweep_batch_matches_oracle) and bench.py's association leg draw from this ONE generator: the timed data is the tested data.
+    Returns (cloud f32 [n_map, 3], model f64 [n_map, 3], label i32, qpos [n_query, 3], obs [n_query, n_obs, 3], olab i32 [n_query, n_obs])."""
+    rng = np.random.default_rng(seed)
+    model = np.column_stack([rng.uniform(0, 440, n_map), rng.uniform(0, 220, n_map), rng.normal(0, 0.3, n_map)])
+    cloud = (model + rng.normal(0, 0.05, model.shape)).astype(np.float32)        # first-seen positions differ from the refined models
+    label = rng.integers(1, 7, n_map).astype(np.int32)
+    qpos = np.column_stack([rng.uniform(0, 440, n_query), rng.uniform(0, 220, n_query), np.full(n_query, 2.0)])
+    obs = np.zeros((n_query, n_obs, 3))
+    olab = np.zeros((n_query, n_obs), np.int32)
+    for i in range(n_query):
+        d2 = ((model[:, :2] - qpos[i, :2]) ** 2).sum(1)
+        near = np.argpartition(d2, n_obs)[:n_obs]
+        obs[i] = model[near] + rng.normal(0, 0.1, (n_obs, 3))
+        olab[i] = label[near]
+        olab[i, ::7] = (olab[i, ::7] % 6) + 1                                    # some detections carry the wrong label
+        obs[i, 3] += 5.0                                                         # and one is off by more than the threshold
+    return cloud, model, label, qpos, obs, olab

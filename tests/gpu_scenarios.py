@@ -433,6 +433,37 @@ def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1, re
     json.dump(res, open(out, "w"))
 
 
+def pair_verify(out, preset="C4", relmeas=1):
+    """Diagnostic: ONE un-captured exact joint pass (profile_exact_joint) of the preset's shards with SLIDE_PAIR_VERIFY=1 — every system the
+    pair kernel factors is also factored by the step kernels on a copy and compared tile by tile (stderr)."""
+    import torch
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)
+    import slide_slam_amd as s
+    from slide_slam_amd.distributed import PassDriver, gpu_matcher, setup_local_shards
+    from slide_slam_amd.synth import SynthConfig, make_relmeas, make_robot_log, make_world
+    cfg = SynthConfig.preset(preset)
+    wm = make_world(cfg)
+    R = cfg.robots
+    logs = [make_robot_log(cfg, wm, r) for r in range(R)]
+    A = [s.SlideBackend(s.default_params(**chart_kw(s)), 1) for _ in range(R)]
+    for a, lg in zip(A, logs):
+        ingest(a, lg, s.FRAME_FOREIGN)
+    batch = s.CholBatch(R)
+    for t, a in enumerate(A):
+        a.graph.join_chol_batch(batch, t)
+    bufA, infoA = setup_local_shards(A, gpu_matcher, device=dev)
+    dA = PassDriver(A, bufA, infoA["n_slots"], batch=batch, device=dev, arrow=True, sep_dim=infoA["sep_dim"], sep_prof=infoA.get("sep_prof"))
+    if relmeas:
+        dA.setup_ghosts(make_relmeas(cfg, logs))
+    st, ns = batch.profile_exact_joint(dA.ptrs)
+    say("stages", st, "separator block columns", ns, "pair timeouts", s.pair_timeouts())
+    for a in A:
+        a.graph.join_chol_batch(None)
+    json.dump(dict(stages=st), open(out, "w"))
+
+
 def rank_threads(out, preset="C4", world=8, passes=3, relmeas=0, mode="ingest"):
     """BASELINE configs[3]'s own arrangement on the ONE visible GPU: `world` ranks of cfg.robots / world robots, every rank a thread
     with its own CholBatch (LocalRanks: the TorchComm interface over barriers — the box allows few processes on the card), the pass cut
@@ -496,6 +527,6 @@ def rank_threads(out, preset="C4", world=8, passes=3, relmeas=0, mode="ingest"):
 
 
 if __name__ == "__main__":
-    fn = {"rank_threads": rank_threads, "arrow_parity": arrow_parity, "c4_parity": c4_parity, "c3_joint": c3_joint, "c5_stream": c5_stream, "c3_converge": c3_converge, "c3_assoc_check": c3_assoc_check, "tiny_pcg": tiny_pcg}[sys.argv[1]]
+    fn = {"rank_threads": rank_threads, "pair_verify": pair_verify, "arrow_parity": arrow_parity, "c4_parity": c4_parity, "c3_joint": c3_joint, "c5_stream": c5_stream, "c3_converge": c3_converge, "c3_assoc_check": c3_assoc_check, "tiny_pcg": tiny_pcg}[sys.argv[1]]
     extra = [int(a) if a.lstrip("-").isdigit() else a for a in sys.argv[3:]]
     fn(sys.argv[2], *extra)

@@ -44,6 +44,33 @@ def test_dense_spd_solve_left_looking_persistent(gpu, n):
     assert np.array_equal(x2, x), "the persistent factorisation is not deterministic"
 
 
+@pytest.mark.parametrize("n", [6, 64, 65, 128, 130, 200, 256, 330, 1000, 1990, 3776])   # T = 1, 1, 2, 2, 3, 4, 4, 6, 16, 32, 59: odd and even, the last column alone or in a pair
+def test_dense_spd_solve_two_columns_per_launch(gpu, n):
+    """The pair kernel (k_chol_pair_batched: block columns k, k + 1 in ONE launch; every type-A workgroup carries the sub-diagonal tile
+    and the next diagonal block redundantly, the previous pair's panels as pending panels, one rank-128 pass per launch behind them) vs
+    numpy AND vs the step kernels' result; deterministic; no flag wait gave up."""
+    rng = np.random.default_rng(n)
+    A = _spd(n, rng)
+    b = rng.normal(size=n)
+    x, _ = gpu.dense_spd_solve(A, b, method=2)
+    ref = np.linalg.solve(A, b)
+    assert gpu.pair_timeouts() == 0
+    assert np.linalg.norm(x - ref) <= 1e-9 * np.linalg.norm(ref)
+    x0, _ = gpu.dense_spd_solve(A, b, method=0)
+    assert np.linalg.norm(x - x0) <= 1e-10 * np.linalg.norm(ref)
+    x2, ms = gpu.dense_spd_solve(A, b, repeats=3, method=2)
+    assert np.array_equal(x2, x), "the pair kernel is not deterministic"
+
+
+def test_dense_spd_solve_two_columns_per_launch_rejects_indefinite(gpu):
+    for bad in (40, 100, 140):      # in the first column of a pair, in the second, in a later pair
+        A = np.eye(200)
+        A[bad, bad] = -1.0
+        with pytest.raises(gpu.SlideError):
+            gpu.dense_spd_solve(A, np.ones(200), method=2)
+    assert gpu.pair_timeouts() == 0
+
+
 def test_dense_spd_solve_left_looking_rejects_indefinite(gpu):
     A = np.eye(200)
     A[140, 140] = -1.0
@@ -143,22 +170,11 @@ def test_knn_capacity_error(gpu):
 
 def test_assoc_sweep_batch_matches_oracle(gpu):
     """The batched association sweep at the headline sizes (BASELINE configs[3]: N_map = 10 k, K = 1000, N_obs = 20) over 5000 query
-    frames: identical map indices to the oracle's getSubmap + matchEllipsoidModels per frame."""
-    rng = np.random.default_rng(77)
+    frames: identical map indices to the oracle's getSubmap + matchEllipsoidModels per frame.  Inputs: synth.assoc_sweep_case, the
+    generator of bench.py's association leg (the timed data is the tested data)."""
+    from slide_slam_amd.synth import assoc_sweep_case
     n_map, K, n_obs, n_q = 10000, 1000, 20, 5000
-    model = np.column_stack([rng.uniform(0, 440, n_map), rng.uniform(0, 220, n_map), rng.normal(0, 0.3, n_map)])
-    cloud = (model + rng.normal(0, 0.05, model.shape)).astype(np.float32)        # first-seen positions differ from the refined models
-    label = rng.integers(1, 7, n_map).astype(np.int32)
-    qpos = np.column_stack([rng.uniform(0, 440, n_q), rng.uniform(0, 220, n_q), np.full(n_q, 2.0)])
-    obs = np.zeros((n_q, n_obs, 3)); olab = np.zeros((n_q, n_obs), np.int32)
-    d2 = None
-    for i in range(n_q):
-        d2 = ((model[:, :2] - qpos[i, :2]) ** 2).sum(1)
-        near = np.argpartition(d2, n_obs)[:n_obs]
-        obs[i] = model[near] + rng.normal(0, 0.1, (n_obs, 3))
-        olab[i] = label[near]
-        olab[i, ::7] = (olab[i, ::7] % 6) + 1                                    # some detections carry the wrong label
-        obs[i, 3] += 5.0                                                         # and one is off by more than the threshold
+    cloud, model, label, qpos, obs, olab = assoc_sweep_case(77, n_map, n_obs, n_q)      # the generator bench.py's association leg times
     got, ms = gpu.assoc_sweep_batch(cloud, model, label, qpos, obs, olab, K, 0.75)
     assert got.shape == (n_q, n_obs) and ms > 0
     L = po.lib()
