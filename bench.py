@@ -243,6 +243,203 @@ def assoc_roofline(s, n_map=10000, K=1000, n_obs=20, n_query=8192, repeats=5):
                     "that over the launch time: the leg is bound by the in-CU select / match arithmetic, not by DRAM"}
 
 
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak, public spec (equal to the matrix figure on this part)
+
+
+def _oplace(gp):
+    """The oracle's parameter struct (oracle/place.hpp) filled from the product's."""
+    import ctypes as C
+
+    class OPlace(C.Structure):
+        _fields_ = [("dilation_factor", C.c_double), ("xy_step", C.c_double), ("yaw_half_range", C.c_double), ("yaw_step", C.c_double),
+                    ("match_threshold", C.c_double), ("match_threshold_dimension", C.c_double), ("disable_yaw_search", C.c_int),
+                    ("ignore_dimension", C.c_int), ("min_num_inliers", C.c_int), ("use_lsq", C.c_int),
+                    ("min_num_map_objects_to_start", C.c_int), ("max_rings", C.c_int)]
+    return OPlace(gp.dilation_factor, gp.search_xy_step_size, gp.match_yaw_half_range, gp.search_yaw_step_size, gp.match_threshold_position,
+                  gp.match_threshold_dimension, gp.disable_yaw_search, gp.ignore_dimension, gp.min_num_inliers,
+                  gp.use_nonlinear_least_squares, gp.min_num_map_objects_to_start, gp.max_rings)
+
+
+def place_roofline(s, with_cpu=True):
+    """SlideMatch (PlaceRecognition::MatchMaps, place_recognition.cpp:98-387; SURVEY 8d: pair-tests/s, bound FP64 vector ALU / LDS) on
+    (a) the reference's own indoor maps (clipper_semantic_object/examples/data/robot{0,1}Map_indoor.txt, the fixture of
+    tests/test_gpu_place.py) and (b) a synthetic pair of 792 / 554 objects at the forest parameters (0.5 m, 5 deg, half range ~130 m;
+    the first `rings` rings of the anytime loop).  Kernel time: HIP events around k_place_sweep + k_place_argmax (slide_last_device_ms)."""
+    import ctypes as C
+    from slide_slam_amd import api
+    golden = os.path.join(ROOT, "tests", "golden")
+
+    def load(name):
+        a = np.loadtxt(os.path.join(golden, name))
+        out = np.zeros((a.shape[0], 7))
+        out[:, :4] = a[:, :4]
+        return out
+    cases = {}
+    ref, qry = load("robot0Map_indoor.txt"), load("robot1Map_indoor.txt")
+    for m in (ref, qry):
+        m[:, 1:3] -= m[:, 1:3].mean(axis=0)
+    cases["reference_indoor_maps"] = (ref, qry, dict(ignore_dimension=1, search_yaw_step_size=np.deg2rad(5.0), search_xy_step_size=0.5), 1)
+    rng = np.random.default_rng(792)
+    n = 792
+    big = np.zeros((n, 7))
+    big[:, 0] = rng.integers(1, 4, n)
+    big[:, 1:3] = rng.uniform(-105.0, 105.0, (n, 2))
+    big[:, 3] = rng.normal(0, 0.3, n)
+    big[:, 4:7] = rng.uniform(0.3, 2.0, (n, 3))
+    keep = rng.permutation(n)[: int(0.7 * n)]
+    q = big[keep].copy()
+    yaw, shift = 0.6, np.array([7.5, -4.0])
+    c, sn = np.cos(-yaw), np.sin(-yaw)
+    xy = q[:, 1:3] - shift
+    q[:, 1] = c * xy[:, 0] - sn * xy[:, 1]
+    q[:, 2] = sn * xy[:, 0] + c * xy[:, 1]
+    q[:, 1:3] += rng.normal(0, 0.05, q[:, 1:3].shape)
+    for m in (big, q):
+        m[:, 1:3] -= m[:, 1:3].mean(axis=0)
+    cases["synthetic_forest_792"] = (big, q, dict(ignore_dimension=1, search_yaw_step_size=np.deg2rad(5.0), search_xy_step_size=0.5, max_rings=6), 1)
+    out = {"bound": "fp64_valu", "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "flop_per_pair_test": 10,
+           "kernel": "k_place_sweep (wavefront per (x, y, yaw) candidate, lanes = query objects, reference map in LDS, first-hit break) + k_place_argmax",
+           "note": "pair tests = candidates x query objects x reference objects (an upper bound of the tests executed: a first hit ends a "
+                   "query object's scan; hits are rare away from the true transform); frac prices them at SURVEY 8d's ~10 flops each "
+                   "against the FP64 vector peak (public spec, 78.6 TFLOP/s) — the map is LDS-resident, HBM traffic is negligible"}
+    for name, (r7, q7, kw, _) in cases.items():
+        gp = s.place_default_params(**kw)
+        g = s.match_maps(r7, q7, gp)            # warm
+        g = s.match_maps(r7, q7, gp)
+        ms = api.last_device_ms(api.MS_PLACE_SWEEP)
+        tests = api.last_device_ms(api.MS_PLACE_PAIR_TESTS)
+        d = {"n_ref": int(len(r7)), "n_query": int(len(q7)), "candidates": int(g["candidates"]), "inliers": int(g["inliers"]),
+             "kernel_ms": ms, "pair_tests": tests, "pair_tests_per_s": tests / (ms * 1e-3), "achieved": tests * 10 / (ms * 1e-3) / 1e12}
+        d["frac"] = d["achieved"] / FP64_VALU_PEAK_TFLOPS
+        if with_cpu:
+            from oracle import pyoracle as po
+            kw2 = dict(kw)
+            kw2["max_rings"] = 1                # a bounded sample of the same sweep: its first ring
+            gp1 = s.place_default_params(**kw2)
+            g1 = s.match_maps(r7, q7, gp1)
+            op = _oplace(gp1)
+            best = np.zeros(3)
+            pr, pq = np.full(len(q7), -1, np.int32), np.full(len(q7), -1, np.int32)
+            r7c, q7c = np.ascontiguousarray(r7), np.ascontiguousarray(q7)
+            t0 = time.perf_counter()
+            inl = po.lib().orc_match_maps(r7c.ctypes.data_as(C.c_void_p), C.c_int(len(r7c)), q7c.ctypes.data_as(C.c_void_p), C.c_int(len(q7c)),
+                                          C.byref(op), best.ctypes.data_as(C.c_void_p), pr.ctypes.data_as(C.c_void_p), pq.ctypes.data_as(C.c_void_p))
+            dt = time.perf_counter() - t0
+            t1 = float(g1["candidates"]) * len(q7) * len(r7)
+            d["cpu_baseline"] = {"kind": "port", "cores": 1, "sample": "the first ring of the same sweep (max_rings = 1)", "seconds": dt,
+                                 "pair_tests_per_s": t1 / dt, "same_result_as_gpu": bool(inl == g1["inliers"] and np.array_equal(best, g1["xyyaw"]))}
+        out[name] = d
+    big_case = out["synthetic_forest_792"]
+    out.update({"achieved": big_case["achieved"], "frac": big_case["frac"], "traffic": None})
+    return out
+
+
+def slidegraph_roofline(s, with_cpu=True, m_clipper=4096):
+    """SlideGraph's kernels: triangle matching (semantic_clipper.cpp:49-118: 24 B read per triangle pair), CLIPPER's affinity
+    (clipper.cpp:21-65: m (m - 1) / 2 evaluations) and the projected-gradient solve (clipper.cpp:172-323: nnz * 12 B per product) — kernel
+    times from slide_last_device_ms (HIP events around the launches; the upload of the dense affinity matrix is outside them)."""
+    import ctypes as C
+    from scipy.spatial import Delaunay
+    from slide_slam_amd import api
+    res = {}
+    ocp = None
+    if with_cpu:
+        from oracle import pyoracle as po
+
+        class OCP(C.Structure):
+            _fields_ = [("tol_u", C.c_double), ("tol_F", C.c_double), ("maxiniters", C.c_int), ("maxoliters", C.c_int), ("beta", C.c_double),
+                        ("maxlsiters", C.c_int), ("eps", C.c_double), ("affinityeps", C.c_double), ("rescale_u0", C.c_int), ("sigma", C.c_double),
+                        ("epsilon", C.c_double), ("mindist", C.c_double)]
+        ocp = OCP()
+        po.lib().orc_clipper_default_params(C.byref(ocp))
+        ocp.sigma, ocp.epsilon = 0.1, 0.3
+    # -- triangles: two Delaunay triangulations of 792-point maps (~1570 triangles each, 2.5 M pairs)
+    rng = np.random.default_rng(14)
+    ref = rng.uniform(-105, 105, (792, 2))
+    qry = ref[rng.permutation(792)[:700]] + rng.normal(0, 0.01, (700, 2))
+    tm = ref[Delaunay(ref, qhull_options="Qt Qbb Qc Qz Q12").simplices].astype(np.float64)
+    td = qry[Delaunay(qry, qhull_options="Qt Qbb Qc Qz Q12").simplices].astype(np.float64)
+    s.match_triangles(tm, td, 0.1)
+    pts, diffs = s.match_triangles(tm, td, 0.1)
+    ms = api.last_device_ms(api.MS_TRI_MATCH)
+    pairs = api.last_device_ms(api.MS_TRI_PAIRS)
+    tri = {"bound": "hbm", "kernel": "k_tri_prepare x 2 + k_tri_match (count pass, emit pass)", "model_triangles": int(len(tm)), "data_triangles": int(len(td)),
+           "matched_pairs": int(len(diffs)), "kernel_ms": ms, "triangle_pairs": pairs, "pairs_per_s": pairs / (ms * 1e-3),
+           "achieved": 2 * pairs * 24 / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+           "note": "algorithmic bytes: 24 B (a sorted distance triple) per triangle pair and pass, two passes (count, emit); the triples of both maps "
+                   "(75 KB) are L2-resident: the bound in practice is the compare / ballot work per pair, not DRAM"}
+    tri["frac"] = tri["achieved"] / HBM_PEAK_GBS
+    if with_cpu:
+        from oracle import pyoracle as po
+        sub = tm[:200]
+        tmf, tdf = np.ascontiguousarray(sub.reshape(-1, 6)), np.ascontiguousarray(td.reshape(-1, 6))
+        cap = len(sub) * len(td)
+        op_, od_ = np.zeros((cap, 3, 4)), np.zeros(cap)
+        t0 = time.perf_counter()
+        po.lib().orc_match_triangles(tmf.ctypes.data_as(C.c_void_p), C.c_int(len(sub)), tdf.ctypes.data_as(C.c_void_p), C.c_int(len(td)),
+                                     C.c_double(0.1), op_.ctypes.data_as(C.c_void_p), od_.ctypes.data_as(C.c_void_p), C.c_int(cap))
+        dt = time.perf_counter() - t0
+        tri["cpu_baseline"] = {"kind": "port", "cores": 1, "sample": "the first 200 model triangles against all data triangles", "seconds": dt,
+                               "pairs_per_s": len(sub) * len(td) / dt}
+    res["triangles"] = tri
+    # -- affinity: m putative associations between two point sets (scorePairwiseConsistency)
+    m = m_clipper
+    D1 = rng.uniform(-100, 100, (m, 2))
+    D2 = D1 + rng.normal(0, 0.02, (m, 2))
+    A = np.column_stack([np.arange(m), rng.permutation(m)]).astype(np.int32)
+    A[: m // 8, 1] = A[: m // 8, 0]                                            # an eighth of the associations are true
+    s.clipper_affinity(D1, D2, A, sigma=0.1, epsilon=0.3)
+    M = s.clipper_affinity(D1, D2, A, sigma=0.1, epsilon=0.3)
+    ms = api.last_device_ms(api.MS_AFFINITY)
+    evals = m * (m - 1) / 2
+    aff = {"bound": "fp64_valu", "kernel": "k_clipper_affinity (one thread per association pair)", "m": m, "kernel_ms": ms, "evaluations": evals,
+           "evaluations_per_s": evals / (ms * 1e-3), "achieved": evals * 64 / (ms * 1e-3) / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": None,
+           "note": "SURVEY 8d charges 64 B per evaluation if the four points were streamed; the two point sets (64 KB) are cache-resident and "
+                   "the m x m dense result (128 MB at m = 4096) is what moves: 8 B written per evaluation"}
+    aff["frac"] = aff["achieved"] / HBM_PEAK_GBS
+    if with_cpu:
+        from oracle import pyoracle as po
+        mc = 1024
+        Ac = np.ascontiguousarray(A[:mc])
+        Mo = np.zeros((mc, mc))
+        opar = po.lib()
+        D1c, D2c = np.ascontiguousarray(D1), np.ascontiguousarray(D2)
+        t0 = time.perf_counter()
+        opar.orc_clipper_affinity(D1c.ctypes.data_as(C.c_void_p), C.c_int(m), D2c.ctypes.data_as(C.c_void_p), C.c_int(m), C.c_int(2),
+                                  Ac.ctypes.data_as(C.c_void_p), C.c_int(mc), C.byref(ocp), Mo.ctypes.data_as(C.c_void_p))
+        dt = time.perf_counter() - t0
+        aff["cpu_baseline"] = {"kind": "port", "cores": 1, "sample": "the first 1024 associations (523 776 evaluations)", "seconds": dt,
+                               "evaluations_per_s": mc * (mc - 1) / 2 / dt}
+    res["affinity"] = aff
+    # -- dense clique: the whole projected-gradient solve on the device (cooperative multi-workgroup solve at m >= 1024)
+    u0 = rng.uniform(0, 1, m)
+    p = s.clipper_params(sigma=0.1, epsilon=0.3)
+    s.clipper_dense_clique(M, u0, p)
+    nodes, u, score = s.clipper_dense_clique(M, u0, p)
+    ms_solve, ms_csr = api.last_device_ms(api.MS_CLQ_SOLVE), api.last_device_ms(api.MS_CLQ_CSR)
+    nnz = api.last_device_ms(api.MS_CLQ_NNZ)
+    wgs, evals_g = s.clipper_last_solve_info()
+    clq = {"bound": "hbm", "kernel": "k_clq_solve_coop" if wgs > 1 else "k_clq_solve", "m": m, "nnz": nnz, "workgroups": int(wgs), "gradient_evaluations": evals_g,
+           "clique_size": int(len(nodes)), "solve_ms": ms_solve, "csr_build_ms": ms_csr, "us_per_product": ms_solve * 1e3 / max(evals_g, 1.0),
+           "achieved": nnz * 12 * evals_g / (ms_solve * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+           "note": "algorithmic bytes: nnz * 12 B (value + column index) per sparse product, one product per gradient evaluation; the CSR "
+                   "(%.1f MB) is L2-resident and every evaluation ends in a grid barrier: the solve is latency-bound, not DRAM-bound.  The dense "
+                   "128 MB affinity matrix is uploaded by the stand-alone entry point; the upload is outside both timers" % (nnz * 12 / 1e6)}
+    clq["frac"] = clq["achieved"] / HBM_PEAK_GBS
+    if with_cpu:
+        from oracle import pyoracle as po
+        on, ou, osc = np.zeros(m, np.int32), np.zeros(m), C.c_double(0)
+        Mc = np.ascontiguousarray(M)
+        t0 = time.perf_counter()
+        n_o = po.lib().orc_clipper_solve(Mc.ctypes.data_as(C.c_void_p), C.c_int(m), u0.ctypes.data_as(C.c_void_p), C.byref(ocp),
+                                         on.ctypes.data_as(C.c_void_p), ou.ctypes.data_as(C.c_void_p), C.byref(osc))
+        dt = time.perf_counter() - t0
+        clq["cpu_baseline"] = {"kind": "port", "cores": 1, "sample": "the same problem from the same start (dense-to-sparse conversion included)", "seconds": dt,
+                               "same_clique_as_gpu": bool(sorted(on[:n_o].tolist()) == sorted(nodes.tolist()))}
+    res["clipper"] = clq
+    return res
+
+
 def _pmc_traffic(kernel, **match):
     """HBM-side bytes per launch of `kernel` from the committed PMC summaries (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     passes, gfx950 corrections applied; a PMC pass cannot run inside the timed bench): newest round first."""
@@ -369,6 +566,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the un-batched re-run and the convergence probe")
     ap.add_argument("--ingest-only", action="store_true", help="build the graph without per-frame solves (profiling aid)")
+    ap.add_argument("--no-place-leg", action="store_true", help="skip the SlideMatch / SlideGraph / CLIPPER legs of the roofline")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the dense-profile legs of the roofline (rocprofv3 runs of the default)")
     ap.add_argument("--dense-profile", action="store_true",
                     help="the whole run on the dense profile (every tile of the lower triangle): the configuration of roofline.dense_profile, "
@@ -941,6 +1139,16 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
         res["roofline"]["assoc"] = assoc_roofline(s)
     except Exception as e:      # noqa: BLE001  (the headline number stands on its own)
         res["roofline"]["assoc"] = {"error": repr(e)}
+    if rank == 0 and not getattr(args, "no_place_leg", False):
+        # A13 - A15 (SlideMatch sweep, SlideGraph triangle matching, CLIPPER): the kernels' own legs, the oracle timed beside them
+        try:
+            res["roofline"]["place"] = place_roofline(s, with_cpu=not args.no_cpu)
+        except Exception as e:      # noqa: BLE001
+            res["roofline"]["place"] = {"error": repr(e)}
+        try:
+            res["roofline"].update(slidegraph_roofline(s, with_cpu=not args.no_cpu))
+        except Exception as e:      # noqa: BLE001
+            res["roofline"]["clipper"] = {"error": repr(e)}
     if not args.no_cpu:
         try:
             from slide_slam_amd.synth import make_robot_log, make_world

@@ -215,6 +215,13 @@ int orc_backend_landmark_table(void* h, int cls, double* xyz, int* label, int ca
 }
 // force a full relinearisation on the next solve (batch Gauss-Newton mode = threshold 0)
 void orc_graph_set_relin_threshold(void* h, double thr) { ((Graph*)h)->P.relin_threshold = thr; }
+// [GTSAM] iSAM2's wildfire threshold on the back-substitution (Graph::wildfire_bound); 0 = off (the default); out3: blocks kept in
+// total, in the last solve, the last solve's first dirty block column
+void orc_graph_set_wildfire(void* h, double thr) { ((Graph*)h)->P.wildfire_threshold = thr > 0.0 ? thr : 0.0; }
+void orc_graph_wildfire_stats(void* h, long long* out3) {
+  const Graph* g = (const Graph*)h;
+  out3[0] = g->wf_kept_total; out3[1] = g->wf_kept_last; out3[2] = g->wf_last_cd;
+}
 
 // ---- association primitives ------------------------------------------------------------------
 // Self-check of the profile-restricted Cholesky (graph.hpp chol_profile): solves A x = b for a row-major SPD matrix (lower triangle

@@ -15,8 +15,10 @@
 //   |delta|_inf >= relinearizeThreshold (0.1) gets theta <- theta (+) delta; (3) because
 //   cached linearisations are only reused for factors none of whose variables moved, the
 //   linear system is J(theta) d = -r(theta) over ALL factors; it is solved exactly (the
-//   reference's multifrontal Cholesky is exact too; its 1e-3 wildfire cut-off on the
-//   back-substitution is NOT restated — documented deviation); (4) estimate = theta (+) delta.
+//   reference's multifrontal Cholesky is exact too); (3b) [GTSAM] iSAM2's WILDFIRE cut-off on the back-substitution
+//   (ISAM2GaussNewtonParams::wildfireThreshold, 1e-3 in GTSAM 4.0.3: a clique is not re-solved when its parents' delta changed by
+//   less than the threshold) restated on the 64-column block chain of the reduced pose system — Graph::wildfire_bound below; OFF
+//   by default (GraphParams::wildfire_threshold = 0: every fixture and parity test compares exact updates); (4) estimate = theta (+) delta.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -66,6 +68,7 @@ struct GraphParams {
 #endif
   double numdiff_delta = ORC_NUMDIFF_DELTA;       // 1e-6: cubeFactor.cpp:43,48 ; cylinderFactor.cpp:41,46
   int num_threads = 1;
+  double wildfire_threshold = 0.0;   // [GTSAM] ISAM2GaussNewtonParams::wildfireThreshold (1e-3 in the reference's build); 0 = exact back-substitution
 };
 
 inline Pose var_pose(const Var& v) {
@@ -591,6 +594,19 @@ class Graph {
   // graph.cpp:260-272
   int solve();
 
+  // ---- [GTSAM] bounded back-substitution (iSAM2's wildfire threshold; graph.cpp:15-18, 260-272) ------------------------------------
+  // State the rule needs across solves: the pose index of every variable, the first (lowest) pose observing a landmark, the lowest
+  // pose touched by the factors merged since the last solve, and the last solve's reduced solution.
+  std::vector<int> wf_pose_idx;        // variable -> pose index (order of insertion among the poses) or -1
+  std::vector<int> wf_lm_first;        // variable -> lowest pose index observing the landmark (1 << 30: none yet)
+  int wf_np = 0;
+  int wf_dirty_min_pose = 1 << 30;     // lowest pose whose blocks of the reduced system the merged factors / relinearisations change
+  std::vector<double> wf_prev;         // the last solve's dp, padded with zeros to whole 64-blocks
+  int wf_Tprev = 0;                    // its block count (0: no previous solution)
+  long long wf_kept_total = 0;
+  int wf_kept_last = 0, wf_last_cd = -1;
+  void wildfire_bound(std::vector<double>& dp, int n, const struct CholProfile& prof);
+
   // ---- one-robot-per-rank restatement of the distributed Gauss-Newton pass (checker of the multi-GPU path;
   // the reference has no such mode: every sloam_node holds a full replica) ---------------------
   std::vector<int> sh_var, sh_owner;   // slot -> variable id (or -1), owner flag
@@ -713,6 +729,8 @@ inline void Graph::merge_pending() {
     key2var[pend_keys[i]] = (int)vars.size();
     var_keys.push_back(pend_keys[i]);
     vars.push_back(v);
+    wf_pose_idx.push_back(v.type == V_POSE ? wf_np++ : -1);
+    wf_lm_first.push_back(1 << 30);
   }
   for (size_t i = 0; i < pend_factors.size(); ++i) {
     Factor f = pend_factors[i];
@@ -727,6 +745,15 @@ inline void Graph::merge_pending() {
       if (b == key2var.end()) continue;
       f.v1 = b->second;
     }
+    // (wildfire rule) the lowest pose whose blocks of the reduced system this factor changes: its pose(s); for a landmark factor
+    // also the first pose that observes the landmark — a new factor changes H_ll, which enters the Schur terms of EVERY observer
+    const int p0 = wf_pose_idx[f.v0];
+    wf_dirty_min_pose = std::min(wf_dirty_min_pose, p0);
+    if (f.type == F_BETWEEN) wf_dirty_min_pose = std::min(wf_dirty_min_pose, wf_pose_idx[f.v1]);
+    else if (f.type == F_BR || f.type == F_CUBE || f.type == F_CYL) {
+      wf_dirty_min_pose = std::min(wf_dirty_min_pose, wf_lm_first[f.v1]);
+      wf_lm_first[f.v1] = std::min(wf_lm_first[f.v1], p0);
+    }
     factors.push_back(f);
   }
   pend_vars.clear(); pend_keys.clear(); pend_factors.clear(); pend_fk0.clear(); pend_fk1.clear();
@@ -738,7 +765,9 @@ inline int Graph::solve() {
 
   // (2) relinearisation  [GTSAM CheckRelinearizationFull: maxDelta >= threshold]
   stats = SolveStats();
-  for (auto& v : vars) {
+  std::vector<char> wf_moved;      // (wildfire rule) the variables that were relinearised
+  for (size_t vi = 0; vi < vars.size(); ++vi) {
+    Var& v = vars[vi];
     const int d = var_dim(v.type);
     double mx = 0.0;
     for (int k = 0; k < d; ++k) mx = std::max(mx, std::fabs(v.delta[k]));
@@ -747,6 +776,24 @@ inline int Graph::solve() {
       var_retract(v, v.delta, P.pose_chart, nv);
       std::memcpy(v.val, nv.val, sizeof(v.val));
       ++stats.n_relin;
+      if (P.wildfire_threshold > 0.0) {
+        if (wf_moved.empty()) wf_moved.assign(vars.size(), 0);
+        wf_moved[vi] = 1;
+      }
+    }
+  }
+  if (!wf_moved.empty()) {
+    // a relinearised landmark changes the blocks of all its observers: from its first one on; a relinearised pose its own, those of
+    // its relative-pose partners and of every pose observing one of its landmarks
+    for (size_t vi = 0; vi < vars.size(); ++vi)
+      if (wf_moved[vi]) wf_dirty_min_pose = std::min(wf_dirty_min_pose, vars[vi].type == V_POSE ? wf_pose_idx[vi] : wf_lm_first[vi]);
+    for (const Factor& f : factors) {
+      if (f.type == F_BETWEEN) {
+        if (wf_moved[f.v0]) wf_dirty_min_pose = std::min(wf_dirty_min_pose, wf_pose_idx[f.v1]);
+        if (wf_moved[f.v1]) wf_dirty_min_pose = std::min(wf_dirty_min_pose, wf_pose_idx[f.v0]);
+      } else if ((f.type == F_BR || f.type == F_CUBE || f.type == F_CYL) && wf_moved[f.v0]) {
+        wf_dirty_min_pose = std::min(wf_dirty_min_pose, wf_lm_first[f.v1]);
+      }
     }
   }
 
@@ -883,6 +930,7 @@ inline int Graph::solve() {
   std::vector<double> dp(n);
   for (int i = 0; i < n; ++i) dp[i] = -g[i];
   chol_solve_lower(S.data(), n, n, dp.data(), &prof);
+  wildfire_bound(dp, n, prof);
   const double t3 = now_sec();
   if (keep_factor) { last_L = S; last_n = n; last_pidx = pidx; }   // for getPoseCovariance (test sizes only: n^2 doubles)
   for (int p = 0; p < np; ++p)
@@ -919,6 +967,51 @@ inline int Graph::solve() {
   const double t4 = now_sec();
   stats.t_linearize = t1 - t0; stats.t_schur = t2 - t1; stats.t_chol = t3 - t2; stats.t_total = t4 - t0;
   return 0;
+}
+
+// [GTSAM] iSAM2's wildfire cut-off (ISAM2::update + calculateEstimate, graph.cpp:260-272; threshold 1e-3 in GTSAM 4.0.3) on the block
+// chain of the reduced pose system, as the product states it (slide_graph_set_wildfire; chol_kernels.hip bwd_chain_body<.., true>):
+// T = ceil(n / 64) blocks of 64 coordinates; block c's solution depends, through L^T x = y, on the blocks c+1 .. prof[c] (prof: the
+// monotone tile profile of the factor).  Below the first DIRTY block column c_d = floor(6 p_min / 64) — p_min the lowest pose whose
+// blocks the factors merged since the last solve or this solve's relinearisations change — a block's factor column and
+// forward-substituted right-hand side are the last solve's, so its solution moves only through the blocks it depends on: the HIGHEST
+// block c < min(T_prev, c_d) all of whose dependencies changed by less than the threshold (infinity norm over the block, against the
+// last solve's values; a block without a previous value counts as changed; a block without dependencies is always re-solved) keeps
+// the last solve's solution, and so does everything below it (the profile is monotone).  dp comes in as the exact solution.
+inline void Graph::wildfire_bound(std::vector<double>& dp, int n, const CholProfile& prof) {
+  const int NB = 64;
+  const int T = (n + NB - 1) / NB;
+  const double thr = P.wildfire_threshold;
+  wf_kept_last = 0;
+  const int np = n / 6;
+  const int pmin = wf_dirty_min_pose;
+  const int c_d = pmin >= np ? T : std::min(T, (6 * std::max(pmin, 0)) / NB);
+  wf_last_cd = c_d;
+  if (thr > 0.0 && wf_Tprev > 0 && c_d > 0) {
+    const int lim = std::min(std::min(wf_Tprev, c_d), T);
+    auto val = [&](const std::vector<double>& v, int i) { return i < (int)v.size() ? v[i] : 0.0; };
+    int stop = -1;
+    for (int c = lim - 1; c >= 0 && stop < 0; --c) {
+      const int last = (prof.rend[c] - 1) / NB;      // prof[c]: the last block row inside the profile of block column c
+      if (last <= c) continue;
+      bool quiet = true;
+      for (int j = c + 1; j <= last && quiet; ++j) {
+        if (j >= wf_Tprev) { quiet = false; break; }
+        for (int k = 0; k < NB; ++k)
+          if (!(std::fabs(val(dp, j * NB + k) - val(wf_prev, j * NB + k)) < thr)) { quiet = false; break; }
+      }
+      if (quiet) stop = c;
+    }
+    if (stop >= 0) {
+      for (int i = 0; i < (stop + 1) * NB && i < n; ++i) dp[i] = val(wf_prev, i);
+      wf_kept_last = stop + 1;
+      wf_kept_total += stop + 1;
+    }
+  }
+  wf_prev.assign((size_t)T * NB, 0.0);
+  for (int i = 0; i < n; ++i) wf_prev[i] = dp[i];
+  wf_Tprev = T;
+  wf_dirty_min_pose = 1 << 30;
 }
 
 inline int Graph::set_shared(const int* cls, const int64_t* idx, const int* owner, int n) {

@@ -157,6 +157,15 @@ class OracleGraph:
     def set_relin_threshold(self, thr):
         self.L.orc_graph_set_relin_threshold(self.h, C.c_double(thr))
 
+    def set_wildfire(self, thr):
+        """[GTSAM] iSAM2's wildfire threshold on the back-substitution (1e-3 in the reference's build); 0 = exact (default)."""
+        self.L.orc_graph_set_wildfire(self.h, C.c_double(thr))
+
+    def wildfire_stats(self):
+        out = (C.c_longlong * 3)()
+        self.L.orc_graph_wildfire_stats(self.h, out)
+        return dict(kept_total=int(out[0]), kept_last=int(out[1]), last_cd=int(out[2]))
+
     def get_pose(self, robot, idx):
         out = np.zeros(7)
         st = self.L.orc_graph_get_pose(self.h, C.c_int(robot), C.c_uint64(idx), _p(out))

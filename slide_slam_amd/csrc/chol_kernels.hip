@@ -2054,14 +2054,18 @@ struct alignas(16) ChainLds {     // one per workgroup, shared by every instanti
 // the threshold; on the block chain of the banded reduced system: block c keeps the solution of the LAST solve (wf_prev) when every
 // block it depends on (c+1 .. prof[c]) changed by less than wf_thr in the infinity norm — and, the profile being monotone, so does
 // every block below it: the first such block (walking down) raises the stop word (status[7]) and all workgroups below leave with their
-// previous values at once instead of passing the chain on hop by hop.  wf_Tprev: blocks >= it have no previous value (new key frames).
+// previous values at once instead of passing the chain on hop by hop.  wf_Tprev: blocks >= it have no previous value (new key frames);
+// wf_lim (<= wf_Tprev): the first DIRTY block column — only blocks below it may keep their value; the re-factored blocks above it are
+// always solved, and their change against the last solve counts like any other dependency's (round 5: they used to count as changed
+// whatever they did, which kept the first blocks below the dirty column from ever being quiet; ISAM2's rule compares the re-eliminated
+// cliques' new delta with the old one too).
 // status[3] counts the blocks that were kept.  Off (the default): the chain always runs in full — the linear system is solved exactly.
 template <bool F32, bool WFIRE = false>
 __device__ __forceinline__ void bwd_chain_body(ChainLds& W, const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
                                                const double* __restrict__ Winv, const double* __restrict__ yv, double* dp, int* status, int bidx,
                                                const float* __restrict__ L32, const int* __restrict__ prof,
                                                const double* __restrict__ wf_prev = nullptr, double wf_thr = 0.0, int wf_Tprev = 0,
-                                               int* wf_lds = nullptr) {
+                                               int* wf_lds = nullptr, int wf_lim = 0) {
   int dummy_state = 0;
   int& wf_state = WFIRE ? *wf_lds : dummy_state;      // (LDS word of the bounded kernel) 0: compute, 1: a block above raised the stop word, 2: all inputs quiet (this block raises it)
   auto& Ms = W.Ms; auto& Lo = W.Lo; auto& Ws = W.Ws; auto& tmp = W.tmp; auto& xs = W.xs; auto& ys = W.ys;
@@ -2150,7 +2154,7 @@ __device__ __forceinline__ void bwd_chain_body(ChainLds& W, const double* __rest
 #pragma unroll
   for (int r = 0; r < 16; ++r) mreg[r] = (worker && 16 * part + r >= col) ? Ms[16 * part + r][col] : 0.0;
   double acc = 0.0;
-  bool wf_quiet = WFIRE && nj > 0 && c < wf_Tprev;      // (polling wave: every block this one depends on changed by less than the threshold, so far)
+  bool wf_quiet = WFIRE && nj > 0 && c < wf_lim;      // (only a block below the first dirty column may keep its value: wf_lim <= wf_Tprev)      // (polling wave: every block this one depends on changed by less than the threshold, so far)
   bool wf_leave = false;
   CSTAMP(1);
   for (int q0 = 0; q0 < nj && !wf_leave; q0 += RB) {
@@ -2246,12 +2250,12 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chol_bwd_chain(const double* 
 // the bounded variant (streaming updates with a wildfire threshold; status[7] = stop word, status[3] = blocks kept, both 0 before)
 __global__ __launch_bounds__(CHAIN_THREADS) void k_chol_bwd_chain_wf(const double* __restrict__ S, int ld, int T, const double* __restrict__ Ld,
                                                            const double* __restrict__ Winv, const double* __restrict__ yv, double* dp, int* status,
-                                                           const int* __restrict__ prof, const double* __restrict__ prev, double thr, int Tprev) {
+                                                           const int* __restrict__ prof, const double* __restrict__ prev, double thr, int Tprev, int lim) {
   __shared__ ChainLds W;
   __shared__ int s_wf;
   const int t = bwd_ticket(&status[4]);
   if (t >= T) return;
-  bwd_chain_body<false, true>(W, S, ld, T, Ld, Winv, yv, dp, status, t, nullptr, prof, prev, thr, Tprev, &s_wf);
+  bwd_chain_body<false, true>(W, S, ld, T, Ld, Winv, yv, dp, status, t, nullptr, prof, prev, thr, Tprev, &s_wf, lim);
 }
 constexpr int BWD_BATCH_MAX = 32;     // systems per batched backward substitution (the segments of eight robots' bands: up to 32)
 struct BwdBatchArgs {
@@ -2987,7 +2991,7 @@ void launch_border_apply(const CholSystem* d, int n, const double* const* xloc, 
 // from then on every launch k takes the one pending panel k-1 in its column, even launches start the rank-128 pass of panels
 // k-2, k-1 over the trailing matrix, odd launches finish the pass their predecessor started and bring column k+1 up to panel k-1.
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp,
-                         int* status, const int* prof, hipStream_t s, const double* wf_prev, double wf_thr, int wf_Tprev);
+                         int* status, const int* prof, hipStream_t s, const double* wf_prev, double wf_thr, int wf_Tprev, int wf_lim);
 void launch_chol_extract_y(const double* S, int ld, int T, double* yv, double* dp, int* status, hipStream_t s, int nbr, int b0, double* prev) {
   hipLaunchKernelGGL(k_chol_extract_y, dim3((T * NB + 255) / 256), dim3(256), 0, s, S, ld, T, (b0 > 0 ? b0 : T) + nbr, yv, dp, status, prev);
 }
@@ -3269,9 +3273,10 @@ void launch_chol_solve_bwd(const CholSystem& cs, hipStream_t s) {
   launch_chol_bwd_all(cs.S, cs.ld, cs.T, cs.Ld, cs.Winv, cs.yv, cs.dp, cs.status, cs.prof, s);
 }
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp,
-                         int* status, const int* prof, hipStream_t s, const double* wf_prev, double wf_thr, int wf_Tprev) {
-  if (wf_prev && wf_thr > 0.0 && wf_Tprev > 0)
-    hipLaunchKernelGGL(k_chol_bwd_chain_wf, dim3(T), dim3(CHAIN_THREADS), 0, s, S, ld, T, Ld, Winv, yv, dp, status, prof, wf_prev, wf_thr, wf_Tprev);
+                         int* status, const int* prof, hipStream_t s, const double* wf_prev, double wf_thr, int wf_Tprev, int wf_lim) {
+  if (wf_lim < 0 || wf_lim > wf_Tprev) wf_lim = wf_Tprev;
+  if (wf_prev && wf_thr > 0.0 && wf_Tprev > 0 && wf_lim > 0)
+    hipLaunchKernelGGL(k_chol_bwd_chain_wf, dim3(T), dim3(CHAIN_THREADS), 0, s, S, ld, T, Ld, Winv, yv, dp, status, prof, wf_prev, wf_thr, wf_Tprev, wf_lim);
   else
     hipLaunchKernelGGL(k_chol_bwd_chain, dim3(T), dim3(CHAIN_THREADS), 0, s, S, ld, T, Ld, Winv, yv, dp, status, prof);
 }

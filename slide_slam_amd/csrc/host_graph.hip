@@ -2115,9 +2115,9 @@ int HostGraph::upload_new() {
     if (d_Winv.ensure((size_t)Tcap * 1024, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_cctr.ensure((size_t)Tcap + 2, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_yv.ensure((size_t)Tcap * NB, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
-    if (d_dp.ensure((size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+    // (the last solve's solution survives the re-allocation: the bounded back-substitution compares against it)
+    if (d_dp.ensure((size_t)Tcap * NB, std::min(d_dp.cap, (size_t)std::max(wf_T, 0) * NB), s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
     if (d_dp_prev.ensure((size_t)Tcap * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
-    wf_T = 0;                // (the last solve's solution did not survive the re-allocation)
     joint_Tcap = 0;      // (the joint-solve buffers follow S's leading dimension)
   }
   // Buffers of the joint solve (the saved system, the f32 factor copy, the chain tables): only for graphs that take part in one —
@@ -2325,7 +2325,8 @@ int HostGraph::sync_lm_slot() {
   return SLIDE_OK;
 }
 
-int HostGraph::enqueue_iteration(bool lookahead, bool skip_relin, int c_d) {
+int HostGraph::enqueue_iteration(bool lookahead, bool skip_relin, int c_d, int wf_cd) {
+  if (wf_cd < 0) wf_cd = c_d;
   hipStream_t s = stream;
   static const char* kNames[] = {"relin", "linearize", "landmark_reduce", "pose_reduce", "schur_assemble", "chol_step",
                                  "chol_catchup", "chol_extract_y", "chol_bwd", "backsub", "estimate"};
@@ -2361,10 +2362,12 @@ int HostGraph::enqueue_iteration(bool lookahead, bool skip_relin, int c_d) {
   // bounded back-substitution (iSAM2's wildfire threshold; set_wildfire): on an incremental update only, and only below the first
   // re-factored block column — there a block's factor column and forward-substituted right-hand side are the last solve's, so its
   // solution moves only through the blocks above it (bwd_chain_body<.., true>)
-  const int wf_Tp = (skip_relin && wildfire_thr > 0.0 && c_d > 0) ? std::min(std::min(wf_T, c_d), G.T) : 0;
+  // (wf_cd: the first DIRTY block column; it is c_d on an incremental update, and also bounds the substitution of an update that has
+  // to re-factor everything — after a re-allocation of S — although nothing below it changed)
+  const int wf_Tp = (skip_relin && wildfire_thr > 0.0 && wf_cd > 0) ? std::min(std::min(wf_T, wf_cd), G.T) : 0;
   if (wf_Tp > 0) {
     STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, G.status, s, 0, 0, d_dp_prev.d));
-    STAGE(8, launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, G.prof, s, d_dp_prev.d, wildfire_thr, wf_Tp));
+    STAGE(8, launch_chol_bwd_all(G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, G.prof, s, d_dp_prev.d, wildfire_thr, std::min(wf_T, G.T), wf_Tp));
   } else {
     STAGE(7, launch_chol_extract_y(G.S, G.ld, G.T, G.yv, G.dp, G.status, s));
     STAGE(8, launch_chol_solve_bwd(CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, nullptr, h_prof.data(), G.prof, G.first, d_ctab.d}, s));
@@ -2430,6 +2433,21 @@ int HostGraph::run_update(double relin_thr, int iterations) {
     if (rc != SLIDE_OK) return rc;
     if (c_d > 0) ++n_inc; else ++n_full;
     last_cd = c_d;
+  } else if (env_inc && wildfire_thr > 0.0 && iterations == 1 && !use_graph && !batch && !force_dense && wf_T > 0 && relin_thr > 0.0) {
+    // an update that cannot keep any factor column (S was re-allocated, the system is still tiny, ...) but has a previous solution:
+    // everything is re-factored, the back-substitution is bounded below the first dirty block column all the same (the rule of
+    // bwd_chain_body<.., true> does not care who recomputed the unchanged columns)
+    launch_relin(G, s);
+    int s0[8];
+    SL_HIP(hipMemcpyAsync(s0, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    int pmin = dirty_min_pose;
+    if (s0[6] > 0) pmin = std::min(pmin, G.P - s0[6]);
+    const int cd = std::min(pmin >= G.P ? G.T : (6 * std::max(pmin, 0)) / NB, G.T);
+    const int rc = enqueue_iteration(false, true, 0, cd);
+    if (rc != SLIDE_OK) return rc;
+    ++n_full;
+    last_cd = 0;
   } else {
     for (int it = 0; it < iterations; ++it) {
       if (use_graph) SL_HIP(hipGraphLaunch(gexec, s));

@@ -363,7 +363,7 @@ class HostGraph {
   int64_t n_rejected = 0;                 // factors / variables refused by merge_pending since creation (slide_graph_stats)
   int upload_new();
   int run_update(double relin_thr, int iterations);
-  int enqueue_iteration(bool lookahead, bool skip_relin = false, int c_d = 0);      // one GN / iSAM2-equivalent pass on `stream`; c_d > 0: block columns below it keep their factor
+  int enqueue_iteration(bool lookahead, bool skip_relin = false, int c_d = 0, int wf_cd = -1);      // one GN / iSAM2-equivalent pass on `stream`; c_d > 0: block columns below it keep their factor
   // Incremental re-factorisation (iSAM2's "re-eliminate only the affected top of the tree", graph.cpp:260-272): the lowest pose whose
   // rows of the reduced system the factors merged since the last solve change; the generation of S the resident factor belongs to
   int dirty_min_pose = 1 << 30;

@@ -101,7 +101,7 @@ void launch_chain_batch(const CholSystem* d, int n, const double* const* in, dou
                         double* const* next_out, hipStream_t s);   // needs the tables (launch_chain_tables) of this factorisation
 void launch_chain_tables(const CholSystem* d, int n, hipStream_t s);
 void launch_chol_bwd_all(const double* S, int ld, int T, const double* Ld, const double* Winv, double* yv, double* dp, int* status, const int* prof, hipStream_t s,
-                         const double* wf_prev = nullptr, double wf_thr = 0.0, int wf_Tprev = 0);      // wf_*: iSAM2's wildfire bound (bwd_chain_body): blocks whose inputs changed by < wf_thr keep wf_prev; status[7] / status[3] must be 0
+                         const double* wf_prev = nullptr, double wf_thr = 0.0, int wf_Tprev = 0, int wf_lim = -1);      // wf_*: iSAM2's wildfire bound (bwd_chain_body): blocks whose inputs changed by < wf_thr keep wf_prev; status[7] / status[3] must be 0
 // marginal covariance of the pose whose first tangent row is row0 (Y: 6 * T * NB scratch doubles holding the six unit columns)
 void launch_pose_covariance(const double* S, int ld, int T, const double* Ld, const double* Winv, double* Y, int row0, double* cov36,
                             hipStream_t s);
