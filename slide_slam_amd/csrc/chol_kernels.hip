@@ -2714,6 +2714,7 @@ struct SyrkArgs {
   const double* S[CHOL_BATCH_MAX]; int ld[CHOL_BATCH_MAX]; int T[CHOL_BATCH_MAX]; int nbr[CHOL_BATCH_MAX];
   int b0[CHOL_BATCH_MAX];              // tile row of the first border row (T, or CholSystem::b0 for a view that covers a range of the columns only)
   double* bord[CHOL_BATCH_MAX]; int ldb[CHOL_BATCH_MAX]; const int* bfirst[CHOL_BATCH_MAX];
+  const double* bsrc[CHOL_BATCH_MAX];  // or null: where the tiles' values before the product are read (CholSystem::bord_src); null: bord itself
   int ks; double* scratch;
   size_t scratch_stride;     // split K with two systems in one launch: system r's partial tiles start at scratch + r * scratch_stride
   int ks_sys[2];             // ... and each may have its own number of chunks (0: ks) — a leaf's product is cut the way a rank owning that leaf cuts it
@@ -2744,15 +2745,18 @@ __device__ __forceinline__ void border_syrk_body(const SyrkArgs& A) {
     c0 += q * len;
     c1 = min(T, c0 + len);
   }
-  if (!st && c0 >= c1) return;
+  const double* bsrc = A.bsrc[r];
+  if (!st && c0 >= c1 && !(bsrc && q == 0)) return;      // (nothing to sum; with a separate source the tile is still copied)
   const double* S = A.S[r];
   const int wq = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
   const int ch = (wq >> 1) & 1, rh = wq & 1;      // column half, row half of the tile
-  if (A.jobs && ib == nbr && rh == 1) return;     // right-hand-side row tile: only its first row is in use (the others are zero and stay zero)
+  if (A.jobs && ib == nbr && rh == 1 && !bsrc) return;     // right-hand-side row tile: only its first row is in use (the others are zero and stay zero)
   const int B0 = A.b0[r];
   const double* pj0 = S + (size_t)lk * ld + (size_t)(B0 + jb) * NB + 32 * ch + 2 * lr;
   const double* pi0 = S + (size_t)lk * ld + (size_t)(B0 + ib) * NB + 32 * rh + 2 * lr;
   double* cbh = A.bord[r] + (size_t)(jb * NB + 32 * ch + 2 * lk) * ldb + (size_t)ib * NB + 32 * rh + 2 * lr;
+  const double* cin = bsrc ? bsrc + (size_t)(jb * NB + 32 * ch + 2 * lk) * ldb + (size_t)ib * NB + 32 * rh + 2 * lr : cbh;
+  const int ldin = ldb;
   if (q > 0) {       // partial of a later chunk: a 64 x 64 scratch tile (leading dimension NB)
     ldb = NB;
     cbh = A.scratch + (size_t)r * A.scratch_stride + ((size_t)(jb * (nbr + 1) + ib) * (ksr - 1) + (q - 1)) * (NB * NB) + (size_t)(32 * ch + 2 * lk) * NB + 32 * rh + 2 * lr;
@@ -2769,7 +2773,7 @@ __device__ __forceinline__ void border_syrk_body(const SyrkArgs& A) {
       if (a0 < a1) total += (a1 - a0) * 16;       // (1 << 30: zero in this segment)
     }
   } else {
-    total = (c1 - c0) * 16;
+    total = c1 > c0 ? (c1 - c0) * 16 : 0;
   }
   int sg_next = 0, rem = 0, issued = 0;           // load side: next segment to open, k-steps left in the open one, steps issued
   const double *lpj = pj0, *lpi = pi0;
@@ -2806,7 +2810,7 @@ __device__ __forceinline__ void border_syrk_body(const SyrkArgs& A) {
     for (int e = 0; e < 4; ++e) {
       v2d c2;
       c2[0] = 0.0; c2[1] = 0.0;
-      if (q == 0) c2 = *(const v2d*)(cbh + (size_t)(8 * e + a) * ldb);
+      if (q == 0) c2 = *(const v2d*)(cin + (size_t)(8 * e + a) * ldin);
       acc[a][0][e] = c2[0]; acc[a][1][e] = c2[1];
     }
   for (int ks0 = 0; ks0 < total; ks0 += RD) {     // (every segment's length is a multiple of 16 k-steps: RD divides the total)
@@ -2887,7 +2891,7 @@ void launch_border_syrk(const CholSystem* d, int n, hipStream_t s, double* scrat
   A.n = n;
   int nb = 0;
   for (int i = 0; i < n; ++i) {
-    A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.nbr[i] = d[i].nbr; A.bord[i] = d[i].bord; A.ldb[i] = d[i].ldb; A.bfirst[i] = d[i].bfirst;
+    A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.nbr[i] = d[i].nbr; A.bord[i] = d[i].bord; A.ldb[i] = d[i].ldb; A.bfirst[i] = d[i].bfirst; A.bsrc[i] = d[i].bord_src;
     A.segtab[i] = d[i].segtab; A.b0[i] = d[i].b0 > 0 ? d[i].b0 : d[i].T;
     nb = d[i].nbr > nb ? d[i].nbr : nb;
   }
@@ -2913,7 +2917,7 @@ void launch_border_syrk_jobs(const CholSystem* d, int n, const int* jobs, int nj
   SyrkArgs A{};
   A.n = n;
   for (int i = 0; i < n; ++i) {
-    A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.nbr[i] = d[i].nbr; A.bord[i] = d[i].bord; A.ldb[i] = d[i].ldb; A.bfirst[i] = d[i].bfirst;
+    A.S[i] = d[i].S; A.ld[i] = d[i].ld; A.T[i] = d[i].T; A.nbr[i] = d[i].nbr; A.bord[i] = d[i].bord; A.ldb[i] = d[i].ldb; A.bfirst[i] = d[i].bfirst; A.bsrc[i] = d[i].bord_src;
     A.segtab[i] = d[i].segtab; A.b0[i] = d[i].b0 > 0 ? d[i].b0 : d[i].T;
   }
   if (njobs <= 0) return;

@@ -103,6 +103,10 @@ struct GraphDev {
                       // border tile row + the right-hand side (HostGraph::seg_tab): what lies outside is never written and stays zero
   double* bord;      // ((nbr + 1) * NB) x (nbr * NB), column-major, ldb: border x border block (lower) + right-hand-side row at nbr * NB
   int ldb;
+  double* bord0;     // the same layout: what the ASSEMBLY writes (own H_ll blocks, -g_l, the separator poses' entries, lambda rows' -I / -r) —
+                     // always the same few positions of a zeroed buffer, so nothing has to be cleared per pass: the robots' border product
+                     // reads it and WRITES bord = bord0 - W W^T (round 5; before, bord was cleared, filled and updated in place: 71 MB of
+                     // zeros written per pass on C4)
   const int* pose_sep; // P   border offset of a SEPARATOR POSE's six coordinates, or -1 / null.  Nested dissection of the robot's own pose
                       //     chain: the poses of a window as wide as the band is (every coupling across it passes through it) are moved
                       //     out of the band into the first nsep border row tiles (k_sep_extract), the chain falls into independent

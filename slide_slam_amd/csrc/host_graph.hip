@@ -399,6 +399,7 @@ static CholSystem chol_system_of(const GraphDev& G, bool joint, float* L32, cons
   c.L32 = joint ? L32 : nullptr;
   c.h_prof = h_prof; c.prof = G.prof; c.first = G.first; c.ctab = ctab;
   c.nbr = G.arrow ? G.nbr : 0; c.bord = G.bord; c.ldb = G.ldb; c.bfirst = bfirst;
+  c.bord_src = G.arrow ? G.bord0 : nullptr;      // (the robots' border product writes bord = bord0 - W W^T)
   c.h_bfirst = (G.arrow && G.nbr > 0) ? h_bfirst : nullptr;
   return c;
 }
@@ -2087,6 +2088,10 @@ int HostGraph::upload_new() {
     SL_HIP(hipStreamSynchronize(s));      // (host vectors that may change right after)
     if (nbr_new > 0) {
       if (d_bord.ensure((size_t)(nbr_new + 1) * NB * nbr_new * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+      // bord0: what the assembly writes — the same positions in every pass of one topology, so it is zeroed HERE (whenever the border's
+      // layout may have changed) and never per pass
+      if (d_bord0.ensure((size_t)(nbr_new + 1) * NB * nbr_new * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
+      SL_HIP(hipMemsetAsync(d_bord0.d, 0, (size_t)(nbr_new + 1) * NB * nbr_new * NB * sizeof(double), s));
       if (d_xloc.ensure((size_t)nbr_new * NB, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
       SL_HIP(hipMemsetAsync(d_xloc.d, 0, (size_t)nbr_new * NB * sizeof(double), s));
     }
@@ -2217,7 +2222,7 @@ int HostGraph::upload_new() {
   }
   G.S0 = d_S0.d; G.save_S0 = 0; G.pcg = d_pcg.d; G.pcg_scal = d_pcg_scal.d;
   G.pcg_tol2 = (batch ? batch->pcg_tolerance() : pcg_tol) * (batch ? batch->pcg_tolerance() : pcg_tol);
-  G.arrow = arrow_now ? 1 : 0; G.nbr = nbr; G.lm_bord = arrow_now ? d_lm_bord.d : nullptr; G.bord = arrow_now ? d_bord.d : nullptr;
+  G.arrow = arrow_now ? 1 : 0; G.nbr = nbr; G.lm_bord = arrow_now ? d_lm_bord.d : nullptr; G.bord = arrow_now ? d_bord.d : nullptr; G.bord0 = arrow_now ? d_bord0.d : nullptr;
   G.ldb = (nbr + 1) * NB;
   G.gh_bord = (arrow_now && lam_total > 0) ? d_gh_bord.d : nullptr;
   G.seg_tab = nullptr;

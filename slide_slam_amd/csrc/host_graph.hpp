@@ -453,7 +453,7 @@ class HostGraph {
   std::vector<int> h_gh_gid, h_gh_bord;                // ghost factor -> index in the job's relative-pose list; -> border offset of its lambda coordinates
   int lam_total = 0;
   DevArr<int> d_lm_bord, d_sep_map, d_bfirst, d_gh_bord;
-  DevArr<double> d_bord, d_xloc;
+  DevArr<double> d_bord, d_bord0, d_xloc;
   int nbr = 0, nbr_alloc = -1, arrow_T = -1;
   bool arrow_on() const;                               // the batch runs exact joint passes and this graph has shared slots + separator offsets
   int sync_self();

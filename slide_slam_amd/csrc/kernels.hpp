@@ -67,6 +67,7 @@ struct CholSystem { double* S; int ld, T; double* Ld; double* Winv; double* yv; 
                     double* ctab;                // 4 * T * 4096 doubles: tables of the chained substitutions in a joint-solve pass (k_chain_tables), or null
                     int nbr;                     // border row tiles between the band and the right-hand-side row (exact joint step: the separator's coupling rows), see b_decode
                     double* bord; int ldb;       // border x border block of the system ((nbr + 1) * NB rows, nbr * NB columns, column-major) — k_border_syrk
+                    const double* bord_src;      // or null: the block's content BEFORE the product lives there (same layout) and k_border_syrk WRITES bord = bord_src - W W^T (GraphDev::bord0)
                     const int* bfirst;           // device, nbr + 1 ints: first block column of the band in which border tile row i can be non-zero (non-decreasing)
                     const int* h_bfirst;         // host copy (plan_step: the border rows still all-zero at a block column are skipped) or null: every row always
                     int b0;                      // tile row (in the system's own row numbering) at which its border rows start; 0: right behind the band (= T).  A SEGMENT of

@@ -1188,13 +1188,11 @@ __global__ __launch_bounds__(256) void k_border_clear_b(const GraphDev* __restri
       double* base = G.S + (size_t)c * NB * G.ld + (size_t)(G.T + t) * NB;
       for (int e = threadIdx.x; e < NB * NB; e += 256) base[(size_t)(e >> 6) * G.ld + (e & 63)] = 0.0;
     }
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < nb; t += (long long)gridDim.x * 256) G.bord[t] = 0.0;
+    (void)nb;      // (the border x border block is not cleared: GraphDev::bord0)
     return;
   }
-  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < nrow * ncol + nb; t += (long long)gridDim.x * 256) {
-    if (t < nrow * ncol) G.S[(size_t)(t / nrow) * G.ld + (size_t)G.T * NB + (size_t)(t % nrow)] = 0.0;
-    else G.bord[t - nrow * ncol] = 0.0;
-  }
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < nrow * ncol; t += (long long)gridDim.x * 256)
+    G.S[(size_t)(t / nrow) * G.ld + (size_t)G.T * NB + (size_t)(t % nrow)] = 0.0;
 }
 __global__ __launch_bounds__(256) void k_border_fill_b(const GraphDev* __restrict__ Gs) {
   const GraphDev G = Gs[blockIdx.z];
@@ -1220,9 +1218,9 @@ __global__ __launch_bounds__(256) void k_border_fill_b(const GraphDev* __restric
     int r = 0;
     while ((r + 1) * (r + 2) / 2 <= lane) ++r;
     const int c = lane - r * (r + 1) / 2;
-    G.bord[(size_t)(o + c) * G.ldb + o + r] = acc[lane];
+    G.bord0[(size_t)(o + c) * G.ldb + o + r] = acc[lane];
   }
-  if (lane < D) G.bord[(size_t)(o + lane) * G.ldb + (size_t)G.nbr * NB] = -acc[45 + lane];
+  if (lane < D) G.bord0[(size_t)(o + lane) * G.ldb + (size_t)G.nbr * NB] = -acc[45 + lane];
 }
 // Separator poses out of the band (nested dissection of the robot's pose chain, graph_dev.hpp pose_sep).  The assembly wrote the
 // whole reduced system in pose order; for every separator pose q (one workgroup) its entries move to where a border variable lives:
@@ -1263,7 +1261,7 @@ __global__ __launch_bounds__(256) void k_sep_extract_b(const GraphDev* __restric
     const int pr = r / 6;
     if (pr < G.P) {
       const int orr = G.pose_sep[pr];
-      if (orr >= 0) G.bord[(size_t)(oq + a) * ldb + orr + (r - 6 * pr)] = v;                     // separator x separator (o_r >= o_c: lower)
+      if (orr >= 0) G.bord0[(size_t)(oq + a) * ldb + orr + (r - 6 * pr)] = v;                     // separator x separator (o_r >= o_c: lower)
       else G.S[(size_t)r * ld + brow + oq + a] = v;                                             // segment behind: border row of q, column r
     }
     *src = (r == c) ? 1.0 : 0.0;
@@ -1272,15 +1270,18 @@ __global__ __launch_bounds__(256) void k_sep_extract_b(const GraphDev* __restric
     const int a = e / nb_rows, b = e % nb_rows;
     double* src = G.S + (size_t)(6 * q + a) * ld + brow + b;
     const double v = *src;
-    if (v != 0.0) { G.bord[(size_t)(oq + a) * ldb + b] = v; *src = 0.0; }
+    // (bord0 is never cleared: an entry that was non-zero in an earlier pass is refreshed even when it is exactly zero now)
+    double* dst = G.bord0 + (size_t)(oq + a) * ldb + b;
+    if (v != 0.0) { *dst = v; *src = 0.0; }
+    else if (b >= G.nsep * NB && *dst != 0.0) *dst = 0.0;      // (rows below nsep * NB are the separator poses' own: part 0 writes them)
   }
   if (part == 0 && tid < 6) {                                // right-hand side
     double* src = G.S + (size_t)(6 * q + tid) * ld + brow + (size_t)G.nbr * NB;
-    G.bord[(size_t)(oq + tid) * ldb + (size_t)G.nbr * NB] = *src;
+    G.bord0[(size_t)(oq + tid) * ldb + (size_t)G.nbr * NB] = *src;
     *src = 0.0;
   }
   if (part == 0 && blockIdx.x == 0)                          // unit diagonal on the padding of the separator part (whole tiles)
-    for (int p = G.nsep_dim + tid; p < G.nsep * NB; p += 256) G.bord[(size_t)p * ldb + p] = 1.0;
+    for (int p = G.nsep_dim + tid; p < G.nsep * NB; p += 256) G.bord0[(size_t)p * ldb + p] = 1.0;
   // (2) row strip: columns from the first column the profile lets reach q's rows, poses that are no separator poses only
   const int c_beg = G.first ? G.first[(6 * q) / NB] * NB : 0;
   for (int e = tid; part == 2 && e < 6 * (6 * q - c_beg); e += 256) {
@@ -1314,8 +1315,8 @@ __global__ __launch_bounds__(256) void k_border_fill_lam_b(const GraphDev* __res
   const int k = e / 6, a = e - 6 * k;
   G.S[(size_t)(6 * G.gh_pose[q] + a) * G.ld + (size_t)G.T * NB + o + k] = G.gh_J[36 * (size_t)q + 6 * k + a];
   if (G.gh_first[q] && a == 0) {
-    G.bord[(size_t)(o + k) * G.ldb + o + k] = -1.0;
-    G.bord[(size_t)(o + k) * G.ldb + (size_t)G.nbr * NB] = -G.gh_r[6 * (size_t)q + k];
+    G.bord0[(size_t)(o + k) * G.ldb + o + k] = -1.0;
+    G.bord0[(size_t)(o + k) * G.ldb + (size_t)G.nbr * NB] = -G.gh_r[6 * (size_t)q + k];
   }
 }
 // separator system of all shared landmarks = sum over the robots of their border blocks after k_border_syrk, gathered through the
@@ -1728,7 +1729,7 @@ void launch_border_assemble_batched(const GraphDev* d, const GraphDev* h, int n,
   long long work = 0;
   for (int i = 0; i < n; ++i) {
     slots = std::max(slots, h[i].n_slots);
-    work = std::max(work, (long long)h[i].nbr * NB * h[i].T * NB + (long long)(h[i].nbr + 1) * NB * h[i].nbr * NB);
+    work = std::max(work, (long long)h[i].nbr * NB * h[i].T * NB);
   }
   if (work <= 0 || slots <= 0) return;
   hipLaunchKernelGGL(k_border_clear_b, dim3((unsigned)std::min<long long>((work + 255) / 256, 4096), 1, n), dim3(256), 0, s, d);
