@@ -22,6 +22,19 @@ static inline int lam_ks_cap(int nl) {
 }
 
 thread_local std::string g_last_error;
+// Every host thread that drives the library puts its stream-capture mode to THREAD-LOCAL once.  Evidence (round 5,
+// gpurun_out/r5_threads_capture.log): with eight rank threads capturing their passes one after the other (g_capture_mtx), a capture came
+// back "invalidated" although the capturing thread's own calls all succeeded — while it captured, the OTHER threads were in
+// begin_pass / prepare_pass (hipMalloc, hipFree, synchronous copies).  A thread in the default (global) mode that makes such a call checks
+// for ongoing captures of every thread and invalidates them; in thread-local mode it only answers for its own.  (hipStreamBeginCapture's
+// mode argument covers the capturing thread alone.)
+void thread_capture_mode_local() {
+  thread_local bool done = false;
+  if (done) return;
+  hipStreamCaptureMode m = hipStreamCaptureModeThreadLocal;
+  (void)hipThreadExchangeStreamCaptureMode(&m);
+  done = true;
+}
 
 bool hip_ok(hipError_t e, const char* what) {
   if (e == hipSuccess) return true;
@@ -107,6 +120,7 @@ HostGraph::~HostGraph() {
   if (stream) (void)hipStreamDestroy(stream);
 }
 int HostGraph::init() {
+  thread_capture_mode_local();
   if (P.device >= 0) SL_HIP(hipSetDevice(P.device));
   // SLIDE_NONBLOCKING_STREAMS=1: the graph's own streams do not synchronise with the legacy (null) stream.  Needed when several host
   // threads drive graphs of ONE process side by side (the ranks-as-threads rehearsal of a multi-rank job): a thread-local stream capture
@@ -300,6 +314,7 @@ static std::string key_name(uint64_t k) {
   return std::string(1, (char)(k >> 56)) + std::to_string((unsigned long long)(k & 0x00ffffffffffffffull));
 }
 int HostGraph::merge_pending() {
+  thread_capture_mode_local();
   if (!pend_vars.empty() || !pend_facs.empty()) topo_dirty = true;
   int refused = 0;
   std::string first;
@@ -1397,12 +1412,18 @@ int CholBatch::capture_pass(double* const* d_bufs, int part, hipGraphExec_t* exe
   if (*exec) { (void)hipGraphExecDestroy(*exec); *exec = nullptr; }
   hipGraph_t graph = nullptr;
   SL_HIP(hipStreamBeginCapture(master, hipStreamCaptureModeThreadLocal));
+  g_last_error.clear();
   const int rc = enqueue_pass(d_bufs, nullptr, nullptr, part);
+  std::string inner = g_last_error;      // (what the first failing call inside the captured region said)
+  {
+    const hipError_t le = hipPeekAtLastError();      // (launches are not checked one by one)
+    if (le != hipSuccess) inner += std::string(inner.empty() ? "" : "; ") + "last launch error: " + hipGetErrorString(le);
+  }
   const hipError_t e = hipStreamEndCapture(master, &graph);
   if (rc != SLIDE_OK || e != hipSuccess || graph == nullptr) {
     (void)hipGetLastError();
     if (graph) (void)hipGraphDestroy(graph);
-    g_last_error = std::string("batched pass: stream capture failed (") + hipGetErrorString(e) + ", enqueue rc " + std::to_string(rc) + ")";
+    g_last_error = std::string("batched pass: stream capture failed (") + hipGetErrorString(e) + ", enqueue rc " + std::to_string(rc) + (inner.empty() ? "" : "; " + inner) + ")";
     return rc != SLIDE_OK ? rc : SLIDE_ERR_HIP;
   }
   const hipError_t ei = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
@@ -1456,6 +1477,7 @@ int CholBatch::profile_pass(double* const* d_bufs, double* ms_steps, int* n_laun
 // Brings every joined graph up to date, clears the status words and decides whether the captured launch sequences still fit
 // (same device views, same exchange buffers, same set of graphs).  Called at the start of a pass (whole, or part 0).
 int CholBatch::begin_pass(double* const* d_bufs, bool* same) {
+  thread_capture_mode_local();
   bool dirty;
   {
     std::lock_guard<std::mutex> lk(mtx);
@@ -1639,6 +1661,7 @@ int CholBatch::pass_all(double* const* d_bufs) {
 // The pass in three stream-ordered parts for a job that spans GPUs (see enqueue_pass): parts 0 and 1 return without a host
 // synchronisation — the caller's collective goes onto stream() behind them — part 2 ends with the one synchronisation of the pass.
 int CholBatch::pass_part(double* const* d_bufs, int part) {
+  thread_capture_mode_local();
   const int slot = part >= 0 && part <= 2 ? part : (part >= 10 && part <= 12 ? part - 7 : (part == 20 ? 6 : -1));
   if (slot < 0) return SLIDE_ERR_INVALID;
   std::lock_guard<std::mutex> pl(pass_mtx);
@@ -1823,6 +1846,7 @@ static int up_csr(DevArr<int>& dptr, DevArr<int>& dval, const std::vector<std::v
 }
 
 int HostGraph::upload_new() {
+  thread_capture_mode_local();
   hipStream_t s = stream;
   if (!topo_dirty && uploaded_once) return SLIDE_OK;      // nothing was added since the last upload: values and topology are resident
   if (ub.begin() != SLIDE_OK) return SLIDE_ERR_HIP;
@@ -2384,6 +2408,7 @@ int HostGraph::enqueue_iteration(bool lookahead, bool skip_relin, int c_d, int w
 }
 
 int HostGraph::run_update(double relin_thr, int iterations) {
+  thread_capture_mode_local();
   hipStream_t s = stream;
   if (G.P == 0) return SLIDE_OK;
   G.relin_thr = relin_thr;

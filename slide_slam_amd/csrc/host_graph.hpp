@@ -21,6 +21,7 @@
 namespace sl {
 
 extern thread_local std::string g_last_error;
+void thread_capture_mode_local();      // (host_graph.hip) once per host thread: stream-capture mode thread-local
 bool hip_ok(hipError_t e, const char* what);
 int decode_status(const int* st8);      // status words of a pass -> SLIDE_OK / SLIDE_ERR_NOT_SPD / SLIDE_ERR_RUNTIME (+ g_last_error)
 #define SL_HIP(x)                                     \

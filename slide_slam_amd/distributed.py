@@ -366,6 +366,8 @@ class PassDriver:
     def __init__(self, shards, bufs, n_slots, batch=None, base=None, world=1, device=None, pcg_iters=0, pcg_tol=0.0, arrow=False, sep_dim=0, sep_prof=None):
         self.shards, self.bufs, self.n_slots, self.batch, self.base, self.world, self.device = shards, bufs, n_slots, batch, base, world, device
         self.ptrs = [b.data_ptr() for b in bufs] if device is not None else None
+        if batch is not None and base is not None and hasattr(base, "bind_stream"):
+            base.bind_stream(batch.stream())      # (ranks as threads: their collectives wait for this stream, not for the device)
         self.passes = 0
         # Collectives of a cut pass: stream-ordered = issued under torch's ExternalStream of the batch's HIP stream (no host
         # synchronisation until the end of the pass).  That path has run with ONE RCCL rank only (no multi-GPU node was available), so a
@@ -793,9 +795,19 @@ class LocalRankComm:
             import torch
             self.torch = torch
 
+    def bind_stream(self, stream_ptr):
+        """The HIP stream this rank's passes run on (PassDriver: its CholBatch's): what _sync waits for beside torch's own stream."""
+        self.stream_ptr = stream_ptr
+
     def _sync(self):
+        # NOT torch.cuda.synchronize(): a device-wide synchronisation of one rank thread invalidates the stream capture another rank
+        # thread has going at that moment (round 5 finding, gpurun_out/r5_threads_capture2.log: part 1's captures came back
+        # "invalidated" while the other threads ran their exchanges).  The rank waits for ITS stream and for torch's current one.
         if self.device is not None:
-            self.torch.cuda.synchronize()
+            ptr = getattr(self, "stream_ptr", None)
+            if ptr:
+                self.torch.cuda.ExternalStream(int(ptr), device=self.device).synchronize()
+            self.torch.cuda.current_stream(self.device).synchronize()
 
     def _rendezvous(self, ranks, item, reduce_fn):
         """Every rank of `ranks` deposits `item`; the lowest rank runs reduce_fn(items in rank order); returns its result to all."""

@@ -470,7 +470,13 @@ def rank_threads(out, preset="C4", world=8, passes=3, relmeas=0, mode="ingest"):
     at its exchanges exactly as a multi-process job cuts it (rank-owned leaves of the separator, the half's all-reduce among its
     ranks, one leader per half) — against ONE process holding all robots."""
     os.environ["SLIDE_NONBLOCKING_STREAMS"] = "1"      # several host threads capture and copy side by side (HostGraph::init)
-    os.environ["SLIDE_PASS_DIRECT"] = "1"              # ... and their passes are issued directly, not as replayed hipGraphs (CholBatch::pass_part)
+    # Round 5: the rank threads CAPTURE and replay their passes like a process does.  Round 4 needed SLIDE_PASS_DIRECT=1 here; the two
+    # causes are fixed at their source — every library thread runs in thread-local capture mode (host_graph.hip
+    # thread_capture_mode_local: a thread in the default global mode invalidates other threads' captures with its hipMalloc / hipFree),
+    # and the thread ranks' collectives no longer synchronise the whole device (LocalRankComm._sync).  SLIDE_TEST_THREAD_DIRECT=1: the
+    # old direct issue.
+    if os.environ.get("SLIDE_TEST_THREAD_DIRECT") == "1":
+        os.environ["SLIDE_PASS_DIRECT"] = "1"
     import torch
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
