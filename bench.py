@@ -440,6 +440,42 @@ def slidegraph_roofline(s, with_cpu=True, m_clipper=4096):
     return res
 
 
+def association_report(s, cfg, logs, frames, merge_n_global, merge_slots):
+    """The sharded job's cross-robot association against the reference's: the timed passes run on the MERGE of the robots'
+    final maps (distributed.associate_global); the reference's replica associates every foreign packet frame by frame against its own moving
+    maps (sloamNode.cpp:912-1002).  Here the product plays that replica at full size (one SlideBackend ingesting all robots), and the two
+    partitions of the landmarks are compared: global landmarks per class, landmarks held by two or more robots (shared slots)."""
+    from slide_slam_amd.distributed import associate_by_ingest
+    from slide_slam_amd.replay import replay_multi, replay_single
+    t0 = time.perf_counter()
+    R = len(logs)
+    P = len(logs[0]["rel7"]) if frames is None else frames
+    own = []
+    for lg in logs:
+        gb = s.SlideBackend(s.default_params(pose_chart=CHART), 1)
+        own.append(replay_single(gb, lg, n_frames=frames))
+    rb = s.SlideBackend(s.default_params(pose_chart=CHART), R)
+    rep = replay_multi(rb, dict(cfg=cfg, logs=logs, relmeas=[]), n_frames=frames, own_node_factory=lambda: s.SlideBackend(s.default_params(pose_chart=CHART), 1))
+    names = ("cyl_id", "cube_id", "ell_id")
+    own_ids = [[own[r][names[c]] for c in range(3)] for r in range(R)]
+    rep_ids = [[[rep["ids"][k][r][c] for k in range(P)] for c in range(3)] for r in range(R)]
+    gid, n_glob, st = associate_by_ingest(own_ids, rep_ids)
+    slots = 0
+    for c in range(3):
+        cnt = np.zeros(n_glob[c], np.int32)
+        for r in range(R):
+            cnt[np.unique(gid[r][c])] += 1
+        slots += int((cnt >= 2).sum())
+    cts = rb.counts()
+    return {"merge_of_final_maps": {"global_landmarks": [int(x) for x in merge_n_global], "shared_slots": int(merge_slots)},
+            "replica_frame_by_frame": {"global_landmarks": [int(x) for x in n_glob], "shared_slots": slots, "split": st["split"], "collapsed": st["collapsed"],
+                                       "replica_counts": [cts["cyl"], cts["cube"], cts["point"]]},
+            "seconds": time.perf_counter() - t0,
+            "note": "the timed passes use the merge; setup_local_shards(assoc=associate_by_ingest(..)) installs the replica's partition instead "
+                    "(tests/test_bench_config.py::test_exact_joint_step_with_the_replicas_frame_by_frame_association: inventory identical to the "
+                    "oracle replica's, 5e-6 to its optimum on C4tiny)"}
+
+
 def _pmc_traffic(kernel, **match):
     """HBM-side bytes per launch of `kernel` from the committed PMC summaries (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     passes, gfx950 corrections applied; a PMC pass cannot run inside the timed bench): newest round first."""
@@ -566,6 +602,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the un-batched re-run and the convergence probe")
     ap.add_argument("--ingest-only", action="store_true", help="build the graph without per-frame solves (profiling aid)")
+    ap.add_argument("--assoc-report", action="store_true", help="add the merge-vs-replica association report: a full-size replica ingests every robot frame by frame (about a minute; profiles/r05_association_c4_full.json holds the round's result)")
     ap.add_argument("--no-place-leg", action="store_true", help="skip the SlideMatch / SlideGraph / CLIPPER legs of the roofline")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the dense-profile legs of the roofline (rocprofv3 runs of the default)")
     ap.add_argument("--dense-profile", action="store_true",
@@ -1139,6 +1176,14 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
         res["roofline"]["assoc"] = assoc_roofline(s)
     except Exception as e:      # noqa: BLE001  (the headline number stands on its own)
         res["roofline"]["assoc"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and info.get("n_global") is not None and getattr(args, "assoc_report", False):
+        try:
+            from slide_slam_amd.synth import make_robot_log, make_world
+            wm_ = make_world(cfg)
+            res["association"] = association_report(s, cfg, [make_robot_log(cfg, wm_, r) for r in range(cfg.robots)], args.frames,
+                                                    info["n_global"], info.get("n_slots", 0))
+        except Exception as e:      # noqa: BLE001
+            res["association"] = {"error": repr(e)}
     if rank == 0 and not getattr(args, "no_place_leg", False):
         # A13 - A15 (SlideMatch sweep, SlideGraph triangle matching, CLIPPER): the kernels' own legs, the oracle timed beside them
         try:

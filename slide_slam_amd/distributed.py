@@ -80,6 +80,52 @@ def associate_global(tables, thresh=(2.0, 2.0, 0.75), matcher=None):
     return gid, n_global
 
 
+def associate_by_ingest(own_ids, replica_ids):
+    """Cross-robot association as the REFERENCE makes it (sloamNode.cpp:912-1002): a host replica ingests every robot's packets frame
+    by frame and associates their detections against its own, still moving, maps.  own_ids[r][cls]: per key frame the landmark id
+    robot r's OWN graph gave every detection; replica_ids[r][cls]: the ids the replica gave the same detections.  The co-occurrences
+    define the global id of every local landmark.  Two things the sharded layout cannot express are counted and resolved first-come:
+    `split` — the replica put detections of ONE local landmark on several of its landmarks; `collapsed` — it put two local
+    landmarks of one robot on the same one (the second gets an id of its own).  Returns (gid, n_global, stats) as associate_global does."""
+    R = len(own_ids)
+    gid = [[None] * 3 for _ in range(R)]
+    n_global = [0, 0, 0]
+    stats = dict(split=0, collapsed=0)
+    for cls in range(3):
+        nglob = 0
+        for r in range(R):
+            for ids in replica_ids[r][cls]:
+                if len(ids):
+                    nglob = max(nglob, int(np.max(ids)) + 1)
+        extra = nglob
+        for r in range(R):
+            nloc = 0
+            for ids in own_ids[r][cls]:
+                if len(ids):
+                    nloc = max(nloc, int(np.max(ids)) + 1)
+            g = np.full(nloc, -1, np.int64)
+            for a, b in zip(own_ids[r][cls], replica_ids[r][cls]):
+                for lo, gl in zip(a, b):
+                    lo, gl = int(lo), int(gl)
+                    if lo < 0 or gl < 0:
+                        continue
+                    if g[lo] < 0:
+                        g[lo] = gl
+                    elif g[lo] != gl:
+                        stats["split"] += 1
+            seen = set()
+            for lo in range(nloc):
+                if g[lo] < 0 or int(g[lo]) in seen:
+                    stats["collapsed"] += int(g[lo] >= 0)
+                    g[lo] = extra
+                    extra += 1
+                else:
+                    seen.add(int(g[lo]))
+            gid[r][cls] = g
+        n_global[cls] = extra
+    return gid, n_global, stats
+
+
 def shared_slots(gid, n_global, rank):
     """Slot table of this rank: slots enumerate (cls, global id) pairs observed by >= 2 robots, in a fixed
     global order; the owner is the lowest rank observing the landmark."""
@@ -286,16 +332,25 @@ class DistributedGraph:
             self._phase(2)
 
 
-def setup_local_shards(shards, matcher, base=None, rank=0, world=1, thresh=(2.0, 2.0, 0.75), device=None):
+def setup_local_shards(shards, matcher, base=None, rank=0, world=1, thresh=(2.0, 2.0, 0.75), device=None, assoc=None):
     """Cross-robot association for ALL robot shards of this process from one host thread (virtual rank of local shard t =
     rank * len(shards) + t; every process holds the same number of shards): all-gather the landmark tables, run the
     deterministic merge, install the shared slots of every local shard and adopt the owners' values.  `base` (a TorchComm) joins
-    the processes of a multi-GPU job; None = single process.  Returns (exchange buffers [one per shard], info)."""
+    the processes of a multi-GPU job; None = single process.  Returns (exchange buffers [one per shard], info).
+    assoc = (gid, n_global) of ALL the job's robots (associate_by_ingest: the reference's frame-by-frame association of a host
+    replica) replaces the merge of the final maps (mode "ingest"; single process or identical on every rank)."""
     R = len(shards)
     mine = [[sh.landmark_table(cls) for cls in range(3)] for sh in shards]
     parts = base.all_gather_object(mine) if (base is not None and world > 1) else [mine]
     tables = [t for part in parts for t in part]
-    gid, n_global = associate_global(tables, thresh, matcher)
+    if assoc is not None:
+        gid, n_global = assoc
+        for r, tb in enumerate(tables):
+            for cls in range(3):
+                if len(gid[r][cls]) != len(tb[cls][1]):
+                    raise ValueError(f"ingest association: robot {r} class {cls} holds {len(tb[cls][1])} landmarks, the id table {len(gid[r][cls])}")
+    else:
+        gid, n_global = associate_global(tables, thresh, matcher)
     bufs, n_slots = [], 0
     if device is not None:
         import torch

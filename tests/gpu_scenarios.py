@@ -351,7 +351,7 @@ def tiny_pcg(out, preset="C3tiny", passes=15, pcg=8):
     json.dump(res, open(out, "w"))
 
 
-def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1, relmeas=0):
+def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1, relmeas=0, assoc="merge"):
     """The EXACT joint step (shared landmarks as the separator of the joint graph) of the HIP shards in one CholBatch — the whole pass
     one replayed hipGraph — against oracle shards taking the same step pass by pass, and (small presets) against the optimum of the
     oracle's joint replica, the reference's arrangement.  mode: replay = streaming build per robot (per-frame solves), ingest = all
@@ -377,19 +377,37 @@ def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1, re
     A = [s.SlideBackend(s.default_params(**chart_kw(s)), 1) for _ in range(R)]
     L = po.lib(native=True)
     O = [po.OracleBackend(po.OrcParams.default(num_threads=min(os.cpu_count() or 1, 16), **chart_kw(po)), 1, L=L) for _ in range(R)]
+    own_out = []
     for a, o, lg in zip(A, O, logs):
         if mode == "ingest":
             ingest(a, lg, s.FRAME_FOREIGN)
             ingest(o, lg, 2)
         else:
-            replay_single(a, lg, collect=False)
+            own_out.append(replay_single(a, lg, collect=(assoc == "ingest")))
             replay_single(o, lg, robot=0, collect=False)
     say("shards built")
+    ingest = None
+    if assoc == "ingest":
+        # the reference's cross-robot association (sloamNode.cpp:912-1002): ONE host replica (the product plays it) ingests every robot's
+        # packets frame by frame; the ids it gives the detections, against the ids the robots' own graphs gave them, define the global
+        # landmarks (distributed.associate_by_ingest) — instead of the merge of the robots' FINAL maps
+        from slide_slam_amd.distributed import associate_by_ingest
+        from slide_slam_amd.replay import replay_multi
+        rb = s.SlideBackend(s.default_params(**chart_kw(s)), R)
+        rep = replay_multi(rb, dict(cfg=cfg, logs=logs, relmeas=[]), own_node_factory=lambda: s.SlideBackend(s.default_params(**chart_kw(s)), 1))
+        names = ("cyl_id", "cube_id", "ell_id")
+        own_ids = [[own_out[r][names[c]] for c in range(3)] for r in range(R)]
+        rep_ids = [[[rep["ids"][k][r][c] for k in range(P)] for c in range(3)] for r in range(R)]
+        gid, n_glob, st = associate_by_ingest(own_ids, rep_ids)
+        say("ingest association:", n_glob, st)
+        ingest = (gid, n_glob)
+        rc_ = rb.counts()
+        ingest_stats = dict(st, replica_counts=[rc_["cyl"], rc_["cube"], rc_["point"]])
     batch = s.CholBatch(R)
     for t, a in enumerate(A):
         a.graph.join_chol_batch(batch, t)
-    bufA, infoA = setup_local_shards(A, gpu_matcher, device=dev)
-    bufO, infoO = setup_local_shards(O, oracle_matcher)
+    bufA, infoA = setup_local_shards(A, gpu_matcher, device=dev, assoc=ingest)
+    bufO, infoO = setup_local_shards(O, oracle_matcher, assoc=ingest)
     dA = PassDriver(A, bufA, infoA["n_slots"], batch=batch, device=dev, arrow=True, sep_dim=infoA["sep_dim"], sep_prof=infoA.get("sep_prof"))
     dO = PassDriver(O, bufO, infoO["n_slots"], arrow=True, sep_dim=infoO["sep_dim"], sep_prof=infoO.get("sep_prof"))
     say("associated:", infoA["n_slots"], infoO["n_slots"], "slots, separator", infoA["sep_dim"], infoO["sep_dim"])
@@ -403,7 +421,7 @@ def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1, re
         assert dO.setup_ghosts(rel) == n_g
         res_n_rel = len(rel)
         say("relative-pose measurements:", len(rel), "ghost slots:", n_g)
-    res = dict(n_gslots=n_g, n_relmeas=(res_n_rel if relmeas else 0), chart=chart_name(), n_slots=[infoA["n_slots"], infoO["n_slots"]], sep_dim=[infoA["sep_dim"], infoO["sep_dim"]],
+    res = dict(n_gslots=n_g, n_relmeas=(res_n_rel if relmeas else 0), chart=chart_name(), assoc=assoc, ingest=(ingest_stats if assoc == "ingest" else None), n_slots=[infoA["n_slots"], infoO["n_slots"]], sep_dim=[infoA["sep_dim"], infoO["sep_dim"]],
                n_global=[list(map(int, infoA["n_global"])), list(map(int, infoO["n_global"]))], gpu_vs_oracle=[], step=[], vs_joint=[], ms=[])
     prev = None
     for p in range(passes):
