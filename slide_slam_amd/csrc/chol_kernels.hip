@@ -28,11 +28,24 @@ constexpr int CHOL_BATCH_MAX = 8;    // systems per batched launch (robots shari
 __device__ inline v4d mfma_f64(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
 __device__ inline double rsqrt_nr(double d) {
-  // 1/sqrt(d): hardware estimate + two Newton steps (full double precision)
+  // 1/sqrt(d): hardware estimate + two Newton steps (full double precision).  Each step as THREE dependent operations instead of four
+  // (t = d y; r = 1/2 - t (y/2); y += y r — y/2 does not wait for t): the four chained calls per 4x4 pivot block sit on the critical path
+  // of every step launch (SLIDE_RSQRT_OLD: round 1-4's form, for comparison)
+#ifdef SLIDE_RSQRT_OLD
   double y = __builtin_amdgcn_rsq(d);
   y = y * (1.5 - 0.5 * d * y * y);
   y = y * (1.5 - 0.5 * d * y * y);
   return y;
+#else
+  double y = __builtin_amdgcn_rsq(d);
+  double t = d * y, h = 0.5 * y;
+  double r = __builtin_fma(-t, h, 0.5);
+  y = __builtin_fma(y, r, y);
+  t = d * y; h = 0.5 * y;
+  r = __builtin_fma(-t, h, 0.5);
+  y = __builtin_fma(y, r, y);
+  return y;
+#endif
 }
 
 __device__ __forceinline__ double bcast_lane(double v, int src) {   // src: compile-time lane

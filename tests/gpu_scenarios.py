@@ -386,7 +386,7 @@ def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1, re
             own_out.append(replay_single(a, lg, collect=(assoc == "ingest")))
             replay_single(o, lg, robot=0, collect=False)
     say("shards built")
-    ingest = None
+    ingest_assoc = None
     if assoc == "ingest":
         # the reference's cross-robot association (sloamNode.cpp:912-1002): ONE host replica (the product plays it) ingests every robot's
         # packets frame by frame; the ids it gives the detections, against the ids the robots' own graphs gave them, define the global
@@ -400,14 +400,14 @@ def arrow_parity(out, preset="C4tiny", passes=6, mode="replay", with_joint=1, re
         rep_ids = [[[rep["ids"][k][r][c] for k in range(P)] for c in range(3)] for r in range(R)]
         gid, n_glob, st = associate_by_ingest(own_ids, rep_ids)
         say("ingest association:", n_glob, st)
-        ingest = (gid, n_glob)
+        ingest_assoc = (gid, n_glob)
         rc_ = rb.counts()
         ingest_stats = dict(st, replica_counts=[rc_["cyl"], rc_["cube"], rc_["point"]])
     batch = s.CholBatch(R)
     for t, a in enumerate(A):
         a.graph.join_chol_batch(batch, t)
-    bufA, infoA = setup_local_shards(A, gpu_matcher, device=dev, assoc=ingest)
-    bufO, infoO = setup_local_shards(O, oracle_matcher, assoc=ingest)
+    bufA, infoA = setup_local_shards(A, gpu_matcher, device=dev, assoc=ingest_assoc)
+    bufO, infoO = setup_local_shards(O, oracle_matcher, assoc=ingest_assoc)
     dA = PassDriver(A, bufA, infoA["n_slots"], batch=batch, device=dev, arrow=True, sep_dim=infoA["sep_dim"], sep_prof=infoA.get("sep_prof"))
     dO = PassDriver(O, bufO, infoO["n_slots"], arrow=True, sep_dim=infoO["sep_dim"], sep_prof=infoO.get("sep_prof"))
     say("associated:", infoA["n_slots"], infoO["n_slots"], "slots, separator", infoA["sep_dim"], infoO["sep_dim"])
