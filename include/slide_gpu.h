@@ -499,7 +499,9 @@ enum {
   SLIDE_MS_PLACE_PAIR_TESTS = 6,  /* count: candidates x query objects x reference objects of the last sweep (a first hit ends a query
                                      object's scan early: upper bound of the pair tests executed) */
   SLIDE_MS_TRI_PAIRS = 7,         /* count: model triangles x data triangles of the last triangle match */
-  SLIDE_MS_COUNT = 8
+  SLIDE_MS_PLACE_DIST_TESTS = 8,  /* count: distance tests the bucketed sweep was given (candidates x sum over the query objects of the
+                                     reference objects of their label): what is left of the pair tests once the label test is a table */
+  SLIDE_MS_COUNT = 9
 };
 int slide_last_device_ms(int what, double* out);
 /* The same for several independent problems in ONE launch, a persistent workgroup per problem — the robot pairs of a multi-robot job

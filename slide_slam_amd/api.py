@@ -729,7 +729,7 @@ def clipper_last_solve_info():
     return w.value, e.value
 
 
-MS_PLACE_SWEEP, MS_TRI_MATCH, MS_CLQ_CSR, MS_CLQ_SOLVE, MS_AFFINITY, MS_CLQ_NNZ, MS_PLACE_PAIR_TESTS, MS_TRI_PAIRS = range(8)
+MS_PLACE_SWEEP, MS_TRI_MATCH, MS_CLQ_CSR, MS_CLQ_SOLVE, MS_AFFINITY, MS_CLQ_NNZ, MS_PLACE_PAIR_TESTS, MS_TRI_PAIRS, MS_PLACE_DIST_TESTS = range(9)
 
 
 def last_device_ms(what):

@@ -169,6 +169,13 @@ struct PlaceDev {
   long long n_cells; int n_yaw;
   double thr_pos, thr_dim; int ignore_dim;
   int32_t* inliers;                                         // n_cells * n_yaw
+  // round 5 (k_place_sweep_b): both maps bucketed by label on the host (stable: the reference's first-hit order inside a label is kept)
+  const double* rxy;       // 2 nr: (x, y) of the reference objects, bucket after bucket; null: the plain kernel
+  const double* rdim;      // 3 nr: their dimensions (read when !ignore_dim)
+  const double* qxy;       // 2 nq: (x, y) of the query objects, ordered by the bucket of their label
+  const double* qdim;      // 3 nq
+  const int32_t* qrange;   // 2 nq: [lo, hi) = the reference bucket a query object scans (empty when the reference holds no such label)
+  double v_crit;           // smallest double whose correctly rounded square root is >= thr_pos: sqrt(v) < thr_pos <=> v < v_crit
 };
 void launch_place_sweep(const PlaceDev& P, hipStream_t s);
 void launch_place_argmax(const int32_t* inliers, long long n, long long* best_idx, int32_t* best_val, hipStream_t s);

@@ -63,6 +63,103 @@ __global__ __launch_bounds__(256) void k_place_sweep(PlaceDev P, const double* _
   }
 }
 
+// Round 5: the same count with both maps BUCKETED BY LABEL.  The reference scans, for every query object, the reference objects in
+// order, skips those of another label and stops at the first hit (place_recognition.cpp:281-357): a stable bucketing keeps "the first
+// hit among the objects of my label" what it was, and the inlier COUNT does not depend on the order of the query objects — so the host
+// sorts both maps by label (stably), and a wavefront scans, per chunk of 64 query objects, only the bucket(s) its lanes ask for: no label
+// test, a third of the pairs at three labels, LDS broadcast reads ((x, y) as one 16-byte entry), and the distance test
+// sqrt(dx^2 + dy^2) < t as dx^2 + dy^2 < v_crit with v_crit = the smallest double whose correctly rounded root is >= t (the same
+// decision bit for bit: sqrt is monotone and correctly rounded on both sides) — the f64 square root was most of a pair test's cost.
+// Query objects live in LDS too (lane-contiguous), every candidate re-uses them.
+__global__ __launch_bounds__(256) void k_place_sweep_b(PlaceDev P, const double* __restrict__ cosv, const double* __restrict__ sinv) {
+  extern __shared__ __align__(16) double lds[];
+  double* rxy = lds;                                   // 2 nr
+  double* rdim = rxy + 2 * (size_t)P.nr;               // 3 nr (only when !ignore_dim)
+  double* qxy = rdim + (P.ignore_dim ? 0 : 3 * (size_t)P.nr);      // 2 nq
+  double* qdim = qxy + 2 * (size_t)P.nq;               // 3 nq (only when !ignore_dim)
+  int* qrange = reinterpret_cast<int*>(qdim + (P.ignore_dim ? 0 : 3 * (size_t)P.nq));   // 2 nq
+  for (int e = threadIdx.x; e < 2 * P.nr; e += blockDim.x) rxy[e] = P.rxy[e];
+  for (int e = threadIdx.x; e < 2 * P.nq; e += blockDim.x) { qxy[e] = P.qxy[e]; qrange[e] = P.qrange[e]; }
+  if (!P.ignore_dim) {
+    for (int e = threadIdx.x; e < 3 * P.nr; e += blockDim.x) rdim[e] = P.rdim[e];
+    for (int e = threadIdx.x; e < 3 * P.nq; e += blockDim.x) qdim[e] = P.qdim[e];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long ncand = P.n_cells * P.n_yaw;
+  const double v_crit = P.v_crit, thr_dim = P.thr_dim;
+  const bool use_dim = !P.ignore_dim;
+  for (long long cand = wave; cand < ncand; cand += nwaves) {
+    const long long cell = cand / P.n_yaw;
+    const int iy = (int)(cand % P.n_yaw);
+    const double x = P.xs[P.cell_x[cell]], y = P.ys[P.cell_y[cell]];
+    const double c = cosv[iy], s = sinv[iy];
+    int inl = 0;
+    for (int j0 = 0; j0 < P.nq; j0 += 64) {
+      const int j = j0 + lane;
+      const bool active = j < P.nq;
+      double tx = 0.0, ty = 0.0, q4 = 0.0, q5 = 0.0, q6 = 0.0;
+      int lo = 0, hi = 0;
+      if (active) {
+        const double q1 = qxy[2 * j], q2 = qxy[2 * j + 1];
+        tx = c * q1 + (-s) * q2 + x * 1.0;
+        ty = s * q1 + c * q2 + y * 1.0;
+        const double tw = 0.0 * q1 + 0.0 * q2 + 1.0 * 1.0;
+        tx = tx / tw; ty = ty / tw;
+        lo = qrange[2 * j]; hi = qrange[2 * j + 1];
+        if (use_dim) { q4 = qdim[3 * j]; q5 = qdim[3 * j + 1]; q6 = qdim[3 * j + 2]; }
+      }
+      bool hit = false;
+      unsigned long long todo = __ballot(active && hi > lo);
+      while (todo) {      // one bucket per chunk (the query objects are sorted by label), two or three where labels meet
+        const int first = __ffsll((long long)todo) - 1;
+        const int blo = __shfl(lo, first), bhi = __shfl(hi, first);
+        const bool mine = active && lo == blo && hi == bhi;
+        bool open_ = mine;                                  // still looking for its first hit
+        int k = blo;
+        if (!use_dim) {
+          // four reference objects per round: whether a query object has A hit does not depend on the order inside the bucket, and
+          // four independent distance tests hide each other's latencies (one test is a chain of five dependent f64 operations
+          // behind an LDS read: 128 cycles per object and wavefront when taken one by one)
+          for (; k + 4 <= bhi; k += 4) {
+            if (((k - blo) & 15) == 0 && __ballot(open_) == 0) { k = bhi; break; }
+            const double x0 = rxy[2 * k] - tx, y0 = rxy[2 * k + 1] - ty, x1 = rxy[2 * k + 2] - tx, y1 = rxy[2 * k + 3] - ty;
+            const double x2 = rxy[2 * k + 4] - tx, y2 = rxy[2 * k + 5] - ty, x3 = rxy[2 * k + 6] - tx, y3 = rxy[2 * k + 7] - ty;
+            const bool ok = (x0 * x0 + y0 * y0 < v_crit) | (x1 * x1 + y1 * y1 < v_crit) | (x2 * x2 + y2 * y2 < v_crit) | (x3 * x3 + y3 * y3 < v_crit);
+            if (open_ && ok) { hit = true; open_ = false; }
+          }
+        }
+        for (; k < bhi; ++k) {
+          if (((k - blo) & 15) == 0 && __ballot(open_) == 0) break;
+          const double xd = rxy[2 * k] - tx, yd = rxy[2 * k + 1] - ty;
+          bool ok = xd * xd + yd * yd < v_crit;
+          if (use_dim) {
+            const double m3 = rdim[3 * k], m4 = rdim[3 * k + 1], m5 = rdim[3 * k + 2];
+            double avg = 0;
+            if (m4 == 0 && m5 == 0) {
+              avg = fabs(m3 - q4);
+            } else {
+              avg += fabs(m3 - q4);
+              avg += fabs(m4 - q5);
+              avg += fabs(m5 - q6);
+              avg /= 3;
+            }
+            ok = ok && (avg < thr_dim);
+          }
+          if (open_ && ok) { hit = true; open_ = false; }
+        }
+        todo &= ~__ballot(mine);
+      }
+      inl += hit ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) inl += __shfl_xor(inl, off);
+    if (lane == 0) P.inliers[cand] = inl;
+  }
+}
+
 // first index of the maximum (the reference keeps a candidate only when it has STRICTLY more inliers)
 __global__ __launch_bounds__(256) void k_place_argmax(const int32_t* __restrict__ v, long long n, long long* best_idx,
                                                       int32_t* best_val) {
@@ -198,6 +295,13 @@ void launch_place_sweep(const PlaceDev& P, hipStream_t s) {
   long long blocks = (ncand + 3) / 4;
   if (blocks > 256 * 8) blocks = 256 * 8;
   if (blocks < 1) blocks = 1;
+  if (P.rxy) {
+    static const bool attr = (hipFuncSetAttribute(reinterpret_cast<const void*>(k_place_sweep_b), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), true);
+    (void)attr;
+    const size_t lds = ((size_t)(P.ignore_dim ? 2 : 5) * (P.nr + P.nq)) * sizeof(double) + 2 * (size_t)P.nq * sizeof(int) + 16;
+    hipLaunchKernelGGL(k_place_sweep_b, dim3((unsigned)blocks), dim3(256), lds, s, P, cosv, sinv);
+    return;
+  }
   hipLaunchKernelGGL(k_place_sweep, dim3((unsigned)blocks), dim3(256), (size_t)P.nr * 6 * sizeof(double), s, P, cosv, sinv);
 }
 void launch_place_argmax(const int32_t* inliers, long long n, long long* best_idx, int32_t* best_val, hipStream_t s) {
