@@ -434,6 +434,7 @@ void CholBatch::detach(HostGraph* g) {
     if (p == g) { p = nullptr; pass_dirty = true; }
 }
 void HostGraph::join_batch(CholBatch* b, int slot) {
+  pred_valid = false; status_clean = false; cache_pose = -1;      // (outside the streaming update: nothing it left behind can be relied on)
   CholBatch* old = nullptr;
   {
     std::lock_guard<std::mutex> lk(mtx);
@@ -1447,6 +1448,7 @@ int CholBatch::profile_pass(double* const* d_bufs, double* ms_steps, int* n_laun
   for (int i = 0; i < n; ++i) {
     HostGraph* g = graphs[i];
     std::lock_guard<std::mutex> gl(g->mtx);
+    g->pred_valid = false; g->status_clean = false; g->cache_pose = -1;      // (a batched pass rewrites the status words, deltas and estimates)
     int rc = g->merge_pending();
     if (rc == SLIDE_OK) rc = g->upload_new();
     if (rc != SLIDE_OK) return rc;
@@ -1494,6 +1496,7 @@ int CholBatch::begin_pass(double* const* d_bufs, bool* same) {
   for (int i = 0; i < n; ++i) {
     HostGraph* g = graphs[i];
     std::lock_guard<std::mutex> gl(g->mtx);
+    g->pred_valid = false; g->status_clean = false; g->cache_pose = -1;      // (a batched pass rewrites the status words, deltas and estimates)
     int rc = g->merge_pending();
     if (rc == SLIDE_OK) rc = g->upload_new();
     if (rc != SLIDE_OK) return rc;
@@ -2402,7 +2405,8 @@ int HostGraph::enqueue_iteration(bool lookahead, bool skip_relin, int c_d, int w
     STAGE(8, launch_chol_solve_bwd(CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, nullptr, h_prof.data(), G.prof, G.first, d_ctab.d}, s));
   }
   STAGE(9, launch_backsub(G, 0, s));
-  STAGE(10, launch_estimate(G, s));
+  if (skip_relin && G.lm_first) STAGE(10, launch_estimate_predict(G, s));      // (streaming update: also predicts the next update's relinearisation, status[5])
+  else STAGE(10, launch_estimate(G, s));
 #undef STAGE
   return SLIDE_OK;
 }
@@ -2412,7 +2416,9 @@ int HostGraph::run_update(double relin_thr, int iterations) {
   hipStream_t s = stream;
   if (G.P == 0) return SLIDE_OK;
   G.relin_thr = relin_thr;
-  SL_HIP(hipMemsetAsync(d_status.d, 0, 8 * sizeof(int), s));
+  if (!status_clean) SL_HIP(hipMemsetAsync(d_status.d, 0, 8 * sizeof(int), s));      // (k_final_pack of the last update left them at zero otherwise)
+  status_clean = false;
+  cache_pose = -1;
   // Replaying a captured hipGraph removes the host launch cost (~250 launches + event traffic per pass) once the
   // SAME resident graph is solved again (batch Gauss-Newton, repeated solve() without new factors).
   const bool same_as_prev = have_prev && std::memcmp(&G_prev, &G, sizeof(GraphDev)) == 0;
@@ -2448,13 +2454,24 @@ int HostGraph::run_update(double relin_thr, int iterations) {
   // status[6]) — known only after k_relin, hence one extra (32-byte) read-back before the rest of the update is enqueued.
   static const bool env_inc = !(getenv("SLIDE_NO_INCREMENTAL") && getenv("SLIDE_NO_INCREMENTAL")[0] == '1');
   const bool try_inc = env_inc && inc_enabled && iterations == 1 && !use_graph && !batch && !force_dense && factor_valid && fact_gen == S_gen && relin_thr > 0.0 && G.T > 2;
+  const bool wf_full_path = !try_inc && env_inc && wildfire_thr > 0.0 && iterations == 1 && !use_graph && !batch && !force_dense && wf_T > 0 && relin_thr > 0.0;
+  static const bool env_pred = !(getenv("SLIDE_NO_PREDICT") && getenv("SLIDE_NO_PREDICT")[0] == '1');
+  const bool use_pred = env_pred && pred_valid && pred_thr == relin_thr;
   if (try_inc) {
     launch_relin(G, s);
-    int s0[8];
-    SL_HIP(hipMemcpyAsync(s0, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
-    SL_HIP(hipStreamSynchronize(s));
     int pmin = dirty_min_pose;
-    if (s0[6] > 0) pmin = std::min(pmin, G.P - s0[6]);
+    if (use_pred) {
+      // no read-back: the last update's k_estimate_predict already said which variables k_relin moves now (delta has not changed
+      // since) and from which pose on their blocks change.  (Factors merged since then only add to dirty_min_pose: a relinearised
+      // pose's new partners / landmarks are poses and first observers that dirty_min_pose already covers.)
+      pmin = std::min(pmin, pred_pose);
+      ++n_pred_used;
+    } else {
+      int s0[8];
+      SL_HIP(hipMemcpyAsync(s0, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+      SL_HIP(hipStreamSynchronize(s));
+      if (s0[6] > 0) pmin = std::min(pmin, G.P - s0[6]);
+    }
     int c_d = pmin >= G.P ? G.T : (6 * std::max(pmin, 0)) / NB;      // (nothing dirty: no step at all, the substitutions are simply repeated)
     c_d = std::min(c_d, G.T);
     G.col0 = c_d * NB;
@@ -2463,16 +2480,21 @@ int HostGraph::run_update(double relin_thr, int iterations) {
     if (rc != SLIDE_OK) return rc;
     if (c_d > 0) ++n_inc; else ++n_full;
     last_cd = c_d;
-  } else if (env_inc && wildfire_thr > 0.0 && iterations == 1 && !use_graph && !batch && !force_dense && wf_T > 0 && relin_thr > 0.0) {
+  } else if (wf_full_path) {
     // an update that cannot keep any factor column (S was re-allocated, the system is still tiny, ...) but has a previous solution:
     // everything is re-factored, the back-substitution is bounded below the first dirty block column all the same (the rule of
     // bwd_chain_body<.., true> does not care who recomputed the unchanged columns)
     launch_relin(G, s);
-    int s0[8];
-    SL_HIP(hipMemcpyAsync(s0, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
-    SL_HIP(hipStreamSynchronize(s));
     int pmin = dirty_min_pose;
-    if (s0[6] > 0) pmin = std::min(pmin, G.P - s0[6]);
+    if (use_pred) {
+      pmin = std::min(pmin, pred_pose);
+      ++n_pred_used;
+    } else {
+      int s0[8];
+      SL_HIP(hipMemcpyAsync(s0, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+      SL_HIP(hipStreamSynchronize(s));
+      if (s0[6] > 0) pmin = std::min(pmin, G.P - s0[6]);
+    }
     const int cd = std::min(pmin >= G.P ? G.T : (6 * std::max(pmin, 0)) / NB, G.T);
     const int rc = enqueue_iteration(false, true, 0, cd);
     if (rc != SLIDE_OK) return rc;
@@ -2489,16 +2511,35 @@ int HostGraph::run_update(double relin_thr, int iterations) {
     ++n_full;
     last_cd = 0;
   }
+  // the closing read-back in one piece: status words + the newest pose's estimate (what a frame returns: HostGraph::get_pose12 serves it
+  // from the cache) — k_final_pack leaves the status words at zero for the next update
   int st[8];
-  SL_HIP(hipMemcpyAsync(st, d_status.d, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
-  SL_HIP(hipStreamSynchronize(s));
+  pred_valid = false;
+  {
+    double fin[16];
+    if (d_final.ensure(16, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    const int newest = (int)G.P - 1;
+    launch_final_pack(G, newest, d_final.d, s);
+    SL_HIP(hipMemcpyAsync(fin, d_final.d, sizeof(fin), hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    std::memcpy(st, fin, sizeof(st));
+    std::memcpy(cache_pose12, fin + 4, 12 * sizeof(double));
+    cache_pose = newest;
+    status_clean = true;
+  }
   SL_HIP(hipGetLastError());
   if (prof.on) prof.collect();
   last_relin = st[2];
   factor_valid = false;
   {
     const int rc = decode_status(st);
-    if (rc != SLIDE_OK) return rc;
+    if (rc != SLIDE_OK) { cache_pose = -1; return rc; }
+  }
+  if (iterations == 1 && !use_graph && !batch && G.lm_first && relin_thr > 0.0) {
+    // (the streaming paths ran k_estimate_predict: st[5] = P - lowest pose the next relinearisation changes, 0: nothing moves)
+    pred_pose = st[5] > 0 ? (int)G.P - st[5] : (1 << 30);
+    pred_thr = relin_thr;
+    pred_valid = (try_inc || wf_full_path);
   }
   factor_valid = true;
   fact_gen = S_gen;
@@ -2581,6 +2622,7 @@ int HostGraph::sync_self() {
 }
 
 int HostGraph::enqueue_phase(int phase, double* d_buf) {
+  pred_valid = false; status_clean = false; cache_pose = -1;      // (outside the streaming update: nothing it left behind can be relied on)
   hipStream_t s = stream;
   const bool joint = pcg_iters > 0 && G.n_slots > 0 && !batch;      // un-batched joint solve: phases 31 / 32 / 33 follow phase 1
   if (phase == 0) {
@@ -2640,6 +2682,7 @@ int HostGraph::enqueue_phase(int phase, double* d_buf) {
 // The launch sequence of a phase (0, 1, 2; 3 / 4 = phase 1 before / after the factor + solve) is replayed as a hipGraph while the
 // resident graph and the exchange buffer stay the same (every pass of a distributed Gauss-Newton run): ~90 launches per pass otherwise
 int HostGraph::launch_phase(int phase, double* d_buf) {
+  pred_valid = false; status_clean = false; cache_pose = -1;      // (outside the streaming update: nothing it left behind can be relied on)
   hipStream_t s = stream;
   static const bool env_graph = !(getenv("SLIDE_NO_GRAPH") && getenv("SLIDE_NO_GRAPH")[0] == '1');
   PhaseGraph& pg = phase_graph[phase];
@@ -2671,6 +2714,7 @@ int HostGraph::launch_phase(int phase, double* d_buf) {
 }
 
 int HostGraph::dist_phase(int phase, double* d_buf) {
+  pred_valid = false; status_clean = false; cache_pose = -1;      // (outside the streaming update: nothing it left behind can be relied on)
   hipStream_t s = stream;
   factor_valid = false;      // (the phases move linearisation points and factor into S on their own schedule)
   if (phase >= 0 && phase <= 2) {
@@ -2729,6 +2773,7 @@ int HostGraph::dist_phase(int phase, double* d_buf) {
 // One distributed Gauss-Newton pass of a graph whose batch holds EVERY robot of the job (all on this GPU): phases 0 / 1 / 2 with
 // the two exchanges as device-side sums between the batch's buffers — stream-ordered, one host synchronisation at the end.
 int HostGraph::dist_pass_local(double* d_buf) {
+  pred_valid = false; status_clean = false; cache_pose = -1;      // (outside the streaming update: nothing it left behind can be relied on)
   if (!batch) { g_last_error = "dist_pass_local: the graph is in no batch"; return SLIDE_ERR_INVALID; }
   hipStream_t s = stream;
   int rc = merge_pending();
@@ -2793,6 +2838,10 @@ int HostGraph::get_pose12(int robot, uint64_t idx, double* out12) {
   if (!robot_ok(robot)) return SLIDE_ERR_INVALID;
   auto it = key2pose.find(pose_key(robot, idx));
   if (it == key2pose.end() || (size_t)it->second >= up_P) return SLIDE_MISSING;
+  if (it->second == cache_pose) {      // (the newest key frame right after its update: came back with the status words)
+    std::memcpy(out12, cache_pose12, 12 * sizeof(double));
+    return SLIDE_OK;
+  }
   SL_HIP(hipMemcpyAsync(out12, d_pose_est.d + 12 * (size_t)it->second, 12 * sizeof(double), hipMemcpyDeviceToHost, stream));
   SL_HIP(hipStreamSynchronize(stream));
   return SLIDE_OK;
@@ -2818,6 +2867,7 @@ void HostGraph::stats(int64_t* o) const {
 int64_t HostGraph::rejected() const { return n_rejected; }
 // 2 x NonlinearFactorGraph::error at the CURRENT estimate: theta <- theta (+) delta, relinearise, sum r^T r
 int HostGraph::chi2(double* out4) {
+  pred_valid = false; status_clean = false; cache_pose = -1;      // (outside the streaming update: nothing it left behind can be relied on)
   int rc = merge_pending();
   if (rc != SLIDE_OK) return rc;
   rc = upload_new();

@@ -375,6 +375,16 @@ class HostGraph {
   double wildfire_thr = 0.0;
   DevArr<double> d_dp_prev;            // the last solve's reduced solution (bounded back-substitution: k_chol_extract_y keeps it)
   int wf_T = 0;                        // block columns of it that are valid (0: none — first solve, or the buffers were re-allocated)
+  // streaming updates without a read-back in the middle (round 5): the last update predicted which variables THIS one relinearises
+  // (k_estimate_predict -> status[5]), its closing read-back brought the status words and the newest pose's estimate in one copy
+  bool pred_valid = false;             // pred_pose / pred_thr describe the delta the device holds right now
+  int pred_pose = 1 << 30;             // lowest pose whose blocks the next relinearisation changes (1 << 30: none)
+  double pred_thr = -1.0;
+  bool status_clean = false;           // the status words are zero (k_final_pack left them so)
+  DevArr<double> d_final;              // 16 doubles: k_final_pack's output
+  int cache_pose = -1;                 // pose index whose estimate cache_pose12 holds (-1: none)
+  double cache_pose12[12];
+  int64_t n_pred_used = 0;
   int64_t n_wf_kept = 0, last_wf_kept = 0;
   bool inc_enabled = true;
 

@@ -1527,6 +1527,43 @@ __device__ __forceinline__ void k_estimate_body(const GraphDev& G) {
   }
 }
 __global__ void k_estimate(GraphDev G) { k_estimate_body(G); }
+// Streaming updates (round 5): k_estimate that also PREDICTS the next update's relinearisation — delta does not change between two
+// solves, so the variables k_relin will move next time (|delta|_inf >= threshold) are known now; the lowest pose whose blocks they
+// change (mark_dirty_pose / mark_dirty_lm, as k_relin reports it in status[6]) goes to status[5] as P - pose.  The host reads it with
+// this update's status words and needs no read-back between k_relin and the rest of the next update.
+__global__ void k_estimate_predict(GraphDev G) {
+  k_estimate_body(G);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int dirty = 0;
+  if (t < G.P) {
+    double mx = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) mx = fmax(mx, fabs(G.pose_delta[6 * (size_t)t + k]));
+    if (mx >= G.relin_thr) dirty = mark_dirty_pose(G, t);
+  } else if (t < G.P + G.L) {
+    const int l = t - G.P;
+    const int d = lm_dim(G.lm_type[l]);
+    double mx = 0.0;
+    for (int k = 0; k < d; ++k) mx = fmax(mx, fabs(G.lm_delta[9 * (size_t)l + k]));
+    if (mx >= G.relin_thr) dirty = mark_dirty_lm(G, l);
+  }
+  if (__ballot(dirty > 0)) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dirty = max(dirty, __shfl_xor(dirty, off));
+    if ((threadIdx.x & 63) == 0 && dirty > 0) atomicMax(&G.status[5], dirty);
+  }
+}
+// the update's closing read-back in ONE piece: the eight status words and the estimate of pose `pose` (the newest key frame, what a frame
+// returns) side by side; the status words are left at zero for the next update (its k_relin counts into them)
+__global__ void k_final_pack(GraphDev G, int pose, double* __restrict__ out) {
+  const int t = threadIdx.x;
+  if (t < 8) {
+    reinterpret_cast<int*>(out)[t] = G.status[t];
+    G.status[t] = 0;
+  } else if (t < 20) {
+    out[4 + (t - 8)] = pose >= 0 ? G.pose_est[12 * (size_t)pose + (t - 8)] : 0.0;
+  }
+}
 __global__ void k_estimate_b(const GraphDev* __restrict__ Gs) { k_estimate_body(Gs[blockIdx.z]); }
 
 // sum of squared whitened residuals of every factor at the last linearisation point (NonlinearFactorGraph::error x 2): one workgroup,
@@ -1708,6 +1745,13 @@ void launch_ghost_exchange(const GraphDev& G, int what, double* buf, hipStream_t
 void launch_estimate(const GraphDev& G, hipStream_t s) {
   if (G.P + G.L == 0) return;
   hipLaunchKernelGGL(k_estimate, dim3(blocks_for(G.P + G.L, 256)), dim3(256), 0, s, G);
+}
+void launch_estimate_predict(const GraphDev& G, hipStream_t s) {
+  if (G.P + G.L == 0) return;
+  hipLaunchKernelGGL(k_estimate_predict, dim3(blocks_for(G.P + G.L, 256)), dim3(256), 0, s, G);
+}
+void launch_final_pack(const GraphDev& G, int pose, double* out16, hipStream_t s) {
+  hipLaunchKernelGGL(k_final_pack, dim3(1), dim3(64), 0, s, G, pose, out16);
 }
 
 void launch_sep_extract_batched(const GraphDev* d, const GraphDev* h, int n, const int* n_sep_poses, hipStream_t s) {
