@@ -120,6 +120,9 @@ struct GraphDev {
   // ---- incremental re-factorisation of the streaming path (HostGraph::run_update) --------------------------------------------------
   const int* lm_first; // L   the first (lowest-index) pose observing a landmark: k_relin reports, in status[6], P - (the lowest pose whose
                        //     rows of the reduced system a relinearisation changes) — 0: nothing was relinearised
+  int pose0;           // first DIRTY pose of an incremental update (0: everything): the factors of earlier poses, the landmarks no pose >= pose0
+                       // observes and those poses' own blocks keep the last solve's linearisation, Schur records, H_pp and g_p (nothing they
+                       // depend on moved: HostGraph::run_update) — the linearisation / landmark / pose kernels leave them alone
   int col0;            // columns of S below it hold the factor of the last solve and are left alone by the assembly (k_schur, k_pad_rhs);
                        // their right-hand-side entries are the forward-substituted ones of that solve (yv).  0: assemble everything.
   // ---- Schur assembly from pair lists (batched exact passes: the topology is fixed between the passes) ------------------------------

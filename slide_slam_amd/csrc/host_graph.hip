@@ -1870,6 +1870,8 @@ int HostGraph::upload_new() {
   UP(d_pr_pose, h_pr_pose, up_pr, 1);
   UP(d_pr_z, h_pr_z, up_pr, 12);
   UP(d_pr_sigma, h_pr_sigma, up_pr, 6);
+  // (the buffers of the last linearisation: an incremental update keeps what nothing touched — HostGraph::lin_gen counts their re-allocations)
+  const size_t lin_caps0 = d_pr_r.cap + d_bt_r.cap + d_bt_J0.cap + d_jbuf.cap + d_ebuf.cap + d_lm_Hinv.cap + d_lm_g.cap + d_pose_H.cap + d_pose_g.cap;
   if (d_pr_r.ensure(std::max<size_t>(6 * npr, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   UP(d_bt_i, h_bt_i, up_bt, 1);
   UP(d_bt_j, h_bt_j, up_bt, 1);
@@ -1904,6 +1906,7 @@ int HostGraph::upload_new() {
   if (d_lm_t.ensure(std::max<size_t>(9 * Ln, 1), 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_pose_H.ensure(std::max<size_t>(36 * Pn, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_pose_g.ensure(std::max<size_t>(6 * Pn, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (d_pr_r.cap + d_bt_r.cap + d_bt_J0.cap + d_jbuf.cap + d_ebuf.cap + d_lm_Hinv.cap + d_lm_g.cap + d_pose_H.cap + d_pose_g.cap != lin_caps0) ++lin_gen;
   std::vector<int> ptr, val;
   if (up_csr(d_lm_ptr, d_lm_fids, lm_fids, ptr, val, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (up_csr(d_pose_ptr, d_pose_fids, pose_fids, ptr, val, s) != SLIDE_OK) return SLIDE_ERR_HIP;
@@ -2275,7 +2278,7 @@ int HostGraph::upload_new() {
     SL_HIP(hipStreamSynchronize(s));
   }
   G.status = d_status.d;
-  G.lm_first = d_lm_first.d; G.col0 = 0;
+  G.lm_first = d_lm_first.d; G.col0 = 0; G.pose0 = 0;
   G.chart = P.pose_chart;
   G.bearing_sigma = P.bearing_range_sigma; G.cyl_sigma = P.cylinder_sigma; G.numdiff_delta = P.numdiff_delta;
   launch_pose_adj(G, s);             // the topology changed: rebuild the pose adjacency of the Schur assembly
@@ -2475,8 +2478,13 @@ int HostGraph::run_update(double relin_thr, int iterations) {
     int c_d = pmin >= G.P ? G.T : (6 * std::max(pmin, 0)) / NB;      // (nothing dirty: no step at all, the substitutions are simply repeated)
     c_d = std::min(c_d, G.T);
     G.col0 = c_d * NB;
+    // the linearisation, the landmark sums / Schur records and the poses' own blocks of everything BEFORE the first dirty pose are the
+    // last solve's (nothing they depend on moved — that is what "dirty" means); the kernels skip them when those buffers still hold them
+    static const bool env_skip = !(getenv("SLIDE_NO_LIN_SKIP") && getenv("SLIDE_NO_LIN_SKIP")[0] == '1');
+    G.pose0 = (env_skip && lin_solved_gen == lin_gen) ? std::max(0, std::min(pmin, (int)G.P)) : 0;
     const int rc = enqueue_iteration(false, true, c_d);
     G.col0 = 0;
+    G.pose0 = 0;
     if (rc != SLIDE_OK) return rc;
     if (c_d > 0) ++n_inc; else ++n_full;
     last_cd = c_d;
@@ -2543,6 +2551,7 @@ int HostGraph::run_update(double relin_thr, int iterations) {
   }
   factor_valid = true;
   fact_gen = S_gen;
+  lin_solved_gen = lin_gen;         // (every linearisation buffer holds this solve's state)
   dirty_min_pose = 1 << 30;
   wf_T = G.T;                       // (dp holds this solve's solution for every block column)
   last_wf_kept = st[3];

@@ -377,6 +377,7 @@ class HostGraph {
   int wf_T = 0;                        // block columns of it that are valid (0: none — first solve, or the buffers were re-allocated)
   // streaming updates without a read-back in the middle (round 5): the last update predicted which variables THIS one relinearises
   // (k_estimate_predict -> status[5]), its closing read-back brought the status words and the newest pose's estimate in one copy
+  unsigned long long lin_gen = 1, lin_solved_gen = 0;      // re-allocations of the linearisation buffers (their contents are dropped) / the value at the last successful solve
   bool pred_valid = false;             // pred_pose / pred_thr describe the delta the device holds right now
   int pred_pose = 1 << 30;             // lowest pose whose blocks the next relinearisation changes (1 << 30: none)
   double pred_thr = -1.0;

@@ -130,6 +130,7 @@ __global__ void k_relin_b(const GraphDev* __restrict__ Gs) { k_relin_body(Gs[blo
 __device__ __forceinline__ void k_lin_pose_factors_body(const GraphDev& G) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < G.n_prior) {
+    if (G.pr_pose[t] < G.pose0) return;      // (incremental update: nothing this factor depends on moved)
     // r = -Local(x, prior), J = I
     const SE3 X = from12(G.pose_val + 12 * (size_t)G.pr_pose[t]);
     const SE3 Z = from12(G.pr_z + 12 * (size_t)t);
@@ -139,6 +140,7 @@ __device__ __forceinline__ void k_lin_pose_factors_body(const GraphDev& G) {
     for (int k = 0; k < 6; ++k) G.pr_r[6 * t + k] = -l[k] / G.pr_sigma[6 * t + k];
   } else if (t < G.n_prior + G.n_between) {
     const int b = t - G.n_prior;
+    if (min(G.bt_i[b], G.bt_j[b]) < G.pose0) return;      // (a relinearised pose dirties its partners: an untouched partner means an untouched factor)
     const SE3 X1 = from12(G.pose_val + 12 * (size_t)G.bt_i[b]);
     const SE3 X2 = from12(G.pose_val + 12 * (size_t)G.bt_j[b]);
     const SE3 Z = from12(G.bt_z + 12 * (size_t)b);
@@ -214,6 +216,7 @@ __device__ __forceinline__ void k_lin_lf_body(const GraphDev& G, int nb1) {
   const int type = G.lf_type[f];
   if ((type == FT_BR) != br_region) return;
   const int p = G.lf_pose[f], l = G.lf_lm[f], slot = G.lf_slot[f];
+  if (p < G.pose0) return;      // (incremental update: neither this pose nor the landmark moved — a moved landmark dirties its first observer)
   double* out = G.jbuf + G.lf_joff[f];
   const SE3 X = from12(G.pose_val + 12 * (size_t)p);
   const double* lv = G.lm_val + 15 * (size_t)l;
@@ -523,6 +526,13 @@ __device__ __forceinline__ void k_landmark_body(const GraphDev& G) {
   const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (l >= G.L) return;
   const int lane = threadIdx.x & 63;
+  if (G.pose0 > 0) {
+    // incremental update: a landmark no pose >= pose0 observes keeps its sums, inverse and Schur records (a new or moved factor, or
+    // the landmark's own relinearisation, would have put its FIRST observer at or above pose0)
+    bool any = false;
+    for (int q = G.lm_ptr[l] + lane; q < G.lm_ptr[l + 1]; q += 64) any = any || G.lf_pose[G.lm_fids[q]] >= G.pose0;
+    if (!__ballot(any)) return;
+  }
   const int type = G.lm_type[l];
   if (type == VT_POINT) landmark_wave<3, MODE>(G, l, lane);
   else if (type == VT_CUBE) landmark_wave<9, MODE>(G, l, lane);
@@ -547,7 +557,7 @@ __device__ __forceinline__ void k_pose_body(const GraphDev& G) {
   __shared__ double part[4][27][65];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int p = blockIdx.x * 4 + wave;
-  if (p >= G.P) return;
+  if (p >= G.P || p < G.pose0) return;      // (incremental update: an earlier pose's H_pp and g_p are the last solve's)
   double H[21], g[6];       // lower triangle, index a (a + 1) / 2 + c, c <= a
 #pragma unroll
   for (int i = 0; i < 21; ++i) H[i] = 0.0;

@@ -6,7 +6,7 @@ timeout -k 10 900 python -m pytest tests/test_golden.py tests/test_gpu_graph.py 
 rc=$?
 tail -6 gpurun_out/r5_stream_tests.log
 if [ $rc -ne 0 ]; then exit 1; fi
-for v in SLIDE_NO_PREDICT=1 SLIDE_NO_PREDICT=0; do
+for v in SLIDE_NO_LIN_SKIP=1 SLIDE_NO_LIN_SKIP=0; do
 env $v timeout -k 10 300 python - <<'PY'
 import os, sys, time
 import numpy as np
@@ -23,6 +23,6 @@ for wf in (0.0, 1e-3):
     if wf: gb.graph.set_wildfire(wf)
     out = replay_single(gb, lg, collect=False)
     t = np.array(out["t_frame"]) * 1e3
-    print(os.environ.get("SLIDE_NO_PREDICT"), "wildfire", wf, "ms/frame mean %.4f last100 %.4f max %.3f" % (t.mean(), t[-100:].mean(), t.max()), gb.graph.incremental_stats())
+    print(os.environ.get("SLIDE_NO_LIN_SKIP"), "wildfire", wf, "ms/frame mean %.4f last100 %.4f max %.3f" % (t.mean(), t[-100:].mean(), t.max()), gb.graph.incremental_stats())
 PY
 done
