@@ -486,7 +486,7 @@ def _pmc_traffic(kernel, **match):
     """HBM-side bytes per launch of `kernel` from the committed PMC summaries (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     passes, gfx950 corrections applied; a PMC pass cannot run inside the timed bench): newest round first."""
     pdir = os.path.join(ROOT, "profiles")
-    for rnd in ("r04", "r03", "r02_dense", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02_dense", "r02", "r01"):
         for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
             if not (name.startswith(rnd + "_pmc_traffic") and name.endswith(".json")):
                 continue
