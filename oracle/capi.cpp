@@ -218,6 +218,22 @@ void orc_graph_set_relin_threshold(void* h, double thr) { ((Graph*)h)->P.relin_t
 // [GTSAM] iSAM2's wildfire threshold on the back-substitution (Graph::wildfire_bound); 0 = off (the default); out3: blocks kept in
 // total, in the last solve, the last solve's first dirty block column
 void orc_graph_set_wildfire(void* h, double thr) { ((Graph*)h)->P.wildfire_threshold = thr > 0.0 ? thr : 0.0; }
+// the rule on plain arrays (unit test of Graph::wildfire_bound): dp (n doubles, the exact solution, overwritten), prev (the last solve's,
+// T * 64 doubles), prof_last[c] = last block row in the profile of block column c, c_d = the first dirty block column; returns the blocks kept
+int orc_wildfire_rule(double* dp, const double* prev, int n, int T, const int* prof_last, int c_d, double thr) {
+  Graph g;
+  g.P.wildfire_threshold = thr;
+  g.wf_prev.assign(prev, prev + (size_t)T * 64);
+  g.wf_Tprev = T;
+  g.wf_dirty_min_pose = (c_d * 64 + 5) / 6;      // the lowest pose whose first coordinate lies in block column c_d
+  CholProfile pf;
+  pf.rend.resize(T);
+  for (int c = 0; c < T; ++c) pf.rend[c] = std::min(n, (prof_last[c] + 1) * 64);
+  std::vector<double> v(dp, dp + n);
+  g.wildfire_bound(v, n, pf);
+  std::memcpy(dp, v.data(), sizeof(double) * n);
+  return g.wf_kept_last;
+}
 void orc_graph_wildfire_stats(void* h, long long* out3) {
   const Graph* g = (const Graph*)h;
   out3[0] = g->wf_kept_total; out3[1] = g->wf_kept_last; out3[2] = g->wf_last_cd;
