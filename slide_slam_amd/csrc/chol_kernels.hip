@@ -694,11 +694,21 @@ struct CholBatchArgs {
   int a_base[CHOL_STEP_BATCH_MAX + 1];      // prefix sums of the type-A workgroup counts
   int b_base[CHOL_STEP_BATCH_MAX + 1];      // prefix sums of the type-B item counts
 };
-__global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int k, int kb, int* __restrict__ ctr, int a_joins) {
+// XCD-aware numbering of the type-A workgroups (round 5; cdna_hip_programming.md T1): blocks b and b + 8 share an XCD (round-robin
+// placement, observed), and the type-A workgroups of ONE system all read the same diagonal tile and pending panel tile — numbered
+// consecutively they sit on eight different XCDs and every L2 fetches those tiles for itself, all at the start of the launch.  The
+// bijective remap below gives the blocks of one XCD a run of consecutive logical numbers, so a system's workgroups share (mostly) one
+// L2.  Speed only: any placement is correct.  SLIDE_CHOL_XCD=1 turns it on; off by default: the C4 pass does not move (2.134 vs 2.134 ms).
+__device__ __forceinline__ int xcd_logical(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+__global__ __launch_bounds__(512) void k_chol_step_batched(CholBatchArgs A, int k, int kb, int* __restrict__ ctr, int a_joins, int xcd_map) {
   __shared__ ALds L;
   __shared__ int s_g;
   if (blockIdx.x == 0 && threadIdx.x == 0) ctr[k + 1] = 0;
-  const int bid = (int)blockIdx.x;
+  int bid = (int)blockIdx.x;
+  if (xcd_map && bid < A.a_base[A.n]) bid = xcd_logical(bid, A.a_base[A.n]);
   if (bid < A.a_base[A.n]) {
     int r = 0;
     while (bid >= A.a_base[r + 1]) ++r;
@@ -3230,7 +3240,8 @@ void launch_chol_batch(const CholSystem* d, int n, int* ctr, hipStream_t s, hipE
     const long long extra = nB < n_cu ? nB : n_cu;
     const long long free_cu = n_cu - nAw > 8 ? n_cu - nAw : 8;
     const int a_joins = nB > free_cu ? 1 : 0;
-    hipLaunchKernelGGL(k_chol_step_batched, dim3((unsigned)(nAw + extra)), dim3(512), 0, s, A, k, k & ~1, ctr, a_joins);
+    static const int xcd_map = getenv("SLIDE_CHOL_XCD") ? atoi(getenv("SLIDE_CHOL_XCD")) : 0;      // measured r5: 0.529 vs 0.526 ms of band factorisations (noise) - opt-in
+    hipLaunchKernelGGL(k_chol_step_batched, dim3((unsigned)(nAw + extra)), dim3(512), 0, s, A, k, k & ~1, ctr, a_joins, (xcd_map && n > 1) ? 1 : 0);
   }
   if (Tmax < 0) Tmax = -Tmax;
   if (after_steps) (void)hipEventRecord(after_steps, s);

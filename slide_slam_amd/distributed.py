@@ -354,7 +354,7 @@ def setup_local_shards(shards, matcher, base=None, rank=0, world=1, thresh=(2.0,
     bufs, n_slots = [], 0
     if device is not None:
         import torch
-        alloc = lambda n: torch.zeros(n, dtype=torch.float64, device=device)
+        alloc = lambda n: _device_zeros(torch, n, device)
         handle = lambda b: b.data_ptr()
     else:
         alloc = lambda n: np.zeros(n)
@@ -402,11 +402,20 @@ def setup_local_shards(shards, matcher, base=None, rank=0, world=1, thresh=(2.0,
             base.all_reduce(total, n15)
         for b in bufs:
             b[:n15] = total
-        if device is not None:
-            torch.cuda.synchronize()
+        if device is not None:      # (torch's stream only: a device-wide wait would invalidate a capture another rank thread has going)
+            torch.cuda.current_stream(device).synchronize()
     for t, sh in enumerate(shards):
         sh.graph.dist_phase(11, handle(bufs[t]))
     return bufs, dict(n_slots=n_slots, n_global=n_global, sep_dim=int(sep_off[-1]), sep_off=sep_off, sep_prof=sep_prof)
+
+
+def _device_zeros(torch, n, device):
+    """n zero doubles on the device, COMPLETE when this returns.  torch.zeros only enqueues the fill on torch's current stream; the
+    buffer's first writers are kernels of non-blocking HIP streams, which nothing orders behind that stream — a fill that is still
+    queued (the streams of several rank threads share hardware queues) would land on top of what they wrote."""
+    buf = torch.zeros(n, dtype=torch.float64, device=device)
+    torch.cuda.current_stream(device).synchronize()
+    return buf
 
 
 class PassDriver:
@@ -570,7 +579,7 @@ class PassDriver:
         if self.sep is None:
             import torch
             self.sep_len = self.batch.sep_buffer_len(self.sep_dim, getattr(self, "n_relmeas", 0))
-            self.sep = torch.zeros(max(self.sep_len, 1), dtype=torch.float64, device=self.device)
+            self.sep = _device_zeros(torch, max(self.sep_len, 1), self.device)
             self.batch.set_exact_joint(True, self.sep.data_ptr(), self.sep_len)
             blocks = getattr(self, "sep_blocks", None)
             if blocks is not None:      # (a dissected layout: the zero block between the leaves is not part of the packed exchange)
@@ -631,7 +640,7 @@ class PassDriver:
             b[:count] = self.bufs[0][:count]
         if self.device is not None:          # (torch's stream; the shards' own streams read the buffers next)
             import torch
-            torch.cuda.synchronize()
+            torch.cuda.current_stream(self.device).synchronize()
 
     def _all(self, count):
         self._local_sum(count); self._exchange(count); self._local_bcast(count)
@@ -770,7 +779,7 @@ class TorchComm:
     def alloc(self, n):
         if self.device is None:
             return np.zeros(n)
-        return self.torch.zeros(n, dtype=self.torch.float64, device=self.device)
+        return _device_zeros(self.torch, n, self.device)
 
     def handle(self, buf):
         return buf if self.device is None else buf.data_ptr()
@@ -890,7 +899,7 @@ class LocalRankComm:
     def alloc(self, n):
         if self.device is None:
             return np.zeros(n)
-        return self.torch.zeros(n, dtype=self.torch.float64, device=self.device)
+        return _device_zeros(self.torch, n, self.device)
 
     def handle(self, buf):
         return buf if self.device is None else buf.data_ptr()
@@ -971,7 +980,7 @@ class ThreadComm:
     def alloc(self, n):
         if self.device is None:
             return np.zeros(n)
-        return self.torch.zeros(n, dtype=self.torch.float64, device=self.device)
+        return _device_zeros(self.torch, n, self.device)
 
     def handle(self, buf):
         return buf if self.device is None else buf.data_ptr()
