@@ -937,6 +937,491 @@ __global__ __launch_bounds__(512, 4) void k_assoc_sweep_512(const float* __restr
   assoc_core(C);
 }
 
+// ---- round 5: the sweep with the distance words in REGISTERS -----------------------------------------------------------------------
+// k_assoc_sweep_512 keeps a frame's n distance words in LDS (40 KB for the 10 k-landmark map) next to 16 KB of select tables, 8 KB of
+// keys and — during the matching — the survivors' double-precision models: 66 KB, two workgroups per CU, and every phase of a frame
+// ends at a workgroup barrier (a frame alone on a CU takes 18.3 us, two side by side 21.5 us each: the phases are latency, not issue).
+// Here a thread keeps ITS keys (map index tid + j * 512, j < NK) in NK registers from the distance scan to the placement of the selected
+// keys — the select's passes never revisit anybody else's — and the exact rule of the matching reads the one or two models it needs
+// from memory instead of LDS copies of all K: 38 KB of LDS per workgroup, THREE workgroups per CU.  Same select (one histogram over bins
+// linear in the squared distance, ranks inside the K-th key's bin, digit passes when that bin overflows), same label groups, same
+// screening bound, same exact rule: the matches are the same ids (tests/test_gpu_kernels.py sweep tests run through this kernel).
+// For: label-gated boxes / points, no submap list asked for, n <= NK * 512, K <= 1024, at most 64 detections per frame.
+// Wave-wide reductions and scans on DPP row operations: __shfl_xor / __shfl_up go through ds_bpermute, whose six lane-address registers per
+// shuffle pattern the compiler keeps for the whole kernel — a dozen of the eighty vector registers of k_assoc_sweep_r.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {      // result uniform (scalar)
+  v = max(v, (unsigned)dpp_i32<0xB1>((int)v));      // quad_perm [1,0,3,2]
+  v = max(v, (unsigned)dpp_i32<0x4E>((int)v));      // quad_perm [2,3,0,1]
+  v = max(v, (unsigned)dpp_i32<0x141>((int)v));     // row_half_mirror
+  v = max(v, (unsigned)dpp_i32<0x140>((int)v));     // row_mirror: every lane of a row of sixteen holds the row's maximum
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16),
+                 c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ float wave_min_f32(float v) {            // result uniform
+  v = fminf(v, __int_as_float(dpp_i32<0xB1>(__float_as_int(v))));
+  v = fminf(v, __int_as_float(dpp_i32<0x4E>(__float_as_int(v))));
+  v = fminf(v, __int_as_float(dpp_i32<0x141>(__float_as_int(v))));
+  v = fminf(v, __int_as_float(dpp_i32<0x140>(__float_as_int(v))));
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)),
+              c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return fminf(fminf(a, b), fminf(c, d));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {            // v >= 0: the bit patterns order like the values
+  return __uint_as_float(wave_max_u32(__float_as_uint(v)));
+}
+__device__ __forceinline__ int wave_incl_scan_i32(int v, int lane) {
+  v += dpp_i32<0x111>(v);      // row_shr:1 (lanes without a source inside their row of sixteen add 0)
+  v += dpp_i32<0x112>(v);
+  v += dpp_i32<0x114>(v);
+  v += dpp_i32<0x118>(v);
+  const int s0 = __builtin_amdgcn_readlane(v, 15), s1 = __builtin_amdgcn_readlane(v, 31), s2 = __builtin_amdgcn_readlane(v, 47);
+  return v + (lane >= 16 ? s0 : 0) + (lane >= 32 ? s1 : 0) + (lane >= 48 ? s2 : 0);
+}
+
+template <int NK, int NTHR>
+__device__ __forceinline__ void sweep_core_r(const AssocCore& C) {
+  __shared__ unsigned long long sbuf64[1536];      // 12 KB: bin counts (1024 x 4 B) + candidate keys (1024 x 8 B); the fallback's per-wave digit histograms (8 x 256 x 4 B) + their sums
+  __shared__ int s_dl[ASSOC_GMAX], s_dgrp[ASSOC_GMAX], s_glab[ASSOC_GMAX], s_gcnt[ASSOC_GMAX], s_gcur[ASSOC_GMAX], s_goff[ASSOC_GMAX], s_ng;
+  __shared__ unsigned long long s_prefix;
+  __shared__ int s_krem, s_stop, s_cnt, s_ccnt, s_bin, s_before;
+  __shared__ unsigned s_wred[16];
+  __shared__ unsigned s_cmax;
+  unsigned* lhist = reinterpret_cast<unsigned*>(sbuf64);
+  unsigned long long* lcand = sbuf64 + ASSOC_BINS / 2;
+  unsigned* whist = reinterpret_cast<unsigned*>(sbuf64);
+  unsigned* hist = whist + 2048;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int nthr = NTHR, nw = NTHR >> 6;
+  const int n = C.n, Ksub = C.K < n ? C.K : n;
+  unsigned long long* sel = assoc_lds;
+  float* fx = reinterpret_cast<float*>(assoc_lds + C.Kp);
+  float* fy = fx + Ksub;
+  float* fz = fx + 2 * (size_t)Ksub;
+  int* sidx = reinterpret_cast<int*>(fx + 3 * (size_t)Ksub);
+  ASTAMP(0);
+  if (tid < ASSOC_GMAX) { s_dl[tid] = tid < C.n_det ? C.det_label[tid] : 0; s_gcnt[tid] = 0; s_gcur[tid] = 0; }
+  for (int b = tid; b < ASSOC_BINS; b += nthr) lhist[b] = 0u;
+  if (tid == 0) { s_prefix = 0ull; s_krem = Ksub; s_stop = 0; s_cnt = 0; s_ccnt = 0; s_bin = -1; s_before = 0; s_cmax = 0u; }
+  // (uniform values the vector ALU produced go back to scalar registers: the kernel has 80 vector registers and needs every one)
+  auto uni = [](float v) -> float { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+  const float qx = uni((float)C.qpos[0]), qy = uni((float)C.qpos[1]), qz = uni((float)C.qpos[2]);
+  // ---- the own keys' distance words: LD loads in flight per stream, straight-line (indices clamped, not branched around) ----
+  // Round j of a thread's keys is map index tid + j * nthr.  Which rounds exist is decided by ONE lane predicate (tid < rem, the partial
+  // round) and scalar compares — twenty per-round index registers and twenty compare masks, kept alive from here to the placement, were
+  // what made the first version of this kernel spill.
+  unsigned r[NK];
+  unsigned bmax = 0u;
+  constexpr int LD = 2;
+  const int nlast = n - 1;
+  const int jfull = n / nthr, rem = n - jfull * nthr;
+  const bool in_rem = tid < rem;
+  auto valid = [&](int j) -> bool { return j < jfull || (j == jfull && in_rem); };
+  auto fresh_tid = [&]() -> int { int t = tid; asm volatile("" : "+v"(t)); return t; };      // (a new value: indices derived from it are not kept across phases)
+  const int t1 = fresh_tid();
+#pragma unroll
+  for (int j0 = 0; j0 < NK; j0 += LD) {
+    float x[LD], y[LD], z[LD];
+#pragma unroll
+    for (int u = 0; u < LD; ++u) {
+      if (j0 + u < NK) {
+        const int i = t1 + (j0 + u) * nthr;
+        const int ic = i < nlast ? i : nlast;
+        x[u] = C.cx[ic]; y[u] = C.cy[ic]; z[u] = C.cz[ic];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < LD; ++u) {
+      if (j0 + u < NK) {
+        const float dx = x[u] - qx, dy = y[u] - qy, dz = z[u] - qz;
+        float d = dx * dx;
+        d += dy * dy;
+        d += dz * dz;
+        const unsigned b = __float_as_uint(d);       // (the arithmetic of dist_bits)
+        r[j0 + u] = b;
+        if (valid(j0 + u)) bmax = b > bmax ? b : bmax;
+        // (consumed here: without the pin the scheduler issues all NK x 3 loads first and their sixty results spill)
+        asm volatile("" : "+v"(r[j0 + u]) : : "memory");
+      }
+    }
+  }
+  bmax = wave_max_u32(bmax);
+  if (lane == 0) s_wred[wave] = bmax;
+  __syncthreads();
+  ASTAMP(1);
+  // (the overflow path below recomputes its keys from the cloud: the register copies are not kept alive for it)
+  auto key_at_g = [&](int i) -> unsigned long long { return ((unsigned long long)dist_bits(C, i, qx, qy, qz) << 32) | (unsigned)i; };
+  int t3 = 0;      // (a fresh copy of the thread index, taken where the keys are written)
+  // a key = (distance word << 32) | map index, written as its two halves (one ds_write2_b32): formed as 64-bit values the twenty keys
+  // want twenty aligned register pairs
+  auto put_key = [&](unsigned long long* dst, int j) {
+    unsigned* p2 = reinterpret_cast<unsigned*>(dst);
+    p2[0] = (unsigned)(t3 + j * nthr);
+    p2[1] = r[j];
+  };
+  float scale = 0.0f;
+  auto bin_of = [&](unsigned bits) -> int {
+    const int b = (int)(__uint_as_float(bits) * scale);
+    return b < ASSOC_BINS - 1 ? b : ASSOC_BINS - 1;
+  };
+  int fbin = -1, shift = 64;
+  bool ranked = false;
+  if (n > 0 && Ksub < n) {
+    for (int w = 0; w < nw; ++w) bmax = s_wred[w] > bmax ? s_wred[w] : bmax;
+    const float rmax = __uint_as_float(bmax);
+    scale = rmax > 0.0f ? ((float)ASSOC_BINS - 0.5f) / rmax : 0.0f;
+    if (!(scale == scale) || scale > 3.0e38f) scale = 0.0f;
+    scale = uni(scale);
+#pragma unroll
+    for (int j = 0; j < NK; ++j)
+    {
+      asm volatile("" : "+v"(r[j]));      // (one bin address at a time: twenty computed ahead of their atomics are twenty more registers)
+      if (valid(j)) atomicAdd(&lhist[bin_of(r[j])], 1u);
+    }
+    __syncthreads();
+    ASTAMP(12);
+    {
+      const int per = (ASSOC_BINS + nthr - 1) / nthr;
+      unsigned own = 0;
+      for (int k = 0; k < per; ++k) { const int bb = tid * per + k; if (bb < ASSOC_BINS) own += lhist[bb]; }
+      const unsigned inc = (unsigned)wave_incl_scan_i32((int)own, lane);
+      if (lane == 63) s_wred[wave] = inc;
+      __syncthreads();
+      unsigned base = 0;
+      for (int w = 0; w < wave; ++w) base += s_wred[w];
+      const unsigned before_t = base + inc - own;
+      if (before_t < (unsigned)Ksub && (unsigned)Ksub <= before_t + own) {      // exactly one thread: the counts sum to n >= K
+        unsigned before = before_t;
+        int bb = tid * per;
+        while (before + lhist[bb] < (unsigned)Ksub) { before += lhist[bb]; ++bb; }
+        s_bin = bb;
+        s_before = (int)before;
+        s_krem = Ksub - (int)before;
+      }
+      __syncthreads();
+    }
+    ASTAMP(13);
+    fbin = s_bin;
+    const int before = s_before, krem = s_krem;
+    const int ncand = (int)lhist[fbin];
+    if (ncand <= ASSOC_CAND_CAP) {
+      unsigned tm = 0u, cm = 0u;
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        asm volatile("" : "+v"(r[j]));
+        if (valid(j)) {
+          const int b = bin_of(r[j]);
+          tm |= (b < fbin ? 1u : 0u) << j;
+          cm |= (b == fbin ? 1u : 0u) << j;
+        }
+      }
+      t3 = fresh_tid();
+      const int ct = __popc(tm), cc = __popc(cm);
+      const int st = wave_incl_scan_i32(ct, lane), sc = wave_incl_scan_i32(cc, lane);
+      int bt = 0, bc = 0;
+      if (lane == 63) {
+        if (st > 0) bt = atomicAdd(&s_cnt, st);
+        if (sc > 0) bc = atomicAdd(&s_ccnt, sc);
+      }
+      bt = __builtin_amdgcn_readlane(bt, 63) + st - ct;
+      bc = __builtin_amdgcn_readlane(bc, 63) + sc - cc;
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        if ((tm >> j) & 1u) put_key(&sel[bt++], j);
+        if ((cm >> j) & 1u) put_key(&lcand[bc++], j);
+      }
+      __syncthreads();
+      ASTAMP(14);
+      for (int jj = tid; jj < ncand; jj += nthr) {
+        const unsigned long long kj = lcand[jj];
+        int rank = 0;
+        for (int i = 0; i < ncand; ++i) rank += lcand[i] < kj ? 1 : 0;
+        if (rank < krem) sel[before + rank] = kj;
+      }
+      ranked = true;
+    } else {
+      // the K-th key's bin overflows the candidate list: most-significant-digit passes over the keys of that bin (as knn_select)
+      __syncthreads();
+      for (int byte = 7; byte >= 0; --byte) {
+        shift = 8 * byte;
+        for (int b = tid; b < 256 * nw; b += nthr) whist[b] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        unsigned* mine = whist + 256 * wave;
+        for (int i = tid; i < n; i += nthr) {
+          const unsigned long long key = key_at_g(i);
+          if (bin_of((unsigned)(key >> 32)) != fbin) continue;
+          if (byte == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&mine[(unsigned)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        for (int b = tid; b < 256; b += nthr) {
+          unsigned t = 0;
+          for (int w = 0; w < nw; ++w) t += whist[256 * w + b];
+          hist[b] = t;
+        }
+        __syncthreads();
+        if (tid < 64) {
+          const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+          const unsigned own = h0 + h1 + h2 + h3;
+          unsigned inc = own;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = (unsigned)__shfl_up((int)inc, off);
+            if (lane >= off) inc += o;
+          }
+          const unsigned kr = (unsigned)s_krem;
+          const unsigned long long reach = __ballot(inc >= kr);
+          const int first = __ffsll((long long)reach) - 1;
+          if (lane == first) {
+            unsigned bef = inc - own;
+            unsigned d = 4 * lane, cnt = h0;
+            if (bef + h0 < kr) { bef += h0; d += 1; cnt = h1;
+              if (bef + h1 < kr) { bef += h1; d += 1; cnt = h2;
+                if (bef + h2 < kr) { bef += h2; d += 1; cnt = h3; } } }
+            s_prefix = prefix | ((unsigned long long)d << shift);
+            s_krem = (int)(kr - bef);
+            s_stop = (bef + cnt == kr) ? 1 : 0;
+          }
+        }
+        __syncthreads();
+        if (s_stop) break;
+      }
+    }
+  }
+  ASTAMP(2);
+  if (fbin < 0) {
+    t3 = fresh_tid();
+#pragma unroll
+    for (int j = 0; j < NK; ++j)
+      if (valid(j)) put_key(&sel[t3 + j * nthr], j);
+  } else if (!ranked) {
+    const unsigned long long lim = shift < 64 ? (s_prefix >> shift) : 0ull;
+    auto taken = [&](unsigned long long key) -> bool {
+      const int b = bin_of((unsigned)(key >> 32));
+      if (b != fbin) return b < fbin;
+      return (key >> shift) <= lim;
+    };
+    const int n_up = (n + nthr - 1) / nthr * nthr;
+    int mine = 0;
+    for (int i = tid; i < n_up; i += nthr) mine += __popcll(__ballot(i < n && taken(key_at_g(i < n ? i : 0))));      // (wave-uniform)
+    int base = 0;
+    if (lane == 0 && mine > 0) base = atomicAdd(&s_cnt, mine);
+    base = __shfl(base, 0);
+    for (int i = tid; i < n_up; i += nthr) {
+      const unsigned long long key = key_at_g(i < n ? i : 0);
+      const bool take = i < n && taken(key);
+      const unsigned long long m = __ballot(take);
+      if (take) sel[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+      base += __popcll(m);
+    }
+  }
+  __syncthreads();
+  ASTAMP(3);
+  ASTAMP(4);
+  // (the thread index as a NEW value: what the phases below derive from it — addresses, lane masks, predicates — is otherwise computed at
+  // the kernel's entry and kept in registers across the select, whose twenty key registers then spill)
+  int tidb = tid;
+  asm volatile("" : "+v"(tidb));
+  const int laneb = tidb & 63;
+  // ---- the survivors grouped by label (assoc_core's staging; the double-precision models stay in memory) ----
+  float cm = 0.0f;
+  {
+    double mx[4], my[4], mz[4];
+    int lab[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int s = tidb + it * nthr;
+      lab[it] = 0;
+      mx[it] = my[it] = mz[it] = 0.0;
+      if (s < Ksub) {
+        const int mi = (int)(sel[s] & 0xffffffffull);
+        const double* mm = C.model + 3 * (size_t)mi;
+        mx[it] = mm[0]; my[it] = mm[1]; mz[it] = mm[2];
+        lab[it] = C.label[mi];
+      }
+    }
+    if (tidb < 64) {
+      const int mylab = s_dl[laneb];
+      const bool in = laneb < C.n_det;
+      bool first = in;
+      for (int p = 0; p < C.n_det; ++p) {
+        const int lp = __builtin_amdgcn_readlane(mylab, p);
+        if (p < laneb && lp == mylab) first = false;
+      }
+      const unsigned long long fm = __ballot(first);
+      int jj = __popcll(fm & ((1ull << laneb) - 1ull));
+      if (first) s_glab[jj] = mylab;
+      const int jf = jj;
+      for (int p = 0; p < C.n_det; ++p) {
+        const int lp = __builtin_amdgcn_readlane(mylab, p), jp = __builtin_amdgcn_readlane(jf, p);
+        if (((fm >> p) & 1ull) && lp == mylab) jj = jp;
+      }
+      if (in) s_dgrp[laneb] = jj;
+      if (laneb == 0) s_ng = __popcll(fm);
+    }
+    __syncthreads();
+    ASTAMP(7);
+    const int ng = s_ng;
+    const int glab_l = laneb < ng ? s_glab[laneb] : 0;
+    float x[4], y[4], z[4];
+    int g[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      g[it] = -1;
+      x[it] = (float)(mx[it] - C.qpos[0]); y[it] = (float)(my[it] - C.qpos[1]); z[it] = (float)(mz[it] - C.qpos[2]);
+    }
+    for (int j = 0; j < ng; ++j) {
+      const int gl = __builtin_amdgcn_readlane(glab_l, j);
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        if (tidb + it * nthr < Ksub && lab[it] == gl) g[it] = j;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      if (g[it] >= 0) cm = fmaxf(cm, fmaxf(fabsf(x[it]), fmaxf(fabsf(y[it]), fabsf(z[it]))));
+    int wc[4] = {0, 0, 0, 0};
+    for (int j = 0; j < ng; ++j) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        if (it * nthr >= Ksub) continue;               // (uniform)
+        const int c = __popcll(__ballot(g[it] == j));
+        if (laneb == j) wc[it] = c;
+      }
+    }
+    const int wtot = wc[0] + wc[1] + wc[2] + wc[3];
+    if (laneb < ng && wtot > 0) atomicAdd(&s_gcnt[laneb], wtot);
+    __syncthreads();
+    ASTAMP(15);
+    {
+      const int v = laneb < ng ? s_gcnt[laneb] : 0;
+      const int inc = wave_incl_scan_i32(v, laneb);
+      if (tidb < ng) s_goff[tidb] = inc - v;
+      int base = inc - v;
+      if (laneb < ng && wtot > 0) base += atomicAdd(&s_gcur[laneb], wtot);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        if (it * nthr >= Ksub) continue;
+        int rank = 0;
+        for (int j = 0; j < ng; ++j) {
+          const unsigned long long m = __ballot(g[it] == j);
+          if (g[it] == j) rank = __popcll(m & ((1ull << laneb) - 1ull));
+        }
+        const int gb = __shfl(base, g[it] >= 0 ? g[it] : 0);
+        if (g[it] >= 0) {
+          const int pos = gb + rank;
+          fx[pos] = x[it]; fy[pos] = y[it]; fz[pos] = z[it];
+          sidx[pos] = tidb + it * nthr;
+        }
+        base += wc[it];
+      }
+    }
+    cm = wave_max_f32(cm);
+    if (laneb == 0) atomicMax(&s_cmax, __float_as_uint(cm));
+  }
+  __syncthreads();
+  ASTAMP(5);
+  // ---- matching: a wavefront per detection over the survivors of its label (assoc_core's grouped branch) ----
+  constexpr double BAND = 1.0 - 0x1p-48;
+  constexpr float U = 0x1p-24f;
+  const float INF = __uint_as_float(0x7f800000u);
+  const float cmax = __uint_as_float(s_cmax);
+  for (int o = wave; o < C.n_det; o += nw) {
+    const double* dw = C.det_world + (size_t)o * C.det_stride + C.det_off;
+    double q[3];
+    float qf[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { q[k] = dw[k]; qf[k] = (float)(q[k] - C.qpos[k]); }
+    const int gg = __builtin_amdgcn_readfirstlane(s_dgrp[o]);
+    const int lo = __builtin_amdgcn_readfirstlane(s_goff[gg]), cnt = __builtin_amdgcn_readfirstlane(s_gcnt[gg]);
+    ASTAMPW(8);
+    ASTAMPW(9);
+    auto fd2 = [&](int t) -> float {
+      const float dx = qf[0] - fx[lo + t], dy = qf[1] - fy[lo + t], dz = qf[2] - fz[lo + t];
+      return dx * dx + dy * dy + dz * dz;
+    };
+    // pass 1: the float distances' minimum over the group; pass 2 recomputes them (three LDS words and eight flops per survivor, ~3 per
+    // laneb) instead of carrying them in registers: the kernel lives in 80 registers
+    float mf = INF;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (int t = laneb; t < cnt; t += 64) mf = fminf(mf, fd2(t));
+    mf = wave_min_f32(mf);
+    const float qm = fmaxf(fabsf(qf[0]), fmaxf(fabsf(qf[1]), fabsf(qf[2])));
+    const float E = 4.0f * U * (qm + cmax);
+    const float T = (sqrtf(mf) + 2.0f * E) * (1.0f + 8.0f * U);
+    const float T2 = mf < INF ? T * T * (1.0f + 4.0f * U) : -1.0f;      // (no survivor of that label: nothing passes)
+    double b2 = -1.0;
+    int bests = INT_MAX;
+    unsigned long long bkey = ~0ull;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (int t = laneb; t < cnt; t += 64) {
+      if (fd2(t) <= T2) {                   // (one or two lanes of the wave, once: their models come from memory)
+        const int s = sidx[lo + t];
+        const unsigned long long key = sel[s];
+        const double* mm = C.model + 3 * (size_t)(key & 0xffffffffull);
+        const double dx = q[0] - mm[0], dy = q[1] - mm[1], dz = q[2] - mm[2];
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        // the exact rule (assoc_core): a later candidate replaces the laneb's best iff its d is strictly smaller — decided on the squared
+        // distances when they differ by more than 2^-48 relative, by the two correctly rounded roots inside that band (equal: the order)
+        bool take = b2 < 0.0 || d2 < b2 * BAND;
+        if (!take && d2 * BAND <= b2) {
+          const double rd = sqrt(d2), rb = sqrt(b2);
+          take = rd < rb || (rd == rb && key < bkey);
+        }
+        if (take) { b2 = d2; bests = s; bkey = key; }
+      }
+    }
+    ASTAMPW(10);
+    double best = C.best_init;
+    const double d = b2 >= 0.0 ? sqrt(b2) : C.best_init;
+    if (d < C.best_init) best = d; else { bests = INT_MAX; bkey = ~0ull; }      // "if (d < bestDist)" against the initial bestDist
+    ASTAMPW(11);
+    // lexicographic (distance, key) minimum over the wave = the reference's strict-'<' first-wins rule, then the threshold test
+    const unsigned long long have = __ballot(bests != INT_MAX);
+    if (__popcll(have) <= 1) {
+      const int w = have ? __ffsll((long long)have) - 1 : 0;
+      if (laneb == w) {
+        const bool ok = (bests != INT_MAX) && (best < C.thresh);
+        C.match_map[o] = ok ? (int32_t)(bkey & 0xffffffffull) : -1;
+      }
+    } else {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off);
+        const int os = __shfl_xor(bests, off);
+        const unsigned klo = (unsigned)__shfl_xor((int)(unsigned)bkey, off), khi = (unsigned)__shfl_xor((int)(unsigned)(bkey >> 32), off);
+        const unsigned long long ok_ = ((unsigned long long)khi << 32) | klo;
+        if (ob < best || (ob == best && ok_ < bkey)) { best = ob; bests = os; bkey = ok_; }
+      }
+      if (laneb == 0) {
+        const bool ok = (bests != INT_MAX) && (best < C.thresh);
+        C.match_map[o] = ok ? (int32_t)(bkey & 0xffffffffull) : -1;
+      }
+    }
+  }
+  ASTAMP(6);
+}
+constexpr int SWEEP_R_NK = 20;
+__global__ __launch_bounds__(512, 6) void k_assoc_sweep_r(const float* __restrict__ cx, const float* __restrict__ cy, const float* __restrict__ cz,
+                                                          const double* __restrict__ model_xyz, const int32_t* __restrict__ label, int n_map,
+                                                          const double* __restrict__ query_pos, const double* __restrict__ obs_xyz,
+                                                          const int32_t* __restrict__ obs_label, int n_obs, int K, int Kp, double thresh,
+                                                          int32_t* __restrict__ out_map_idx) {
+  const int q = blockIdx.x;
+  AssocCore C;
+  C.cx = cx; C.cy = cy; C.cz = cz; C.model = model_xyz; C.label = label; C.n = n_map; C.K = K;
+  C.gate = 1; C.Kp = Kp; C.cached = 0; C.staged = 1;
+  C.thresh = thresh; C.best_init = 1000.0; C.label_gate = 1; C.is_cyl = 0;
+  C.qpos = query_pos + 3 * (size_t)q;
+  C.det_world = obs_xyz + 3 * (size_t)q * n_obs;
+  C.det_stride = 3; C.det_off = 0;
+  C.det_label = obs_label + (size_t)q * n_obs; C.n_det = n_obs;
+  C.match_sub = nullptr; C.submap = nullptr; C.n_sub = nullptr;
+  C.match_map = out_map_idx + (size_t)q * n_obs;
+  sweep_core_r<SWEEP_R_NK, 512>(C);
+}
+
 // updateFactorGraphMap (graphWrapper.cpp:239-275): optimised landmarks -> map models
 __global__ void k_map_refresh(double* cyl_model, int n_cyl, const int* cyl_lid, double* cube_xyz, int n_cube,
                               const int* cube_lid, double* ell_xyz, int n_ell, const int* ell_lid, const double* lm_est) {
@@ -998,6 +1483,15 @@ int launch_assoc_sweep(const float* cx, const float* cy, const float* cz, const 
   // two 512-thread workgroups per CU when the plan's LDS lets two fit (the default since round 4: 0.870 -> 0.710 ms per launch of 8192
   // frames against a 10 k-landmark map, 1.40 -> 1.72 TB/s algorithmic; SLIDE_ASSOC_THREADS=1024: one 1024-thread workgroup per CU)
   static const int env_thr = getenv("SLIDE_ASSOC_THREADS") ? atoi(getenv("SLIDE_ASSOC_THREADS")) : 512;
+  // round 5: the register-resident sweep, three workgroups per CU (SLIDE_ASSOC_REG=0: the kernels below)
+  static const int env_reg = getenv("SLIDE_ASSOC_REG") ? atoi(getenv("SLIDE_ASSOC_REG")) : 1;
+  if (env_reg && env_thr == 512 && n_map > 0 && n_map <= SWEEP_R_NK * 512 && Kp <= 1024 && n_obs <= ASSOC_GMAX) {
+    const int Ksub = K < n_map ? K : n_map;
+    const size_t lds = (size_t)Kp * 8 + (((size_t)Ksub * 16 + 7) / 8) * 8;
+    hipLaunchKernelGGL(k_assoc_sweep_r, dim3(n_query), dim3(512), lds, s, cx, cy, cz, model_xyz, label, n_map, query_pos, obs_xyz, obs_label,
+                       n_obs, K, Kp, thresh, out_map_idx);
+    return 0;
+  }
   if (env_thr == 512 && bytes + 20 * 1024 <= 80 * 1024 && Kp <= 1024)
     hipLaunchKernelGGL(k_assoc_sweep_512, dim3(n_query), dim3(512), bytes, s, cx, cy, cz, model_xyz, label, n_map, query_pos, obs_xyz,
                        obs_label, n_obs, K, Kp, cached, staged, thresh, out_map_idx);
