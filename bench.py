@@ -231,12 +231,12 @@ def assoc_roofline(s, n_map=10000, K=1000, n_obs=20, n_query=8192, repeats=5):
     bytes_per_frame = 12 * n_map + 28 * k_eff + 36 * n_obs
     per_launch_s = ms * 1e-3 / repeats
     ach = bytes_per_frame * n_query / per_launch_s / 1e9
-    return {"bound": "hbm", "kernel": "k_assoc_sweep_512 (float32 K-NN scan, K-select by one histogram over bins linear in the squared distance + ranks inside the K-th key's bin, label-gated nearest neighbour: survivors grouped by label, float screening, the exact double-precision rule on the one or two candidates inside the error bound; two 512-thread workgroups per CU)",
+    return {"bound": "hbm", "kernel": "k_assoc_sweep_r (float32 K-NN scan with a thread's twenty distance words kept in registers, K-select by one histogram over bins linear in the squared distance + ranks inside the K-th key's bin, label-gated nearest neighbour: survivors grouped by label, float screening, the exact double-precision rule on the one or two candidates inside the error bound; 38 KB of LDS, three 512-thread workgroups per CU; SLIDE_ASSOC_REG=0: round 4's k_assoc_sweep_512)",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "bytes_per_frame": bytes_per_frame, "frames_per_launch": n_query, "avg_launch_ms": per_launch_s * 1e3,
             "frames_per_s": n_query / per_launch_s, "matched_fraction": float((out >= 0).mean()),
-            "traffic": _pmc_traffic("k_assoc_sweep_512") or _pmc_traffic("k_assoc_sweep"),
-            "hbm_side_GBs": (((_pmc_traffic("k_assoc_sweep_512") or _pmc_traffic("k_assoc_sweep")) or 0.0) / per_launch_s / 1e9) or None,
+            "traffic": _pmc_traffic("k_assoc_sweep_r") or _pmc_traffic("k_assoc_sweep_512") or _pmc_traffic("k_assoc_sweep"),
+            "hbm_side_GBs": (((_pmc_traffic("k_assoc_sweep_r") or _pmc_traffic("k_assoc_sweep_512") or _pmc_traffic("k_assoc_sweep")) or 0.0) / per_launch_s / 1e9) or None,
             "config": {"n_map": n_map, "K": K, "n_obs": n_obs, "n_query": n_query},
             "note": "algorithmic bytes: every frame is charged the whole float32 cloud although the 120 KB map stays in L2 / "
                     "Infinity Cache across the frames of a launch (SURVEY.md 8d caveat); traffic = HBM-side bytes per launch (PMC), hbm_side_GBs = "

@@ -1,5 +1,6 @@
 """GPU parity tests of the individual kernels, through the C-ABI, against the oracle / numpy."""
 import ctypes as C
+import zlib
 
 import numpy as np
 import pytest
@@ -264,6 +265,57 @@ def test_assoc_sweep_label_groups_and_detection_counts(gpu, n_obs, n_labels, lab
         assert np.array_equal(got[i], want), (i, got[i], want)
         n_match += int((want >= 0).sum())
     assert n_match > 0.5 * n_q * n_obs * 0.8 or n_obs == 1
+
+
+def _sweep_vs_oracle(gpu, cloud, model, label, qpos, obs, olab, K, thresh=0.75):
+    """gpu.assoc_sweep_batch against the oracle's getSubmap + matchEllipsoidModels, frame by frame; returns the matches found."""
+    n_map, (n_q, n_obs) = len(cloud), olab.shape
+    got, _ = gpu.assoc_sweep_batch(cloud, model, label, qpos, obs, olab, K, thresh)
+    L = po.lib()
+    k_eff = min(K, n_map)
+    sub = np.zeros(max(k_eff, 1), np.int32)
+    exp = np.full(n_obs, -1, np.int32)
+    n_match = 0
+    for i in range(n_q):
+        k = L.orc_knn_f32(_p(cloud), C.c_int(n_map), _p(qpos[i]), C.c_int(K), _p(sub))
+        assert k == k_eff
+        sm = np.ascontiguousarray(model[sub[:k]]); sl = np.ascontiguousarray(label[sub[:k]])
+        L.orc_match_boxes(C.c_int(2), C.c_int(n_obs), _p(np.ascontiguousarray(obs[i])), _p(np.ascontiguousarray(olab[i])), C.c_int(k),
+                          _p(sm), _p(sl), C.c_double(thresh), _p(exp))
+        want = np.where(exp >= 0, sub[np.maximum(exp, 0)], -1)
+        assert np.array_equal(got[i], want), (i, got[i], want)
+        n_match += int((want >= 0).sum())
+    return n_match
+
+
+@pytest.mark.parametrize("kind", ["coincident", "outlier", "tiny", "full_rounds", "k_beyond_n", "one"])
+def test_assoc_sweep_degenerate_clouds(gpu, kind):
+    """The register-resident sweep kernel (k_assoc_sweep_r, round 5) on the clouds that leave its main path: thousands of coincident
+    landmarks around the K-th neighbour (the K-th key's bin overflows the candidate list: digit passes, ties by map index), one far
+    outlier (every other key in the first bin), maps smaller than a workgroup, a map that fills all twenty rounds of 512 keys exactly,
+    K beyond the map, a map of one landmark.  Identical map indices to the oracle."""
+    rng = np.random.default_rng(zlib.crc32(kind.encode()))
+    n_obs, n_q, K = 12, 24, 1000
+    n_map = dict(coincident=6000, outlier=5000, tiny=300, full_rounds=10240, k_beyond_n=700, one=1)[kind]
+    model = np.column_stack([rng.uniform(0, 120, n_map), rng.uniform(0, 120, n_map), rng.normal(0, 0.3, n_map)])
+    if kind == "coincident":
+        model[1500:4500] = model[1500]                       # 3000 landmarks in one spot
+        model[4500:4600] = model[1500] + rng.normal(0, 1e-4, (100, 3))
+    if kind == "outlier":
+        model[777] = [1.0e6, -2.0e6, 5.0e5]
+    label = rng.integers(1, 5, n_map).astype(np.int32)
+    cloud = model.astype(np.float32)
+    qpos = np.column_stack([rng.uniform(30, 90, n_q), rng.uniform(30, 90, n_q), np.full(n_q, 2.0)])
+    if kind == "coincident":
+        qpos[::2] = model[1500] + rng.normal(0, 8.0, (len(qpos[::2]), 3))      # the spot within the K nearest, partly
+    obs = np.zeros((n_q, n_obs, 3)); olab = np.zeros((n_q, n_obs), np.int32)
+    for i in range(n_q):
+        near = np.argsort(((model[:, :2] - qpos[i, :2]) ** 2).sum(1))[:n_obs]
+        near = np.resize(near, n_obs)
+        obs[i] = model[near] + rng.normal(0, 0.1, (n_obs, 3))
+        olab[i] = label[near]
+    n_match = _sweep_vs_oracle(gpu, cloud, model, label, qpos, obs, olab, K)
+    assert n_match > 0.5 * n_q * n_obs
 
 
 @pytest.mark.parametrize("offset", [0.0, 7000.0])

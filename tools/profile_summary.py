@@ -37,7 +37,7 @@ for tag, fs, ws, stats in (("bench", "pmc_f", "pmc_w", st), ("assoc", "apmc_f", 
         lines.append(f"{tag:6s} {k[:48]:48s} dispatches {max(nf, nw):6d}  FETCH_SIZE {sf / max(nf, 1):12.1f} KiB/dispatch (x2 on gfx950)  "
                      f"WRITE_SIZE {sw / max(nw, 1):12.1f} KiB/dispatch")
         short = k.split("::")[-1]
-        if short in ("k_chol_step_batched", "k_assoc_sweep", "k_assoc_sweep_512", "k_pcg_symv", "k_pcg_tl_symv", "k_schur_b", "k_border_syrk", "k_chol_step", "k_sep_gather"):
+        if short in ("k_chol_step_batched", "k_assoc_sweep", "k_assoc_sweep_512", "k_assoc_sweep_r", "k_pcg_symv", "k_pcg_tl_symv", "k_schur_b", "k_border_syrk", "k_chol_step", "k_sep_gather"):
             # full-size dispatches only: the streaming build also launches these kernels on growing systems
             fetch_kib, write_kib = sf / max(nf, 1), sw / max(nw, 1)
             js = {"kernel": short, "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_round.sh {rnd}); "
