@@ -326,6 +326,9 @@ int slide_dense_spd_solve_ex(const double* A, int n, const double* b, double* x,
  * column, 2: two block columns per launch.  After the call the band tiles hold L, the border rows W = B L^-T, the RHS row y = L^-1 b. */
 int slide_debug_chol_bordered(const double* S_in, int ld, int T, int nbr, const int* prof, const int* bfirst, const int* ord, int b0, int kofs,
                               int n_copies, int method, double* S_out, double* Ld_out, double* Winv_out, int* status_out, double* max_copy_diff);
+/* LDS flag waits of the pair kernel (method 2) that gave up since the library was loaded: 0 unless the kernel is broken (its waits are
+ * bounded so that every wave reaches the end of its launch); the tests assert 0. */
+int slide_debug_pair_timeouts(void);
 
 /* ------------------------------------------------------------------------------------------------
  * S3 — association (include/core/sloam.h:88-108, src/core/sloam.cpp:73-306; *MapManager::getSubmap)

@@ -30,7 +30,7 @@ EXPORTS = [
     "slide_graph_gauss_newton", "slide_graph_get_pose", "slide_graph_get_pose12", "slide_graph_get_all_poses",
     "slide_graph_get_landmark", "slide_graph_get_pose_covariance", "slide_graph_stats", "slide_graph_rejected_count", "slide_graph_set_shared", "slide_graph_dist_phase", "slide_chol_batch_create", "slide_chol_batch_destroy", "slide_graph_join_chol_batch", "slide_graph_dist_pass_local", "slide_chol_batch_pass", "slide_chol_batch_pass_part", "slide_chol_batch_stream", "slide_chol_batch_set_pcg", "slide_graph_set_pcg", "slide_chol_batch_set_pcg_tolerance", "slide_graph_set_pcg_tolerance", "slide_graph_set_separator", "slide_chol_batch_set_exact_joint", "slide_chol_batch_sep_buffer_len", "slide_chol_batch_sep_exchange_len", "slide_chol_batch_profile_exact_joint", "slide_graph_get_border_profile", "slide_graph_get_incremental_stats", "slide_graph_set_wildfire", "slide_graph_get_wildfire_stats", "slide_graph_get_segments", "slide_graph_get_segment_table", "slide_chol_batch_set_segments", "slide_clipper_dense_clique_batch", "slide_clipper_last_solve_info", "slide_last_device_ms", "slide_chol_batch_set_separator_profile", "slide_chol_batch_set_separator_blocks", "slide_chol_batch_set_separator_owner", "slide_chol_batch_sep_segment", "slide_graph_set_incremental", "slide_graph_set_ghost_ids", "slide_graph_get_pcg_stats", "slide_graph_get_tile_profile", "slide_graph_set_dense_profile", "slide_graph_chi2", "slide_chol_batch_profile", "slide_graph_set_ghosts", "slide_graph_add_relative_meas_ghost",
     "slide_backend_landmark_table", "slide_graph_set_profiling", "slide_graph_get_profile",
-    "slide_dense_spd_solve", "slide_dense_spd_solve_ex", "slide_debug_chol_bordered", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device", "slide_assoc_sweep_batch",
+    "slide_dense_spd_solve", "slide_dense_spd_solve_ex", "slide_debug_chol_bordered", "slide_debug_pair_timeouts", "slide_submap_knn", "slide_assoc_match_cylinders", "slide_assoc_match_boxes", "slide_assoc_sweep_batch_device", "slide_assoc_sweep_batch",
     "slide_backend_create", "slide_backend_destroy", "slide_backend_process_frame", "slide_backend_ingest_solve",
     "slide_backend_end_frame", "slide_backend_graph", "slide_backend_counts", "slide_backend_map_model",
     "slide_place_default_params", "slide_match_maps", "slide_find_inter_loop_closure", "slide_find_intra_loop_closure",
