@@ -981,7 +981,7 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v, int lane) {
   return v + (lane >= 16 ? s0 : 0) + (lane >= 32 ? s1 : 0) + (lane >= 48 ? s2 : 0);
 }
 
-template <int NK, int NTHR>
+template <int NK, int NTHR, int NREG>
 __device__ __forceinline__ void sweep_core_r(const AssocCore& C) {
   __shared__ unsigned long long sbuf64[1536];      // 12 KB: bin counts (1024 x 4 B) + candidate keys (1024 x 8 B); the fallback's per-wave digit histograms (8 x 256 x 4 B) + their sums
   __shared__ int s_dl[ASSOC_GMAX], s_dgrp[ASSOC_GMAX], s_glab[ASSOC_GMAX], s_gcnt[ASSOC_GMAX], s_gcur[ASSOC_GMAX], s_goff[ASSOC_GMAX], s_ng;
@@ -1012,7 +1012,10 @@ __device__ __forceinline__ void sweep_core_r(const AssocCore& C) {
   // Round j of a thread's keys is map index tid + j * nthr.  Which rounds exist is decided by ONE lane predicate (tid < rem, the partial
   // round) and scalar compares — twenty per-round index registers and twenty compare masks, kept alive from here to the placement, were
   // what made the first version of this kernel spill.
-  unsigned r[NK];
+  // rounds NREG .. NK - 1 of the words live in LDS (in the region the staging of the survivors takes over after the placement): with all
+  // twenty in registers five dwords per lane spilled
+  unsigned r[NREG];
+  unsigned* rl = reinterpret_cast<unsigned*>(fx);      // [(j - NREG) * nthr + tid]
   unsigned bmax = 0u;
   constexpr int LD = 2;
   const int nlast = n - 1;
@@ -1040,10 +1043,15 @@ __device__ __forceinline__ void sweep_core_r(const AssocCore& C) {
         d += dy * dy;
         d += dz * dz;
         const unsigned b = __float_as_uint(d);       // (the arithmetic of dist_bits)
-        r[j0 + u] = b;
         if (valid(j0 + u)) bmax = b > bmax ? b : bmax;
         // (consumed here: without the pin the scheduler issues all NK x 3 loads first and their sixty results spill)
-        asm volatile("" : "+v"(r[j0 + u]) : : "memory");
+        if (j0 + u < NREG) {
+          r[j0 + u] = b;
+          asm volatile("" : "+v"(r[j0 + u]) : : "memory");
+        } else {
+          rl[(j0 + u - NREG) * nthr + tid] = b;
+          asm volatile("" : : : "memory");
+        }
       }
     }
   }
@@ -1053,13 +1061,14 @@ __device__ __forceinline__ void sweep_core_r(const AssocCore& C) {
   ASTAMP(1);
   // (the overflow path below recomputes its keys from the cloud: the register copies are not kept alive for it)
   auto key_at_g = [&](int i) -> unsigned long long { return ((unsigned long long)dist_bits(C, i, qx, qy, qz) << 32) | (unsigned)i; };
+  auto rw = [&](int j) -> unsigned { return j < NREG ? r[j < NREG ? j : 0] : rl[(j - NREG) * nthr + tid]; };      // (j: compile-time after unrolling; own words only: no barrier needed)
   int t3 = 0;      // (a fresh copy of the thread index, taken where the keys are written)
   // a key = (distance word << 32) | map index, written as its two halves (one ds_write2_b32): formed as 64-bit values the twenty keys
   // want twenty aligned register pairs
   auto put_key = [&](unsigned long long* dst, int j) {
     unsigned* p2 = reinterpret_cast<unsigned*>(dst);
     p2[0] = (unsigned)(t3 + j * nthr);
-    p2[1] = r[j];
+    p2[1] = rw(j);
   };
   float scale = 0.0f;
   auto bin_of = [&](unsigned bits) -> int {
@@ -1077,8 +1086,8 @@ __device__ __forceinline__ void sweep_core_r(const AssocCore& C) {
 #pragma unroll
     for (int j = 0; j < NK; ++j)
     {
-      asm volatile("" : "+v"(r[j]));      // (one bin address at a time: twenty computed ahead of their atomics are twenty more registers)
-      if (valid(j)) atomicAdd(&lhist[bin_of(r[j])], 1u);
+      if (j < NREG) asm volatile("" : "+v"(r[j < NREG ? j : 0]));      // (one bin address at a time: twenty computed ahead of their atomics are twenty more registers)
+      if (valid(j)) atomicAdd(&lhist[bin_of(rw(j))], 1u);
     }
     __syncthreads();
     ASTAMP(12);
@@ -1110,9 +1119,9 @@ __device__ __forceinline__ void sweep_core_r(const AssocCore& C) {
       unsigned tm = 0u, cm = 0u;
 #pragma unroll
       for (int j = 0; j < NK; ++j) {
-        asm volatile("" : "+v"(r[j]));
+        if (j < NREG) asm volatile("" : "+v"(r[j < NREG ? j : 0]));
         if (valid(j)) {
-          const int b = bin_of(r[j]);
+          const int b = bin_of(rw(j));
           tm |= (b < fbin ? 1u : 0u) << j;
           cm |= (b == fbin ? 1u : 0u) << j;
         }
@@ -1402,7 +1411,7 @@ __device__ __forceinline__ void sweep_core_r(const AssocCore& C) {
   }
   ASTAMP(6);
 }
-constexpr int SWEEP_R_NK = 20;
+constexpr int SWEEP_R_NK = 20, SWEEP_R_NREG = 16;
 __global__ __launch_bounds__(512, 6) void k_assoc_sweep_r(const float* __restrict__ cx, const float* __restrict__ cy, const float* __restrict__ cz,
                                                           const double* __restrict__ model_xyz, const int32_t* __restrict__ label, int n_map,
                                                           const double* __restrict__ query_pos, const double* __restrict__ obs_xyz,
@@ -1419,7 +1428,7 @@ __global__ __launch_bounds__(512, 6) void k_assoc_sweep_r(const float* __restric
   C.det_label = obs_label + (size_t)q * n_obs; C.n_det = n_obs;
   C.match_sub = nullptr; C.submap = nullptr; C.n_sub = nullptr;
   C.match_map = out_map_idx + (size_t)q * n_obs;
-  sweep_core_r<SWEEP_R_NK, 512>(C);
+  sweep_core_r<SWEEP_R_NK, 512, SWEEP_R_NREG>(C);
 }
 
 // updateFactorGraphMap (graphWrapper.cpp:239-275): optimised landmarks -> map models
@@ -1487,7 +1496,8 @@ int launch_assoc_sweep(const float* cx, const float* cy, const float* cz, const 
   static const int env_reg = getenv("SLIDE_ASSOC_REG") ? atoi(getenv("SLIDE_ASSOC_REG")) : 1;
   if (env_reg && env_thr == 512 && n_map > 0 && n_map <= SWEEP_R_NK * 512 && Kp <= 1024 && n_obs <= ASSOC_GMAX) {
     const int Ksub = K < n_map ? K : n_map;
-    const size_t lds = (size_t)Kp * 8 + (((size_t)Ksub * 16 + 7) / 8) * 8;
+    // keys + the staged survivors (16 B each); the same region first holds the last four rounds of distance words (4 x 512 x 4 B)
+    const size_t lds = (size_t)Kp * 8 + std::max<size_t>((((size_t)Ksub * 16 + 7) / 8) * 8, (size_t)(SWEEP_R_NK - SWEEP_R_NREG) * 512 * 4);
     hipLaunchKernelGGL(k_assoc_sweep_r, dim3(n_query), dim3(512), lds, s, cx, cy, cz, model_xyz, label, n_map, query_pos, obs_xyz, obs_label,
                        n_obs, K, Kp, thresh, out_map_idx);
     return 0;
