@@ -500,6 +500,26 @@ def _pmc_traffic(kernel, **match):
     return None
 
 
+def _pmc_mfma_util(kernel, avg_launch_ms=None):
+    """Matrix-pipe utilisation of `kernel` from the committed PMC summary (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES in its own pass,
+    tools/gpu_r5_mfma.sh; the kernel's LARGEST grid = the exact joint passes' launches): {"busy_cycles_per_launch", "util_profiled"
+    (busy / (the profiled dispatches' own duration x 2.4 GHz x 1024 SIMDs)), "util_at_this_runs_launch_time"} or None."""
+    pdir = os.path.join(ROOT, "profiles")
+    try:
+        with open(os.path.join(pdir, "r05_pmc_mfma_util.json")) as fh:
+            groups = json.load(fh).get(kernel) or []
+    except (OSError, ValueError):
+        return None
+    if not groups:
+        return None
+    g = max(groups, key=lambda e: e.get("grid", 0))
+    out = {"busy_cycles_per_launch": g.get("mfma_busy_cycles_per_dispatch"), "util_profiled": g.get("mfma_util"), "grid": g.get("grid"),
+           "source": "profiles/r05_pmc_mfma_util.json (SQ_VALU_MFMA_BUSY_CYCLES; 64 busy cycles = one v_mfma_f64_16x16x4_f64)"}
+    if avg_launch_ms and g.get("mfma_busy_cycles_per_dispatch"):
+        out["util_at_this_runs_launch_time"] = g["mfma_busy_cycles_per_dispatch"] / (avg_launch_ms * 1e-3 * 2.4e9 * 1024)
+    return out
+
+
 def chol_flops(T, prof=None):
     """FLOPs of one factorisation with the RHS row: per block column k with n_k rows below it INSIDE THE PROFILE (prof[k] = last
     tile row of column k the solver touches; None = every tile of the lower triangle), trailing update n_k^2 * 64 + triangular solve
@@ -1056,7 +1076,7 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
                 "bound": "latency", "flops": fl_band, "window_ms": ms_band, "launches": bt["launches"],
                 "flops_per_launch": fl_band / max(bt["launches"], 1), "avg_launch_ms": ms_band * groups / max(bt["launches"], 1),
                 "achieved": tf(fl_band / groups, ms_band), "aggregate": tf(fl_band, ms_band), "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS,
-                "frac": tf(fl_band / groups, ms_band) / FP64_MFMA_PEAK_TFLOPS,
+                "frac": tf(fl_band / groups, ms_band) / FP64_MFMA_PEAK_TFLOPS, "mfma_util_pmc": _pmc_mfma_util("k_chol_step_batched"),
                 "note": "every launch is the serial chain of one 64-column diagonal block (sixteen dependent 4x4 pivot steps) beside the "
                         "panel tiles of the band and of the border: bound by that chain's latency, not by the matrix pipe; avg_launch_ms = "
                         "the window over the launches of one sequence (dispatch gaps included), rocprofv3's per-launch average is in "
@@ -1066,7 +1086,7 @@ def report(args, s, cfg, rank, world, wdev, R, backend, dt, shards, rep, t_build
                           "workgroups from a job table balanced over the XCD queues, operand loads fifteen k-steps ahead across the segments of a cut band)",
                 "bound": "mfma", "flops_per_launch": fl_done, "flops_dense_equivalent": fl_dense, "avg_launch_ms": ms_syrk,
                 "achieved": tf(fl_done, ms_syrk), "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS, "frac": tf(fl_done, ms_syrk) / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": _pmc_traffic("k_border_syrk"),
+                "traffic": _pmc_traffic("k_border_syrk"), "mfma_util_pmc": _pmc_mfma_util("k_border_syrk", ms_syrk),
                 "traffic_note": "HBM-side bytes per k_border_syrk launch averaged over the THREE launches of a pass (this one, plus the two small "
                                 "ones at the separator's own levels): the robots' launch carries ~3x the figure less a few MB"},
             "separator": {
