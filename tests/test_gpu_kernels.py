@@ -288,15 +288,16 @@ def _sweep_vs_oracle(gpu, cloud, model, label, qpos, obs, olab, K, thresh=0.75):
     return n_match
 
 
-@pytest.mark.parametrize("kind", ["coincident", "outlier", "tiny", "full_rounds", "k_beyond_n", "one"])
+@pytest.mark.parametrize("kind", ["coincident", "outlier", "tiny", "full_rounds", "k_beyond_n", "one", "beyond_rounds"])
 def test_assoc_sweep_degenerate_clouds(gpu, kind):
     """The register-resident sweep kernel (k_assoc_sweep_r, round 5) on the clouds that leave its main path: thousands of coincident
     landmarks around the K-th neighbour (the K-th key's bin overflows the candidate list: digit passes, ties by map index), one far
     outlier (every other key in the first bin), maps smaller than a workgroup, a map that fills all twenty rounds of 512 keys exactly,
-    K beyond the map, a map of one landmark.  Identical map indices to the oracle."""
+    K beyond the map, a map of one landmark — and a map of 12 000 landmarks, beyond the twenty rounds (round 4's kernel takes it).
+    Identical map indices to the oracle."""
     rng = np.random.default_rng(zlib.crc32(kind.encode()))
     n_obs, n_q, K = 12, 24, 1000
-    n_map = dict(coincident=6000, outlier=5000, tiny=300, full_rounds=10240, k_beyond_n=700, one=1)[kind]
+    n_map = dict(coincident=6000, outlier=5000, tiny=300, full_rounds=10240, k_beyond_n=700, one=1, beyond_rounds=12000)[kind]
     model = np.column_stack([rng.uniform(0, 120, n_map), rng.uniform(0, 120, n_map), rng.normal(0, 0.3, n_map)])
     if kind == "coincident":
         model[1500:4500] = model[1500]                       # 3000 landmarks in one spot
