@@ -328,6 +328,7 @@ int HostGraph::merge_pending() {
       h_pose_val.insert(h_pose_val.end(), v.val, v.val + 12);
       pose_fids.emplace_back();
       pose_bt.emplace_back();
+      h_reach.push_back((int)h_reach.size());
     } else {
       if (key2lm.count(v.key)) { refuse("value inserted twice:", v.key); continue; }
       key2lm[v.key] = (int)h_lm_type.size();
@@ -335,6 +336,7 @@ int HostGraph::merge_pending() {
       h_lm_type.push_back(v.type);
       h_lm_val.insert(h_lm_val.end(), v.val, v.val + 15);
       lm_fids.emplace_back();
+      h_lm_last.push_back(-1);
     }
   }
   pend_vars.clear();
@@ -363,6 +365,11 @@ int HostGraph::merge_pending() {
       h_bt_sigma.insert(h_bt_sigma.end(), f.sigma, f.sigma + 6);
       pose_bt[a->second].push_back(bi << 1);
       pose_bt[b->second].push_back((bi << 1) | 1);
+      csr_bt.touch(std::min(a->second, b->second));
+      {
+        const int lo = std::min(a->second, b->second), hi = std::max(a->second, b->second);
+        h_reach[lo] = std::max(h_reach[lo], hi);
+      }
     } else {
       auto b = key2lm.find(f.k1);
       if (b == key2lm.end()) { refuse("factor on a landmark that is not in the graph:", f.k1); continue; }
@@ -389,6 +396,18 @@ int HostGraph::merge_pending() {
       jbuf_used += lf_jsize(f.type);
       ebuf_used += lf_esize(f.type);
       lm_fids[b->second].push_back(fid);
+      csr_lm.touch(b->second);
+      csr_pose.touch(a->second);
+      lm_first_from = std::min(lm_first_from, b->second);
+      // the profile's input, kept current: every observer of the landmark now couples to pose max(last observer, this pose); this pose to it too
+      {
+        const int pnew = a->second, l = b->second;
+        if (pnew > h_lm_last[l]) {
+          h_lm_last[l] = pnew;
+          for (int x : lm_fids[l]) h_reach[h_lf_pose[x]] = std::max(h_reach[h_lf_pose[x]], pnew);
+        }
+        h_reach[pnew] = std::max(h_reach[pnew], h_lm_last[l]);
+      }
       // keep the pose's list sorted by (landmark id, factor id): the Schur kernel merges two such lists
       std::vector<int>& pl = pose_fids[a->second];
       auto pos = std::upper_bound(pl.begin(), pl.end(), fid, [&](int x, int y) {
@@ -1833,19 +1852,23 @@ static int up_tail(DevArr<T>& d, const std::vector<T>& h, size_t old_n, size_t p
   if (d.ensure(std::max<size_t>(n, 1), old_n * per, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   return d.upload(h.data() + old_n * per, old_n * per, n - old_n * per, s);
 }
-static int up_csr(DevArr<int>& dptr, DevArr<int>& dval, const std::vector<std::vector<int>>& lists, std::vector<int>& ptr,
-                  std::vector<int>& val, hipStream_t s) {
-  ptr.resize(lists.size() + 1);
-  val.clear();
-  ptr[0] = 0;
-  for (size_t i = 0; i < lists.size(); ++i) {
-    val.insert(val.end(), lists[i].begin(), lists[i].end());
-    ptr[i + 1] = (int)val.size();
+// lists -> device CSR, from the lowest list that changed since the last upload on (HostGraph::CsrMirror)
+static int up_csr(CsrMirror& M, DevArr<int>& dptr, DevArr<int>& dval, const std::vector<std::vector<int>>& lists, hipStream_t s) {
+  const int n = (int)lists.size();
+  int from = std::min(M.dirty_from, (int)M.ptr.size() - 1);
+  from = std::max(0, std::min(from, n));
+  M.ptr.resize((size_t)from + 1);
+  M.val.resize((size_t)M.ptr[from]);
+  M.off0 = M.val.size();
+  for (int i = from; i < n; ++i) {
+    M.val.insert(M.val.end(), lists[i].begin(), lists[i].end());
+    M.ptr.push_back((int)M.val.size());
   }
-  if (dptr.ensure(ptr.size(), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
-  if (dval.ensure(std::max<size_t>(val.size(), 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
-  if (dptr.upload(ptr.data(), 0, ptr.size(), s) != SLIDE_OK) return SLIDE_ERR_HIP;
-  return dval.upload(val.data(), 0, val.size(), s);
+  M.dirty_from = n;
+  if (dptr.ensure(M.ptr.size(), (size_t)from, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (dval.ensure(std::max<size_t>(M.val.size(), 1), M.off0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (dptr.upload(M.ptr.data() + from, (size_t)from, M.ptr.size() - (size_t)from, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  return dval.upload(M.val.data() + M.off0, M.off0, M.val.size() - M.off0, s);
 }
 
 int HostGraph::upload_new() {
@@ -1907,30 +1930,38 @@ int HostGraph::upload_new() {
   if (d_pose_H.ensure(std::max<size_t>(36 * Pn, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_pose_g.ensure(std::max<size_t>(6 * Pn, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (d_pr_r.cap + d_bt_r.cap + d_bt_J0.cap + d_jbuf.cap + d_ebuf.cap + d_lm_Hinv.cap + d_lm_g.cap + d_pose_H.cap + d_pose_g.cap != lin_caps0) ++lin_gen;
-  std::vector<int> ptr, val;
-  if (up_csr(d_lm_ptr, d_lm_fids, lm_fids, ptr, val, s) != SLIDE_OK) return SLIDE_ERR_HIP;
-  if (up_csr(d_pose_ptr, d_pose_fids, pose_fids, ptr, val, s) != SLIDE_OK) return SLIDE_ERR_HIP;
-  std::vector<int> lms(val.size());
-  for (size_t i = 0; i < val.size(); ++i) lms[i] = h_lf_lm[val[i]];
-  if (d_pose_lms.ensure(std::max<size_t>(lms.size(), 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
-  if (d_pose_lms.upload(lms.data(), 0, lms.size(), s) != SLIDE_OK) return SLIDE_ERR_HIP;
-  std::vector<long long> ped(val.size());
-  for (size_t i = 0; i < val.size(); ++i) {
-    const int ty = h_lm_type[h_lf_lm[val[i]]];
-    const int dim = ty == VT_POINT ? 3 : (ty == VT_CUBE ? 9 : 7);
-    ped[i] = ((long long)h_lf_eoff[val[i]] << 4) | dim;
+  if (up_csr(csr_lm, d_lm_ptr, d_lm_fids, lm_fids, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (up_csr(csr_pose, d_pose_ptr, d_pose_fids, pose_fids, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  {
+    // the two per-entry tables of the pose CSR follow its rewritten tail
+    const std::vector<int>& val = csr_pose.val;
+    const size_t o0 = csr_pose.off0;
+    hc_pose_lms.resize(val.size());
+    hc_pose_ed.resize(val.size());
+    for (size_t i = o0; i < val.size(); ++i) {
+      hc_pose_lms[i] = h_lf_lm[val[i]];
+      const int ty = h_lm_type[h_lf_lm[val[i]]];
+      const int dim = ty == VT_POINT ? 3 : (ty == VT_CUBE ? 9 : 7);
+      hc_pose_ed[i] = ((long long)h_lf_eoff[val[i]] << 4) | dim;
+    }
+    if (d_pose_lms.ensure(std::max<size_t>(val.size(), 1), o0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_pose_lms.upload(hc_pose_lms.data() + o0, o0, val.size() - o0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_pose_ed.ensure(std::max<size_t>(val.size(), 1), o0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_pose_ed.upload(hc_pose_ed.data() + o0, o0, val.size() - o0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   }
-  if (d_pose_ed.ensure(std::max<size_t>(ped.size(), 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
-  if (d_pose_ed.upload(ped.data(), 0, ped.size(), s) != SLIDE_OK) return SLIDE_ERR_HIP;
   // k_schur keeps a landmark -> slot table (2 B per landmark) and a pose adjacency bitmap (1 bit per pose) in dynamic LDS
   if ((Ln + 7) / 8 * 8 * sizeof(short) + ((Pn + 31) / 32 + 1) * sizeof(unsigned) > 120 * 1024) {
     (void)ub.flush(s);
     g_last_error = "Schur LDS lookup capacity exceeded (about 60000 landmarks in one graph)";
     return SLIDE_ERR_CAPACITY;
   }
-  if (up_csr(d_pose_bt_ptr, d_pose_bt, pose_bt, ptr, val, s) != SLIDE_OK) return SLIDE_ERR_HIP;
-  if (d_lm_first.ensure(std::max<size_t>(Ln, 1), 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
-  if (d_lm_first.upload(h_lm_first.data(), 0, Ln, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  if (up_csr(csr_bt, d_pose_bt_ptr, d_pose_bt, pose_bt, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+  {
+    const size_t f0 = std::min<size_t>((size_t)std::max(lm_first_from, 0), std::min(up_L, Ln));      // (new landmarks and every touched one)
+    if (d_lm_first.ensure(std::max<size_t>(Ln, 1), f0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    if (d_lm_first.upload(h_lm_first.data() + f0, f0, Ln - f0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
+    lm_first_from = 1 << 30;
+  }
   // (the batch stays open across the profile below: its two small arrays ride in the same copy; flushed right after)
   // exact joint step: this robot's border = its shared landmarks and the lambda coordinates of its relative-pose factors
   const bool arrow_now = arrow_on();
@@ -2171,14 +2202,7 @@ int HostGraph::upload_new() {
   // relative-pose factor); block column c reaches the tile row of the farthest reach of its poses; the running maximum over c is
   // closed under the fill of the factorisation (eliminating column c fills rows <= prof[c] of columns <= prof[c] only).
   {
-    std::vector<int> lm_last(Ln, -1), reach(Pn);
-    for (size_t f = 0; f < nlf; ++f) lm_last[h_lf_lm[f]] = std::max(lm_last[h_lf_lm[f]], h_lf_pose[f]);
-    for (size_t p = 0; p < Pn; ++p) reach[p] = (int)p;
-    for (size_t f = 0; f < nlf; ++f) reach[h_lf_pose[f]] = std::max(reach[h_lf_pose[f]], lm_last[h_lf_lm[f]]);
-    for (size_t b = 0; b < nbt; ++b) {
-      const int lo = std::min(h_bt_i[b], h_bt_j[b]), hi = std::max(h_bt_i[b], h_bt_j[b]);
-      reach[lo] = std::max(reach[lo], hi);
-    }
+    const std::vector<int>& reach = h_reach;      // (kept current by merge_pending: no pass over all factors per update)
     const bool dense = force_dense;      // measurement aid (slide_graph_set_dense_profile / SLIDE_CHOL_DENSE=1): ignore the structure
     std::vector<int> prof(T), first(T);
     for (int c = 0; c < T; ++c) prof[c] = dense ? T - 1 : c;

@@ -60,6 +60,13 @@ struct DownloadBatch {
   int run(hipStream_t s);
 };
 
+// host mirror of a device CSR (HostGraph: landmark -> factors, pose -> factors, pose -> relative-pose factors)
+struct CsrMirror {
+  std::vector<int> ptr{0}, val;
+  int dirty_from = 0;      // lists from this index on changed since the last upload (lists beyond the mirror are new anyway)
+  size_t off0 = 0;         // (set by the upload) first value entry it rewrote
+  void touch(int i) { if (i < dirty_from) dirty_from = i; }
+};
 // growable device array; contents below `used` survive a growth
 template <class T>
 struct DevArr {
@@ -404,6 +411,15 @@ class HostGraph {
   std::vector<double> h_br_z, h_cu_z, h_cu_sigma, h_cy_z;
   int64_t jbuf_used = 0, ebuf_used = 0;
   std::vector<std::vector<int>> lm_fids, pose_fids, pose_bt;
+  // host mirrors of their device CSR forms.  A streaming update touches the lists of the newest pose and of the few landmarks it
+  // observes (the youngest ones: landmark ids grow with the first observation), so only the tail from the lowest touched list on is
+  // rebuilt and uploaded (round 5: the three full rebuilds + the two per-factor tables were ~0.1 ms of host work and 350 KB of
+  // upload per frame at 625 poses, growing with the graph).
+  CsrMirror csr_lm, csr_pose, csr_bt;
+  std::vector<int> hc_pose_lms;           // per entry of the pose CSR: the factor's landmark
+  std::vector<long long> hc_pose_ed;      // ... and its E record (offset << 4 | tangent dimension)
+  int lm_first_from = 0;                  // h_lm_first changed from this landmark on since the last upload
+  std::vector<int> h_lm_last, h_reach;    // per landmark the last observing pose; per pose the last pose it couples to (the profile's input)
   size_t up_P = 0, up_L = 0, up_pr = 0, up_bt = 0, up_lf = 0, up_br = 0, up_cu = 0, up_cy = 0;
   int last_relin = 0;
   bool topo_dirty = true, uploaded_once = false;      // upload_new has work only after merge_pending consumed something
