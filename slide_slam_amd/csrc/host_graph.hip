@@ -2432,7 +2432,12 @@ int HostGraph::enqueue_iteration(bool lookahead, bool skip_relin, int c_d, int w
     STAGE(8, launch_chol_solve_bwd(CholSystem{G.S, G.ld, G.T, G.Ld, G.Winv, G.yv, G.dp, G.status, nullptr, h_prof.data(), G.prof, G.first, d_ctab.d}, s));
   }
   STAGE(9, launch_backsub(G, 0, s));
-  if (skip_relin && G.lm_first) STAGE(10, launch_estimate_predict(G, s));      // (streaming update: also predicts the next update's relinearisation, status[5])
+  if (skip_relin && G.lm_first) {
+    // (streaming update: also predicts the next update's relinearisation, status[5], and — when run_update asked for it — packs the
+    // closing read-back in its last workgroup)
+    STAGE(10, launch_estimate_predict(G, s, ei_final_pose, ei_final_out));
+    if (ei_final_out) ei_final_done = true;
+  }
   else STAGE(10, launch_estimate(G, s));
 #undef STAGE
   return SLIDE_OK;
@@ -2484,6 +2489,11 @@ int HostGraph::run_update(double relin_thr, int iterations) {
   const bool wf_full_path = !try_inc && env_inc && wildfire_thr > 0.0 && iterations == 1 && !use_graph && !batch && !force_dense && wf_T > 0 && relin_thr > 0.0;
   static const bool env_pred = !(getenv("SLIDE_NO_PREDICT") && getenv("SLIDE_NO_PREDICT")[0] == '1');
   const bool use_pred = env_pred && pred_valid && pred_thr == relin_thr;
+  if (d_final.ensure(18, 0, s, true) != SLIDE_OK) return SLIDE_ERR_HIP;      // 16 doubles of the closing read-back + the arrival counter of the fused pack (zero)
+  ei_final_done = false;
+  static const bool env_fuse_final = !(getenv("SLIDE_NO_FUSED_FINAL") && getenv("SLIDE_NO_FUSED_FINAL")[0] == '1');
+  if ((try_inc || wf_full_path) && env_fuse_final) { ei_final_out = d_final.d; ei_final_pose = (int)G.P - 1; }
+  else { ei_final_out = nullptr; ei_final_pose = -1; }
   if (try_inc) {
     launch_relin(G, s);
     int pmin = dirty_min_pose;
@@ -2549,9 +2559,9 @@ int HostGraph::run_update(double relin_thr, int iterations) {
   pred_valid = false;
   {
     double fin[16];
-    if (d_final.ensure(16, 0, s) != SLIDE_OK) return SLIDE_ERR_HIP;
     const int newest = (int)G.P - 1;
-    launch_final_pack(G, newest, d_final.d, s);
+    if (!ei_final_done) launch_final_pack(G, newest, d_final.d, s);      // (otherwise k_estimate_predict's last workgroup packed them)
+    ei_final_out = nullptr; ei_final_pose = -1; ei_final_done = false;
     SL_HIP(hipMemcpyAsync(fin, d_final.d, sizeof(fin), hipMemcpyDeviceToHost, s));
     SL_HIP(hipStreamSynchronize(s));
     std::memcpy(st, fin, sizeof(st));

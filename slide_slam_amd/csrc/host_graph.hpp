@@ -416,6 +416,7 @@ class HostGraph {
   // rebuilt and uploaded (round 5: the three full rebuilds + the two per-factor tables were ~0.1 ms of host work and 350 KB of
   // upload per frame at 625 poses, growing with the graph).
   CsrMirror csr_lm, csr_pose, csr_bt;
+  double* ei_final_out = nullptr; int ei_final_pose = -1; bool ei_final_done = false;      // run_update -> enqueue_iteration: the closing pack fused into k_estimate_predict
   std::vector<int> hc_pose_lms;           // per entry of the pose CSR: the factor's landmark
   std::vector<long long> hc_pose_ed;      // ... and its E record (offset << 4 | tangent dimension)
   int lm_first_from = 0;                  // h_lm_first changed from this landmark on since the last upload

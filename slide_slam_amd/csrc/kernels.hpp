@@ -18,7 +18,7 @@ void launch_backsub(const GraphDev& G, int mode, hipStream_t s);       // mode: 
 void launch_shared_pack(const GraphDev& G, int what, double* buf, hipStream_t s);
 void launch_shared_unpack(const GraphDev& G, int what, const double* buf, hipStream_t s);
 void launch_estimate(const GraphDev& G, hipStream_t s);
-void launch_estimate_predict(const GraphDev& G, hipStream_t s);      // + status[5] = P - (lowest pose the NEXT update's relinearisations change), 0: none
+void launch_estimate_predict(const GraphDev& G, hipStream_t s, int pose = -1, double* out17 = nullptr);      // out17 (or null): the closing pack of k_final_pack by the last workgroup — 16 doubles + an arrival counter (zero before the launch)
 void launch_final_pack(const GraphDev& G, int pose, double* out16, hipStream_t s);      // out16: 8 status ints (then cleared) | pose_est of `pose` (12 doubles)
 void launch_chi2(const GraphDev& G, double* out4, hipStream_t s);   // sum of squared whitened residuals at the last linearisation point
 void launch_pose_adj(const GraphDev& G, hipStream_t s);        // pose adjacency bitmap of the Schur assembly (topology only)

@@ -127,8 +127,7 @@ __global__ void k_relin_b(const GraphDev* __restrict__ Gs) { k_relin_body(Gs[blo
 // ------------------------------------------------------------------------------------------------
 // prior / between factors   [GTSAM PriorFactor / BetweenFactor<Pose3>]
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void k_lin_pose_factors_body(const GraphDev& G) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void k_lin_pose_factors_body(const GraphDev& G, int t) {
   if (t < G.n_prior) {
     if (G.pr_pose[t] < G.pose0) return;      // (incremental update: nothing this factor depends on moved)
     // r = -Local(x, prior), J = I
@@ -177,8 +176,8 @@ __device__ __forceinline__ void k_lin_pose_factors_body(const GraphDev& G) {
     }
   }
 }
-__global__ __launch_bounds__(128) void k_lin_pose_factors(GraphDev G) { k_lin_pose_factors_body(G); }
-__global__ __launch_bounds__(128) void k_lin_pose_factors_b(const GraphDev* __restrict__ Gs) { k_lin_pose_factors_body(Gs[blockIdx.z]); }
+__global__ __launch_bounds__(128) void k_lin_pose_factors(GraphDev G) { k_lin_pose_factors_body(G, blockIdx.x * blockDim.x + threadIdx.x); }
+__global__ __launch_bounds__(128) void k_lin_pose_factors_b(const GraphDev* __restrict__ Gs) { k_lin_pose_factors_body(Gs[blockIdx.z], blockIdx.x * blockDim.x + threadIdx.x); }
 
 // ------------------------------------------------------------------------------------------------
 // landmark factors
@@ -208,9 +207,9 @@ __device__ inline void cyl_err(const SE3& X, const double* q, const double* z, d
 // Jacobians: one lane's work — with 32 lanes per factor a wavefront held two of them, 2 of 64 lanes active, and bearing-range
 // factors are most of a SLAM graph); the workgroups behind them give every factor 32 lanes and linearise cubes / cylinders by the
 // reference's central differences (one error evaluation per lane) — wavefronts whose two factors are bearing-range leave at once.
-__device__ __forceinline__ void k_lin_lf_body(const GraphDev& G, int nb1) {
-  const bool br_region = (int)blockIdx.x < nb1;
-  const int f = br_region ? (int)(blockIdx.x * 256 + threadIdx.x) : (int)((((int)blockIdx.x - nb1) * 256 + threadIdx.x) >> 5);
+__device__ __forceinline__ void k_lin_lf_body(const GraphDev& G, int nb1, int bid) {
+  const bool br_region = bid < nb1;
+  const int f = br_region ? (int)(bid * 256 + threadIdx.x) : (int)(((bid - nb1) * 256 + threadIdx.x) >> 5);
   const int j = br_region ? 0 : (threadIdx.x & 31);
   if (f >= G.n_lf) return;
   const int type = G.lf_type[f];
@@ -309,8 +308,16 @@ __device__ __forceinline__ void k_lin_lf_body(const GraphDev& G, int nb1) {
     }
   }
 }
-__global__ __launch_bounds__(256) void k_lin_lf(GraphDev G, int nb1) { k_lin_lf_body(G, nb1); }
-__global__ __launch_bounds__(256) void k_lin_lf_b(const GraphDev* __restrict__ Gs, int nb1) { k_lin_lf_body(Gs[blockIdx.z], nb1); }
+// nb0 leading workgroups linearise the prior / between / ghost factors (round 5: one launch instead of two — the two kinds of factors do
+// not depend on each other, and a launch costs a streaming update ~8 us of its ~280)
+__global__ __launch_bounds__(256) void k_lin_lf(GraphDev G, int nb0, int nb1) {
+  if ((int)blockIdx.x < nb0) k_lin_pose_factors_body(G, blockIdx.x * 256 + threadIdx.x);
+  else k_lin_lf_body(G, nb1, (int)blockIdx.x - nb0);
+}
+__global__ __launch_bounds__(256) void k_lin_lf_b(const GraphDev* __restrict__ Gs, int nb0, int nb1) {
+  if ((int)blockIdx.x < nb0) k_lin_pose_factors_body(Gs[blockIdx.z], blockIdx.x * 256 + threadIdx.x);
+  else k_lin_lf_body(Gs[blockIdx.z], nb1, (int)blockIdx.x - nb0);
+}
 
 // ------------------------------------------------------------------------------------------------
 // landmark reduce: H_ll = sum Jl^T Jl, g_l = sum Jl^T r, H_ll^-1, and per factor
@@ -907,7 +914,16 @@ __device__ __forceinline__ void k_schur_body(const GraphDev& G, int pj, int yb) 
   __syncthreads();      // the tile is reused by the next chunk
   }
 }
-__global__ __launch_bounds__(256) void k_schur(GraphDev G) { k_schur_body<false>(G, blockIdx.x, blockIdx.y); }
+__device__ __forceinline__ void k_pad_rhs_body(const GraphDev& G, int bid);
+// workgroups x >= P (y = 0) of the launch write the right-hand-side row and the padding of the last tile (k_pad_rhs_body: they depend on
+// k_pose only, like the Schur blocks — round 5: one launch instead of two on the streaming path)
+__global__ __launch_bounds__(256) void k_schur(GraphDev G) {
+  if ((int)blockIdx.x >= G.P) {
+    if (blockIdx.y == 0) k_pad_rhs_body(G, (int)blockIdx.x - G.P);
+    return;
+  }
+  k_schur_body<false>(G, blockIdx.x, blockIdx.y);
+}
 __global__ __launch_bounds__(256) void k_schur_b(const GraphDev* __restrict__ Gs) {
   const GraphDev G = Gs[blockIdx.z];
   k_schur_body<false>(G, blockIdx.x, blockIdx.y);
@@ -1057,9 +1073,9 @@ void launch_scatter(const void* stage, unsigned desc_off, int nseg, hipStream_t 
   if (nseg > 0) hipLaunchKernelGGL(k_scatter, dim3(nseg, 8), dim3(256), 0, s, static_cast<const unsigned char*>(stage), desc_off);
 }
 
-__device__ __forceinline__ void k_pad_rhs_body(const GraphDev& G) {
+__device__ __forceinline__ void k_pad_rhs_body(const GraphDev& G, int bid) {
   const int n = 6 * G.P, NT = G.T * NB;
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long t = (long long)bid * 256 + threadIdx.x;
   if (t < NT) {
     const int c = (int)t;
     // (the right-hand-side row lies below the border rows; columns left of col0 keep the forward-substituted entries of the last solve)
@@ -1075,10 +1091,10 @@ __device__ __forceinline__ void k_pad_rhs_body(const GraphDev& G) {
   G.S[(size_t)c * G.ld + r] = (c == r) ? 1.0 : 0.0;
   if (G.save_S0) G.S0[(size_t)c * G.ld + r] = (c == r) ? 1.0 : 0.0;
 }
-__global__ void k_pad_rhs(GraphDev G) { k_pad_rhs_body(G); }
-__global__ void k_pad_rhs_b(const GraphDev* __restrict__ Gs) {
+__global__ __launch_bounds__(256) void k_pad_rhs(GraphDev G) { k_pad_rhs_body(G, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_pad_rhs_b(const GraphDev* __restrict__ Gs) {
   const GraphDev G = Gs[blockIdx.z];
-  k_pad_rhs_body(G);
+  k_pad_rhs_body(G, blockIdx.x);
 }
 
 // landmark back-substitution  delta_l = -H_ll^-1 (g_l + sum_f E_f^T delta_p), and delta_p = dp.
@@ -1541,7 +1557,7 @@ __global__ void k_estimate(GraphDev G) { k_estimate_body(G); }
 // solves, so the variables k_relin will move next time (|delta|_inf >= threshold) are known now; the lowest pose whose blocks they
 // change (mark_dirty_pose / mark_dirty_lm, as k_relin reports it in status[6]) goes to status[5] as P - pose.  The host reads it with
 // this update's status words and needs no read-back between k_relin and the rest of the next update.
-__global__ void k_estimate_predict(GraphDev G) {
+__global__ void k_estimate_predict(GraphDev G, int pose, double* __restrict__ out) {
   k_estimate_body(G);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   int dirty = 0;
@@ -1561,6 +1577,30 @@ __global__ void k_estimate_predict(GraphDev G) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) dirty = max(dirty, __shfl_xor(dirty, off));
     if ((threadIdx.x & 63) == 0 && dirty > 0) atomicMax(&G.status[5], dirty);
+  }
+  // the closing pack (k_final_pack) by the LAST workgroup to get here (round 5: one launch less per streaming update): out[16] is the
+  // arrival counter (zero before the launch; the last workgroup leaves it at zero)
+  if (out) {
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int* cnt = reinterpret_cast<int*>(out + 16);
+      const int a = atomicAdd(cnt, 1);
+      s_last = (a == (int)gridDim.x - 1) ? 1 : 0;
+      if (s_last) *cnt = 0;
+    }
+    __syncthreads();
+    if (s_last) {
+      __threadfence();
+      const int tt = threadIdx.x;
+      if (tt < 8) {
+        reinterpret_cast<int*>(out)[tt] = __hip_atomic_load(&G.status[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        G.status[tt] = 0;
+      } else if (tt < 20) {
+        out[4 + (tt - 8)] = pose >= 0 ? __hip_atomic_load(&G.pose_est[12 * (size_t)pose + (tt - 8)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+    }
   }
 }
 // the update's closing read-back in ONE piece: the eight status words and the estimate of pose `pose` (the newest key frame, what a frame
@@ -1613,9 +1653,13 @@ void launch_relin(const GraphDev& G, hipStream_t s) {
   hipLaunchKernelGGL(k_relin, dim3(blocks_for(G.P + G.L, 256)), dim3(256), 0, s, G);
 }
 void launch_linearize(const GraphDev& G, hipStream_t s) {
-  if (G.n_prior + G.n_between + G.n_ghost > 0)
-    hipLaunchKernelGGL(k_lin_pose_factors, dim3(blocks_for(G.n_prior + G.n_between + G.n_ghost, 128)), dim3(128), 0, s, G);
-  if (G.n_lf > 0) hipLaunchKernelGGL(k_lin_lf, dim3(blocks_for(G.n_lf, 256) + blocks_for(32LL * G.n_lf, 256)), dim3(256), 0, s, G, (int)blocks_for(G.n_lf, 256));
+  const int npf = G.n_prior + G.n_between + G.n_ghost;
+  if (G.n_lf > 0) {
+    const int nb0 = npf > 0 ? (int)blocks_for(npf, 256) : 0;
+    hipLaunchKernelGGL(k_lin_lf, dim3(nb0 + blocks_for(G.n_lf, 256) + blocks_for(32LL * G.n_lf, 256)), dim3(256), 0, s, G, nb0, (int)blocks_for(G.n_lf, 256));
+  } else if (npf > 0) {
+    hipLaunchKernelGGL(k_lin_pose_factors, dim3(blocks_for(npf, 128)), dim3(128), 0, s, G);
+  }
 }
 void launch_landmark(const GraphDev& G, int mode, hipStream_t s) {
   if (G.L == 0) return;
@@ -1630,10 +1674,10 @@ void launch_schur(const GraphDev& G, hipStream_t s) {
   if (G.P == 0) return;
   static const int env_split = getenv("SLIDE_SCHUR_SPLIT") ? atoi(getenv("SLIDE_SCHUR_SPLIT")) : 0;     // diagnostic
   const int split = env_split > 0 ? env_split : (G.schur_split > 0 ? G.schur_split : 2);
-  hipLaunchKernelGGL(k_schur, dim3(G.P, split > 0 ? split : 1), dim3(256), (size_t)((G.L + 7) / 8 * 8) * sizeof(short) + (size_t)((G.P + 31) / 32 + 1) * sizeof(unsigned), s, G);
   const long long NT = (long long)G.T * NB;
   const long long tot = NT + (NT - 6LL * G.P) * NT;
-  hipLaunchKernelGGL(k_pad_rhs, dim3(blocks_for(tot, 256)), dim3(256), 0, s, G);
+  hipLaunchKernelGGL(k_schur, dim3(G.P + (unsigned)blocks_for(tot, 256), split > 0 ? split : 1), dim3(256),
+                     (size_t)((G.L + 7) / 8 * 8) * sizeof(short) + (size_t)((G.P + 31) / 32 + 1) * sizeof(unsigned), s, G);
 }
 void launch_backsub(const GraphDev& G, int mode, hipStream_t s) {
   if (G.P + G.L == 0) return;
@@ -1717,8 +1761,12 @@ void launch_phase0_batched(const GraphDev* d, const GraphDev* h, int n, double* 
   BufPtrs B{};
   for (int i = 0; i < n; ++i) B.p[i] = bufs[i];
   if (P + L > 0) hipLaunchKernelGGL(k_relin_b, dim3(blocks_for(P + L, 256), 1, n), dim3(256), 0, s, d);
-  if (npf > 0) hipLaunchKernelGGL(k_lin_pose_factors_b, dim3(blocks_for(npf, 128), 1, n), dim3(128), 0, s, d);
-  if (nlf > 0) hipLaunchKernelGGL(k_lin_lf_b, dim3(blocks_for(nlf, 256) + blocks_for(32LL * nlf, 256), 1, n), dim3(256), 0, s, d, (int)blocks_for(nlf, 256));
+  if (nlf > 0) {
+    const int nb0 = npf > 0 ? (int)blocks_for(npf, 256) : 0;
+    hipLaunchKernelGGL(k_lin_lf_b, dim3(nb0 + blocks_for(nlf, 256) + blocks_for(32LL * nlf, 256), 1, n), dim3(256), 0, s, d, nb0, (int)blocks_for(nlf, 256));
+  } else if (npf > 0) {
+    hipLaunchKernelGGL(k_lin_pose_factors_b, dim3(blocks_for(npf, 128), 1, n), dim3(128), 0, s, d);
+  }
   if (L > 0 && pack) hipLaunchKernelGGL(k_landmark_b<1>, dim3(blocks_for(L, 4), 1, n), dim3(256), 0, s, d);      // (!pack: the exact joint pass sums and finishes in one launch, k_landmark_b<3>)
   if (slots > 0 && pack) hipLaunchKernelGGL(k_shared_pack_b, dim3(blocks_for(54LL * slots, 128), 1, n), dim3(128), 0, s, d, 0, B);
 }
@@ -1756,9 +1804,9 @@ void launch_estimate(const GraphDev& G, hipStream_t s) {
   if (G.P + G.L == 0) return;
   hipLaunchKernelGGL(k_estimate, dim3(blocks_for(G.P + G.L, 256)), dim3(256), 0, s, G);
 }
-void launch_estimate_predict(const GraphDev& G, hipStream_t s) {
+void launch_estimate_predict(const GraphDev& G, hipStream_t s, int pose, double* out17) {
   if (G.P + G.L == 0) return;
-  hipLaunchKernelGGL(k_estimate_predict, dim3(blocks_for(G.P + G.L, 256)), dim3(256), 0, s, G);
+  hipLaunchKernelGGL(k_estimate_predict, dim3(blocks_for(G.P + G.L, 256)), dim3(256), 0, s, G, pose, out17);
 }
 void launch_final_pack(const GraphDev& G, int pose, double* out16, hipStream_t s) {
   hipLaunchKernelGGL(k_final_pack, dim3(1), dim3(64), 0, s, G, pose, out16);
