@@ -917,12 +917,15 @@ __device__ __forceinline__ void k_schur_body(const GraphDev& G, int pj, int yb) 
 __device__ __forceinline__ void k_pad_rhs_body(const GraphDev& G, int bid);
 // workgroups x >= P (y = 0) of the launch write the right-hand-side row and the padding of the last tile (k_pad_rhs_body: they depend on
 // k_pose only, like the Schur blocks — round 5: one launch instead of two on the streaming path)
-__global__ __launch_bounds__(256) void k_schur(GraphDev G) {
-  if ((int)blockIdx.x >= G.P) {
-    if (blockIdx.y == 0) k_pad_rhs_body(G, (int)blockIdx.x - G.P);
+// p_first: the first pose column the launch covers (an incremental update re-assembles from G.col0 on: the pose columns left of it
+// would leave at once — 575 of 625 workgroups on a streaming frame — and are not launched)
+__global__ __launch_bounds__(256) void k_schur(GraphDev G, int p_first) {
+  const int x = (int)blockIdx.x + p_first;
+  if (x >= G.P) {
+    if (blockIdx.y == 0) k_pad_rhs_body(G, x - G.P);
     return;
   }
-  k_schur_body<false>(G, blockIdx.x, blockIdx.y);
+  k_schur_body<false>(G, x, blockIdx.y);
 }
 __global__ __launch_bounds__(256) void k_schur_b(const GraphDev* __restrict__ Gs) {
   const GraphDev G = Gs[blockIdx.z];
@@ -1676,8 +1679,9 @@ void launch_schur(const GraphDev& G, hipStream_t s) {
   const int split = env_split > 0 ? env_split : (G.schur_split > 0 ? G.schur_split : 2);
   const long long NT = (long long)G.T * NB;
   const long long tot = NT + (NT - 6LL * G.P) * NT;
-  hipLaunchKernelGGL(k_schur, dim3(G.P + (unsigned)blocks_for(tot, 256), split > 0 ? split : 1), dim3(256),
-                     (size_t)((G.L + 7) / 8 * 8) * sizeof(short) + (size_t)((G.P + 31) / 32 + 1) * sizeof(unsigned), s, G);
+  const int p_first = G.col0 > 5 ? std::min((G.col0 - 5 + 5) / 6, G.P) : 0;      // smallest pj with 6 pj + 5 >= col0
+  hipLaunchKernelGGL(k_schur, dim3((unsigned)(G.P - p_first) + (unsigned)blocks_for(tot, 256), split > 0 ? split : 1), dim3(256),
+                     (size_t)((G.L + 7) / 8 * 8) * sizeof(short) + (size_t)((G.P + 31) / 32 + 1) * sizeof(unsigned), s, G, p_first);
 }
 void launch_backsub(const GraphDev& G, int mode, hipStream_t s) {
   if (G.P + G.L == 0) return;
