@@ -56,7 +56,7 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False) -> s
         src = os.path.join(CSRC, name)
         obj = os.path.join(OUT_DIR, name.replace(".hip", ".stamps.o" if stamps else ".o"))
         if stamps:
-            extra = [*extra, "-DSLIDE_STAMPS"]
+            extra = [*extra, "-DSLIDE_STAMPS", *(["-DSLIDE_STAMP_BLOCK=" + os.environ["SLIDE_STAMP_BLOCK"]] if os.environ.get("SLIDE_STAMP_BLOCK") else [])]
         objs.append(obj)
         if force or _deps_newer(obj, src):
             cmd = [HIPCC, *COMMON, *extra, "-c", src, "-o", obj]

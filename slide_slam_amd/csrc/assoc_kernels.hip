@@ -26,8 +26,11 @@ namespace sl {
 #ifdef SLIDE_STAMPS
 // experiment builds (python -m slide_slam_amd.build --stamps): phase time stamps of workgroup 0 (100 MHz wall clock)
 __device__ unsigned long long g_assoc_stamps[16];
-#define ASTAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) g_assoc_stamps[i] = wall_clock64(); } while (0)
-#define ASTAMPW(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_assoc_stamps[i] = wall_clock64(); } while (0)      // wave 0, no barrier
+#ifndef SLIDE_STAMP_BLOCK
+#define SLIDE_STAMP_BLOCK 0      // the workgroup that stamps (k_assoc_frame: 0 cylinders, 1 cubes, 2 points)
+#endif
+#define ASTAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == SLIDE_STAMP_BLOCK) g_assoc_stamps[i] = wall_clock64(); } while (0)
+#define ASTAMPW(i) do { if (threadIdx.x == 0 && blockIdx.x == SLIDE_STAMP_BLOCK) g_assoc_stamps[i] = wall_clock64(); } while (0)      // wave 0, no barrier
 #else
 #define ASTAMP(i)
 #define ASTAMPW(i)
