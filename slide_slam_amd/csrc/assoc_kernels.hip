@@ -388,7 +388,11 @@ __device__ inline void assoc_core(const AssocCore& C) {
   int Ksub = C.n;
   // the submap ORDER (nearest first, ties by map index) matters to the caller only when it asks for the list or for positions in it;
   // the matching itself needs it for ties alone: "the first of equally distant candidates" = the one with the smallest key
-  const bool need_sort = C.submap != nullptr || C.match_sub != nullptr;
+  // positions in the submap asked for WITHOUT the list itself (the per-frame path, round 5): a match's position is the RANK of its key
+  // among the K selected ones — counted by its wavefront, nine reads per lane at 557 landmarks — and the bitonic sort (9.2 of that
+  // frame kernel's 18.4 us) is not needed
+  const bool rank_mode = C.gate && C.match_sub != nullptr && C.submap == nullptr;
+  const bool need_sort = C.submap != nullptr;
   if (C.gate) {
     Ksub = C.n > 0 ? knn_select(C, sel, hist, dcache, need_sort) : 0;
     if (C.submap)
@@ -551,26 +555,41 @@ __device__ inline void assoc_core(const AssocCore& C) {
     // (a lane without a candidate holds (best_init, INT_MAX, ~0) and loses to every lane with one: when at most one lane has a
     // candidate — the rule after the screening — there is nothing to reduce)
     const unsigned long long have = __ballot(bs != INT_MAX);
+    int w = 0;
     if (__popcll(have) <= 1) {
-      const int w = have ? __ffsll((long long)have) - 1 : 0;
-      if (lane == w) {
-        const bool ok = (bs != INT_MAX) && (b < C.thresh);
-        if (C.match_sub) C.match_sub[o] = ok ? bs : -1;
-        C.match_map[o] = ok ? (int32_t)(bk & 0xffffffffull) : -1;
+      w = have ? __ffsll((long long)have) - 1 : 0;
+    } else {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(b, off);
+        const int os = __shfl_xor(bs, off);
+        const unsigned klo = (unsigned)__shfl_xor((int)(unsigned)bk, off), khi = (unsigned)__shfl_xor((int)(unsigned)(bk >> 32), off);
+        const unsigned long long ok_ = ((unsigned long long)khi << 32) | klo;
+        if (ob < b || (ob == b && ok_ < bk)) { b = ob; bs = os; bk = ok_; }
+      }
+    }
+    if (rank_mode) {
+      // lane w's result to every lane; the position in the (never formed) nearest-first list = the keys below the match's
+      const double bw = __shfl(b, w);
+      const int bsw = __shfl(bs, w);
+      const unsigned klo = (unsigned)__shfl((int)(unsigned)bk, w), khi = (unsigned)__shfl((int)(unsigned)(bk >> 32), w);
+      const unsigned long long bkw = ((unsigned long long)khi << 32) | klo;
+      const bool ok = (bsw != INT_MAX) && (bw < C.thresh);
+      int rank = 0;
+      if (ok) {
+        for (int s = lane; s < Ksub; s += 64) rank += sel[s] < bkw ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rank += __shfl_xor(rank, off);
+      }
+      if (lane == 0) {
+        C.match_sub[o] = ok ? rank : -1;
+        C.match_map[o] = ok ? (int32_t)(bkw & 0xffffffffull) : -1;
       }
       return;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ob = __shfl_xor(b, off);
-      const int os = __shfl_xor(bs, off);
-      const unsigned klo = (unsigned)__shfl_xor((int)(unsigned)bk, off), khi = (unsigned)__shfl_xor((int)(unsigned)(bk >> 32), off);
-      const unsigned long long ok_ = ((unsigned long long)khi << 32) | klo;
-      if (ob < b || (ob == b && ok_ < bk)) { b = ob; bs = os; bk = ok_; }
-    }
-    if (lane == 0) {
+    if (lane == w) {
       const bool ok = (bs != INT_MAX) && (b < C.thresh);
-      if (C.match_sub) C.match_sub[o] = ok ? bs : -1;      // (position in the sorted submap: the list was sorted when this is asked for)
+      if (C.match_sub) C.match_sub[o] = ok ? bs : -1;      // (position in the sorted submap: the list was sorted when this is asked for; pure matchers: the index itself)
       C.match_map[o] = ok ? (int32_t)(bk & 0xffffffffull) : -1;
     }
   };

@@ -81,7 +81,8 @@ int HostBackend::associate(const SE3& poseEstimate, const slide_detections_t& de
     else { F[c].thresh = P.ellipsoid_match_thresh; F[c].best_init = 1000; F[c].label_gate = 1; }
     F[c].det = d_det[c].d; F[c].det_label = d_det_label[c].d; F[c].n_det = nd[c];
     F[c].det_world = d_det_world[c].d; F[c].match_sub = d_match_sub[c].d; F[c].match_map = d_match_map[c].d;
-    F[c].submap = d_submap[c].d; F[c].n_sub = d_nsub.d + c;
+    // (the nearest-first submap list itself is not asked for: the matches' positions in it are counted on the device, assoc_core rank_mode)
+    F[c].submap = nullptr; F[c].n_sub = nullptr;
   }
   double pose12[12];
   to12(poseEstimate, pose12);
@@ -89,12 +90,7 @@ int HostBackend::associate(const SE3& poseEstimate, const slide_detections_t& de
   if (d_cls3.upload(F, 0, 3, s) != SLIDE_OK) return SLIDE_ERR_HIP;
   if (ub.flush(s) != SLIDE_OK) return SLIDE_ERR_HIP;
   launch_assoc_frame(d_cls3.d, lds_bytes, d_pose12.d, s);
-  int nsub[4] = {0, 0, 0, 0};
-  std::vector<int> sub_all[3];                     // the whole submap table comes along: its length is only known afterwards
-  db.add(nsub, d_nsub.d, 3 * sizeof(int));
   for (int c = 0; c < 3; ++c) {
-    sub_all[c].resize(std::max(maps[c].K, 1));
-    db.add(sub_all[c].data(), d_submap[c].d, sub_all[c].size() * sizeof(int));
     if (!nd[c]) continue;
     db.add(A.det_world[c].data(), d_det_world[c].d, A.det_world[c].size() * sizeof(double));
     db.add(A.match_sub[c].data(), d_match_sub[c].d, nd[c] * sizeof(int));
@@ -102,10 +98,6 @@ int HostBackend::associate(const SE3& poseEstimate, const slide_detections_t& de
   }
   if (db.run(s) != SLIDE_OK) return SLIDE_ERR_HIP;
   SL_HIP(hipGetLastError());
-  for (int c = 0; c < 3; ++c) {
-    // matchesMap_: submap index -> map index (std::map<int,int> in the reference)
-    maps[c].matchesMap.assign(sub_all[c].begin(), sub_all[c].begin() + std::min<size_t>(nsub[c], sub_all[c].size()));
-  }
   if (first_scan_shortcut && firstScan) {   // sloam.cpp:235-248: the first scan is never matched
     firstScan = false;
     for (int c = 0; c < 3; ++c) { A.match_sub[c].assign(nd[c], -1); A.match_map[c].assign(nd[c], -1); }
