@@ -502,7 +502,7 @@ def _pmc_traffic(kernel, **match):
 
 def _pmc_mfma_util(kernel, avg_launch_ms=None):
     """Matrix-pipe utilisation of `kernel` from the committed PMC summary (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES in its own pass,
-    tools/gpu_r5_mfma.sh; the kernel's LARGEST grid = the exact joint passes' launches): {"busy_cycles_per_launch", "util_profiled"
+    tools/gpu_mfma_util.sh; the kernel's LARGEST grid = the exact joint passes' launches): {"busy_cycles_per_launch", "util_profiled"
     (busy / (the profiled dispatches' own duration x 2.4 GHz x 1024 SIMDs)), "util_at_this_runs_launch_time"} or None."""
     pdir = os.path.join(ROOT, "profiles")
     try:

@@ -6,5 +6,5 @@ timeout -k 10 700 python bench.py > gpurun_out/r5_bench.json 2> gpurun_out/r5_be
 echo "bench done"
 BENCH_ARGS="--no-place-leg" timeout -k 10 1000 bash tools/profile_round.sh r05 || { echo "profile failed"; exit 1; }
 echo "profiles done"
-bash tools/gpu_r5_place_trace.sh
+bash tools/gpu_place_traces.sh
 echo "place traces done"

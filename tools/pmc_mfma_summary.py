@@ -1,4 +1,4 @@
-# MFMA-pipe utilisation per kernel from a rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES run (tools/gpu_r5_mfma.sh):
+# MFMA-pipe utilisation per kernel from a rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES run (tools/gpu_mfma_util.sh):
 #   usage: pmc_mfma_summary.py <rocprof out dir> <round>
 # SQ_VALU_MFMA_BUSY_CYCLES sums the cycles in which a SIMD's matrix pipe is busy over all SIMDs of the chip (1024 on MI355X: 256 CUs x 4);
 # a v_mfma_f64_16x16x4_f64 keeps its pipe busy for 64 cycles (2048 flop).  Dispatches are grouped by (kernel, grid size): the streaming
@@ -28,7 +28,7 @@ for (k, grid), (n, busy, ns) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
     lines.append(f"{k[:40]:40s} grid {grid:9d}  dispatches {n:6d}  MFMA busy cycles/dispatch {busy / n:12.0f} (= {busy / n / 64 * 2048 / 1e6:9.1f} MFLOP)  "
                  f"avg {ns / n / 1e3:8.2f} us  matrix-pipe utilisation {'n/a' if util is None else f'{100 * util:6.2f} %'}")
     js[k.split("::")[-1]].append({"grid": grid, "dispatches": n, "mfma_busy_cycles_per_dispatch": busy / n, "avg_us": ns / n / 1e3, "mfma_util": util})
-head = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES over the round's profile command (tools/gpu_r5_mfma.sh), by kernel and grid size;\n"
+head = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES over the round's profile command (tools/gpu_mfma_util.sh), by kernel and grid size;\n"
         "utilisation = busy cycles / (dispatch duration x 2.4 GHz x 1024 SIMDs); 64 busy cycles = one v_mfma_f64_16x16x4_f64 = 2048 flop\n")
 open(os.path.join(root, "profiles", f"{rnd}_pmc_mfma_util.txt"), "w").write(head + "\n".join(lines) + "\n")
 json.dump(js, open(os.path.join(root, "profiles", f"{rnd}_pmc_mfma_util.json"), "w"), indent=1)
