@@ -7,7 +7,9 @@ timeout -k 10 400 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_chol
 rc=$?
 tail -5 gpurun_out/r5_pair_unit.log
 if [ $rc -ne 0 ]; then exit 1; fi
-MASKS="15" bash tools/gpu_pair_verify.sh || exit 1
+# step kernels vs pair kernel on the systems of a C4 exact pass, tile by tile (SLIDE_PAIR_VERIFY=1, one un-captured pass)
+SLIDE_CHOL_PAIR=15 SLIDE_PAIR_VERIFY=1 timeout -k 10 200 python tests/gpu_scenarios.py pair_verify gpurun_out/r5_vfy_15.json C4 1 > gpurun_out/r5_vfy_15.log 2>&1 || { tail -3 gpurun_out/r5_vfy_15.log; exit 1; }
+grep "pair verify" gpurun_out/r5_vfy_15.log | head -20
 export SLIDE_CHOL_PAIR=${PAIR_MASK:-15}
 timeout -k 10 700 python -m pytest tests/test_bench_config.py -x -q -m gpu -k "exact_joint_step and not rccl and not eight_ranks and not four_ranks and not two_ranks" > gpurun_out/r5_pair_exact.log 2>&1
 rc=$?
